@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference)
+on the build's seeded synthetic weights and inputs.
+
+Runs only in the build container (the reference tree does not travel to the GPU
+box).  Fixtures hold seeds + expected outputs of the reference itself; inputs and
+weights are re-created from the seeds by ``neural_marionette_amd.synth``.
+
+  python tools/make_golden.py            # writes every case
+  python tools/make_golden.py g2 g3      # subset
+
+The VRNN noise is injected by replacing ``torch.distributions.normal._standard_normal``
+(the name ``Normal.rsample`` resolves at call time).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from neural_marionette_amd.spec import HotPathOptions, DETECTOR_LOSS_KEYS  # noqa: E402
+from neural_marionette_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+S = 10
+
+
+def _ref_opt(G):
+    opt = pickle.load(open(os.path.join(REF, "pretrained/aist/opt.pickle"), "rb"))
+    opt.grid_size = G
+    return opt
+
+
+def _ref_net(opt, sd):
+    from model.neural_marionette import NeuralMarionette
+    net = NeuralMarionette(opt).eval()
+    net.load_state_dict(sd)
+    net.anneal(1)           # switches the affinity graph on (kypt_detector.py:71-78)
+    return net
+
+
+class EpsFeed:
+    """Feeds pre-drawn eps tensors to Normal.rsample in call order."""
+
+    def __init__(self, chunks):
+        self.chunks = list(chunks)
+        self.i = 0
+
+    def __call__(self, shape, dtype, device):
+        e = self.chunks[self.i]
+        self.i += 1
+        assert tuple(shape) == tuple(e.shape), (tuple(shape), tuple(e.shape))
+        return e.clone()
+
+    def __enter__(self):
+        import torch.distributions.normal as tdn
+        self._tdn, self._old = tdn, tdn._standard_normal
+        tdn._standard_normal = self
+        return self
+
+    def __exit__(self, *a):
+        self._tdn._standard_normal = self._old
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _sub(x, step):
+    """strided spatial sub-sample of the last three dims"""
+    return _np(x[..., ::step, ::step, ::step])
+
+
+def case_g1():
+    """Config 1 of BASELINE.json: 64^3, B=1, T=4, detector forward only."""
+    G, B, T, wseed, iseed = 64, 1, 4, 11, 21
+    opt = _ref_opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=wseed, variant="peaky")
+    net = _ref_net(opt, sd)
+    vox = synth.figure_clip(B, T, G, seed=iseed)
+    with torch.no_grad():
+        r = net.kypt_detector(vox)
+    np.savez_compressed(
+        os.path.join(OUT, "g1_detector64.npz"),
+        meta=np.array([G, B, T, wseed, iseed]), variant="peaky", clip="figure",
+        keypoints=_np(r["keypoints"]),
+        losses=np.array([float(r[k]) for k in DETECTOR_LOSS_KEYS], dtype=np.float64),
+        heatmaps_sub=_sub(r["heatmaps"], 2), heatmaps_sum=_np(r["heatmaps"].sum(dim=(3, 4, 5))),
+        first_feature_sub=_sub(r["first_feature"], 2),
+        first_feature_sum=_np(r["first_feature"].double().sum(dim=(2, 3, 4))),
+        recon_sub=_sub(r["recon"], 4), recon_sum=_np(r["recon"].double().sum(dim=(2, 3, 4, 5))),
+        recon_occ=_np((r["recon"] >= 0.5).sum(dim=(2, 3, 4, 5))),
+        recon_margin=np.array(float((r["recon"] - 0.5).abs().min())),
+        affinity=_np(r["affinity"]),
+    )
+    print("g1 ok", float(r["recon_loss"]))
+
+
+def case_g2():
+    """32^3 B=2 T=4 full forward (detector + VRNN.encode) with recorded eps."""
+    G, B, T, wseed, iseed, eseed = 32, 2, 4, 3, 5, 9
+    opt = _ref_opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=wseed, variant="peaky")
+    net = _ref_net(opt, sd)
+    vox = synth.figure_clip(B, T, G, seed=iseed)
+    eps = synth.make_eps((T, S, B, o.nlatent_kypt), seed=eseed)
+    with torch.no_grad(), EpsFeed(eps):
+        r = net(vox, {"detector": True, "learner": True})
+    d = net.dyna_module
+    np.savez_compressed(
+        os.path.join(OUT, "g2_forward32.npz"),
+        meta=np.array([G, B, T, wseed, iseed, eseed]), variant="peaky", clip="figure",
+        keypoints=_np(r["keypoints"]), heatmaps=_np(r["heatmaps"]),
+        first_feature=_np(r["first_feature"]),
+        recon_sub=_sub(r["recon"], 2), recon_sum=_np(r["recon"].double().sum(dim=(2, 3, 4, 5))),
+        recon_occ=_np((r["recon"] >= 0.5).sum(dim=(2, 3, 4, 5))),
+        losses=np.array([float(r[k]) for k in DETECTOR_LOSS_KEYS], dtype=np.float64),
+        affinity=_np(r["affinity"]),
+        kypt_recon=_np(r["kypt_recon"]), R=_np(r["R"]), z_kypts=_np(r["z_kypts"]),
+        h_kypts=_np(r["h_kypts"]), kl_kypt=np.array(float(r["kl_kypt"])),
+        kypt_recon_loss=np.array(float(r["kypt_recon_loss"])),
+        parents=_np(d.parents), order=_np(d.priority.indices), order_values=_np(d.priority.values),
+        A=_np(d.A),
+    )
+    print("g2 ok", float(r["kl_kypt"]))
+
+
+def case_g3():
+    """Skeleton trees: affinity (N,K,K,1) -> (A, parents, priority) for several seeds."""
+    from utils.dyna_utils import process_affinity_glob
+    from oracle import nm_oracle as O
+    K, N = 24, 2
+    affs, As, pars, ords, vals = [], [], [], [], []
+    for seed in range(12):
+        rng = np.random.default_rng([seed, 0x73EE])
+        if seed == 0:
+            params = torch.ones(N, K, K - 1)            # the all-ties init of the reference
+        elif seed < 4:
+            params = torch.from_numpy(np.round(rng.standard_normal((N, K, K - 1)) * 2) / 2).float()  # many ties
+        else:
+            params = torch.from_numpy(rng.standard_normal((N, K, K - 1)) * (1 + seed % 3)).float()
+        aff = O.affinity_v3(params)
+        A, pri, par = process_affinity_glob(aff)
+        affs.append(_np(aff)); As.append(_np(A)); pars.append(_np(par))
+        ords.append(_np(pri.indices)); vals.append(_np(pri.values))
+    np.savez_compressed(os.path.join(OUT, "g3_trees.npz"), affinity=np.stack(affs), A=np.stack(As),
+                        parents=np.stack(pars), order=np.stack(ords), order_values=np.stack(vals))
+    print("g3 ok")
+
+
+def case_g4():
+    """generate(): 32^3, B=2, Tcond=3, Ttot=8 with recorded eps."""
+    G, B, T, Tc, wseed, iseed, eseed = 32, 2, 8, 3, 4, 6, 10
+    opt = _ref_opt(G)
+    opt.Tcond = Tc
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=wseed, variant="peaky")
+    net = _ref_net(opt, sd)
+    vox = synth.figure_clip(B, T, G, seed=iseed)
+    Z = o.nlatent_kypt
+    e_enc = synth.make_eps((Tc, S, B, Z), seed=eseed)
+    e_post = synth.make_eps((Tc, S, B, Z), seed=eseed + 1)
+    e_prior = synth.make_eps((T - Tc, B, Z), seed=eseed + 2)
+    acts = {"detector": True, "learner": True}
+    with torch.no_grad():
+        with EpsFeed(e_enc):        # a first encode builds the tree (generate needs .parents)
+            net(vox[:, :Tc].contiguous(), acts)
+        with EpsFeed(list(e_post) + list(e_prior)):
+            r = net.generate(vox, acts)
+    d = net.dyna_module
+    np.savez_compressed(
+        os.path.join(OUT, "g4_generate32.npz"),
+        meta=np.array([G, B, T, Tc, wseed, iseed, eseed]), variant="peaky", clip="figure",
+        keypoints=_np(r["keypoints"]), gen_sub=_sub(r["gen"], 2),
+        gen_sum=_np(r["gen"].double().sum(dim=(2, 3, 4, 5))),
+        gen_occ=_np((r["gen"] >= 0.5).sum(dim=(2, 3, 4, 5))),
+        parents=_np(d.parents), order=_np(d.priority.indices),
+    )
+    print("g4 ok")
+
+
+def case_g5():
+    """Odd-size plumbing (output_padding path of the hourglass): 40^3, B=1, T=3 detector."""
+    G, B, T, wseed, iseed = 40, 1, 3, 7, 8
+    opt = _ref_opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=wseed, variant="peaky")
+    net = _ref_net(opt, sd)
+    vox = synth.figure_clip(B, T, G, seed=iseed)
+    with torch.no_grad():
+        r = net.kypt_detector(vox)
+    np.savez_compressed(
+        os.path.join(OUT, "g5_detector40.npz"),
+        meta=np.array([G, B, T, wseed, iseed]), variant="peaky", clip="figure",
+        keypoints=_np(r["keypoints"]), heatmaps=_np(r["heatmaps"]),
+        losses=np.array([float(r[k]) for k in DETECTOR_LOSS_KEYS], dtype=np.float64),
+        recon_sub=_sub(r["recon"], 2), recon_sum=_np(r["recon"].double().sum(dim=(2, 3, 4, 5))),
+    )
+    print("g5 ok")
+
+
+CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5)
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    for name in (sys.argv[1:] or list(CASES)):
+        CASES[name]()
