@@ -1,0 +1,165 @@
+/* nm355 — C ABI of the MI355X-native Neural Marionette hot path (libnm355.so).
+ *
+ * The reference (jinseokbae/neural_marionette) is pure PyTorch: it has no FFI / plugin
+ * boundary of its own.  The boundary it exposes for this path is the nn.Module surface
+ * of NeuralMarionette / KyptDetector / HSVRNNBVH; this header is the C interface that
+ * the drop-in Python shells (neural_marionette_amd/modules.py) bind with ctypes, one
+ * entry point per reference method.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous fp32 (or int32 where stated) memory
+ *    owned by the caller, in exactly the layout of the reference tensor named in the
+ *    comment; the library never keeps a caller pointer past the call's stream-ordered
+ *    completion (weights are copied/re-packed into ctx-owned memory by
+ *    nm_ctx_set_weights).
+ *  - calls are asynchronous on the ctx stream (nm_ctx_set_stream); no hidden device
+ *    synchronisation except in create / destroy / set_weights / workspace growth.
+ *  - return value: 0 = OK, <0 = error (NM_ERR_*); message via nm_last_error()
+ *    (thread-local).  No exceptions or abort() cross this boundary.
+ *  - a ctx is bound to one device and one stream and is not thread-safe.
+ */
+#ifndef NM355_H
+#define NM355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_ABI_VERSION 1
+
+#define NM_OK 0
+#define NM_ERR_ARG (-1)
+#define NM_ERR_HIP (-2)
+#define NM_ERR_STATE (-3)
+#define NM_ERR_UNSUPPORTED (-4)
+
+typedef struct nm_ctx nm_ctx;
+
+/* Hot-path hyper-parameters (pretrained/aist/opt.pickle of the reference; fields read at
+ * model/kypt_detector.py:18-68, model/hsvrnn_bvh.py:14-20). */
+typedef struct nm_config {
+    int32_t device;          /* HIP device ordinal */
+    int32_t grid_size;       /* G: occupancy grid edge (64; multiples of 8 >= 32) */
+    int32_t nkeypoints;      /* K (24) */
+    int32_t nlatent;         /* Z (128) */
+    int32_t nhidden;         /* H (512) */
+    int32_t nneighbor;       /* N (2) affinity neighbours */
+    float gaussian_sigma;    /* 1.5 */
+    float sep_sigma;         /* 0.02 */
+    int32_t vol_fit_chamfer; /* 1: vol_fit_type == 'chamfer', 0: 'none' */
+    int32_t use_graph_traj;  /* graph_traj_weight > 0 */
+} nm_config;
+
+typedef struct nm_named_tensor {
+    const char* name;        /* state_dict key of the reference module */
+    const float* data;       /* device pointer, contiguous fp32, torch layout */
+    int64_t numel;
+} nm_named_tensor;
+
+int nm_abi_version(void);
+const char* nm_last_error(void);
+
+int nm_ctx_create(nm_ctx** out, const nm_config* cfg);
+int nm_ctx_destroy(nm_ctx* ctx);
+int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream);
+/* Replaces NeuralMarionette.load_state_dict / .cuda() for the HIP path: copies every
+ * tensor and re-packs conv weights into the MFMA layout.  Must be called again after an
+ * optimizer step.  All 337 keys of the reference state_dict are required. */
+int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count);
+/* Bytes of ctx-owned workspace a (B, T) call needs (allocated lazily, grown on demand). */
+size_t nm_workspace_bytes(nm_ctx* ctx, int32_t B, int32_t T);
+
+/* KyptDetector.forward — model/kypt_detector.py:81-169.
+ *  vox        (B,T,1,G,G,G)            in
+ *  keypoints  (B,T,K,4)                out  [x1,x2,x3,intensity]
+ *  heatmaps   (B,T,K,g,g,g) g=G/4      out
+ *  first_feature (B,128,g,g,g)         out
+ *  recon      (B,T,1,G,G,G)            out
+ *  affinity   (N,K,K,1) or NULL        out  (get_affinity, :171-211, ver 3)
+ *  losses11   11 floats                out  order: recon_loss, vol_fit_reg, kypt_const_loss,
+ *             separation_loss, sparsity_loss, local_const_loss, time_const_loss,
+ *             sparsity_const_loss, intensity_const_loss, graph_traj_loss, graph_vol_loss
+ *  affinity_on mirrors KyptDetector.affinity_start (anneal(), :71-78). */
+int nm_detector_forward(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t affinity_on,
+                        float* keypoints, float* heatmaps, float* first_feature, float* recon,
+                        float* affinity, float* losses11);
+
+/* KyptDetector.decode_from_dyna — model/kypt_detector.py:213-241.
+ *  keypoints (B,Tg,K,4), first_feature (B,128,g,g,g), first_frame (B,1,G,G,G) -> gen (B,Tg,1,G,G,G) */
+int nm_decode_from_keypoints(nm_ctx* ctx, const float* keypoints, const float* first_feature,
+                             const float* first_frame, int32_t B, int32_t Tg, float* gen);
+
+/* KyptDetector.get_affinity (ver 3) — model/kypt_detector.py:191-199 -> (N,K,K,1) */
+int nm_get_affinity(nm_ctx* ctx, float* affinity);
+
+/* Skeleton handed to the VRNN entry points (result of process_affinity_glob,
+ * utils/dyna_utils.py:6-171, computed on the host by neural_marionette_amd.skeleton):
+ *  parents (K) int32, parents[root] == root;  order (K) int32 = priority.indices */
+int nm_vrnn_set_tree(nm_ctx* ctx, const int32_t* parents_host, const int32_t* order_host);
+
+/* HSVRNNBVH.get_offset — model/hsvrnn_bvh.py:236-253.  keypoints (B,T,K,4) -> offset (B,K,3) */
+int nm_vrnn_offsets(nm_ctx* ctx, const float* keypoints, int32_t B, int32_t T, float* offset);
+
+/* HSVRNNBVH.encode — model/hsvrnn_bvh.py:67-156.
+ *  keypoints (B,T,K,4) in; eps (T,S,B,Z) standard-normal draws in t order (required);
+ *  kypt_recon (B,T,K,4), R (B,T,K,3,3), z (B,T,Z), h (B,T+1,H) out;
+ *  scalars2: kl_kypt (mean), kypt_recon_loss (mean);  best_idx (B,T) int32 out or NULL. */
+int nm_vrnn_encode(nm_ctx* ctx, const float* keypoints, const float* eps, int32_t B, int32_t T,
+                   int32_t S, float* kypt_recon, float* R, float* z, float* h, float* scalars2,
+                   int32_t* best_idx);
+
+/* HSVRNNBVH.generate — model/hsvrnn_bvh.py:158-234.
+ *  keypoints_cond (B,Tcond,K,4); eps_post (Tcond,S,B,Z); eps_prior (Ttot-Tcond,B,Z);
+ *  out_cond (B,Tcond,K,4), out_gen (B,Ttot-Tcond,K,4); h_last (B,H) or NULL. */
+int nm_vrnn_generate(nm_ctx* ctx, const float* keypoints_cond, const float* eps_post,
+                     const float* eps_prior, int32_t B, int32_t Tcond, int32_t Ttot, int32_t S,
+                     float* out_cond, float* out_gen, float* h_last);
+
+/* One VRNN step for hand-rolled rollouts (vis_generation.py:97-127 of the reference):
+ *  posterior != 0: best-of-S posterior step against kp_obs (B,K*4), eps (S,B,Z);
+ *  posterior == 0: prior step, eps (B,Z), S ignored.
+ *  h_in (B,H), offset (B,K,3) -> kp_out (B,K*4), z_out (B,Z), h_out (B,H). */
+int nm_vrnn_step(nm_ctx* ctx, int32_t posterior, const float* h_in, const float* kp_obs,
+                 const float* offset, const float* eps, int32_t B, int32_t S, float* kp_out,
+                 float* z_out, float* h_out);
+
+/* Sub-module callables the reference's demo scripts reach into (hsvrnn_bvh.py:29-57):
+ *  which: 0 extract_post_dist (H+K*4 -> 2Z), 1 extract_prior_dist (H -> 2Z),
+ *         2 root_intensity_decoder (H+Z -> 3+K, tanh), 3 joint_matrix_decoder (H+Z -> 6K) */
+int nm_vrnn_mlp(nm_ctx* ctx, int32_t which, const float* x, int32_t B, float* y);
+/* kypt_rnn_cell: x (B,K*4+Z), h (B,H) -> h_out (B,H) */
+int nm_vrnn_gru(nm_ctx* ctx, const float* x, const float* h, int32_t B, float* h_out);
+/* extract_kypt_from_latent_and_state — hsvrnn_bvh.py:255-286: dec_in (B,H+Z), offset (B,K,3)
+ *  -> kp (B,K*4), R (B,K,3,3) */
+int nm_vrnn_fk(nm_ctx* ctx, const float* dec_in, const float* offset, int32_t B, float* kp, float* R);
+
+/* ---- op-level entry points (unit parity tests; activations are channels-last) ------------ */
+/* Conv3d.  in [N][D][H][W][Cin8] (Cin8 = Cin rounded up to 8, extra channels zero), weight in
+ * torch OIDHW layout, out [N][OD][OH][OW][Cout].  in_scale/in_shift [N][Cin8] or NULL apply
+ * y = lrelu_slope(x*scale+shift) to the input first.  If gn_groups > 0, also returns the
+ * following GroupNorm's per-(n,c) scale/shift (gn_gamma/gn_beta [Cout]) in gn_scale/gn_shift. */
+int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                 const float* in_scale, const float* in_shift, float in_slope,
+                 const float* weight, const float* bias, int32_t Cout, int32_t ks, int32_t stride,
+                 int32_t pad, float* out, int32_t gn_groups, const float* gn_gamma,
+                 const float* gn_beta, float* gn_scale, float* gn_shift);
+int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                 const float* weight_iodhw, const float* bias, int32_t Cout, int32_t outpad, float* out,
+                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale,
+                 float* gn_shift);
+/* out = T_a(a) + T_b(b) with T(x) = lrelu_slope(x*scale+shift); b may be NULL */
+int nm_op_apply2(nm_ctx* ctx, const float* a, const float* a_scale, const float* a_shift, float a_slope,
+                 const float* b, const float* b_scale, const float* b_shift, float b_slope,
+                 int32_t N, int32_t voxels, int32_t C, float* out);
+int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out);
+int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out);
+int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out);
+/* host helper: torch.linspace(-1, 1, n) as the kernels evaluate it */
+int nm_host_linspace(int32_t n, float* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NM355_H */

@@ -1,0 +1,185 @@
+// C ABI (include/nm355.h): context management, error reporting and the op-level entry
+// points used by the unit parity tests.  The network-level entry points live in
+// nm_net.hip / nm_vrnn.hip.
+#include "nm_ctx.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+
+static thread_local char g_err[512] = "";
+
+void nm_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int nm_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return NM_OK;
+    nm_set_error("%s: %s", what, hipGetErrorString(e));
+    return NM_ERR_HIP;
+}
+
+int nm_ctx_reserve(nm_ctx* ctx, size_t bytes) {
+    if (ctx->ws.cap >= bytes) return NM_OK;
+    int rc = nm_check_hip(hipStreamSynchronize(ctx->stream), "reserve: stream sync");
+    if (rc) return rc;
+    if (ctx->ws.base) { (void)hipFree(ctx->ws.base); ctx->ws.base = nullptr; ctx->ws.cap = 0; }
+    size_t want = bytes + bytes / 16 + (1 << 20);
+    rc = nm_check_hip(hipMalloc(reinterpret_cast<void**>(&ctx->ws.base), want), "reserve: hipMalloc workspace");
+    if (rc) return rc;
+    ctx->ws.cap = want;
+    return NM_OK;
+}
+
+float* nm_ctx_weight_alloc(nm_ctx* ctx, size_t floats) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (floats ? floats : 1) * sizeof(float)) != hipSuccess) return nullptr;
+    ctx->owned.push_back(p);
+    return static_cast<float*>(p);
+}
+
+extern "C" {
+
+int nm_abi_version(void) { return NM_ABI_VERSION; }
+const char* nm_last_error(void) { return g_err; }
+
+int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
+    if (!out || !cfg) { nm_set_error("ctx_create: null argument"); return NM_ERR_ARG; }
+    if (cfg->grid_size < 32 || cfg->grid_size % 8) { nm_set_error("ctx_create: grid_size %d unsupported", cfg->grid_size); return NM_ERR_UNSUPPORTED; }
+    if (cfg->nkeypoints <= 1 || cfg->nkeypoints > 32 || cfg->nkeypoints % 8) { nm_set_error("ctx_create: nkeypoints %d unsupported (multiple of 8, <= 32)", cfg->nkeypoints); return NM_ERR_UNSUPPORTED; }
+    int ndev = 0;
+    int rc = nm_check_hip(hipGetDeviceCount(&ndev), "ctx_create: hipGetDeviceCount");
+    if (rc) return rc;
+    if (cfg->device < 0 || cfg->device >= ndev) { nm_set_error("ctx_create: device %d of %d", cfg->device, ndev); return NM_ERR_ARG; }
+    rc = nm_check_hip(hipSetDevice(cfg->device), "ctx_create: hipSetDevice");
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    rc = nm_check_hip(hipGetDeviceProperties(&prop, cfg->device), "ctx_create: props");
+    if (rc) return rc;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        nm_set_error("ctx_create: device arch '%s' is not gfx950 (this library is MI355X-only)", prop.gcnArchName);
+        return NM_ERR_UNSUPPORTED;
+    }
+    nm_ctx* c = new nm_ctx();
+    c->cfg = *cfg;
+    *out = c;
+    return NM_OK;
+}
+
+int nm_ctx_destroy(nm_ctx* ctx) {
+    if (!ctx) return NM_OK;
+    (void)hipSetDevice(ctx->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : ctx->owned) (void)hipFree(p);
+    if (ctx->ws.base) (void)hipFree(ctx->ws.base);
+    delete ctx;
+    return NM_OK;
+}
+
+int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) {
+    if (!ctx) { nm_set_error("set_stream: null ctx"); return NM_ERR_ARG; }
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return NM_OK;
+}
+
+int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count) {
+    if (!ctx || !tensors || count <= 0) { nm_set_error("set_weights: bad arguments"); return NM_ERR_ARG; }
+    std::map<std::string, std::pair<const float*, int64_t>> sd;
+    for (int i = 0; i < count; ++i) {
+        if (!tensors[i].name || !tensors[i].data) { nm_set_error("set_weights: entry %d is null", i); return NM_ERR_ARG; }
+        sd[tensors[i].name] = std::make_pair(tensors[i].data, tensors[i].numel);
+    }
+    (void)hipSetDevice(ctx->cfg.device);
+    return nm_net_set_weights(ctx, sd);
+}
+
+int nm_host_linspace(int32_t n, float* out) {
+    if (n < 2 || !out) { nm_set_error("linspace: bad arguments"); return NM_ERR_ARG; }
+    const float step = 2.0f / (float)(n - 1);
+    for (int i = 0; i < n; ++i) out[i] = i < n / 2 ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(n - 1 - i), 1.0f);
+    return NM_OK;
+}
+
+// ---- op-level entry points -------------------------------------------------------------------
+static TensorRef make_ref(const float* p, const float* sc, const float* sh, float slope, int N, int D, int H, int W, int C) {
+    TensorRef t; t.p = p; t.scale = sc; t.shift = sh; t.slope = slope; t.N = N; t.D = D; t.H = H; t.W = W; t.C = C;
+    return t;
+}
+
+static int finish_gn(nm_ctx* ctx, const float* part, int N, int nblk, int C, int groups, double count,
+                     const float* gamma, const float* beta, float* scale, float* shift) {
+    return nm_launch_gn_finalize(part, N, nblk, C, groups, count, gamma, beta, 1e-5f, scale, shift, ctx->stream);
+}
+
+int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                 const float* in_scale, const float* in_shift, float in_slope, const float* weight,
+                 const float* bias, int32_t Cout, int32_t ks, int32_t stride, int32_t pad, float* out,
+                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) {
+    if (!ctx || !in || !weight || !out) { nm_set_error("op_conv3d: null argument"); return NM_ERR_ARG; }
+    const int Cin_pad = (Cin + 7) & ~7, Co_pad = (Cout + 31) & ~31;
+    ConvGeom g; g.ks = ks; g.stride = stride; g.pad = pad;
+    g.OD = (D + 2 * pad - ks) / stride + 1; g.OH = (H + 2 * pad - ks) / stride + 1; g.OW = (W + 2 * pad - ks) / stride + 1;
+    g.Cout = Cout; g.Co_pad = Co_pad;
+    const int nblk = nm_conv_blocks_per_frame(g);
+    const size_t wfl = nm_packed_weight_floats(ks, Cin_pad, Co_pad);
+    const size_t pfl = (size_t)N * nblk * Cout * 2;
+    int rc = nm_ctx_reserve(ctx, (wfl + pfl) * sizeof(float) + 4096);
+    if (rc) return rc;
+    ctx->ws.release(0);
+    float* wp = ctx->ws.f(wfl);
+    float* part = gn_groups > 0 ? ctx->ws.f(pfl) : nullptr;
+    rc = nm_launch_pack_conv_weight(weight, Cout, Cin, ks, wp, Cin_pad, Co_pad, ctx->stream);
+    if (rc) return rc;
+    TensorRef t = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad);
+    rc = nm_launch_conv(t, wp, bias, out, g, part, ctx->stream);
+    if (rc) return rc;
+    if (gn_groups > 0)
+        rc = finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)g.OD * g.OH * g.OW * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
+    return rc;
+}
+
+int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                 const float* weight, const float* bias, int32_t Cout, int32_t outpad, float* out,
+                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) {
+    if (!ctx || !in || !weight || !out || !bias) { nm_set_error("op_convT2: null argument"); return NM_ERR_ARG; }
+    const int OD = 2 * D + outpad, OH = 2 * H + outpad, OW = 2 * W + outpad;
+    TensorRef t = make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, Cin);
+    int rc = nm_launch_convT2(t, weight, bias, out, Cout, OD, OH, OW, ctx->stream);
+    if (rc || gn_groups <= 0) return rc;
+    const int vox = OD * OH * OW, nblk = nm_stats_blocks_per_frame(vox);
+    rc = nm_ctx_reserve(ctx, (size_t)N * nblk * Cout * 2 * sizeof(float) + 4096);
+    if (rc) return rc;
+    ctx->ws.release(0);
+    float* part = ctx->ws.f((size_t)N * nblk * Cout * 2);
+    rc = nm_launch_gn_partials(out, N, vox, Cout, part, ctx->stream);
+    if (rc) return rc;
+    return finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)vox * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
+}
+
+int nm_op_apply2(nm_ctx* ctx, const float* a, const float* a_scale, const float* a_shift, float a_slope,
+                 const float* b, const float* b_scale, const float* b_shift, float b_slope, int32_t N,
+                 int32_t voxels, int32_t C, float* out) {
+    if (!ctx || !a || !out) { nm_set_error("op_apply2: null argument"); return NM_ERR_ARG; }
+    TensorRef ta = make_ref(a, a_scale, a_shift, a_slope, N, 1, 1, voxels, C);
+    TensorRef tb = make_ref(b, b_scale, b_shift, b_slope, N, 1, 1, voxels, C);
+    return nm_launch_apply2(ta, b ? &tb : nullptr, out, ctx->stream);
+}
+
+int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out) {
+    if (!ctx || !in || !out) { nm_set_error("op_upsample2: null argument"); return NM_ERR_ARG; }
+    return nm_launch_upsample2(make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, C), out, ctx->stream);
+}
+
+int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out) {
+    if (!ctx || !vox || !out) { nm_set_error("op_pack_input: null argument"); return NM_ERR_ARG; }
+    return nm_launch_pack_input(vox, B, T, G, mean_over_t, out, ctx->stream);
+}
+
+int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out) {
+    if (!ctx || !in || !out) { nm_set_error("op_cl_to_ncdhw: null argument"); return NM_ERR_ARG; }
+    return nm_launch_cl_to_ncdhw(make_ref(in, nullptr, nullptr, 1.0f, N, 1, 1, voxels, C), out, ctx->stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Shared declarations of the nm355 HIP library (gfx950 / CDNA4 only).
+//
+// Activation layout everywhere inside the library: channels-last
+//   [frame n][z][y][x][C]   fp32, C a multiple of 8
+// so that a voxel's channel vector is one contiguous run (coalesced 16-B loads, and the
+// K dimension of the implicit GEMM is contiguous for the MFMA A operand).
+//
+// "Lazy" tensors: a conv writes its raw output plus per-block GroupNorm partial sums;
+// nm_gn_finalize turns those into per-(frame, channel) scale/shift, and the *consumer*
+// applies  y = lrelu(x * scale + shift)  while it stages its input tile (TensorRef).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NM_OK 0
+#define NM_ERR_ARG (-1)
+#define NM_ERR_HIP (-2)
+#define NM_ERR_STATE (-3)
+#define NM_ERR_UNSUPPORTED (-4)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// A tensor reference with an optional pending per-(n,c) affine + leaky-relu.
+struct TensorRef {
+    const float* p;       // [N][D][H][W][C]
+    const float* scale;   // [N][C] or nullptr  (nullptr => identity affine)
+    const float* shift;   // [N][C] or nullptr
+    float slope;          // leaky-relu slope applied after the affine; 1.0f => none
+    int N, D, H, W, C;
+};
+
+struct ConvGeom {
+    int ks, stride, pad;
+    int OD, OH, OW;
+    int Cout;      // real output channels (multiple of 8, or 24 for the heat-map heads)
+    int Co_pad;    // packed weight columns (multiple of 32)
+};
+
+void nm_set_error(const char* fmt, ...);
+int nm_check_hip(hipError_t e, const char* what);
+
+// ---- nm_conv.hip -------------------------------------------------------------------
+// packed weight layout: [tap][Cin/4][Co_pad][4]
+size_t nm_packed_weight_floats(int ks, int Cin_pad, int Co_pad);
+int nm_launch_pack_conv_weight(const float* w_oidhw, int Cout, int Cin, int ks, float* packed,
+                               int Cin_pad, int Co_pad, hipStream_t s);
+// number of per-frame partial blocks the conv epilogue writes (for sizing `part`)
+int nm_conv_blocks_per_frame(const ConvGeom& g);
+int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
+                   const ConvGeom& g, float* part /*[N][nblk][Cout][2] or null*/, hipStream_t s);
+
+// ---- nm_elem.hip -------------------------------------------------------------------
+int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count,
+                          const float* gamma, const float* beta, float eps, float* scale,
+                          float* shift, hipStream_t s);
+// partial sums of an already materialised raw tensor (producers without a stats epilogue)
+int nm_stats_blocks_per_frame(int voxels);
+int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part, hipStream_t s);
+int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s);
+int nm_launch_convT2(const TensorRef& in, const float* w_iodhw, const float* bias, float* out,
+                     int Cout, int OD, int OH, int OW, hipStream_t s);
+int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s);
+int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t, float* out,
+                         hipStream_t s);
+int nm_launch_cl_to_ncdhw(const TensorRef& in, float* out, hipStream_t s);

@@ -1,0 +1,309 @@
+// 3-D convolution as an implicit GEMM on the fp32 matrix cores of gfx950.
+//
+// Replaces, for the hot path, every nn.Conv3d the reference reaches through torch
+// (modules/vox_modules.py:12,26,30,39,53; model/kypt_detector.py:279,295,381,429-457):
+//   k5 s1 p2, k3 s1 p1, k2 s2 p0 ("pool"), k1.
+//
+//   Out[m, co] = sum_{tap, ci} In[vox(m) * stride + tap - pad, ci] * W[tap, ci, co]
+//
+// * M = output voxels of one frame, tiled as a power-of-two 3-D brick (BM = 128 * MT rows);
+//   N = output channels (32 * NT per block); K = taps x Cin, walked in LDS chunks of KC
+//   channels.
+// * MFMA: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD).  Lane l feeds
+//   A[row l&31][k = l>>5] and B[k = l>>5][col l&31]; the K order is permuted so that the
+//   lane half h owns four consecutive channels 4*(2*kq+h)+{0..3}: one ds_read_b128 (A) and
+//   one global 16-B load (B) feed four back-to-back MFMAs.
+// * A: the input brick + halo is staged once per channel chunk into LDS as
+//   [channel quad][halo voxel] float4, with the producer's GroupNorm affine + LeakyReLU
+//   applied on the way in (zero padding is applied after the transform).
+// * B: packed weights [tap][Cin/4][Co_pad][4] are read straight from L2 (every block reads
+//   the same few hundred KB), prefetched one tap ahead in registers.
+// * Epilogue: bias, coalesced channels-last store (128-B runs), and per-(block, channel)
+//   sum / sum-of-squares partials for the following GroupNorm (deterministic: no float
+//   atomics).
+#include "nm_common.h"
+
+namespace {
+
+struct ConvParams {
+    const float* in; const float* in_scale; const float* in_shift; float in_slope;
+    int N, ID, IH, IW, Cin;
+    const float* w; const float* bias;
+    float* out; float* part;
+    int OD, OH, OW, Cout, Co_pad;
+    int ks, stride, pad;
+    int bz_l2, by_l2, bx_l2;      // brick dims (log2)
+    int nbz, nby, nbx;            // bricks per frame
+    int KC;                       // channels per LDS chunk (8 or 16)
+    int HZ, HY, HX, HV, HVp;      // halo dims, voxels, padded plane stride (HVp % 8 == 2)
+};
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+
+// One LDS-resident channel chunk (NKQ octets of channels): walk the taps, B operand
+// prefetched one tap ahead, 4*NKQ*MT*NT MFMAs per tap.
+template <int MT, int NT, int NKQ>
+__device__ __forceinline__ void mfma_chunk(const ConvParams& p, const f32x4* lds, const f32x4* __restrict__ wq,
+                                           size_t tap_stride, int taps, int h, const int (&arow)[MT],
+                                           f32x16 (&acc)[MT][NT]) {
+    f32x4 bcur[NKQ][NT];
+#pragma unroll
+    for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bcur[kq][nt] = wq[(size_t)(2 * kq) * p.Co_pad + nt * 32];
+    int tx = 0, ty = 0, tz = 0;
+    for (int tap = 0; tap < taps; ++tap) {
+        const f32x4* wn = wq + (size_t)min(tap + 1, taps - 1) * tap_stride;
+        f32x4 bnxt[NKQ][NT];
+#pragma unroll
+        for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bnxt[kq][nt] = wn[(size_t)(2 * kq) * p.Co_pad + nt * 32];
+        const int tapoff = (tz * p.HY + ty) * p.HX + tx;
+        f32x4 a[NKQ][MT];
+#pragma unroll
+        for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[kq][mt] = lds[(2 * kq + h) * p.HVp + arow[mt] + tapoff];
+#pragma unroll
+        for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kq][mt][s], bcur[kq][nt][s], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bcur[kq][nt] = bnxt[kq][nt];
+        if (++tx == p.ks) { tx = 0; if (++ty == p.ks) { ty = 0; ++tz; } }
+    }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
+    extern __shared__ f32x4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int nblk = p.nbz * p.nby * p.nbx;
+    const int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
+    const int bxi = br % p.nbx, byi = (br / p.nbx) % p.nby, bzi = br / (p.nbx * p.nby);
+    const int oz0 = bzi << p.bz_l2, oy0 = byi << p.by_l2, ox0 = bxi << p.bx_l2;
+    const int co_base = blockIdx.y * (NT * 32);
+    const int BXm = (1 << p.bx_l2) - 1, BYm = (1 << p.by_l2) - 1;
+
+    // LDS voxel offset of each of this lane's A rows (row m -> brick (z,y,x))
+    int arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (wave * MT + mt) * 32 + l31;
+        int x = m & BXm, y = (m >> p.bx_l2) & BYm, z = m >> (p.bx_l2 + p.by_l2);
+        bool ok = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
+        arow[mt] = ok ? ((z * p.stride) * p.HY + y * p.stride) * p.HX + x * p.stride : 0;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int Q = p.Cin >> 2;
+    const int taps = p.ks * p.ks * p.ks;
+    const int iz0 = oz0 * p.stride - p.pad, iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+    const size_t tap_stride = (size_t)Q * p.Co_pad;                 // float4 units per tap
+    const f32x4* __restrict__ w4 = reinterpret_cast<const f32x4*>(p.w);
+
+    for (int c0 = 0; c0 < p.Cin; c0 += p.KC) {
+        const int kc = min(p.KC, p.Cin - c0);
+        const int nq = kc >> 2;
+        __syncthreads();
+        // ---- stage the halo brick of channels [c0, c0+kc) ------------------------------
+        for (int i = tid; i < p.HV * nq; i += 256) {
+            int q = i % nq, hv = i / nq;
+            int hx = hv % p.HX, t2 = hv / p.HX;
+            int hy = t2 % p.HY, hz = t2 / p.HY;
+            int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gz < (unsigned)p.ID && (unsigned)gy < (unsigned)p.IH && (unsigned)gx < (unsigned)p.IW) {
+                int c = c0 + 4 * q;
+                v = *reinterpret_cast<const f32x4*>(p.in + ((((size_t)n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + c);
+                if (p.in_scale) {
+                    f32x4 sc = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)n * p.Cin + c);
+                    f32x4 sh = *reinterpret_cast<const f32x4*>(p.in_shift + (size_t)n * p.Cin + c);
+                    v = v * sc + sh;
+                }
+                if (p.in_slope != 1.0f) {
+                    v[0] = lrelu(v[0], p.in_slope); v[1] = lrelu(v[1], p.in_slope);
+                    v[2] = lrelu(v[2], p.in_slope); v[3] = lrelu(v[3], p.in_slope);
+                }
+            }
+            lds[q * p.HVp + hv] = v;
+        }
+        __syncthreads();
+
+        // ---- MFMA over taps x channel octets -------------------------------------------
+        const f32x4* wq = w4 + ((size_t)(c0 >> 2) + h) * p.Co_pad + co_base + l31;
+        if (kc >= 16) mfma_chunk<MT, NT, 2>(p, lds, wq, tap_stride, taps, h, arow, acc);
+        else          mfma_chunk<MT, NT, 1>(p, lds, wq, tap_stride, taps, h, arow, acc);
+    }
+
+    // ---- epilogue: bias, store, GroupNorm partials ------------------------------------------
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);                  // [4 waves][NT*32][2]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co_base + nt * 32 + l31;
+        const bool cv = co < p.Cout;
+        const float bv = (cv && p.bias) ? p.bias[co] : 0.f;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                int m = (wave * MT + mt) * 32 + row;
+                int x = m & BXm, y = (m >> p.bx_l2) & BYm, z = m >> (p.bx_l2 + p.by_l2);
+                int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
+                float v = acc[mt][nt][r] + bv;
+                if (cv && oz < p.OD && oy < p.OH && ox < p.OW) {
+                    p.out[((((size_t)n * p.OD + oz) * p.OH + oy) * p.OW + ox) * p.Cout + co] = v;
+                    s += v; ss += v * v;
+                }
+            }
+        }
+        if (p.part) {
+            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+            if (h == 0) { red[(wave * NT * 32 + nt * 32 + l31) * 2] = s; red[(wave * NT * 32 + nt * 32 + l31) * 2 + 1] = ss; }
+        }
+    }
+    if (p.part) {
+        __syncthreads();
+        if (tid < NT * 32) {
+            int co = co_base + tid;
+            if (co < p.Cout) {
+                float s = 0.f, ss = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { s += red[(wv * NT * 32 + tid) * 2]; ss += red[(wv * NT * 32 + tid) * 2 + 1]; }
+                float* dst = p.part + (((size_t)n * nblk + br) * p.Cout + co) * 2;
+                dst[0] = s; dst[1] = ss;
+            }
+        }
+    }
+}
+
+// OIDHW (Cout, Cin, k, k, k) -> [tap][Cin_pad/4][Co_pad][4], zero padded
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int ks,
+                                        float* __restrict__ packed, int Cin_pad, int Co_pad) {
+    const int taps = ks * ks * ks;
+    const size_t total = (size_t)taps * Cin_pad * Co_pad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int j = i & 3;
+        size_t r = i >> 2;
+        int co = r % Co_pad; r /= Co_pad;
+        int q = r % (Cin_pad / 4);
+        int tap = r / (Cin_pad / 4);
+        int ci = q * 4 + j;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * taps + tap];
+        packed[i] = v;
+    }
+}
+
+int ceil_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+struct Tiling { int MT, NT, bz_l2, by_l2, bx_l2, nbz, nby, nbx, KC, HZ, HY, HX, HV, HVp; size_t lds_bytes; };
+
+Tiling choose_tiling(const ConvGeom& g, int Cin) {
+    Tiling t;
+    const int vox = g.OD * g.OH * g.OW;
+    t.MT = vox >= 256 ? 2 : 1;
+    t.NT = (g.Co_pad % 64 == 0) ? 2 : 1;
+    const int bm_l2 = t.MT == 2 ? 8 : 7;
+    t.bx_l2 = min(3, ceil_log2(g.OW));
+    t.by_l2 = min(3, ceil_log2(g.OH));
+    t.bz_l2 = bm_l2 - t.bx_l2 - t.by_l2;
+    const int BX = 1 << t.bx_l2, BY = 1 << t.by_l2, BZ = min(1 << t.bz_l2, g.OD);
+    t.nbx = (g.OW + BX - 1) / BX; t.nby = (g.OH + BY - 1) / BY; t.nbz = (g.OD + (1 << t.bz_l2) - 1) >> t.bz_l2;
+    t.HX = (min(BX, g.OW) - 1) * g.stride + g.ks;
+    t.HY = (min(BY, g.OH) - 1) * g.stride + g.ks;
+    t.HZ = (BZ - 1) * g.stride + g.ks;
+    t.HV = t.HX * t.HY * t.HZ;
+    t.HVp = t.HV + ((2 - (t.HV & 7)) & 7);
+    t.KC = (Cin % 16 == 0) ? 16 : 8;
+    if ((size_t)(t.KC / 4) * t.HVp * 16 > 72 * 1024 && t.KC == 16) t.KC = 8;
+    t.lds_bytes = max((size_t)(t.KC / 4) * t.HVp * 16, (size_t)4 * 64 * 2 * sizeof(float));
+    return t;
+}
+
+template <int MT, int NT>
+int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(256), t.lds_bytes, s, p);
+    return nm_check_hip(hipGetLastError(), "conv_mfma launch");
+}
+
+}  // namespace
+
+size_t nm_packed_weight_floats(int ks, int Cin_pad, int Co_pad) {
+    return (size_t)ks * ks * ks * Cin_pad * Co_pad;
+}
+
+int nm_launch_pack_conv_weight(const float* w, int Cout, int Cin, int ks, float* packed, int Cin_pad,
+                               int Co_pad, hipStream_t s) {
+    if (Cin_pad % 8 || Co_pad % 32 || Cin > Cin_pad || Cout > Co_pad) {
+        nm_set_error("pack_conv_weight: bad padding Cin=%d/%d Cout=%d/%d", Cin, Cin_pad, Cout, Co_pad);
+        return NM_ERR_ARG;
+    }
+    size_t total = nm_packed_weight_floats(ks, Cin_pad, Co_pad);
+    int blocks = (int)min((total + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, ks, packed, Cin_pad, Co_pad);
+    return nm_check_hip(hipGetLastError(), "pack_conv_weight launch");
+}
+
+int nm_conv_blocks_per_frame(const ConvGeom& g) {
+    Tiling t = choose_tiling(g, 16);
+    return t.nbz * t.nby * t.nbx;
+}
+
+int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
+                   const ConvGeom& g, float* part, hipStream_t s) {
+    if (in.C % 8 != 0 || g.Co_pad % 32 != 0 || g.Cout > g.Co_pad || g.Cout <= 0) {
+        nm_set_error("conv: unsupported channels Cin=%d Cout=%d Co_pad=%d", in.C, g.Cout, g.Co_pad);
+        return NM_ERR_ARG;
+    }
+    if ((in.D + 2 * g.pad - g.ks) / g.stride + 1 != g.OD || (in.H + 2 * g.pad - g.ks) / g.stride + 1 != g.OH ||
+        (in.W + 2 * g.pad - g.ks) / g.stride + 1 != g.OW) {
+        nm_set_error("conv: geometry mismatch in=(%d,%d,%d) k=%d s=%d p=%d out=(%d,%d,%d)", in.D, in.H, in.W,
+                     g.ks, g.stride, g.pad, g.OD, g.OH, g.OW);
+        return NM_ERR_ARG;
+    }
+    if ((in.scale == nullptr) != (in.shift == nullptr)) { nm_set_error("conv: scale/shift must come together"); return NM_ERR_ARG; }
+    Tiling t = choose_tiling(g, in.C);
+    if (t.lds_bytes > 160 * 1024) { nm_set_error("conv: LDS tile %zu B too large", t.lds_bytes); return NM_ERR_UNSUPPORTED; }
+    ConvParams p;
+    p.in = in.p; p.in_scale = in.scale; p.in_shift = in.shift; p.in_slope = in.slope;
+    p.N = in.N; p.ID = in.D; p.IH = in.H; p.IW = in.W; p.Cin = in.C;
+    p.w = w_packed; p.bias = bias; p.out = out; p.part = part;
+    p.OD = g.OD; p.OH = g.OH; p.OW = g.OW; p.Cout = g.Cout; p.Co_pad = g.Co_pad;
+    p.ks = g.ks; p.stride = g.stride; p.pad = g.pad;
+    p.bz_l2 = t.bz_l2; p.by_l2 = t.by_l2; p.bx_l2 = t.bx_l2; p.nbz = t.nbz; p.nby = t.nby; p.nbx = t.nbx;
+    p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp;
+    dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
+    if (t.MT == 2 && t.NT == 2) return launch_t<2, 2>(p, t, grid, s);
+    if (t.MT == 2 && t.NT == 1) return launch_t<2, 1>(p, t, grid, s);
+    if (t.MT == 1 && t.NT == 2) return launch_t<1, 2>(p, t, grid, s);
+    return launch_t<1, 1>(p, t, grid, s);
+}

@@ -1,0 +1,73 @@
+// Context object behind the C ABI (include/nm355.h): device, stream, packed weights,
+// stream-ordered bump-allocated workspace.
+#pragma once
+#include "nm_common.h"
+#include "../../include/nm355.h"
+#include <map>
+#include <string>
+#include <vector>
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, top = 0, peak = 0;
+    bool dry = false;            // dry run: only measure the high-water mark, launch nothing
+    bool overflow = false;
+
+    void* alloc_bytes(size_t bytes) {
+        size_t a = (top + 255) & ~(size_t)255;
+        top = a + bytes;
+        if (top > peak) peak = top;
+        if (dry) return reinterpret_cast<void*>((uintptr_t)256);
+        if (top > cap) { overflow = true; return nullptr; }
+        return base + a;
+    }
+    float* f(size_t n) { return static_cast<float*>(alloc_bytes(n * sizeof(float))); }
+    size_t mark() const { return top; }
+    void release(size_t m) { top = m; }
+};
+
+// ---- network weights (ctx-owned device copies) -------------------------------------------
+struct ConvW { int Cin = 0, Cin_pad = 0, Cout = 0, Co_pad = 0, ks = 0; float* wp = nullptr; float* bias = nullptr; };
+struct NormW { int C = 0, groups = 0; float* gamma = nullptr; float* beta = nullptr; };
+struct ResW { ConvW c1, c2, cs; NormW n1, n2, ns; bool has_skip = false; };
+struct PoolW { ConvW c; NormW n; };
+struct UpW { int Cin = 0, Cout = 0; float* w = nullptr; float* bias = nullptr; NormW n; };
+struct HourglassW { PoolW p1, p2, p3; ResW e1, e2, e3, d3, d2, d1, s1, s2, s3; UpW u3, u2, u1; };
+struct FeatNetW { ConvW c0; NormW n0; PoolW p1, p3; ResW r2, r5; HourglassW hg; };
+struct LinearW { int in = 0, out = 0; float* w = nullptr; float* b = nullptr; };
+
+struct DetectorW {
+    FeatNetW frame, clip;
+    ConvW head, clip_head, adjust;
+    float* prop = nullptr;                 // [w0, w1, b] of propagate_heatmaps (device)
+    ConvW d1, d4, d8, d11; NormW dn2, dn5, dn9, dn12;
+    float* d14 = nullptr;                  // [32 weights, bias] of the final 1x1 conv (device)
+    float* affinity_params = nullptr;      // (N,K,K-1)
+};
+
+struct VrnnW {
+    LinearW post0, post2, prior0, prior2, root0, root2, joint0, joint2;
+    float *w_ih = nullptr, *w_hh = nullptr, *b_ih = nullptr, *b_hh = nullptr;
+    float* h0 = nullptr;                   // init_kypt_rnn_state (1,H)
+    float* offset_param = nullptr;         // (K,3)
+    int32_t* parents = nullptr;            // device (K)
+    int32_t* order = nullptr;              // device (K)
+    std::vector<int32_t> parents_h, order_h;
+    bool has_tree = false;
+};
+
+struct nm_ctx {
+    nm_config cfg;
+    hipStream_t stream = nullptr;
+    Arena ws;                              // activations / scratch, reset per call
+    std::vector<void*> owned;              // weight allocations
+    bool has_weights = false;
+    DetectorW det;
+    VrnnW vrnn;
+};
+
+int nm_ctx_reserve(nm_ctx* ctx, size_t bytes);        // grow the workspace (synchronises)
+float* nm_ctx_weight_alloc(nm_ctx* ctx, size_t floats);
+
+// nm_net.hip
+int nm_net_set_weights(nm_ctx* ctx, const std::map<std::string, std::pair<const float*, int64_t>>& sd);

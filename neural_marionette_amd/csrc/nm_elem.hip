@@ -1,0 +1,269 @@
+// HBM-bound helper kernels around the conv stack (all channels-last, 16-B vector access):
+//   gn_finalize   per-block (sum, sumsq) partials -> per-(frame, channel) scale / shift
+//                 (nn.GroupNorm(C//16, C), eps 1e-5, biased variance: vox_modules.py:14,28,32,41,55,70)
+//   gn_partials   partials of a materialised tensor (producers without a stats epilogue)
+//   apply2        out = T_a(a) + T_b(b): residual sums of vox_modules.py:44-47,109-118
+//   convT2        ConvTranspose3d(k2, s2, output_padding): vox_modules.py:68
+//   upsample2     nn.Upsample(x2, trilinear, align_corners=False): kypt_detector.py:427,441
+//   pack_input    occupancy clip -> [frame][voxel][occ, x1, x2, x3, 0,0,0,0]
+//                 (add_coord_channels, kypt_detector_utils.py:4-26; clip mean kypt_detector.py:312)
+//   cl_to_ncdhw   channels-last -> NCDHW (first_feature output of kypt_detector.py:166)
+#include "nm_common.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+__device__ __forceinline__ f32x4 load_t(const TensorRef& t, size_t n, size_t vox_in_frame_times_C_plus_c, int c) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(t.p + n * ((size_t)t.D * t.H * t.W * t.C) + vox_in_frame_times_C_plus_c);
+    if (t.scale) {
+        f32x4 sc = *reinterpret_cast<const f32x4*>(t.scale + n * t.C + c);
+        f32x4 sh = *reinterpret_cast<const f32x4*>(t.shift + n * t.C + c);
+        v = v * sc + sh;
+    }
+    if (t.slope != 1.0f) {
+        v[0] = lrelu(v[0], t.slope); v[1] = lrelu(v[1], t.slope);
+        v[2] = lrelu(v[2], t.slope); v[3] = lrelu(v[3], t.slope);
+    }
+    return v;
+}
+
+// one block per (frame, group)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double sh_s[256], sh_ss[256];
+    const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups;
+    double s = 0.0, ss = 0.0;
+    const int total = nblk * cpg;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        int blk = i / cpg, c = g * cpg + i % cpg;
+        const float* q = part + (((size_t)n * nblk + blk) * C + c) * 2;
+        s += (double)q[0]; ss += (double)q[1];
+    }
+    sh_s[threadIdx.x] = s; sh_ss[threadIdx.x] = ss;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { sh_s[threadIdx.x] += sh_s[threadIdx.x + st]; sh_ss[threadIdx.x] += sh_ss[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    const double mean = sh_s[0] / count;
+    double var = sh_ss[0] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    if (threadIdx.x < cpg) {
+        int c = g * cpg + threadIdx.x;
+        float sc = (float)rstd * gamma[c];
+        scale[(size_t)n * C + c] = sc;
+        shift[(size_t)n * C + c] = -sc * (float)mean + beta[c];
+    }
+}
+
+#define NM_STATS_VB 512
+__global__ __launch_bounds__(256) void gn_partials_kernel(const float* __restrict__ x, int voxels, int C, int nblk,
+                                                          float* __restrict__ part) {
+    __shared__ float sh[256 * 2];
+    const int n = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+    const int lanes = 256 / C;
+    const int c = threadIdx.x % C, vl = threadIdx.x / C;
+    float s = 0.f, ss = 0.f;
+    if (vl < lanes) {
+        const int v0 = blk * NM_STATS_VB, v1 = min(voxels, v0 + NM_STATS_VB);
+        for (int v = v0 + vl; v < v1; v += lanes) {
+            float t = x[((size_t)n * voxels + v) * C + c];
+            s += t; ss += t * t;
+        }
+    }
+    sh[threadIdx.x * 2] = s; sh[threadIdx.x * 2 + 1] = ss;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < lanes; ++l) { a += sh[(l * C + c) * 2]; b += sh[(l * C + c) * 2 + 1]; }
+        float* dst = part + (((size_t)n * nblk + blk) * C + c) * 2;
+        dst[0] = a; dst[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void apply2_kernel(TensorRef a, TensorRef b, int has_b, float* __restrict__ out) {
+    const size_t per_frame = (size_t)a.D * a.H * a.W * a.C;       // floats
+    const size_t total4 = (size_t)a.N * per_frame / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        size_t e = i * 4;
+        size_t n = e / per_frame, r = e % per_frame;
+        int c = (int)(r % a.C);
+        f32x4 v = load_t(a, n, r, c);
+        if (has_b) v = v + load_t(b, n, r, c);
+        *reinterpret_cast<f32x4*>(out + e) = v;
+    }
+}
+
+// ConvTranspose3d k2 s2: out[2i+a] += x[i] * W[ci][co][a]; one thread per (out voxel, 4 channels)
+__global__ __launch_bounds__(256) void convT2_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int Cout, int OD, int OH, int OW) {
+    const int cq = Cout / 4;
+    const size_t total = (size_t)in.N * OD * OH * OW * cq;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int q = (int)(i % cq); size_t r = i / cq;
+        int ox = (int)(r % OW); r /= OW;
+        int oy = (int)(r % OH); r /= OH;
+        int oz = (int)(r % OD); size_t n = r / OD;
+        int co = q * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + co);
+        int iz = oz >> 1, iy = oy >> 1, ix = ox >> 1;
+        if (iz < in.D && iy < in.H && ix < in.W) {
+            int tap = ((oz & 1) * 2 + (oy & 1)) * 2 + (ox & 1);
+            size_t vo = (((size_t)iz * in.H + iy) * in.W + ix) * in.C;
+            for (int c = 0; c < in.C; c += 4) {
+                f32x4 x = load_t(in, n, vo + c, c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* wr = w + ((size_t)(c + j) * Cout + co) * 8 + tap;
+                    acc[0] += x[j] * wr[0]; acc[1] += x[j] * wr[8]; acc[2] += x[j] * wr[16]; acc[3] += x[j] * wr[24];
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + ((((size_t)n * OD + oz) * OH + oy) * OW + ox) * Cout + co) = acc;
+    }
+}
+
+// trilinear x2, align_corners=False: src = (dst + 0.5) / 2 - 0.5 clamped at 0
+__device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1) {
+    float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    i1 = i0 + (i0 < I - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void upsample2_kernel(TensorRef in, float* __restrict__ out) {
+    const int OD = in.D * 2, OH = in.H * 2, OW = in.W * 2, cq = in.C / 4;
+    const size_t total = (size_t)in.N * OD * OH * OW * cq;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int q = (int)(i % cq); size_t r = i / cq;
+        int ox = (int)(r % OW); r /= OW;
+        int oy = (int)(r % OH); r /= OH;
+        int oz = (int)(r % OD); size_t n = r / OD;
+        int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+        up_idx(oz, in.D, z0, z1, lz); up_idx(oy, in.H, y0, y1, ly); up_idx(ox, in.W, x0, x1, lx);
+        const int c = q * 4;
+        auto at = [&](int z, int y, int x) { return load_t(in, n, (((size_t)z * in.H + y) * in.W + x) * in.C + c, c); };
+        const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
+        f32x4 v = wz0 * (wy0 * (wx0 * at(z0, y0, x0) + lx * at(z0, y0, x1)) + ly * (wx0 * at(z0, y1, x0) + lx * at(z0, y1, x1))) +
+                  lz * (wy0 * (wx0 * at(z1, y0, x0) + lx * at(z1, y0, x1)) + ly * (wx0 * at(z1, y1, x0) + lx * at(z1, y1, x1)));
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
+__device__ __forceinline__ float lin_coord(int i, int G) {
+    // torch.linspace(-1, 1, G) in fp32: symmetric evaluation from both ends, one rounding (fma)
+    const float step = 2.0f / (float)(G - 1);
+    return i < G / 2 ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(G - 1 - i), 1.0f);
+}
+
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ vox, int B, int T, int G, int mean_t,
+                                                         float* __restrict__ out) {
+    const size_t G3 = (size_t)G * G * G;
+    const int frames = mean_t ? B : B * T;
+    const size_t total = (size_t)frames * G3;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t f = i / G3, v = i % G3;
+        float occ;
+        if (mean_t) {
+            float s = 0.f;
+            for (int t = 0; t < T; ++t) s += vox[(f * T + t) * G3 + v];
+            occ = s / (float)T;
+        } else {
+            occ = vox[f * G3 + v];
+        }
+        int x = (int)(v % G), y = (int)((v / G) % G), z = (int)(v / ((size_t)G * G));
+        f32x4 a = {occ, lin_coord(z, G), lin_coord(y, G), lin_coord(x, G)};
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        f32x4* o = reinterpret_cast<f32x4*>(out + i * 8);
+        o[0] = a; o[1] = b;
+    }
+}
+
+// [n][vox][C] -> [n][C][vox], 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void cl_to_ncdhw_kernel(TensorRef in, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int voxels = in.D * in.H * in.W;
+    const int n = blockIdx.z, v0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        int v = v0 + j, c = c0 + tx;
+        float val = 0.f;
+        if (v < voxels && c < in.C) {
+            val = in.p[((size_t)n * voxels + v) * in.C + c];
+            if (in.scale) val = val * in.scale[(size_t)n * in.C + c] + in.shift[(size_t)n * in.C + c];
+            if (in.slope != 1.0f) val = lrelu(val, in.slope);
+        }
+        tile[j][tx] = val;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j, v = v0 + tx;
+        if (v < voxels && c < in.C) out[((size_t)n * in.C + c) * voxels + v] = tile[tx][j];
+    }
+}
+
+int grid_for(size_t work_items) { return (int)min((work_items + 255) / 256, (size_t)(256 * 16)); }
+
+}  // namespace
+
+int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count, const float* gamma,
+                          const float* beta, float eps, float* scale, float* shift, hipStream_t s) {
+    if (groups <= 0 || C % groups != 0 || C / groups > 256) { nm_set_error("gn_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift);
+    return nm_check_hip(hipGetLastError(), "gn_finalize launch");
+}
+
+int nm_stats_blocks_per_frame(int voxels) { return (voxels + NM_STATS_VB - 1) / NM_STATS_VB; }
+
+int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part, hipStream_t s) {
+    if (C > 256 || C <= 0) { nm_set_error("gn_partials: C=%d unsupported", C); return NM_ERR_ARG; }
+    int nblk = nm_stats_blocks_per_frame(voxels);
+    hipLaunchKernelGGL(gn_partials_kernel, dim3(N * nblk), dim3(256), 0, s, x, voxels, C, nblk, part);
+    return nm_check_hip(hipGetLastError(), "gn_partials launch");
+}
+
+int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s) {
+    if (a.C % 4) { nm_set_error("apply2: C %% 4 != 0"); return NM_ERR_ARG; }
+    if (b && (b->N != a.N || b->D != a.D || b->H != a.H || b->W != a.W || b->C != a.C)) { nm_set_error("apply2: shape mismatch"); return NM_ERR_ARG; }
+    size_t total4 = (size_t)a.N * a.D * a.H * a.W * a.C / 4;
+    TensorRef bb = b ? *b : a;
+    hipLaunchKernelGGL(apply2_kernel, dim3(grid_for(total4)), dim3(256), 0, s, a, bb, b ? 1 : 0, out);
+    return nm_check_hip(hipGetLastError(), "apply2 launch");
+}
+
+int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, float* out, int Cout, int OD, int OH,
+                     int OW, hipStream_t s) {
+    if (Cout % 4 || in.C % 4) { nm_set_error("convT2: channels must be multiples of 4"); return NM_ERR_ARG; }
+    if (OD < 2 * in.D || OD > 2 * in.D + 1 || OH < 2 * in.H || OH > 2 * in.H + 1 || OW < 2 * in.W || OW > 2 * in.W + 1) {
+        nm_set_error("convT2: bad output size"); return NM_ERR_ARG;
+    }
+    size_t total = (size_t)in.N * OD * OH * OW * (Cout / 4);
+    hipLaunchKernelGGL(convT2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w, bias, out, Cout, OD, OH, OW);
+    return nm_check_hip(hipGetLastError(), "convT2 launch");
+}
+
+int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s) {
+    if (in.C % 4) { nm_set_error("upsample2: C %% 4 != 0"); return NM_ERR_ARG; }
+    size_t total = (size_t)in.N * in.D * in.H * in.W * 8 * (in.C / 4);
+    hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out);
+    return nm_check_hip(hipGetLastError(), "upsample2 launch");
+}
+
+int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t, float* out, hipStream_t s) {
+    size_t total = (size_t)(mean_over_t ? B : B * T) * G * G * G;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, vox, B, T, G, mean_over_t, out);
+    return nm_check_hip(hipGetLastError(), "pack_input launch");
+}
+
+int nm_launch_cl_to_ncdhw(const TensorRef& in, float* out, hipStream_t s) {
+    int voxels = in.D * in.H * in.W;
+    dim3 grid((voxels + 31) / 32, (in.C + 31) / 32, in.N);
+    hipLaunchKernelGGL(cl_to_ncdhw_kernel, grid, dim3(256), 0, s, in, out);
+    return nm_check_hip(hipGetLastError(), "cl_to_ncdhw launch");
+}

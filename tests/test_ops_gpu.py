@@ -1,0 +1,198 @@
+"""Op-level parity: each HIP kernel family, called through the C ABI, against the same ATen
+CPU op the oracle (and the reference) uses.  fp32 tolerance: 2e-5 relative to the output's
+max magnitude (fp32 accumulation-order noise; the 1e-4 budget of BASELINE.json is for the
+end-to-end keypoints / latents)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from neural_marionette_amd import _lib
+    cfg = _lib.NmConfig(device=0, grid_size=64, nkeypoints=24, nlatent=128, nhidden=512, nneighbor=2,
+                        gaussian_sigma=1.5, sep_sigma=0.02, vol_fit_chamfer=1, use_graph_traj=1)
+    c = _lib.Context(cfg)
+    c.bind_stream()
+    yield c
+    c.close()
+
+
+def to_cl(x, cpad=None):
+    """NCDHW cpu -> channels-last device tensor (channels zero-padded to a multiple of 8)."""
+    N, Cc = x.shape[:2]
+    cp = cpad or ((Cc + 7) // 8 * 8)
+    y = torch.zeros(N, *x.shape[2:], cp)
+    y[..., :Cc] = x.permute(0, 2, 3, 4, 1)
+    return y.contiguous().cuda()
+
+
+def from_cl(y, Cc):
+    return y[..., :Cc].permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def relerr(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def dev(t):
+    return None if t is None else t.contiguous().cuda()
+
+
+CONV_CASES = [
+    # Cin, Cout, ks, stride, pad, size, N, prologue, groups
+    (32, 64, 3, 1, 1, 16, 2, False, 4),
+    (64, 64, 3, 1, 1, 16, 1, True, 4),
+    (4, 32, 5, 1, 2, 16, 2, False, 2),
+    (32, 32, 2, 2, 0, 16, 2, True, 2),
+    (64, 128, 1, 1, 0, 8, 2, False, 8),
+    (48, 72, 3, 1, 1, 4, 3, True, 4),
+    (72, 72, 3, 1, 1, 2, 3, False, 4),
+    (72, 48, 3, 1, 1, 5, 2, True, 3),
+    (128, 24, 1, 1, 0, 8, 2, True, 0),
+    (48, 48, 2, 2, 0, 5, 2, False, 3),
+    (128, 64, 3, 1, 1, 12, 1, True, 4),
+    (256, 256, 3, 1, 1, 6, 1, False, 16),
+    (184, 128, 1, 1, 0, 10, 1, False, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "ci%d_co%d_k%d_s%d_d%d" % (c[0], c[1], c[2], c[3], c[5]))
+def test_conv3d(ctx, case):
+    from neural_marionette_amd import _lib
+    Cin, Cout, ks, stride, pad, size, N, prologue, groups = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    dims = (size, size + (1 if size % 2 else 0) * 0, size)
+    x = torch.randn(N, Cin, *dims, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, ks, generator=g) / (Cin * ks ** 3) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    cp = (Cin + 7) // 8 * 8
+    if prologue:
+        sc = torch.rand(N, Cin, generator=g) + 0.5
+        sh = torch.randn(N, Cin, generator=g) * 0.3
+        xin = F.leaky_relu(x * sc[:, :, None, None, None] + sh[:, :, None, None, None], 0.01)
+        scp = torch.zeros(N, cp); scp[:, :Cin] = sc
+        shp = torch.zeros(N, cp); shp[:, :Cin] = sh
+        slope = 0.01
+    else:
+        xin, scp, shp, slope = x, None, None, 1.0
+    ref = F.conv3d(xin, w, b, stride=stride, padding=pad)
+    od = ref.shape[2:]
+    out = torch.full((N, *od, Cout), float("nan")).cuda()
+    gam = torch.rand(Cout, generator=g) + 0.5
+    bet = torch.randn(Cout, generator=g) * 0.2
+    gsc = torch.zeros(N, Cout).cuda(); gsh = torch.zeros(N, Cout).cuda()
+    xd, wd, bd, scd, shd, gd, btd = to_cl(x), dev(w), dev(b), dev(scp), dev(shp), dev(gam), dev(bet)
+    _lib.check(ctx.lib.nm_op_conv3d(ctx.handle, _lib.ptr(xd), N, *dims, Cin, _lib.ptr(scd), _lib.ptr(shd), slope,
+                                    _lib.ptr(wd), _lib.ptr(bd), Cout, ks, stride, pad, _lib.ptr(out), groups,
+                                    _lib.ptr(gd), _lib.ptr(btd), _lib.ptr(gsc), _lib.ptr(gsh)), "op_conv3d")
+    torch.cuda.synchronize()
+    got = from_cl(out, Cout)
+    assert torch.isfinite(got).all(), "unwritten / non-finite outputs"
+    e = relerr(got, ref)
+    assert e < REL, f"conv raw output rel err {e:.3e}"
+    if groups:
+        refn = F.group_norm(ref, groups, gam, bet, 1e-5)
+        gotn = got * gsc.cpu()[:, :, None, None, None] + gsh.cpu()[:, :, None, None, None]
+        e = relerr(gotn, refn)
+        assert e < REL, f"fused GroupNorm rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("Cin,Cout,size,outpad,groups", [(72, 48, 2, 0, 3), (48, 32, 5, 1, 2), (32, 64, 8, 0, 4), (32, 128, 3, 1, 8)])
+def test_convT2(ctx, Cin, Cout, size, outpad, groups):
+    from neural_marionette_amd import _lib
+    g = torch.Generator().manual_seed(Cin * 131 + Cout)
+    N = 2
+    x = torch.randn(N, Cin, size, size, size, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, 2, generator=g) / (Cin * 8) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    gam = torch.rand(Cout, generator=g) + 0.5
+    bet = torch.randn(Cout, generator=g) * 0.2
+    ref = F.conv_transpose3d(x, w, b, stride=2, output_padding=outpad)
+    od = ref.shape[2]
+    out = torch.full((N, od, od, od, Cout), float("nan")).cuda()
+    gsc = torch.zeros(N, Cout).cuda(); gsh = torch.zeros(N, Cout).cuda()
+    xd, wd, bd, gd, btd = to_cl(x), dev(w), dev(b), dev(gam), dev(bet)
+    _lib.check(ctx.lib.nm_op_convT2(ctx.handle, _lib.ptr(xd), N, size, size, size, Cin, _lib.ptr(wd), _lib.ptr(bd),
+                                    Cout, outpad, _lib.ptr(out), groups, _lib.ptr(gd), _lib.ptr(btd),
+                                    _lib.ptr(gsc), _lib.ptr(gsh)), "op_convT2")
+    torch.cuda.synchronize()
+    got = from_cl(out, Cout)
+    e = relerr(got, ref)
+    assert e < REL, f"convT raw rel err {e:.3e}"
+    refn = F.group_norm(ref, groups, gam, bet, 1e-5)
+    gotn = got * gsc.cpu()[:, :, None, None, None] + gsh.cpu()[:, :, None, None, None]
+    e = relerr(gotn, refn)
+    assert e < REL, f"convT GroupNorm rel err {e:.3e}"
+
+
+def test_apply2(ctx):
+    from neural_marionette_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    N, V, Cc = 3, 125, 48
+    a = torch.randn(N, V, Cc, generator=g); b = torch.randn(N, V, Cc, generator=g)
+    sa = torch.rand(N, Cc, generator=g) + 0.5; ha = torch.randn(N, Cc, generator=g)
+    sb = torch.rand(N, Cc, generator=g) + 0.5; hb = torch.randn(N, Cc, generator=g)
+    ref = F.leaky_relu(a * sa[:, None] + ha[:, None], 0.01) + (b * sb[:, None] + hb[:, None])
+    out = torch.empty(N, V, Cc).cuda()
+    t = [dev(v) for v in (a, sa, ha, b, sb, hb)]
+    _lib.check(ctx.lib.nm_op_apply2(ctx.handle, _lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), 0.01,
+                                    _lib.ptr(t[3]), _lib.ptr(t[4]), _lib.ptr(t[5]), 1.0, N, V, Cc, _lib.ptr(out)), "apply2")
+    torch.cuda.synchronize()
+    assert relerr(out.cpu(), ref) < 1e-6
+    # single-source form
+    _lib.check(ctx.lib.nm_op_apply2(ctx.handle, _lib.ptr(t[0]), None, None, 1.0, None, None, None, 1.0, N, V, Cc,
+                                    _lib.ptr(out)), "apply2")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), a)
+
+
+@pytest.mark.parametrize("size,Cc", [(4, 16), (5, 8), (8, 128)])
+def test_upsample2(ctx, size, Cc):
+    from neural_marionette_amd import _lib
+    g = torch.Generator().manual_seed(size)
+    x = torch.randn(2, Cc, size, size, size, generator=g)
+    ref = F.interpolate(x, scale_factor=2.0, mode="trilinear", align_corners=False)
+    out = torch.empty(2, 2 * size, 2 * size, 2 * size, Cc).cuda()
+    xd = to_cl(x)
+    _lib.check(ctx.lib.nm_op_upsample2(ctx.handle, _lib.ptr(xd), 2, size, size, size, Cc, _lib.ptr(out)), "upsample2")
+    torch.cuda.synchronize()
+    e = relerr(from_cl(out, Cc), ref)
+    assert e < 2e-6, f"trilinear rel err {e:.3e}"
+
+
+def test_pack_input(ctx):
+    from neural_marionette_amd import _lib
+    from oracle import nm_oracle as O
+    B, T, G = 2, 3, 16
+    vox = (torch.rand(B, T, 1, G, G, G) < 0.1).float()
+    vd = vox.cuda()
+    out = torch.empty(B * T, G, G, G, 8).cuda()
+    _lib.check(ctx.lib.nm_op_pack_input(ctx.handle, _lib.ptr(vd), B, T, G, 0, _lib.ptr(out)), "pack_input")
+    torch.cuda.synchronize()
+    ref = O.add_coords(vox.view(B * T, 1, G, G, G))
+    got = out.cpu()
+    assert torch.equal(from_cl(out, 4)[:, 0], ref[:, 0])
+    assert (from_cl(out, 4)[:, 1:] - ref[:, 1:]).abs().max().item() <= 6e-8
+    assert got[..., 4:].abs().max().item() == 0.0
+    out2 = torch.empty(B, G, G, G, 8).cuda()
+    _lib.check(ctx.lib.nm_op_pack_input(ctx.handle, _lib.ptr(vd), B, T, G, 1, _lib.ptr(out2)), "pack_input")
+    torch.cuda.synchronize()
+    assert torch.equal(from_cl(out2, 4)[:, 0], vox.mean(dim=1)[:, 0])
+
+
+def test_cl_to_ncdhw(ctx):
+    from neural_marionette_amd import _lib
+    x = torch.randn(2, 100, 40)
+    out = torch.empty(2, 40, 100).cuda()
+    xd = x.cuda()
+    _lib.check(ctx.lib.nm_op_cl_to_ncdhw(ctx.handle, _lib.ptr(xd), 2, 100, 40, _lib.ptr(out)), "cl_to_ncdhw")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), x.permute(0, 2, 1))
