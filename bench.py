@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py — voxel-frames/s of the Neural Marionette hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): AIST++-shaped synthetic clips, 64^3 occupancy grid,
+T = 16, B = 4 clips per GPU, full NeuralMarionette.forward (keypoint detector incl. all 11
+losses + HSVRNNBVH.encode), fp32, seeded random weights of the reference architecture.  A
+"step" is one forward over one batch of B*T = 64 voxel-frames whose inputs are already
+resident in HBM.  N > 1: independent clips per rank (weak scaling, no data-path collective);
+launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+
+Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel
+(HIP-event timed inside the timed region, algorithmic FLOPs) and the CPU baseline (the
+oracle — a port of the reference on PyTorch-CPU ops — timed on the host cores, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+G, T, B_PER_GPU, S = 64, 16, 4, 10
+FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def cpu_baseline(sd, opts, net, dev):
+    """Oracle (kind 'port') on a bounded sample of the same workload: clips of 64^3 x T=16."""
+    from neural_marionette_amd import synth
+    from oracle import nm_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    nb = 2
+    vox = synth.figure_clip(nb, T, G, seed=1001)
+    eps = synth.make_eps((T, S, nb, opts.nlatent_kypt), seed=1002)
+    with torch.no_grad():
+        O.nm_forward(sd, opts, vox[:1, :4].contiguous(), eps[:4, :, :1].contiguous())   # warm the thread pool
+        times = []
+        t_all = time.perf_counter()
+        ref = None
+        while len(times) < 3 and (time.perf_counter() - t_all) < 25.0:
+            t0 = time.perf_counter()
+            ref = O.nm_forward(sd, opts, vox, eps)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    # parity of the GPU path on exactly this sample (keypoint L2 vs the CPU reference port)
+    out = net(vox.to(dev), {"detector": True, "learner": True}, eps=eps.to(dev))
+    torch.cuda.synchronize(dev)
+    d = (out["keypoints"][..., :3].cpu() - ref["keypoints"][..., :3]).double()
+    l2 = d.pow(2).sum(-1).sqrt().max().item()
+    return dict(value=nb * T / med, unit="voxel-frames/s", cores=threads, kind="port",
+                sample=f"{len(times)} x oracle.nm_forward on {nb} clips of 64^3 x T=16 (median), "
+                       f"torch {torch.__version__} CPU ops, {threads} threads"), l2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from neural_marionette_amd import NeuralMarionette, HotPathOptions, synth, _lib
+    opts = HotPathOptions(grid_size=G)
+    sd = synth.make_state_dict(opts, seed=42, variant="peaky")
+    net = NeuralMarionette(opts)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    net.anneal(1)
+    acts = {"detector": True, "learner": True}
+    vox = synth.figure_clip(B_PER_GPU, T, G, seed=1 + rank).to(dev)           # resident in HBM
+    eps = synth.make_eps((T, S, B_PER_GPU, opts.nlatent_kypt), seed=100 + rank).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        net(vox, acts, eps=eps)
+    eng = net._engine
+    lib, h = eng.ctx.lib, eng.ctx.handle
+    _lib.check(lib.nm_prof_enable(h, 1), "prof_enable")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net(vox, acts, eps=eps)
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.check(lib.nm_prof_enable(h, 0), "prof_enable")
+    if dist_on:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        frames = world * B_PER_GPU * T * args.steps
+        # dominant kernel = the conv variant with the largest event-timed total
+        best = None
+        for v in range(4):
+            ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+            _lib.check(lib.nm_prof_read(h, v, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
+            if n.value and (best is None or ms.value > best[1]):
+                best = (lib.nm_prof_kernel_name(v).decode(), ms.value, fl.value, n.value)
+        roof = None
+        if best:
+            name, ms, fl, n = best
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, kernel=name, launches=n,
+                        avg_launch_ms=ms / n, kernel_time_share=ms * 1e-3 / dt)
+        cpu, l2 = (None, None)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, l2 = cpu_baseline(sd, opts, net, dev)
+        line = dict(
+            metric="voxel-frames/sec (64^3, T=16)", value=frames / dt, unit="voxel-frames/s",
+            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload="AIST++-shaped synthetic clips 64^3 T=16 B=4/GPU, full NeuralMarionette.forward "
+                                 "(detector + 11 losses + HSVRNNBVH.encode, best-of-10), fp32, random-init weights",
+                        grid=G, T=T, clips_per_gpu=B_PER_GPU, global_clips=world * B_PER_GPU,
+                        parallelism=f"clip-sharded x{world} (no data-path collective)"),
+            roofline=roof, cpu_baseline=cpu, kypt_l2_vs_cpu=l2,
+        )
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,13 @@ int nm_op_apply2(nm_ctx* ctx, const float* a, const float* a_scale, const float*
 int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out);
 int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out);
 int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out);
+/* ---- live kernel timing for bench.py's roofline leg -------------------------------------------
+ * While enabled, every conv launch on the ctx stream is bracketed by a HIP event pair.
+ * nm_prof_read sums duration and ALGORITHMIC flops (2*voxels*Cout*Cin*k^3, un-padded) of one
+ * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2)). */
+int nm_prof_enable(nm_ctx* ctx, int32_t on);
+int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches);
+const char* nm_prof_kernel_name(int32_t variant);
 /* host helper: torch.linspace(-1, 1, n) as the kernels evaluate it */
 int nm_host_linspace(int32_t n, float* out_host);
 

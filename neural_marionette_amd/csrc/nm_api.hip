@@ -95,6 +95,27 @@ int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t coun
     return nm_net_set_weights(ctx, sd);
 }
 
+int nm_prof_enable(nm_ctx* ctx, int32_t on) {
+    if (!ctx) { nm_set_error("prof_enable: null ctx"); return NM_ERR_ARG; }
+    nm_conv_prof_enable(on);
+    if (on) nm_conv_prof_reset();
+    return NM_OK;
+}
+
+int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) {
+    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 3) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
+    long long n = 0;
+    int rc = nm_conv_prof_collect(variant, ms_total, flops_total, &n);
+    if (rc) { nm_set_error("prof_read: event query failed"); return rc; }
+    *launches = n;
+    return NM_OK;
+}
+
+const char* nm_prof_kernel_name(int32_t variant) {
+    static const char* names[4] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>"};
+    return (variant >= 0 && variant < 4) ? names[variant] : "";
+}
+
 int nm_host_linspace(int32_t n, float* out) {
     if (n < 2 || !out) { nm_set_error("linspace: bad arguments"); return NM_ERR_ARG; }
     const float step = 2.0f / (float)(n - 1);

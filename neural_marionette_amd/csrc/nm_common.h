@@ -48,7 +48,11 @@ int nm_launch_pack_conv_weight(const float* w_oidhw, int Cout, int Cin, int ks, 
 // number of per-frame partial blocks the conv epilogue writes (for sizing `part`)
 int nm_conv_blocks_per_frame(const ConvGeom& g);
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
-                   const ConvGeom& g, float* part /*[N][nblk][Cout][2] or null*/, hipStream_t s);
+                   const ConvGeom& g, float* part /*[N][nblk][Cout][2] or null*/, hipStream_t s,
+                   int cin_real = 0 /* un-padded Cin, for the profiler's FLOP count */);
+void nm_conv_prof_enable(int on);
+int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, long long* launches);
+void nm_conv_prof_reset();
 
 // ---- nm_elem.hip -------------------------------------------------------------------
 int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count,
@@ -64,3 +68,6 @@ int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s);
 int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t, float* out,
                          hipStream_t s);
 int nm_launch_cl_to_ncdhw(const TensorRef& in, float* out, hipStream_t s);
+// in holds N frames picked with a stride (frame n of the output = frame n*frame_stride of in.p)
+int nm_launch_cl_to_ncdhw_strided(const TensorRef& in, int frame_stride, float* out, hipStream_t s);
+int nm_launch_ncdhw_to_cl(const float* in, int N, int voxels, int C, float* out, hipStream_t s);

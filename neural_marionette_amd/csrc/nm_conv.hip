@@ -22,6 +22,7 @@
 //   sum / sum-of-squares partials for the following GroupNorm (deterministic: no float
 //   atomics).
 #include "nm_common.h"
+#include <vector>
 
 namespace {
 
@@ -35,6 +36,7 @@ struct ConvParams {
     int bz_l2, by_l2, bx_l2;      // brick dims (log2)
     int nbz, nby, nbx;            // bricks per frame
     int KC;                       // channels per LDS chunk (8 or 16)
+    int cin_real;                 // un-padded input channels (profiling only)
     int HZ, HY, HX, HV, HVp;      // halo dims, voxels, padded plane stride (HVp % 8 == 2)
 };
 
@@ -242,6 +244,19 @@ Tiling choose_tiling(const ConvGeom& g, int Cin) {
     return t;
 }
 
+// ---- optional live timing of the conv launches (bench.py roofline leg) ---------------------------
+struct ProfRec { hipEvent_t a, b; int variant; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;                 // records of the current window
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t prof_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
 template <int MT, int NT>
 int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
@@ -251,7 +266,15 @@ int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv)");
         attr_set = true;
     }
+    ProfRec rec;
+    if (g_prof_on) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = (MT - 1) * 2 + (NT - 1);
+        // algorithmic work: real channels and taps, no padding
+        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
+        (void)hipEventRecord(rec.a, s);
+    }
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(256), t.lds_bytes, s, p);
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
@@ -278,8 +301,30 @@ int nm_conv_blocks_per_frame(const ConvGeom& g) {
     return t.nbz * t.nby * t.nbx;
 }
 
+void nm_conv_prof_enable(int on) { g_prof_on = on != 0; }
+
+// Sums the event-timed launches of one kernel variant recorded since the last reset.
+// variant = (MT-1)*2 + (NT-1).  Synchronises on the recorded events.
+int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, long long* launches) {
+    double ms = 0.0, fl = 0.0; long long n = 0;
+    for (const ProfRec& r : g_prof) {
+        if (r.variant != variant) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return NM_ERR_HIP;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return NM_ERR_HIP;
+        ms += t; fl += r.flops; ++n;
+    }
+    *ms_total = ms; *flops_total = fl; *launches = n;
+    return NM_OK;
+}
+
+void nm_conv_prof_reset() {
+    for (const ProfRec& r : g_prof) { g_event_pool.push_back(r.a); g_event_pool.push_back(r.b); }
+    g_prof.clear();
+}
+
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
-                   const ConvGeom& g, float* part, hipStream_t s) {
+                   const ConvGeom& g, float* part, hipStream_t s, int cin_real) {
     if (in.C % 8 != 0 || g.Co_pad % 32 != 0 || g.Cout > g.Co_pad || g.Cout <= 0) {
         nm_set_error("conv: unsupported channels Cin=%d Cout=%d Co_pad=%d", in.C, g.Cout, g.Co_pad);
         return NM_ERR_ARG;
@@ -300,6 +345,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.OD = g.OD; p.OH = g.OH; p.OW = g.OW; p.Cout = g.Cout; p.Co_pad = g.Co_pad;
     p.ks = g.ks; p.stride = g.stride; p.pad = g.pad;
     p.bz_l2 = t.bz_l2; p.by_l2 = t.by_l2; p.bx_l2 = t.bx_l2; p.nbz = t.nbz; p.nby = t.nby; p.nbx = t.nbx;
+    p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
     if (t.MT == 2 && t.NT == 2) return launch_t<2, 2>(p, t, grid, s);

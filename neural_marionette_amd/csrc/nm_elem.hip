@@ -186,17 +186,18 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 }
 
 // [n][vox][C] -> [n][C][vox], 32x32 tiles through LDS
-__global__ __launch_bounds__(256) void cl_to_ncdhw_kernel(TensorRef in, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void cl_to_ncdhw_kernel(TensorRef in, int frame_stride, float* __restrict__ out) {
     __shared__ float tile[32][33];
     const int voxels = in.D * in.H * in.W;
     const int n = blockIdx.z, v0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const size_t nin = (size_t)n * frame_stride;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         int v = v0 + j, c = c0 + tx;
         float val = 0.f;
         if (v < voxels && c < in.C) {
-            val = in.p[((size_t)n * voxels + v) * in.C + c];
-            if (in.scale) val = val * in.scale[(size_t)n * in.C + c] + in.shift[(size_t)n * in.C + c];
+            val = in.p[(nin * voxels + v) * in.C + c];
+            if (in.scale) val = val * in.scale[nin * in.C + c] + in.shift[nin * in.C + c];
             if (in.slope != 1.0f) val = lrelu(val, in.slope);
         }
         tile[j][tx] = val;
@@ -205,6 +206,22 @@ __global__ __launch_bounds__(256) void cl_to_ncdhw_kernel(TensorRef in, float* _
     for (int j = ty; j < 32; j += 8) {
         int c = c0 + j, v = v0 + tx;
         if (v < voxels && c < in.C) out[((size_t)n * in.C + c) * voxels + v] = tile[tx][j];
+    }
+}
+
+// [n][C][vox] -> [n][vox][C]
+__global__ __launch_bounds__(256) void ncdhw_to_cl_kernel(const float* __restrict__ in, int voxels, int C, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, v0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j, v = v0 + tx;
+        tile[j][tx] = (v < voxels && c < C) ? in[((size_t)n * C + c) * voxels + v] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int v = v0 + j, c = c0 + tx;
+        if (v < voxels && c < C) out[((size_t)n * voxels + v) * C + c] = tile[tx][j];
     }
 }
 
@@ -261,9 +278,17 @@ int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t,
     return nm_check_hip(hipGetLastError(), "pack_input launch");
 }
 
-int nm_launch_cl_to_ncdhw(const TensorRef& in, float* out, hipStream_t s) {
+int nm_launch_cl_to_ncdhw_strided(const TensorRef& in, int frame_stride, float* out, hipStream_t s) {
     int voxels = in.D * in.H * in.W;
     dim3 grid((voxels + 31) / 32, (in.C + 31) / 32, in.N);
-    hipLaunchKernelGGL(cl_to_ncdhw_kernel, grid, dim3(256), 0, s, in, out);
+    hipLaunchKernelGGL(cl_to_ncdhw_kernel, grid, dim3(256), 0, s, in, frame_stride, out);
     return nm_check_hip(hipGetLastError(), "cl_to_ncdhw launch");
+}
+
+int nm_launch_cl_to_ncdhw(const TensorRef& in, float* out, hipStream_t s) { return nm_launch_cl_to_ncdhw_strided(in, 1, out, s); }
+
+int nm_launch_ncdhw_to_cl(const float* in, int N, int voxels, int C, float* out, hipStream_t s) {
+    dim3 grid((voxels + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(ncdhw_to_cl_kernel, grid, dim3(256), 0, s, in, voxels, C, out);
+    return nm_check_hip(hipGetLastError(), "ncdhw_to_cl launch");
 }

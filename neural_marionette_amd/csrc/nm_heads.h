@@ -1,0 +1,20 @@
+// launchers of nm_heads.hip
+#pragma once
+#include "nm_common.h"
+
+int nm_launch_heatmap(const float* head, const float* clip_head, const float* prop, int F, int T, int K, int g,
+                      float* heatmaps, float* part, hipStream_t s);
+int nm_launch_keypoints(const float* part, int F, int K, int g, float* keypoints, float* heat_mean, hipStream_t s);
+int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s);
+int nm_launch_combined(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int F,
+                       int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s);
+int nm_tail_blocks(int G);
+int nm_launch_decoder_tail(const TensorRef& x, const float* w14, const float* first_frames, int ff_stride_frames, int T,
+                           const float* target, const float* keypoints, int K, int G, float* recon, float* part,
+                           hipStream_t s);
+int nm_launch_clip_loss(const float* keypoints, const float* affinity, int B, int T, int K, int N, float sep_sigma,
+                        float* out, hipStream_t s);
+int nm_launch_loss_finalize(const float* tail_part, int tail_blocks, int B, int T, int K, int N, int G,
+                            const float* heat_mean, const float* clip_part, const float* affinity, int chamfer,
+                            int use_traj, float* losses, hipStream_t s);
+int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_t s);

@@ -1,1 +1,447 @@
+// Detector heads, decoder tail and losses (HBM-/latency-bound kernels, wavefront = 64).
+//
+//   heatmap_kernel      1x1 head outputs -> LeakyReLU -> propagate(2->1) -> Softplus, heat-maps in
+//                       NCDHW + per-plane marginal partial sums       (kypt_detector.py:336-343)
+//   keypoints_kernel    marginals -> (x1,x2,x3,intensity)             (kypt_detector_utils.py:28-55)
+//   gauss_table_kernel  separable 1-D gaussians per (frame, keypoint) (kypt_detector_utils.py:57-90)
+//   combined_kernel     [gauss_t | first_feature | gauss_0 | coords]  (kypt_detector.py:406-407)
+//   decoder_tail_kernel conv1x1(32->1) + sigmoid(10*(tanh(v)+first_frame-0.5)), BCE partials,
+//                       occupancy-masked chamfer partials     (kypt_detector.py:410,91-92;
+//                                                              kypt_detector_utils.py:140-153)
+//   clip_loss_kernel / loss_finalize_kernel  separation, graph consistency, trajectory losses
+//                       (kypt_detector_utils.py:92-133,172-265) and the 11 scalar means
+//   affinity_kernel     get_affinity ver 3                            (kypt_detector.py:191-199)
 #include "nm_common.h"
+#include "nm_heads.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float lin_coord(int i, int G) {
+    const float step = 2.0f / (float)(G - 1);
+    return i < G / 2 ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(G - 1 - i), 1.0f);
+}
+
+// deterministic block sum (256 threads); result valid in every thread
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    float r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// grid (F, g): one z-plane of one frame.  LDS: K * g * g floats.
+__global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ head, const float* __restrict__ clip_head,
+                                                      const float* __restrict__ prop, int T, int K, int g,
+                                                      float* __restrict__ heatmaps, float* __restrict__ part) {
+    extern __shared__ float tile[];                       // [K][g*g]
+    const int f = blockIdx.x, z = blockIdx.y, b = f / T;
+    const int g2 = g * g, g3 = g2 * g;
+    const float w0 = prop[0], w1 = prop[1], pb = prop[2];
+    for (int v = threadIdx.x; v < g2; v += 256) {
+        const size_t vox = (size_t)z * g2 + v;
+        const float* hp = head + ((size_t)f * g3 + vox) * K;
+        const float* cp = clip_head + ((size_t)b * g3 + vox) * K;
+        for (int k = 0; k < K; k += 4) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(hp + k);
+            f32x4 c = *reinterpret_cast<const f32x4*>(cp + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float hm = softplus(w0 * lrelu(a[j], 0.01f) + w1 * lrelu(c[j], 0.01f) + pb);
+                heatmaps[((size_t)f * K + k + j) * g3 + vox] = hm;
+                tile[(k + j) * g2 + v] = hm;
+            }
+        }
+    }
+    __syncthreads();
+    // per (k, row y): sum over x;  per (k, col x): sum over y   of (hm + 1e-6)
+    const int stride = 2 * g + 2;
+    for (int task = threadIdx.x; task < K * g * 2; task += 256) {
+        int k = task / (2 * g), r = task % (2 * g);
+        const float* tk = tile + k * g2;
+        float s = 0.f;
+        if (r < g) { for (int x = 0; x < g; ++x) s += tk[r * g + x] + 1e-6f; }
+        else { int x = r - g; for (int y = 0; y < g; ++y) s += tk[y * g + x] + 1e-6f; }
+        part[(((size_t)f * K + k) * g + z) * stride + r] = s;
+    }
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float* tk = tile + k * g2;
+        float s = 0.f, s6 = 0.f;
+        for (int v = 0; v < g2; ++v) { s += tk[v]; s6 += tk[v] + 1e-6f; }
+        float* dst = part + (((size_t)f * K + k) * g + z) * stride + 2 * g;
+        dst[0] = s; dst[1] = s6;
+    }
+}
+
+// one block per frame, thread k < K finishes keypoint k
+__global__ __launch_bounds__(64) void keypoints_kernel(const float* __restrict__ part, int K, int g,
+                                                       float* __restrict__ keypoints, float* __restrict__ heat_mean) {
+    __shared__ float means[64];
+    const int f = blockIdx.x, k = threadIdx.x;
+    const int stride = 2 * g + 2;
+    float mean = 0.f, c[3] = {0.f, 0.f, 0.f};
+    if (k < K) {
+        const float* p = part + ((size_t)f * K + k) * g * stride;
+        float tot = 0.f, tot6 = 0.f;
+        for (int z = 0; z < g; ++z) { tot += p[z * stride + 2 * g]; tot6 += p[z * stride + 2 * g + 1]; }
+        mean = tot / (float)(g * g * g);
+        // axis 0 (z): weights are the plane sums
+        { float cz = 0.f; for (int z = 0; z < g; ++z) cz += (p[z * stride + 2 * g + 1] / tot6) * lin_coord(z, g); c[0] = cz; }
+        for (int d = 1; d < 3; ++d) {
+            float S = 0.f;
+            for (int j = 0; j < g; ++j) { float w = 0.f; for (int z = 0; z < g; ++z) w += p[z * stride + (d - 1) * g + j]; S += w; }
+            float cd = 0.f;
+            for (int j = 0; j < g; ++j) { float w = 0.f; for (int z = 0; z < g; ++z) w += p[z * stride + (d - 1) * g + j]; cd += (w / S) * lin_coord(j, g); }
+            c[d] = cd;
+        }
+        heat_mean[(size_t)f * K + k] = mean;
+    }
+    means[threadIdx.x] = (k < K) ? mean : -INFINITY;
+    __syncthreads();
+    if (k < K) {
+        float mx = -INFINITY;
+        for (int j = 0; j < K; ++j) mx = fmaxf(mx, means[j]);
+        float* o = keypoints + ((size_t)f * K + k) * 4;
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = mean / (mx + 1e-6f);
+    }
+}
+
+// E[f][k][d][j] = exp(-(lin_j - c_d)^2 / width)
+__global__ __launch_bounds__(256) void gauss_table_kernel(const float* __restrict__ keypoints, int FK, int g, float width,
+                                                          float* __restrict__ table) {
+    const int total = FK * 3 * g;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int j = i % g, d = (i / g) % 3, fk = i / (3 * g);
+        float diff = lin_coord(j, g) - keypoints[(size_t)fk * 4 + d];
+        table[i] = expf(-(diff * diff) / width);
+    }
+}
+
+// combined[f][v][Cc]: [0,K) gauss_t | [K,K+Fd) feature of the clip's first frame | gauss_0 | 3 coords | zero pad
+// (f - f % T is frame 0 of the same clip; first_feature is channels-last with a frame stride)
+__global__ __launch_bounds__(256) void combined_kernel(const float* __restrict__ table, const float* __restrict__ keypoints,
+                                                       const float* __restrict__ first_feature, int ff_stride, int F, int T,
+                                                       int K, int Fd, int g, int Cc, float* __restrict__ out) {
+    const int g2 = g * g, g3 = g2 * g, cq = Cc / 4;
+    const size_t total = (size_t)F * g3 * cq;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int q = (int)(i % cq); size_t r = i / cq;
+        int v = (int)(r % g3); int f = (int)(r / g3);
+        int b = f / T, f0 = b * T;
+        int x = v % g, y = (v / g) % g, z = v / g2;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = q * 4 + j;
+            float val = 0.f;
+            if (c < K) {
+                const float* e = table + ((size_t)f * K + c) * 3 * g;
+                val = ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f * K + c) * 4 + 3];
+            } else if (c < K + Fd) {
+                val = first_feature[(((size_t)b * ff_stride) * g3 + v) * Fd + (c - K)];
+            } else if (c < 2 * K + Fd) {
+                int k = c - K - Fd;
+                const float* e = table + ((size_t)f0 * K + k) * 3 * g;
+                val = ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f0 * K + k) * 4 + 3];
+            } else if (c < 2 * K + Fd + 3) {
+                int d = c - 2 * K - Fd;
+                val = lin_coord(d == 0 ? z : (d == 1 ? y : x), g);
+            }
+            o[j] = val;
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    }
+}
+
+// grid (ceil(G3/256), F).  x: raw 32-channel tensor with pending GN affine + lrelu.
+__global__ __launch_bounds__(256) void decoder_tail_kernel(TensorRef x, const float* __restrict__ w14, const float* __restrict__ first_frames,
+                                                           int ff_stride_frames, int T, const float* __restrict__ target,
+                                                           const float* __restrict__ keypoints, int K, int G,
+                                                           float* __restrict__ recon, float* __restrict__ part) {
+    __shared__ float sh[256];
+    __shared__ float kp[32 * 3];
+    const int f = blockIdx.y, b = f / T;
+    const size_t G3 = (size_t)G * G * G;
+    const size_t v = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (keypoints && threadIdx.x < K * 3) kp[threadIdx.x] = keypoints[((size_t)f * K + threadIdx.x / 3) * 4 + threadIdx.x % 3];
+    __syncthreads();
+    float bce = 0.f, cham = 0.f, cnt = 0.f;
+    if (v < G3) {
+        const int C = x.C;
+        const float* px = x.p + ((size_t)f * G3 + v) * C;
+        float acc = 0.f;
+        for (int c = 0; c < C; c += 4) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(px + c);
+            f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + c);
+            f32x4 sh4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + c);
+            f32x4 wv = *reinterpret_cast<const f32x4*>(w14 + c);
+            a = a * sc + sh4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += lrelu(a[j], x.slope) * wv[j];
+        }
+        acc += w14[C];
+        const float ff = first_frames[((size_t)b * ff_stride_frames) * G3 + v];
+        const float pre = 10.0f * ((tanhf(acc) + ff) - 0.5f);
+        const float p = 1.0f / (1.0f + expf(-pre));
+        recon[(size_t)f * G3 + v] = p;
+        if (target) {
+            const float y = target[(size_t)f * G3 + v];
+            bce = (y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f);
+            if (keypoints && y != 0.f) {
+                int xx = (int)(v % G), yy = (int)((v / G) % G), zz = (int)(v / ((size_t)G * G));
+                float cz = lin_coord(zz, G), cy = lin_coord(yy, G), cx = lin_coord(xx, G);
+                float best = INFINITY;
+                for (int k = 0; k < K; ++k) {
+                    float d0 = cz - kp[k * 3], d1 = cy - kp[k * 3 + 1], d2 = cx - kp[k * 3 + 2];
+                    best = fminf(best, (d0 * d0 + d1 * d1) + d2 * d2);
+                }
+                cham = best * y; cnt = y;
+            }
+        }
+    }
+    if (part) {
+        float s0 = block_sum256(bce, sh), s1 = block_sum256(cham, sh), s2 = block_sum256(cnt, sh);
+        if (threadIdx.x == 0) {
+            float* dst = part + ((size_t)f * gridDim.x + blockIdx.x) * 3;
+            dst[0] = s0; dst[1] = s1; dst[2] = s2;
+        }
+    }
+}
+
+// one block per clip b: partial sums of the keypoint-only losses
+//   out[b][0] separation_b   [1] sum_t local   [2] sum_t time   [3] sum vel term   [4] sum acc term
+__global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict__ keypoints, const float* __restrict__ affinity,
+                                                        int T, int K, int N, float sep_sigma, float* __restrict__ out) {
+    __shared__ float sh[256];
+    extern __shared__ float dyn[];
+    float* pos = dyn;                      // [T][K][3]
+    float* mean = dyn + T * K * 3;         // [K][3]
+    float* infl = mean + K * 3;            // [K][K]
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < T * K * 3; i += 256) {
+        int d = i % 3, tk = i / 3;
+        pos[i] = keypoints[((size_t)b * T * K + tk) * 4 + d];
+    }
+    if (affinity) for (int i = threadIdx.x; i < K * K; i += 256) {
+        float m = -INFINITY;
+        for (int n = 0; n < N; ++n) m = fmaxf(m, affinity[(size_t)n * K * K + i]);
+        infl[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * 3; i += 256) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += pos[t * K * 3 + i];
+        mean[i] = s / (float)T;
+    }
+    __syncthreads();
+    float sep = 0.f, loc = 0.f, tim = 0.f, vel = 0.f, acc = 0.f;
+    const float sep_den = 2.0f * sep_sigma * sep_sigma;
+    for (int pr = threadIdx.x; pr < K * K; pr += 256) {
+        const int k = pr / K, l = pr % K;
+        // separation: temporal mean of squared distances of mean-centred trajectories
+        float d2s = 0.f, dsum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            float s = 0.f, sd = 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float a = pos[(t * K + k) * 3 + d], c = pos[(t * K + l) * 3 + d];
+                float u = (a - mean[k * 3 + d]) - (c - mean[l * 3 + d]);
+                s += u * u;
+                float w = a - c;
+                sd += w * w;
+            }
+            d2s += s; dsum += sd;
+        }
+        sep += expf(-(d2s / (float)T) / sep_den);
+        if (affinity) {
+            const float in = infl[pr];
+            const float dmean = dsum / (float)T;
+            float tl = 0.f, tt = 0.f;
+            for (int t = 0; t < T; ++t) {
+                float sd = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { float w = pos[(t * K + k) * 3 + d] - pos[(t * K + l) * 3 + d]; sd += w * w; }
+                tl += sd * in;
+                tt += fabsf(sd - dmean) * in;
+            }
+            loc += tl; tim += tt;
+            // trajectory: cosine of velocities / accelerations of k and l (eps 1e-6 on each norm)
+            for (int t = 0; t + 1 < T; ++t) {
+                float vk[3], vl[3], nk = 0.f, nl = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    vk[d] = pos[((t + 1) * K + k) * 3 + d] - pos[(t * K + k) * 3 + d];
+                    vl[d] = pos[((t + 1) * K + l) * 3 + d] - pos[(t * K + l) * 3 + d];
+                    nk += vk[d] * vk[d]; nl += vl[d] * vl[d];
+                }
+                nk = fmaxf(sqrtf(nk), 1e-6f); nl = fmaxf(sqrtf(nl), 1e-6f);
+                float cs = 0.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) cs += (vk[d] / nk) * (vl[d] / nl);
+                vel += ((-cs + 1.0f) / 2.0f) * in;
+                if (t + 2 < T) {
+                    float ak[3], al[3], mk = 0.f, ml = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        float vk2 = pos[((t + 2) * K + k) * 3 + d] - pos[((t + 1) * K + k) * 3 + d];
+                        float vl2 = pos[((t + 2) * K + l) * 3 + d] - pos[((t + 1) * K + l) * 3 + d];
+                        ak[d] = vk2 - vk[d]; al[d] = vl2 - vl[d];
+                        mk += ak[d] * ak[d]; ml += al[d] * al[d];
+                    }
+                    mk = fmaxf(sqrtf(mk), 1e-6f); ml = fmaxf(sqrtf(ml), 1e-6f);
+                    float ca = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) ca += (ak[d] / mk) * (al[d] / ml);
+                    acc += ((-ca + 1.0f) / 2.0f) * in;
+                }
+            }
+        }
+    }
+    float s0 = block_sum256(sep, sh), s1 = block_sum256(loc, sh), s2 = block_sum256(tim, sh);
+    float s3 = block_sum256(vel, sh), s4 = block_sum256(acc, sh);
+    if (threadIdx.x == 0) {
+        float* o = out + (size_t)b * 5;
+        o[0] = (s0 - (float)K) / (float)(K * (K - 1));
+        o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4;
+    }
+}
+
+// single block: the 11 scalar means of KyptDetector.forward (kypt_detector.py:155-165)
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ tail_part, int tail_blocks, int B, int T,
+                                                            int K, int N, int G, const float* __restrict__ heat_mean,
+                                                            const float* __restrict__ clip_part, const float* __restrict__ affinity,
+                                                            int chamfer, int use_traj, float* __restrict__ losses) {
+    __shared__ float sh[256];
+    const int F = B * T;
+    const float G3 = (float)G * (float)G * (float)G;
+    float rec = 0.f, vol = 0.f, sp = 0.f;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < tail_blocks; ++j) {
+            const float* p = tail_part + ((size_t)f * tail_blocks + j) * 3;
+            s0 += p[0]; s1 += p[1]; s2 += p[2];
+        }
+        rec += s0 / G3;
+        vol += s1 / s2;
+        float a = 0.f;
+        for (int k = 0; k < K; ++k) a += fabsf(heat_mean[(size_t)f * K + k]);
+        sp += a / (float)K;
+    }
+    rec = block_sum256(rec, sh); vol = block_sum256(vol, sh); sp = block_sum256(sp, sh);
+    float sep = 0.f, loc = 0.f, tim = 0.f, vel = 0.f, acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* c = clip_part + (size_t)b * 5;
+        sep += c[0]; loc += c[1]; tim += c[2]; vel += c[3]; acc += c[4];
+    }
+    sep = block_sum256(sep, sh); loc = block_sum256(loc, sh); tim = block_sum256(tim, sh);
+    vel = block_sum256(vel, sh); acc = block_sum256(acc, sh);
+    float spc = 0.f;
+    if (affinity) {
+        for (int i = threadIdx.x; i < K * K; i += 256) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n)
+                for (int m = 0; m < N; ++m)
+                    if (m != n) { float p = affinity[(size_t)n * K * K + i] * affinity[(size_t)m * K * K + i]; s += p * p; }
+            spc += s;
+        }
+    }
+    spc = block_sum256(spc, sh);
+    if (threadIdx.x == 0) {
+        const float KK = (float)(K * K);
+        losses[0] = rec / (float)F;
+        losses[1] = chamfer ? vol / (float)F : 0.f;
+        losses[2] = 0.f;
+        losses[3] = sep / (float)B;
+        losses[4] = sp / (float)F;
+        losses[5] = affinity ? loc / KK / (float)F : 0.f;
+        losses[6] = affinity ? tim / KK / (float)F : 0.f;
+        losses[7] = affinity ? spc / KK : 0.f;
+        losses[8] = 0.f;
+        losses[9] = (affinity && use_traj) ? (vel / (float)(B * (T - 1)) + acc / (float)(B * (T - 2))) / KK : 0.f;
+        losses[10] = 0.f;
+    }
+}
+
+// rows (n,k): softmax over K-1 logits, zero re-inserted on the diagonal
+__global__ void affinity_kernel(const float* __restrict__ params, int N, int K, float* __restrict__ out) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N * K) return;
+    const int k = row % K;
+    const float* p = params + (size_t)row * (K - 1);
+    float mx = -INFINITY;
+    for (int j = 0; j < K - 1; ++j) mx = fmaxf(mx, p[j]);
+    float s = 0.f;
+    for (int j = 0; j < K - 1; ++j) s += expf(p[j] - mx);
+    float* o = out + (size_t)row * K;
+    for (int j = 0; j < K; ++j) {
+        if (j == k) o[j] = 0.f;
+        else { int src = j < k ? j : j - 1; o[j] = expf(p[src] - mx) / s; }
+    }
+}
+
+}  // namespace
+
+int nm_launch_heatmap(const float* head, const float* clip_head, const float* prop, int F, int T, int K, int g,
+                      float* heatmaps, float* part, hipStream_t s) {
+    if (K % 4 || K > 32) { nm_set_error("heatmap: K=%d unsupported", K); return NM_ERR_ARG; }
+    size_t lds = (size_t)K * g * g * sizeof(float);
+    hipLaunchKernelGGL(heatmap_kernel, dim3(F, g), dim3(256), lds, s, head, clip_head, prop, T, K, g, heatmaps, part);
+    return nm_check_hip(hipGetLastError(), "heatmap launch");
+}
+
+int nm_launch_keypoints(const float* part, int F, int K, int g, float* keypoints, float* heat_mean, hipStream_t s) {
+    hipLaunchKernelGGL(keypoints_kernel, dim3(F), dim3(64), 0, s, part, K, g, keypoints, heat_mean);
+    return nm_check_hip(hipGetLastError(), "keypoints launch");
+}
+
+int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s) {
+    int total = FK * 3 * g;
+    hipLaunchKernelGGL(gauss_table_kernel, dim3((total + 255) / 256), dim3(256), 0, s, keypoints, FK, g, width, table);
+    return nm_check_hip(hipGetLastError(), "gauss_table launch");
+}
+
+int nm_launch_combined(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int F,
+                       int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s) {
+    size_t total = (size_t)F * g * g * g * (Cc / 4);
+    int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(combined_kernel, dim3(blocks), dim3(256), 0, s, table, keypoints, first_feature, ff_stride, F, T, K, Fd,
+                       g, Cc, out);
+    return nm_check_hip(hipGetLastError(), "combined launch");
+}
+
+int nm_tail_blocks(int G) { return (int)(((size_t)G * G * G + 255) / 256); }
+
+int nm_launch_decoder_tail(const TensorRef& x, const float* w14, const float* first_frames, int ff_stride_frames, int T,
+                           const float* target, const float* keypoints, int K, int G, float* recon, float* part,
+                           hipStream_t s) {
+    if (x.C % 4 || !x.scale) { nm_set_error("decoder_tail: needs a lazy GN input with C %% 4 == 0"); return NM_ERR_ARG; }
+    hipLaunchKernelGGL(decoder_tail_kernel, dim3(nm_tail_blocks(G), x.N), dim3(256), 0, s, x, w14, first_frames,
+                       ff_stride_frames, T, target, keypoints, K, G, recon, part);
+    return nm_check_hip(hipGetLastError(), "decoder_tail launch");
+}
+
+int nm_launch_clip_loss(const float* keypoints, const float* affinity, int B, int T, int K, int N, float sep_sigma,
+                        float* out, hipStream_t s) {
+    size_t lds = ((size_t)T * K * 3 + K * 3 + K * K) * sizeof(float);
+    hipLaunchKernelGGL(clip_loss_kernel, dim3(B), dim3(256), lds, s, keypoints, affinity, T, K, N, sep_sigma, out);
+    return nm_check_hip(hipGetLastError(), "clip_loss launch");
+}
+
+int nm_launch_loss_finalize(const float* tail_part, int tail_blocks, int B, int T, int K, int N, int G,
+                            const float* heat_mean, const float* clip_part, const float* affinity, int chamfer,
+                            int use_traj, float* losses, hipStream_t s) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, tail_part, tail_blocks, B, T, K, N, G, heat_mean,
+                       clip_part, affinity, chamfer, use_traj, losses);
+    return nm_check_hip(hipGetLastError(), "loss_finalize launch");
+}
+
+int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(affinity_kernel, dim3((N * K + 63) / 64), dim3(64), 0, s, params, N, K, out);
+    return nm_check_hip(hipGetLastError(), "affinity launch");
+}

@@ -1,0 +1,444 @@
+"""Drop-in nn.Module shells over the nm355 C ABI.
+
+The reference exposes no FFI; its boundary for this path is the nn.Module surface of
+``NeuralMarionette`` / ``KyptDetector`` / ``HSVRNNBVH`` (model/neural_marionette.py:6-103,
+model/kypt_detector.py:10-241, model/hsvrnn_bvh.py:10-286): attribute names, call
+signatures, returned dict keys and ``state_dict`` keys.  These shells keep that surface
+and route every computation to libnm355.so (HIP, gfx950).  There is no PyTorch or CPU
+fallback: parameters must live on a HIP device, and a missing library raises.
+
+Parameters are ordinary ``nn.Parameter`` objects stored under the reference's key names
+(checkpoints load unchanged); the engine re-uploads / re-packs them into the library's
+MFMA layouts whenever their version counters change (load_state_dict, optimizer step).
+
+Round-1 scope: inference / forward values.  The returned tensors carry no autograd
+graph (the training step is the next row of SURVEY §8(f)).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .skeleton import build_skeleton
+from .spec import DETECTOR_LOSS_KEYS, FEAT_DIM, FROZEN_KEYS, HotPathOptions, param_spec
+
+Priority = namedtuple("Priority", ["values", "indices"])   # what torch.topk returns in the reference
+
+
+class _Node(nn.Module):
+    """Container whose only job is to hold parameters / children under given names."""
+
+    def forward(self, *a, **k):  # pragma: no cover - containers are never called
+        raise RuntimeError("parameter container; the computation lives in libnm355.so")
+
+
+def _plant(root: nn.Module, dotted: str, shape, requires_grad: bool = True) -> None:
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    node.register_parameter(parts[-1], nn.Parameter(torch.zeros(*shape), requires_grad=requires_grad))
+
+
+class Engine:
+    """One nm_ctx + weight synchronisation for a NeuralMarionette instance."""
+
+    def __init__(self, opts: HotPathOptions, owner: nn.Module):
+        self.opts = opts
+        self.owner = owner          # module whose state_dict has the reference's 337 keys
+        self.ctx: Optional[_lib.Context] = None
+        self._stamp = None
+        self._named = None
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _device(self) -> torch.device:
+        p = next(self.owner.parameters())
+        if not p.is_cuda:
+            raise _lib.NmError("NeuralMarionette parameters are on the CPU: call .cuda() first — the HIP library "
+                               "is the only implementation of this path (no CPU fallback)")
+        return p.device
+
+    def ready(self) -> _lib.Context:
+        dev = self._device()
+        if self.ctx is None or self.ctx.device != dev:
+            o = self.opts
+            cfg = _lib.NmConfig(device=dev.index or 0, grid_size=o.grid_size, nkeypoints=o.nkeypoints,
+                                nlatent=o.nlatent_kypt, nhidden=o.nhidden_kypt, nneighbor=o.nneighbor,
+                                gaussian_sigma=o.gaussian_sigma, sep_sigma=o.sep_sigma,
+                                vol_fit_chamfer=int(o.vol_fit_type == "chamfer"),
+                                use_graph_traj=int(o.graph_traj_weight > 0))
+            self.ctx = _lib.Context(cfg)
+            self._stamp = None
+        self.ctx.bind_stream()
+        self._sync_weights()
+        return self.ctx
+
+    def _sync_weights(self) -> None:
+        if self._named is None:
+            self._named = list(self.owner.state_dict(keep_vars=True).items())   # Parameter objects persist
+        sd = self._named
+        stamp = tuple((t.data_ptr(), t._version) for _, t in sd)
+        if stamp == self._stamp:
+            return
+        names, keep = [], []
+        arr = (_lib.NmNamedTensor * len(sd))()
+        for i, (k, t) in enumerate(sd):
+            d = t.detach()
+            if d.dtype != torch.float32 or not d.is_contiguous():
+                d = d.float().contiguous()
+            keep.append(d)
+            names.append(k.encode())
+            arr[i].name = names[-1]
+            arr[i].data = d.data_ptr()
+            arr[i].numel = d.numel()
+        _lib.check(self.ctx.lib.nm_ctx_set_weights(self.ctx.handle, arr, len(sd)), "set_weights")
+        self._stamp = stamp
+
+    def call(self, fn: str, *args) -> None:
+        _lib.check(getattr(self.ctx.lib, fn)(self.ctx.handle, *args), fn)
+
+
+def _f32(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+# ==========================================================================================
+# detector
+# ==========================================================================================
+class KyptDetector(_Node):
+    """model/kypt_detector.py:10-241."""
+
+    def __init__(self, options, _engine: Optional[Engine] = None):
+        super().__init__()
+        o = HotPathOptions.from_any(options)
+        o.check_fast_path()
+        self._o = o
+        self.vol_fit_type = o.vol_fit_type
+        self.fixed_sigma = bool(o.fixed_sigma)
+        self.keypoints_graph = o.keypoints_graph
+        self.keypoints_detach = bool(o.keypoints_detach)
+        self.affinity_ver = o.affinity_ver
+        self.graph_loss_ver = o.graph_loss_ver
+        self.gaussian_sigma = o.gaussian_sigma
+        self.input_dim = o.input_dim
+        self.grid_size = o.grid_size
+        self.nkeypoints = o.nkeypoints
+        self.nneighbor = o.nneighbor
+        self.sigmas = [o.gaussian_sigma] * o.nkeypoints
+        self.sep_sigma = o.sep_sigma
+        self.affinity_anneal = o.affinity_anneal
+        self.affinity_start = False
+        for key, shape in param_spec(o):
+            if key.startswith("kypt_detector."):
+                _plant(self, key[len("kypt_detector."):], shape)
+        object.__setattr__(self, "_engine", _engine)
+
+    def _eng(self) -> Engine:
+        if self._engine is None:
+            raise _lib.NmError("KyptDetector must be created through NeuralMarionette (the library context "
+                               "needs the full 337-tensor state_dict)")
+        return self._engine
+
+    def anneal(self, nepoch):
+        """kypt_detector.py:71-78."""
+        if self.affinity_anneal > nepoch:
+            self.affinity_params.requires_grad = False
+        elif not self.affinity_start:
+            self.affinity_start = True
+            self.affinity_params.requires_grad = True
+
+    def forward(self, seq, Tcond=None):
+        """KyptDetector.forward (kypt_detector.py:81-169) -> the same dict of 16 entries."""
+        eng = self._eng()
+        ctx = eng.ready()
+        dev = ctx.device
+        B, T = int(seq.shape[0]), int(seq.shape[1])
+        G, K, g = self.grid_size, self.nkeypoints, self.grid_size // 4
+        if tuple(seq.shape[2:]) != (1, G, G, G):
+            raise ValueError(f"expected seq of shape (B,T,1,{G},{G},{G}), got {tuple(seq.shape)}")
+        vox = _f32(seq, dev)
+        kp = torch.empty(B, T, K, 4, device=dev)
+        hm = torch.empty(B, T, K, g, g, g, device=dev)
+        ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev)
+        recon = torch.empty(B, T, 1, G, G, G, device=dev)
+        aff = torch.empty(self.nneighbor, K, K, 1, device=dev) if self.affinity_start else None
+        losses = torch.empty(len(DETECTOR_LOSS_KEYS), device=dev)
+        eng.call("nm_detector_forward", _lib.ptr(vox), B, T, int(self.affinity_start), _lib.ptr(kp), _lib.ptr(hm),
+                 _lib.ptr(ff), _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses))
+        out = dict(recon=recon, keypoints=kp, heatmaps=hm, affinity=aff)
+        for i, name in enumerate(DETECTOR_LOSS_KEYS):
+            out[name] = losses[i]
+        out["first_feature"] = ff
+        return out
+
+    def get_affinity(self):
+        """kypt_detector.py:171-211 (ver 3) -> (N,K,K,1)."""
+        eng = self._eng()
+        ctx = eng.ready()
+        aff = torch.empty(self.nneighbor, self.nkeypoints, self.nkeypoints, 1, device=ctx.device)
+        eng.call("nm_get_affinity", _lib.ptr(aff))
+        return aff
+
+    def decode_from_dyna(self, keypoints, first_feature, first_frame):
+        """kypt_detector.py:213-241 -> {'gen': (B,Tgen,1,G,G,G)}."""
+        eng = self._eng()
+        ctx = eng.ready()
+        dev = ctx.device
+        B, Tg = int(keypoints.shape[0]), int(keypoints.shape[1])
+        G = self.grid_size
+        gen = torch.empty(B, Tg, 1, G, G, G, device=dev)
+        kp, ff, fr = _f32(keypoints, dev), _f32(first_feature, dev), _f32(first_frame, dev)
+        eng.call("nm_decode_from_keypoints", _lib.ptr(kp), _lib.ptr(ff), _lib.ptr(fr), B, Tg, _lib.ptr(gen))
+        return dict(gen=gen)
+
+
+# ==========================================================================================
+# VRNN
+# ==========================================================================================
+class _Mlp(_Node):
+    """nn.Sequential(Linear, LeakyReLU, Linear[, Tanh]) stand-in (hsvrnn_bvh.py:29-54): parameters under '0' / '2'."""
+
+    def __init__(self, which: int, nout: int, owner: "HSVRNNBVH"):
+        super().__init__()
+        self._which, self._nout = which, nout
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, x):
+        eng = self._owner._eng()
+        ctx = eng.ready()
+        xx = _f32(x, ctx.device)
+        lead = xx.shape[:-1]
+        xx = xx.reshape(-1, xx.shape[-1])
+        y = torch.empty(xx.shape[0], self._nout, device=ctx.device)
+        eng.call("nm_vrnn_mlp", self._which, _lib.ptr(xx), int(xx.shape[0]), _lib.ptr(y))
+        return y.reshape(*lead, self._nout)
+
+
+class _Gru(_Node):
+    """nn.GRUCell stand-in (hsvrnn_bvh.py:57)."""
+
+    def __init__(self, owner: "HSVRNNBVH"):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, x, h):
+        eng = self._owner._eng()
+        ctx = eng.ready()
+        xx, hh = _f32(x, ctx.device), _f32(h, ctx.device)
+        out = torch.empty_like(hh)
+        eng.call("nm_vrnn_gru", _lib.ptr(xx), _lib.ptr(hh), int(xx.shape[0]), _lib.ptr(out))
+        return out
+
+
+class HSVRNNBVH(_Node):
+    """model/hsvrnn_bvh.py:10-286."""
+
+    def __init__(self, options, _engine: Optional[Engine] = None):
+        super().__init__()
+        o = HotPathOptions.from_any(options)
+        o.check_fast_path()
+        self._o = o
+        self.nkeypoints = o.nkeypoints
+        self.nlatent_kypt = o.nlatent_kypt
+        self.nhidden_kypt = o.nhidden_kypt
+        self.input_dim = o.input_dim
+        self.transition_type = o.transition_type
+        self.state_mode = o.state_mode
+        self.action_mode = o.action_mode
+        K, Z = o.nkeypoints, o.nlatent_kypt
+        self.add_module("extract_post_dist", _Mlp(0, 2 * Z, self))
+        self.add_module("extract_prior_dist", _Mlp(1, 2 * Z, self))
+        self.add_module("root_intensity_decoder", _Mlp(2, 3 + K, self))
+        self.add_module("joint_matrix_decoder", _Mlp(3, 6 * K, self))
+        self.add_module("kypt_rnn_cell", _Gru(self))
+        for key, shape in param_spec(o):
+            if key.startswith("dyna_module."):
+                _plant(self, key[len("dyna_module."):], shape, requires_grad=key not in FROZEN_KEYS)
+        self.A, self.priority, self.parents = None, None, None
+        object.__setattr__(self, "_engine", _engine)
+        object.__setattr__(self, "_tree_key", None)
+
+    def _eng(self) -> Engine:
+        if self._engine is None:
+            raise _lib.NmError("HSVRNNBVH must be created through NeuralMarionette (the library context needs "
+                               "the full 337-tensor state_dict)")
+        return self._engine
+
+    # -- skeleton ---------------------------------------------------------------------------
+    def _ensure_tree(self, affinity, ctx) -> None:
+        """First encode() builds and caches the tree (hsvrnn_bvh.py:75-79); later calls reuse it."""
+        if self.A is None:
+            if affinity is None:
+                raise _lib.NmError("the skeleton has not been built yet: call encode() (or pass an affinity) first")
+            sk = build_skeleton(affinity.detach().float().cpu().numpy())
+            dev = ctx.device
+            self.A = torch.from_numpy(sk.A).float().to(dev)
+            self.priority = Priority(values=torch.from_numpy(sk.dist).to(dev), indices=torch.from_numpy(sk.order).to(dev))
+            self.parents = torch.from_numpy(sk.parents).to(dev)
+        key = (self.parents.data_ptr(), self.priority.indices.data_ptr(), id(ctx))
+        if key != self._tree_key:
+            par = self.parents.detach().cpu().numpy().astype(np.int32)
+            order = self.priority.indices.detach().cpu().numpy().astype(np.int32)
+            self._eng().call("nm_vrnn_set_tree", par.ctypes.data_as(_lib.c_int32_p), order.ctypes.data_as(_lib.c_int32_p))
+            object.__setattr__(self, "_tree_key", key)
+
+    def _eps(self, n, shape, dev, eps):
+        if eps is not None:
+            return _f32(eps, dev)
+        # the reference draws one rsample per step from the device generator (hsvrnn_bvh.py:107,216)
+        return torch.stack([torch.randn(*shape, device=dev) for _ in range(n)], dim=0) if n else torch.empty(0, *shape, device=dev)
+
+    # -- public surface -----------------------------------------------------------------------
+    def encode(self, keypoints, affinity, SAMPLE_NUM=10, eps=None):
+        """hsvrnn_bvh.py:67-156.  ``eps`` (T,S,B,Z) injects the standard-normal draws."""
+        eng = self._eng()
+        ctx = eng.ready()
+        dev = ctx.device
+        self._ensure_tree(affinity, ctx)
+        B, T, K, _ = keypoints.shape
+        Z, H, S = self.nlatent_kypt, self.nhidden_kypt, int(SAMPLE_NUM)
+        kp = _f32(keypoints, dev)
+        e = self._eps(T, (S, B, Z), dev, eps)
+        rec = torch.empty(B, T, K, 4, device=dev)
+        R = torch.empty(B, T, K, 3, 3, device=dev)
+        z = torch.empty(B, T, Z, device=dev)
+        h = torch.empty(B, T + 1, H, device=dev)
+        sc = torch.empty(2, device=dev)
+        best = torch.empty(B, T, device=dev, dtype=torch.int32)
+        eng.call("nm_vrnn_encode", _lib.ptr(kp), _lib.ptr(e), B, T, S, _lib.ptr(rec), _lib.ptr(R), _lib.ptr(z),
+                 _lib.ptr(h), _lib.ptr(sc), _lib.ptr(best))
+        return dict(kypt_recon=rec, R=R, z_kypts=z, h_kypts=h, kl_kypt=sc[0], kypt_recon_loss=sc[1],
+                    gae_recon_loss=torch.tensor(0).to(dev), topo_recon_loss=torch.tensor(0).to(dev),
+                    best_idx=best)
+
+    def generate(self, keypoints_cond, affinity=None, Ttot=10, Tcond=3, SAMPLE_NUM=10, eps_post=None, eps_prior=None):
+        """hsvrnn_bvh.py:158-234."""
+        eng = self._eng()
+        ctx = eng.ready()
+        dev = ctx.device
+        self._ensure_tree(affinity, ctx)
+        B, Tc_in, K, _ = keypoints_cond.shape
+        Z, S = self.nlatent_kypt, int(SAMPLE_NUM)
+        if Tc_in != Tcond:
+            raise ValueError("keypoints_cond must hold exactly Tcond frames ('dl' transition)")
+        kp = _f32(keypoints_cond, dev)
+        e_post = self._eps(Tcond, (S, B, Z), dev, eps_post)
+        e_prior = self._eps(Ttot - Tcond, (B, Z), dev, eps_prior)
+        cond = torch.empty(B, Tcond, K, 4, device=dev)
+        gen = torch.empty(B, Ttot - Tcond, K, 4, device=dev)
+        eng.call("nm_vrnn_generate", _lib.ptr(kp), _lib.ptr(e_post), _lib.ptr(e_prior) if Ttot > Tcond else None,
+                 B, Tcond, Ttot, S, _lib.ptr(cond), _lib.ptr(gen) if Ttot > Tcond else None, None)
+        return dict(keypoints_cond=cond, keypoints_gen=gen)
+
+    def get_offset(self, keypoints):
+        """hsvrnn_bvh.py:236-253 -> (B,K,3,1), detached."""
+        eng = self._eng()
+        ctx = eng.ready()
+        self._ensure_tree(None, ctx)
+        B, T, K, _ = keypoints.shape
+        kp = _f32(keypoints, ctx.device)
+        off = torch.empty(B, K, 3, device=ctx.device)
+        eng.call("nm_vrnn_offsets", _lib.ptr(kp), B, T, _lib.ptr(off))
+        return off[..., None]
+
+    def extract_kypt_from_latent_and_state(self, decoder_input, offset):
+        """hsvrnn_bvh.py:255-286: (B,H+Z), (B,K,3,1) -> (B,K*4), (B,K,3,3)."""
+        eng = self._eng()
+        ctx = eng.ready()
+        self._ensure_tree(None, ctx)
+        x = _f32(decoder_input, ctx.device)
+        off = _f32(offset.reshape(offset.shape[0], self.nkeypoints, 3), ctx.device)
+        B = int(x.shape[0])
+        kp = torch.empty(B, self.nkeypoints * 4, device=ctx.device)
+        R = torch.empty(B, self.nkeypoints, 3, 3, device=ctx.device)
+        eng.call("nm_vrnn_fk", _lib.ptr(x), _lib.ptr(off), B, _lib.ptr(kp), _lib.ptr(R))
+        return kp, R
+
+    def step(self, h, offset, eps, keypoints_obs=None, SAMPLE_NUM=10):
+        """One fused VRNN step for hand-rolled rollouts (vis_generation.py:97-127 of the reference does the
+        same with five sub-module calls): posterior best-of-S when ``keypoints_obs`` is given, else prior.
+        Returns (keypoints_flat (B,K*4), z (B,Z), h_next (B,H))."""
+        eng = self._eng()
+        ctx = eng.ready()
+        self._ensure_tree(None, ctx)
+        dev = ctx.device
+        hh = _f32(h, dev)
+        B = int(hh.shape[0])
+        off = _f32(offset.reshape(B, self.nkeypoints, 3), dev)
+        e = _f32(eps, dev)
+        obs = None if keypoints_obs is None else _f32(keypoints_obs.reshape(B, -1), dev)
+        kp = torch.empty(B, self.nkeypoints * 4, device=dev)
+        z = torch.empty(B, self.nlatent_kypt, device=dev)
+        hn = torch.empty_like(hh)
+        eng.call("nm_vrnn_step", int(obs is not None), _lib.ptr(hh), _lib.ptr(obs), _lib.ptr(off), _lib.ptr(e), B,
+                 int(SAMPLE_NUM), _lib.ptr(kp), _lib.ptr(z), _lib.ptr(hn))
+        return kp, z, hn
+
+
+# ==========================================================================================
+# top level
+# ==========================================================================================
+class NeuralMarionette(nn.Module):
+    """model/neural_marionette.py:6-103."""
+
+    def __init__(self, options=None):
+        super().__init__()
+        self.options = options
+        o = HotPathOptions.from_any(options)
+        o.check_fast_path()
+        engine = Engine(o, self)
+        object.__setattr__(self, "_engine", engine)
+        self.kypt_detector = KyptDetector(o, _engine=engine)
+        self.Tcond = o.Tcond
+        self.dyna_module = HSVRNNBVH(o, _engine=engine)
+        self.current_actives = {"detector": True, "learner": True}
+        self.transition_type = o.transition_type
+
+    def anneal(self, nepoch, nbatch=None):
+        if nbatch is None:
+            self.kypt_detector.anneal(nepoch)
+
+    def control_active(self, module_actives):
+        """neural_marionette.py:22-32."""
+        for name in self.current_actives:
+            if self.current_actives[name] != module_actives[name]:
+                module = self.kypt_detector if name == "detector" else self.dyna_module
+                for p in module.parameters():
+                    p.requires_grad = module_actives[name]
+                self.current_actives[name] = module_actives[name]
+
+    def forward(self, vox_seq, module_actives=None, eps=None):
+        """neural_marionette.py:34-56.  ``eps`` optionally injects the VRNN noise (T,S,B,Z)."""
+        log: Dict[str, torch.Tensor] = dict()
+        keypoints = affinity = None
+        if module_actives["detector"] or module_actives["learner"]:
+            det = self.kypt_detector(vox_seq)
+            keypoints, affinity = det["keypoints"], det.get("affinity")
+            log.update(det)
+        if module_actives["learner"]:
+            log.update(self.dyna_module.encode(keypoints.detach(), affinity.detach(), eps=eps))
+        return log
+
+    def generate(self, vox_seq, module_actives=None, eps_post=None, eps_prior=None):
+        """neural_marionette.py:58-103 ('dl' transition)."""
+        B, T = vox_seq.shape[:2]
+        assert self.Tcond < T
+        log = dict()
+        if module_actives["learner"]:
+            det = self.kypt_detector(vox_seq[:, :self.Tcond].contiguous())
+            keypoints = det["keypoints"]
+            dyn = self.dyna_module.generate(keypoints, det.get("affinity"), Ttot=T, Tcond=self.Tcond,
+                                            eps_post=eps_post, eps_prior=eps_prior)
+            gen = self.kypt_detector.decode_from_dyna(dyn["keypoints_gen"], det["first_feature"], vox_seq[:, 0])["gen"]
+            log.update(gen=torch.cat([det["recon"][:, :self.Tcond], gen], dim=1),
+                       keypoints=torch.cat([keypoints[:, :self.Tcond], dyn["keypoints_gen"]], dim=1),
+                       A_hats=None)
+        return log

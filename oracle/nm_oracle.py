@@ -337,7 +337,7 @@ def _adjacency_lists(K: int, A: np.ndarray, W: Optional[np.ndarray]):
     adj: List[Dict[int, float]] = [dict() for _ in range(K)]
     rows, cols = np.where(A)
     for u, v in zip(rows.tolist(), cols.tolist()):
-        w = 1.0 if W is None else float(W[u, v])
+        w = 1 if W is None else W[u, v]      # int for the unweighted pass, np.float32 for the nudged pass
         adj[u][v] = w
         adj[v][u] = w
     return adj
@@ -345,13 +345,15 @@ def _adjacency_lists(K: int, A: np.ndarray, W: Optional[np.ndarray]):
 
 def _all_pairs(K: int, adj, big: float) -> np.ndarray:
     """Single-source Dijkstra from every node with a (dist, counter) heap; distances
-    accumulate from the source outward, unreachable pairs keep ``big``
+    accumulate from the source outward in the dtype of the edge weights (python int for
+    the unweighted passes, np.float32 for the tie-nudged passes — the reference hands
+    np.float32 weights to its graph library), unreachable pairs keep ``big``
     (dyna_utils.py:21-34)."""
     D = np.ones((K, K)) * big
     for s in range(K):
         dist: Dict[int, float] = {}
-        seen = {s: 0.0}
-        heap = [(0.0, 0, s)]
+        seen = {s: 0}
+        heap = [(0, 0, s)]
         cnt = 1
         while heap:
             d, _, v = heapq.heappop(heap)

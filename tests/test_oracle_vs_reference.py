@@ -1,0 +1,87 @@
+"""Pins the oracle directly against the reference implementation, imported from
+/root/reference.  That tree exists only in the build container, so these tests skip
+on the GPU box (the committed fixtures of tests/golden/ carry the same evidence there)."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "model")), reason="reference tree not present")
+
+from neural_marionette_amd import synth
+from neural_marionette_amd.spec import HotPathOptions, DETECTOR_LOSS_KEYS, param_spec
+from oracle import nm_oracle as O
+
+
+@pytest.fixture(scope="module")
+def ref_modules():
+    sys.path.insert(0, REF)
+    try:
+        from model.neural_marionette import NeuralMarionette
+        from utils.dyna_utils import process_affinity_glob
+        yield NeuralMarionette, process_affinity_glob
+    finally:
+        sys.path.remove(REF)
+
+
+def _opt(G):
+    opt = pickle.load(open(os.path.join(REF, "pretrained/aist/opt.pickle"), "rb"))
+    opt.grid_size = G
+    return opt
+
+
+def test_state_dict_layout(ref_modules):
+    NeuralMarionette, _ = ref_modules
+    net = NeuralMarionette(_opt(64))
+    ref = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert ref == [(k, tuple(s)) for k, s in param_spec(HotPathOptions())]
+
+
+def test_trees_many_seeds(ref_modules):
+    _, process_affinity_glob = ref_modules
+    rng = np.random.default_rng(7)
+    for trial in range(80):
+        p = rng.standard_normal((2, 24, 23)) * [0.1, 1.0, 4.0][trial % 3]
+        if trial % 5 == 0:
+            p = np.round(p * 2) / 2
+        aff = O.affinity_v3(torch.from_numpy(p).float())
+        A, pri, par = process_affinity_glob(aff)
+        A2, order, vals, parents = O.build_tree(aff)
+        assert np.array_equal(par.numpy(), parents), trial
+        assert np.array_equal(A.numpy(), A2), trial
+        assert np.array_equal(pri.values.numpy(), vals), trial
+        assert int(pri.indices[0]) == int(order[0])
+
+
+@pytest.mark.parametrize("variant,clip", [("peaky", "figure"), ("default", "bernoulli")])
+def test_full_forward_32(ref_modules, variant, clip):
+    NeuralMarionette, _ = ref_modules
+    import torch.distributions.normal as tdn
+    G, B, T = 32, 2, 5
+    opt = _opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=17, variant=variant)
+    net = NeuralMarionette(opt).eval()
+    net.load_state_dict(sd)
+    net.anneal(1)
+    vox = synth.figure_clip(B, T, G, seed=2) if clip == "figure" else synth.bernoulli_clip(B, T, G, seed=2)
+    eps = synth.make_eps((T, 10, B, 128), seed=3)
+    it = iter(eps)
+    old = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: next(it).clone()
+    try:
+        with torch.no_grad():
+            ref = net(vox, {"detector": True, "learner": True})
+    finally:
+        tdn._standard_normal = old
+    with torch.no_grad():
+        mine = O.nm_forward(sd, o, vox, eps)
+    for k in ("recon", "keypoints", "heatmaps", "affinity", "first_feature", "kypt_recon", "R", "z_kypts", "h_kypts"):
+        assert torch.equal(ref[k], mine[k]), k
+    for k in DETECTOR_LOSS_KEYS + ("kl_kypt", "kypt_recon_loss"):
+        assert float(ref[k]) == float(mine[k]), k
+    assert np.array_equal(net.dyna_module.parents.numpy(), mine["parents"])
