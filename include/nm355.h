@@ -139,12 +139,20 @@ int nm_vrnn_fk(nm_ctx* ctx, const float* dec_in, const float* offset, int32_t B,
 /* Conv3d.  in [N][D][H][W][Cin8] (Cin8 = Cin rounded up to 8, extra channels zero), weight in
  * torch OIDHW layout, out [N][OD][OH][OW][Cout].  in_scale/in_shift [N][Cin8] or NULL apply
  * y = lrelu_slope(x*scale+shift) to the input first.  If gn_groups > 0, also returns the
- * following GroupNorm's per-(n,c) scale/shift (gn_gamma/gn_beta [Cout]) in gn_scale/gn_shift. */
+ * following GroupNorm's per-(n,c) scale/shift (gn_gamma/gn_beta [Cout]) in gn_scale/gn_shift.
+ * up2 != 0: `in` is at half resolution and its trilinear x2 upsampling (align_corners=False) is
+ * what gets convolved (nn.Upsample fused into the conv, kypt_detector.py:427-429,441-444). */
 int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                  const float* in_scale, const float* in_shift, float in_slope,
                  const float* weight, const float* bias, int32_t Cout, int32_t ks, int32_t stride,
                  int32_t pad, float* out, int32_t gn_groups, const float* gn_gamma,
-                 const float* gn_beta, float* gn_scale, float* gn_shift);
+                 const float* gn_beta, float* gn_scale, float* gn_shift, int32_t up2);
+/* First layer of a feature net (kypt_detector.py:265): Conv3d(1+3 -> Cout, k5, p2) on
+ * cat[occ, coord ramps] evaluated as conv(occ) + weight-only constant field.  occ [N][G][G][G],
+ * weight (Cout,4,5,5,5) OIDHW, out [N][G][G][G][Cout] (+ following GroupNorm as in nm_op_conv3d). */
+int nm_op_conv5_occ(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, const float* weight,
+                    const float* bias, int32_t Cout, float* out, int32_t gn_groups,
+                    const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift);
 int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                  const float* weight_iodhw, const float* bias, int32_t Cout, int32_t outpad, float* out,
                  int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale,
@@ -159,7 +167,8 @@ int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, i
 /* ---- live kernel timing for bench.py's roofline leg -------------------------------------------
  * While enabled, every conv launch on the ctx stream is bracketed by a HIP event pair.
  * nm_prof_read sums duration and ALGORITHMIC flops (2*voxels*Cout*Cin*k^3, un-padded) of one
- * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2)). */
+ * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2); 4 = the
+ * first-layer occupancy kernel conv_k5occ_kernel, credited with the reference's dense 4-channel k5 work). */
 int nm_prof_enable(nm_ctx* ctx, int32_t on);
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches);
 const char* nm_prof_kernel_name(int32_t variant);

@@ -57,7 +57,8 @@ SIGNATURES = {
     "nm_vrnn_gru": (C.c_int, [C.c_void_p, _P, _P, _I, _P]),
     "nm_vrnn_fk": (C.c_int, [C.c_void_p, _P, _P, _I, _P, _P]),
     "nm_op_conv3d": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P,
-                                _I, _P, _P, _P, _P]),
+                                _I, _P, _P, _P, _P, _I]),
+    "nm_op_conv5_occ": (C.c_int, [C.c_void_p, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "nm_op_convT2": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     "nm_op_apply2": (C.c_int, [C.c_void_p, _P, _P, _P, _F, _P, _P, _P, _F, _I, _I, _I, _P]),
     "nm_op_upsample2": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _I, _P]),

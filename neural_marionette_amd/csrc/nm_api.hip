@@ -103,7 +103,7 @@ int nm_prof_enable(nm_ctx* ctx, int32_t on) {
 }
 
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) {
-    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 3) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
+    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 4) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
     long long n = 0;
     int rc = nm_conv_prof_collect(variant, ms_total, flops_total, &n);
     if (rc) { nm_set_error("prof_read: event query failed"); return rc; }
@@ -112,8 +112,9 @@ int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_t
 }
 
 const char* nm_prof_kernel_name(int32_t variant) {
-    static const char* names[4] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>"};
-    return (variant >= 0 && variant < 4) ? names[variant] : "";
+    static const char* names[5] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
+                                   "conv_k5occ_kernel"};
+    return (variant >= 0 && variant < 5) ? names[variant] : "";
 }
 
 int nm_host_linspace(int32_t n, float* out) {
@@ -137,11 +138,13 @@ static int finish_gn(nm_ctx* ctx, const float* part, int N, int nblk, int C, int
 int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                  const float* in_scale, const float* in_shift, float in_slope, const float* weight,
                  const float* bias, int32_t Cout, int32_t ks, int32_t stride, int32_t pad, float* out,
-                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) {
+                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift,
+                 int32_t up2) {
     if (!ctx || !in || !weight || !out) { nm_set_error("op_conv3d: null argument"); return NM_ERR_ARG; }
     const int Cin_pad = (Cin + 7) & ~7, Co_pad = (Cout + 31) & ~31;
-    ConvGeom g; g.ks = ks; g.stride = stride; g.pad = pad;
-    g.OD = (D + 2 * pad - ks) / stride + 1; g.OH = (H + 2 * pad - ks) / stride + 1; g.OW = (W + 2 * pad - ks) / stride + 1;
+    const int us = up2 ? 2 : 1;
+    ConvGeom g; g.ks = ks; g.stride = stride; g.pad = pad; g.up2 = up2 ? 1 : 0;
+    g.OD = (us * D + 2 * pad - ks) / stride + 1; g.OH = (us * H + 2 * pad - ks) / stride + 1; g.OW = (us * W + 2 * pad - ks) / stride + 1;
     g.Cout = Cout; g.Co_pad = Co_pad;
     const int nblk = nm_conv_blocks_per_frame(g);
     const size_t wfl = nm_packed_weight_floats(ks, Cin_pad, Co_pad);
@@ -158,6 +161,31 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     if (rc) return rc;
     if (gn_groups > 0)
         rc = finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)g.OD * g.OH * g.OW * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
+    return rc;
+}
+
+int nm_op_conv5_occ(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, const float* weight, const float* bias, int32_t Cout,
+                    float* out, int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) {
+    if (!ctx || !occ || !weight || !bias || !out) { nm_set_error("op_conv5_occ: null argument"); return NM_ERR_ARG; }
+    const int Co_pad = (Cout + 31) & ~31;
+    const size_t G3 = (size_t)G * G * G;
+    const int nblk = nm_occ_blocks_per_frame(G);
+    const size_t fl = nm_packed_weight_floats(5, 8, Co_pad) + (size_t)128 * Co_pad + (size_t)Cout * 125 + G3 * (9 + Cout) + (size_t)N * nblk * Cout * 2;
+    int rc = nm_ctx_reserve(ctx, fl * sizeof(float) + 16384);
+    if (rc) return rc;
+    ctx->ws.release(0);
+    float* wfull = ctx->ws.f(nm_packed_weight_floats(5, 8, Co_pad)); float* wocc = ctx->ws.f((size_t)128 * Co_pad);
+    float* tmp = ctx->ws.f((size_t)Cout * 125); float* zero = ctx->ws.f(G3); float* packed_in = ctx->ws.f(G3 * 8);
+    float* field = ctx->ws.f(G3 * Cout); float* part = ctx->ws.f((size_t)N * nblk * Cout * 2);
+    hipStream_t s = ctx->stream;
+    if ((rc = nm_launch_pack_conv_weight(weight, Cout, 4, 5, wfull, 8, Co_pad, s))) return rc;
+    if ((rc = nm_launch_pack_occ_weight(weight, Cout, tmp, wocc, Co_pad, s))) return rc;
+    if ((rc = nm_check_hip(hipMemsetAsync(zero, 0, G3 * sizeof(float), s), "memset"))) return rc;
+    if ((rc = nm_launch_pack_input(zero, 1, 1, G, 0, packed_in, s))) return rc;
+    ConvGeom g; g.ks = 5; g.stride = 1; g.pad = 2; g.OD = g.OH = g.OW = G; g.Cout = Cout; g.Co_pad = Co_pad;
+    if ((rc = nm_launch_conv(make_ref(packed_in, nullptr, nullptr, 1.0f, 1, G, G, G, 8), wfull, bias, field, g, nullptr, s, 4))) return rc;
+    if ((rc = nm_launch_conv_k5occ(occ, N, G, wocc, field, out, Cout, Co_pad, gn_groups > 0 ? part : nullptr, s))) return rc;
+    if (gn_groups > 0) rc = finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)G3 * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
     return rc;
 }
 

@@ -35,6 +35,7 @@ struct ConvGeom {
     int OD, OH, OW;
     int Cout;      // real output channels (multiple of 8, or 24 for the heat-map heads)
     int Co_pad;    // packed weight columns (multiple of 32)
+    int up2 = 0;   // the input tensor is stored at half resolution; its trilinear x2 upsampling is convolved
 };
 
 void nm_set_error(const char* fmt, ...);
@@ -50,6 +51,11 @@ int nm_conv_blocks_per_frame(const ConvGeom& g);
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
                    const ConvGeom& g, float* part /*[N][nblk][Cout][2] or null*/, hipStream_t s,
                    int cin_real = 0 /* un-padded Cin, for the profiler's FLOP count */);
+// first layer: occupancy channel as a taps-as-K GEMM + weight-only constant field (see nm_conv.hip)
+int nm_occ_blocks_per_frame(int G);
+int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s);
+int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
+                         int Co_pad, float* part, hipStream_t s);
 void nm_conv_prof_enable(int on);
 int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, long long* launches);
 void nm_conv_prof_reset();
@@ -67,6 +73,7 @@ int nm_launch_convT2(const TensorRef& in, const float* w_iodhw, const float* bia
 int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s);
 int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t, float* out,
                          hipStream_t s);
+int nm_launch_mean_t(const float* vox, int B, int T, size_t G3, float* out, hipStream_t s);
 int nm_launch_cl_to_ncdhw(const TensorRef& in, float* out, hipStream_t s);
 // in holds N frames picked with a stride (frame n of the output = frame n*frame_stride of in.p)
 int nm_launch_cl_to_ncdhw_strided(const TensorRef& in, int frame_stride, float* out, hipStream_t s);

@@ -37,11 +37,42 @@ struct ConvParams {
     int nbz, nby, nbx;            // bricks per frame
     int KC;                       // channels per LDS chunk (8 or 16)
     int cin_real;                 // un-padded input channels (profiling only)
+    int up2;                      // input is stored at half resolution: stage its trilinear x2 upsampling
     int HZ, HY, HX, HV, HVp;      // halo dims, voxels, padded plane stride (HVp % 8 == 2)
+    int CVp;                      // up2: plane stride of the coarse LDS tile
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+
+// activated input sample: x * scale + shift, LeakyReLU (the producer's pending GroupNorm)
+__device__ __forceinline__ f32x4 load_act(const ConvParams& p, int n, int z, int y, int x, int c) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.in + ((((size_t)n * p.ID + z) * p.IH + y) * p.IW + x) * p.Cin + c);
+    if (p.in_scale) {
+        f32x4 sc = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)n * p.Cin + c);
+        f32x4 sh = *reinterpret_cast<const f32x4*>(p.in_shift + (size_t)n * p.Cin + c);
+        v = v * sc + sh;
+    }
+    if (p.in_slope != 1.0f) {
+        v[0] = lrelu(v[0], p.in_slope); v[1] = lrelu(v[1], p.in_slope);
+        v[2] = lrelu(v[2], p.in_slope); v[3] = lrelu(v[3], p.in_slope);
+    }
+    return v;
+}
+
+__device__ __forceinline__ int up_lo(int o) {          // first source index of output index o (o >= 0)
+    float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+    return src < 0.f ? 0 : (int)src;
+}
+
+// source index / weight of output index o for scale-2 linear interpolation, align_corners=False
+__device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1) {
+    float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    i1 = i0 + (i0 < I - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
 
 // One LDS-resident channel chunk (NKQ octets of channels): walk the taps, B operand
 // prefetched one tap ahead, 4*NKQ*MT*NT MFMAs per tap.
@@ -83,6 +114,145 @@ __device__ __forceinline__ void mfma_chunk(const ConvParams& p, const f32x4* lds
             for (int nt = 0; nt < NT; ++nt) bcur[kq][nt] = bnxt[kq][nt];
         if (++tx == p.ks) { tx = 0; if (++ty == p.ks) { ty = 0; ++tz; } }
     }
+}
+
+// bias (or a per-voxel constant field), coalesced channels-last store, GroupNorm partials
+struct EpiArgs {
+    float* out; float* part; const float* bias; const float* field;
+    int OD, OH, OW, Cout, bz_l2, by_l2, bx_l2;
+};
+
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue(const EpiArgs& p, float* red /*[4][NT*32][2] LDS*/, f32x16 (&acc)[MT][NT], int n, int br,
+                                         int nblk, int oz0, int oy0, int ox0, int co_base) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int BXm = (1 << p.bx_l2) - 1, BYm = (1 << p.by_l2) - 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co_base + nt * 32 + l31;
+        const bool cv = co < p.Cout;
+        const float bv = (cv && p.bias) ? p.bias[co] : 0.f;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                int m = (wave * MT + mt) * 32 + row;
+                int x = m & BXm, y = (m >> p.bx_l2) & BYm, z = m >> (p.bx_l2 + p.by_l2);
+                int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
+                if (cv && oz < p.OD && oy < p.OH && ox < p.OW) {
+                    const size_t vo = (((size_t)oz * p.OH + oy) * p.OW + ox) * p.Cout + co;
+                    float v = acc[mt][nt][r] + (p.field ? p.field[vo] : bv);
+                    p.out[(size_t)n * p.OD * p.OH * p.OW * p.Cout + vo] = v;
+                    s += v; ss += v * v;
+                }
+            }
+        }
+        if (p.part) {
+            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+            if (h == 0) { red[(wave * NT * 32 + nt * 32 + l31) * 2] = s; red[(wave * NT * 32 + nt * 32 + l31) * 2 + 1] = ss; }
+        }
+    }
+    if (p.part) {
+        __syncthreads();
+        if (tid < NT * 32) {
+            int co = co_base + tid;
+            if (co < p.Cout) {
+                float s = 0.f, ss = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { s += red[(wv * NT * 32 + tid) * 2]; ss += red[(wv * NT * 32 + tid) * 2 + 1]; }
+                float* dst = p.part + (((size_t)n * nblk + br) * p.Cout + co) * 2;
+                dst[0] = s; dst[1] = ss;
+            }
+        }
+    }
+}
+
+// ---- first layer, occupancy channel only ------------------------------------------------------------------------
+// conv5(cat[occ, x1, x2, x3]) = conv5_ch0(occ) + field, field = conv5(cat[0, x1, x2, x3]) + bias depends on the
+// weights only (the coordinate ramps and their zero padding are the same for every frame:
+// kypt_detector_utils.py:19-26), so per frame only the occupancy channel is convolved: an implicit GEMM
+// whose K dimension is the 125 taps (padded to 128), M a 4x8x8 brick, operands from a 8x12x12 fp32 halo tile.
+struct OccParams {
+    const float* occ;      // [N][G][G][G]
+    const float* w;        // packed [32 tap-quads][Co_pad][4]
+    const float* field;    // [G][G][G][Cout]
+    float* out; float* part;
+    int N, G, Cout, Co_pad;
+};
+
+__host__ __device__ constexpr int occ_tap_off(int t) { return t < 125 ? ((t / 25) * 12 + (t / 5) % 5) * 12 + t % 5 : 0; }
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_k5occ_kernel(OccParams p) {
+    __shared__ float tile[8 * 12 * 12 + 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nb = p.G >> 3, nbz = p.G >> 2;
+    const int nblk = nbz * nb * nb;
+    const int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
+    const int oz0 = (br / (nb * nb)) << 2, oy0 = ((br / nb) % nb) << 3, ox0 = (br % nb) << 3;
+    const int co_base = blockIdx.y * (NT * 32);
+    const float* src = p.occ + (size_t)n * p.G * p.G * p.G;
+    for (int i = tid; i < 8 * 12 * 12; i += 256) {
+        int hx = i % 12, hy = (i / 12) % 12, hz = i / 144;
+        int gz = oz0 - 2 + hz, gy = oy0 - 2 + hy, gx = ox0 - 2 + hx;
+        float v = 0.f;
+        if ((unsigned)gz < (unsigned)p.G && (unsigned)gy < (unsigned)p.G && (unsigned)gx < (unsigned)p.G)
+            v = src[((size_t)gz * p.G + gy) * p.G + gx];
+        tile[i] = v;
+    }
+    int arow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int m = (wave * 2 + mt) * 32 + l31;
+        arow[mt] = ((m >> 6) * 12 + ((m >> 3) & 7)) * 12 + (m & 7);
+    }
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    __syncthreads();
+    const f32x4* __restrict__ wq = reinterpret_cast<const f32x4*>(p.w) + (size_t)h * p.Co_pad + co_base + l31;
+    f32x4 bcur[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bcur[nt] = wq[nt * 32];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        f32x4 bnxt[NT];
+        const int on = o < 15 ? o + 1 : 15;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bnxt[nt] = wq[(size_t)(2 * on) * p.Co_pad + nt * 32];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int off = h ? occ_tap_off(8 * o + 4 + s) : occ_tap_off(8 * o + s);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float a = tile[arow[mt] + off];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcur[nt][s], acc[mt][nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
+    }
+    EpiArgs e;
+    e.out = p.out; e.part = p.part; e.bias = nullptr; e.field = p.field;
+    e.OD = p.G; e.OH = p.G; e.OW = p.G; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3;
+    __syncthreads();
+    epilogue<2, NT>(e, tile + 8 * 12 * 12, acc, n, br, nblk, oz0, oy0, ox0, co_base);
+}
+
+// (Cout, 4, 5,5,5) OIDHW -> the occupancy channel's taps as a (Cout, 125) matrix
+__global__ void extract_occ_weight_kernel(const float* __restrict__ w, int Cout, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Cout * 125) out[i] = w[(size_t)(i / 125) * 4 * 125 + i % 125];
 }
 
 template <int MT, int NT>
@@ -127,26 +297,55 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         const int nq = kc >> 2;
         __syncthreads();
         // ---- stage the halo brick of channels [c0, c0+kc) ------------------------------
-        for (int i = tid; i < p.HV * nq; i += 256) {
-            int q = i % nq, hv = i / nq;
-            int hx = hv % p.HX, t2 = hv / p.HX;
-            int hy = t2 % p.HY, hz = t2 / p.HY;
-            int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gz < (unsigned)p.ID && (unsigned)gy < (unsigned)p.IH && (unsigned)gx < (unsigned)p.IW) {
-                int c = c0 + 4 * q;
-                v = *reinterpret_cast<const f32x4*>(p.in + ((((size_t)n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + c);
-                if (p.in_scale) {
-                    f32x4 sc = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)n * p.Cin + c);
-                    f32x4 sh = *reinterpret_cast<const f32x4*>(p.in_shift + (size_t)n * p.Cin + c);
-                    v = v * sc + sh;
-                }
-                if (p.in_slope != 1.0f) {
-                    v[0] = lrelu(v[0], p.in_slope); v[1] = lrelu(v[1], p.in_slope);
-                    v[2] = lrelu(v[2], p.in_slope); v[3] = lrelu(v[3], p.in_slope);
+        if (!p.up2) {
+            for (int i = tid; i < p.HV * nq; i += 256) {
+                int q = i % nq, hv = i / nq;
+                int hx = hv % p.HX, t2 = hv / p.HX;
+                int hy = t2 % p.HY, hz = t2 / p.HY;
+                int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)gz < (unsigned)p.ID && (unsigned)gy < (unsigned)p.IH && (unsigned)gx < (unsigned)p.IW)
+                    v = load_act(p, n, gz, gy, gx, c0 + 4 * q);
+                lds[q * p.HVp + hv] = v;
+            }
+        } else {
+            // nn.Upsample(x2, trilinear, align_corners=False) of the activated coarse tensor (kypt_detector.py:427,441),
+            // fused: (1) the coarse voxels this brick touches go to LDS once (activated), (2) the fine halo tile is
+            // interpolated LDS -> LDS.
+            f32x4* ldc = lds + (p.KC >> 2) * p.HVp;
+            const int cz0 = up_lo(max(iz0, 0)), cy0 = up_lo(max(iy0, 0)), cx0 = up_lo(max(ix0, 0));
+            const int CZ = min(p.ID - 1, up_lo(min(iz0 + p.HZ - 1, 2 * p.ID - 1)) + 1) - cz0 + 1;
+            const int CY = min(p.IH - 1, up_lo(min(iy0 + p.HY - 1, 2 * p.IH - 1)) + 1) - cy0 + 1;
+            const int CX = min(p.IW - 1, up_lo(min(ix0 + p.HX - 1, 2 * p.IW - 1)) + 1) - cx0 + 1;
+            for (int i = tid; i < CZ * CY * CX * nq; i += 256) {
+                int q = i % nq, cv = i / nq;
+                int x = cv % CX, t2 = cv / CX;
+                int y = t2 % CY, z = t2 / CY;
+                ldc[q * p.CVp + cv] = load_act(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
+            }
+            __syncthreads();
+            for (int hv = tid; hv < p.HV; hv += 256) {
+                int hx = hv % p.HX, t2 = hv / p.HX;
+                int hy = t2 % p.HY, hz = t2 / p.HY;
+                int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+                if ((unsigned)gz < (unsigned)(2 * p.ID) && (unsigned)gy < (unsigned)(2 * p.IH) && (unsigned)gx < (unsigned)(2 * p.IW)) {
+                    int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+                    up_idx(gz, p.ID, z0, z1, lz); up_idx(gy, p.IH, y0, y1, ly); up_idx(gx, p.IW, x0, x1, lx);
+                    const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
+                    const int r00 = ((z0 - cz0) * CY + (y0 - cy0)) * CX, r01 = ((z0 - cz0) * CY + (y1 - cy0)) * CX;
+                    const int r10 = ((z1 - cz0) * CY + (y0 - cy0)) * CX, r11 = ((z1 - cz0) * CY + (y1 - cy0)) * CX;
+                    const int a0 = x0 - cx0, a1 = x1 - cx0;
+                    for (int q = 0; q < nq; ++q) {
+                        const f32x4* cq = ldc + q * p.CVp;
+                        lds[q * p.HVp + hv] =
+                            wz0 * (wy0 * (wx0 * cq[r00 + a0] + lx * cq[r00 + a1]) + ly * (wx0 * cq[r01 + a0] + lx * cq[r01 + a1])) +
+                            lz * (wy0 * (wx0 * cq[r10 + a0] + lx * cq[r10 + a1]) + ly * (wx0 * cq[r11 + a0] + lx * cq[r11 + a1]));
+                    }
+                } else {
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    for (int q = 0; q < nq; ++q) lds[q * p.HVp + hv] = zero;
                 }
             }
-            lds[q * p.HVp + hv] = v;
         }
         __syncthreads();
 
@@ -156,48 +355,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         else          mfma_chunk<MT, NT, 1>(p, lds, wq, tap_stride, taps, h, arow, acc);
     }
 
-    // ---- epilogue: bias, store, GroupNorm partials ------------------------------------------
+    EpiArgs e;
+    e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
+    e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = p.bz_l2; e.by_l2 = p.by_l2; e.bx_l2 = p.bx_l2;
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);                  // [4 waves][NT*32][2]
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = co_base + nt * 32 + l31;
-        const bool cv = co < p.Cout;
-        const float bv = (cv && p.bias) ? p.bias[co] : 0.f;
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                int m = (wave * MT + mt) * 32 + row;
-                int x = m & BXm, y = (m >> p.bx_l2) & BYm, z = m >> (p.bx_l2 + p.by_l2);
-                int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
-                float v = acc[mt][nt][r] + bv;
-                if (cv && oz < p.OD && oy < p.OH && ox < p.OW) {
-                    p.out[((((size_t)n * p.OD + oz) * p.OH + oy) * p.OW + ox) * p.Cout + co] = v;
-                    s += v; ss += v * v;
-                }
-            }
-        }
-        if (p.part) {
-            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-            if (h == 0) { red[(wave * NT * 32 + nt * 32 + l31) * 2] = s; red[(wave * NT * 32 + nt * 32 + l31) * 2 + 1] = ss; }
-        }
-    }
-    if (p.part) {
-        __syncthreads();
-        if (tid < NT * 32) {
-            int co = co_base + tid;
-            if (co < p.Cout) {
-                float s = 0.f, ss = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < 4; ++wv) { s += red[(wv * NT * 32 + tid) * 2]; ss += red[(wv * NT * 32 + tid) * 2 + 1]; }
-                float* dst = p.part + (((size_t)n * nblk + br) * p.Cout + co) * 2;
-                dst[0] = s; dst[1] = ss;
-            }
-        }
-    }
+    epilogue<MT, NT>(e, reinterpret_cast<float*>(lds), acc, n, br, nblk, oz0, oy0, ox0, co_base);
 }
 
 // OIDHW (Cout, Cin, k, k, k) -> [tap][Cin_pad/4][Co_pad][4], zero padded
@@ -220,7 +382,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
 
 int ceil_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-struct Tiling { int MT, NT, bz_l2, by_l2, bx_l2, nbz, nby, nbx, KC, HZ, HY, HX, HV, HVp; size_t lds_bytes; };
+struct Tiling { int MT, NT, bz_l2, by_l2, bx_l2, nbz, nby, nbx, KC, HZ, HY, HX, HV, HVp, CVp; size_t lds_bytes; };
 
 Tiling choose_tiling(const ConvGeom& g, int Cin) {
     Tiling t;
@@ -239,8 +401,13 @@ Tiling choose_tiling(const ConvGeom& g, int Cin) {
     t.HV = t.HX * t.HY * t.HZ;
     t.HVp = t.HV + ((2 - (t.HV & 7)) & 7);
     t.KC = (Cin % 16 == 0) ? 16 : 8;
-    if ((size_t)(t.KC / 4) * t.HVp * 16 > 72 * 1024 && t.KC == 16) t.KC = 8;
-    t.lds_bytes = max((size_t)(t.KC / 4) * t.HVp * 16, (size_t)4 * 64 * 2 * sizeof(float));
+    t.CVp = 0;
+    if (g.up2) {
+        int cv = ((t.HZ >> 1) + 2) * ((t.HY >> 1) + 2) * ((t.HX >> 1) + 2);
+        t.CVp = cv + ((2 - (cv & 7)) & 7);
+    }
+    if ((size_t)(t.KC / 4) * (t.HVp + t.CVp) * 16 > 72 * 1024 && t.KC == 16) t.KC = 8;
+    t.lds_bytes = max((size_t)(t.KC / 4) * (t.HVp + t.CVp) * 16, (size_t)4 * 64 * 2 * sizeof(float));
     return t;
 }
 
@@ -329,8 +496,9 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
         nm_set_error("conv: unsupported channels Cin=%d Cout=%d Co_pad=%d", in.C, g.Cout, g.Co_pad);
         return NM_ERR_ARG;
     }
-    if ((in.D + 2 * g.pad - g.ks) / g.stride + 1 != g.OD || (in.H + 2 * g.pad - g.ks) / g.stride + 1 != g.OH ||
-        (in.W + 2 * g.pad - g.ks) / g.stride + 1 != g.OW) {
+    const int us = g.up2 ? 2 : 1;
+    if ((us * in.D + 2 * g.pad - g.ks) / g.stride + 1 != g.OD || (us * in.H + 2 * g.pad - g.ks) / g.stride + 1 != g.OH ||
+        (us * in.W + 2 * g.pad - g.ks) / g.stride + 1 != g.OW) {
         nm_set_error("conv: geometry mismatch in=(%d,%d,%d) k=%d s=%d p=%d out=(%d,%d,%d)", in.D, in.H, in.W,
                      g.ks, g.stride, g.pad, g.OD, g.OH, g.OW);
         return NM_ERR_ARG;
@@ -346,10 +514,39 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.ks = g.ks; p.stride = g.stride; p.pad = g.pad;
     p.bz_l2 = t.bz_l2; p.by_l2 = t.by_l2; p.bx_l2 = t.bx_l2; p.nbz = t.nbz; p.nby = t.nby; p.nbx = t.nbx;
     p.cin_real = cin_real > 0 ? cin_real : in.C;
-    p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp;
+    p.up2 = g.up2 ? 1 : 0;
+    p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
     if (t.MT == 2 && t.NT == 2) return launch_t<2, 2>(p, t, grid, s);
     if (t.MT == 2 && t.NT == 1) return launch_t<2, 1>(p, t, grid, s);
     if (t.MT == 1 && t.NT == 2) return launch_t<1, 2>(p, t, grid, s);
     return launch_t<1, 1>(p, t, grid, s);
+}
+
+int nm_occ_blocks_per_frame(int G) { return (G / 8) * (G / 8) * (G / 4); }
+
+// packs the occupancy-channel taps of a (Cout,4,5,5,5) weight into [32 tap-quads][Co_pad][4]; tmp: Cout*125 floats
+int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s) {
+    hipLaunchKernelGGL(extract_occ_weight_kernel, dim3((Cout * 125 + 255) / 256), dim3(256), 0, s, w_oidhw, Cout, tmp);
+    int rc = nm_check_hip(hipGetLastError(), "extract_occ_weight launch");
+    if (rc) return rc;
+    return nm_launch_pack_conv_weight(tmp, Cout, 125, 1, packed, 128, Co_pad, s);
+}
+
+int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
+                         int Co_pad, float* part, hipStream_t s) {
+    if (G % 8 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("conv_k5occ: unsupported G=%d Cout=%d", G, Cout); return NM_ERR_ARG; }
+    OccParams p; p.occ = occ; p.w = w_packed; p.field = field; p.out = out; p.part = part; p.N = N; p.G = G; p.Cout = Cout; p.Co_pad = Co_pad;
+    const int NT = (Co_pad % 64 == 0) ? 2 : 1;
+    dim3 grid((unsigned)(N * nm_occ_blocks_per_frame(G)), (unsigned)(Co_pad / (NT * 32)));
+    ProfRec rec;
+    if (g_prof_on) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 4;
+        rec.flops = 2.0 * N * (double)G * G * G * Cout * 4.0 * 125.0;   // the reference's dense k5 layer over 4 input channels
+        (void)hipEventRecord(rec.a, s);
+    }
+    if (NT == 2) hipLaunchKernelGGL((conv_k5occ_kernel<2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_k5occ_kernel<1>), grid, dim3(256), 0, s, p);
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    return nm_check_hip(hipGetLastError(), "conv_k5occ launch");
 }

@@ -209,6 +209,16 @@ __global__ __launch_bounds__(256) void cl_to_ncdhw_kernel(TensorRef in, int fram
     }
 }
 
+// clip mean over T (kypt_detector.py:312): sequential sum then one division, like the reference's mean(dim=1)
+__global__ __launch_bounds__(256) void mean_t_kernel(const float* __restrict__ vox, int T, size_t G3, size_t total, float* __restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / G3, v = i % G3;
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += vox[(b * T + t) * G3 + v];
+        out[i] = s / (float)T;
+    }
+}
+
 // [n][C][vox] -> [n][vox][C]
 __global__ __launch_bounds__(256) void ncdhw_to_cl_kernel(const float* __restrict__ in, int voxels, int C, float* __restrict__ out) {
     __shared__ float tile[32][33];
@@ -291,4 +301,10 @@ int nm_launch_ncdhw_to_cl(const float* in, int N, int voxels, int C, float* out,
     dim3 grid((voxels + 31) / 32, (C + 31) / 32, N);
     hipLaunchKernelGGL(ncdhw_to_cl_kernel, grid, dim3(256), 0, s, in, voxels, C, out);
     return nm_check_hip(hipGetLastError(), "ncdhw_to_cl launch");
+}
+
+int nm_launch_mean_t(const float* vox, int B, int T, size_t G3, float* out, hipStream_t s) {
+    size_t total = (size_t)B * G3;
+    hipLaunchKernelGGL(mean_t_kernel, dim3(grid_for(total)), dim3(256), 0, s, vox, T, G3, total, out);
+    return nm_check_hip(hipGetLastError(), "mean_t launch");
 }

@@ -18,7 +18,7 @@ namespace {
 
 const float LRELU = 0.01f;
 const int FEAT = 128;
-const size_t FRAME_CHUNK = 32;     // frames per pass through the conv stacks (bounds the workspace)
+const size_t FRAME_CHUNK = 64;     // frames per pass through the conv stacks (bounds the workspace)
 
 // ------------------------------------------------------------------------------------------
 // weights
@@ -93,9 +93,33 @@ struct Loader {
     FeatNetW featnet(const std::string& p, int cout) {
         FeatNetW f; const int c4 = cout / 4, c2 = cout / 2;
         f.c0 = conv(p + ".0.block.0", c4, 4, 5); f.n0 = norm(p + ".0.block.1", c4);
+        first_layer_tables(p + ".0.block.0", f);
         f.p1 = pool(p + ".1", c4); f.r2 = res(p + ".2", c4, c2); f.p3 = pool(p + ".3", c2);
         f.hg = hourglass(p + ".4", c2, c2); f.r5 = res(p + ".5", c2, cout);
         return f;
+    }
+    // occupancy-channel taps packed for the taps-as-K kernel, and the constant field
+    //   field = conv5(cat[0, x1, x2, x3]) + bias      (one frame, [G^3][Cout])
+    // computed once per weight update with the generic conv on a zero-occupancy frame.
+    void first_layer_tables(const std::string& p, FeatNetW& f) {
+        const int G = c->cfg.grid_size, Cout = f.c0.Cout;
+        const size_t G3 = (size_t)G * G * G;
+        const float* src = get(p + ".weight", (int64_t)Cout * 4 * 125);
+        if (!src || !f.c0.wp) return;
+        f.occ_w = nm_ctx_weight_alloc(c, (size_t)128 * f.c0.Co_pad);
+        f.field = nm_ctx_weight_alloc(c, G3 * Cout);
+        float* tmp = nm_ctx_weight_alloc(c, (size_t)Cout * 125 + G3 * 9);      // freed with the other weights at the next update
+        if (!f.occ_w || !f.field || !tmp) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return; }
+        float* zero = tmp + (size_t)Cout * 125; float* packed_in = zero + G3;
+        int r = nm_launch_pack_occ_weight(src, Cout, tmp, f.occ_w, f.c0.Co_pad, c->stream);
+        if (!r) r = nm_check_hip(hipMemsetAsync(zero, 0, G3 * sizeof(float), c->stream), "set_weights: memset");
+        if (!r) r = nm_launch_pack_input(zero, 1, 1, G, 0, packed_in, c->stream);
+        if (!r) {
+            TensorRef t; t.p = packed_in; t.scale = nullptr; t.shift = nullptr; t.slope = 1.0f; t.N = 1; t.D = t.H = t.W = G; t.C = 8;
+            ConvGeom g; g.ks = 5; g.stride = 1; g.pad = 2; g.OD = g.OH = g.OW = G; g.Cout = Cout; g.Co_pad = f.c0.Co_pad;
+            r = nm_launch_conv(t, f.c0.wp, f.c0.bias, f.field, g, nullptr, c->stream, 4);
+        }
+        if (r && !rc) rc = r;
     }
     LinearW linear(const std::string& p, int out, int in) {
         LinearW l; l.in = in; l.out = out; l.w = copy(p + ".weight", (int64_t)out * in); l.b = copy(p + ".bias", out); return l;
@@ -130,10 +154,12 @@ TensorRef mk(const float* p, int N, int D, int H, int W, int C, const float* sc 
 size_t vox(const TensorRef& t) { return (size_t)t.D * t.H * t.W; }
 
 // conv (+ optional GroupNorm statistics): returns the lazy output
+// (up2: `in` is stored at half resolution and its trilinear x2 upsampling is what gets convolved)
 TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, int stride, int pad, float slope_after,
-                  float* out_buf = nullptr) {
-    ConvGeom g; g.ks = w.ks; g.stride = stride; g.pad = pad;
-    g.OD = (in.D + 2 * pad - w.ks) / stride + 1; g.OH = (in.H + 2 * pad - w.ks) / stride + 1; g.OW = (in.W + 2 * pad - w.ks) / stride + 1;
+                  float* out_buf = nullptr, bool up2 = false) {
+    ConvGeom g; g.ks = w.ks; g.stride = stride; g.pad = pad; g.up2 = up2 ? 1 : 0;
+    const int us = up2 ? 2 : 1;
+    g.OD = (us * in.D + 2 * pad - w.ks) / stride + 1; g.OH = (us * in.H + 2 * pad - w.ks) / stride + 1; g.OW = (us * in.W + 2 * pad - w.ks) / stride + 1;
     g.Cout = w.Cout; g.Co_pad = w.Co_pad;
     const size_t ov = (size_t)g.OD * g.OH * g.OW;
     float* out = out_buf ? out_buf : n.alloc((size_t)in.N * ov * w.Cout);
@@ -210,10 +236,27 @@ TensorRef hourglass(Net& n, const TensorRef& x0, const HourglassW& w, int Ng) {
     return x;
 }
 
-// _build_feature_net (kypt_detector.py:264-272); `in` is [N][G][G][G][8] = occupancy + 3 coord ramps
-void feature_net(Net& n, const TensorRef& in, const FeatNetW& w, int g, float* out_buf) {
+// Basic3DBlock(k5) on cat[occ, x1, x2, x3] (kypt_detector.py:265, kypt_detector_utils.py:4-26): only the occupancy
+// channel is convolved per frame, the coordinate channels' contribution (+ bias) is the weight-only `field`.
+TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w) {
+    const int Cout = w.c0.Cout;
+    const size_t G3 = (size_t)G * G * G;
+    float* out = n.alloc((size_t)N * G3 * Cout);
+    const int nblk = nm_occ_blocks_per_frame(G);
+    float* part = n.alloc((size_t)N * nblk * Cout * 2);
+    float* scale = n.alloc((size_t)N * Cout); float* shift = n.alloc((size_t)N * Cout);
+    if (n.live()) {
+        n.run(nm_launch_conv_k5occ(occ, N, G, w.occ_w, w.field, out, Cout, w.c0.Co_pad, part, n.s));
+        n.run(nm_launch_gn_finalize(part, N, nblk, Cout, w.n0.groups, (double)G3 * (Cout / w.n0.groups), w.n0.gamma, w.n0.beta,
+                                    1e-5f, scale, shift, n.s));
+    }
+    return mk(out, N, G, G, G, Cout, scale, shift, LRELU);
+}
+
+// _build_feature_net (kypt_detector.py:264-272); `occ` is the occupancy [N][G][G][G]
+void feature_net(Net& n, const float* occ, int N, int G, const FeatNetW& w, int g, float* out_buf) {
     const size_t m = n.ws.mark();
-    TensorRef x = conv_gn(n, in, w.c0, &w.n0, 1, 2, LRELU);
+    TensorRef x = first_layer(n, occ, N, G, w);
     x = pool(n, x, w.p1);
     x = res(n, x, w.r2);
     x = pool(n, x, w.p3);
@@ -251,15 +294,9 @@ void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int fea
                                      Cc, comb, n.s));
         TensorRef x = mk(comb, nf, g, g, g, Cc);
         x = conv_gn(n, x, d.adjust, nullptr, 1, 0, LRELU);
-        float* u1 = n.alloc((size_t)nf * g3 * 8 * FEAT);
-        if (n.live()) n.run(nm_launch_upsample2(x, u1, n.s));
-        x = mk(u1, nf, 2 * g, 2 * g, 2 * g, FEAT);
-        x = conv_gn(n, x, d.d1, &d.dn2, 1, 1, LRELU);
+        x = conv_gn(n, x, d.d1, &d.dn2, 1, 1, LRELU, nullptr, true);    // Upsample(x2, trilinear) fused into the staging
         x = conv_gn(n, x, d.d4, &d.dn5, 1, 1, LRELU);
-        float* u2 = n.alloc((size_t)nf * G3 * (FEAT / 2));
-        if (n.live()) n.run(nm_launch_upsample2(x, u2, n.s));
-        x = mk(u2, nf, G, G, G, FEAT / 2);
-        x = conv_gn(n, x, d.d8, &d.dn9, 1, 1, LRELU);
+        x = conv_gn(n, x, d.d8, &d.dn9, 1, 1, LRELU, nullptr, true);    // second Upsample(x2) likewise
         x = conv_gn(n, x, d.d11, &d.dn12, 1, 1, LRELU);
         if (n.live())
             n.run(nm_launch_decoder_tail(x, d.d14, first_frames + (size_t)b0 * ff_stride * G3, ff_stride, T,
@@ -289,19 +326,17 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
 
     {   // spatio-temporal heat-map from the clip mean, once per clip (kypt_detector.py:311-316)
         const size_t m = n.ws.mark();
-        float* in = n.alloc((size_t)B * G3 * 8);
+        float* in = n.alloc((size_t)B * G3);
         float* fclip = n.alloc((size_t)B * g3 * 2 * FEAT);
-        if (n.live()) n.run(nm_launch_pack_input(vox_in, B, T, G, 1, in, n.s));
-        feature_net(n, mk(in, B, G, G, G, 8), d.clip, g, fclip);
+        if (n.live()) n.run(nm_launch_mean_t(vox_in, B, T, G3, in, n.s));
+        feature_net(n, in, B, G, d.clip, g, fclip);
         conv_gn(n, mk(fclip, B, g, g, g, 2 * FEAT), d.clip_head, nullptr, 1, 0, 1.0f, clip_head);
         n.ws.release(m);
     }
     for (size_t f0 = 0; f0 < (size_t)F; f0 += FRAME_CHUNK) {   // per-frame encoder (kypt_detector.py:330-336)
         const int nf = (int)(((size_t)F - f0) < FRAME_CHUNK ? ((size_t)F - f0) : FRAME_CHUNK);
         const size_t m = n.ws.mark();
-        float* in = n.alloc((size_t)nf * G3 * 8);
-        if (n.live()) n.run(nm_launch_pack_input(vox_in + f0 * G3, nf, 1, G, 0, in, n.s));
-        feature_net(n, mk(in, nf, G, G, G, 8), d.frame, g, feat + f0 * g3 * FEAT);
+        feature_net(n, vox_in + f0 * G3, nf, G, d.frame, g, feat + f0 * g3 * FEAT);
         n.ws.release(m);
     }
     {   // heads -> heat-maps -> keypoints (kypt_detector.py:336-347)

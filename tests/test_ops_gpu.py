@@ -92,7 +92,7 @@ def test_conv3d(ctx, case):
     xd, wd, bd, scd, shd, gd, btd = to_cl(x), dev(w), dev(b), dev(scp), dev(shp), dev(gam), dev(bet)
     _lib.check(ctx.lib.nm_op_conv3d(ctx.handle, _lib.ptr(xd), N, *dims, Cin, _lib.ptr(scd), _lib.ptr(shd), slope,
                                     _lib.ptr(wd), _lib.ptr(bd), Cout, ks, stride, pad, _lib.ptr(out), groups,
-                                    _lib.ptr(gd), _lib.ptr(btd), _lib.ptr(gsc), _lib.ptr(gsh)), "op_conv3d")
+                                    _lib.ptr(gd), _lib.ptr(btd), _lib.ptr(gsc), _lib.ptr(gsh), 0), "op_conv3d")
     torch.cuda.synchronize()
     got = from_cl(out, Cout)
     assert torch.isfinite(got).all(), "unwritten / non-finite outputs"
@@ -103,6 +103,74 @@ def test_conv3d(ctx, case):
         gotn = got * gsc.cpu()[:, :, None, None, None] + gsh.cpu()[:, :, None, None, None]
         e = relerr(gotn, refn)
         assert e < REL, f"fused GroupNorm rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("Cin,Cout,size,prologue", [(128, 64, 8, False), (64, 32, 12, True), (16, 32, 5, True)])
+def test_conv3d_fused_upsample(ctx, Cin, Cout, size, prologue):
+    """Upsample(x2, trilinear, align_corners=False) -> Conv3d(k3) -> GroupNorm, the upsampling fused into the
+    conv's staging (decoder layers .0/.1 and .7/.8 of kypt_detector.py:427-444)."""
+    from neural_marionette_amd import _lib
+    g = torch.Generator().manual_seed(Cin + size)
+    N = 2
+    x = torch.randn(N, Cin, size, size, size, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    if prologue:
+        sc = torch.rand(N, Cin, generator=g) + 0.5
+        sh = torch.randn(N, Cin, generator=g) * 0.3
+        xin = F.leaky_relu(x * sc[:, :, None, None, None] + sh[:, :, None, None, None], 0.01)
+        slope = 0.01
+    else:
+        sc = sh = None
+        xin, slope = F.leaky_relu(x, 0.01), 0.01
+    ref = F.conv3d(F.interpolate(xin, scale_factor=2.0, mode="trilinear", align_corners=False), w, b, padding=1)
+    groups = Cout // 16
+    gam = torch.rand(Cout, generator=g) + 0.5
+    bet = torch.randn(Cout, generator=g) * 0.2
+    out = torch.full((N, 2 * size, 2 * size, 2 * size, Cout), float("nan")).cuda()
+    gsc = torch.zeros(N, Cout).cuda(); gsh = torch.zeros(N, Cout).cuda()
+    xd, wd, bd, scd, shd, gd, btd = to_cl(x), dev(w), dev(b), dev(sc), dev(sh), dev(gam), dev(bet)
+    _lib.check(ctx.lib.nm_op_conv3d(ctx.handle, _lib.ptr(xd), N, size, size, size, Cin, _lib.ptr(scd), _lib.ptr(shd), slope,
+                                    _lib.ptr(wd), _lib.ptr(bd), Cout, 3, 1, 1, _lib.ptr(out), groups, _lib.ptr(gd),
+                                    _lib.ptr(btd), _lib.ptr(gsc), _lib.ptr(gsh), 1), "op_conv3d(up2)")
+    torch.cuda.synchronize()
+    got = from_cl(out, Cout)
+    assert torch.isfinite(got).all()
+    e = relerr(got, ref)
+    assert e < REL, f"fused upsample+conv rel err {e:.3e}"
+    refn = F.group_norm(ref, groups, gam, bet, 1e-5)
+    e = relerr(got * gsc.cpu()[:, :, None, None, None] + gsh.cpu()[:, :, None, None, None], refn)
+    assert e < REL, f"fused GroupNorm rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("G,Cout,N", [(16, 32, 3), (24, 64, 2), (32, 32, 1)])
+def test_conv5_occupancy_first_layer(ctx, G, Cout, N):
+    """Basic3DBlock(1+3 -> Cout, k5) on cat[occ, coords] as conv(occ) + constant field (kypt_detector.py:265)."""
+    from neural_marionette_amd import _lib
+    from oracle import nm_oracle as O
+    g = torch.Generator().manual_seed(G + Cout)
+    occ = (torch.rand(N, 1, G, G, G, generator=g) < 0.05).float()
+    if N > 1:
+        occ[1] = torch.rand(1, G, G, G, generator=g)          # the clip-mean net sees fractional occupancy
+    w = torch.randn(Cout, 4, 5, 5, 5, generator=g) / (4 * 125) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv3d(O.add_coords(occ), w, b, padding=2)
+    groups = Cout // 16
+    gam = torch.rand(Cout, generator=g) + 0.5
+    bet = torch.randn(Cout, generator=g) * 0.2
+    out = torch.full((N, G, G, G, Cout), float("nan")).cuda()
+    gsc = torch.zeros(N, Cout).cuda(); gsh = torch.zeros(N, Cout).cuda()
+    od, wd, bd, gd, btd = occ.reshape(N, G, G, G).contiguous().cuda(), dev(w), dev(b), dev(gam), dev(bet)
+    _lib.check(ctx.lib.nm_op_conv5_occ(ctx.handle, _lib.ptr(od), N, G, _lib.ptr(wd), _lib.ptr(bd), Cout, _lib.ptr(out),
+                                       groups, _lib.ptr(gd), _lib.ptr(btd), _lib.ptr(gsc), _lib.ptr(gsh)), "op_conv5_occ")
+    torch.cuda.synchronize()
+    got = from_cl(out, Cout)
+    assert torch.isfinite(got).all()
+    e = relerr(got, ref)
+    assert e < REL, f"occupancy first layer rel err {e:.3e}"
+    refn = F.group_norm(ref, groups, gam, bet, 1e-5)
+    e = relerr(got * gsc.cpu()[:, :, None, None, None] + gsh.cpu()[:, :, None, None, None], refn)
+    assert e < REL, f"GroupNorm rel err {e:.3e}"
 
 
 @pytest.mark.parametrize("Cin,Cout,size,outpad,groups", [(72, 48, 2, 0, 3), (48, 32, 5, 1, 2), (32, 64, 8, 0, 4), (32, 128, 3, 1, 8)])
