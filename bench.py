@@ -146,8 +146,16 @@ def main():
         if best:
             name, ms, fl, n = best
             ach = fl / (ms * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel from the committed PMC passes (separate rocprofv3 --pmc runs)
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if pm.get("kernel") == name:
+                    traffic = pm["traffic_bytes_per_launch"]
+            except Exception:
+                pass
             roof = dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, kernel=name, launches=n,
+                        frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=traffic, kernel=name, launches=n,
                         avg_launch_ms=ms / n, kernel_time_share=ms * 1e-3 / dt)
         cpu, l2 = (None, None)
         if world == 1 and not args.no_cpu_baseline:

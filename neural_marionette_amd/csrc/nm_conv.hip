@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_kernel(OccParams p) {
     const int h = lane >> 5, l31 = lane & 31;
     const int nb = p.G >> 3, nbz = p.G >> 2;
     const int nblk = nbz * nb * nb;
-    const int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
+    // frame index fastest: the blocks in flight share one brick of the constant field (L2 reuse across frames)
+    const int n = blockIdx.x % p.N, br = blockIdx.x / p.N;
     const int oz0 = (br / (nb * nb)) << 2, oy0 = ((br / nb) % nb) << 3, ox0 = (br % nb) << 3;
     const int co_base = blockIdx.y * (NT * 32);
     const float* src = p.occ + (size_t)n * p.G * p.G * p.G;

@@ -22,7 +22,6 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 __device__ __forceinline__ float softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-#define NB 8   // samples per wavefront pass
 
 struct LinJob {
     const float* W; int ldw; int col0;
@@ -35,25 +34,43 @@ struct LinJob {
 };
 struct LinJobs { LinJob j[5]; int n; int start[6]; };
 
-// acc[s] += sum_k W[k] * x[b0+s][k] over this lane's k's
+// acc[s] += sum_k W[k] * x[b0+s][k] over this lane's k's.  NB = samples per wavefront pass.
+// 16-B loads when rows are 4-float aligned (every weight / activation stride of this model is).
+template <int NB>
 __device__ __forceinline__ void dot_seg(const float* __restrict__ w, const float* __restrict__ x, int n, int ld, int b0,
                                         int batch, int lane, float (&acc)[NB]) {
     if (!x) return;
-    for (int k = lane; k < n; k += 64) {
-        const float wv = w[k];
+    const bool vec = ((n | ld) & 3) == 0 && ((((uintptr_t)w) | ((uintptr_t)x)) & 15) == 0;
+    if (vec) {
+#pragma unroll 2
+        for (int k = lane * 4; k < n; k += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
 #pragma unroll
-        for (int s = 0; s < NB; ++s) {
-            int b = b0 + s; b = b < batch ? b : batch - 1;
-            acc[s] += wv * x[(size_t)b * ld + k];
+            for (int s = 0; s < NB; ++s) {
+                int b = b0 + s; b = b < batch ? b : batch - 1;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * ld + k);
+                acc[s] += ((wv[0] * xv[0] + wv[1] * xv[1]) + wv[2] * xv[2]) + wv[3] * xv[3];
+            }
+        }
+    } else {
+        for (int k = lane; k < n; k += 64) {
+            const float wv = w[k];
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                int b = b0 + s; b = b < batch ? b : batch - 1;
+                acc[s] += wv * x[(size_t)b * ld + k];
+            }
         }
     }
 }
+template <int NB>
 __device__ __forceinline__ void wave_reduce(float (&acc)[NB]) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
         for (int s = 0; s < NB; ++s) acc[s] += __shfl_xor(acc[s], off);
 }
+template <int NB>
 __device__ __forceinline__ float pick(const float (&acc)[NB], int s) {
     float v = acc[0];
 #pragma unroll
@@ -62,6 +79,7 @@ __device__ __forceinline__ float pick(const float (&acc)[NB], int s) {
 }
 
 // out[b][r] = act(W[r, col0:col0+na+nb] . [xa[b] | xb[b]] + bias[r] + add[b % add_mod][r])
+template <int NB>
 __global__ __launch_bounds__(256) void linear_rows_kernel(LinJobs jobs) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -95,6 +113,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinJobs jobs) {
 // second layer of a prior / posterior MLP: rows (r, r+Z) -> mu, std = softplus(.)+1e-4 and, when eps is given,
 // z[i][b][r] = mu + eps[i][b][r] * std   (hsvrnn_bvh.py:93-107)
 struct DistJob { const float* W; const float* bias; const float* x; float* mu; float* sig; const float* eps; float* z; int S; };
+template <int NB>
 __global__ __launch_bounds__(256) void dist_rows_kernel(DistJob a, DistJob b, int njobs, int Z, int hid, int B) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -121,6 +140,7 @@ __global__ __launch_bounds__(256) void dist_rows_kernel(DistJob a, DistJob b, in
 }
 
 // GRUCell (gate order r,z,n; ATen form h' = (h - n) * z + n).  gh = W_hh h + b_hh from the h-phase.
+template <int NB>
 __global__ __launch_bounds__(256) void gru_rows_kernel(const float* __restrict__ W_ih, const float* __restrict__ b_ih,
                                                        const float* __restrict__ xa, int na, int lda,
                                                        const float* __restrict__ xb, int nb, int ldb,
@@ -311,12 +331,29 @@ void add_job(LinJobs& J, const LinearW& L, int col0, const float* xa, int na, in
     J.n++;
 }
 
+int pick_nb(int batch) { return batch >= 8 ? 8 : (batch >= 4 ? 4 : (batch >= 2 ? 2 : 1)); }
+
 int launch_jobs(const LinJobs& J, hipStream_t s) {
     int maxb = 0;
     for (int i = 0; i < J.n; ++i) maxb = J.j[i].batch > maxb ? J.j[i].batch : maxb;
-    dim3 grid((J.start[J.n] + 3) / 4, (maxb + NB - 1) / NB);
-    hipLaunchKernelGGL(linear_rows_kernel, grid, dim3(256), 0, s, J);
+    const int nb = pick_nb(maxb);
+    dim3 grid((J.start[J.n] + 3) / 4, (maxb + nb - 1) / nb);
+    if (nb == 1) hipLaunchKernelGGL((linear_rows_kernel<1>), grid, dim3(256), 0, s, J);
+    else if (nb == 2) hipLaunchKernelGGL((linear_rows_kernel<2>), grid, dim3(256), 0, s, J);
+    else if (nb == 4) hipLaunchKernelGGL((linear_rows_kernel<4>), grid, dim3(256), 0, s, J);
+    else hipLaunchKernelGGL((linear_rows_kernel<8>), grid, dim3(256), 0, s, J);
     return nm_check_hip(hipGetLastError(), "linear_rows launch");
+}
+
+int launch_gru(const float* W_ih, const float* b_ih, const float* xa, int na, int lda, const float* xb, int nb_, int ldb,
+               const float* gh, const float* h, int ldh, float* hout, int ldo, int H, int B, hipStream_t s) {
+    const int nb = pick_nb(B);
+    dim3 grid((H + 3) / 4, (B + nb - 1) / nb);
+    if (nb == 1) hipLaunchKernelGGL((gru_rows_kernel<1>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B);
+    else if (nb == 2) hipLaunchKernelGGL((gru_rows_kernel<2>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B);
+    else if (nb == 4) hipLaunchKernelGGL((gru_rows_kernel<4>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B);
+    else hipLaunchKernelGGL((gru_rows_kernel<8>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B);
+    return nm_check_hip(hipGetLastError(), "gru launch");
 }
 
 StepBufs alloc_step(Arena& ws, int B, int S, int K, int Z, int H) {
@@ -364,8 +401,12 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         DistJob jq{w.post2.w, w.post2.b, sb.hid_post, sb.qmu, sb.qsig, io.eps, sb.z, S};
         DistJob first = prior ? jp : jq, second = jq;
         const int nj = (prior && post) ? 2 : 1;
-        dim3 grid((nj * Z + 3) / 4, (B + NB - 1) / NB);
-        hipLaunchKernelGGL(dist_rows_kernel, grid, dim3(256), 0, s, first, second, nj, Z, 128, B);
+        const int nb = pick_nb(B);
+        dim3 grid((nj * Z + 3) / 4, (B + nb - 1) / nb);
+        if (nb == 1) hipLaunchKernelGGL((dist_rows_kernel<1>), grid, dim3(256), 0, s, first, second, nj, Z, 128, B);
+        else if (nb == 2) hipLaunchKernelGGL((dist_rows_kernel<2>), grid, dim3(256), 0, s, first, second, nj, Z, 128, B);
+        else if (nb == 4) hipLaunchKernelGGL((dist_rows_kernel<4>), grid, dim3(256), 0, s, first, second, nj, Z, 128, B);
+        else hipLaunchKernelGGL((dist_rows_kernel<8>), grid, dim3(256), 0, s, first, second, nj, Z, 128, B);
         if ((rc = nm_check_hip(hipGetLastError(), "dist_rows launch"))) return rc;
     }
     {   // 3. decoders: z-halves of the first layers (+ shared h-half), then the heads
@@ -392,10 +433,7 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         if ((rc = nm_check_hip(hipGetLastError(), "fk launch"))) return rc;
     }
     if (io.hout) {   // 5. GRU
-        dim3 grid((H + 3) / 4, (B + NB - 1) / NB);
-        hipLaunchKernelGGL(gru_rows_kernel, grid, dim3(256), 0, s, w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz,
-                           sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B);
-        if ((rc = nm_check_hip(hipGetLastError(), "gru launch"))) return rc;
+        if ((rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s))) return rc;
     }
     return NM_OK;
 }
@@ -581,10 +619,7 @@ int nm_vrnn_gru(nm_ctx* c, const float* x, const float* h, int32_t B, float* h_o
     LinearW hh; hh.in = H; hh.out = 3 * H; hh.w = w.w_hh; hh.b = w.b_hh;
     add_job(J, hh, 0, h, H, H, nullptr, 0, 0, true, nullptr, 0, 1, gh, 3 * H, 0, B);
     if ((rc = launch_jobs(J, c->stream))) return rc;
-    dim3 grid((H + 3) / 4, (B + NB - 1) / NB);
-    hipLaunchKernelGGL(gru_rows_kernel, grid, dim3(256), 0, c->stream, w.w_ih, w.b_ih, x, in, in, (const float*)nullptr, 0, 0, gh, h, H,
-                       h_out, H, H, B);
-    return nm_check_hip(hipGetLastError(), "gru launch");
+    return launch_gru(w.w_ih, w.b_ih, x, in, in, nullptr, 0, 0, gh, h, H, h_out, H, H, B, c->stream);
 }
 
 int nm_vrnn_fk(nm_ctx* c, const float* dec_in, const float* offset, int32_t B, float* kp, float* R) {

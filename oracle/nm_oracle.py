@@ -625,19 +625,19 @@ def vrnn_generate(sd: SD, opts, keypoints_cond: Tensor, order, parents, Ttot: in
     B, _, K, _ = keypoints_cond.shape
     h = sd[DYN + ".init_kypt_rnn_state"].expand(B, -1)
     offset = bone_offsets(sd, keypoints_cond, parents)
-    cond, gen = [], []
+    cond, gen, hs, zs = [], [], [h], []
     for t in range(Tcond):
         flat = keypoints_cond[:, t].reshape(B, -1)
-        h, _, bf, _, _, _, _ = _posterior_step(sd, h, flat, eps_post[t], offset, order, parents)
-        cond.append(bf.view(B, K, -1))
+        h, bz, bf, _, _, _, _ = _posterior_step(sd, h, flat, eps_post[t], offset, order, parents)
+        cond.append(bf.view(B, K, -1)); hs.append(h); zs.append(bz)
     for t in range(Tcond, Ttot):
         pm, ps = _dist_params(_mlp(h, sd, DYN + ".extract_prior_dist"))
         z = pm + eps_prior[t - Tcond] * ps
         f, _ = fk_decode(sd, torch.cat([h, z], dim=-1), offset, order, parents)
         h = gru_cell(sd, torch.cat([f, z], dim=-1), h)
-        gen.append(f.view(B, K, -1))
+        gen.append(f.view(B, K, -1)); hs.append(h); zs.append(z)
     return dict(keypoints_cond=torch.stack(cond, 1)[..., :4], keypoints_gen=torch.stack(gen, 1)[..., :4],
-                h_last=h)
+                h_last=h, h_seq=torch.stack(hs, 1), z_seq=torch.stack(zs, 1), offset=offset)
 
 
 # --------------------------------------------------------------------------------------
