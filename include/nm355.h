@@ -164,10 +164,19 @@ int nm_op_apply2(nm_ctx* ctx, const float* a, const float* a_scale, const float*
 int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out);
 int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out);
 int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out);
+/* Conv arithmetic (process-wide).  mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for every conv.
+ * mode 1 (default): layers with Cin % 16 == 0 run on the fp16 matrix cores with every fp32 operand split
+ * into fp16 hi + lo*2^-11 and three products x_hi*w_hi + 2^-11 (x_hi*w_lo + x_lo*w_hi) accumulated in
+ * fp32 — error within one fp32 rounding of the exact product, same tolerance class as the fp32 fma
+ * chain, 16x/3 the MFMA rate.  Parity tests run in both modes. */
+int nm_set_conv_mode(nm_ctx* ctx, int32_t mode);
+int nm_get_conv_mode(nm_ctx* ctx);
+
 /* ---- live kernel timing for bench.py's roofline leg -------------------------------------------
  * While enabled, every conv launch on the ctx stream is bracketed by a HIP event pair.
  * nm_prof_read sums duration and ALGORITHMIC flops (2*voxels*Cout*Cin*k^3, un-padded) of one
- * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2); 4 = the
+ * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2); 5,6 =
+ * conv_f16s_kernel<2,1>/<2,2> (algorithmic fp32-equivalent flops, i.e. 1/3 of the issued MFMA flops); 4 = the
  * first-layer occupancy kernel conv_k5occ_kernel, credited with the reference's dense 4-channel k5 work). */
 int nm_prof_enable(nm_ctx* ctx, int32_t on);
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches);

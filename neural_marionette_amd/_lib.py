@@ -64,6 +64,8 @@ SIGNATURES = {
     "nm_op_upsample2": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _I, _P]),
     "nm_op_pack_input": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _P]),
     "nm_op_cl_to_ncdhw": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P]),
+    "nm_set_conv_mode": (C.c_int, [C.c_void_p, _I]),
+    "nm_get_conv_mode": (C.c_int, [C.c_void_p]),
     "nm_prof_enable": (C.c_int, [C.c_void_p, _I]),
     "nm_prof_read": (C.c_int, [C.c_void_p, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nm_prof_kernel_name": (C.c_char_p, [_I]),

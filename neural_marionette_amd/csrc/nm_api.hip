@@ -95,6 +95,14 @@ int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t coun
     return nm_net_set_weights(ctx, sd);
 }
 
+int nm_set_conv_mode(nm_ctx* ctx, int32_t mode) {
+    if (!ctx || mode < 0 || mode > 1) { nm_set_error("set_conv_mode: mode must be 0 (fp32 MFMA) or 1 (split-fp16 MFMA)"); return NM_ERR_ARG; }
+    nm_conv_set_mode(mode);
+    return NM_OK;
+}
+
+int nm_get_conv_mode(nm_ctx* ctx) { (void)ctx; return nm_conv_get_mode(); }
+
 int nm_prof_enable(nm_ctx* ctx, int32_t on) {
     if (!ctx) { nm_set_error("prof_enable: null ctx"); return NM_ERR_ARG; }
     nm_conv_prof_enable(on);
@@ -103,7 +111,7 @@ int nm_prof_enable(nm_ctx* ctx, int32_t on) {
 }
 
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) {
-    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 4) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
+    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 6) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
     long long n = 0;
     int rc = nm_conv_prof_collect(variant, ms_total, flops_total, &n);
     if (rc) { nm_set_error("prof_read: event query failed"); return rc; }
@@ -112,9 +120,9 @@ int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_t
 }
 
 const char* nm_prof_kernel_name(int32_t variant) {
-    static const char* names[5] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
-                                   "conv_k5occ_kernel"};
-    return (variant >= 0 && variant < 5) ? names[variant] : "";
+    static const char* names[7] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
+                                   "conv_k5occ_kernel", "conv_f16s_kernel<2,1>", "conv_f16s_kernel<2,2>"};
+    return (variant >= 0 && variant < 7) ? names[variant] : "";
 }
 
 int nm_host_linspace(int32_t n, float* out) {
@@ -149,15 +157,17 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     const int nblk = nm_conv_blocks_per_frame(g);
     const size_t wfl = nm_packed_weight_floats(ks, Cin_pad, Co_pad);
     const size_t pfl = (size_t)N * nblk * Cout * 2;
-    int rc = nm_ctx_reserve(ctx, (wfl + pfl) * sizeof(float) + 4096);
+    int rc = nm_ctx_reserve(ctx, (2 * wfl + pfl) * sizeof(float) + 8192);
     if (rc) return rc;
     ctx->ws.release(0);
     float* wp = ctx->ws.f(wfl);
+    float* wp16 = (Cin % 16 == 0) ? ctx->ws.f(wfl) : nullptr;
     float* part = gn_groups > 0 ? ctx->ws.f(pfl) : nullptr;
     rc = nm_launch_pack_conv_weight(weight, Cout, Cin, ks, wp, Cin_pad, Co_pad, ctx->stream);
     if (rc) return rc;
+    if (wp16 && (rc = nm_launch_pack_conv_weight16(weight, Cout, Cin, ks, wp16, Co_pad, ctx->stream))) return rc;
     TensorRef t = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad);
-    rc = nm_launch_conv(t, wp, bias, out, g, part, ctx->stream);
+    rc = nm_launch_conv(t, wp, bias, out, g, part, ctx->stream, Cin, wp16);
     if (rc) return rc;
     if (gn_groups > 0)
         rc = finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)g.OD * g.OH * g.OW * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);

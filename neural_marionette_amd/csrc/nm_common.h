@@ -50,7 +50,12 @@ int nm_launch_pack_conv_weight(const float* w_oidhw, int Cout, int Cin, int ks, 
 int nm_conv_blocks_per_frame(const ConvGeom& g);
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
                    const ConvGeom& g, float* part /*[N][nblk][Cout][2] or null*/, hipStream_t s,
-                   int cin_real = 0 /* un-padded Cin, for the profiler's FLOP count */);
+                   int cin_real = 0 /* un-padded Cin, for the profiler's FLOP count */,
+                   const void* w_packed16 = nullptr /* split-fp16 weights; enables the fp16-split kernel */);
+// conv arithmetic: 0 = exact fp32 MFMA, 1 = split-fp16 MFMA (3 products, fp32 accumulate) where Cin % 16 == 0
+void nm_conv_set_mode(int mode);
+int nm_conv_get_mode();
+int nm_launch_pack_conv_weight16(const float* w_oidhw, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s);
 // first layer: occupancy channel as a taps-as-K GEMM + weight-only constant field (see nm_conv.hip)
 int nm_occ_blocks_per_frame(int G);
 int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s);

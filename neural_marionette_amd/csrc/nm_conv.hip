@@ -383,6 +383,190 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, i
 
 int ceil_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+
+// ---- split-fp16 variant ------------------------------------------------------------------------------------------
+// Same implicit GEMM on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA rate) with fp32-equivalent
+// accuracy: every fp32 operand v is split as v = hi + lo * 2^-11 with hi = fp16(v), lo = fp16((v - hi) * 2^11), and
+//   x * w  ~=  x_hi * w_hi  +  2^-11 (x_hi * w_lo + x_lo * w_hi)
+// (the dropped lo*lo term is <= 2^-22 relative, the size of one fp32 rounding).  fp16 x fp16 products are exact in the
+// fp32 accumulators; the correction terms use their own accumulator so that nothing depends on fp16 subnormals.
+// 3 MFMAs per k-step instead of 1, at 16x the rate.  Activations are split while they are staged into LDS (planes
+// [hi|lo][lane half][halo voxel] of 8 halves = 16 B), weights are split once per weight update
+// ([tap][Cin/16][hi|lo][lane half][Co_pad][8 halves]).  Requires Cin % 16 == 0; other layers use the fp32 kernel.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define NM_SPLIT_SCALE 2048.0f
+
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        _Float16 h0 = (_Float16)a[j], h1 = (_Float16)b[j];
+        hi[j] = h0; hi[4 + j] = h1;
+        lo[j] = (_Float16)((a[j] - (float)h0) * NM_SPLIT_SCALE);
+        lo[4 + j] = (_Float16)((b[j] - (float)h1) * NM_SPLIT_SCALE);
+    }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
+    extern __shared__ f32x4 lds[];
+    half8* ldh = reinterpret_cast<half8*>(lds);                    // [hl*2 + h][HVp] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nblk = p.nbz * p.nby * p.nbx;
+    const int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
+    const int bxi = br % p.nbx, byi = (br / p.nbx) % p.nby, bzi = br / (p.nbx * p.nby);
+    const int oz0 = bzi << p.bz_l2, oy0 = byi << p.by_l2, ox0 = bxi << p.bx_l2;
+    const int co_base = blockIdx.y * (NT * 32);
+    const int BXm = (1 << p.bx_l2) - 1, BYm = (1 << p.by_l2) - 1;
+    int arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (wave * MT + mt) * 32 + l31;
+        int x = m & BXm, y = (m >> p.bx_l2) & BYm, z = m >> (p.bx_l2 + p.by_l2);
+        bool ok = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
+        arow[mt] = ok ? ((z * p.stride) * p.HY + y * p.stride) * p.HX + x * p.stride : 0;
+    }
+    f32x16 acc[MT][NT], accl[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accl[mt][nt][r] = 0.f; }
+
+    const int C16 = p.Cin >> 4;
+    const int taps = p.ks * p.ks * p.ks;
+    const int iz0 = oz0 * p.stride - p.pad, iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+    const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+    const size_t plane = (size_t)p.Co_pad;                          // half8 units between (hl,h) planes of one (tap,c16)
+    const size_t tap_stride = (size_t)C16 * 4 * plane;
+
+    for (int cb = 0; cb < C16; ++cb) {
+        const int c0 = cb << 4;
+        __syncthreads();
+        if (!p.up2) {
+            for (int i = tid; i < p.HV * 2; i += 256) {
+                const int hh = i & 1, hv = i >> 1;
+                int hx = hv % p.HX, t2 = hv / p.HX;
+                int hy = t2 % p.HY, hz = t2 / p.HY;
+                int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+                if ((unsigned)gz < (unsigned)p.ID && (unsigned)gy < (unsigned)p.IH && (unsigned)gx < (unsigned)p.IW) {
+                    a = load_act(p, n, gz, gy, gx, c0 + 8 * hh);
+                    b = load_act(p, n, gz, gy, gx, c0 + 8 * hh + 4);
+                }
+                half8 hi, lo;
+                split8(a, b, hi, lo);
+                ldh[hh * p.HVp + hv] = hi;
+                ldh[(2 + hh) * p.HVp + hv] = lo;
+            }
+        } else {
+            // fused Upsample(x2, trilinear): activated coarse voxels -> LDS (fp32), then interpolate + split
+            f32x4* ldc = lds + 4 * p.HVp;
+            const int cz0 = up_lo(max(iz0, 0)), cy0 = up_lo(max(iy0, 0)), cx0 = up_lo(max(ix0, 0));
+            const int CZ = min(p.ID - 1, up_lo(min(iz0 + p.HZ - 1, 2 * p.ID - 1)) + 1) - cz0 + 1;
+            const int CY = min(p.IH - 1, up_lo(min(iy0 + p.HY - 1, 2 * p.IH - 1)) + 1) - cy0 + 1;
+            const int CX = min(p.IW - 1, up_lo(min(ix0 + p.HX - 1, 2 * p.IW - 1)) + 1) - cx0 + 1;
+            for (int i = tid; i < CZ * CY * CX * 4; i += 256) {
+                int q = i & 3, cv = i >> 2;
+                int x = cv % CX, t2 = cv / CX;
+                int y = t2 % CY, z = t2 / CY;
+                ldc[q * p.CVp + cv] = load_act(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
+            }
+            __syncthreads();
+            for (int i = tid; i < p.HV * 2; i += 256) {
+                const int hh = i & 1, hv = i >> 1;
+                int hx = hv % p.HX, t2 = hv / p.HX;
+                int hy = t2 % p.HY, hz = t2 / p.HY;
+                int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+                f32x4 v[2];
+                v[0] = f32x4{0.f, 0.f, 0.f, 0.f}; v[1] = v[0];
+                if ((unsigned)gz < (unsigned)(2 * p.ID) && (unsigned)gy < (unsigned)(2 * p.IH) && (unsigned)gx < (unsigned)(2 * p.IW)) {
+                    int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+                    up_idx(gz, p.ID, z0, z1, lz); up_idx(gy, p.IH, y0, y1, ly); up_idx(gx, p.IW, x0, x1, lx);
+                    const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
+                    const int r00 = ((z0 - cz0) * CY + (y0 - cy0)) * CX, r01 = ((z0 - cz0) * CY + (y1 - cy0)) * CX;
+                    const int r10 = ((z1 - cz0) * CY + (y0 - cy0)) * CX, r11 = ((z1 - cz0) * CY + (y1 - cy0)) * CX;
+                    const int a0 = x0 - cx0, a1 = x1 - cx0;
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const f32x4* cq = ldc + (2 * hh + qq) * p.CVp;
+                        v[qq] = wz0 * (wy0 * (wx0 * cq[r00 + a0] + lx * cq[r00 + a1]) + ly * (wx0 * cq[r01 + a0] + lx * cq[r01 + a1])) +
+                                lz * (wy0 * (wx0 * cq[r10 + a0] + lx * cq[r10 + a1]) + ly * (wx0 * cq[r11 + a0] + lx * cq[r11 + a1]));
+                    }
+                }
+                half8 hi, lo;
+                split8(v[0], v[1], hi, lo);
+                ldh[hh * p.HVp + hv] = hi;
+                ldh[(2 + hh) * p.HVp + hv] = lo;
+            }
+        }
+        __syncthreads();
+
+        // weights of (tap, cb): planes hi/lo for this lane half
+        const half8* wq = w8 + ((size_t)cb * 4 + h) * plane + co_base + l31;
+        half8 bh[NT], bl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bh[nt] = wq[nt * 32]; bl[nt] = wq[2 * plane + nt * 32]; }
+        int tx = 0, ty = 0, tz = 0;
+        for (int tap = 0; tap < taps; ++tap) {
+            const half8* wn = wq + (size_t)min(tap + 1, taps - 1) * tap_stride;
+            half8 bhn[NT], bln[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bhn[nt] = wn[nt * 32]; bln[nt] = wn[2 * plane + nt * 32]; }
+            const int tapoff = (tz * p.HY + ty) * p.HX + tx;
+            half8 ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                ah[mt] = ldh[h * p.HVp + arow[mt] + tapoff];
+                al[mt] = ldh[(2 + h) * p.HVp + arow[mt] + tapoff];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], accl[mt][nt], 0, 0, 0);
+                    accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], accl[mt][nt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bh[nt] = bhn[nt]; bl[nt] = bln[nt]; }
+            if (++tx == p.ks) { tx = 0; if (++ty == p.ks) { ty = 0; ++tz; } }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] += accl[mt][nt][r] * (1.0f / NM_SPLIT_SCALE);
+    EpiArgs e;
+    e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
+    e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = p.bz_l2; e.by_l2 = p.by_l2; e.bx_l2 = p.bx_l2;
+    __syncthreads();
+    epilogue<MT, NT>(e, reinterpret_cast<float*>(lds), acc, n, br, nblk, oz0, oy0, ox0, co_base);
+}
+
+// OIDHW fp32 -> split fp16 [tap][Cin/16][hi|lo][lane half][Co_pad][8]
+__global__ void pack_conv_weight16_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, _Float16* __restrict__ packed,
+                                          int Co_pad) {
+    const int taps = ks * ks * ks, C16 = Cin >> 4;
+    const size_t total = (size_t)taps * C16 * 2 * Co_pad * 8;          // (tap, cb, h, co, j): writes hi and lo
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int j = i & 7; size_t r = i >> 3;
+        int co = r % Co_pad; r /= Co_pad;
+        int hh = r & 1; r >>= 1;
+        int cb = r % C16; int tap = r / C16;
+        int ci = cb * 16 + hh * 8 + j;
+        float v = (co < Cout) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+        _Float16 hi = (_Float16)v;
+        _Float16 lo = (_Float16)((v - (float)hi) * NM_SPLIT_SCALE);
+        size_t base = ((((size_t)tap * C16 + cb) * 4) * Co_pad) * 8;
+        packed[base + ((size_t)hh * Co_pad + co) * 8 + j] = hi;
+        packed[base + ((size_t)(2 + hh) * Co_pad + co) * 8 + j] = lo;
+    }
+}
+
 struct Tiling { int MT, NT, bz_l2, by_l2, bx_l2, nbz, nby, nbx, KC, HZ, HY, HX, HV, HVp, CVp; size_t lds_bytes; };
 
 Tiling choose_tiling(const ConvGeom& g, int Cin) {
@@ -446,7 +630,40 @@ int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
     return nm_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
+template <int MT, int NT>
+int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16s)");
+        attr_set = true;
+    }
+    ProfRec rec;
+    if (g_prof_on) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 5 + (NT - 1);
+        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
+        (void)hipEventRecord(rec.a, s);
+    }
+    hipLaunchKernelGGL((conv_f16s_kernel<MT, NT>), grid, dim3(256), t.lds_bytes, s, p);
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    return nm_check_hip(hipGetLastError(), "conv_f16s launch");
+}
+
+int g_conv_mode = 1;      // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
+
 }  // namespace
+
+void nm_conv_set_mode(int mode) { g_conv_mode = mode; }
+int nm_conv_get_mode() { return g_conv_mode; }
+
+int nm_launch_pack_conv_weight16(const float* w, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s) {
+    if (Cin % 16 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("pack_conv_weight16: Cin=%d must be a multiple of 16", Cin); return NM_ERR_ARG; }
+    size_t total = (size_t)ks * ks * ks * (Cin / 16) * 2 * Co_pad * 8;
+    int blocks = (int)min((total + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(pack_conv_weight16_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, ks, reinterpret_cast<_Float16*>(packed), Co_pad);
+    return nm_check_hip(hipGetLastError(), "pack_conv_weight16 launch");
+}
 
 size_t nm_packed_weight_floats(int ks, int Cin_pad, int Co_pad) {
     return (size_t)ks * ks * ks * Cin_pad * Co_pad;
@@ -492,7 +709,7 @@ void nm_conv_prof_reset() {
 }
 
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
-                   const ConvGeom& g, float* part, hipStream_t s, int cin_real) {
+                   const ConvGeom& g, float* part, hipStream_t s, int cin_real, const void* w_packed16) {
     if (in.C % 8 != 0 || g.Co_pad % 32 != 0 || g.Cout > g.Co_pad || g.Cout <= 0) {
         nm_set_error("conv: unsupported channels Cin=%d Cout=%d Co_pad=%d", in.C, g.Cout, g.Co_pad);
         return NM_ERR_ARG;
@@ -518,6 +735,10 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.up2 = g.up2 ? 1 : 0;
     p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
+    if (g_conv_mode == 1 && w_packed16 && in.C % 16 == 0 && t.KC == 16 && t.MT == 2) {
+        p.w = static_cast<const float*>(w_packed16);
+        return t.NT == 2 ? launch_f16s<2, 2>(p, t, grid, s) : launch_f16s<2, 1>(p, t, grid, s);
+    }
     if (t.MT == 2 && t.NT == 2) return launch_t<2, 2>(p, t, grid, s);
     if (t.MT == 2 && t.NT == 1) return launch_t<2, 1>(p, t, grid, s);
     if (t.MT == 1 && t.NT == 2) return launch_t<1, 2>(p, t, grid, s);

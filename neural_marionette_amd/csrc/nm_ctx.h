@@ -27,7 +27,12 @@ struct Arena {
 };
 
 // ---- network weights (ctx-owned device copies) -------------------------------------------
-struct ConvW { int Cin = 0, Cin_pad = 0, Cout = 0, Co_pad = 0, ks = 0; float* wp = nullptr; float* bias = nullptr; };
+struct ConvW {
+    int Cin = 0, Cin_pad = 0, Cout = 0, Co_pad = 0, ks = 0;
+    float* wp = nullptr;      // fp32 packed [tap][Cin/4][Co_pad][4]
+    void* wp16 = nullptr;     // split-fp16 packed (Cin % 16 == 0 only), see nm_conv.hip
+    float* bias = nullptr;
+};
 struct NormW { int C = 0, groups = 0; float* gamma = nullptr; float* beta = nullptr; };
 struct ResW { ConvW c1, c2, cs; NormW n1, n2, ns; bool has_skip = false; };
 struct PoolW { ConvW c; NormW n; };

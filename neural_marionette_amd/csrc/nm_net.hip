@@ -54,6 +54,11 @@ struct Loader {
         w.wp = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, w.Cin_pad, w.Co_pad));
         if (!w.wp) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
         int r = nm_launch_pack_conv_weight(src, Cout, Cin, ks, w.wp, w.Cin_pad, w.Co_pad, c->stream);
+        if (!r && Cin % 16 == 0) {
+            w.wp16 = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, Cin, w.Co_pad));      // same byte count as fp32
+            if (!w.wp16) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
+            r = nm_launch_pack_conv_weight16(src, Cout, Cin, ks, w.wp16, w.Co_pad, c->stream);
+        }
         if (r && !rc) rc = r;
         return w;
     }
@@ -172,7 +177,7 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
     if (n.live()) {
         if (in.C != w.Cin_pad) { nm_set_error("conv_gn: input has %d channels, layer expects %d", in.C, w.Cin_pad); n.rc = NM_ERR_STATE; }
         else {
-            n.run(nm_launch_conv(in, w.wp, w.bias, out, g, part, n.s, w.Cin));
+            n.run(nm_launch_conv(in, w.wp, w.bias, out, g, part, n.s, w.Cin, w.wp16));
             if (gn) n.run(nm_launch_gn_finalize(part, in.N, nblk, w.Cout, gn->groups, (double)ov * (w.Cout / gn->groups),
                                                 gn->gamma, gn->beta, 1e-5f, scale, shift, n.s));
         }

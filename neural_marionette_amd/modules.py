@@ -17,6 +17,7 @@ graph (the training step is the next row of SURVEY §8(f)).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import namedtuple
 from typing import Dict, Optional
 
@@ -57,6 +58,8 @@ class Engine:
         self.ctx: Optional[_lib.Context] = None
         self._stamp = None
         self._named = None
+        # conv arithmetic: 1 = split-fp16 MFMA with fp32-equivalent accuracy (default), 0 = exact fp32 MFMA
+        self.conv_mode = 0 if os.environ.get("NM355_CONV_MODE", "split16").lower() in ("fp32", "0", "exact") else 1
 
     # -- plumbing ---------------------------------------------------------------------------
     def _device(self) -> torch.device:
@@ -78,6 +81,7 @@ class Engine:
             self.ctx = _lib.Context(cfg)
             self._stamp = None
         self.ctx.bind_stream()
+        _lib.check(self.ctx.lib.nm_set_conv_mode(self.ctx.handle, self.conv_mode), "set_conv_mode")
         self._sync_weights()
         return self.ctx
 
@@ -405,6 +409,13 @@ class NeuralMarionette(nn.Module):
     def anneal(self, nepoch, nbatch=None):
         if nbatch is None:
             self.kypt_detector.anneal(nepoch)
+
+    def set_conv_mode(self, mode: str) -> None:
+        """'split16' (default): convs with Cin % 16 == 0 on the fp16 matrix cores, operands split hi/lo, fp32
+        accumulate (fp32-equivalent accuracy); 'fp32': exact fp32 MFMA everywhere."""
+        if mode not in ("split16", "fp32"):
+            raise ValueError("conv mode must be 'split16' or 'fp32'")
+        self._engine.conv_mode = 1 if mode == "split16" else 0
 
     def control_active(self, module_actives):
         """neural_marionette.py:22-32."""

@@ -22,12 +22,16 @@ KP_TOL = 1e-4
 ACTS = {"detector": True, "learner": True}
 
 
-def _net(o, sd):
+def _net(o, sd, mode="split16"):
     net = NeuralMarionette(o)
     net.load_state_dict(sd)
     net = net.cuda().eval()
     net.anneal(1)
+    net.set_conv_mode(mode)
     return net
+
+
+MODES = ["split16", "fp32"]
 
 
 def _err(a, b):
@@ -47,12 +51,13 @@ def _check_losses(out, ref_losses, tol=2e-5):
         assert e <= tol * max(1.0, abs(r)), f"{k}: got {float(out[k])} want {r}"
 
 
-def test_g2_forward32_vs_reference_fixture(golden_dir):
+@pytest.mark.parametrize("mode", MODES)
+def test_g2_forward32_vs_reference_fixture(golden_dir, mode):
     g = _load(golden_dir, "g2_forward32.npz")
     G, B, T, wseed, iseed, eseed = [int(v) for v in g["meta"]]
     o = HotPathOptions(grid_size=G)
     sd = synth.make_state_dict(o, seed=wseed, variant=str(g["variant"]))
-    net = _net(o, sd)
+    net = _net(o, sd, mode)
     vox = synth.figure_clip(B, T, G, seed=iseed)
     eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=eseed)
     out = net(vox.cuda(), ACTS, eps=eps.cuda())
@@ -101,11 +106,12 @@ def test_g2_vrnn_unit_parity_on_reference_keypoints(golden_dir):
     assert out["gae_recon_loss"].dtype == torch.int64
 
 
-def test_g1_config1_detector64(golden_dir):
+@pytest.mark.parametrize("mode", MODES)
+def test_g1_config1_detector64(golden_dir, mode):
     g = _load(golden_dir, "g1_detector64.npz")
     G, B, T, wseed, iseed = [int(v) for v in g["meta"]]
     o = HotPathOptions(grid_size=G)
-    net = _net(o, synth.make_state_dict(o, seed=wseed, variant=str(g["variant"])))
+    net = _net(o, synth.make_state_dict(o, seed=wseed, variant=str(g["variant"])), mode)
     vox = synth.figure_clip(B, T, G, seed=iseed)
     out = net.kypt_detector(vox.cuda())
     torch.cuda.synchronize()
@@ -194,11 +200,12 @@ def test_submodule_callables_vs_oracle():
         assert _err(hn, O.gru_cell(sd, torch.cat([f, zz], -1), h)) < 2e-5
 
 
-def test_config2_full_size_vs_oracle():
+@pytest.mark.parametrize("mode", MODES)
+def test_config2_full_size_vs_oracle(mode):
     """BASELINE config 2: 64^3, B=4, T=16 full forward, fp32, against the CPU oracle."""
     o = HotPathOptions(grid_size=64)
     sd = synth.make_state_dict(o, seed=42, variant="peaky")
-    net = _net(o, sd)
+    net = _net(o, sd, mode)
     B, T = 4, 16
     vox = synth.figure_clip(B, T, 64, seed=77)
     eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=78)

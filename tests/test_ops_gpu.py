@@ -64,9 +64,11 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "split16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "ci%d_co%d_k%d_s%d_d%d" % (c[0], c[1], c[2], c[3], c[5]))
-def test_conv3d(ctx, case):
+def test_conv3d(ctx, case, mode):
     from neural_marionette_amd import _lib
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, mode), "set_conv_mode")
     Cin, Cout, ks, stride, pad, size, N, prologue, groups = case
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     dims = (size, size + (1 if size % 2 else 0) * 0, size)
@@ -105,11 +107,13 @@ def test_conv3d(ctx, case):
         assert e < REL, f"fused GroupNorm rel err {e:.3e}"
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "split16"])
 @pytest.mark.parametrize("Cin,Cout,size,prologue", [(128, 64, 8, False), (64, 32, 12, True), (16, 32, 5, True)])
-def test_conv3d_fused_upsample(ctx, Cin, Cout, size, prologue):
+def test_conv3d_fused_upsample(ctx, Cin, Cout, size, prologue, mode):
     """Upsample(x2, trilinear, align_corners=False) -> Conv3d(k3) -> GroupNorm, the upsampling fused into the
     conv's staging (decoder layers .0/.1 and .7/.8 of kypt_detector.py:427-444)."""
     from neural_marionette_amd import _lib
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, mode), "set_conv_mode")
     g = torch.Generator().manual_seed(Cin + size)
     N = 2
     x = torch.randn(N, Cin, size, size, size, generator=g)
@@ -264,3 +268,30 @@ def test_cl_to_ncdhw(ctx):
     _lib.check(ctx.lib.nm_op_cl_to_ncdhw(ctx.handle, _lib.ptr(xd), 2, 100, 40, _lib.ptr(out)), "cl_to_ncdhw")
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), x.permute(0, 2, 1))
+
+
+def test_split16_matches_fp32_on_wide_dynamic_range(ctx):
+    """The split-fp16 path must stay fp32-equivalent for tiny weights (fp16 subnormal range) and large activations."""
+    from neural_marionette_amd import _lib
+    g = torch.Generator().manual_seed(99)
+    N, Cin, Cout, size = 1, 64, 64, 12
+    x = torch.randn(N, Cin, size, size, size, generator=g) * torch.logspace(-3, 2, Cin)[None, :, None, None, None]
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * torch.logspace(-5, -1, Cout)[:, None, None, None, None]
+    b = torch.zeros(Cout)
+    ref = F.conv3d(x.double(), w.double(), None, padding=1)
+    outs = []
+    for mode in (0, 1):
+        _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, mode), "set_conv_mode")
+        out = torch.full((N, size, size, size, Cout), float("nan")).cuda()
+        xd, wd, bd = to_cl(x), dev(w), dev(b)
+        _lib.check(ctx.lib.nm_op_conv3d(ctx.handle, _lib.ptr(xd), N, size, size, size, Cin, None, None, 1.0, _lib.ptr(wd),
+                                        _lib.ptr(bd), Cout, 3, 1, 1, _lib.ptr(out), 0, None, None, None, None, 0), "op_conv3d")
+        torch.cuda.synchronize()
+        outs.append(from_cl(out, Cout).double())
+    # per output channel relative error (channels span 4 decades of weight scale)
+    scale = ref.abs().amax(dim=(0, 2, 3, 4)) + 1e-300
+    e32 = ((outs[0] - ref).abs().amax(dim=(0, 2, 3, 4)) / scale).max().item()
+    e16 = ((outs[1] - ref).abs().amax(dim=(0, 2, 3, 4)) / scale).max().item()
+    print("per-channel rel err vs fp64: fp32 MFMA %.3e, split-fp16 %.3e" % (e32, e16))
+    assert e32 < 2e-5 and e16 < 2e-5
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, 1), "set_conv_mode")
