@@ -26,6 +26,8 @@
 
 namespace {
 
+#define NM_SPLIT_SCALE 2048.0f   // lo parts of the split-fp16 operands are stored times 2^11
+
 struct ConvParams {
     const float* in; const float* in_scale; const float* in_shift; float in_slope;
     int N, ID, IH, IW, Cin;
@@ -40,10 +42,28 @@ struct ConvParams {
     int up2;                      // input is stored at half resolution: stage its trilinear x2 upsampling
     int HZ, HY, HX, HV, HVp;      // halo dims, voxels, padded plane stride (HVp % 8 == 2)
     int CVp;                      // up2: plane stride of the coarse LDS tile
+    int ZP;                       // f16s: pitch between halo z-planes in LDS (>= HY*HX, = 4 mod 16)
+#ifdef NM_DIAG
+    unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
+#endif
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+
+__device__ __forceinline__ f32x4 load_raw(const ConvParams& p, int n, int z, int y, int x, int c) {
+    return *reinterpret_cast<const f32x4*>(p.in + ((((size_t)n * p.ID + z) * p.IH + y) * p.IW + x) * p.Cin + c);
+}
+
+// pending GroupNorm of the producer: x * scale + shift, LeakyReLU
+__device__ __forceinline__ f32x4 apply_act(const ConvParams& p, f32x4 v, const f32x4& sc, const f32x4& sh) {
+    if (p.in_scale) v = v * sc + sh;
+    if (p.in_slope != 1.0f) {            // LeakyReLU with slope in [0,1): max(v, slope * v)
+        v[0] = fmaxf(v[0], v[0] * p.in_slope); v[1] = fmaxf(v[1], v[1] * p.in_slope);
+        v[2] = fmaxf(v[2], v[2] * p.in_slope); v[3] = fmaxf(v[3], v[3] * p.in_slope);
+    }
+    return v;
+}
 
 // activated input sample: x * scale + shift, LeakyReLU (the producer's pending GroupNorm)
 __device__ __forceinline__ f32x4 load_act(const ConvParams& p, int n, int z, int y, int x, int c) {
@@ -120,6 +140,7 @@ __device__ __forceinline__ void mfma_chunk(const ConvParams& p, const f32x4* lds
 struct EpiArgs {
     float* out; float* part; const float* bias; const float* field;
     int OD, OH, OW, Cout, bz_l2, by_l2, bx_l2;
+    int xz_tiles;      // 1: each 32-row MFMA tile is an 8(x) x 4(z) slab at one y (conflict-free ds_read_b128, see conv_f16s)
 };
 
 template <int MT, int NT>
@@ -141,12 +162,76 @@ __device__ __forceinline__ void epilogue(const EpiArgs& p, float* red /*[4][NT*3
                 int row = (r & 3) + 8 * (r >> 2) + 4 * h;
                 int m = (wave * MT + mt) * 32 + row;
                 int x = m & BXm, y = (m >> p.bx_l2) & BYm, z = m >> (p.bx_l2 + p.by_l2);
+                if (p.xz_tiles) { const int c = row >> 2; x = (((0x96 >> c) & 1) << 2) + (row & 3); z = c >> 1; y = wave * MT + mt; }
                 int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
                 if (cv && oz < p.OD && oy < p.OH && ox < p.OW) {
                     const size_t vo = (((size_t)oz * p.OH + oy) * p.OW + ox) * p.Cout + co;
                     float v = acc[mt][nt][r] + (p.field ? p.field[vo] : bv);
                     p.out[(size_t)n * p.OD * p.OH * p.OW * p.Cout + vo] = v;
                     s += v; ss += v * v;
+                }
+            }
+        }
+        if (p.part) {
+            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+            if (h == 0) { red[(wave * NT * 32 + nt * 32 + l31) * 2] = s; red[(wave * NT * 32 + nt * 32 + l31) * 2 + 1] = ss; }
+        }
+    }
+    if (p.part) {
+        __syncthreads();
+        if (tid < NT * 32) {
+            int co = co_base + tid;
+            if (co < p.Cout) {
+                float s = 0.f, ss = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { s += red[(wv * NT * 32 + tid) * 2]; ss += red[(wv * NT * 32 + tid) * 2 + 1]; }
+                float* dst = p.part + (((size_t)n * nblk + br) * p.Cout + co) * 2;
+                dst[0] = s; dst[1] = ss;
+            }
+        }
+    }
+}
+
+// Epilogue of the 8(x) x 4(z) tile mapping.  Register r of a 32x32 accumulator is row (r&3) + 8(r>>2) + 4h, i.e.
+// z = r>>2, x = 4 * (h ^ G[r>>2]) + (r&3) with G = {0,1,1,0}; y is the tile index.  Interior bricks with all 32
+// channels of every N tile valid take the branch-free path: one base pointer per tile, constant row offsets.
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_xz(const EpiArgs& p, float* red, f32x16 (&acc)[MT][NT], f32x16 (&accl)[MT][NT], int n,
+                                            int br, int nblk, int oz0, int oy0, int ox0, int co_base) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const bool interior = (oz0 + 4 <= p.OD) && (oy0 + 8 <= p.OH) && (ox0 + 8 <= p.OW) && (co_base + NT * 32 <= p.Cout);
+    const size_t sX = (size_t)p.Cout, sZ = (size_t)p.OH * p.OW * p.Cout;
+    const size_t xo0 = (size_t)(4 * h) * sX, xo1 = (size_t)(4 * (h ^ 1)) * sX;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co_base + nt * 32 + l31;
+        const bool cv = co < p.Cout;
+        const float bv = (cv && p.bias) ? p.bias[co] : 0.f;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int y = wave * MT + mt;
+            float* base = p.out + ((((size_t)n * p.OD + oz0) * p.OH + oy0 + y) * p.OW + ox0) * sX + co;
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = r >> 2;
+                    const size_t off = (size_t)g * sZ + ((g == 1 || g == 2) ? xo1 : xo0) + (size_t)(r & 3) * sX;
+                    const float v = (acc[mt][nt][r] + accl[mt][nt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
+                    base[off] = v;
+                    s += v; ss += v * v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = r >> 2;
+                    const int x = 4 * (h ^ ((g == 1 || g == 2) ? 1 : 0)) + (r & 3);
+                    if (cv && oz0 + g < p.OD && oy0 + y < p.OH && ox0 + x < p.OW) {
+                        const float v = (acc[mt][nt][r] + accl[mt][nt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
+                        base[(size_t)g * sZ + (size_t)x * sX] = v;
+                        s += v; ss += v * v;
+                    }
                 }
             }
         }
@@ -245,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_kernel(OccParams p) {
     }
     EpiArgs e;
     e.out = p.out; e.part = p.part; e.bias = nullptr; e.field = p.field;
-    e.OD = p.G; e.OH = p.G; e.OW = p.G; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3;
+    e.OD = p.G; e.OH = p.G; e.OW = p.G; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3; e.xz_tiles = 0;
     __syncthreads();
     epilogue<2, NT>(e, tile + 8 * 12 * 12, acc, n, br, nblk, oz0, oy0, ox0, co_base);
 }
@@ -358,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 
     EpiArgs e;
     e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
-    e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = p.bz_l2; e.by_l2 = p.by_l2; e.bx_l2 = p.bx_l2;
+    e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = p.bz_l2; e.by_l2 = p.by_l2; e.bx_l2 = p.bx_l2; e.xz_tiles = 0;
     __syncthreads();
     epilogue<MT, NT>(e, reinterpret_cast<float*>(lds), acc, n, br, nblk, oz0, oy0, ox0, co_base);
 }
@@ -394,37 +479,68 @@ int ceil_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // [hi|lo][lane half][halo voxel] of 8 halves = 16 B), weights are split once per weight update
 // ([tap][Cin/16][hi|lo][lane half][Co_pad][8 halves]).  Requires Cin % 16 == 0; other layers use the fp32 kernel.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-#define NM_SPLIT_SCALE 2048.0f
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, half8& hi, half8& lo) {
+    // pairwise so that the conversions can use the packed cvt instructions
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        _Float16 h0 = (_Float16)a[j], h1 = (_Float16)b[j];
-        hi[j] = h0; hi[4 + j] = h1;
-        lo[j] = (_Float16)((a[j] - (float)h0) * NM_SPLIT_SCALE);
-        lo[4 + j] = (_Float16)((b[j] - (float)h1) * NM_SPLIT_SCALE);
+        const f32x2 v = (j < 2) ? f32x2{a[2 * j], a[2 * j + 1]} : f32x2{b[2 * j - 4], b[2 * j - 3]};
+        const half2v hh = __builtin_convertvector(v, half2v);
+        const f32x2 back = __builtin_convertvector(hh, f32x2);
+        const half2v ll = __builtin_convertvector((v - back) * NM_SPLIT_SCALE, half2v);
+        hi[2 * j] = hh[0]; hi[2 * j + 1] = hh[1];
+        lo[2 * j] = ll[0]; lo[2 * j + 1] = ll[1];
     }
 }
 
-template <int MT, int NT>
+// Brick = 4(z) x 8(y) x 8(x) output voxels, 256 GEMM rows.  Each 32-row MFMA tile is the 8(x) x 4(z) slab of one
+// brick row y: with the halo tile's plane pitch ZP = 4 (mod 16) slots, the four 16-lane groups of a ds_read_b128
+// then hit 16 distinct 16-B slots (conflict-free; the natural (y,x) tile order is a 3-way conflict and makes the
+// Cout = 32 layers LDS-bound).  Staging: thread -> one (halo row position, lane half), loops over the halo planes, so
+// all index arithmetic and the y/x interpolation weights are computed once per kernel.
+template <int MT, int NT, int KS, bool UP2>
 __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
+    constexpr int HZ = KS + 3;                                     // halo planes of a 4-deep brick, stride 1
+    constexpr int HB = HZ / 2;                                     // planes per load batch
+    // Cout = 32 layers: the weights of 9 taps at a time are shared by the block's four waves through LDS (double
+    // buffered, filled by direct-to-LDS loads one tap-group ahead).  Four waves each fetching their own copy of
+    // B from L2 keep the CU's vector-memory path ~70 % busy and stretch the MFMA phase by ~40 %.
+    constexpr bool BLDS = (NT == 1 && KS == 3);
+    constexpr int GB = 9 * 4 * 32 * NT;                            // half8 slots of one 9-tap weight group
     extern __shared__ f32x4 lds[];
-    half8* ldh = reinterpret_cast<half8*>(lds);                    // [hl*2 + h][HVp] x 16 B
+    half8* ldh = reinterpret_cast<half8*>(lds);                    // [hl*2 + h][HVp] x 16 B, voxel = hz*ZP + hy*HX + hx
+    half8* ldb = ldh + 4 * p.HVp;                                  // BLDS: two weight-group buffers of GB slots
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int nblk = p.nbz * p.nby * p.nbx;
-    const int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
-    const int bxi = br % p.nbx, byi = (br / p.nbx) % p.nby, bzi = br / (p.nbx * p.nby);
-    const int oz0 = bzi << p.bz_l2, oy0 = byi << p.by_l2, ox0 = bxi << p.bx_l2;
     const int co_base = blockIdx.y * (NT * 32);
-    const int BXm = (1 << p.bx_l2) - 1, BYm = (1 << p.by_l2) - 1;
+    const int C16 = p.Cin >> 4;
+    const int taps = p.ks * p.ks * p.ks;
+    const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+    const size_t plane = (size_t)p.Co_pad;                          // half8 units between (hl,h) planes of one (tap,c16)
+    const size_t tap_stride = (size_t)C16 * 4 * plane;
+    // Persistent workgroups: each walks a contiguous run of bricks (neighbouring bricks share halo voxels -> L2 reuse
+    // in time, and the ~10 us a short-lived workgroup spends being dispatched and retired is paid once).
+    const int total_items = p.N * nblk;
+    const int per = (total_items + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int item_end = min(total_items, ((int)blockIdx.x + 1) * per);
+    for (int item = (int)blockIdx.x * per; item < item_end; ++item) {
+    const int n = item / nblk, br = item % nblk;
+    const int bxi = br % p.nbx, byi = (br / p.nbx) % p.nby, bzi = br / (p.nbx * p.nby);
+    const int oz0 = bzi << 2, oy0 = byi << 3, ox0 = bxi << 3;
     int arow[MT];
+    {
+        const int c = l31 >> 2;
+        const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = (wave * MT + mt) * 32 + l31;
-        int x = m & BXm, y = (m >> p.bx_l2) & BYm, z = m >> (p.bx_l2 + p.by_l2);
-        bool ok = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
-        arow[mt] = ok ? ((z * p.stride) * p.HY + y * p.stride) * p.HX + x * p.stride : 0;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int y = wave * MT + mt;
+            bool ok = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
+            arow[mt] = ok ? z * p.stride * p.ZP + y * p.stride * p.HX + x * p.stride : 0;
+        }
     }
     f32x16 acc[MT][NT], accl[MT][NT];
 #pragma unroll
@@ -434,117 +550,301 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accl[mt][nt][r] = 0.f; }
 
-    const int C16 = p.Cin >> 4;
-    const int taps = p.ks * p.ks * p.ks;
     const int iz0 = oz0 * p.stride - p.pad, iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
-    const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
-    const size_t plane = (size_t)p.Co_pad;                          // half8 units between (hl,h) planes of one (tap,c16)
-    const size_t tap_stride = (size_t)C16 * 4 * plane;
 
+    // this thread's staging column: halo position (hy,hx) and lane half
+    const int s_hh = tid & 1, s_r = tid >> 1;
+    const bool s_on = s_r < p.HY * p.HX;
+    const int s_hy = s_r / p.HX, s_hx = s_r % p.HX;
+    const int s_gy = iy0 + s_hy, s_gx = ix0 + s_hx;
+    const int s_lds = s_hy * p.HX + s_hx;
+    const int us = UP2 ? 2 : 1;
+    const bool s_in = s_on && (unsigned)s_gy < (unsigned)(us * p.IH) && (unsigned)s_gx < (unsigned)(us * p.IW);
+    // up2: coarse tile geometry and this column's y/x interpolation
+    int cz0 = 0, cy0 = 0, cx0 = 0, CZ = 0, CY = 0, CX = 0, u_r0 = 0, u_r1 = 0, u_a0 = 0, u_a1 = 0;
+    float u_ly = 0.f, u_lx = 0.f;
+    if (UP2) {
+        cz0 = up_lo(max(iz0, 0)); cy0 = up_lo(max(iy0, 0)); cx0 = up_lo(max(ix0, 0));
+        CZ = min(p.ID - 1, up_lo(min(iz0 + p.HZ - 1, 2 * p.ID - 1)) + 1) - cz0 + 1;
+        CY = min(p.IH - 1, up_lo(min(iy0 + p.HY - 1, 2 * p.IH - 1)) + 1) - cy0 + 1;
+        CX = min(p.IW - 1, up_lo(min(ix0 + p.HX - 1, 2 * p.IW - 1)) + 1) - cx0 + 1;
+        if (s_in) {
+            int y0, y1, x0, x1;
+            up_idx(s_gy, p.IH, y0, y1, u_ly); up_idx(s_gx, p.IW, x0, x1, u_lx);
+            u_r0 = (y0 - cy0) * CX; u_r1 = (y1 - cy0) * CX; u_a0 = x0 - cx0; u_a1 = x1 - cx0;
+        }
+    }
+
+#ifdef NM_DIAG
+#define NM_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)item * 16 + (i)] = clock64(); } while (0)
+#else
+#define NM_STAMP(i) do {} while (0)
+#endif
+    // direct-to-LDS copy of the weights of taps [9g, 9g+9) of chunk cb into weight buffer `buf`
+    auto issue_b_group = [&](int cb, int g, int buf) {
+        if (!BLDS) return;
+        constexpr int PER_TAP = 2 * NT;                            // 1-KiB wave-instructions per tap
+#pragma unroll
+        for (int k = 0; k < (9 * PER_TAP + 3) / 4; ++k) {
+            const int j = wave + 4 * k;                            // wave-uniform instruction index within the group
+            if (j < 9 * PER_TAP) {
+                const int t = j / PER_TAP, sl = (j % PER_TAP) * 64 + lane;     // slot within the tap's 128*NT slots
+                const int pl = sl / (32 * NT), co = sl % (32 * NT);
+                const half8* src = w8 + ((size_t)(9 * g + t) * C16 * 4 + (size_t)cb * 4 + pl) * plane + co_base + co;
+                half8* dst = ldb + buf * GB + t * (128 * NT) + (j % PER_TAP) * 64;         // + lane * 16 B by hardware
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    // raw input of one channel chunk, fetched one chunk ahead (BLDS variants: there are registers to spare at 2 waves/SIMD)
+    constexpr bool PFA = BLDS;
+    f32x4 pa[PFA && !UP2 ? HZ : 1], pb[PFA && !UP2 ? HZ : 1], prc[4];
+    int pci[4] = {-1, -1, -1, -1};
+    auto prefetch_chunk = [&](int c0) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        if (!UP2) {
+            if (s_on) {
+#pragma unroll
+                for (int hz = 0; hz < (PFA && !UP2 ? HZ : 1); ++hz) {
+                    const int gz = iz0 + hz;
+                    const bool in = s_in && (unsigned)gz < (unsigned)p.ID;
+                    pa[hz] = in ? load_raw(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh) : z4;
+                    pb[hz] = in ? load_raw(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh + 4) : z4;
+                }
+            }
+        } else {
+            const int ncv = CZ * CY * CX * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + 256 * k;
+                pci[k] = -1; prc[k] = z4;
+                if (i < ncv) {
+                    int q = i & 3, cv = i >> 2;
+                    int x = cv % CX, t2 = cv / CX;
+                    int y = t2 % CY, z = t2 / CY;
+                    pci[k] = q * p.CVp + cv;
+                    prc[k] = load_raw(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
+                }
+            }
+        }
+    };
+    if (PFA) prefetch_chunk(0);
+    NM_STAMP(0);
     for (int cb = 0; cb < C16; ++cb) {
         const int c0 = cb << 4;
         __syncthreads();
-        if (!p.up2) {
-            for (int i = tid; i < p.HV * 2; i += 256) {
-                const int hh = i & 1, hv = i >> 1;
-                int hx = hv % p.HX, t2 = hv / p.HX;
-                int hy = t2 % p.HY, hz = t2 / p.HY;
-                int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
-                f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-                if ((unsigned)gz < (unsigned)p.ID && (unsigned)gy < (unsigned)p.IH && (unsigned)gx < (unsigned)p.IW) {
-                    a = load_act(p, n, gz, gy, gx, c0 + 8 * hh);
-                    b = load_act(p, n, gz, gy, gx, c0 + 8 * hh + 4);
+        if (cb < 2) NM_STAMP(1 + cb * 4);
+        issue_b_group(cb, 0, 0);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        if (!UP2) {
+            if (s_on) {
+                f32x4 sca = zero4, sha = zero4, scb = zero4, shb = zero4;
+                if (p.in_scale) {
+                    const float* ps = p.in_scale + (size_t)n * p.Cin + c0 + 8 * s_hh; const float* ph = p.in_shift + (size_t)n * p.Cin + c0 + 8 * s_hh;
+                    sca = *reinterpret_cast<const f32x4*>(ps); scb = *reinterpret_cast<const f32x4*>(ps + 4);
+                    sha = *reinterpret_cast<const f32x4*>(ph); shb = *reinterpret_cast<const f32x4*>(ph + 4);
                 }
-                half8 hi, lo;
-                split8(a, b, hi, lo);
-                ldh[hh * p.HVp + hv] = hi;
-                ldh[(2 + hh) * p.HVp + hv] = lo;
+                if (PFA) {
+                    // the raw column was prefetched (before the loop / during the previous chunk's last tap group)
+#pragma unroll
+                    for (int hz = 0; hz < HZ; ++hz) {
+                        const int gz = iz0 + hz;
+                        const bool in = s_in && (unsigned)gz < (unsigned)p.ID;
+                        f32x4 a = in ? apply_act(p, pa[hz], sca, sha) : zero4;
+                        f32x4 b = in ? apply_act(p, pb[hz], scb, shb) : zero4;
+                        half8 hi, lo;
+                        split8(a, b, hi, lo);
+                        ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
+                        ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
+                    }
+                } else {
+                    // global loads of half the column first (HB planes x 8 channels), then activate / split / write
+#pragma unroll
+                    for (int hb = 0; hb < HZ; hb += HB) {
+                        f32x4 ra[HB], rb[HB];
+#pragma unroll
+                        for (int j = 0; j < HB; ++j) {
+                            const int gz = iz0 + hb + j;
+                            const bool in = s_in && (unsigned)gz < (unsigned)p.ID;
+                            ra[j] = in ? load_raw(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh) : zero4;
+                            rb[j] = in ? load_raw(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh + 4) : zero4;
+                        }
+#pragma unroll
+                        for (int j = 0; j < HB; ++j) {
+                            const int hz = hb + j, gz = iz0 + hz;
+                            const bool in = s_in && (unsigned)gz < (unsigned)p.ID;
+                            f32x4 a = in ? apply_act(p, ra[j], sca, sha) : zero4;
+                            f32x4 b = in ? apply_act(p, rb[j], scb, shb) : zero4;
+                            half8 hi, lo;
+                            split8(a, b, hi, lo);
+                            ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
+                            ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
+                        }
+                    }
+                }
             }
         } else {
             // fused Upsample(x2, trilinear): activated coarse voxels -> LDS (fp32), then interpolate + split
-            f32x4* ldc = lds + 4 * p.HVp;
-            const int cz0 = up_lo(max(iz0, 0)), cy0 = up_lo(max(iy0, 0)), cx0 = up_lo(max(ix0, 0));
-            const int CZ = min(p.ID - 1, up_lo(min(iz0 + p.HZ - 1, 2 * p.ID - 1)) + 1) - cz0 + 1;
-            const int CY = min(p.IH - 1, up_lo(min(iy0 + p.HY - 1, 2 * p.IH - 1)) + 1) - cy0 + 1;
-            const int CX = min(p.IW - 1, up_lo(min(ix0 + p.HX - 1, 2 * p.IW - 1)) + 1) - cx0 + 1;
-            for (int i = tid; i < CZ * CY * CX * 4; i += 256) {
-                int q = i & 3, cv = i >> 2;
-                int x = cv % CX, t2 = cv / CX;
-                int y = t2 % CY, z = t2 / CY;
-                ldc[q * p.CVp + cv] = load_act(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
-            }
-            __syncthreads();
-            for (int i = tid; i < p.HV * 2; i += 256) {
-                const int hh = i & 1, hv = i >> 1;
-                int hx = hv % p.HX, t2 = hv / p.HX;
-                int hy = t2 % p.HY, hz = t2 / p.HY;
-                int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
-                f32x4 v[2];
-                v[0] = f32x4{0.f, 0.f, 0.f, 0.f}; v[1] = v[0];
-                if ((unsigned)gz < (unsigned)(2 * p.ID) && (unsigned)gy < (unsigned)(2 * p.IH) && (unsigned)gx < (unsigned)(2 * p.IW)) {
-                    int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
-                    up_idx(gz, p.ID, z0, z1, lz); up_idx(gy, p.IH, y0, y1, ly); up_idx(gx, p.IW, x0, x1, lx);
-                    const float wz0 = 1.f - lz, wy0 = 1.f - ly, wx0 = 1.f - lx;
-                    const int r00 = ((z0 - cz0) * CY + (y0 - cy0)) * CX, r01 = ((z0 - cz0) * CY + (y1 - cy0)) * CX;
-                    const int r10 = ((z1 - cz0) * CY + (y0 - cy0)) * CX, r11 = ((z1 - cz0) * CY + (y1 - cy0)) * CX;
-                    const int a0 = x0 - cx0, a1 = x1 - cx0;
+            f32x4* ldc = lds + 4 * p.HVp + (BLDS ? GB : 0);   // BLDS: aliases weight buffer 1 (idle during staging)
+            {
+                const int ncv = CZ * CY * CX * 4;
+                if (!PFA) {
 #pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const f32x4* cq = ldc + (2 * hh + qq) * p.CVp;
-                        v[qq] = wz0 * (wy0 * (wx0 * cq[r00 + a0] + lx * cq[r00 + a1]) + ly * (wx0 * cq[r01 + a0] + lx * cq[r01 + a1])) +
-                                lz * (wy0 * (wx0 * cq[r10 + a0] + lx * cq[r10 + a1]) + ly * (wx0 * cq[r11 + a0] + lx * cq[r11 + a1]));
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = tid + 256 * k;
+                        pci[k] = -1; prc[k] = zero4;
+                        if (i < ncv) {
+                            int q = i & 3, cv = i >> 2;
+                            int x = cv % CX, t2 = cv / CX;
+                            int y = t2 % CY, z = t2 / CY;
+                            pci[k] = q * p.CVp + cv;
+                            prc[k] = load_raw(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
+                        }
                     }
                 }
-                half8 hi, lo;
-                split8(v[0], v[1], hi, lo);
-                ldh[hh * p.HVp + hv] = hi;
-                ldh[(2 + hh) * p.HVp + hv] = lo;
-            }
-        }
-        __syncthreads();
-
-        // weights of (tap, cb): planes hi/lo for this lane half
-        const half8* wq = w8 + ((size_t)cb * 4 + h) * plane + co_base + l31;
-        half8 bh[NT], bl[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { bh[nt] = wq[nt * 32]; bl[nt] = wq[2 * plane + nt * 32]; }
-        int tx = 0, ty = 0, tz = 0;
-        for (int tap = 0; tap < taps; ++tap) {
-            const half8* wn = wq + (size_t)min(tap + 1, taps - 1) * tap_stride;
-            half8 bhn[NT], bln[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { bhn[nt] = wn[nt * 32]; bln[nt] = wn[2 * plane + nt * 32]; }
-            const int tapoff = (tz * p.HY + ty) * p.HX + tx;
-            half8 ah[MT], al[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                ah[mt] = ldh[h * p.HVp + arow[mt] + tapoff];
-                al[mt] = ldh[(2 + h) * p.HVp + arow[mt] + tapoff];
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                    accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], accl[mt][nt], 0, 0, 0);
-                    accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], accl[mt][nt], 0, 0, 0);
+                for (int k = 0; k < 4; ++k) {
+                    if (pci[k] >= 0) {
+                        const int c = c0 + 4 * ((tid + 256 * k) & 3);
+                        f32x4 sc = zero4, sh = zero4;
+                        if (p.in_scale) { sc = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)n * p.Cin + c); sh = *reinterpret_cast<const f32x4*>(p.in_shift + (size_t)n * p.Cin + c); }
+                        ldc[pci[k]] = apply_act(p, prc[k], sc, sh);
+                    }
                 }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { bh[nt] = bhn[nt]; bl[nt] = bln[nt]; }
-            if (++tx == p.ks) { tx = 0; if (++ty == p.ks) { ty = 0; ++tz; } }
+                for (int i = tid + 1024; i < ncv; i += 256) {          // (never taken for 4x8x8 bricks; kept for safety)
+                    int q = i & 3, cv = i >> 2;
+                    int x = cv % CX, t2 = cv / CX;
+                    int y = t2 % CY, z = t2 / CY;
+                    ldc[q * p.CVp + cv] = load_act(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
+                }
+            }
+            __syncthreads();
+            if (s_on) {
+                // separable: bilinear (y,x) interpolation of a coarse plane is computed once and reused by the two or
+                // three fine planes that blend it (same association as the direct trilinear formula)
+                const float wy0 = 1.f - u_ly, wx0 = 1.f - u_lx;
+                const f32x4* cq0 = ldc + (2 * s_hh) * p.CVp;
+                const f32x4* cq1 = ldc + (2 * s_hh + 1) * p.CVp;
+                auto bilin = [&](const f32x4* cq, int pz) {
+                    return wy0 * (wx0 * cq[pz + u_r0 + u_a0] + u_lx * cq[pz + u_r0 + u_a1]) +
+                           u_ly * (wx0 * cq[pz + u_r1 + u_a0] + u_lx * cq[pz + u_r1 + u_a1]);
+                };
+                int zc0 = -1, zc1 = -1;
+                f32x4 b0a = zero4, b0b = zero4, b1a = zero4, b1b = zero4;      // bilinear planes z0 / z1, channel quads a / b
+#pragma unroll 1
+                for (int hz = 0; hz < HZ; ++hz) {
+                    const int gz = iz0 + hz;
+                    f32x4 va = zero4, vb = zero4;
+                    if (s_in && (unsigned)gz < (unsigned)(2 * p.ID)) {
+                        int z0, z1; float lz;
+                        up_idx(gz, p.ID, z0, z1, lz);
+                        if (z0 != zc0) {                                       // wave-uniform: gz is the same in every lane
+                            if (z0 == zc1) { b0a = b1a; b0b = b1b; }
+                            else { b0a = bilin(cq0, (z0 - cz0) * CY * CX); b0b = bilin(cq1, (z0 - cz0) * CY * CX); }
+                            zc0 = z0;
+                        }
+                        if (z1 != zc1) {
+                            if (z1 == zc0) { b1a = b0a; b1b = b0b; }
+                            else { b1a = bilin(cq0, (z1 - cz0) * CY * CX); b1b = bilin(cq1, (z1 - cz0) * CY * CX); }
+                            zc1 = z1;
+                        }
+                        const float wz0 = 1.f - lz;
+                        va = wz0 * b0a + lz * b1a;
+                        vb = wz0 * b0b + lz * b1b;
+                    }
+                    half8 hi, lo;
+                    split8(va, vb, hi, lo);
+                    ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
+                    ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
+                }
+            }
         }
+        if (cb < 2) NM_STAMP(2 + cb * 4);
+        if (BLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weight group 0 has landed in LDS
+        __syncthreads();
+        if (cb < 2) NM_STAMP(3 + cb * 4);
+
+        if (BLDS) {
+            for (int g = 0; g < 3; ++g) {
+                if (g < 2) issue_b_group(cb, g + 1, (g + 1) & 1);
+                else if (PFA && cb + 1 < C16) prefetch_chunk(c0 + 16);
+                const half8* bb = ldb + (g & 1) * GB + h * 32 + l31;
+#pragma unroll 3
+                for (int t = 0; t < 9; ++t) {
+                    const int ty = t / 3, tx = t % 3;
+                    const int tapoff = g * p.ZP + ty * p.HX + tx;
+                    const half8 bh0 = bb[t * 128], bl0 = bb[t * 128 + 64];
+                    half8 ah[MT], al[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        ah[mt] = ldh[h * p.HVp + arow[mt] + tapoff];
+                        al[mt] = ldh[(2 + h) * p.HVp + arow[mt] + tapoff];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh0, acc[mt][0], 0, 0, 0);
+                        accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl0, accl[mt][0], 0, 0, 0);
+                        accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh0, accl[mt][0], 0, 0, 0);
+                    }
+                }
+                if (g < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+            }
+        } else {
+        // weights of (tap, cb): planes hi/lo for this lane half, prefetched PF taps ahead (a tap is only 6-12 MFMAs =
+            // 200-400 cycles, about an L2 round trip)
+            constexpr int PF = (NT == 1) ? 2 : 1;
+            const half8* wq = w8 + ((size_t)cb * 4 + h) * plane + co_base + l31;
+            half8 bh[PF + 1][NT], bl[PF + 1][NT];
+    #pragma unroll
+            for (int f = 0; f < PF; ++f) {
+                const half8* wf = wq + (size_t)min(f, taps - 1) * tap_stride;
+    #pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { bh[f][nt] = wf[nt * 32]; bl[f][nt] = wf[2 * plane + nt * 32]; }
+            }
+            int tx = 0, ty = 0, tz = 0;
+            for (int tap = 0; tap < taps; ++tap) {
+                const half8* wn = wq + (size_t)min(tap + PF, taps - 1) * tap_stride;
+    #ifdef NM_EXP_NOB
+                if (tap < 0)
+    #endif
+    #pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { bh[PF][nt] = wn[nt * 32]; bl[PF][nt] = wn[2 * plane + nt * 32]; }
+                const int tapoff = tz * p.ZP + ty * p.HX + tx;
+                half8 ah[MT], al[MT];
+    #ifdef NM_EXP_NOA
+                if (tap == 0)
+    #endif
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    ah[mt] = ldh[h * p.HVp + arow[mt] + tapoff];
+                    al[mt] = ldh[(2 + h) * p.HVp + arow[mt] + tapoff];
+                }
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[0][nt], acc[mt][nt], 0, 0, 0);
+                        accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[0][nt], accl[mt][nt], 0, 0, 0);
+                        accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[0][nt], accl[mt][nt], 0, 0, 0);
+                    }
+    #pragma unroll
+                for (int f = 0; f < PF; ++f)
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { bh[f][nt] = bh[f + 1][nt]; bl[f][nt] = bl[f + 1][nt]; }
+                if (++tx == p.ks) { tx = 0; if (++ty == p.ks) { ty = 0; ++tz; } }
+            }
+        }
+        if (cb < 2) NM_STAMP(4 + cb * 4);
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] += accl[mt][nt][r] * (1.0f / NM_SPLIT_SCALE);
+    NM_STAMP(9);
     EpiArgs e;
     e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
-    e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = p.bz_l2; e.by_l2 = p.by_l2; e.bx_l2 = p.bx_l2;
+    e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3; e.xz_tiles = 1;
     __syncthreads();
-    epilogue<MT, NT>(e, reinterpret_cast<float*>(lds), acc, n, br, nblk, oz0, oy0, ox0, co_base);
+    epilogue_xz<MT, NT>(e, reinterpret_cast<float*>(lds), acc, accl, n, br, nblk, oz0, oy0, ox0, co_base);
+    NM_STAMP(10);
+    }   // persistent item loop
 }
 
 // OIDHW fp32 -> split fp16 [tap][Cin/16][hi|lo][lane half][Co_pad][8]
@@ -630,11 +930,11 @@ int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
     return nm_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int KS, bool UP2>
 int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT, KS, UP2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16s)");
         attr_set = true;
@@ -645,15 +945,22 @@ int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) 
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
         (void)hipEventRecord(rec.a, s);
     }
-    hipLaunchKernelGGL((conv_f16s_kernel<MT, NT>), grid, dim3(256), t.lds_bytes, s, p);
+    dim3 pgrid(min(grid.x, 512u), grid.y);                          // persistent: ~2 resident workgroups per CU
+    hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2>), pgrid, dim3(256), t.lds_bytes, s, p);
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
 }
 
+#ifdef NM_DIAG
+unsigned long long* g_stamps = nullptr;
+#endif
 int g_conv_mode = 1;      // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
 
 }  // namespace
 
+#ifdef NM_DIAG
+extern "C" void nm_diag_set_stamps(void* p) { g_stamps = static_cast<unsigned long long*>(p); }
+#endif
 void nm_conv_set_mode(int mode) { g_conv_mode = mode; }
 int nm_conv_get_mode() { return g_conv_mode; }
 
@@ -733,11 +1040,29 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.bz_l2 = t.bz_l2; p.by_l2 = t.by_l2; p.bx_l2 = t.bx_l2; p.nbz = t.nbz; p.nby = t.nby; p.nbx = t.nbx;
     p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.up2 = g.up2 ? 1 : 0;
-    p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp;
+#ifdef NM_DIAG
+    p.stamps = g_stamps;
+#endif
+    p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp; p.ZP = t.HY * t.HX;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
-    if (g_conv_mode == 1 && w_packed16 && in.C % 16 == 0 && t.KC == 16 && t.MT == 2) {
-        p.w = static_cast<const float*>(w_packed16);
-        return t.NT == 2 ? launch_f16s<2, 2>(p, t, grid, s) : launch_f16s<2, 1>(p, t, grid, s);
+    if (g_conv_mode == 1 && w_packed16 && in.C % 16 == 0 && t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2 &&
+        g.stride == 1 && (g.ks == 1 || g.ks == 3) && t.HZ == g.ks + 3 && t.HY * t.HX * 2 <= 256) {
+        // halo planes padded to a pitch of 4 (mod 16) 16-B slots: conflict-free A reads (see conv_f16s_kernel)
+        Tiling t16 = t;
+        const int area = t.HY * t.HX;
+        p.ZP = area + ((4 - (area & 15)) & 15);
+        const int hv = t.HZ * p.ZP;
+        p.HVp = hv + ((2 - (hv & 7)) & 7);
+        const bool blds = (t.NT == 1 && g.ks == 3);
+        const size_t bbytes = blds ? (size_t)2 * 9 * 4 * 32 * 16 : 0;          // two 9-tap weight groups (Cout = 32 layers)
+        t16.lds_bytes = max(blds ? (size_t)4 * p.HVp * 16 + bbytes : (size_t)4 * (p.HVp + t.CVp) * 16, (size_t)4 * 64 * 2 * sizeof(float));
+        if (t16.lds_bytes <= 80 * 1024) {
+            p.w = static_cast<const float*>(w_packed16);
+            if (g.ks == 3 && g.up2) return t.NT == 2 ? launch_f16s<2, 2, 3, true>(p, t16, grid, s) : launch_f16s<2, 1, 3, true>(p, t16, grid, s);
+            if (g.ks == 3) return t.NT == 2 ? launch_f16s<2, 2, 3, false>(p, t16, grid, s) : launch_f16s<2, 1, 3, false>(p, t16, grid, s);
+            if (!g.up2) return t.NT == 2 ? launch_f16s<2, 2, 1, false>(p, t16, grid, s) : launch_f16s<2, 1, 1, false>(p, t16, grid, s);
+        }
+        p.HVp = t.HVp;
     }
     if (t.MT == 2 && t.NT == 2) return launch_t<2, 2>(p, t, grid, s);
     if (t.MT == 2 && t.NT == 1) return launch_t<2, 1>(p, t, grid, s);
