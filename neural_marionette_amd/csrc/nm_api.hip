@@ -204,14 +204,16 @@ int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
                  int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) {
     if (!ctx || !in || !weight || !out || !bias) { nm_set_error("op_convT2: null argument"); return NM_ERR_ARG; }
     const int OD = 2 * D + outpad, OH = 2 * H + outpad, OW = 2 * W + outpad;
-    TensorRef t = make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, Cin);
-    int rc = nm_launch_convT2(t, weight, bias, out, Cout, OD, OH, OW, ctx->stream);
-    if (rc || gn_groups <= 0) return rc;
     const int vox = OD * OH * OW, nblk = nm_stats_blocks_per_frame(vox);
-    rc = nm_ctx_reserve(ctx, (size_t)N * nblk * Cout * 2 * sizeof(float) + 4096);
+    int rc = nm_ctx_reserve(ctx, ((size_t)N * nblk * Cout * 2 + (size_t)Cin * Cout * 8) * sizeof(float) + 8192);
     if (rc) return rc;
     ctx->ws.release(0);
+    float* wt = ctx->ws.f((size_t)Cin * Cout * 8);
     float* part = ctx->ws.f((size_t)N * nblk * Cout * 2);
+    if ((rc = nm_launch_transpose_convT_weight(weight, Cin, Cout, wt, ctx->stream))) return rc;
+    TensorRef t = make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, Cin);
+    rc = nm_launch_convT2(t, wt, bias, out, Cout, OD, OH, OW, ctx->stream);
+    if (rc || gn_groups <= 0) return rc;
     rc = nm_launch_gn_partials(out, N, vox, Cout, part, ctx->stream);
     if (rc) return rc;
     return finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)vox * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);

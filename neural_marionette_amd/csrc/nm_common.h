@@ -73,7 +73,9 @@ int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups,
 int nm_stats_blocks_per_frame(int voxels);
 int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part, hipStream_t s);
 int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s);
-int nm_launch_convT2(const TensorRef& in, const float* w_iodhw, const float* bias, float* out,
+// w_t: weights transposed to [tap][Cin][Cout] by nm_launch_transpose_convT_weight
+int nm_launch_transpose_convT_weight(const float* w_iodhw, int Cin, int Cout, float* out, hipStream_t s);
+int nm_launch_convT2(const TensorRef& in, const float* w_t, const float* bias, float* out,
                      int Cout, int OD, int OH, int OW, hipStream_t s);
 int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s);
 int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t, float* out,

@@ -378,6 +378,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     const size_t tap_stride = (size_t)Q * p.Co_pad;                 // float4 units per tap
     const f32x4* __restrict__ w4 = reinterpret_cast<const f32x4*>(p.w);
 
+    // p.KC channels are staged per pass (as many as the LDS budget allows: tiny volumes take the whole Cin at once,
+    // one staging phase + two barriers instead of Cin/16 of them); the MFMA walk consumes them 16 at a time.
     for (int c0 = 0; c0 < p.Cin; c0 += p.KC) {
         const int kc = min(p.KC, p.Cin - c0);
         const int nq = kc >> 2;
@@ -436,9 +438,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         __syncthreads();
 
         // ---- MFMA over taps x channel octets -------------------------------------------
-        const f32x4* wq = w4 + ((size_t)(c0 >> 2) + h) * p.Co_pad + co_base + l31;
-        if (kc >= 16) mfma_chunk<MT, NT, 2>(p, lds, wq, tap_stride, taps, h, arow, acc);
-        else          mfma_chunk<MT, NT, 1>(p, lds, wq, tap_stride, taps, h, arow, acc);
+        for (int s0 = 0; s0 < kc; s0 += 16) {
+            const f32x4* wq = w4 + ((size_t)((c0 + s0) >> 2) + h) * p.Co_pad + co_base + l31;
+            const f32x4* sub = lds + (s0 >> 2) * p.HVp;
+            if (kc - s0 >= 16) mfma_chunk<MT, NT, 2>(p, sub, wq, tap_stride, taps, h, arow, acc);
+            else               mfma_chunk<MT, NT, 1>(p, sub, wq, tap_stride, taps, h, arow, acc);
+        }
     }
 
     EpiArgs e;
@@ -885,13 +890,22 @@ Tiling choose_tiling(const ConvGeom& g, int Cin) {
     t.HZ = (BZ - 1) * g.stride + g.ks;
     t.HV = t.HX * t.HY * t.HZ;
     t.HVp = t.HV + ((2 - (t.HV & 7)) & 7);
-    t.KC = (Cin % 16 == 0) ? 16 : 8;
     t.CVp = 0;
     if (g.up2) {
         int cv = ((t.HZ >> 1) + 2) * ((t.HY >> 1) + 2) * ((t.HX >> 1) + 2);
         t.CVp = cv + ((2 - (cv & 7)) & 7);
     }
-    if ((size_t)(t.KC / 4) * (t.HVp + t.CVp) * 16 > 72 * 1024 && t.KC == 16) t.KC = 8;
+    // channels staged per pass: 16 by default; more when the halo tile is small (<= 48 KB of LDS in total), 8 when
+    // even 16 do not fit in 72 KB
+    const size_t per16 = (size_t)4 * (t.HVp + t.CVp) * 16;
+    t.KC = (Cin % 16 == 0) ? 16 : 8;
+    if (per16 > 72 * 1024) t.KC = 8;
+    else {
+        int k = (int)((48 * 1024) / per16) * 16;
+        if (k > 16) t.KC = min(k, (Cin + 15) & ~15);
+        if (t.KC > Cin) t.KC = Cin;
+        if (t.KC % 8) t.KC = (Cin % 16 == 0) ? 16 : 8;
+    }
     t.lds_bytes = max((size_t)(t.KC / 4) * (t.HVp + t.CVp) * 16, (size_t)4 * 64 * 2 * sizeof(float));
     return t;
 }

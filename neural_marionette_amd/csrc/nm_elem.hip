@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void apply2_kernel(TensorRef a, TensorRef b, i
     }
 }
 
-// ConvTranspose3d k2 s2: out[2i+a] += x[i] * W[ci][co][a]; one thread per (out voxel, 4 channels)
+// ConvTranspose3d k2 s2: out[2i+a] += x[i] * W[ci][co][a]; one thread per (out voxel, 4 channels);
+// the weights arrive transposed to [tap][ci][co] (nm_launch_transpose_convT_weight)
 __global__ __launch_bounds__(256) void convT2_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ out, int Cout, int OD, int OH, int OW) {
     const int cq = Cout / 4;
@@ -119,8 +120,9 @@ __global__ __launch_bounds__(256) void convT2_kernel(TensorRef in, const float* 
                 f32x4 x = load_t(in, n, vo + c, c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float* wr = w + ((size_t)(c + j) * Cout + co) * 8 + tap;
-                    acc[0] += x[j] * wr[0]; acc[1] += x[j] * wr[8]; acc[2] += x[j] * wr[16]; acc[3] += x[j] * wr[24];
+                    // w is pre-transposed to [tap][ci][co]: one 16-B load, coalesced across the threads of a voxel
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + ((size_t)tap * in.C + c + j) * Cout + co);
+                    acc[0] += x[j] * wv[0]; acc[1] += x[j] * wv[1]; acc[2] += x[j] * wv[2]; acc[3] += x[j] * wv[3];
                 }
             }
         }
@@ -219,6 +221,14 @@ __global__ __launch_bounds__(256) void mean_t_kernel(const float* __restrict__ v
     }
 }
 
+// (Cin, Cout, 2,2,2) IODHW -> [tap][Cin][Cout]
+__global__ void transpose_convT_weight_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * Cout * 8) return;
+    int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cout * Cin);
+    out[i] = w[((size_t)ci * Cout + co) * 8 + tap];
+}
+
 // [n][C][vox] -> [n][vox][C]
 __global__ __launch_bounds__(256) void ncdhw_to_cl_kernel(const float* __restrict__ in, int voxels, int C, float* __restrict__ out) {
     __shared__ float tile[32][33];
@@ -307,4 +317,10 @@ int nm_launch_mean_t(const float* vox, int B, int T, size_t G3, float* out, hipS
     size_t total = (size_t)B * G3;
     hipLaunchKernelGGL(mean_t_kernel, dim3(grid_for(total)), dim3(256), 0, s, vox, T, G3, total, out);
     return nm_check_hip(hipGetLastError(), "mean_t launch");
+}
+
+int nm_launch_transpose_convT_weight(const float* w_iodhw, int Cin, int Cout, float* out, hipStream_t s) {
+    int total = Cin * Cout * 8;
+    hipLaunchKernelGGL(transpose_convT_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w_iodhw, Cin, Cout, out);
+    return nm_check_hip(hipGetLastError(), "transpose_convT_weight launch");
 }

@@ -80,7 +80,10 @@ struct Loader {
     }
     UpW up(const std::string& p, int ci, int co) {
         UpW u; u.Cin = ci; u.Cout = co;
-        u.w = copy(p + ".block.0.weight", (int64_t)ci * co * 8); u.bias = copy(p + ".block.0.bias", co);
+        const float* src = get(p + ".block.0.weight", (int64_t)ci * co * 8);
+        u.w = nm_ctx_weight_alloc(c, (size_t)ci * co * 8);
+        if (src && u.w) { int r = nm_launch_transpose_convT_weight(src, ci, co, u.w, c->stream); if (r && !rc) rc = r; }
+        u.bias = copy(p + ".block.0.bias", co);
         u.n = norm(p + ".block.1", co);
         return u;
     }
