@@ -94,6 +94,13 @@ int nm_decode_from_keypoints(nm_ctx* ctx, const float* keypoints, const float* f
 /* KyptDetector.get_affinity (ver 3) — model/kypt_detector.py:191-199 -> (N,K,K,1) */
 int nm_get_affinity(nm_ctx* ctx, float* affinity);
 
+/* Input path on the device: episodic_normalization (zero translation) + voxelize of
+ * utils/dataset_utils.py:9-31, evaluated operation by operation in fp64 so that the voxel indices
+ * are bit-exact.  points (T,N,3) float64 -> vox (T,1,G,G,G) fp32 {0,1};
+ * idx_out (T,N,3) int32 receives the indices (may be NULL).  Does not need weights. */
+int nm_voxelize_clip(nm_ctx* ctx, const double* points, int32_t T, int64_t N, double scale, float* vox,
+                     int32_t* idx_out);
+
 /* Skeleton handed to the VRNN entry points (result of process_affinity_glob,
  * utils/dyna_utils.py:6-171, computed on the host by neural_marionette_amd.skeleton):
  *  parents (K) int32, parents[root] == root;  order (K) int32 = priority.indices */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "nm_detector_forward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "nm_decode_from_keypoints": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _P]),
     "nm_get_affinity": (C.c_int, [C.c_void_p, _P]),
+    "nm_voxelize_clip": (C.c_int, [C.c_void_p, _P, _I, C.c_int64, C.c_double, _P, _P]),
     "nm_vrnn_set_tree": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "nm_vrnn_offsets": (C.c_int, [C.c_void_p, _P, _I, _I, _P]),
     "nm_vrnn_encode": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -115,8 +116,8 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
         raise NmError("nm355 needs device tensors (HIP); got a CPU tensor — there is no CPU fallback")
     if not t.is_contiguous():
         raise NmError("nm355 needs contiguous tensors")
-    if t.dtype not in (torch.float32, torch.int32):
-        raise NmError(f"nm355 needs fp32/int32 tensors, got {t.dtype}")
+    if t.dtype not in (torch.float32, torch.int32, torch.float64):
+        raise NmError(f"nm355 needs fp32/int32 (fp64 for point clouds) tensors, got {t.dtype}")
     return t.data_ptr()
 
 

@@ -445,3 +445,73 @@ int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_
     hipLaunchKernelGGL(affinity_kernel, dim3((N * K + 63) / 64), dim3(64), 0, s, params, N, K, out);
     return nm_check_hip(hipGetLastError(), "affinity launch");
 }
+
+// ---- input path: episodic normalisation + voxelisation on the device ---------------------------------
+// Restates utils/dataset_utils.py:9-31 operation by operation in fp64 so that the voxel indices are bit-exact:
+//   seq' = ((seq - bmin) * scale / (blen + 1e-5)) * 2 - 1,  idx = int32((seq' + 1) / (2/G + 1e-5)),  grid[idx] = 1.
+namespace {
+
+// per-block partial bbox of the whole episode: part[blk][6] = (min xyz, max xyz)
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const double* __restrict__ pts, size_t npts, double* __restrict__ part) {
+    __shared__ double sh[256 * 6];
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < npts; i += (size_t)gridDim.x * 256)
+        for (int d = 0; d < 3; ++d) { double v = pts[i * 3 + d]; mn[d] = fmin(mn[d], v); mx[d] = fmax(mx[d], v); }
+    for (int d = 0; d < 3; ++d) { sh[threadIdx.x * 6 + d] = mn[d]; sh[threadIdx.x * 6 + 3 + d] = mx[d]; }
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            for (int d = 0; d < 3; ++d) {
+                sh[threadIdx.x * 6 + d] = fmin(sh[threadIdx.x * 6 + d], sh[(threadIdx.x + st) * 6 + d]);
+                sh[threadIdx.x * 6 + 3 + d] = fmax(sh[threadIdx.x * 6 + 3 + d], sh[(threadIdx.x + st) * 6 + 3 + d]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) part[(size_t)blockIdx.x * 6 + threadIdx.x] = sh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void voxelize_kernel(const double* __restrict__ pts, int T, size_t N, int G, double scale,
+                                                       const double* __restrict__ part, int nparts, float* __restrict__ vox,
+                                                       int32_t* __restrict__ idx_out) {
+    __shared__ double bb[6];
+    if (threadIdx.x < 6) {
+        double v = part[threadIdx.x];
+        for (int j = 1; j < nparts; ++j) v = threadIdx.x < 3 ? fmin(v, part[(size_t)j * 6 + threadIdx.x]) : fmax(v, part[(size_t)j * 6 + threadIdx.x]);
+        bb[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const double blen = fmax(fmax(bb[3] - bb[0], bb[4] - bb[1]), bb[5] - bb[2]);
+    const double den = blen + 1e-5;
+    const double step = 2.0 / (double)G + 1e-5;
+    const size_t G3 = (size_t)G * G * G;
+    const size_t total = (size_t)T * N;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int id[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double v = pts[i * 3 + d] - bb[d];
+            v = v * scale; v = v / den; v = v * 2.0; v = v - 1.0;
+            v = v + 0.0;                       // the reference adds the (zero) translation vector
+            v = v - (-1.0);
+            v = v / step;
+            id[d] = (int)v;                    // astype(np.int32): truncation toward zero
+        }
+        if (idx_out) { idx_out[i * 3] = id[0]; idx_out[i * 3 + 1] = id[1]; idx_out[i * 3 + 2] = id[2]; }
+        if ((unsigned)id[0] < (unsigned)G && (unsigned)id[1] < (unsigned)G && (unsigned)id[2] < (unsigned)G)
+            vox[(i / N) * G3 + ((size_t)id[0] * G + id[1]) * G + id[2]] = 1.0f;     // idempotent set: no atomics needed
+    }
+}
+
+}  // namespace
+
+int nm_launch_voxelize(const double* pts, int T, size_t N, int G, double scale, double* part_ws /* >= 256*6 doubles */,
+                       float* vox, int32_t* idx_out, hipStream_t s) {
+    const size_t npts = (size_t)T * N;
+    const int nparts = (int)((npts + 255) / 256 < 256 ? (npts + 255) / 256 : 256);
+    int rc = nm_check_hip(hipMemsetAsync(vox, 0, (size_t)T * G * G * G * sizeof(float), s), "voxelize: memset");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nparts), dim3(256), 0, s, pts, npts, part_ws);
+    hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)((npts + 255) / 256 < 2048 ? (npts + 255) / 256 : 2048)), dim3(256), 0, s, pts, T, N,
+                       G, scale, part_ws, nparts, vox, idx_out);
+    return nm_check_hip(hipGetLastError(), "voxelize launch");
+}

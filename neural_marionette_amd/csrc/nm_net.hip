@@ -494,6 +494,16 @@ int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* fir
     return with_workspace(c, [&]() { return decode_graph(c, keypoints, first_feature, first_frame, B, Tg, gen); });
 }
 
+int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, double scale, float* vox, int32_t* idx_out) {
+    if (!c || !points || !vox || T <= 0 || N <= 0) { nm_set_error("voxelize_clip: bad argument"); return NM_ERR_ARG; }
+    int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
+    if (rc) return rc;
+    if ((rc = nm_ctx_reserve(c, 256 * 6 * sizeof(double) + 4096))) return rc;
+    c->ws.release(0);
+    double* part = static_cast<double*>(c->ws.alloc_bytes(256 * 6 * sizeof(double)));
+    return nm_launch_voxelize(points, T, (size_t)N, c->cfg.grid_size, scale, part, vox, idx_out, c->stream);
+}
+
 int nm_get_affinity(nm_ctx* c, float* affinity) {
     int rc = check_ready(c, "get_affinity");
     if (rc) return rc;

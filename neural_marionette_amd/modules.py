@@ -417,6 +417,20 @@ class NeuralMarionette(nn.Module):
             raise ValueError("conv mode must be 'split16' or 'fp32'")
         self._engine.conv_mode = 1 if mode == "split16" else 0
 
+    def voxelize(self, points, scale: float = 1.0, return_indices: bool = False):
+        """Device version of the reference's input path (utils/dataset_utils.py:9-31 as used by
+        dataset/dataset.py:70-86 and vis_generation.py:14-25): per-episode bbox normalisation + occupancy
+        voxelisation.  points (T,N,3) -> (T,1,G,G,G) fp32; voxel indices are bit-exact (fp64 arithmetic)."""
+        eng = self._engine
+        ctx = eng.ready()
+        pts = points.detach().to(device=ctx.device, dtype=torch.float64).contiguous()
+        T, N = int(pts.shape[0]), int(pts.shape[1])
+        G = eng.opts.grid_size
+        vox = torch.empty(T, 1, G, G, G, device=ctx.device)
+        idx = torch.empty(T, N, 3, device=ctx.device, dtype=torch.int32) if return_indices else None
+        eng.call("nm_voxelize_clip", _lib.ptr(pts), T, N, float(scale), _lib.ptr(vox), _lib.ptr(idx))
+        return (vox, idx) if return_indices else vox
+
     def control_active(self, module_actives):
         """neural_marionette.py:22-32."""
         for name in self.current_actives:

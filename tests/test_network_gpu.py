@@ -321,3 +321,25 @@ def test_config5_rollout64(B):
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / 5 / Tt * 1e6
     print("config-5 B=%d: %.1f us per VRNN step (eager, %d steps)" % (B, us, Tt))
+
+
+@pytest.mark.parametrize("G,N,scale", [(64, 20000, 1.0), (64, 5000, 0.9), (96, 3000, 1.0)])
+def test_voxelize_on_device_bit_exact(G, N, scale):
+    """episodic normalisation + voxelisation; integer voxel indices must be bit-exact against the
+    fp64 numpy evaluation of the reference's formulas (utils/dataset_utils.py:9-31, restated in synth.py and pinned
+    against the reference in tests/test_oracle_vs_reference.py)."""
+    o = HotPathOptions(grid_size=G)
+    net = _net(o, synth.make_state_dict(o, seed=1))
+    rng = np.random.default_rng(G + N)
+    T = 5
+    pts = synth.figure_points(T, N, rng)
+    pts[0, 0] = pts.reshape(-1, 3).min(0)           # bbox corners themselves are points of the cloud
+    pts[1, 1] = pts.reshape(-1, 3).max(0)
+    norm = synth.episodic_normalization(pts, scale=scale)
+    ref_idx = synth.voxel_indices(norm, G)
+    ref_vox = np.stack([synth.voxelize(norm[t], G) for t in range(T)])[:, None]
+    vox, idx = net.voxelize(torch.from_numpy(pts), scale=scale, return_indices=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), ref_idx), "voxel indices must be bit-exact"
+    assert np.array_equal(vox.cpu().numpy(), ref_vox)
+    assert vox.shape == (T, 1, G, G, G) and vox.dtype == torch.float32

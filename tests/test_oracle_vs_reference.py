@@ -85,3 +85,21 @@ def test_full_forward_32(ref_modules, variant, clip):
     for k in DETECTOR_LOSS_KEYS + ("kl_kypt", "kypt_recon_loss"):
         assert float(ref[k]) == float(mine[k]), k
     assert np.array_equal(net.dyna_module.parents.numpy(), mine["parents"])
+
+
+def test_input_path_restatement_matches_reference():
+    """synth.episodic_normalization / voxelize (the restated input path) against
+    utils/dataset_utils.py of the reference: identical floats and identical occupancy grids."""
+    sys.path.insert(0, REF)
+    try:
+        from utils import dataset_utils as DU
+    finally:
+        sys.path.remove(REF)
+    rng = np.random.default_rng(4)
+    for G, scale in ((64, 1.0), (64, 0.9), (96, 1.0)):
+        pts = synth.figure_points(4, 4000, rng)
+        a = DU.episodic_normalization(pts, scale=scale)
+        b = synth.episodic_normalization(pts, scale=scale)
+        assert np.array_equal(a, b)
+        for t in range(4):
+            assert np.array_equal(DU.voxelize(a[t], (G, G, G))[0], synth.voxelize(b[t], G))
