@@ -127,10 +127,16 @@ int nm_vrnn_generate(nm_ctx* ctx, const float* keypoints_cond, const float* eps_
 /* One VRNN step for hand-rolled rollouts (vis_generation.py:97-127 of the reference):
  *  posterior != 0: best-of-S posterior step against kp_obs (B,K*4), eps (S,B,Z);
  *  posterior == 0: prior step, eps (B,Z), S ignored.
- *  h_in (B,H), offset (B,K,3) -> kp_out (B,K*4), z_out (B,Z), h_out (B,H). */
+ *  h_in (B,H), offset (B,K,3) -> kp_out (B,K*4), z_out (B,Z), h_out (B,H) (NULL: skip the GRU update). */
 int nm_vrnn_step(nm_ctx* ctx, int32_t posterior, const float* h_in, const float* kp_obs,
                  const float* offset, const float* eps, int32_t B, int32_t S, float* kp_out,
                  float* z_out, float* h_out);
+
+/* idx = argmin over rows r of || rows[r] - target[r*target_row_stride] ||^2 (first minimum; stride 0 =
+ * one target for all rows): the sample selection of vis_generation.py:109-110 / vis_interpolation.py:113-119.
+ *  rows (B,D), target (D) or (B,D), idx_out (1) int32 on the device, dist_out (1) or NULL. */
+int nm_rows_argmin_dist(nm_ctx* ctx, const float* rows, const float* target, int32_t target_row_stride,
+                        int32_t B, int32_t D, int32_t* idx_out, float* dist_out);
 
 /* Sub-module callables the reference's demo scripts reach into (hsvrnn_bvh.py:29-57):
  *  which: 0 extract_post_dist (H+K*4 -> 2Z), 1 extract_prior_dist (H -> 2Z),

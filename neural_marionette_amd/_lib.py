@@ -54,6 +54,7 @@ SIGNATURES = {
     "nm_vrnn_encode": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "nm_vrnn_generate": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "nm_vrnn_step": (C.c_int, [C.c_void_p, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "nm_rows_argmin_dist": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P]),
     "nm_vrnn_mlp": (C.c_int, [C.c_void_p, _I, _P, _I, _P]),
     "nm_vrnn_gru": (C.c_int, [C.c_void_p, _P, _P, _I, _P]),
     "nm_vrnn_fk": (C.c_int, [C.c_void_p, _P, _P, _I, _P, _P]),

@@ -569,7 +569,7 @@ int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* k
                  int32_t B, int32_t S, float* kp_out, float* z_out, float* h_out) {
     int rc = ready(c, "vrnn_step", true);
     if (rc) return rc;
-    if (!h_in || !offset || !eps || !kp_out || !z_out || !h_out || B <= 0 || (posterior && (!kp_obs || S <= 0))) {
+    if (!h_in || !offset || !eps || !kp_out || !z_out || B <= 0 || (posterior && (!kp_obs || S <= 0))) {
         nm_set_error("vrnn_step: bad argument"); return NM_ERR_ARG;
     }
     if (!posterior) S = 1;
@@ -586,6 +586,35 @@ int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* k
     io.best = nullptr; io.ldbest = 0; io.kl = nullptr; io.rec = nullptr; io.ldstat = 0;
     io.hout = h_out; io.ldho = H; io.want_prior = false;
     return vrnn_step(c, sb, io, B, S);
+}
+
+// idx = argmin_r sum_d (rows[r][d] - target[r * tstride + d])^2  (first minimum), one block
+__global__ __launch_bounds__(256) void rows_argmin_kernel(const float* __restrict__ rows, const float* __restrict__ target, int tstride,
+                                                          int B, int D, int32_t* __restrict__ idx, float* __restrict__ dist) {
+    __shared__ float bd[256]; __shared__ int bi[256];
+    float best = INFINITY; int besti = 0x7fffffff;
+    for (int r = threadIdx.x; r < B; r += 256) {
+        float d = 0.f;
+        for (int k = 0; k < D; ++k) { float u = rows[(size_t)r * D + k] - target[(size_t)r * tstride + k]; d += u * u; }
+        if (d < best) { best = d; besti = r; }
+    }
+    bd[threadIdx.x] = best; bi[threadIdx.x] = besti;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            float o = bd[threadIdx.x + st]; int oi = bi[threadIdx.x + st];
+            if (o < bd[threadIdx.x] || (o == bd[threadIdx.x] && oi < bi[threadIdx.x])) { bd[threadIdx.x] = o; bi[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { idx[0] = bi[0]; if (dist) dist[0] = bd[0]; }
+}
+
+int nm_rows_argmin_dist(nm_ctx* c, const float* rows, const float* target, int32_t target_row_stride, int32_t B, int32_t D,
+                        int32_t* idx_out, float* dist_out) {
+    if (!c || !rows || !target || !idx_out || B <= 0 || D <= 0) { nm_set_error("rows_argmin_dist: bad argument"); return NM_ERR_ARG; }
+    hipLaunchKernelGGL(rows_argmin_kernel, dim3(1), dim3(256), 0, c->stream, rows, target, target_row_stride, B, D, idx_out, dist_out);
+    return nm_check_hip(hipGetLastError(), "rows_argmin launch");
 }
 
 int nm_vrnn_mlp(nm_ctx* c, int32_t which, const float* x, int32_t B, float* y) {

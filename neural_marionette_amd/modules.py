@@ -366,10 +366,10 @@ class HSVRNNBVH(_Node):
         eng.call("nm_vrnn_fk", _lib.ptr(x), _lib.ptr(off), B, _lib.ptr(kp), _lib.ptr(R))
         return kp, R
 
-    def step(self, h, offset, eps, keypoints_obs=None, SAMPLE_NUM=10):
+    def step(self, h, offset, eps, keypoints_obs=None, SAMPLE_NUM=10, update_state=True):
         """One fused VRNN step for hand-rolled rollouts (vis_generation.py:97-127 of the reference does the
         same with five sub-module calls): posterior best-of-S when ``keypoints_obs`` is given, else prior.
-        Returns (keypoints_flat (B,K*4), z (B,Z), h_next (B,H))."""
+        Returns (keypoints_flat (B,K*4), z (B,Z), h_next (B,H) or None when ``update_state`` is False)."""
         eng = self._eng()
         ctx = eng.ready()
         self._ensure_tree(None, ctx)
@@ -381,10 +381,22 @@ class HSVRNNBVH(_Node):
         obs = None if keypoints_obs is None else _f32(keypoints_obs.reshape(B, -1), dev)
         kp = torch.empty(B, self.nkeypoints * 4, device=dev)
         z = torch.empty(B, self.nlatent_kypt, device=dev)
-        hn = torch.empty_like(hh)
+        hn = torch.empty_like(hh) if update_state else None
         eng.call("nm_vrnn_step", int(obs is not None), _lib.ptr(hh), _lib.ptr(obs), _lib.ptr(off), _lib.ptr(e), B,
                  int(SAMPLE_NUM), _lib.ptr(kp), _lib.ptr(z), _lib.ptr(hn))
         return kp, z, hn
+
+    def nearest_row(self, rows, target):
+        """Index (python int) of the row of ``rows`` (B,D) nearest to ``target`` ((D,) or (B,D)) in squared L2 —
+        the sample selection of the reference's demo loops (vis_generation.py:109-110)."""
+        eng = self._eng()
+        ctx = eng.ready()
+        r = _f32(rows.reshape(rows.shape[0], -1), ctx.device)
+        t = _f32(target.reshape(-1, r.shape[1]), ctx.device)
+        idx = torch.empty(1, device=ctx.device, dtype=torch.int32)
+        eng.call("nm_rows_argmin_dist", _lib.ptr(r), _lib.ptr(t), 0 if t.shape[0] == 1 else int(r.shape[1]),
+                 int(r.shape[0]), int(r.shape[1]), _lib.ptr(idx), None)
+        return int(idx.item())
 
 
 # ==========================================================================================
@@ -430,6 +442,84 @@ class NeuralMarionette(nn.Module):
         idx = torch.empty(T, N, 3, device=ctx.device, dtype=torch.int32) if return_indices else None
         eng.call("nm_voxelize_clip", _lib.ptr(pts), T, N, float(scale), _lib.ptr(vox), _lib.ptr(idx))
         return (vox, idx) if return_indices else vox
+
+    # -- sampling drivers: the rollout loops of the reference's demo scripts as methods ------------
+    @torch.no_grad()
+    def sample_generation(self, cond_voxel, Tgen=25, sample_num=3, eps_post=None, eps_prior=None):
+        """vis_generation.py:81-136: condition on ``cond_voxel`` (Tcond,1,G,G,G) with best-of-``sample_num``
+        posterior steps, then roll ``sample_num`` independent prior trajectories for ``Tgen`` steps and decode each.
+        eps_post (Tcond,sample_num,Z) / eps_prior (Tgen,sample_num,Z) inject the noise.
+        Returns keypoints_cond (1,Tcond,K,4) [the detected keypoints, as the script records], keypoints_gen
+        (1,Tgen,sample_num,K,4) and voxels (sample_num,Tcond+Tgen,1,G,G,G) binarised at 0.5."""
+        d = self.dyna_module
+        S, K, Z = int(sample_num), d.nkeypoints, d.nlatent_kypt
+        det = self.kypt_detector(cond_voxel[None])
+        kp = det["keypoints"]
+        Tc = int(kp.shape[1])
+        dev = kp.device
+        d._ensure_tree(det["affinity"], self._engine.ready())
+        e_post = _f32(eps_post, dev) if eps_post is not None else torch.randn(Tc, S, Z, device=dev)
+        e_prior = _f32(eps_prior, dev) if eps_prior is not None else torch.randn(Tgen, S, Z, device=dev)
+        h = d.init_kypt_rnn_state.detach()
+        offset = d.get_offset(kp)
+        cond = []
+        for t in range(Tc):
+            _, _, h = d.step(h, offset, e_post[t][:, None], keypoints_obs=kp[:, t], SAMPLE_NUM=S)
+            cond.append(kp[0, t])
+        h = h.expand(S, -1).contiguous()
+        off = offset.expand(S, -1, -1, -1).contiguous()
+        gen = []
+        for t in range(Tgen):
+            kps, _, h = d.step(h, off, e_prior[t])
+            gen.append(kps.view(S, K, 4))
+        cond_k = torch.stack(cond, 0)[None]
+        gen_k = torch.stack(gen, 0)[None]
+        full = torch.cat([cond_k.expand(S, -1, -1, -1), gen_k[0].transpose(0, 1)], dim=1).contiguous()
+        ff = det["first_feature"].expand(S, -1, -1, -1, -1).contiguous()
+        fr = cond_voxel[None, 0].to(dev).expand(S, -1, -1, -1, -1).contiguous()
+        vox = self.kypt_detector.decode_from_dyna(full, ff, fr)["gen"]
+        return dict(keypoints_cond=cond_k, keypoints_gen=gen_k, voxels=(vox >= 0.5).float(), voxels_raw=vox)
+
+    @torch.no_grad()
+    def sample_interpolation(self, target_voxel, sample_rate=10, sample_num=10000, eps_a=None, eps_b=None):
+        """vis_interpolation.py:80-143: key frames every ``sample_rate`` steps (and the last one) are matched with a
+        posterior sample, the frames in between come from the prior trajectory (out of ``sample_num``) that lands
+        nearest the next key frame.  eps_a (T,sample_num,Z): the step's first draw (posterior at key frames, prior
+        otherwise); eps_b (T,sample_num,Z): the second (prior, 'for choosing') draw at key frames.
+        Returns keypoints (1,T,K,4), voxels (T,1,G,G,G) binarised at 0.5, and the selected row per key frame."""
+        d = self.dyna_module
+        S, K, Z = int(sample_num), d.nkeypoints, d.nlatent_kypt
+        det = self.kypt_detector(target_voxel[None])
+        kp = det["keypoints"]
+        T = int(kp.shape[1])
+        dev = kp.device
+        d._ensure_tree(det["affinity"], self._engine.ready())
+        ea = _f32(eps_a, dev) if eps_a is not None else torch.randn(T, S, Z, device=dev)
+        eb = _f32(eps_b, dev) if eps_b is not None else torch.randn(T, S, Z, device=dev)
+        h = d.init_kypt_rnn_state.detach().expand(S, -1).contiguous()
+        off = d.get_offset(kp).expand(S, -1, -1, -1).contiguous()
+        selected, pending, picks = [], [], []
+        for t in range(T):
+            obs = kp[:, t].reshape(1, -1)
+            if t % sample_rate == 0 or t == T - 1:
+                obs_rows = obs.expand(S, -1).contiguous()
+                kp_post, z_post, _ = d.step(h, off, ea[t][None], keypoints_obs=obs_rows, SAMPLE_NUM=1, update_state=False)
+                kp_pri, _, _ = d.step(h, off, eb[t], update_state=False)
+                i1 = d.nearest_row(kp_post, obs)
+                i2 = d.nearest_row(kp_pri, kp_post[i1])
+                pending.append(obs_rows)
+                selected += [s[i2].view(K, 4) for s in pending]
+                pending = []
+                picks.append((i1, i2))
+                h1 = d.kypt_rnn_cell(torch.cat([kp_post[i1], z_post[i1]])[None], h[i1][None])
+                h = h1.expand(S, -1).contiguous()
+            else:
+                kps, _, h = d.step(h, off, ea[t])
+                pending.append(kps)
+        sel = torch.stack(selected, 0)[None].clone()
+        sel[0, :, :, -1] = sel[0, 0, :, -1]
+        vox = self.kypt_detector.decode_from_dyna(sel, det["first_feature"], target_voxel[None, 0].to(dev))["gen"][0]
+        return dict(keypoints=sel, voxels=(vox >= 0.5).float(), voxels_raw=vox, picks=picks)
 
     def control_active(self, module_actives):
         """neural_marionette.py:22-32."""

@@ -664,3 +664,84 @@ def nm_generate(sd: SD, opts, vox: Tensor, order, parents, eps_post: Tensor, eps
     return dict(gen=torch.cat([det["recon"][:, :Tc], gen], dim=1),
                 keypoints=torch.cat([det["keypoints"][:, :Tc], g["keypoints_gen"]], dim=1),
                 A_hats=None)
+
+
+# --------------------------------------------------------------------------------------
+# sampling drivers (vis_generation.py, vis_interpolation.py) — SURVEY 8(f3)
+# --------------------------------------------------------------------------------------
+def _prior_rows(sd: SD, h: Tensor, eps: Tensor, offset, order, parents):
+    """one prior sample per row: hsvrnn_bvh.py:210-218 as used by the demo loops."""
+    pm, ps = _dist_params(_mlp(h, sd, DYN + ".extract_prior_dist"))
+    z = pm + eps * ps
+    f, _ = fk_decode(sd, torch.cat([h, z], dim=-1), offset, order, parents)
+    return f, z
+
+
+def sample_generation(sd: SD, opts, cond_voxel: Tensor, Tgen: int, sample_num: int, eps_post: Tensor, eps_prior: Tensor,
+                      order=None, parents=None):
+    """vis_generation.py:81-136.  cond_voxel (Tcond,1,G,G,G); eps_post (Tcond,S,Z); eps_prior (Tgen,S,Z)."""
+    S, K = sample_num, opts.nkeypoints
+    det = detector_forward(sd, opts, cond_voxel[None])
+    kp = det["keypoints"]
+    if order is None:
+        _, order, _, parents = build_tree(det["affinity"])
+    Tc = kp.shape[1]
+    h = sd[DYN + ".init_kypt_rnn_state"].expand(S, -1)
+    off = bone_offsets(sd, kp, parents).expand(S, -1, -1, -1)
+    cond, gen = [], []
+    for t in range(Tc):                                                   # :97-115
+        flat = kp[:, t].reshape(1, -1).expand(S, -1)
+        mu, sig = _dist_params(_mlp(torch.cat([h, flat], dim=-1), sd, DYN + ".extract_post_dist"))
+        z = mu + eps_post[t] * sig
+        f, _ = fk_decode(sd, torch.cat([h, z], dim=-1), off, order, parents)
+        i = int((f - flat).pow(2).sum(dim=-1).argmin())
+        f, z, h = f[i][None].expand(S, -1), z[i][None].expand(S, -1), h[i][None].expand(S, -1)
+        cond.append(flat[i].view(K, 4))
+        h = gru_cell(sd, torch.cat([f, z], dim=-1), h)
+    for t in range(Tgen):                                                 # :117-127
+        f, z = _prior_rows(sd, h, eps_prior[t], off, order, parents)
+        gen.append(f.view(S, K, 4))
+        h = gru_cell(sd, torch.cat([f, z], dim=-1), h)
+    cond_k, gen_k = torch.stack(cond, 0)[None], torch.stack(gen, 0)[None]
+    vox = []
+    for s in range(S):                                                    # :132-139
+        full = torch.cat([cond_k, gen_k[:, :, s]], dim=1)
+        vox.append(decode_from_keypoints(sd, opts, full, det["first_feature"], cond_voxel[None, 0])[0])
+    vox = torch.stack(vox, 0)
+    return dict(keypoints_cond=cond_k, keypoints_gen=gen_k, voxels=(vox >= 0.5).float(), voxels_raw=vox)
+
+
+def sample_interpolation(sd: SD, opts, target_voxel: Tensor, sample_rate: int, sample_num: int, eps_a: Tensor, eps_b: Tensor,
+                         order=None, parents=None):
+    """vis_interpolation.py:80-143.  eps_a / eps_b (T,S,Z): first / second normal draw of each step."""
+    S, K = sample_num, opts.nkeypoints
+    det = detector_forward(sd, opts, target_voxel[None])
+    kp = det["keypoints"]
+    if order is None:
+        _, order, _, parents = build_tree(det["affinity"])
+    T = kp.shape[1]
+    h = sd[DYN + ".init_kypt_rnn_state"].expand(S, -1)
+    off = bone_offsets(sd, kp, parents).expand(S, -1, -1, -1)
+    selected, pending, picks = [], [], []
+    for t in range(T):
+        flat = kp[:, t].reshape(1, -1).expand(S, -1)
+        if t % sample_rate == 0 or t == T - 1:                            # :99-122
+            mu, sig = _dist_params(_mlp(torch.cat([h, flat], dim=-1), sd, DYN + ".extract_post_dist"))
+            z = mu + eps_a[t] * sig
+            f, _ = fk_decode(sd, torch.cat([h, z], dim=-1), off, order, parents)
+            fc, _ = _prior_rows(sd, h, eps_b[t], off, order, parents)
+            i1 = int((f - flat).pow(2).sum(dim=-1).argmin())
+            f, z, h = f[i1][None].expand(S, -1), z[i1][None].expand(S, -1), h[i1][None].expand(S, -1)
+            i2 = int((fc - f).pow(2).sum(dim=-1).argmin())
+            pending.append(flat)
+            selected += [s[i2].view(K, 4) for s in pending]
+            pending = []
+            picks.append((i1, i2))
+        else:                                                             # :123-130
+            f, z = _prior_rows(sd, h, eps_a[t], off, order, parents)
+            pending.append(f)
+        h = gru_cell(sd, torch.cat([f, z], dim=-1), h)
+    sel = torch.stack(selected, 0)[None].clone()
+    sel[0, :, :, -1] = sel[0, 0, :, -1]                                   # :133
+    vox = decode_from_keypoints(sd, opts, sel, det["first_feature"], target_voxel[None, 0])[0]
+    return dict(keypoints=sel, voxels=(vox >= 0.5).float(), voxels_raw=vox, picks=picks)

@@ -343,3 +343,50 @@ def test_voxelize_on_device_bit_exact(G, N, scale):
     assert np.array_equal(idx.cpu().numpy(), ref_idx), "voxel indices must be bit-exact"
     assert np.array_equal(vox.cpu().numpy(), ref_vox)
     assert vox.shape == (T, 1, G, G, G) and vox.dtype == torch.float32
+
+
+def test_generation_driver_vs_oracle():
+    """NeuralMarionette.sample_generation (vis_generation.py:81-136) against the oracle's restatement."""
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=23, variant="peaky")
+    net = _net(o, sd)
+    Tc, Tg, S = 5, 6, 3
+    vox = synth.figure_clip(1, Tc, 32, seed=3)[0]
+    e_post, e_prior = synth.make_eps((Tc, S, 128), 5), synth.make_eps((Tg, S, 128), 6)
+    out = net.sample_generation(vox.cuda(), Tgen=Tg, sample_num=S, eps_post=e_post.cuda(), eps_prior=e_prior.cuda())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.sample_generation(sd, o, vox, Tg, S, e_post, e_prior)
+    assert _err(out["keypoints_cond"], ref["keypoints_cond"]) < KP_TOL
+    e = _err(out["keypoints_gen"], ref["keypoints_gen"])
+    print("generation driver: generated keypoints err %.3e" % e)
+    assert e < 1e-3 and _err(out["keypoints_gen"][:, :2], ref["keypoints_gen"][:, :2]) < KP_TOL
+    assert out["voxels"].shape == (S, Tc + Tg, 1, 32, 32, 32)
+    margin = (ref["voxels_raw"] - 0.5).abs()
+    mism = ((out["voxels"].cpu() != ref["voxels"]) & (margin > 1e-3)).sum().item()
+    assert mism == 0, f"{mism} binarised voxels differ away from the 0.5 threshold"
+
+
+def test_interpolation_driver_vs_oracle():
+    """NeuralMarionette.sample_interpolation (vis_interpolation.py:80-143), selection indices exact."""
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=29, variant="peaky")
+    net = _net(o, sd)
+    T, S, rate = 11, 256, 5
+    vox = synth.figure_clip(1, T, 32, seed=8)[0]
+    ea, eb = synth.make_eps((T, S, 128), 9), synth.make_eps((T, S, 128), 10)
+    out = net.sample_interpolation(vox.cuda(), sample_rate=rate, sample_num=S, eps_a=ea.cuda(), eps_b=eb.cuda())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.sample_interpolation(sd, o, vox, rate, S, ea, eb)
+    print("interpolation picks", out["picks"], ref["picks"])
+    assert out["picks"][0] == ref["picks"][0], "first key frame's sample selection must match exactly"
+    if out["picks"] == ref["picks"]:
+        e = _err(out["keypoints"], ref["keypoints"])
+        print("interpolation driver: keypoints err %.3e" % e)
+        assert e < 1e-3
+    assert out["keypoints"].shape == (1, T, 24, 4) and out["voxels"].shape == (T, 1, 32, 32, 32)
+    # large sample count of the demo (10 000 rows) runs through the same kernels
+    big = net.sample_interpolation(vox[:3].cuda(), sample_rate=2, sample_num=10000)
+    torch.cuda.synchronize()
+    assert torch.isfinite(big["keypoints"]).all()

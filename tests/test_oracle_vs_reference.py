@@ -103,3 +103,127 @@ def test_input_path_restatement_matches_reference():
         assert np.array_equal(a, b)
         for t in range(4):
             assert np.array_equal(DU.voxelize(a[t], (G, G, G))[0], synth.voxelize(b[t], G))
+
+
+def _ref_net_and_feed(ref_modules, G, seed):
+    NeuralMarionette, _ = ref_modules
+    opt = _opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=seed, variant="peaky")
+    net = NeuralMarionette(opt).eval()
+    net.load_state_dict(sd)
+    net.anneal(1)
+    return net, o, sd
+
+
+class _Feed:
+    """hands pre-drawn eps tensors to Normal.rsample in call order (zeros once exhausted)"""
+
+    def __init__(self, chunks):
+        self.it = iter(chunks)
+
+    def __call__(self, shape, dtype, device):
+        e = next(self.it, None)
+        return torch.zeros(shape, dtype=dtype) if e is None or tuple(e.shape) != tuple(shape) else e.clone()
+
+
+def test_generation_driver_matches_reference_modules(ref_modules):
+    """oracle.sample_generation against the rollout of vis_generation.py:81-136 re-run on the REFERENCE's own
+    sub-modules (the script itself imports open3d/cv2 and cannot be imported here)."""
+    import torch.distributions.normal as tdn
+    from torch.distributions.normal import Normal
+    import torch.nn.functional as F
+    G, Tc, Tg, S = 32, 4, 5, 3
+    net, o, sd = _ref_net_and_feed(ref_modules, G, 23)
+    dm = net.dyna_module
+    vox = synth.figure_clip(1, Tc, G, seed=3)[0]
+    e_post, e_prior = synth.make_eps((Tc, S, 128), 5), synth.make_eps((Tg, S, 128), 6)
+    old = tdn._standard_normal
+    try:
+        with torch.no_grad():
+            tdn._standard_normal = _Feed([])
+            det = net.kypt_detector(vox[None])
+            kp = det["keypoints"]
+            dm.encode(kp, det["affinity"])                     # builds the tree (its own draws are irrelevant)
+            tdn._standard_normal = _Feed(list(e_post) + list(e_prior))
+            h = dm.init_kypt_rnn_state.expand(S, -1)
+            off = dm.get_offset(kp).expand(S, -1, -1, -1)
+            gen = []
+            for t in range(Tc):
+                flat = kp[:, t].clone().view(1, -1).expand(S, -1)
+                mu, sg = torch.chunk(dm.extract_post_dist(torch.cat([h, flat], -1)), 2, -1)
+                z = Normal(mu, F.softplus(sg) + 1e-4).rsample()
+                f, _ = dm.extract_kypt_from_latent_and_state(torch.cat([h, z], -1), off)
+                i = (f - flat).pow(2).sum(-1).argmin()
+                f, z, h = f[i][None].expand(S, -1), z[i][None].expand(S, -1), h[i][None].expand(S, -1)
+                h = dm.kypt_rnn_cell(torch.cat([f, z], -1), h)
+            for t in range(Tg):
+                mu, sg = torch.chunk(dm.extract_prior_dist(h), 2, -1)
+                z = Normal(mu, F.softplus(sg) + 1e-4).rsample()
+                f, _ = dm.extract_kypt_from_latent_and_state(torch.cat([h, z], -1), off)
+                gen.append(f.view(-1, 24, 4))
+                h = dm.kypt_rnn_cell(torch.cat([f, z], -1), h)
+            gen = torch.stack(gen, 0)[None]
+            full0 = torch.cat([kp[:, :Tc], gen[:, :, 0]], dim=1)
+            vox0 = net.kypt_detector.decode_from_dyna(full0, det["first_feature"], vox[None, 0])["gen"][0]
+    finally:
+        tdn._standard_normal = old
+    with torch.no_grad():
+        mine = O.sample_generation(sd, o, vox, Tg, S, e_post, e_prior)
+    assert torch.equal(mine["keypoints_gen"], gen)
+    assert torch.equal(mine["keypoints_cond"], kp[:, :Tc])
+    assert torch.equal(mine["voxels_raw"][0], vox0)
+
+
+def test_interpolation_driver_matches_reference_modules(ref_modules):
+    """oracle.sample_interpolation against the loop of vis_interpolation.py:80-143 on the reference's sub-modules."""
+    import torch.distributions.normal as tdn
+    from torch.distributions.normal import Normal
+    import torch.nn.functional as F
+    G, T, S, rate = 32, 7, 24, 3
+    net, o, sd = _ref_net_and_feed(ref_modules, G, 29)
+    dm = net.dyna_module
+    vox = synth.figure_clip(1, T, G, seed=8)[0]
+    ea, eb = synth.make_eps((T, S, 128), 9), synth.make_eps((T, S, 128), 10)
+    draws = []
+    for t in range(T):
+        draws += [ea[t], eb[t]] if (t % rate == 0 or t == T - 1) else [ea[t]]
+    old = tdn._standard_normal
+    try:
+        with torch.no_grad():
+            tdn._standard_normal = _Feed([])
+            det = net.kypt_detector(vox[None])
+            kp = det["keypoints"]
+            dm.encode(kp, det["affinity"])
+            tdn._standard_normal = _Feed(draws)
+            h = dm.init_kypt_rnn_state.expand(S, -1)
+            off = dm.get_offset(kp).expand(S, -1, -1, -1)
+            sel, pend = [], []
+            for t in range(T):
+                flat = kp[:, t].clone().view(1, -1).expand(S, -1)
+                if t % rate == 0 or t == T - 1:
+                    mu, sg = torch.chunk(dm.extract_post_dist(torch.cat([h, flat], -1)), 2, -1)
+                    pm, ps = torch.chunk(dm.extract_prior_dist(h), 2, -1)
+                    z = Normal(mu, F.softplus(sg) + 1e-4).rsample()
+                    zc = Normal(pm, F.softplus(ps) + 1e-4).rsample()
+                    f, _ = dm.extract_kypt_from_latent_and_state(torch.cat([h, z], -1), off)
+                    fc, _ = dm.extract_kypt_from_latent_and_state(torch.cat([h, zc], -1), off)
+                    i = (f - flat).pow(2).sum(-1).argmin()
+                    f, z, h = f[i][None].expand(S, -1), z[i][None].expand(S, -1), h[i][None].expand(S, -1)
+                    j = (fc - f).pow(2).sum(-1).argmin()
+                    pend.append(flat)
+                    sel += [s_[j].view(24, 4) for s_ in pend]
+                    pend = []
+                else:
+                    pm, ps = torch.chunk(dm.extract_prior_dist(h), 2, -1)
+                    z = Normal(pm, F.softplus(ps) + 1e-4).rsample()
+                    f, _ = dm.extract_kypt_from_latent_and_state(torch.cat([h, z], -1), off)
+                    pend.append(f)
+                h = dm.kypt_rnn_cell(torch.cat([f, z], -1), h)
+            sel = torch.stack(sel, 0)[None]
+            sel[0, :, :, -1] = sel[0, 0, :, -1]
+    finally:
+        tdn._standard_normal = old
+    with torch.no_grad():
+        mine = O.sample_interpolation(sd, o, vox, rate, S, ea, eb)
+    assert torch.equal(mine["keypoints"], sel)
