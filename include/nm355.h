@@ -86,6 +86,15 @@ int nm_detector_forward(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int
                         float* keypoints, float* heatmaps, float* first_feature, float* recon,
                         float* affinity, float* losses11);
 
+/* NeuralMarionette.forward with detector + learner active (model/neural_marionette.py:34-56) in one call:
+ * nm_detector_forward followed by nm_vrnn_encode on the detected keypoints, with the VRNN issued on a
+ * ctx-owned side stream as soon as the keypoints exist so that it runs beside the decoder (it does not
+ * depend on it).  Needs nm_vrnn_set_tree.  Arguments as in the two separate calls. */
+int nm_forward_fused(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t affinity_on, const float* eps,
+                     int32_t S, float* keypoints, float* heatmaps, float* first_feature, float* recon,
+                     float* affinity, float* losses11, float* kypt_recon, float* R, float* z, float* h,
+                     float* scalars2, int32_t* best_idx);
+
 /* KyptDetector.decode_from_dyna — model/kypt_detector.py:213-241.
  *  keypoints (B,Tg,K,4), first_feature (B,128,g,g,g), first_frame (B,1,G,G,G) -> gen (B,Tg,1,G,G,G) */
 int nm_decode_from_keypoints(nm_ctx* ctx, const float* keypoints, const float* first_feature,

@@ -64,6 +64,15 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
     }
     nm_ctx* c = new nm_ctx();
     c->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_clip, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_kp, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) {
+        nm_set_error("ctx_create: could not create the side stream / events");
+        delete c;
+        return NM_ERR_HIP;
+    }
     *out = c;
     return NM_OK;
 }
@@ -74,6 +83,9 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (void* p : ctx->owned) (void)hipFree(p);
     if (ctx->ws.base) (void)hipFree(ctx->ws.base);
+    if (ctx->ws2.base) (void)hipFree(ctx->ws2.base);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side}) if (e) (void)hipEventDestroy(e);
     delete ctx;
     return NM_OK;
 }

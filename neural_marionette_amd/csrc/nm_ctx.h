@@ -68,7 +68,10 @@ struct VrnnW {
 struct nm_ctx {
     nm_config cfg;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;         // ctx-owned side stream: clip-mean net / VRNN run beside the frame stack
+    hipEvent_t ev_fork = nullptr, ev_clip = nullptr, ev_kp = nullptr, ev_side = nullptr;
     Arena ws;                              // activations / scratch, reset per call
+    Arena ws2;                             // scratch of work issued on stream2 (VRNN beside the decoder)
     std::vector<void*> owned;              // weight allocations
     bool has_weights = false;
     DetectorW det;

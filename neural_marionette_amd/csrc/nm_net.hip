@@ -13,6 +13,7 @@
 #include "nm_ctx.h"
 #include "nm_heads.h"
 #include <cmath>
+#include <functional>
 
 namespace {
 
@@ -146,6 +147,7 @@ __global__ void pack_small_kernel(const float* a, int na, const float* b, int nb
 struct Net {
     nm_ctx* c; hipStream_t s; Arena& ws; int rc = NM_OK;
     explicit Net(nm_ctx* ctx) : c(ctx), s(ctx->stream), ws(ctx->ws) {}
+    Net(nm_ctx* ctx, hipStream_t stream) : c(ctx), s(stream), ws(ctx->ws) {}
     bool ok() const { return rc == NM_OK; }
     bool live() const { return rc == NM_OK && !ws.dry; }
     void run(int r) { if (r && !rc) rc = r; }
@@ -316,8 +318,11 @@ void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int fea
     n.ws.release(m0);
 }
 
+// `after_keypoints` (optional) is called once the keypoints kernel has been enqueued, in the live pass only: the
+// fused forward uses it to start the VRNN on the side stream while the decoder runs.
 int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on, float* keypoints, float* heatmaps,
-                   float* first_feature, float* recon, float* affinity, float* losses) {
+                   float* first_feature, float* recon, float* affinity, float* losses,
+                   const std::function<int()>* after_keypoints = nullptr) {
     Net n(c);
     const DetectorW& d = c->det;
     const int K = c->cfg.nkeypoints, G = c->cfg.grid_size, g = G / 4, F = B * T, N = c->cfg.nneighbor;
@@ -332,14 +337,26 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
     float* tail_part = n.alloc((size_t)F * tb * 3);
     float* aff = affinity_on ? (affinity ? affinity : n.alloc((size_t)N * K * K)) : nullptr;
 
-    {   // spatio-temporal heat-map from the clip mean, once per clip (kypt_detector.py:311-316)
-        const size_t m = n.ws.mark();
-        float* in = n.alloc((size_t)B * G3);
-        float* fclip = n.alloc((size_t)B * g3 * 2 * FEAT);
-        if (n.live()) n.run(nm_launch_mean_t(vox_in, B, T, G3, in, n.s));
-        feature_net(n, in, B, G, d.clip, g, fclip);
-        conv_gn(n, mk(fclip, B, g, g, g, 2 * FEAT), d.clip_head, nullptr, 1, 0, 1.0f, clip_head);
-        n.ws.release(m);
+    {   // spatio-temporal heat-map from the clip mean, once per clip (kypt_detector.py:311-316).  Only B frames of
+        // small, latency-bound launches: issued on the side stream so that it runs beside the per-frame encoder.  Its
+        // scratch stays allocated (no release) until the call ends because the two streams run concurrently.
+        Net n2(c, c->stream2);
+        if (n.live()) {
+            n.run(nm_check_hip(hipEventRecord(c->ev_fork, n.s), "fork event"));
+            n.run(nm_check_hip(hipStreamWaitEvent(c->stream2, c->ev_fork, 0), "side stream wait"));
+        }
+        float* in = n2.alloc((size_t)B * G3);
+        float* fclip = n2.alloc((size_t)B * g3 * 2 * FEAT);
+        if (n2.live()) n2.run(nm_launch_mean_t(vox_in, B, T, G3, in, n2.s));
+        const size_t saved_peak = n2.ws.peak;
+        n2.ws.peak = n2.ws.top;
+        feature_net(n2, in, B, G, d.clip, g, fclip);
+        const size_t local_peak = n2.ws.peak;                        // high-water mark of the clip net's scratch
+        n2.ws.peak = saved_peak > local_peak ? saved_peak : local_peak;
+        n2.ws.top = local_peak;                                      // keep that scratch out of reach of the main stream
+        conv_gn(n2, mk(fclip, B, g, g, g, 2 * FEAT), d.clip_head, nullptr, 1, 0, 1.0f, clip_head);
+        if (n2.live()) n2.run(nm_check_hip(hipEventRecord(c->ev_clip, c->stream2), "clip event"));
+        n.run(n2.rc);
     }
     for (size_t f0 = 0; f0 < (size_t)F; f0 += FRAME_CHUNK) {   // per-frame encoder (kypt_detector.py:330-336)
         const int nf = (int)(((size_t)F - f0) < FRAME_CHUNK ? ((size_t)F - f0) : FRAME_CHUNK);
@@ -352,8 +369,10 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
         float* head = n.alloc((size_t)F * g3 * K);
         conv_gn(n, mk(feat, F, g, g, g, FEAT), d.head, nullptr, 1, 0, 1.0f, head);
         if (n.live()) {
+            n.run(nm_check_hip(hipStreamWaitEvent(n.s, c->ev_clip, 0), "join clip net"));
             n.run(nm_launch_heatmap(head, clip_head, d.prop, F, T, K, g, heatmaps, heat_part, n.s));
             n.run(nm_launch_keypoints(heat_part, F, K, g, keypoints, heat_mean, n.s));
+            if (after_keypoints && n.ok()) n.run((*after_keypoints)());
         }
         n.ws.release(m);
     }
@@ -482,6 +501,33 @@ int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32
         nm_set_error("detector_forward: null / non-positive argument"); return NM_ERR_ARG;
     }
     return with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11); });
+}
+
+int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, const float* eps, int32_t S,
+                     float* keypoints, float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11,
+                     float* kypt_recon, float* R, float* z, float* h, float* scalars2, int32_t* best_idx) {
+    int rc = check_ready(c, "forward_fused");
+    if (rc) return rc;
+    if (!vox || !eps || !keypoints || !heatmaps || !first_feature || !recon || !losses11 || !kypt_recon || !R || !z || !h ||
+        !scalars2 || B <= 0 || T <= 0 || S <= 0) { nm_set_error("forward_fused: null / non-positive argument"); return NM_ERR_ARG; }
+    if (!c->vrnn.has_tree) { nm_set_error("forward_fused: nm_vrnn_set_tree has not been called"); return NM_ERR_STATE; }
+    // VRNN encode on the side stream, beside the decoder: it only needs the keypoints
+    std::function<int()> hook = [&]() -> int {
+        int r = nm_check_hip(hipEventRecord(c->ev_kp, c->stream), "keypoints event");
+        if (!r) r = nm_check_hip(hipStreamWaitEvent(c->stream2, c->ev_kp, 0), "side stream wait");
+        if (r) return r;
+        std::swap(c->ws, c->ws2);
+        hipStream_t main = c->stream;
+        c->stream = c->stream2;
+        r = nm_vrnn_encode(c, keypoints, eps, B, T, S, kypt_recon, R, z, h, scalars2, best_idx);
+        c->stream = main;
+        std::swap(c->ws, c->ws2);
+        if (!r) r = nm_check_hip(hipEventRecord(c->ev_side, c->stream2), "side event");
+        return r;
+    };
+    rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11, &hook); });
+    if (rc) return rc;
+    return nm_check_hip(hipStreamWaitEvent(c->stream, c->ev_side, 0), "join side stream");
 }
 
 int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* first_feature, const float* first_frame,

@@ -534,12 +534,47 @@ class NeuralMarionette(nn.Module):
         """neural_marionette.py:34-56.  ``eps`` optionally injects the VRNN noise (T,S,B,Z)."""
         log: Dict[str, torch.Tensor] = dict()
         keypoints = affinity = None
+        d, det_m = self.dyna_module, self.kypt_detector
+        if module_actives["learner"] and d.A is not None and det_m.affinity_start:
+            return self._forward_fused(vox_seq, eps)
         if module_actives["detector"] or module_actives["learner"]:
             det = self.kypt_detector(vox_seq)
             keypoints, affinity = det["keypoints"], det.get("affinity")
             log.update(det)
         if module_actives["learner"]:
             log.update(self.dyna_module.encode(keypoints.detach(), affinity.detach(), eps=eps))
+        return log
+
+    def _forward_fused(self, vox_seq, eps, SAMPLE_NUM=10):
+        """Detector + VRNN encode in one library call (nm_forward_fused): same outputs as the two-call path; the VRNN
+        runs on a side stream beside the decoder.  Used once the skeleton tree is cached."""
+        eng = self._engine
+        ctx = eng.ready()
+        dev = ctx.device
+        d, dm = self.kypt_detector, self.dyna_module
+        dm._ensure_tree(None, ctx)
+        B, T = int(vox_seq.shape[0]), int(vox_seq.shape[1])
+        G, K, g, Z, H, S = d.grid_size, d.nkeypoints, d.grid_size // 4, dm.nlatent_kypt, dm.nhidden_kypt, int(SAMPLE_NUM)
+        if tuple(vox_seq.shape[2:]) != (1, G, G, G):
+            raise ValueError(f"expected seq of shape (B,T,1,{G},{G},{G}), got {tuple(vox_seq.shape)}")
+        vox = _f32(vox_seq, dev)
+        e = dm._eps(T, (S, B, Z), dev, eps)
+        kp = torch.empty(B, T, K, 4, device=dev); hm = torch.empty(B, T, K, g, g, g, device=dev)
+        ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev); recon = torch.empty(B, T, 1, G, G, G, device=dev)
+        aff = torch.empty(d.nneighbor, K, K, 1, device=dev)
+        losses = torch.empty(len(DETECTOR_LOSS_KEYS), device=dev)
+        rec = torch.empty(B, T, K, 4, device=dev); R = torch.empty(B, T, K, 3, 3, device=dev)
+        z = torch.empty(B, T, Z, device=dev); h = torch.empty(B, T + 1, H, device=dev)
+        sc = torch.empty(2, device=dev); best = torch.empty(B, T, device=dev, dtype=torch.int32)
+        eng.call("nm_forward_fused", _lib.ptr(vox), B, T, 1, _lib.ptr(e), S, _lib.ptr(kp), _lib.ptr(hm), _lib.ptr(ff),
+                 _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses), _lib.ptr(rec), _lib.ptr(R), _lib.ptr(z), _lib.ptr(h),
+                 _lib.ptr(sc), _lib.ptr(best))
+        log = dict(recon=recon, keypoints=kp, heatmaps=hm, affinity=aff)
+        for i, name in enumerate(DETECTOR_LOSS_KEYS):
+            log[name] = losses[i]
+        log["first_feature"] = ff
+        log.update(kypt_recon=rec, R=R, z_kypts=z, h_kypts=h, kl_kypt=sc[0], kypt_recon_loss=sc[1],
+                   gae_recon_loss=torch.tensor(0).to(dev), topo_recon_loss=torch.tensor(0).to(dev), best_idx=best)
         return log
 
     def generate(self, vox_seq, module_actives=None, eps_post=None, eps_prior=None):
