@@ -126,6 +126,25 @@ int nm_vrnn_encode(nm_ctx* ctx, const float* keypoints, const float* eps, int32_
                    int32_t S, float* kypt_recon, float* R, float* z, float* h, float* scalars2,
                    int32_t* best_idx);
 
+/* ---- training, learner mode (pretrained_mode = 1: detector frozen, train.py:146) -------------------------
+ * nm_vrnn_encode_train = nm_vrnn_encode + a ctx-owned tape of the activations the backward pass needs.
+ * nm_vrnn_encode_backward back-propagates L = c_rec * kypt_recon_loss + c_kl * kl_kypt through time
+ * (dscal2 = device pointer to [dL/dkl_kypt, dL/dkypt_recon_loss], i.e. the loss weights as autograd hands
+ * them over) and overwrites the gradient buffers named like the reference's dyna_module parameters
+ * (all 21 trainable tensors; offset_param has requires_grad = False, hsvrnn_bvh.py:64-65).
+ * nm_adam_step is torch.optim.Adam's update (no weight decay / amsgrad) for one flat tensor. */
+typedef struct nm_named_grad {
+    const char* name;        /* state_dict key, e.g. "dyna_module.kypt_rnn_cell.weight_ih" */
+    float* data;             /* device pointer, same shape as the parameter, overwritten */
+    int64_t numel;
+} nm_named_grad;
+int nm_vrnn_encode_train(nm_ctx* ctx, const float* keypoints, const float* eps, int32_t B, int32_t T,
+                         int32_t S, float* kypt_recon, float* R, float* z, float* h, float* scalars2,
+                         int32_t* best_idx);
+int nm_vrnn_encode_backward(nm_ctx* ctx, const float* dscal2, const nm_named_grad* grads, int32_t count);
+int nm_adam_step(nm_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                 int32_t step, float lr, float beta1, float beta2, float eps);
+
 /* HSVRNNBVH.generate — model/hsvrnn_bvh.py:158-234.
  *  keypoints_cond (B,Tcond,K,4); eps_post (Tcond,S,B,Z); eps_prior (Ttot-Tcond,B,Z);
  *  out_cond (B,Tcond,K,4), out_gen (B,Ttot-Tcond,K,4); h_last (B,H) or NULL. */

@@ -53,6 +53,9 @@ SIGNATURES = {
     "nm_vrnn_set_tree": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "nm_vrnn_offsets": (C.c_int, [C.c_void_p, _P, _I, _I, _P]),
     "nm_vrnn_encode": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "nm_vrnn_encode_train": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "nm_vrnn_encode_backward": (C.c_int, [C.c_void_p, _P, C.POINTER(NmNamedTensor), _I]),
+    "nm_adam_step": (C.c_int, [C.c_void_p, _P, _P, _P, _P, C.c_int64, _I, _F, _F, _F, _F]),
     "nm_vrnn_generate": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "nm_vrnn_step": (C.c_int, [C.c_void_p, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "nm_rows_argmin_dist": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P]),

@@ -31,6 +31,7 @@ struct LinJob {
     const float* add; int ldadd; int add_mod;
     float* out; int ldo;
     int rows; int act; int batch;
+    const float* gate; int ldgate;     // backward: multiply by LeakyReLU'(saved activation) = (gate > 0 ? 1 : 0.01)
 };
 struct LinJobs { LinJob j[5]; int n; int start[6]; };
 
@@ -106,13 +107,14 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinJobs jobs) {
         if (J.add) v += J.add[(size_t)(b % J.add_mod) * J.ldadd + r];
         if (J.act == 1) v = lrelu(v, 0.01f);
         else if (J.act == 2) v = tanhf(v);
+        if (J.gate) v *= (J.gate[(size_t)b * J.ldgate + r] > 0.f ? 1.0f : 0.01f);
         J.out[(size_t)b * J.ldo + r] = v;
     }
 }
 
 // second layer of a prior / posterior MLP: rows (r, r+Z) -> mu, std = softplus(.)+1e-4 and, when eps is given,
 // z[i][b][r] = mu + eps[i][b][r] * std   (hsvrnn_bvh.py:93-107)
-struct DistJob { const float* W; const float* bias; const float* x; float* mu; float* sig; const float* eps; float* z; int S; };
+struct DistJob { const float* W; const float* bias; const float* x; float* mu; float* sig; const float* eps; float* z; int S; float* raw_s; };
 template <int NB>
 __global__ __launch_bounds__(256) void dist_rows_kernel(DistJob a, DistJob b, int njobs, int Z, int hid, int B) {
     const int lane = threadIdx.x & 63;
@@ -130,8 +132,10 @@ __global__ __launch_bounds__(256) void dist_rows_kernel(DistJob a, DistJob b, in
     if (lane < NB && b0 + lane < B) {
         const int bb = b0 + lane;
         const float mu = pick(am, lane) + J.bias[r];
-        const float sg = softplus(pick(as, lane) + J.bias[r + Z]) + 1e-4f;
+        const float sraw = pick(as, lane) + J.bias[r + Z];
+        const float sg = softplus(sraw) + 1e-4f;
         J.mu[(size_t)bb * Z + r] = mu; J.sig[(size_t)bb * Z + r] = sg;
+        if (J.raw_s) J.raw_s[(size_t)bb * Z + r] = sraw;
         if (J.eps) for (int i = 0; i < J.S; ++i) {
             const size_t o = ((size_t)i * B + bb) * Z + r;
             J.z[o] = mu + J.eps[o] * sg;
@@ -145,7 +149,8 @@ __global__ __launch_bounds__(256) void gru_rows_kernel(const float* __restrict__
                                                        const float* __restrict__ xa, int na, int lda,
                                                        const float* __restrict__ xb, int nb, int ldb,
                                                        const float* __restrict__ gh, const float* __restrict__ h, int ldh,
-                                                       float* __restrict__ hout, int ldo, int H, int B) {
+                                                       float* __restrict__ hout, int ldo, int H, int B,
+                                                       float* __restrict__ tape_gates /* [4][B][H]: r, z, n, W_hn h + b_hn; or null */) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= H) return;
@@ -167,6 +172,10 @@ __global__ __launch_bounds__(256) void gru_rows_kernel(const float* __restrict__
         const float ng = tanhf((pick(an, lane) + b_ih[2 * H + j]) + rg * g[2 * H + j]);
         const float hp = h[(size_t)b * ldh + j];
         hout[(size_t)b * ldo + j] = (hp - ng) * zg + ng;
+        if (tape_gates) {
+            const size_t o = (size_t)b * H + j, pl = (size_t)B * H;
+            tape_gates[o] = rg; tape_gates[pl + o] = zg; tape_gates[2 * pl + o] = ng; tape_gates[3 * pl + o] = g[2 * H + j];
+        }
     }
 }
 
@@ -185,6 +194,9 @@ struct FkArgs {
     int32_t* best; int ldbest;         // or null
     float* kl; float* rec; int ldstat; // per-sample sums (or null)
     int K, S, B, Z;
+    // training tape (all null in inference): hidden layers of the best sample's decoders, its heads, rotations, noise
+    const float* hr; const float* hj; const float* eps;              // sources: [S*B][128], [S*B][128], (S,B,Z)
+    float *t_hr, *t_hj, *t_raw, *t_rot6, *t_Rl, *t_Rg, *t_eps;       // [B][128], [B][128], [B][3+K], [B][6K], [B][9K], [B][9K], [B][Z]
 };
 
 __global__ __launch_bounds__(256) void fk_kernel(FkArgs a) {
@@ -258,6 +270,14 @@ __global__ __launch_bounds__(256) void fk_kernel(FkArgs a) {
     }
     if (a.out_z) for (int t = threadIdx.x; t < a.Z; t += 256) a.out_z[(size_t)b * a.ldz + t] = a.z[((size_t)(bi * a.B + b)) * a.Z + t];
     if (a.out_R) for (int t = threadIdx.x; t < K * 9; t += 256) a.out_R[(size_t)b * a.ldR + t] = Rg[bi * K * 9 + t];
+    if (a.t_hr) {
+        const size_t sb = (size_t)(bi * a.B + b);
+        for (int t = threadIdx.x; t < 128; t += 256) { a.t_hr[(size_t)b * 128 + t] = a.hr[sb * 128 + t]; a.t_hj[(size_t)b * 128 + t] = a.hj[sb * 128 + t]; }
+        for (int t = threadIdx.x; t < 3 + K; t += 256) a.t_raw[(size_t)b * (3 + K) + t] = rt[t];
+        for (int t = threadIdx.x; t < 6 * K; t += 256) a.t_rot6[(size_t)b * 6 * K + t] = a.rot[sb * 6 * K + t];
+        for (int t = threadIdx.x; t < 9 * K; t += 256) { a.t_Rl[(size_t)b * 9 * K + t] = Rl[bi * K * 9 + t]; a.t_Rg[(size_t)b * 9 * K + t] = Rg[bi * K * 9 + t]; }
+        for (int t = threadIdx.x; t < a.Z; t += 256) a.t_eps[(size_t)b * a.Z + t] = a.eps[sb * a.Z + t];
+    }
     if (a.kl) {
         float v = 0.f;
         for (int t = threadIdx.x; t < a.Z; t += 256) {
@@ -317,6 +337,227 @@ __global__ __launch_bounds__(256) void vrnn_stats_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ===================================================================================================================
+// Training (learner mode): back-propagation through time of HSVRNNBVH.encode
+// (hsvrnn_bvh.py:67-156) for L = c_rec * kypt_recon_loss + c_kl * kl_kypt.  The best-of-S argmin is a constant of
+// the backward pass (the reference's autograd only flows through the gathered sample), offsets are detached
+// (hsvrnn_bvh.py:253), the detected keypoints are detached (neural_marionette.py:53).
+// ===================================================================================================================
+// per-step slices of the training tape (see VrnnTape)
+struct StepTape { float *hid_p, *hid_q, *pmu, *psig, *praw, *qmu, *qsig, *qraw, *hr, *hj, *raw, *rot6, *Rl, *Rg, *eps, *gates; };
+
+struct VrnnTape {
+    int B = 0, T = 0, S = 0;
+    float* base = nullptr; size_t cap = 0;
+    // [T][B][...] planes
+    float *hid_p, *hid_q, *pmu, *psig, *praw, *qmu, *qsig, *qraw, *hr, *hj, *raw, *rot6, *Rl, *Rg, *eps, *gates;
+    float *kp_obs, *kp_rec, *z, *h, *offset;       // copies of the call's inputs / outputs ((B,T,..) layouts)
+    StepTape at(int t, int K, int Z, int H) const {
+        StepTape s; const size_t b = (size_t)t * B;
+        s.hid_p = hid_p + b * 128; s.hid_q = hid_q + b * 128; s.pmu = pmu + b * Z; s.psig = psig + b * Z; s.praw = praw + b * Z;
+        s.qmu = qmu + b * Z; s.qsig = qsig + b * Z; s.qraw = qraw + b * Z; s.hr = hr + b * 128; s.hj = hj + b * 128;
+        s.raw = raw + b * (3 + K); s.rot6 = rot6 + b * 6 * K; s.Rl = Rl + b * 9 * K; s.Rg = Rg + b * 9 * K; s.eps = eps + b * Z;
+        s.gates = gates + b * 4 * H;
+        return s;
+    }
+};
+VrnnTape g_tape;
+
+int tape_reserve(VrnnTape& tp, int B, int T, int S, int K, int Z, int H, hipStream_t s) {
+    const size_t per_tb = 128 * 4 + 6 * Z + (3 + K) + 6 * K + 18 * K + Z + 4 * H;
+    const size_t floats = (size_t)T * B * per_tb + (size_t)B * T * (K * 4 * 2 + Z) + (size_t)B * (T + 1) * H + (size_t)B * K * 3 + 1024;
+    if (tp.cap < floats) {
+        if (hipStreamSynchronize(s) != hipSuccess) return NM_ERR_HIP;
+        if (tp.base) (void)hipFree(tp.base);
+        tp.base = nullptr; tp.cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&tp.base), floats * sizeof(float)) != hipSuccess) { nm_set_error("vrnn tape: hipMalloc failed"); return NM_ERR_HIP; }
+        tp.cap = floats;
+    }
+    tp.B = B; tp.T = T; tp.S = S;
+    float* q = tp.base; const size_t tb = (size_t)T * B;
+    auto take = [&](size_t n) { float* r = q; q += n; return r; };
+    tp.hid_p = take(tb * 128); tp.hid_q = take(tb * 128); tp.pmu = take(tb * Z); tp.psig = take(tb * Z); tp.praw = take(tb * Z);
+    tp.qmu = take(tb * Z); tp.qsig = take(tb * Z); tp.qraw = take(tb * Z); tp.hr = take(tb * 128); tp.hj = take(tb * 128);
+    tp.raw = take(tb * (3 + K)); tp.rot6 = take(tb * 6 * K); tp.Rl = take(tb * 9 * K); tp.Rg = take(tb * 9 * K); tp.eps = take(tb * Z);
+    tp.gates = take(tb * 4 * H);
+    tp.kp_obs = take((size_t)B * T * K * 4); tp.kp_rec = take((size_t)B * T * K * 4); tp.z = take((size_t)B * T * Z);
+    tp.h = take((size_t)B * (T + 1) * H); tp.offset = take((size_t)B * K * 3);
+    return NM_OK;
+}
+
+// out[c][r] = in[r][c]
+__global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols, int ldin, float* __restrict__ out, int ldo, int col_off) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) { int r = r0 + j, c = c0 + tx; tile[j][tx] = (r < rows && c < cols) ? in[(size_t)r * ldin + c] : 0.f; }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) { int c = c0 + j, r = r0 + tx; if (c < cols && r < rows) out[(size_t)c * ldo + col_off + r] = tile[tx][j]; }
+}
+// out[c][col_off + r] = in[r][c] for r < rows, c < cols (in has leading dimension ldin)
+int launch_transpose(const float* in, int rows, int cols, int ldin, float* out, int ldo, int col_off, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, in, rows, cols, ldin, out, ldo, col_off);
+    return nm_check_hip(hipGetLastError(), "transpose launch");
+}
+
+// GRU cell backward (elementwise part): gates from the tape, dh_t -> dgi, dgh, dh_{t-1} (direct path)
+__global__ void gru_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ gates, const float* __restrict__ hprev, int ldh,
+                               int B, int H, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dhprev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, j = i % H;
+    const size_t pl = (size_t)B * H;
+    const float r = gates[i], z = gates[pl + i], n = gates[2 * pl + i], ghn = gates[3 * pl + i];
+    const float d = dh[i], hp = hprev[(size_t)b * ldh + j];
+    const float dn = d * (1.f - z), dz = d * (hp - n);
+    const float dpn = dn * (1.f - n * n), dr = dpn * ghn;
+    const float dpz = dz * z * (1.f - z), dpr = dr * r * (1.f - r);
+    float* gi = dgi + (size_t)b * 3 * H; float* gh = dgh + (size_t)b * 3 * H;
+    gi[j] = dpr; gi[H + j] = dpz; gi[2 * H + j] = dpn;
+    gh[j] = dpr; gh[H + j] = dpz; gh[2 * H + j] = dpn * r;
+    dhprev[i] = d * z;
+}
+
+__device__ __forceinline__ void cross3(const float* u, const float* v, float* o) {
+    o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0];
+}
+
+// forward kinematics + 6-D rotation backward for one sample per block.
+//   dx [B][ldx]: gradient wrt the GRU input (first K*4 entries = d kp*); adds the reconstruction-loss term.
+//   outputs: draw [B][3+K] (already through tanh'), drot6 [B][6K]
+__global__ __launch_bounds__(64) void fk_bwd_kernel(const float* __restrict__ dx, int ldx, const float* __restrict__ kp_rec,
+                                                    const float* __restrict__ kp_obs, int ldkp, const float* __restrict__ dscal,
+                                                    float inv_bt, const float* __restrict__ Rl, const float* __restrict__ Rg,
+                                                    const float* __restrict__ offset, const float* __restrict__ raw,
+                                                    const float* __restrict__ rot6, const int32_t* __restrict__ order,
+                                                    const int32_t* __restrict__ parents, int K, float* __restrict__ draw,
+                                                    float* __restrict__ drot6) {
+    extern __shared__ float sm[];
+    float* dpos = sm;               // [K][3]
+    float* dRg = dpos + K * 3;      // [K][9]
+    float* dRl = dRg + K * 9;       // [K][9]
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float c_rec = dscal[1] * inv_bt;
+    const float* rw = raw + (size_t)b * (3 + K);
+    for (int i = t; i < K * 4; i += 64) {
+        const int k = i >> 2, c = i & 3;
+        const float g = dx[(size_t)b * ldx + i] + c_rec * 2.f * (kp_rec[(size_t)b * ldkp + i] - kp_obs[(size_t)b * ldkp + i]);
+        if (c < 3) dpos[k * 3 + c] = g;
+        else draw[(size_t)b * (3 + K) + 3 + k] = g * 0.5f * (1.f - rw[3 + k] * rw[3 + k]);
+    }
+    for (int i = t; i < K * 9; i += 64) { dRg[i] = 0.f; dRl[i] = 0.f; }
+    __syncthreads();
+    if (t == 0) {
+        const float* RL = Rl + (size_t)b * 9 * K; const float* RG = Rg + (size_t)b * 9 * K;
+        const float* off = offset + (size_t)b * K * 3;
+        for (int o = K - 1; o >= 1; --o) {
+            const int idx = order[o], par = parents[idx];
+            float* gG = dRg + idx * 9;
+            for (int r = 0; r < 3; ++r) {
+                for (int m = 0; m < 3; ++m) gG[r * 3 + m] += dpos[idx * 3 + r] * off[idx * 3 + m];
+                dpos[par * 3 + r] += dpos[idx * 3 + r];
+            }
+            const float* P = RG + par * 9; const float* L = RL + idx * 9;
+            float* gL = dRl + idx * 9; float* gP = dRg + par * 9;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    gL[r * 3 + c] = (P[0 * 3 + r] * gG[0 * 3 + c] + P[1 * 3 + r] * gG[1 * 3 + c]) + P[2 * 3 + r] * gG[2 * 3 + c];      // P^T gG
+                    gP[r * 3 + c] += (gG[r * 3 + 0] * L[c * 3 + 0] + gG[r * 3 + 1] * L[c * 3 + 1]) + gG[r * 3 + 2] * L[c * 3 + 2];    // gG L^T
+                }
+        }
+        const int root = order[0];
+        for (int e = 0; e < 9; ++e) dRl[root * 9 + e] = dRg[root * 9 + e];
+        for (int c = 0; c < 3; ++c) draw[(size_t)b * (3 + K) + c] = dpos[root * 3 + c] * (1.f - rw[c] * rw[c]);
+    }
+    __syncthreads();
+    if (t < K) {     // 6-D -> rotation backward (geo_utils.py:56-78)
+        const float* p6 = rot6 + (size_t)b * 6 * K + t * 6;
+        const float a[3] = {p6[0], p6[1], p6[2]}, bb[3] = {p6[3], p6[4], p6[5]};
+        const float na = sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]), da = na + 1e-10f;
+        const float x[3] = {a[0] / da, a[1] / da, a[2] / da};
+        float c[3]; cross3(x, bb, c);
+        const float nc = sqrtf((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]), dc = nc + 1e-10f;
+        const float z[3] = {c[0] / dc, c[1] / dc, c[2] / dc};
+        const float* g = dRl + t * 9;
+        float gx[3] = {g[0], g[3], g[6]}, gy[3] = {g[1], g[4], g[7]}, gz[3] = {g[2], g[5], g[8]};
+        float tmp[3];
+        cross3(x, gy, tmp); for (int i = 0; i < 3; ++i) gz[i] += tmp[i];          // y = z x x
+        cross3(gy, z, tmp); for (int i = 0; i < 3; ++i) gx[i] += tmp[i];
+        const float cg = c[0] * gz[0] + c[1] * gz[1] + c[2] * gz[2];
+        float gc[3];
+        for (int i = 0; i < 3; ++i) gc[i] = gz[i] / dc - (nc > 0.f ? c[i] * cg / (nc * dc * dc) : 0.f);
+        cross3(bb, gc, tmp); for (int i = 0; i < 3; ++i) gx[i] += tmp[i];          // c = x x b
+        float gb[3]; cross3(gc, x, gb);
+        const float ag = a[0] * gx[0] + a[1] * gx[1] + a[2] * gx[2];
+        float* o = drot6 + (size_t)b * 6 * K + t * 6;
+        for (int i = 0; i < 3; ++i) { o[i] = gx[i] / da - (na > 0.f ? a[i] * ag / (na * da * da) : 0.f); o[3 + i] = gb[i]; }
+    }
+}
+
+// reparameterisation + KL backward: dz* -> (d raw_q, d raw_p) of the second MLP layers (mu | pre-softplus std)
+__global__ void dist_bwd_kernel(const float* __restrict__ dx, int ldx, int xoff, const float* __restrict__ dzdec, int lddz,
+                                const float* __restrict__ eps, const float* __restrict__ qmu, const float* __restrict__ qsig,
+                                const float* __restrict__ qraw, const float* __restrict__ pmu, const float* __restrict__ psig,
+                                const float* __restrict__ praw, const float* __restrict__ dscal, float inv_btz, int B, int Z,
+                                float* __restrict__ drq, float* __restrict__ drp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Z) return;
+    const int b = i / Z, j = i % Z;
+    const float dz = dx[(size_t)b * ldx + xoff + j] + dzdec[(size_t)b * lddz + j];
+    const float ckl = dscal[0] * inv_btz;
+    const float qs = qsig[i], ps = psig[i], d = qmu[i] - pmu[i], ips2 = 1.f / (ps * ps);
+    const float dqm = dz + ckl * d * ips2, dpm = -ckl * d * ips2;
+    const float dqs = dz * eps[i] + ckl * (qs * ips2 - 1.f / qs);
+    const float dps = ckl * (-(qs * qs + d * d) * ips2 / ps + 1.f / ps);
+    const float sq = qraw[i] > 20.f ? 1.f : sigmoidf(qraw[i]), sp = praw[i] > 20.f ? 1.f : sigmoidf(praw[i]);
+    drq[(size_t)b * 2 * Z + j] = dqm; drq[(size_t)b * 2 * Z + Z + j] = dqs * sq;
+    drp[(size_t)b * 2 * Z + j] = dpm; drp[(size_t)b * 2 * Z + Z + j] = dps * sp;
+}
+
+// weight gradient of a linear layer over all (t,b) samples: dW[r][k] = sum_s dA[s][r] * X[s][k], db[r] = sum_s dA[s][r].
+// X = [xa | xb] with per-sample strides (samples are indexed s = t*B + b).  One wavefront per output row.
+struct WgSeg { const float* p; int n; size_t st, sb; };
+__global__ __launch_bounds__(256) void wgrad_rows_kernel(const float* __restrict__ dA, int ldA, int rows, WgSeg xa, WgSeg xb, int T, int B,
+                                                         float* __restrict__ dW, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int in = xa.n + xb.n, S = T * B;
+    for (int k0 = 0; k0 < in; k0 += 64) {
+        const int k = k0 + lane;
+        float acc = 0.f;
+        if (k < in) {
+            const bool first = k < xa.n;
+            const WgSeg& sg = first ? xa : xb;
+            const int kk = first ? k : k - xa.n;
+            for (int s = 0; s < S; ++s) {
+                const int t = s / B, b = s % B;
+                acc += dA[(size_t)s * ldA + r] * sg.p[(size_t)t * sg.st + (size_t)b * sg.sb + kk];
+            }
+            dW[(size_t)r * in + k] = acc;
+        }
+    }
+    if (db && lane == 0) { float a = 0.f; for (int s = 0; s < S; ++s) a += dA[(size_t)s * ldA + r]; db[r] = a; }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += x[(size_t)r * cols + c];
+    out[c] = a;
+}
+
+// fused Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float lr, float b1, float b2, float eps, float bc1, float bc2) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = v[i] = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
 struct StepBufs {
     float *hid_prior, *hid_post, *rh, *jh, *gh, *pmu, *psig, *qmu, *qsig, *z, *hr, *hj, *rootout, *rot;
 };
@@ -326,7 +567,7 @@ void add_job(LinJobs& J, const LinearW& L, int col0, const float* xa, int na, in
     LinJob& j = J.j[J.n];
     j.W = L.w; j.ldw = L.in; j.col0 = col0; j.xa = xa; j.na = na; j.lda = lda; j.xb = xb; j.nb = nb; j.ldb = ldb;
     j.bias = bias ? L.b : nullptr; j.add = add; j.ldadd = ldadd; j.add_mod = add_mod > 0 ? add_mod : 1;
-    j.out = out; j.ldo = ldo; j.rows = L.out; j.act = act; j.batch = batch;
+    j.out = out; j.ldo = ldo; j.rows = L.out; j.act = act; j.batch = batch; j.gate = nullptr; j.ldgate = 0;
     J.start[J.n + 1] = J.start[J.n] + L.out;
     J.n++;
 }
@@ -346,13 +587,13 @@ int launch_jobs(const LinJobs& J, hipStream_t s) {
 }
 
 int launch_gru(const float* W_ih, const float* b_ih, const float* xa, int na, int lda, const float* xb, int nb_, int ldb,
-               const float* gh, const float* h, int ldh, float* hout, int ldo, int H, int B, hipStream_t s) {
+               const float* gh, const float* h, int ldh, float* hout, int ldo, int H, int B, hipStream_t s, float* tg = nullptr) {
     const int nb = pick_nb(B);
     dim3 grid((H + 3) / 4, (B + nb - 1) / nb);
-    if (nb == 1) hipLaunchKernelGGL((gru_rows_kernel<1>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B);
-    else if (nb == 2) hipLaunchKernelGGL((gru_rows_kernel<2>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B);
-    else if (nb == 4) hipLaunchKernelGGL((gru_rows_kernel<4>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B);
-    else hipLaunchKernelGGL((gru_rows_kernel<8>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B);
+    if (nb == 1) hipLaunchKernelGGL((gru_rows_kernel<1>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B, tg);
+    else if (nb == 2) hipLaunchKernelGGL((gru_rows_kernel<2>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B, tg);
+    else if (nb == 4) hipLaunchKernelGGL((gru_rows_kernel<4>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B, tg);
+    else hipLaunchKernelGGL((gru_rows_kernel<8>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B, tg);
     return nm_check_hip(hipGetLastError(), "gru launch");
 }
 
@@ -367,6 +608,7 @@ StepBufs alloc_step(Arena& ws, int B, int S, int K, int Z, int H) {
 }
 
 struct StepIO {
+    const StepTape* tape = nullptr;
     const float* h; int ldh;           // h_{t-1} [B][ldh]
     const float* obs; int ldobs;       // detected keypoints (posterior) or null (prior)
     const float* eps;                  // (S,B,Z) posterior / (B,Z) prior
@@ -397,8 +639,8 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         if ((rc = launch_jobs(J, s))) return rc;
     }
     {   // 2. distribution parameters + samples
-        DistJob jp{w.prior2.w, w.prior2.b, sb.hid_prior, sb.pmu, sb.psig, post ? nullptr : io.eps, sb.z, 1};
-        DistJob jq{w.post2.w, w.post2.b, sb.hid_post, sb.qmu, sb.qsig, io.eps, sb.z, S};
+        DistJob jp{w.prior2.w, w.prior2.b, sb.hid_prior, sb.pmu, sb.psig, post ? nullptr : io.eps, sb.z, 1, io.tape ? io.tape->praw : nullptr};
+        DistJob jq{w.post2.w, w.post2.b, sb.hid_post, sb.qmu, sb.qsig, io.eps, sb.z, S, io.tape ? io.tape->qraw : nullptr};
         DistJob first = prior ? jp : jq, second = jq;
         const int nj = (prior && post) ? 2 : 1;
         const int nb = pick_nb(B);
@@ -428,12 +670,15 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         a.out_kp = io.out_kp; a.ldkp = io.ldkp; a.out_z = io.out_z; a.ldz = io.ldz; a.out_R = io.out_R; a.ldR = io.ldR;
         a.best = io.best; a.ldbest = io.ldbest; a.kl = kl ? io.kl : nullptr; a.rec = io.rec; a.ldstat = io.ldstat;
         a.K = K; a.S = S; a.B = B; a.Z = Z;
+        a.hr = sb.hr; a.hj = sb.hj; a.eps = io.eps;
+        a.t_hr = a.t_hj = a.t_raw = a.t_rot6 = a.t_Rl = a.t_Rg = a.t_eps = nullptr;
+        if (io.tape) { a.t_hr = io.tape->hr; a.t_hj = io.tape->hj; a.t_raw = io.tape->raw; a.t_rot6 = io.tape->rot6; a.t_Rl = io.tape->Rl; a.t_Rg = io.tape->Rg; a.t_eps = io.tape->eps; }
         size_t lds = ((size_t)S * K * 21 + S) * sizeof(float);
         hipLaunchKernelGGL(fk_kernel, dim3(B), dim3(256), lds, s, a);
         if ((rc = nm_check_hip(hipGetLastError(), "fk launch"))) return rc;
     }
     if (io.hout) {   // 5. GRU
-        if ((rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s))) return rc;
+        if ((rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s, io.tape ? io.tape->gates : nullptr))) return rc;
     }
     return NM_OK;
 }
@@ -491,8 +736,8 @@ int nm_vrnn_offsets(nm_ctx* c, const float* keypoints, int32_t B, int32_t T, flo
     return nm_check_hip(hipGetLastError(), "offsets launch");
 }
 
-int nm_vrnn_encode(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
-                   float* R, float* z, float* h, float* scalars2, int32_t* best_idx) {
+static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
+                       float* R, float* z, float* h, float* scalars2, int32_t* best_idx, bool train) {
     int rc = ready(c, "vrnn_encode", true);
     if (rc) return rc;
     if (!keypoints || !eps || !kypt_recon || !R || !z || !h || !scalars2 || B <= 0 || T <= 0 || S <= 0) {
@@ -507,6 +752,7 @@ int nm_vrnn_encode(nm_ctx* c, const float* keypoints, const float* eps, int32_t 
     float* offset = c->ws.f((size_t)B * K * 3);
     float* kl = c->ws.f((size_t)B * T); float* rec = c->ws.f((size_t)B * T);
     if (c->ws.overflow) { nm_set_error("vrnn_encode: workspace overflow"); return NM_ERR_STATE; }
+    if (train && (rc = tape_reserve(g_tape, B, T, S, K, Z, H, c->stream))) return rc;
     if ((rc = nm_vrnn_offsets(c, keypoints, B, T, offset))) return rc;
     hipLaunchKernelGGL(broadcast_rows_kernel, dim3((H * B + 255) / 256), dim3(256), 0, c->stream, c->vrnn.h0, H, h, (T + 1) * H, B);
     for (int t = 0; t < T; ++t) {
@@ -521,10 +767,172 @@ int nm_vrnn_encode(nm_ctx* c, const float* keypoints, const float* eps, int32_t 
         io.kl = kl + t; io.rec = rec + t; io.ldstat = T;
         io.hout = h + (size_t)(t + 1) * H; io.ldho = (T + 1) * H;
         io.want_prior = true;
-        if ((rc = vrnn_step(c, sb, io, B, S))) return rc;
+        StepTape st; StepBufs sbt = sb;
+        if (train) {   // this step's hidden layers / distribution parameters land in the tape instead of the scratch
+            st = g_tape.at(t, K, Z, H); io.tape = &st;
+            sbt.hid_prior = st.hid_p; sbt.hid_post = st.hid_q; sbt.pmu = st.pmu; sbt.psig = st.psig; sbt.qmu = st.qmu; sbt.qsig = st.qsig;
+        }
+        if ((rc = vrnn_step(c, sbt, io, B, S))) return rc;
+    }
+    if (train) {
+        hipStream_t s = c->stream;
+        (void)hipMemcpyAsync(g_tape.kp_obs, keypoints, (size_t)B * T * S4 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(g_tape.kp_rec, kypt_recon, (size_t)B * T * S4 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(g_tape.z, z, (size_t)B * T * Z * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(g_tape.h, h, (size_t)B * (T + 1) * H * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(g_tape.offset, offset, (size_t)B * K * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
     }
     hipLaunchKernelGGL(vrnn_stats_kernel, dim3(1), dim3(256), 0, c->stream, kl, rec, B * T, Z, scalars2);
     return nm_check_hip(hipGetLastError(), "vrnn_encode");
+}
+
+int nm_vrnn_encode(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
+                   float* R, float* z, float* h, float* scalars2, int32_t* best_idx) {
+    return encode_impl(c, keypoints, eps, B, T, S, kypt_recon, R, z, h, scalars2, best_idx, false);
+}
+
+int nm_vrnn_encode_train(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
+                         float* R, float* z, float* h, float* scalars2, int32_t* best_idx) {
+    return encode_impl(c, keypoints, eps, B, T, S, kypt_recon, R, z, h, scalars2, best_idx, true);
+}
+
+static int launch_wgrad(const float* dA, int ldA, int rows, WgSeg xa, WgSeg xb, int T, int B, float* dW, float* db, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dA, ldA, rows, xa, xb, T, B, dW, db);
+    return nm_check_hip(hipGetLastError(), "wgrad launch");
+}
+
+int nm_vrnn_encode_backward(nm_ctx* c, const float* dscal2, const nm_named_grad* grads, int32_t count) {
+    int rc = ready(c, "vrnn_encode_backward", true);
+    if (rc) return rc;
+    const VrnnTape& tp = g_tape;
+    if (!tp.base || tp.B <= 0) { nm_set_error("vrnn_encode_backward: no recorded forward (call nm_vrnn_encode_train first)"); return NM_ERR_STATE; }
+    if (!dscal2 || !grads || count <= 0) { nm_set_error("vrnn_encode_backward: bad argument"); return NM_ERR_ARG; }
+    const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4, B = tp.B, T = tp.T, R0 = 3 + K, J6 = 6 * K;
+    const VrnnW& w = c->vrnn;
+    std::map<std::string, std::pair<float*, int64_t>> out;
+    for (int i = 0; i < count; ++i) if (grads[i].name && grads[i].data) out[grads[i].name] = std::make_pair(grads[i].data, grads[i].numel);
+    auto G = [&](const char* name, int64_t numel) -> float* {
+        auto it = out.find(std::string("dyna_module.") + name);
+        if (it == out.end() || it->second.second != numel) { if (!rc) { nm_set_error("vrnn_encode_backward: gradient buffer '%s' missing or wrong size", name); rc = NM_ERR_ARG; } return nullptr; }
+        return it->second.first;
+    };
+    float* g_ih = G("kypt_rnn_cell.weight_ih", (int64_t)3 * H * (S4 + Z)); float* g_hh = G("kypt_rnn_cell.weight_hh", (int64_t)3 * H * H);
+    float* g_bih = G("kypt_rnn_cell.bias_ih", 3 * H); float* g_bhh = G("kypt_rnn_cell.bias_hh", 3 * H);
+    float* g_r0 = G("root_intensity_decoder.0.weight", (int64_t)128 * (H + Z)); float* g_r0b = G("root_intensity_decoder.0.bias", 128);
+    float* g_r2 = G("root_intensity_decoder.2.weight", (int64_t)R0 * 128); float* g_r2b = G("root_intensity_decoder.2.bias", R0);
+    float* g_j0 = G("joint_matrix_decoder.0.weight", (int64_t)128 * (H + Z)); float* g_j0b = G("joint_matrix_decoder.0.bias", 128);
+    float* g_j2 = G("joint_matrix_decoder.2.weight", (int64_t)J6 * 128); float* g_j2b = G("joint_matrix_decoder.2.bias", J6);
+    float* g_q0 = G("extract_post_dist.0.weight", (int64_t)128 * (H + S4)); float* g_q0b = G("extract_post_dist.0.bias", 128);
+    float* g_q2 = G("extract_post_dist.2.weight", (int64_t)2 * Z * 128); float* g_q2b = G("extract_post_dist.2.bias", 2 * Z);
+    float* g_p0 = G("extract_prior_dist.0.weight", (int64_t)128 * H); float* g_p0b = G("extract_prior_dist.0.bias", 128);
+    float* g_p2 = G("extract_prior_dist.2.weight", (int64_t)2 * Z * 128); float* g_p2b = G("extract_prior_dist.2.bias", 2 * Z);
+    float* g_h0 = G("init_kypt_rnn_state", H);
+    if (rc) return rc;
+
+    const size_t tb = (size_t)T * B;
+    const size_t fl = (size_t)(S4 + Z) * 3 * H + (size_t)H * 3 * H + 128 * R0 + 128 * J6 + (size_t)(H + Z) * 256 + 2 * 128 * 2 * Z + (size_t)H * 256 +
+                      tb * (6 * H + R0 + J6 + 4 * 128 + 4 * Z) + (size_t)B * (2 * H + S4 + Z + Z) + 4096;
+    if ((rc = nm_ctx_reserve(c, fl * sizeof(float)))) return rc;
+    Arena& ws = c->ws; ws.release(0);
+    hipStream_t s = c->stream;
+    float* WihT = ws.f((size_t)(S4 + Z) * 3 * H); float* WhhT = ws.f((size_t)H * 3 * H);
+    float* Wr2T = ws.f(128 * R0); float* Wj2T = ws.f(128 * J6); float* WdecT = ws.f((size_t)(H + Z) * 256);
+    float* Wq2T = ws.f(128 * 2 * Z); float* Wp2T = ws.f(128 * 2 * Z); float* WpqT = ws.f((size_t)H * 256);
+    float* dgi = ws.f(tb * 3 * H); float* dgh = ws.f(tb * 3 * H); float* draw = ws.f(tb * R0); float* drot6 = ws.f(tb * J6);
+    float* da_r = ws.f(tb * 128); float* da_j = ws.f(tb * 128); float* da_q = ws.f(tb * 128); float* da_p = ws.f(tb * 128);
+    float* drq = ws.f(tb * 2 * Z); float* drp = ws.f(tb * 2 * Z);
+    float* dh[2] = {ws.f((size_t)B * H), ws.f((size_t)B * H)};
+    float* dx = ws.f((size_t)B * (S4 + Z)); float* dzdec = ws.f((size_t)B * Z);
+    if (ws.overflow) { nm_set_error("vrnn_encode_backward: workspace overflow"); return NM_ERR_STATE; }
+
+    // transposed weights (the backward products x = dy W are row dots of W^T)
+    if ((rc = launch_transpose(w.w_ih, 3 * H, S4 + Z, S4 + Z, WihT, 3 * H, 0, s))) return rc;
+    if ((rc = launch_transpose(w.w_hh, 3 * H, H, H, WhhT, 3 * H, 0, s))) return rc;
+    if ((rc = launch_transpose(w.root2.w, R0, 128, 128, Wr2T, R0, 0, s))) return rc;
+    if ((rc = launch_transpose(w.joint2.w, J6, 128, 128, Wj2T, J6, 0, s))) return rc;
+    if ((rc = launch_transpose(w.root0.w, 128, H + Z, H + Z, WdecT, 256, 0, s))) return rc;
+    if ((rc = launch_transpose(w.joint0.w, 128, H + Z, H + Z, WdecT, 256, 128, s))) return rc;
+    if ((rc = launch_transpose(w.post2.w, 2 * Z, 128, 128, Wq2T, 2 * Z, 0, s))) return rc;
+    if ((rc = launch_transpose(w.prior2.w, 2 * Z, 128, 128, Wp2T, 2 * Z, 0, s))) return rc;
+    if ((rc = launch_transpose(w.post0.w, 128, H, H + S4, WpqT, 256, 0, s))) return rc;
+    if ((rc = launch_transpose(w.prior0.w, 128, H, H, WpqT, 256, 128, s))) return rc;
+    if ((rc = nm_check_hip(hipMemsetAsync(dh[0], 0, (size_t)B * H * sizeof(float), s), "memset dh"))) return rc;
+
+    auto job = [&](LinJobs& J, const float* W, int ldw, int rows, const float* xa, int na, int lda, const float* xb, int nb, int ldb,
+                   const float* add, int ldadd, float* o, int ldo, const float* gate, int ldgate) {
+        LinearW L; L.w = const_cast<float*>(W); L.b = nullptr; L.in = ldw; L.out = rows;
+        add_job(J, L, 0, xa, na, lda, xb, nb, ldb, false, add, ldadd, B, o, ldo, 0, B);
+        J.j[J.n - 1].gate = gate; J.j[J.n - 1].ldgate = ldgate;
+    };
+    int cur = 0;
+    const float inv_bt = 1.0f / (float)(B * T), inv_btz = 1.0f / ((float)B * (float)T * (float)Z);
+    for (int t = T - 1; t >= 0; --t) {
+        const StepTape st = tp.at(t, K, Z, H);
+        const float* hprev = tp.h + (size_t)t * H;                        // (B, T+1, H) layout
+        float* dgi_t = dgi + (size_t)t * B * 3 * H; float* dgh_t = dgh + (size_t)t * B * 3 * H;
+        float* draw_t = draw + (size_t)t * B * R0; float* drot_t = drot6 + (size_t)t * B * J6;
+        float* dar = da_r + (size_t)t * B * 128; float* daj = da_j + (size_t)t * B * 128;
+        float* daq = da_q + (size_t)t * B * 128; float* dap = da_p + (size_t)t * B * 128;
+        float* drq_t = drq + (size_t)t * B * 2 * Z; float* drp_t = drp + (size_t)t * B * 2 * Z;
+        float* dhp = dh[cur ^ 1];
+        hipLaunchKernelGGL(gru_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, s, dh[cur], st.gates, hprev, (T + 1) * H, B, H, dgi_t, dgh_t, dhp);
+        { LinJobs J; J.n = 0; J.start[0] = 0;
+          job(J, WihT, 3 * H, S4 + Z, dgi_t, 3 * H, 3 * H, nullptr, 0, 0, nullptr, 0, dx, S4 + Z, nullptr, 0);
+          job(J, WhhT, 3 * H, H, dgh_t, 3 * H, 3 * H, nullptr, 0, 0, dhp, H, dhp, H, nullptr, 0);
+          if ((rc = launch_jobs(J, s))) return rc; }
+        hipLaunchKernelGGL(fk_bwd_kernel, dim3(B), dim3(64), (size_t)K * 21 * sizeof(float), s, dx, S4 + Z, tp.kp_rec + (size_t)t * S4,
+                           tp.kp_obs + (size_t)t * S4, T * S4, dscal2, inv_bt, st.Rl, st.Rg, tp.offset, st.raw, st.rot6, w.order, w.parents, K,
+                           draw_t, drot_t);
+        { LinJobs J; J.n = 0; J.start[0] = 0;
+          job(J, Wr2T, R0, 128, draw_t, R0, R0, nullptr, 0, 0, nullptr, 0, dar, 128, st.hr, 128);
+          job(J, Wj2T, J6, 128, drot_t, J6, J6, nullptr, 0, 0, nullptr, 0, daj, 128, st.hj, 128);
+          if ((rc = launch_jobs(J, s))) return rc; }
+        { LinJobs J; J.n = 0; J.start[0] = 0;
+          job(J, WdecT, 256, H, dar, 128, 128, daj, 128, 128, dhp, H, dhp, H, nullptr, 0);
+          job(J, WdecT + (size_t)H * 256, 256, Z, dar, 128, 128, daj, 128, 128, nullptr, 0, dzdec, Z, nullptr, 0);
+          if ((rc = launch_jobs(J, s))) return rc; }
+        hipLaunchKernelGGL(dist_bwd_kernel, dim3((B * Z + 255) / 256), dim3(256), 0, s, dx, S4 + Z, S4, dzdec, Z, st.eps, st.qmu, st.qsig, st.qraw,
+                           st.pmu, st.psig, st.praw, dscal2, inv_btz, B, Z, drq_t, drp_t);
+        { LinJobs J; J.n = 0; J.start[0] = 0;
+          job(J, Wq2T, 2 * Z, 128, drq_t, 2 * Z, 2 * Z, nullptr, 0, 0, nullptr, 0, daq, 128, st.hid_q, 128);
+          job(J, Wp2T, 2 * Z, 128, drp_t, 2 * Z, 2 * Z, nullptr, 0, 0, nullptr, 0, dap, 128, st.hid_p, 128);
+          if ((rc = launch_jobs(J, s))) return rc; }
+        { LinJobs J; J.n = 0; J.start[0] = 0;
+          job(J, WpqT, 256, H, daq, 128, 128, dap, 128, 128, dhp, H, dhp, H, nullptr, 0);
+          if ((rc = launch_jobs(J, s))) return rc; }
+        cur ^= 1;
+    }
+    // init_kypt_rnn_state is expanded over the batch: its gradient is the batch sum of dh_0
+    hipLaunchKernelGGL(colsum_kernel, dim3((H + 255) / 256), dim3(256), 0, s, dh[cur], B, H, g_h0);
+
+    // weight gradients: one GEMM-like pass per layer over all (t, b) samples
+    const size_t hB = (size_t)(T + 1) * H;
+    WgSeg none{nullptr, 0, 0, 0};
+    WgSeg x_h{tp.h, H, (size_t)H, hB};                                       // h_{t-1}: (B, T+1, H)
+    WgSeg x_kp{tp.kp_rec, S4, (size_t)S4, (size_t)T * S4}, x_obs{tp.kp_obs, S4, (size_t)S4, (size_t)T * S4};
+    WgSeg x_z{tp.z, Z, (size_t)Z, (size_t)T * Z};
+    WgSeg x_hr{tp.hr, 128, (size_t)B * 128, 128}, x_hj{tp.hj, 128, (size_t)B * 128, 128};
+    WgSeg x_uq{tp.hid_q, 128, (size_t)B * 128, 128}, x_up{tp.hid_p, 128, (size_t)B * 128, 128};
+    if ((rc = launch_wgrad(dgi, 3 * H, 3 * H, x_kp, x_z, T, B, g_ih, g_bih, s))) return rc;
+    if ((rc = launch_wgrad(dgh, 3 * H, 3 * H, x_h, none, T, B, g_hh, g_bhh, s))) return rc;
+    if ((rc = launch_wgrad(draw, R0, R0, x_hr, none, T, B, g_r2, g_r2b, s))) return rc;
+    if ((rc = launch_wgrad(drot6, J6, J6, x_hj, none, T, B, g_j2, g_j2b, s))) return rc;
+    if ((rc = launch_wgrad(da_r, 128, 128, x_h, x_z, T, B, g_r0, g_r0b, s))) return rc;
+    if ((rc = launch_wgrad(da_j, 128, 128, x_h, x_z, T, B, g_j0, g_j0b, s))) return rc;
+    if ((rc = launch_wgrad(drq, 2 * Z, 2 * Z, x_uq, none, T, B, g_q2, g_q2b, s))) return rc;
+    if ((rc = launch_wgrad(drp, 2 * Z, 2 * Z, x_up, none, T, B, g_p2, g_p2b, s))) return rc;
+    if ((rc = launch_wgrad(da_q, 128, 128, x_h, x_obs, T, B, g_q0, g_q0b, s))) return rc;
+    if ((rc = launch_wgrad(da_p, 128, 128, x_h, none, T, B, g_p0, g_p0b, s))) return rc;
+    return nm_check_hip(hipGetLastError(), "vrnn_encode_backward");
+}
+
+int nm_adam_step(nm_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, int32_t step, float lr,
+                 float beta1, float beta2, float eps) {
+    if (!c || !param || !grad || !exp_avg || !exp_avg_sq || numel <= 0 || step <= 0) { nm_set_error("adam_step: bad argument"); return NM_ERR_ARG; }
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    int blocks = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, c->stream, param, grad, exp_avg, exp_avg_sq, (size_t)numel, lr, beta1, beta2, eps, bc1, bc2);
+    return nm_check_hip(hipGetLastError(), "adam launch");
 }
 
 int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_post, const float* eps_prior, int32_t B,
@@ -674,6 +1082,7 @@ int nm_vrnn_fk(nm_ctx* c, const float* dec_in, const float* offset, int32_t B, f
     a.order = w.order; a.parents = w.parents; a.qmu = a.qsig = a.pmu = a.psig = nullptr;
     a.out_kp = kp; a.ldkp = K * 4; a.out_z = nullptr; a.ldz = 0; a.out_R = R; a.ldR = K * 9;
     a.best = nullptr; a.ldbest = 0; a.kl = nullptr; a.rec = nullptr; a.ldstat = 0; a.K = K; a.S = 1; a.B = B; a.Z = Z;
+    a.hr = a.hj = a.eps = nullptr; a.t_hr = a.t_hj = a.t_raw = a.t_rot6 = a.t_Rl = a.t_Rg = a.t_eps = nullptr;
     size_t lds = ((size_t)K * 21 + 1) * sizeof(float);
     hipLaunchKernelGGL(fk_kernel, dim3(B), dim3(256), lds, c->stream, a);
     return nm_check_hip(hipGetLastError(), "fk launch");

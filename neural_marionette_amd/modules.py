@@ -242,6 +242,46 @@ class _Gru(_Node):
         return out
 
 
+class _EncodeTrain(torch.autograd.Function):
+    """HSVRNNBVH.encode with a backward pass (learner mode): forward = nm_vrnn_encode_train, backward =
+    nm_vrnn_encode_backward (BPTT kernels in nm_vrnn.hip).  Only the two scalar losses carry gradients, exactly
+    what the reference's training loss consumes (train.py:389-398)."""
+
+    @staticmethod
+    def forward(ctx, module, kp, eps, S, names, *params):
+        eng = module._eng()
+        c = eng.ready()
+        dev = c.device
+        B, T, K, _ = kp.shape
+        Z, H = module.nlatent_kypt, module.nhidden_kypt
+        rec = torch.empty(B, T, K, 4, device=dev); R = torch.empty(B, T, K, 3, 3, device=dev)
+        z = torch.empty(B, T, Z, device=dev); h = torch.empty(B, T + 1, H, device=dev)
+        sc = torch.empty(2, device=dev); best = torch.empty(B, T, device=dev, dtype=torch.int32)
+        eng.call("nm_vrnn_encode_train", _lib.ptr(kp), _lib.ptr(eps), B, T, S, _lib.ptr(rec), _lib.ptr(R), _lib.ptr(z),
+                 _lib.ptr(h), _lib.ptr(sc), _lib.ptr(best))
+        ctx.module, ctx.names = module, names
+        ctx.shapes = [p.shape for p in params]
+        ctx.mark_non_differentiable(rec, R, z, h, best)
+        return sc[0].clone(), sc[1].clone(), rec, R, z, h, best
+
+    @staticmethod
+    def backward(ctx, dkl, drec, *unused):
+        eng = ctx.module._eng()
+        c = eng.ready()
+        dev = c.device
+        zero = torch.zeros((), device=dev)
+        dscal = torch.stack([(dkl if dkl is not None else zero).float().reshape(()),
+                             (drec if drec is not None else zero).float().reshape(())]).contiguous()
+        grads = [torch.empty(shp, device=dev) for shp in ctx.shapes]
+        arr = (_lib.NmNamedTensor * len(grads))()
+        keep = []
+        for i, (n, g) in enumerate(zip(ctx.names, grads)):
+            keep.append(n.encode())
+            arr[i].name, arr[i].data, arr[i].numel = keep[-1], g.data_ptr(), g.numel()
+        eng.call("nm_vrnn_encode_backward", _lib.ptr(dscal), arr, len(grads))
+        return (None, None, None, None, None, *grads)
+
+
 class HSVRNNBVH(_Node):
     """model/hsvrnn_bvh.py:10-286."""
 
@@ -311,6 +351,12 @@ class HSVRNNBVH(_Node):
         Z, H, S = self.nlatent_kypt, self.nhidden_kypt, int(SAMPLE_NUM)
         kp = _f32(keypoints, dev)
         e = self._eps(T, (S, B, Z), dev, eps)
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and named:
+            names = ["dyna_module." + n for n, _ in named]
+            kl, rl, rec, R, z, h, best = _EncodeTrain.apply(self, kp, e, S, names, *[p for _, p in named])
+            return dict(kypt_recon=rec, R=R, z_kypts=z, h_kypts=h, kl_kypt=kl, kypt_recon_loss=rl,
+                        gae_recon_loss=torch.tensor(0).to(dev), topo_recon_loss=torch.tensor(0).to(dev), best_idx=best)
         rec = torch.empty(B, T, K, 4, device=dev)
         R = torch.empty(B, T, K, 3, 3, device=dev)
         z = torch.empty(B, T, Z, device=dev)
@@ -535,7 +581,8 @@ class NeuralMarionette(nn.Module):
         log: Dict[str, torch.Tensor] = dict()
         keypoints = affinity = None
         d, det_m = self.dyna_module, self.kypt_detector
-        if module_actives["learner"] and d.A is not None and det_m.affinity_start:
+        if module_actives["learner"] and d.A is not None and det_m.affinity_start and not \
+                (torch.is_grad_enabled() and any(p.requires_grad for p in d.parameters())):
             return self._forward_fused(vox_seq, eps)
         if module_actives["detector"] or module_actives["learner"]:
             det = self.kypt_detector(vox_seq)

@@ -390,3 +390,64 @@ def test_interpolation_driver_vs_oracle():
     big = net.sample_interpolation(vox[:3].cuda(), sample_rate=2, sample_num=10000)
     torch.cuda.synchronize()
     assert torch.isfinite(big["keypoints"]).all()
+
+
+def _oracle_learner_grads(sd, o, kp, order, parents, eps, w_rec=1.0, w_kl=0.003):
+    names = [k for k in sd if k.startswith("dyna_module.") and k != "dyna_module.offset_param"]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sd2 = dict(sd); sd2.update(leaf)
+    r = O.vrnn_encode(sd2, o, kp, order, parents, eps)
+    loss = w_rec * r["kypt_recon_loss"] + w_kl * r["kl_kypt"]
+    grads = torch.autograd.grad(loss, [leaf[k] for k in names])
+    return float(loss), dict(zip(names, grads))
+
+
+def test_learner_mode_gradients_vs_oracle_and_reference_fixture(golden_dir):
+    """SURVEY 8(f1), learner mode: d(kypt_recon_loss + 0.003 kl_kypt)/d(dyna_module params) from the HIP BPTT kernels
+    against the oracle's autograd (all elements) and the reference's autograd fixture G6 (sub-sampled)."""
+    g = _load(golden_dir, "g6_learner_grads.npz")
+    B, T, wseed, kseed, eseed = [int(v) for v in g["meta"]]
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=wseed, variant="default")
+    net = _net(o, sd)
+    net.train()
+    gen = torch.Generator().manual_seed(kseed)
+    kp = torch.rand(B, T, o.nkeypoints, 4, generator=gen) * torch.tensor([1.6, 1.6, 1.6, 1.0]) - torch.tensor([0.8, 0.8, 0.8, 0.0])
+    eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=eseed)
+    aff = O.affinity_v3(sd["kypt_detector.affinity_params"])
+    net.zero_grad()
+    out = net.dyna_module.encode(kp.cuda(), aff.cuda(), eps=eps.cuda())
+    loss = 1.0 * out["kypt_recon_loss"] + 0.003 * out["kl_kypt"]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    ref_loss, ref = _oracle_learner_grads(sd, o, kp, g["order"], g["parents"], eps)
+    worst = 0.0
+    for name, p in net.dyna_module.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        r = ref["dyna_module." + name]
+        assert p.grad is not None, name
+        e = (p.grad.cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-12)
+        worst = max(worst, e)
+        print("grad %-40s rel err %.2e (|g|max %.3e)" % (name, e, r.abs().max().item()))
+        assert e < 2e-3, name
+        gf = p.grad.cpu().reshape(-1).double()
+        fx = g["g:" + name]
+        mine = np.concatenate([[gf.sum().item(), gf.abs().sum().item()], gf[::97].numpy()])
+        assert np.abs(mine[2:] - fx[2:]).max() <= 2e-3 * max(np.abs(fx[2:]).max(), 1e-12), name
+    print("worst relative gradient error %.2e" % worst)
+    # a fused Adam step equals torch.optim.Adam on the same gradients
+    from neural_marionette_amd import _lib
+    p0 = net.dyna_module.kypt_rnn_cell.weight_hh
+    ref_p = p0.detach().clone().requires_grad_(True)
+    ref_p.grad = p0.grad.clone()
+    opt = torch.optim.Adam([ref_p], lr=4e-4)
+    opt.step()
+    m = torch.zeros_like(p0); v = torch.zeros_like(p0); mine_p = p0.detach().clone()
+    eng = net._engine
+    eng.call("nm_adam_step", _lib.ptr(mine_p), _lib.ptr(p0.grad.contiguous()), _lib.ptr(m), _lib.ptr(v), mine_p.numel(), 1,
+             4e-4, 0.9, 0.999, 1e-8)
+    torch.cuda.synchronize()
+    assert (mine_p - ref_p.detach()).abs().max().item() < 1e-7

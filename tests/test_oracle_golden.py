@@ -110,3 +110,36 @@ def test_g5_odd_hourglass40(golden_dir):
     _close(r["keypoints"], g["keypoints"], what="keypoints")
     _close(r["heatmaps"], g["heatmaps"], what="heatmaps")
     _close([float(r[k]) for k in DETECTOR_LOSS_KEYS], g["losses"], what="losses")
+
+
+def learner_loss_and_grads(sd, o, kp, order, parents, eps, w_rec=1.0, w_kl=0.003):
+    """autograd of the oracle's own VRNN restatement: the gradient reference for the HIP backward"""
+    names = [k for k in sd if k.startswith("dyna_module.") and k != "dyna_module.offset_param"]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sd2 = dict(sd); sd2.update(leaf)
+    r = O.vrnn_encode(sd2, o, kp, order, parents, eps)
+    loss = w_rec * r["kypt_recon_loss"] + w_kl * r["kl_kypt"]
+    grads = torch.autograd.grad(loss, [leaf[k] for k in names])
+    return float(loss), {k: g for k, g in zip(names, grads)}, r
+
+
+def test_g6_learner_gradients(golden_dir):
+    g = _load(golden_dir, "g6_learner_grads.npz")
+    B, T, wseed, kseed, eseed = [int(v) for v in g["meta"]]
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=wseed, variant="default")
+    gen = torch.Generator().manual_seed(kseed)
+    kp = torch.rand(B, T, o.nkeypoints, 4, generator=gen) * torch.tensor([1.6, 1.6, 1.6, 1.0]) - torch.tensor([0.8, 0.8, 0.8, 0.0])
+    eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=eseed)
+    loss, grads, _ = learner_loss_and_grads(sd, o, kp, g["order"], g["parents"], eps)
+    assert abs(loss - float(g["loss"])) < 1e-6 * max(1.0, abs(float(g["loss"])))
+    checked = 0
+    for k, gr in grads.items():
+        key = "g:" + k[len("dyna_module."):]
+        assert key in g.files, key
+        flat = gr.reshape(-1).double()
+        mine = np.concatenate([[flat.sum().item(), flat.abs().sum().item()], flat[::97].numpy()])
+        ref = g[key]
+        assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+        checked += 1
+    assert checked == 21

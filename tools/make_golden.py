@@ -209,7 +209,39 @@ def case_g5():
     print("g5 ok")
 
 
-CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5)
+def case_g6():
+    """Learner-mode training gradients (pretrained_mode=1: detector frozen, train.py:146,177-181):
+    d(1.0 * kypt_recon_loss + 0.003 * kl_kypt) / d(dyna_module parameters) by the reference's autograd,
+    B=3, T=5, recorded eps.  Every gradient is stored as (sum, abs-sum, every 97th element)."""
+    from oracle import nm_oracle as O
+    B, T, wseed, kseed, eseed = 3, 5, 13, 14, 15
+    opt = _ref_opt(32)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=wseed, variant="default")
+    net = _ref_net(opt, sd)
+    g = torch.Generator().manual_seed(kseed)
+    kp = torch.rand(B, T, o.nkeypoints, 4, generator=g) * torch.tensor([1.6, 1.6, 1.6, 1.0]) - torch.tensor([0.8, 0.8, 0.8, 0.0])
+    eps = synth.make_eps((T, S, B, o.nlatent_kypt), seed=eseed)
+    aff = net.kypt_detector.get_affinity().detach()
+    for p in net.parameters():
+        p.grad = None
+    with EpsFeed(eps):
+        r = net.dyna_module.encode(kp, aff)
+    loss = 1.0 * r["kypt_recon_loss"] + 0.003 * r["kl_kypt"]
+    loss.backward()
+    out = dict(meta=np.array([B, T, wseed, kseed, eseed]), loss=np.array(float(loss)),
+               kypt_recon_loss=np.array(float(r["kypt_recon_loss"])), kl_kypt=np.array(float(r["kl_kypt"])),
+               parents=_np(net.dyna_module.parents), order=_np(net.dyna_module.priority.indices))
+    for name, p in net.dyna_module.named_parameters():
+        if p.grad is None:
+            continue
+        gflat = p.grad.reshape(-1).double()
+        out["g:" + name] = np.concatenate([[gflat.sum().item(), gflat.abs().sum().item()], gflat[::97].numpy()])
+    np.savez_compressed(os.path.join(OUT, "g6_learner_grads.npz"), **out)
+    print("g6 ok", float(loss), sorted(k for k in out if k.startswith("g:"))[:3])
+
+
+CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6)
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
