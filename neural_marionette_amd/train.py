@@ -1,0 +1,78 @@
+"""Learner-mode training step (first half).
+
+The reference's `pretrained_mode = 1` regime (train.py:146, 270-276; the mode stored in
+pretrained/aist/opt.pickle): the keypoint detector is frozen and only the dynamics module
+trains, on `keypoints.detach()` (neural_marionette.py:53).  One step of train.py:376-412 is
+
+    log  = network(voxel, {'detector': False, 'learner': True})
+    loss = sum_k weight[k] * log[k]          (train.py:389-398; only kypt_recon_loss and kl_kypt carry gradients)
+    loss.backward();  optimizer.step()       (Adam, lr 4e-4, defaults; re-created every epoch, train.py:366-374)
+
+Here the forward and the back-propagation through time run in libnm355.so, the gradient
+all-reduce (clip-sharded data parallelism) goes through `torch.distributed` — backend "nccl" is
+RCCL over xGMI on the GPU box — as ONE flat bucket of 1.53 M floats (6.1 MB), and Adam is the
+library's fused kernel.  Detector-mode training (conv backward) is not built yet.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+# AIST loss weights of the reference (train.py:177-181 / opt.pickle)
+LEARNER_LOSS_WEIGHTS = {"kypt_recon_loss": 1.0, "kl_kypt": 0.003}
+
+
+def allreduce_mean_(tensors, world: Optional[int] = None) -> None:
+    """Average a list of gradient tensors across ranks through one flat bucket (in place)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    world = world or dist.get_world_size()
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
+class LearnerTrainer:
+    def __init__(self, net, lr: float = 4e-4, weights: Optional[Dict[str, float]] = None,
+                 betas=(0.9, 0.999), eps: float = 1e-8):
+        self.net = net
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.weights = dict(LEARNER_LOSS_WEIGHTS if weights is None else weights)
+        net.control_active({"detector": False, "learner": True})
+        self.params = [p for p in net.dyna_module.parameters() if p.requires_grad]
+        self.reset_optimizer()
+
+    def reset_optimizer(self) -> None:
+        """The reference re-instantiates Adam at every epoch (train.py:366-374): state starts from zero."""
+        self.t = 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    def step(self, vox, eps=None) -> Dict[str, float]:
+        net = self.net
+        for p in self.params:
+            p.grad = None
+        log = net(vox, {"detector": False, "learner": True}, eps=eps)
+        loss = sum(w * log[k] for k, w in self.weights.items())
+        loss.backward()
+        grads = [p.grad for p in self.params]
+        allreduce_mean_(grads)
+        eng = net._engine
+        eng.ready()
+        self.t += 1
+        with torch.no_grad():
+            for p, g, m, v in zip(self.params, grads, self.m, self.v):
+                eng.call("nm_adam_step", _lib.ptr(p.data), _lib.ptr(g.contiguous()), _lib.ptr(m), _lib.ptr(v), p.numel(), self.t,
+                         self.lr, self.betas[0], self.betas[1], self.eps)
+                p.add_(0)      # the kernel updated the storage behind autograd's back: bump the version counter so that
+                               # Engine._sync_weights re-uploads / re-packs the weights before the next forward
+        return {"loss": float(loss), **{k: float(log[k]) for k in self.weights}}

@@ -451,3 +451,49 @@ def test_learner_mode_gradients_vs_oracle_and_reference_fixture(golden_dir):
              4e-4, 0.9, 0.999, 1e-8)
     torch.cuda.synchronize()
     assert (mine_p - ref_p.detach()).abs().max().item() < 1e-7
+
+
+def test_learner_training_trajectory_vs_oracle():
+    """Three learner-mode training steps (detector frozen, Adam lr 4e-4): loss trajectory and updated weights against the
+    oracle's autograd + torch.optim.Adam on the CPU with the same noise."""
+    from neural_marionette_amd.train import LearnerTrainer
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=31, variant="peaky")
+    net = _net(o, sd)
+    net.train()
+    B, T = 2, 4
+    vox = synth.figure_clip(B, T, 32, seed=12)
+    epss = [synth.make_eps((T, 10, B, o.nlatent_kypt), seed=40 + i) for i in range(3)]
+    # oracle side: detector once (frozen), then autograd steps on the VRNN
+    with torch.no_grad():
+        det = O.detector_forward(sd, o, vox)
+        _, order, _, parents = O.build_tree(det["affinity"])
+    names = [k for k in sd if k.startswith("dyna_module.") and k != "dyna_module.offset_param"]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    opt = torch.optim.Adam([leaf[k] for k in names], lr=4e-4)
+    ref_losses = []
+    for e in epss:
+        sd2 = dict(sd); sd2.update(leaf)
+        r = O.vrnn_encode(sd2, o, det["keypoints"], order, parents, e)
+        loss = 1.0 * r["kypt_recon_loss"] + 0.003 * r["kl_kypt"]
+        opt.zero_grad(); loss.backward(); opt.step()
+        ref_losses.append(float(loss))
+    tr = LearnerTrainer(net, lr=4e-4)
+    losses = [tr.step(vox.cuda(), eps=e.cuda())["loss"] for e in epss]
+    torch.cuda.synchronize()
+    print("learner training losses", losses, "oracle", ref_losses)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b))
+    assert losses[-1] < losses[0]
+    w = net.dyna_module.kypt_rnn_cell.weight_hh.detach().cpu()
+    # Adam's first steps move every weight by ~lr * sign(g): elements whose gradient is at rounding-noise level may
+    # legitimately move the other way, so the check is on the bulk of the update, not on the worst element
+    diff = (w - leaf["dyna_module.kypt_rnn_cell.weight_hh"].detach()).abs()
+    upd = (w - sd["dyna_module.kypt_rnn_cell.weight_hh"]).abs()
+    print("weight_hh after 3 steps: mean abs diff %.3e, mean update %.3e, elements off by > 1e-5: %.4f %%" %
+          (diff.mean().item(), upd.mean().item(), 100.0 * (diff > 1e-5).float().mean().item()))
+    assert diff.mean().item() < 0.01 * upd.mean().item()
+    assert (diff > 1e-5).float().mean().item() < 0.01
+    # detector parameters are untouched and carry no gradient
+    assert torch.equal(net.kypt_detector.affinity_params.detach().cpu(), sd["kypt_detector.affinity_params"])
+    assert net.kypt_detector.affinity_params.grad is None

@@ -57,3 +57,34 @@ def test_world2_gloo_matches_single_process():
         assert p.exitcode == 0
     assert torch.equal(full, ref)
     assert abs(float(loss) - float(ref_loss)) < 1e-6
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_marionette_amd.train import allreduce_mean_
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = [torch.randn(7, 5, generator=g), torch.randn(11, generator=g), torch.randn(3, 2, 2, generator=g)]
+    mine = [t.clone() for t in grads]
+    allreduce_mean_(mine)
+    if rank == 0:
+        q.put((grads, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_allreduce_world2():
+    """the flat-bucket gradient all-reduce of the learner training step (RCCL on the GPU box, gloo here)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    g0, avg = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gen = torch.Generator().manual_seed(101)
+    g1 = [torch.randn(7, 5, generator=gen), torch.randn(11, generator=gen), torch.randn(3, 2, 2, generator=gen)]
+    for a, b, c in zip(g0, g1, avg):
+        assert torch.allclose(c, (a + b) / 2, atol=1e-7)
