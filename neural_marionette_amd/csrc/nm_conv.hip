@@ -43,10 +43,15 @@ struct ConvParams {
     int HZ, HY, HX, HV, HVp;      // halo dims, voxels, padded plane stride (HVp % 8 == 2)
     int CVp;                      // up2: plane stride of the coarse LDS tile
     int ZP;                       // f16s: pitch between halo z-planes in LDS (>= HY*HX, = 4 mod 16)
+    int stagger;                  // f16s: shader cycles the second workgroup of a CU waits before its first brick
 #ifdef NM_DIAG
     unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
 #endif
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every global store of
+// the previous brick's epilogue to be acknowledged (3-4k cycles per brick in the persistent conv_f16s loop).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
@@ -55,12 +60,17 @@ __device__ __forceinline__ f32x4 load_raw(const ConvParams& p, int n, int z, int
     return *reinterpret_cast<const f32x4*>(p.in + ((((size_t)n * p.ID + z) * p.IH + y) * p.IW + x) * p.Cin + c);
 }
 
-// pending GroupNorm of the producer: x * scale + shift, LeakyReLU
+// pending GroupNorm of the producer: x * scale + shift, LeakyReLU.  Written per component with scalar fma / mul / max:
+// packed fp32 VALU (v_pk_*_f32) beside another wave's MFMAs costs several times its issue slot on gfx950, and the
+// staging phases of these kernels always run beside the co-resident workgroup's MFMA phase.
 __device__ __forceinline__ f32x4 apply_act(const ConvParams& p, f32x4 v, const f32x4& sc, const f32x4& sh) {
-    if (p.in_scale) v = v * sc + sh;
+    if (p.in_scale) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(v[j], sc[j], sh[j]);
+    }
     if (p.in_slope != 1.0f) {            // LeakyReLU with slope in [0,1): max(v, slope * v)
-        v[0] = fmaxf(v[0], v[0] * p.in_slope); v[1] = fmaxf(v[1], v[1] * p.in_slope);
-        v[2] = fmaxf(v[2], v[2] * p.in_slope); v[3] = fmaxf(v[3], v[3] * p.in_slope);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], v[j] * p.in_slope);
     }
     return v;
 }
@@ -68,16 +78,12 @@ __device__ __forceinline__ f32x4 apply_act(const ConvParams& p, f32x4 v, const f
 // activated input sample: x * scale + shift, LeakyReLU (the producer's pending GroupNorm)
 __device__ __forceinline__ f32x4 load_act(const ConvParams& p, int n, int z, int y, int x, int c) {
     f32x4 v = *reinterpret_cast<const f32x4*>(p.in + ((((size_t)n * p.ID + z) * p.IH + y) * p.IW + x) * p.Cin + c);
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
     if (p.in_scale) {
-        f32x4 sc = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)n * p.Cin + c);
-        f32x4 sh = *reinterpret_cast<const f32x4*>(p.in_shift + (size_t)n * p.Cin + c);
-        v = v * sc + sh;
+        sc = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)n * p.Cin + c);
+        sh = *reinterpret_cast<const f32x4*>(p.in_shift + (size_t)n * p.Cin + c);
     }
-    if (p.in_slope != 1.0f) {
-        v[0] = lrelu(v[0], p.in_slope); v[1] = lrelu(v[1], p.in_slope);
-        v[2] = lrelu(v[2], p.in_slope); v[3] = lrelu(v[3], p.in_slope);
-    }
-    return v;
+    return apply_act(p, v, sc, sh);
 }
 
 __device__ __forceinline__ int up_lo(int o) {          // first source index of output index o (o >= 0)
@@ -219,7 +225,9 @@ __device__ __forceinline__ void epilogue_xz(const EpiArgs& p, float* red, f32x16
                     const int g = r >> 2;
                     const size_t off = (size_t)g * sZ + ((g == 1 || g == 2) ? xo1 : xo0) + (size_t)(r & 3) * sX;
                     const float v = (acc[mt][nt][r] + accl[mt][nt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
+#ifndef NM_EXP_NOEPI
                     base[off] = v;
+#endif
                     s += v; ss += v * v;
                 }
             } else {
@@ -241,7 +249,7 @@ __device__ __forceinline__ void epilogue_xz(const EpiArgs& p, float* red, f32x16
         }
     }
     if (p.part) {
-        __syncthreads();
+        lds_barrier();
         if (tid < NT * 32) {
             int co = co_base + tid;
             if (co < p.Cout) {
@@ -488,16 +496,18 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// v = hi + lo * 2^-11 with hi = rne_f16(v), lo = rne_f16((v - hi) * 2^11).  v - hi is exact in fp32, so the lo part is
+// one v_fma_mix{lo,hi}_f16 of (hi, -2^11, v * 2^11): 2.5 VALU per value, none of them packed fp32 math.
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, half8& hi, half8& lo) {
-    // pairwise so that the conversions can use the packed cvt instructions
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f32x2 v = (j < 2) ? f32x2{a[2 * j], a[2 * j + 1]} : f32x2{b[2 * j - 4], b[2 * j - 3]};
-        const half2v hh = __builtin_convertvector(v, half2v);
-        const f32x2 back = __builtin_convertvector(hh, f32x2);
-        const half2v ll = __builtin_convertvector((v - back) * NM_SPLIT_SCALE, half2v);
+        const float v0 = (j < 2) ? a[2 * j] : b[2 * j - 4], v1 = (j < 2) ? a[2 * j + 1] : b[2 * j - 3];
+        half2v hh = __builtin_convertvector(f32x2{v0, v1}, half2v);        // v_cvt_pk_f16_f32
+        asm volatile("" : "+v"(hh));                                         // keep the packed pair (no per-half re-conversion)
+        const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
         hi[2 * j] = hh[0]; hi[2 * j + 1] = hh[1];
-        lo[2 * j] = ll[0]; lo[2 * j + 1] = ll[1];
+        lo[2 * j] = (_Float16)__builtin_fmaf((float)hh[0], -NM_SPLIT_SCALE, t0);
+        lo[2 * j + 1] = (_Float16)__builtin_fmaf((float)hh[1], -NM_SPLIT_SCALE, t1);
     }
 }
 
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     extern __shared__ f32x4 lds[];
     half8* ldh = reinterpret_cast<half8*>(lds);                    // [hl*2 + h][HVp] x 16 B, voxel = hz*ZP + hy*HX + hx
     half8* ldb = ldh + 4 * p.HVp;                                  // BLDS: two weight-group buffers of GB slots
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int nblk = p.nbz * p.nby * p.nbx;
     const int co_base = blockIdx.y * (NT * 32);
@@ -527,10 +537,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
     const size_t plane = (size_t)p.Co_pad;                          // half8 units between (hl,h) planes of one (tap,c16)
     const size_t tap_stride = (size_t)C16 * 4 * plane;
+    const int lane_off = h * (int)plane + l31;                      // per-lane part of every weight address
     // Persistent workgroups: each walks a contiguous run of bricks (neighbouring bricks share halo voxels -> L2 reuse
     // in time, and the ~10 us a short-lived workgroup spends being dispatched and retired is paid once).
     const int total_items = p.N * nblk;
     const int per = (total_items + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (p.stagger > 0) {
+        // Two persistent workgroups share each CU and run the same stage / MFMA sequence: started together they stay
+        // in lockstep (both staging while the matrix pipe idles, then both contending for it).  The one whose waves
+        // sit in the odd wave slots starts late by about half a stage+MFMA period so the phases interleave.
+        const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_ID[3:0] = wave slot
+        if (hwid & 1) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     const int item_end = min(total_items, ((int)blockIdx.x + 1) * per);
     for (int item = (int)blockIdx.x * per; item < item_end; ++item) {
     const int n = item / nblk, br = item % nblk;
@@ -581,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     }
 
 #ifdef NM_DIAG
-#define NM_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)item * 16 + (i)] = clock64(); } while (0)
+#define NM_STAMP(i) do { if (p.stamps && lane == 0) p.stamps[((size_t)item * 4 + wave) * 16 + (i)] = clock64(); } while (0)
 #else
 #define NM_STAMP(i) do {} while (0)
 #endif
@@ -593,9 +614,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
         for (int k = 0; k < (9 * PER_TAP + 3) / 4; ++k) {
             const int j = wave + 4 * k;                            // wave-uniform instruction index within the group
             if (j < 9 * PER_TAP) {
-                const int t = j / PER_TAP, sl = (j % PER_TAP) * 64 + lane;     // slot within the tap's 128*NT slots
-                const int pl = sl / (32 * NT), co = sl % (32 * NT);
-                const half8* src = w8 + ((size_t)(9 * g + t) * C16 * 4 + (size_t)cb * 4 + pl) * plane + co_base + co;
+                // NT == 1: slot (j % 2) * 64 + lane of the tap's 128 = plane (j % 2) * 2 + h, channel l31: a wave-uniform
+                // base (scalar registers) plus one per-lane offset shared by every load
+                const int t = j / PER_TAP;
+                const half8* src = w8 + ((size_t)(9 * g + t) * C16 * 4 + (size_t)cb * 4 + (j % PER_TAP) * 2) * plane + co_base + lane_off;
                 half8* dst = ldb + buf * GB + t * (128 * NT) + (j % PER_TAP) * 64;         // + lane * 16 B by hardware
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -603,7 +625,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
         }
     };
     // raw input of one channel chunk, fetched one chunk ahead (BLDS variants: there are registers to spare at 2 waves/SIMD)
+#ifdef NM_EXP_NOPFA
+    constexpr bool PFA = false;
+#else
     constexpr bool PFA = BLDS;
+#endif
     f32x4 pa[PFA && !UP2 ? HZ : 1], pb[PFA && !UP2 ? HZ : 1], prc[4];
     int pci[4] = {-1, -1, -1, -1};
     auto prefetch_chunk = [&](int c0) {
@@ -636,30 +662,42 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     };
     if (PFA) prefetch_chunk(0);
     NM_STAMP(0);
+#ifdef NM_DIAG
+    if (p.stamps && lane == 0) {
+        p.stamps[((size_t)item * 4 + wave) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+        p.stamps[((size_t)item * 4 + wave) * 16 + 14] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+        p.stamps[((size_t)item * 4 + wave) * 16 + 13] = blockIdx.x;
+    }
+#endif
     for (int cb = 0; cb < C16; ++cb) {
         const int c0 = cb << 4;
-        __syncthreads();
+        lds_barrier();
         if (cb < 2) NM_STAMP(1 + cb * 4);
         issue_b_group(cb, 0, 0);
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         if (!UP2) {
             if (s_on) {
+                // columns outside the volume load zeros and get scale = shift = 0, so they stage exact zeros without a
+                // per-value select; whether a halo plane lies inside the volume is uniform over the workgroup
                 f32x4 sca = zero4, sha = zero4, scb = zero4, shb = zero4;
-                if (p.in_scale) {
+                if (p.in_scale && s_in) {
                     const float* ps = p.in_scale + (size_t)n * p.Cin + c0 + 8 * s_hh; const float* ph = p.in_shift + (size_t)n * p.Cin + c0 + 8 * s_hh;
                     sca = *reinterpret_cast<const f32x4*>(ps); scb = *reinterpret_cast<const f32x4*>(ps + 4);
                     sha = *reinterpret_cast<const f32x4*>(ph); shb = *reinterpret_cast<const f32x4*>(ph + 4);
                 }
+                const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (PFA) {
                     // the raw column was prefetched (before the loop / during the previous chunk's last tap group)
 #pragma unroll
                     for (int hz = 0; hz < HZ; ++hz) {
-                        const int gz = iz0 + hz;
-                        const bool in = s_in && (unsigned)gz < (unsigned)p.ID;
-                        f32x4 a = in ? apply_act(p, pa[hz], sca, sha) : zero4;
-                        f32x4 b = in ? apply_act(p, pb[hz], scb, shb) : zero4;
-                        half8 hi, lo;
-                        split8(a, b, hi, lo);
+                        half8 hi = zero8, lo = zero8;
+                        if ((unsigned)(iz0 + hz) < (unsigned)p.ID) {
+#ifdef NM_EXP_NOSPLIT
+                            hi = *reinterpret_cast<half8*>(&pa[hz]); lo = *reinterpret_cast<half8*>(&pb[hz]);
+#else
+                            split8(apply_act(p, pa[hz], sca, sha), apply_act(p, pb[hz], scb, shb), hi, lo);
+#endif
+                        }
                         ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
                         ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
                     }
@@ -677,12 +715,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                         }
 #pragma unroll
                         for (int j = 0; j < HB; ++j) {
-                            const int hz = hb + j, gz = iz0 + hz;
-                            const bool in = s_in && (unsigned)gz < (unsigned)p.ID;
-                            f32x4 a = in ? apply_act(p, ra[j], sca, sha) : zero4;
-                            f32x4 b = in ? apply_act(p, rb[j], scb, shb) : zero4;
-                            half8 hi, lo;
-                            split8(a, b, hi, lo);
+                            const int hz = hb + j;
+                            half8 hi = zero8, lo = zero8;
+                            if ((unsigned)(iz0 + hz) < (unsigned)p.ID)
+                                split8(apply_act(p, ra[j], sca, sha), apply_act(p, rb[j], scb, shb), hi, lo);
                             ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
                             ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
                         }
@@ -724,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                     ldc[q * p.CVp + cv] = load_act(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (s_on) {
                 // separable: bilinear (y,x) interpolation of a coarse plane is computed once and reused by the two or
                 // three fine planes that blend it (same association as the direct trilinear formula)
@@ -732,8 +768,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                 const f32x4* cq0 = ldc + (2 * s_hh) * p.CVp;
                 const f32x4* cq1 = ldc + (2 * s_hh + 1) * p.CVp;
                 auto bilin = [&](const f32x4* cq, int pz) {
-                    return wy0 * (wx0 * cq[pz + u_r0 + u_a0] + u_lx * cq[pz + u_r0 + u_a1]) +
-                           u_ly * (wx0 * cq[pz + u_r1 + u_a0] + u_lx * cq[pz + u_r1 + u_a1]);
+                    const f32x4 a = cq[pz + u_r0 + u_a0], b = cq[pz + u_r0 + u_a1], c = cq[pz + u_r1 + u_a0], d = cq[pz + u_r1 + u_a1];
+                    f32x4 r;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        r[j] = __builtin_fmaf(u_ly, __builtin_fmaf(u_lx, d[j], wx0 * c[j]), wy0 * __builtin_fmaf(u_lx, b[j], wx0 * a[j]));
+                    return r;
                 };
                 int zc0 = -1, zc1 = -1;
                 f32x4 b0a = zero4, b0b = zero4, b1a = zero4, b1b = zero4;      // bilinear planes z0 / z1, channel quads a / b
@@ -755,8 +795,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                             zc1 = z1;
                         }
                         const float wz0 = 1.f - lz;
-                        va = wz0 * b0a + lz * b1a;
-                        vb = wz0 * b0b + lz * b1b;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            va[j] = __builtin_fmaf(lz, b1a[j], wz0 * b0a[j]);
+                            vb[j] = __builtin_fmaf(lz, b1b[j], wz0 * b0b[j]);
+                        }
                     }
                     half8 hi, lo;
                     split8(va, vb, hi, lo);
@@ -767,77 +810,104 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
         }
         if (cb < 2) NM_STAMP(2 + cb * 4);
         if (BLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weight group 0 has landed in LDS
-        __syncthreads();
+        lds_barrier();
         if (cb < 2) NM_STAMP(3 + cb * 4);
 
         if (BLDS) {
+            // One software-pipelined pass over the 27 taps.  Left to itself the scheduler sinks every ds_read next to its
+            // use and waits on it, and a wave that has the matrix pipe to itself then keeps it under 50 % busy.  Here
+            // each operand register is refilled for the next tap right after the last MFMA that reads it (the B pair is
+            // double buffered), so a read has 3-6 MFMAs (100-200 cycles) to land; sched_barrier pins that order.
+            // Accumulation order per accumulator is unchanged: acc += ah*bh; accl += ah*bl, then al*bh.
+            static_assert(!BLDS || MT == 2, "pipelined tap loop is written for two M tiles");
+            const half8* a_h = ldh + h * p.HVp;
+            const half8* a_l = ldh + (2 + h) * p.HVp;
+            auto aoff = [&](int t) { return (t / 3) * p.HX + (t % 3); };                    // within one 9-tap group
+            half8 ah0 = a_h[arow[0]], al0 = a_l[arow[0]], ah1 = a_h[arow[MT - 1]], al1 = a_l[arow[MT - 1]];
+            half8 bhv[2], blv[2];
+#pragma unroll 1
             for (int g = 0; g < 3; ++g) {
                 if (g < 2) issue_b_group(cb, g + 1, (g + 1) & 1);
                 else if (PFA && cb + 1 < C16) prefetch_chunk(c0 + 16);
                 const half8* bb = ldb + (g & 1) * GB + h * 32 + l31;
-#pragma unroll 3
+                const int zo = g * p.ZP, zn = min(g + 1, 2) * p.ZP;             // plane offsets of this / the next group
+                bhv[0] = bb[0]; blv[0] = bb[64];
+#pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int ty = t / 3, tx = t % 3;
-                    const int tapoff = g * p.ZP + ty * p.HX + tx;
-                    const half8 bh0 = bb[t * 128], bl0 = bb[t * 128 + 64];
-                    half8 ah[MT], al[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        ah[mt] = ldh[h * p.HVp + arow[mt] + tapoff];
-                        al[mt] = ldh[(2 + h) * p.HVp + arow[mt] + tapoff];
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh0, acc[mt][0], 0, 0, 0);
-                        accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl0, accl[mt][0], 0, 0, 0);
-                        accl[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh0, accl[mt][0], 0, 0, 0);
-                    }
+                    const int c = t & 1;
+                    const int nxt = (t < 8) ? zo + aoff(t + 1) : zn;             // A offset of the next tap (next group: tap 0)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bhv[c], acc[0][0], 0, 0, 0);
+                    if (t < 8) { bhv[c ^ 1] = bb[(t + 1) * 128]; blv[c ^ 1] = bb[(t + 1) * 128 + 64]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    accl[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, blv[c], accl[0][0], 0, 0, 0);
+                    ah0 = a_h[arow[0] + nxt];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bhv[c], acc[MT - 1][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accl[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, blv[c], accl[MT - 1][0], 0, 0, 0);
+                    ah1 = a_h[arow[MT - 1] + nxt];
+                    __builtin_amdgcn_sched_barrier(0);
+                    accl[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bhv[c], accl[0][0], 0, 0, 0);
+                    al0 = a_l[arow[0] + nxt];
+                    __builtin_amdgcn_sched_barrier(0);
+                    accl[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bhv[c], accl[MT - 1][0], 0, 0, 0);
+                    al1 = a_l[arow[MT - 1] + nxt];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (g < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+                if (g < 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); }
             }
         } else {
-        // weights of (tap, cb): planes hi/lo for this lane half, prefetched PF taps ahead (a tap is only 6-12 MFMAs =
-            // 200-400 cycles, about an L2 round trip)
+            // weights of (tap, cb): planes hi/lo for this lane half come straight from L2, prefetched PF taps ahead
+            // (a tap is only 6-12 MFMAs = 200-400 cycles, about an L2 round trip); the A operands of tap t+1 are
+            // read from LDS while the MFMAs of tap t issue
             constexpr int PF = (NT == 1) ? 2 : 1;
-            const half8* wq = w8 + ((size_t)cb * 4 + h) * plane + co_base + l31;
+            constexpr int TAPS = KS * KS * KS;
+            const half8* wq = w8 + (size_t)cb * 4 * plane + co_base;               // wave-uniform; lanes add lane_off
             half8 bh[PF + 1][NT], bl[PF + 1][NT];
-    #pragma unroll
+#pragma unroll
             for (int f = 0; f < PF; ++f) {
-                const half8* wf = wq + (size_t)min(f, taps - 1) * tap_stride;
-    #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) { bh[f][nt] = wf[nt * 32]; bl[f][nt] = wf[2 * plane + nt * 32]; }
+                const half8* wf = wq + (size_t)min(f, TAPS - 1) * tap_stride;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { bh[f][nt] = wf[lane_off + nt * 32]; bl[f][nt] = (wf + 2 * plane)[lane_off + nt * 32]; }
             }
-            int tx = 0, ty = 0, tz = 0;
-            for (int tap = 0; tap < taps; ++tap) {
-                const half8* wn = wq + (size_t)min(tap + PF, taps - 1) * tap_stride;
-    #ifdef NM_EXP_NOB
-                if (tap < 0)
-    #endif
-    #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) { bh[PF][nt] = wn[nt * 32]; bl[PF][nt] = wn[2 * plane + nt * 32]; }
-                const int tapoff = tz * p.ZP + ty * p.HX + tx;
-                half8 ah[MT], al[MT];
-    #ifdef NM_EXP_NOA
-                if (tap == 0)
-    #endif
-    #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    ah[mt] = ldh[h * p.HVp + arow[mt] + tapoff];
-                    al[mt] = ldh[(2 + h) * p.HVp + arow[mt] + tapoff];
-                }
-    #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-    #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[0][nt], acc[mt][nt], 0, 0, 0);
-                        accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[0][nt], accl[mt][nt], 0, 0, 0);
-                        accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[0][nt], accl[mt][nt], 0, 0, 0);
+            // same rotation as above: A operands of tap t+1 are read from LDS right after the last MFMA of tap t that
+            // uses the register (6-10 MFMAs ahead of their first use)
+            const half8* a_h = ldh + h * p.HVp;
+            const half8* a_l = ldh + (2 + h) * p.HVp;
+            auto aoff = [&](int t) { return (t / KS) * p.HX + (t % KS); };                  // within one z-plane of taps
+            constexpr int TP = KS * KS;
+            half8 ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { ah[mt] = a_h[arow[mt]]; al[mt] = a_l[arow[mt]]; }
+#pragma unroll 1
+            for (int tz = 0; tz < KS; ++tz) {
+                const int zo = tz * p.ZP, zn = min(tz + 1, KS - 1) * p.ZP;
+#pragma unroll
+                for (int t = 0; t < TP; ++t) {
+                    const int tap = tz * TP + t;
+                    const int nxt = (t + 1 < TP) ? zo + aoff(t + 1) : zn;
+                    const half8* wn = wq + (size_t)min(tap + PF, TAPS - 1) * tap_stride;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { bh[PF][nt] = wn[lane_off + nt * 32]; bl[PF][nt] = (wn + 2 * plane)[lane_off + nt * 32]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[0][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[0][nt], accl[mt][nt], 0, 0, 0);
+                        ah[mt] = a_h[arow[mt] + nxt];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[0][nt], accl[mt][nt], 0, 0, 0);
+                        al[mt] = a_l[arow[mt] + nxt];
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-    #pragma unroll
-                for (int f = 0; f < PF; ++f)
-    #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) { bh[f][nt] = bh[f + 1][nt]; bl[f][nt] = bl[f + 1][nt]; }
-                if (++tx == p.ks) { tx = 0; if (++ty == p.ks) { ty = 0; ++tz; } }
+#pragma unroll
+                    for (int f = 0; f < PF; ++f)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) { bh[f][nt] = bh[f + 1][nt]; bl[f][nt] = bl[f + 1][nt]; }
+                }
             }
         }
         if (cb < 2) NM_STAMP(4 + cb * 4);
@@ -846,7 +916,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     EpiArgs e;
     e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
     e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3; e.xz_tiles = 1;
-    __syncthreads();
+    lds_barrier();
     epilogue_xz<MT, NT>(e, reinterpret_cast<float*>(lds), acc, accl, n, br, nblk, oz0, oy0, ox0, co_base);
     NM_STAMP(10);
     }   // persistent item loop
@@ -968,6 +1038,7 @@ int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) 
 #ifdef NM_DIAG
 unsigned long long* g_stamps = nullptr;
 #endif
+int g_stagger = [] { const char* e = getenv("NM355_STAGGER"); return e ? atoi(e) : 0; }();
 int g_conv_mode = 1;      // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
 
 }  // namespace
@@ -1054,6 +1125,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.bz_l2 = t.bz_l2; p.by_l2 = t.by_l2; p.bx_l2 = t.bx_l2; p.nbz = t.nbz; p.nby = t.nby; p.nbx = t.nbx;
     p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.up2 = g.up2 ? 1 : 0;
+    p.stagger = g_stagger;
 #ifdef NM_DIAG
     p.stamps = g_stamps;
 #endif
