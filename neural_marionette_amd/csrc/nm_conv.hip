@@ -22,6 +22,7 @@
 //   sum / sum-of-squares partials for the following GroupNorm (deterministic: no float
 //   atomics).
 #include "nm_common.h"
+#include <utility>
 #include <vector>
 
 namespace {
@@ -922,6 +923,318 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     }   // persistent item loop
 }
 
+// 16-byte global load the compiler's wait-count tracking does not see.  hipcc waits vmcnt(0) at the first use of an
+// ordinary load result whenever an LDS-DMA is in flight, which would drain the weight pipeline of conv_f16p at the first
+// staging piece; the kernel instead waits explicitly (its group-end vmcnt(0)) before the results are used.
+__device__ __forceinline__ f32x4 load16_untracked(const float* q) {
+    f32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(q) : "memory");
+    return r;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+template <int V> using ic = std::integral_constant<int, V>;
+
+// ---- conv_f16p: k3 s1 p1 split-fp16 conv, 8x8x8 bricks, eight waves, one persistent workgroup per CU --------------
+// conv_f16s runs two independent 4-wave workgroups per CU and leaves the matrix pipe ~50 % idle: staging, the epilogue
+// and the per-brick set-up of one workgroup only overlap the other's MFMAs by chance.  Here one 512-thread workgroup
+// owns the CU and walks a flat stream of (brick, cout group, channel chunk) steps; while the 162 MFMAs per wave of
+// step s issue, the raw input of step s+1 is loaded, activated and split into registers in <= 6-VALU pieces placed
+// one per MFMA gap (they ride in the MFMA shadow), and only the LDS write of the staged registers and the epilogue
+// sit between two MFMA streams.  Weights: 9-tap groups through LDS, three buffers (buffer g always holds tap group
+// g), filled by direct-to-LDS loads two groups ahead so the first B operands of a group are read before the
+// barrier that ends the previous one.  Cout is processed 32 channels per step (grid-stride over cout groups, the
+// same brick's groups back to back: its input stays in L2).
+//   LDS: halo [hi h0 | hi h1 | lo h0 | lo h1][1000] x 16 B, weights [3][9 taps][4 planes][32] x 16 B, GroupNorm scratch.
+template <bool UP2>
+__global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
+    constexpr int HV = 1000, ZP = 100, HX = 10;
+    constexpr int GB = 9 * 4 * 32;                                  // half8 slots of one weight group
+    extern __shared__ f32x4 lds[];
+    half8* ldh = reinterpret_cast<half8*>(lds);
+    half8* ldb = ldh + 4 * HV;
+    float* red = reinterpret_cast<float*>(ldb + 3 * GB);            // [8 waves][2 mt][32][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int C16 = p.Cin >> 4;
+    const int ncg = p.Cout >> 5;
+    const int nbx = p.OW >> 3, nby = p.OH >> 3, nbz = p.OD >> 3, nbr = nbx * nby * nbz;
+    const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+    const size_t plane = (size_t)p.Co_pad;
+    const int lane_off = h * (int)plane + l31;
+    const int total = p.N * nbr * ncg;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int id_first = (int)blockIdx.x * per, id_last = min(total, id_first + per);
+    if (id_first >= id_last) return;
+
+    // MFMA rows of this wave: tile mt = the 8(x) x 4(z) slab z in [4mt, 4mt+4) of brick row y = wave
+    int arow[2];
+    {
+        const int c = l31 >> 2;
+        const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
+        arow[0] = z * ZP + wave * HX + x;
+        arow[1] = arow[0] + 4 * ZP;
+    }
+    // staging units of this thread: unit u = tid + 512k covers halo voxel u >> 1, channels 8 * (u & 1) .. +7 of the chunk
+    const int hh = tid & 1;
+    int u_slot[4], u_rel[4], u_pos[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = tid + 512 * k, vox = min(u >> 1, HV - 1);
+        const int hz = vox / 100, r = vox % 100, hy = r / 10, hx = r % 10;
+        u_slot[k] = hz * ZP + hy * HX + hx;
+        u_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin;
+        u_pos[k] = (u < 2 * HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
+    }
+
+    struct Work { int n, oz0, oy0, ox0, cg; };
+    auto decode = [&](int id) {
+        Work w;
+        w.cg = id % ncg; const int bid = id / ncg;
+        w.n = bid / nbr; const int br = bid % nbr;
+        w.ox0 = (br % nbx) << 3; w.oy0 = ((br / nbx) % nby) << 3; w.oz0 = (br / (nbx * nby)) << 3;
+        return w;
+    };
+    // raw input (two f32x4 per unit) of chunk cb of a work item; units outside the volume read as zero
+    f32x4 raw[4][2];
+    unsigned inb = 0;                                               // bit k: unit k of the step being staged lies inside the volume
+    auto unit_inside = [&](const Work& w, int k) {
+        const int hz = u_pos[k] & 0xff, hy = (u_pos[k] >> 8) & 0xff, hx = u_pos[k] >> 16;
+        return u_pos[k] >= 0 && (unsigned)(w.oz0 - 1 + hz) < (unsigned)p.ID && (unsigned)(w.oy0 - 1 + hy) < (unsigned)p.IH &&
+               (unsigned)(w.ox0 - 1 + hx) < (unsigned)p.IW;
+    };
+    auto unit_ptr = [&](const Work& w, int cb, int k) {
+        const long long base = ((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin;
+        return p.in + base + u_rel[k] + cb * 16 + 8 * hh;
+    };
+    auto load_unit = [&](const Work& w, int cb, auto K) {            // branch-free: outside units read the tensor's first bytes
+        constexpr int k = decltype(K)::value;
+        const float* q = ((inb >> k) & 1) ? unit_ptr(w, cb, k) : p.in;
+#ifdef NM_EXP_NOLD
+        raw[k][0] = f32x4{0.f, 0.f, 0.f, 0.f}; raw[k][1] = raw[k][0]; (void)q;
+#else
+        raw[k][0] = load16_untracked(q);
+        raw[k][1] = load16_untracked(q + 4);
+#endif
+    };
+    f32x4 sc[2], sh[2];
+    const float* aff_scale = p.in_scale ? p.in_scale : nullptr;
+    auto load_affine = [&](const Work& w, int cb) {
+        const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
+        sc[0] = one4; sc[1] = one4; sh[0] = z4; sh[1] = z4;
+        if (aff_scale) {
+            const float* ps = p.in_scale + (size_t)w.n * p.Cin + cb * 16 + 8 * hh; const float* ph = p.in_shift + (size_t)w.n * p.Cin + cb * 16 + 8 * hh;
+            sc[0] = load16_untracked(ps); sc[1] = load16_untracked(ps + 4);
+            sh[0] = load16_untracked(ph); sh[1] = load16_untracked(ph + 4);
+        }
+    };
+    // the staged loads have landed: drain and tie every destination register to the wait so no use can move above it
+    auto wait_loads = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[2][0]), "+v"(raw[2][1]),
+                       "+v"(raw[3][0]), "+v"(raw[3][1]), "+v"(sc[0]), "+v"(sc[1]), "+v"(sh[0]), "+v"(sh[1])
+                     :: "memory");
+    };
+    // conversion pieces: j = 0..3 activates value pair j of the unit (in place), j = 4..7 splits pair j - 4
+    half8 st_hi[4], st_lo[4];
+    auto convert_piece = [&](auto K, auto J) {
+        constexpr int k = decltype(K)::value, j = decltype(J)::value;
+        constexpr int q = (j & 3) >> 1, e = 2 * (j & 1);            // pair j & 3 = elements e, e + 1 of quad q
+        if constexpr (j < 4) {
+            float v0 = __builtin_fmaf(raw[k][q][e], sc[q][e], sh[q][e]), v1 = __builtin_fmaf(raw[k][q][e + 1], sc[q][e + 1], sh[q][e + 1]);
+            v0 = fmaxf(v0, v0 * p.in_slope); v1 = fmaxf(v1, v1 * p.in_slope);     // LeakyReLU, slope in (0, 1]
+            const bool ok = (inb >> k) & 1;                         // padding is zero AFTER the activation
+            raw[k][q][e] = ok ? v0 : 0.f; raw[k][q][e + 1] = ok ? v1 : 0.f;
+        } else {
+            const float v0 = raw[k][q][e], v1 = raw[k][q][e + 1];
+            half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
+            asm volatile("" : "+v"(hv));
+            const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
+            constexpr int o = 4 * q + e;
+            st_hi[k][o] = hv[0]; st_hi[k][o + 1] = hv[1];
+            st_lo[k][o] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
+            st_lo[k][o + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+        }
+    };
+    auto write_staged = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (u_pos[k] >= 0) { ldh[hh * HV + u_slot[k]] = st_hi[k]; ldh[(2 + hh) * HV + u_slot[k]] = st_lo[k]; }
+    };
+    // direct-to-LDS copy of tap group g of (cout group cg, chunk cb) into weight buffer g: 18 one-KiB wave loads
+    auto issue_b_group = [&](int cg, int cb, int g) {
+        auto one = [&](int j) {
+            const int t = j >> 1;
+            const half8* src = w8 + ((size_t)(9 * g + t) * C16 * 4 + (size_t)cb * 4 + (j & 1) * 2) * plane + cg * 32 + lane_off;
+            half8* dst = ldb + g * GB + t * 128 + (j & 1) * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        };
+        one(wave); one(wave + 8);
+        if (wave < 2) one(wave + 16);
+    };
+
+    f32x16 acc[2], accl[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; accl[mt][r] = 0.f; }
+
+    // ---- prologue: stage the first step in the open, start the weight pipeline
+    Work cur = decode(id_first);
+    int id = id_first, cb = 0;
+    issue_b_group(cur.cg, 0, 0);
+    issue_b_group(cur.cg, 0, 1);
+    inb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) inb |= (unit_inside(cur, k) ? 1u : 0u) << k;
+    static_for<4>([&](auto K) { load_unit(cur, 0, K); });
+    load_affine(cur, 0);
+    wait_loads();
+    static_for<32>([&](auto Q) { convert_piece(ic<decltype(Q)::value / 8>{}, ic<decltype(Q)::value % 8>{}); });
+    write_staged();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    const half8* a_h = ldh + h * HV;
+    const half8* a_l = ldh + (2 + h) * HV;
+    const half8* b0 = ldb + h * 32 + l31;
+    half8 bhv[2], blv[2];
+    bhv[0] = b0[0]; blv[0] = b0[64];
+
+#ifdef NM_DIAG
+    int step_no = 0;
+#define NM_PSTAMP(i) do { if (p.stamps && lane == 0 && step_no < 64) p.stamps[(((size_t)blockIdx.x * 64 + step_no) * 8 + wave) * 16 + (i)] = clock64(); } while (0)
+#else
+#define NM_PSTAMP(i) do {} while (0)
+#endif
+    for (;;) {
+        // next step of the stream
+        int nid = id, ncb = cb + 1;
+        if (ncb == C16) { ncb = 0; nid = id + 1; }
+        const bool has_next = nid < id_last;
+        if (!has_next) { nid = id; ncb = cb; }                      // last step: stage a copy of itself (never written) so the
+        Work nxt = cur;                                             // stream body stays branch-free
+        if (nid != id) nxt = decode(nid);
+
+        NM_PSTAMP(0);
+        half8 ah0 = a_h[arow[0]], al0 = a_l[arow[0]], ah1 = a_h[arow[1]], al1 = a_l[arow[1]];
+        static_for<27>([&](auto TT) {
+            constexpr int tt = decltype(TT)::value, g = tt / 9, t = tt % 9, c = tt & 1;
+            const half8* bb = b0 + g * GB;
+            if constexpr (t == 0) {                                 // weights two groups ahead (buffer index = tap group)
+                if constexpr (g == 0) issue_b_group(cur.cg, cb, 2);
+                else issue_b_group(nxt.cg, ncb, g - 1);
+            }
+            // staging work of the next step placed in this tap's six MFMA gaps
+            auto gap = [&](auto SUB) {
+                constexpr int q = tt * 6 + decltype(SUB)::value;
+                if constexpr (q == 0) {
+                    inb = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) inb |= (unit_inside(nxt, k) ? 1u : 0u) << k;
+                }
+                if constexpr (q >= 1 && q <= 4) load_unit(nxt, ncb, ic<q - 1>{});
+                if constexpr (q == 5) load_affine(nxt, ncb);
+#ifndef NM_EXP_NOCVT
+                if constexpr (q >= 60 && q < 92) convert_piece(ic<(q - 60) / 8>{}, ic<(q - 60) % 8>{});
+#endif
+            };
+            constexpr int tn = (t + 1) % 9;
+            const int nxa = (t < 8) ? g * ZP + (tn / 3) * HX + (tn % 3) : (g < 2 ? g + 1 : 2) * ZP;
+            const half8* bn = (t < 8) ? bb + tn * 128 : b0 + ((g + 1) % 3) * GB;
+
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bhv[c], acc[0], 0, 0, 0);
+            bhv[c ^ 1] = bn[0]; blv[c ^ 1] = bn[64];
+            gap(ic<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, blv[c], accl[0], 0, 0, 0);
+            ah0 = a_h[arow[0] + nxa];
+            gap(ic<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bhv[c], acc[1], 0, 0, 0);
+            gap(ic<2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, blv[c], accl[1], 0, 0, 0);
+            ah1 = a_h[arow[1] + nxa];
+            gap(ic<3>{});
+            __builtin_amdgcn_sched_barrier(0);
+            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bhv[c], accl[0], 0, 0, 0);
+            al0 = a_l[arow[0] + nxa];
+            gap(ic<4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bhv[c], accl[1], 0, 0, 0);
+            al1 = a_l[arow[1] + nxa];
+            gap(ic<5>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (t == 8) {
+                NM_PSTAMP(1 + 3 * g);
+                if constexpr (g == 0) wait_loads(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                NM_PSTAMP(2 + 3 * g);
+                lds_barrier();
+                NM_PSTAMP(3 + 3 * g);
+            }
+        });
+        // 27 taps are an odd count: the B pair prefetched for the next step sits in slot 1; move it to slot 0
+        bhv[0] = bhv[1]; blv[0] = blv[1];
+
+        // every wave is past its last read of the halo tile: drop in the next step's
+#ifndef NM_EXP_NOWR
+        if (has_next) write_staged();
+#endif
+        NM_PSTAMP(10);
+
+        if (cb == C16 - 1) {
+            // epilogue of the brick: bias, channels-last store, GroupNorm partials of the two 4x8x8 sub-bricks
+            const int co = cur.cg * 32 + l31;
+            const float bv = p.bias ? p.bias[co] : 0.f;
+            const size_t sX = (size_t)p.Cout, sZ = (size_t)p.OH * p.OW * p.Cout;
+            const size_t xo0 = (size_t)(4 * h) * sX, xo1 = (size_t)(4 * (h ^ 1)) * sX;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float* base = p.out + ((((size_t)cur.n * p.OD + cur.oz0 + 4 * mt) * p.OH + cur.oy0 + wave) * p.OW + cur.ox0) * sX + co;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gz = r >> 2;
+                    const size_t off = (size_t)gz * sZ + ((gz == 1 || gz == 2) ? xo1 : xo0) + (size_t)(r & 3) * sX;
+                    const float v = (acc[mt][r] + accl[mt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
+#ifndef NM_EXP_NOEPI
+                    base[off] = v;
+#endif
+                    s1 += v; s2 += v * v;
+                    acc[mt][r] = 0.f; accl[mt][r] = 0.f;
+                }
+                if (p.part) {
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    if (h == 0) { red[((wave * 2 + mt) * 32 + l31) * 2] = s1; red[((wave * 2 + mt) * 32 + l31) * 2 + 1] = s2; }
+                }
+            }
+        }
+        NM_PSTAMP(11);
+        lds_barrier();
+        NM_PSTAMP(12);
+        if (cb == C16 - 1 && p.part && tid < 64) {
+            const int mt = tid >> 5, cl = tid & 31;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) { s1 += red[((wv * 2 + mt) * 32 + cl) * 2]; s2 += red[((wv * 2 + mt) * 32 + cl) * 2 + 1]; }
+            const int br4 = ((((cur.oz0 >> 2) + mt) * nby + (cur.oy0 >> 3)) * nbx) + (cur.ox0 >> 3);
+            float* dst = p.part + (((size_t)cur.n * (2 * nbr) + br4) * p.Cout + cur.cg * 32 + cl) * 2;
+            dst[0] = s1; dst[1] = s2;
+        }
+        if (!has_next) break;
+        id = nid; cb = ncb; cur = nxt;
+#ifdef NM_DIAG
+        ++step_no;
+#endif
+    }
+}
+
 // OIDHW fp32 -> split fp16 [tap][Cin/16][hi|lo][lane half][Co_pad][8]
 __global__ void pack_conv_weight16_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, _Float16* __restrict__ packed,
                                           int Co_pad) {
@@ -1035,9 +1348,38 @@ int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) 
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
 }
 
+int g_num_cus = 0;
+
+template <bool UP2>
+int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p)");
+        attr_set = true;
+    }
+    if (g_num_cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nm_check_hip(hipErrorUnknown, "device query");
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    ProfRec rec;
+    if (g_prof_on) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 7;
+        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
+        (void)hipEventRecord(rec.a, s);
+    }
+    dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
+    hipLaunchKernelGGL((conv_f16p_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    return nm_check_hip(hipGetLastError(), "conv_f16p launch");
+}
+
 #ifdef NM_DIAG
 unsigned long long* g_stamps = nullptr;
 #endif
+int g_f16p = [] { const char* e = getenv("NM355_F16P"); return e ? atoi(e) : 1; }();    // 0: keep conv_f16s for every layer (diagnostic)
 int g_stagger = [] { const char* e = getenv("NM355_STAGGER"); return e ? atoi(e) : 0; }();
 int g_conv_mode = 1;      // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
 
@@ -1131,6 +1473,13 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
 #endif
     p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp; p.ZP = t.HY * t.HX;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
+    if (g_conv_mode == 1 && g_f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
+        g.OD % 8 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0) {
+        const int work = in.N * (g.OD / 8) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 32);
+        p.w = static_cast<const float*>(w_packed16);
+        const size_t lds_bytes = (size_t)4 * 1000 * 16 + (size_t)3 * 9 * 4 * 32 * 16 + (size_t)8 * 2 * 32 * 2 * sizeof(float);
+        return launch_f16p<false>(p, lds_bytes, work, s);
+    }
     if (g_conv_mode == 1 && w_packed16 && in.C % 16 == 0 && t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2 &&
         g.stride == 1 && (g.ks == 1 || g.ks == 3) && t.HZ == g.ks + 3 && t.HY * t.HX * 2 <= 256) {
         // halo planes padded to a pitch of 4 (mod 16) 16-B slots: conflict-free A reads (see conv_f16s_kernel)

@@ -61,6 +61,11 @@ CONV_CASES = [
     (128, 64, 3, 1, 1, 12, 1, True, 4),
     (256, 256, 3, 1, 1, 6, 1, False, 16),
     (184, 128, 1, 1, 0, 10, 1, False, 0),
+    # conv_f16p (8x8x8 bricks, persistent stream): several bricks / cout groups / channel chunks per workgroup
+    (32, 64, 3, 1, 1, 32, 3, True, 4),
+    (64, 32, 3, 1, 1, 16, 40, True, 2),
+    (16, 32, 3, 1, 1, 24, 2, False, 2),
+    (32, 96, 3, 1, 1, 16, 33, False, 3),
 ]
 
 
