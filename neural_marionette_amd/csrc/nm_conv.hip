@@ -932,6 +932,17 @@ __device__ __forceinline__ f32x4 load16_untracked(const float* q) {
     return r;
 }
 
+// 16-byte LDS read the compiler's wait-count tracking does not see (byte address = base + OFF).  The pipelined tap stream of
+// conv_f16p keeps 12 reads in flight and waits with an exact s_waitcnt lgkmcnt(10) before each MFMA; with tracked reads hipcc
+// falls back to lgkmcnt(0) every second tap, which drains the read issued one instruction earlier.
+template <int OFF>
+__device__ __forceinline__ half8 lds_read16_untracked(unsigned base) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+    half8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(base), "n"(OFF) : "memory");
+    return r;
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
@@ -939,30 +950,40 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 template <int V> using ic = std::integral_constant<int, V>;
 
-// ---- conv_f16p: k3 s1 p1 split-fp16 conv, 8x8x8 bricks, eight waves, one persistent workgroup per CU --------------
+// ---- conv_f16p: k3 s1 p1 split-fp16 conv, one persistent 4-wave workgroup per CU, everything in the MFMA shadow ----
 // conv_f16s runs two independent 4-wave workgroups per CU and leaves the matrix pipe ~50 % idle: staging, the epilogue
-// and the per-brick set-up of one workgroup only overlap the other's MFMAs by chance.  Here one 512-thread workgroup
-// owns the CU and walks a flat stream of (brick, cout group, channel chunk) steps; while the 162 MFMAs per wave of
-// step s issue, the raw input of step s+1 is loaded, activated and split into registers in <= 6-VALU pieces placed
-// one per MFMA gap (they ride in the MFMA shadow), and only the LDS write of the staged registers and the epilogue
-// sit between two MFMA streams.  Weights: 9-tap groups through LDS, three buffers (buffer g always holds tap group
-// g), filled by direct-to-LDS loads two groups ahead so the first B operands of a group are read before the
-// barrier that ends the previous one.  Cout is processed 32 channels per step (grid-stride over cout groups, the
-// same brick's groups back to back: its input stays in L2).
-//   LDS: halo [hi h0 | hi h1 | lo h0 | lo h1][1000] x 16 B, weights [3][9 taps][4 planes][32] x 16 B, GroupNorm scratch.
+// and the per-brick set-up of one workgroup overlap the other's MFMAs only by chance.  Here ONE workgroup of four waves
+// (one per SIMD, 512 registers each) owns the CU and walks a flat stream of steps (4x8x8 brick, 32-channel cout group,
+// 16-channel chunk).  A step is 27 taps x 6 MFMAs per wave, fully unrolled; every other instruction of the kernel is
+// cut into pieces of <= ~6 VALU / one memory instruction and pinned (sched_barrier) into one of the step's 162 MFMA
+// gaps, where it issues while the matrix pipe works:
+//   * raw input of step s+1: one 16-byte load per tap (taps 0-9; a burst of loads backs up the CU's address unit and
+//     stalls the issuing wave), GroupNorm affine + LeakyReLU + hi/lo split and the LDS write in taps 18-26, into the
+//     second halo buffer;
+//   * weights: 9-tap groups through LDS, three buffers (buffer g always holds tap group g), filled by direct-to-LDS
+//     loads two groups ahead, so the B operands of a group's first tap are read before the barrier ending the previous one;
+//   * the previous brick's epilogue: its outputs wait in 64 registers, stores go out in taps 0-6, GroupNorm partial sums
+//     in taps 9-15.
+// Only three barriers per step (group ends, with counted vmcnt waits for the weight loads) and 64 VALU per brick
+// (outputs = acc + accl / 2^11 + bias) are outside the shadow.  Cout is processed 32 channels per step, the cout groups of a
+// brick back to back (its input stays in L2).
+//   LDS: halo [2 buffers][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [3][9 taps][4 planes][32] x 16 B, GroupNorm scratch.
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
 template <bool UP2>
-__global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
-    constexpr int HV = 1000, ZP = 100, HX = 10;
+__global__ __launch_bounds__(256, 1) void conv_f16p_kernel(ConvParams p) {
+    constexpr int HV = 600, ZP = 100, HX = 10;
     constexpr int GB = 9 * 4 * 32;                                  // half8 slots of one weight group
+    constexpr int NP = 10;                                          // 16-byte input pieces per thread and step (2400 / 256)
     extern __shared__ f32x4 lds[];
-    half8* ldh = reinterpret_cast<half8*>(lds);
-    half8* ldb = ldh + 4 * HV;
-    float* red = reinterpret_cast<float*>(ldb + 3 * GB);            // [8 waves][2 mt][32][2]
+    half8* ldh = reinterpret_cast<half8*>(lds);                     // [2][4][HV]
+    half8* ldb = ldh + 8 * HV;                                      // [3][GB]
+    float* red = reinterpret_cast<float*>(ldb + 3 * GB);            // [4 waves][2 mt][32][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int C16 = p.Cin >> 4;
     const int ncg = p.Cout >> 5;
-    const int nbx = p.OW >> 3, nby = p.OH >> 3, nbz = p.OD >> 3, nbr = nbx * nby * nbz;
+    const int nbx = p.OW >> 3, nby = p.OH >> 3, nbz = p.OD >> 2, nbr = nbx * nby * nbz;
     const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
     const size_t plane = (size_t)p.Co_pad;
     const int lane_off = h * (int)plane + l31;
@@ -971,24 +992,25 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
     const int id_first = (int)blockIdx.x * per, id_last = min(total, id_first + per);
     if (id_first >= id_last) return;
 
-    // MFMA rows of this wave: tile mt = the 8(x) x 4(z) slab z in [4mt, 4mt+4) of brick row y = wave
+    // MFMA rows of this wave: tile mt = the 8(x) x 4(z) slab of brick row y = 2 * wave + mt
     int arow[2];
     {
         const int c = l31 >> 2;
         const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
-        arow[0] = z * ZP + wave * HX + x;
-        arow[1] = arow[0] + 4 * ZP;
+        arow[0] = z * ZP + (2 * wave) * HX + x;
+        arow[1] = arow[0] + HX;
     }
-    // staging units of this thread: unit u = tid + 512k covers halo voxel u >> 1, channels 8 * (u & 1) .. +7 of the chunk
-    const int hh = tid & 1;
-    int u_slot[4], u_rel[4], u_pos[4];
+    // staging pieces of this thread: piece k = channels 4 * quad .. +3 (of the chunk's 16) of halo voxel (tid >> 2) + 64k;
+    // four neighbouring lanes fetch one voxel's 64 contiguous bytes
+    const int quad = tid & 3;
+    int pc_slot[NP], pc_rel[NP], pc_pos[NP];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int u = tid + 512 * k, vox = min(u >> 1, HV - 1);
-        const int hz = vox / 100, r = vox % 100, hy = r / 10, hx = r % 10;
-        u_slot[k] = hz * ZP + hy * HX + hx;
-        u_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin;
-        u_pos[k] = (u < 2 * HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
+    for (int k = 0; k < NP; ++k) {
+        const int v = (tid >> 2) + 64 * k, vc = min(v, HV - 1);
+        const int hz = vc / 100, r = vc % 100, hy = r / 10, hx = r % 10;
+        pc_slot[k] = (quad >> 1) * HV + hz * ZP + hy * HX + hx;    // half8 slot of the hi part in a halo buffer (lo: + 2 HV)
+        pc_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin + 4 * quad;
+        pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
     }
 
     struct Work { int n, oz0, oy0, ox0, cg; };
@@ -996,76 +1018,69 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
         Work w;
         w.cg = id % ncg; const int bid = id / ncg;
         w.n = bid / nbr; const int br = bid % nbr;
-        w.ox0 = (br % nbx) << 3; w.oy0 = ((br / nbx) % nby) << 3; w.oz0 = (br / (nbx * nby)) << 3;
+        w.ox0 = (br % nbx) << 3; w.oy0 = ((br / nbx) % nby) << 3; w.oz0 = (br / (nbx * nby)) << 2;
         return w;
     };
-    // raw input (two f32x4 per unit) of chunk cb of a work item; units outside the volume read as zero
-    f32x4 raw[4][2];
-    unsigned inb = 0;                                               // bit k: unit k of the step being staged lies inside the volume
-    auto unit_inside = [&](const Work& w, int k) {
-        const int hz = u_pos[k] & 0xff, hy = (u_pos[k] >> 8) & 0xff, hx = u_pos[k] >> 16;
-        return u_pos[k] >= 0 && (unsigned)(w.oz0 - 1 + hz) < (unsigned)p.ID && (unsigned)(w.oy0 - 1 + hy) < (unsigned)p.IH &&
+    f32x4 raw[NP];
+    unsigned inb = 0;                                               // bit k: piece k of the step being staged lies inside the volume
+    auto piece_inside = [&](const Work& w, int k) {
+        const int hz = pc_pos[k] & 0xff, hy = (pc_pos[k] >> 8) & 0xff, hx = pc_pos[k] >> 16;
+        return pc_pos[k] >= 0 && (unsigned)(w.oz0 - 1 + hz) < (unsigned)p.ID && (unsigned)(w.oy0 - 1 + hy) < (unsigned)p.IH &&
                (unsigned)(w.ox0 - 1 + hx) < (unsigned)p.IW;
     };
-    auto unit_ptr = [&](const Work& w, int cb, int k) {
-        const long long base = ((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin;
-        return p.in + base + u_rel[k] + cb * 16 + 8 * hh;
-    };
-    auto load_unit = [&](const Work& w, int cb, auto K) {            // branch-free: outside units read the tensor's first bytes
+    auto load_piece = [&](const Work& w, int cb, auto K) {          // branch-free: outside pieces read the tensor's first bytes
         constexpr int k = decltype(K)::value;
-        const float* q = ((inb >> k) & 1) ? unit_ptr(w, cb, k) : p.in;
-#ifdef NM_EXP_NOLD
-        raw[k][0] = f32x4{0.f, 0.f, 0.f, 0.f}; raw[k][1] = raw[k][0]; (void)q;
-#else
-        raw[k][0] = load16_untracked(q);
-        raw[k][1] = load16_untracked(q + 4);
-#endif
+        const bool in = piece_inside(w, k);
+        inb = (inb & ~(1u << k)) | ((in ? 1u : 0u) << k);
+        const long long base = ((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin;
+        const float* q = in ? p.in + base + pc_rel[k] + cb * 16 : p.in;
+        raw[k] = load16_untracked(q);
     };
-    f32x4 sc[2], sh[2];
-    const float* aff_scale = p.in_scale ? p.in_scale : nullptr;
-    auto load_affine = [&](const Work& w, int cb) {
-        const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
-        sc[0] = one4; sc[1] = one4; sh[0] = z4; sh[1] = z4;
-        if (aff_scale) {
-            const float* ps = p.in_scale + (size_t)w.n * p.Cin + cb * 16 + 8 * hh; const float* ph = p.in_shift + (size_t)w.n * p.Cin + cb * 16 + 8 * hh;
-            sc[0] = load16_untracked(ps); sc[1] = load16_untracked(ps + 4);
-            sh[0] = load16_untracked(ph); sh[1] = load16_untracked(ph + 4);
-        }
+    f32x4 sc, sh;
+    const bool has_affine = p.in_scale != nullptr;
+    auto load_affine = [&](const Work& w, int cb) {                 // always two loads: the vmcnt waits below count instructions
+        const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 + 4 * quad : p.in;
+        const float* ph = has_affine ? p.in_shift + (size_t)w.n * p.Cin + cb * 16 + 4 * quad : p.in;
+        sc = load16_untracked(ps);
+        sh = load16_untracked(ph);
     };
     // the staged loads have landed: drain and tie every destination register to the wait so no use can move above it
     auto wait_loads = [&]() {
         asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[2][0]), "+v"(raw[2][1]),
-                       "+v"(raw[3][0]), "+v"(raw[3][1]), "+v"(sc[0]), "+v"(sc[1]), "+v"(sh[0]), "+v"(sh[1])
+                     : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]),
+                       "+v"(raw[8]), "+v"(raw[9]), "+v"(sc), "+v"(sh)
                      :: "memory");
     };
-    // conversion pieces: j = 0..3 activates value pair j of the unit (in place), j = 4..7 splits pair j - 4
-    half8 st_hi[4], st_lo[4];
-    auto convert_piece = [&](auto K, auto J) {
+    // conversion of piece k in five gap-sized parts: j = 0 / 2 activate value pair 0 / 1 (in place), j = 1 / 3 split it,
+    // j = 4 writes the four hi and four lo halves into halo buffer `buf`
+    half4v cv_hi, cv_lo;
+    auto convert_piece = [&](int buf, auto K, auto J) {
         constexpr int k = decltype(K)::value, j = decltype(J)::value;
-        constexpr int q = (j & 3) >> 1, e = 2 * (j & 1);            // pair j & 3 = elements e, e + 1 of quad q
-        if constexpr (j < 4) {
-            float v0 = __builtin_fmaf(raw[k][q][e], sc[q][e], sh[q][e]), v1 = __builtin_fmaf(raw[k][q][e + 1], sc[q][e + 1], sh[q][e + 1]);
+        constexpr int e = j & 2;                                    // pair = elements e, e + 1
+        if constexpr (j == 0 || j == 2) {
+            float v0 = raw[k][e], v1 = raw[k][e + 1];
+            if (has_affine) { v0 = __builtin_fmaf(v0, sc[e], sh[e]); v1 = __builtin_fmaf(v1, sc[e + 1], sh[e + 1]); }
             v0 = fmaxf(v0, v0 * p.in_slope); v1 = fmaxf(v1, v1 * p.in_slope);     // LeakyReLU, slope in (0, 1]
             const bool ok = (inb >> k) & 1;                         // padding is zero AFTER the activation
-            raw[k][q][e] = ok ? v0 : 0.f; raw[k][q][e + 1] = ok ? v1 : 0.f;
-        } else {
-            const float v0 = raw[k][q][e], v1 = raw[k][q][e + 1];
+            raw[k][e] = ok ? v0 : 0.f; raw[k][e + 1] = ok ? v1 : 0.f;
+        } else if constexpr (j == 1 || j == 3) {
+            const float v0 = raw[k][e], v1 = raw[k][e + 1];
             half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
             asm volatile("" : "+v"(hv));
             const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
-            constexpr int o = 4 * q + e;
-            st_hi[k][o] = hv[0]; st_hi[k][o + 1] = hv[1];
-            st_lo[k][o] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
-            st_lo[k][o + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+            cv_hi[e] = hv[0]; cv_hi[e + 1] = hv[1];
+            cv_lo[e] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
+            cv_lo[e + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+        } else {
+            if (pc_pos[k] >= 0) {
+                half4v* dst = reinterpret_cast<half4v*>(ldh + buf * 4 * HV + pc_slot[k]) + (quad & 1);
+                dst[0] = cv_hi;
+                dst[4 * HV] = cv_lo;                                // + 2 HV half8 slots
+            }
         }
     };
-    auto write_staged = [&]() {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (u_pos[k] >= 0) { ldh[hh * HV + u_slot[k]] = st_hi[k]; ldh[(2 + hh) * HV + u_slot[k]] = st_lo[k]; }
-    };
-    // direct-to-LDS copy of tap group g of (cout group cg, chunk cb) into weight buffer g: 18 one-KiB wave loads
+    // direct-to-LDS copy of tap group g of (cout group cg, chunk cb) into weight buffer g: 18 one-KiB wave loads; every
+    // wave issues five (two are issued twice) so that the counted vmcnt waits below are the same in all waves
     auto issue_b_group = [&](int cg, int cb, int g) {
         auto one = [&](int j) {
             const int t = j >> 1;
@@ -1074,37 +1089,78 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         };
-        one(wave); one(wave + 8);
-        if (wave < 2) one(wave + 16);
+        one(wave); one(wave + 4); one(wave + 8); one(wave + 12); one(min(wave + 16, 17));
     };
 
-    f32x16 acc[2], accl[2];
+    f32x16 acc[2], accl[2], outv[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; accl[mt][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; accl[mt][r] = 0.f; outv[mt][r] = 0.f; }
+
+    // ---- epilogue of a finished brick, in pieces (bias, channels-last store, GroupNorm partials of the 4x8x8 brick)
+    Work epi;                                                       // the brick whose outputs sit in outv
+    epi.n = 0; epi.oz0 = 0; epi.oy0 = 0; epi.ox0 = 0; epi.cg = 0;
+    float gs1[2] = {0.f, 0.f}, gs2[2] = {0.f, 0.f};
+    const size_t sX = (size_t)p.Cout, sZ = (size_t)p.OH * p.OW * p.Cout;
+    auto epi_store = [&](auto E) {                                  // store e = 16 mt + r of the 32 per lane
+        constexpr int e = decltype(E)::value, mt = e >> 4, r = e & 15, gz = r >> 2;
+        float* base = p.out + ((((size_t)epi.n * p.OD + epi.oz0) * p.OH + epi.oy0 + 2 * wave + mt) * p.OW + epi.ox0) * sX + epi.cg * 32 + l31;
+        const size_t xo = (size_t)(4 * ((gz == 1 || gz == 2) ? (h ^ 1) : h)) * sX;
+        base[(size_t)gz * sZ + xo + (size_t)(r & 3) * sX] = outv[mt][r];
+    };
+    auto epi_sum = [&](auto E) {                                    // values 2e, 2e + 1 of the 32 per lane: e = 0..15
+        constexpr int e = decltype(E)::value, mt = (e >> 3) & 1, r = (2 * e) & 15;
+        if constexpr (r == 0) { gs1[mt] = 0.f; gs2[mt] = 0.f; }
+        const float v0 = outv[mt][r], v1 = outv[mt][r + 1];
+        gs1[mt] += v0; gs2[mt] += v0 * v0;
+        gs1[mt] += v1; gs2[mt] += v1 * v1;
+    };
+    auto epi_red = [&]() {                                          // wave partials -> LDS
+        if (p.part) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float a = gs1[mt] + __shfl_xor(gs1[mt], 32), b = gs2[mt] + __shfl_xor(gs2[mt], 32);
+                if (h == 0) { red[((wave * 2 + mt) * 32 + l31) * 2] = a; red[((wave * 2 + mt) * 32 + l31) * 2 + 1] = b; }
+            }
+        }
+    };
+    auto epi_part = [&]() {                                         // after a barrier: 32 threads sum the eight partials
+        if (p.part && tid < 32) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a += red[(i * 32 + tid) * 2]; b += red[(i * 32 + tid) * 2 + 1]; }
+            const int br = ((epi.oz0 >> 2) * nby + (epi.oy0 >> 3)) * nbx + (epi.ox0 >> 3);
+            float* dst = p.part + (((size_t)epi.n * nbr + br) * p.Cout + epi.cg * 32 + tid) * 2;
+            dst[0] = a; dst[1] = b;
+        }
+    };
+    auto epi_take = [&](const Work& w) {                            // outputs of the brick just accumulated (64 VALU, exposed)
+        const float bv = p.bias ? p.bias[w.cg * 32 + l31] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) outv[mt][r] = (acc[mt][r] + accl[mt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
+        epi = w;
+    };
 
     // ---- prologue: stage the first step in the open, start the weight pipeline
     Work cur = decode(id_first);
-    int id = id_first, cb = 0;
+    int id = id_first, cb = 0, hb = 0;
     issue_b_group(cur.cg, 0, 0);
     issue_b_group(cur.cg, 0, 1);
-    inb = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) inb |= (unit_inside(cur, k) ? 1u : 0u) << k;
-    static_for<4>([&](auto K) { load_unit(cur, 0, K); });
+    static_for<NP>([&](auto K) { load_piece(cur, 0, K); });
     load_affine(cur, 0);
     wait_loads();
-    static_for<32>([&](auto Q) { convert_piece(ic<decltype(Q)::value / 8>{}, ic<decltype(Q)::value % 8>{}); });
-    write_staged();
+    static_for<NP * 5>([&](auto Q) { convert_piece(0, ic<decltype(Q)::value / 5>{}, ic<decltype(Q)::value % 5>{}); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
-    const half8* a_h = ldh + h * HV;
-    const half8* a_l = ldh + (2 + h) * HV;
     const half8* b0 = ldb + h * 32 + l31;
-    half8 bhv[2], blv[2];
-    bhv[0] = b0[0]; blv[0] = b0[64];
+    half8 bhv[3], blv[3];                                           // operand registers: three taps deep (index = tap % 3)
+    bhv[0] = b0[0]; blv[0] = b0[64]; bhv[1] = b0[128]; blv[1] = b0[192];
+    bool pending = false;                                           // outv / epi hold a brick whose epilogue has not run
+    bool part_due = false;                                          // red[] holds that brick's partial sums
 
 #ifdef NM_DIAG
     int step_no = 0;
@@ -1112,127 +1168,131 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
 #else
 #define NM_PSTAMP(i) do {} while (0)
 #endif
-    for (;;) {
-        // next step of the stream
-        int nid = id, ncb = cb + 1;
-        if (ncb == C16) { ncb = 0; nid = id + 1; }
-        const bool has_next = nid < id_last;
-        if (!has_next) { nid = id; ncb = cb; }                      // last step: stage a copy of itself (never written) so the
-        Work nxt = cur;                                             // stream body stays branch-free
-        if (nid != id) nxt = decode(nid);
-
+    auto step = [&](auto EPI, const Work& nxt, int ncb) {
+        constexpr bool WITH_EPI = decltype(EPI)::value;
         NM_PSTAMP(0);
-        half8 ah0 = a_h[arow[0]], al0 = a_l[arow[0]], ah1 = a_h[arow[1]], al1 = a_l[arow[1]];
+        const half8* a_h = ldh + hb * 4 * HV + h * HV;
+        const half8* a_l = a_h + 2 * HV;
+        // operands are read two taps (12 MFMAs, ~400 cycles) ahead of their use: with one wave per SIMD nothing else
+        // hides the LDS latency.  One read per MFMA gap, so before each MFMA "all but the 10 youngest LDS operations are
+        // done" (lgkmcnt(10)) covers both of its operands (other LDS traffic in the gaps only makes that stricter).
+        const unsigned va0 = (unsigned)(size_t)(ldh + hb * 4 * HV + h * HV + arow[0]);      // LDS byte addresses
+        const unsigned va1 = va0 + HX * 16;
+        const unsigned vb = (unsigned)(size_t)b0;
+        constexpr int LO = 2 * HV * 16;                             // hi -> lo plane of the halo tile, bytes
+        half8 ah0[3], al0[3], ah1[3], al1[3];
+        ah0[0] = lds_read16_untracked<0>(va0); al0[0] = lds_read16_untracked<LO>(va0);
+        ah1[0] = lds_read16_untracked<0>(va1); al1[0] = lds_read16_untracked<LO>(va1);
+        ah0[1] = lds_read16_untracked<16>(va0); al0[1] = lds_read16_untracked<LO + 16>(va0);
+        ah1[1] = lds_read16_untracked<16>(va1); al1[1] = lds_read16_untracked<LO + 16>(va1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         static_for<27>([&](auto TT) {
-            constexpr int tt = decltype(TT)::value, g = tt / 9, t = tt % 9, c = tt & 1;
-            const half8* bb = b0 + g * GB;
+            constexpr int tt = decltype(TT)::value, g = tt / 9, t = tt % 9, i = tt % 3, j = (tt + 2) % 3;
             if constexpr (t == 0) {                                 // weights two groups ahead (buffer index = tap group)
                 if constexpr (g == 0) issue_b_group(cur.cg, cb, 2);
                 else issue_b_group(nxt.cg, ncb, g - 1);
             }
-            // staging work of the next step placed in this tap's six MFMA gaps
             auto gap = [&](auto SUB) {
-                constexpr int q = tt * 6 + decltype(SUB)::value;
-                if constexpr (q == 0) {
-                    inb = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) inb |= (unit_inside(nxt, k) ? 1u : 0u) << k;
-                }
-                if constexpr (q >= 1 && q <= 4) load_unit(nxt, ncb, ic<q - 1>{});
-                if constexpr (q == 5) load_affine(nxt, ncb);
-#ifndef NM_EXP_NOCVT
-                if constexpr (q >= 60 && q < 92) convert_piece(ic<(q - 60) / 8>{}, ic<(q - 60) % 8>{});
+                constexpr int sub = decltype(SUB)::value, q = tt * 6 + sub;
+#ifndef NM_EXP_BARE
+                if constexpr (q == 1) load_affine(nxt, ncb);
+                if constexpr (sub == 0 && tt < NP) load_piece(nxt, ncb, ic<(tt < NP ? tt : 0)>{});
+                if constexpr (WITH_EPI && tt < 7 && sub >= 1 && (tt * 5 + sub - 1) < 32) epi_store(ic<(tt * 5 + sub - 1) & 31>{});
+                if constexpr (WITH_EPI && q >= 54 && q < 70) epi_sum(ic<(q - 54) & 15>{});
+                if constexpr (WITH_EPI && q == 90) epi_red();
+                if constexpr (q >= 108 && q < 108 + NP * 5) convert_piece(hb ^ 1, ic<(q >= 108 && q < 108 + NP * 5) ? (q - 108) / 5 : 0>{}, ic<(q >= 108 ? q - 108 : 0) % 5>{});
 #endif
             };
-            constexpr int tn = (t + 1) % 9;
-            const int nxa = (t < 8) ? g * ZP + (tn / 3) * HX + (tn % 3) : (g < 2 ? g + 1 : 2) * ZP;
-            const half8* bn = (t < 8) ? bb + tn * 128 : b0 + ((g + 1) % 3) * GB;
+            constexpr int u = tt + 2, ug = (u < 27) ? u / 9 : 0, ut = (u < 27) ? u % 9 : u - 27;
+            constexpr bool a_next = u < 27;                        // taps 25, 26: dummy A reads keep the one-read-per-gap count
+            constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;          // byte offsets of tap tt + 2
+            constexpr int BO = (ug * GB + ut * 128) * 16;
+#define NM_WAIT_OPERANDS(x, y) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(x), "+v"(y) :: "memory")   // ties the MFMA below to the wait
 
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bhv[c], acc[0], 0, 0, 0);
-            bhv[c ^ 1] = bn[0]; blv[c ^ 1] = bn[64];
+            NM_WAIT_OPERANDS(ah0[i], bhv[i]);
+            if constexpr (WITH_EPI && tt == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bhv[i], zero16, 0, 0, 0);
+            else acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bhv[i], acc[0], 0, 0, 0);
+            bhv[j] = lds_read16_untracked<BO>(vb);
             gap(ic<0>{});
             __builtin_amdgcn_sched_barrier(0);
-            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, blv[c], accl[0], 0, 0, 0);
-            ah0 = a_h[arow[0] + nxa];
+            NM_WAIT_OPERANDS(ah0[i], blv[i]);
+            if constexpr (WITH_EPI && tt == 0) accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], blv[i], zero16, 0, 0, 0);
+            else accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], blv[i], accl[0], 0, 0, 0);
+            ah0[j] = lds_read16_untracked<a_next ? AO : 0>(va0);
             gap(ic<1>{});
             __builtin_amdgcn_sched_barrier(0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bhv[c], acc[1], 0, 0, 0);
+            NM_WAIT_OPERANDS(ah1[i], bhv[i]);
+            if constexpr (WITH_EPI && tt == 0) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bhv[i], zero16, 0, 0, 0);
+            else acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bhv[i], acc[1], 0, 0, 0);
+            blv[j] = lds_read16_untracked<BO + 64 * 16>(vb);
             gap(ic<2>{});
             __builtin_amdgcn_sched_barrier(0);
-            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, blv[c], accl[1], 0, 0, 0);
-            ah1 = a_h[arow[1] + nxa];
+            NM_WAIT_OPERANDS(ah1[i], blv[i]);
+            if constexpr (WITH_EPI && tt == 0) accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], blv[i], zero16, 0, 0, 0);
+            else accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], blv[i], accl[1], 0, 0, 0);
+            ah1[j] = lds_read16_untracked<a_next ? AO : 0>(va1);
             gap(ic<3>{});
             __builtin_amdgcn_sched_barrier(0);
-            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bhv[c], accl[0], 0, 0, 0);
-            al0 = a_l[arow[0] + nxa];
+            NM_WAIT_OPERANDS(al0[i], bhv[i]);
+            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[i], bhv[i], accl[0], 0, 0, 0);
+            al0[j] = lds_read16_untracked<a_next ? AO + LO : 0>(va0);
             gap(ic<4>{});
             __builtin_amdgcn_sched_barrier(0);
-            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bhv[c], accl[1], 0, 0, 0);
-            al1 = a_l[arow[1] + nxa];
+            NM_WAIT_OPERANDS(al1[i], bhv[i]);
+            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[i], bhv[i], accl[1], 0, 0, 0);
+            al1[j] = lds_read16_untracked<a_next ? AO + LO : 0>(va1);
             gap(ic<5>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (t == 8) {
+                // group end.  g = 0: only the weight loads of tap 0 must have landed; younger in issue order are 2 affine +
+                // 9 piece loads (+ 32 stores).  g = 1: pieces and weights (they are converted / read next).  g = 2: weights.
                 NM_PSTAMP(1 + 3 * g);
-                if constexpr (g == 0) wait_loads(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef NM_EXP_BARE
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+                if constexpr (g == 0) { if constexpr (WITH_EPI) asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
+                else if constexpr (g == 1) wait_loads();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 NM_PSTAMP(2 + 3 * g);
                 lds_barrier();
                 NM_PSTAMP(3 + 3 * g);
+                // the dummy reads of taps 25 / 26 land after they issue: their registers stay reserved up to here
+                if constexpr (g == 2)
+                    asm volatile("" :: "v"(ah0[0]), "v"(al0[0]), "v"(ah1[0]), "v"(al1[0]), "v"(ah0[1]), "v"(al0[1]), "v"(ah1[1]), "v"(al1[1]));
             }
         });
-        // 27 taps are an odd count: the B pair prefetched for the next step sits in slot 1; move it to slot 0
-        bhv[0] = bhv[1]; blv[0] = blv[1];
+    };
 
-        // every wave is past its last read of the halo tile: drop in the next step's
-#ifndef NM_EXP_NOWR
-        if (has_next) write_staged();
-#endif
+    for (;;) {
+        int nid = id, ncb = cb + 1;
+        if (ncb == C16) { ncb = 0; nid = id + 1; }
+        const bool has_next = nid < id_last;
+        if (!has_next) { nid = id; ncb = cb; }                      // last step: stage a copy of itself (never read)
+        Work nxt = cur;
+        if (nid != id) nxt = decode(nid);
+        if (part_due) { epi_part(); part_due = false; }             // before this step's first weight load (vmcnt counts)
+        if (pending) { step(std::true_type{}, nxt, ncb); pending = false; part_due = true; }
+        else step(std::false_type{}, nxt, ncb);
         NM_PSTAMP(10);
-
-        if (cb == C16 - 1) {
-            // epilogue of the brick: bias, channels-last store, GroupNorm partials of the two 4x8x8 sub-bricks
-            const int co = cur.cg * 32 + l31;
-            const float bv = p.bias ? p.bias[co] : 0.f;
-            const size_t sX = (size_t)p.Cout, sZ = (size_t)p.OH * p.OW * p.Cout;
-            const size_t xo0 = (size_t)(4 * h) * sX, xo1 = (size_t)(4 * (h ^ 1)) * sX;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                float* base = p.out + ((((size_t)cur.n * p.OD + cur.oz0 + 4 * mt) * p.OH + cur.oy0 + wave) * p.OW + cur.ox0) * sX + co;
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gz = r >> 2;
-                    const size_t off = (size_t)gz * sZ + ((gz == 1 || gz == 2) ? xo1 : xo0) + (size_t)(r & 3) * sX;
-                    const float v = (acc[mt][r] + accl[mt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
-#ifndef NM_EXP_NOEPI
-                    base[off] = v;
-#endif
-                    s1 += v; s2 += v * v;
-                    acc[mt][r] = 0.f; accl[mt][r] = 0.f;
-                }
-                if (p.part) {
-                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                    if (h == 0) { red[((wave * 2 + mt) * 32 + l31) * 2] = s1; red[((wave * 2 + mt) * 32 + l31) * 2 + 1] = s2; }
-                }
-            }
-        }
-        NM_PSTAMP(11);
-        lds_barrier();
-        NM_PSTAMP(12);
-        if (cb == C16 - 1 && p.part && tid < 64) {
-            const int mt = tid >> 5, cl = tid & 31;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < 8; ++wv) { s1 += red[((wv * 2 + mt) * 32 + cl) * 2]; s2 += red[((wv * 2 + mt) * 32 + cl) * 2 + 1]; }
-            const int br4 = ((((cur.oz0 >> 2) + mt) * nby + (cur.oy0 >> 3)) * nbx) + (cur.ox0 >> 3);
-            float* dst = p.part + (((size_t)cur.n * (2 * nbr) + br4) * p.Cout + cur.cg * 32 + cl) * 2;
-            dst[0] = s1; dst[1] = s2;
-        }
+        if (cb == C16 - 1) { epi_take(cur); pending = true; }
+        NM_PSTAMP(11); NM_PSTAMP(12);
         if (!has_next) break;
-        id = nid; cb = ncb; cur = nxt;
+        id = nid; cb = ncb; cur = nxt; hb ^= 1;
 #ifdef NM_DIAG
         ++step_no;
 #endif
     }
+    // ---- drain: the last brick's epilogue in the open
+    if (part_due) epi_part();
+    lds_barrier();
+    static_for<32>([&](auto E) { epi_store(E); });
+    static_for<16>([&](auto E) { epi_sum(E); });
+    epi_red();
+    lds_barrier();
+    epi_part();
 }
 
 // OIDHW fp32 -> split fp16 [tap][Cin/16][hi|lo][lane half][Co_pad][8]
@@ -1371,7 +1431,7 @@ int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream
         (void)hipEventRecord(rec.a, s);
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
-    hipLaunchKernelGGL((conv_f16p_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16p_kernel<UP2>), grid, dim3(256), lds_bytes, s, p);
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
@@ -1474,10 +1534,10 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp; p.ZP = t.HY * t.HX;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
     if (g_conv_mode == 1 && g_f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
-        g.OD % 8 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0) {
-        const int work = in.N * (g.OD / 8) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 32);
+        g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0) {
+        const int work = in.N * (g.OD / 4) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 32);
         p.w = static_cast<const float*>(w_packed16);
-        const size_t lds_bytes = (size_t)4 * 1000 * 16 + (size_t)3 * 9 * 4 * 32 * 16 + (size_t)8 * 2 * 32 * 2 * sizeof(float);
+        const size_t lds_bytes = (size_t)8 * 600 * 16 + (size_t)3 * 9 * 4 * 32 * 16 + (size_t)4 * 2 * 32 * 2 * sizeof(float);
         return launch_f16p<false>(p, lds_bytes, work, s);
     }
     if (g_conv_mode == 1 && w_packed16 && in.C % 16 == 0 && t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2 &&
