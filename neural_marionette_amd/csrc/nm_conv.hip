@@ -226,9 +226,7 @@ __device__ __forceinline__ void epilogue_xz(const EpiArgs& p, float* red, f32x16
                     const int g = r >> 2;
                     const size_t off = (size_t)g * sZ + ((g == 1 || g == 2) ? xo1 : xo0) + (size_t)(r & 3) * sX;
                     const float v = (acc[mt][nt][r] + accl[mt][nt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
-#ifndef NM_EXP_NOEPI
                     base[off] = v;
-#endif
                     s += v; ss += v * v;
                 }
             } else {
@@ -534,7 +532,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     const int nblk = p.nbz * p.nby * p.nbx;
     const int co_base = blockIdx.y * (NT * 32);
     const int C16 = p.Cin >> 4;
-    const int taps = p.ks * p.ks * p.ks;
     const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
     const size_t plane = (size_t)p.Co_pad;                          // half8 units between (hl,h) planes of one (tap,c16)
     const size_t tap_stride = (size_t)C16 * 4 * plane;
@@ -626,11 +623,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
         }
     };
     // raw input of one channel chunk, fetched one chunk ahead (BLDS variants: there are registers to spare at 2 waves/SIMD)
-#ifdef NM_EXP_NOPFA
-    constexpr bool PFA = false;
-#else
     constexpr bool PFA = BLDS;
-#endif
     f32x4 pa[PFA && !UP2 ? HZ : 1], pb[PFA && !UP2 ? HZ : 1], prc[4];
     int pci[4] = {-1, -1, -1, -1};
     auto prefetch_chunk = [&](int c0) {
@@ -693,11 +686,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                     for (int hz = 0; hz < HZ; ++hz) {
                         half8 hi = zero8, lo = zero8;
                         if ((unsigned)(iz0 + hz) < (unsigned)p.ID) {
-#ifdef NM_EXP_NOSPLIT
-                            hi = *reinterpret_cast<half8*>(&pa[hz]); lo = *reinterpret_cast<half8*>(&pb[hz]);
-#else
                             split8(apply_act(p, pa[hz], sca, sha), apply_act(p, pb[hz], scb, shb), hi, lo);
-#endif
                         }
                         ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
                         ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
@@ -943,6 +932,13 @@ __device__ __forceinline__ half8 lds_read16_untracked(unsigned base) {
     return r;
 }
 
+// the same with a wave-uniform 64-bit base (scalar registers) and a 32-bit per-lane byte offset
+__device__ __forceinline__ f32x4 load16_untracked(const float* base, unsigned byte_off) {
+    f32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(byte_off), "s"(base) : "memory");
+    return r;
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
@@ -950,68 +946,42 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 template <int V> using ic = std::integral_constant<int, V>;
 
-// ---- conv_f16p: k3 s1 p1 split-fp16 conv, one persistent 4-wave workgroup per CU, everything in the MFMA shadow ----
+// ---- conv_f16p: k3 s1 p1 split-fp16 conv, one persistent workgroup per CU, MFMA waves + producer waves ---------------
 // conv_f16s runs two independent 4-wave workgroups per CU and leaves the matrix pipe ~50 % idle: staging, the epilogue
-// and the per-brick set-up of one workgroup overlap the other's MFMAs only by chance.  Here ONE workgroup of four waves
-// (one per SIMD, 512 registers each) owns the CU and walks a flat stream of steps (4x8x8 brick, 32-channel cout group,
-// 16-channel chunk).  A step is 27 taps x 6 MFMAs per wave, fully unrolled; every other instruction of the kernel is
-// cut into pieces of <= ~6 VALU / one memory instruction and pinned (sched_barrier) into one of the step's 162 MFMA
-// gaps, where it issues while the matrix pipe works:
-//   * raw input of step s+1: one 16-byte load per tap (taps 0-9; a burst of loads backs up the CU's address unit and
-//     stalls the issuing wave), GroupNorm affine + LeakyReLU + hi/lo split and the LDS write in taps 18-26, into the
-//     second halo buffer;
-//   * weights: 9-tap groups through LDS, three buffers (buffer g always holds tap group g), filled by direct-to-LDS
-//     loads two groups ahead, so the B operands of a group's first tap are read before the barrier ending the previous one;
-//   * the previous brick's epilogue: its outputs wait in 64 registers, stores go out in taps 0-6, GroupNorm partial sums
-//     in taps 9-15.
-// Only three barriers per step (group ends, with counted vmcnt waits for the weight loads) and 64 VALU per brick
-// (outputs = acc + accl / 2^11 + bias) are outside the shadow.  Cout is processed 32 channels per step, the cout groups of a
-// brick back to back (its input stays in L2).
+// and the per-brick set-up of one workgroup overlap the other's MFMAs only by chance.  Here ONE workgroup owns the CU and
+// walks a flat stream of steps (4x8x8 brick, 32-channel cout group, 16-channel chunk), with two kinds of waves:
+//   * waves 0-3, one per SIMD, issue nothing but the step's 27 taps x 6 MFMAs, one LDS operand read per MFMA gap (three
+//     taps deep, exact lgkmcnt waits) and the previous brick's epilogue, cut into <= 4-instruction pieces pinned into the
+//     gaps (stores in taps 0-6, GroupNorm partial sums in taps 9-11); the accumulators never wait for anything else;
+//   * waves 4-7, the second wave of each SIMD, are producers: they fetch the raw input of step s+1 (16-byte pieces, four
+//     lanes per voxel), apply the pending GroupNorm affine + LeakyReLU, split to hi/lo fp16 and write the other halo
+//     buffer - all before the second barrier of step s, so the MFMA waves read the first operands of step s+1 during the
+//     last two taps of step s - and stream the weights: 9-tap groups through LDS, three buffers (buffer g always holds tap
+//     group g), direct-to-LDS loads issued two groups ahead.
+// Three barriers per step (tap-group ends).  Cout is processed 32 channels per step, the cout groups of a brick back to
+// back (its input stays in L2).
 //   LDS: halo [2 buffers][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [3][9 taps][4 planes][32] x 16 B, GroupNorm scratch.
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
 template <bool UP2>
-__global__ __launch_bounds__(256, 1) void conv_f16p_kernel(ConvParams p) {
+__global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
     constexpr int HV = 600, ZP = 100, HX = 10;
     constexpr int GB = 9 * 4 * 32;                                  // half8 slots of one weight group
-    constexpr int NP = 10;                                          // 16-byte input pieces per thread and step (2400 / 256)
+    constexpr int NP = 10;                                          // 16-byte input pieces per producer thread and step (2400 / 256)
     extern __shared__ f32x4 lds[];
     half8* ldh = reinterpret_cast<half8*>(lds);                     // [2][4][HV]
     half8* ldb = ldh + 8 * HV;                                      // [3][GB]
-    float* red = reinterpret_cast<float*>(ldb + 3 * GB);            // [4 waves][2 mt][32][2]
+    float* red = reinterpret_cast<float*>(ldb + 3 * GB);            // [4 waves][32 channels][2]
+    float* lbias = red + 256;                                       // [Cout] bias (zeros without one), written once by the producers
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int C16 = p.Cin >> 4;
     const int ncg = p.Cout >> 5;
     const int nbx = p.OW >> 3, nby = p.OH >> 3, nbz = p.OD >> 2, nbr = nbx * nby * nbz;
-    const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
-    const size_t plane = (size_t)p.Co_pad;
-    const int lane_off = h * (int)plane + l31;
     const int total = p.N * nbr * ncg;
     const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int id_first = (int)blockIdx.x * per, id_last = min(total, id_first + per);
     if (id_first >= id_last) return;
-
-    // MFMA rows of this wave: tile mt = the 8(x) x 4(z) slab of brick row y = 2 * wave + mt
-    int arow[2];
-    {
-        const int c = l31 >> 2;
-        const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
-        arow[0] = z * ZP + (2 * wave) * HX + x;
-        arow[1] = arow[0] + HX;
-    }
-    // staging pieces of this thread: piece k = channels 4 * quad .. +3 (of the chunk's 16) of halo voxel (tid >> 2) + 64k;
-    // four neighbouring lanes fetch one voxel's 64 contiguous bytes
-    const int quad = tid & 3;
-    int pc_slot[NP], pc_rel[NP], pc_pos[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int v = (tid >> 2) + 64 * k, vc = min(v, HV - 1);
-        const int hz = vc / 100, r = vc % 100, hy = r / 10, hx = r % 10;
-        pc_slot[k] = (quad >> 1) * HV + hz * ZP + hy * HX + hx;    // half8 slot of the hi part in a halo buffer (lo: + 2 HV)
-        pc_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin + 4 * quad;
-        pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
-    }
 
     struct Work { int n, oz0, oy0, ox0, cg; };
     auto decode = [&](int id) {
@@ -1021,266 +991,377 @@ __global__ __launch_bounds__(256, 1) void conv_f16p_kernel(ConvParams p) {
         w.ox0 = (br % nbx) << 3; w.oy0 = ((br / nbx) % nby) << 3; w.oz0 = (br / (nbx * nby)) << 2;
         return w;
     };
-    f32x4 raw[NP];
-    unsigned inb = 0;                                               // bit k: piece k of the step being staged lies inside the volume
-    auto piece_inside = [&](const Work& w, int k) {
-        const int hz = pc_pos[k] & 0xff, hy = (pc_pos[k] >> 8) & 0xff, hx = pc_pos[k] >> 16;
-        return pc_pos[k] >= 0 && (unsigned)(w.oz0 - 1 + hz) < (unsigned)p.ID && (unsigned)(w.oy0 - 1 + hy) < (unsigned)p.IH &&
-               (unsigned)(w.ox0 - 1 + hx) < (unsigned)p.IW;
-    };
-    auto load_piece = [&](const Work& w, int cb, auto K) {          // branch-free: outside pieces read the tensor's first bytes
-        constexpr int k = decltype(K)::value;
-        const bool in = piece_inside(w, k);
-        inb = (inb & ~(1u << k)) | ((in ? 1u : 0u) << k);
-        const long long base = ((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin;
-        const float* q = in ? p.in + base + pc_rel[k] + cb * 16 : p.in;
-        raw[k] = load16_untracked(q);
-    };
-    f32x4 sc, sh;
-    const bool has_affine = p.in_scale != nullptr;
-    auto load_affine = [&](const Work& w, int cb) {                 // always two loads: the vmcnt waits below count instructions
-        const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 + 4 * quad : p.in;
-        const float* ph = has_affine ? p.in_shift + (size_t)w.n * p.Cin + cb * 16 + 4 * quad : p.in;
-        sc = load16_untracked(ps);
-        sh = load16_untracked(ph);
-    };
-    // the staged loads have landed: drain and tie every destination register to the wait so no use can move above it
-    auto wait_loads = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]),
-                       "+v"(raw[8]), "+v"(raw[9]), "+v"(sc), "+v"(sh)
-                     :: "memory");
-    };
-    // conversion of piece k in five gap-sized parts: j = 0 / 2 activate value pair 0 / 1 (in place), j = 1 / 3 split it,
-    // j = 4 writes the four hi and four lo halves into halo buffer `buf`
-    half4v cv_hi, cv_lo;
-    auto convert_piece = [&](int buf, auto K, auto J) {
-        constexpr int k = decltype(K)::value, j = decltype(J)::value;
-        constexpr int e = j & 2;                                    // pair = elements e, e + 1
-        if constexpr (j == 0 || j == 2) {
-            float v0 = raw[k][e], v1 = raw[k][e + 1];
-            if (has_affine) { v0 = __builtin_fmaf(v0, sc[e], sh[e]); v1 = __builtin_fmaf(v1, sc[e + 1], sh[e + 1]); }
-            v0 = fmaxf(v0, v0 * p.in_slope); v1 = fmaxf(v1, v1 * p.in_slope);     // LeakyReLU, slope in (0, 1]
-            const bool ok = (inb >> k) & 1;                         // padding is zero AFTER the activation
-            raw[k][e] = ok ? v0 : 0.f; raw[k][e + 1] = ok ? v1 : 0.f;
-        } else if constexpr (j == 1 || j == 3) {
-            const float v0 = raw[k][e], v1 = raw[k][e + 1];
-            half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
-            asm volatile("" : "+v"(hv));
-            const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
-            cv_hi[e] = hv[0]; cv_hi[e + 1] = hv[1];
-            cv_lo[e] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
-            cv_lo[e + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
-        } else {
-            if (pc_pos[k] >= 0) {
-                half4v* dst = reinterpret_cast<half4v*>(ldh + buf * 4 * HV + pc_slot[k]) + (quad & 1);
-                dst[0] = cv_hi;
-                dst[4 * HV] = cv_lo;                                // + 2 HV half8 slots
-            }
+    // the stream: both roles walk it in lockstep (three barriers per step)
+    auto next_work = [&](Work w) {                                  // id + 1 without the divisions of decode()
+        if (++w.cg == ncg) {
+            w.cg = 0;
+            if ((w.ox0 += 8) == p.OW) { w.ox0 = 0; if ((w.oy0 += 8) == p.OH) { w.oy0 = 0; if ((w.oz0 += 4) == p.OD) { w.oz0 = 0; ++w.n; } } }
         }
+        return w;
     };
-    // direct-to-LDS copy of tap group g of (cout group cg, chunk cb) into weight buffer g: 18 one-KiB wave loads; every
-    // wave issues five (two are issued twice) so that the counted vmcnt waits below are the same in all waves
-    auto issue_b_group = [&](int cg, int cb, int g) {
-        auto one = [&](int j) {
-            const int t = j >> 1;
-            const half8* src = w8 + ((size_t)(9 * g + t) * C16 * 4 + (size_t)cb * 4 + (j & 1) * 2) * plane + cg * 32 + lane_off;
-            half8* dst = ldb + g * GB + t * 128 + (j & 1) * 64;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        };
-        one(wave); one(wave + 4); one(wave + 8); one(wave + 12); one(min(wave + 16, 17));
+    struct Step { Work w; int id, cb; };
+    auto advance = [&](Step& st) {                                  // false (and st unchanged) on the block's last step
+        if (st.cb + 1 < C16) { ++st.cb; return true; }
+        if (st.id + 1 >= id_last) return false;
+        st.cb = 0; ++st.id; st.w = next_work(st.w);
+        return true;
     };
-
-    f32x16 acc[2], accl[2], outv[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; accl[mt][r] = 0.f; outv[mt][r] = 0.f; }
-
-    // ---- epilogue of a finished brick, in pieces (bias, channels-last store, GroupNorm partials of the 4x8x8 brick)
-    Work epi;                                                       // the brick whose outputs sit in outv
-    epi.n = 0; epi.oz0 = 0; epi.oy0 = 0; epi.ox0 = 0; epi.cg = 0;
-    float gs1[2] = {0.f, 0.f}, gs2[2] = {0.f, 0.f};
-    const size_t sX = (size_t)p.Cout, sZ = (size_t)p.OH * p.OW * p.Cout;
-    auto epi_store = [&](auto E) {                                  // store e = 16 mt + r of the 32 per lane
-        constexpr int e = decltype(E)::value, mt = e >> 4, r = e & 15, gz = r >> 2;
-        float* base = p.out + ((((size_t)epi.n * p.OD + epi.oz0) * p.OH + epi.oy0 + 2 * wave + mt) * p.OW + epi.ox0) * sX + epi.cg * 32 + l31;
-        const size_t xo = (size_t)(4 * ((gz == 1 || gz == 2) ? (h ^ 1) : h)) * sX;
-        base[(size_t)gz * sZ + xo + (size_t)(r & 3) * sX] = outv[mt][r];
-    };
-    auto epi_sum = [&](auto E) {                                    // values 2e, 2e + 1 of the 32 per lane: e = 0..15
-        constexpr int e = decltype(E)::value, mt = (e >> 3) & 1, r = (2 * e) & 15;
-        if constexpr (r == 0) { gs1[mt] = 0.f; gs2[mt] = 0.f; }
-        const float v0 = outv[mt][r], v1 = outv[mt][r + 1];
-        gs1[mt] += v0; gs2[mt] += v0 * v0;
-        gs1[mt] += v1; gs2[mt] += v1 * v1;
-    };
-    auto epi_red = [&]() {                                          // wave partials -> LDS
-        if (p.part) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const float a = gs1[mt] + __shfl_xor(gs1[mt], 32), b = gs2[mt] + __shfl_xor(gs2[mt], 32);
-                if (h == 0) { red[((wave * 2 + mt) * 32 + l31) * 2] = a; red[((wave * 2 + mt) * 32 + l31) * 2 + 1] = b; }
-            }
-        }
-    };
-    auto epi_part = [&]() {                                         // after a barrier: 32 threads sum the eight partials
-        if (p.part && tid < 32) {
-            float a = 0.f, b = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { a += red[(i * 32 + tid) * 2]; b += red[(i * 32 + tid) * 2 + 1]; }
-            const int br = ((epi.oz0 >> 2) * nby + (epi.oy0 >> 3)) * nbx + (epi.ox0 >> 3);
-            float* dst = p.part + (((size_t)epi.n * nbr + br) * p.Cout + epi.cg * 32 + tid) * 2;
-            dst[0] = a; dst[1] = b;
-        }
-    };
-    auto epi_take = [&](const Work& w) {                            // outputs of the brick just accumulated (64 VALU, exposed)
-        const float bv = p.bias ? p.bias[w.cg * 32 + l31] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) outv[mt][r] = (acc[mt][r] + accl[mt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
-        epi = w;
-    };
-
-    // ---- prologue: stage the first step in the open, start the weight pipeline
-    Work cur = decode(id_first);
-    int id = id_first, cb = 0, hb = 0;
-    issue_b_group(cur.cg, 0, 0);
-    issue_b_group(cur.cg, 0, 1);
-    static_for<NP>([&](auto K) { load_piece(cur, 0, K); });
-    load_affine(cur, 0);
-    wait_loads();
-    static_for<NP * 5>([&](auto Q) { convert_piece(0, ic<decltype(Q)::value / 5>{}, ic<decltype(Q)::value % 5>{}); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-
-    const half8* b0 = ldb + h * 32 + l31;
-    half8 bhv[3], blv[3];                                           // operand registers: three taps deep (index = tap % 3)
-    bhv[0] = b0[0]; blv[0] = b0[64]; bhv[1] = b0[128]; blv[1] = b0[192];
-    bool pending = false;                                           // outv / epi hold a brick whose epilogue has not run
-    bool part_due = false;                                          // red[] holds that brick's partial sums
-
 #ifdef NM_DIAG
     int step_no = 0;
 #define NM_PSTAMP(i) do { if (p.stamps && lane == 0 && step_no < 64) p.stamps[(((size_t)blockIdx.x * 64 + step_no) * 8 + wave) * 16 + (i)] = clock64(); } while (0)
 #else
 #define NM_PSTAMP(i) do {} while (0)
 #endif
-    auto step = [&](auto EPI, const Work& nxt, int ncb) {
-        constexpr bool WITH_EPI = decltype(EPI)::value;
-        NM_PSTAMP(0);
-        const half8* a_h = ldh + hb * 4 * HV + h * HV;
-        const half8* a_l = a_h + 2 * HV;
-        // operands are read two taps (12 MFMAs, ~400 cycles) ahead of their use: with one wave per SIMD nothing else
-        // hides the LDS latency.  One read per MFMA gap, so before each MFMA "all but the 10 youngest LDS operations are
-        // done" (lgkmcnt(10)) covers both of its operands (other LDS traffic in the gaps only makes that stricter).
-        const unsigned va0 = (unsigned)(size_t)(ldh + hb * 4 * HV + h * HV + arow[0]);      // LDS byte addresses
-        const unsigned va1 = va0 + HX * 16;
-        const unsigned vb = (unsigned)(size_t)b0;
-        constexpr int LO = 2 * HV * 16;                             // hi -> lo plane of the halo tile, bytes
-        half8 ah0[3], al0[3], ah1[3], al1[3];
-        ah0[0] = lds_read16_untracked<0>(va0); al0[0] = lds_read16_untracked<LO>(va0);
-        ah1[0] = lds_read16_untracked<0>(va1); al1[0] = lds_read16_untracked<LO>(va1);
-        ah0[1] = lds_read16_untracked<16>(va0); al0[1] = lds_read16_untracked<LO + 16>(va0);
-        ah1[1] = lds_read16_untracked<16>(va1); al1[1] = lds_read16_untracked<LO + 16>(va1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        static_for<27>([&](auto TT) {
-            constexpr int tt = decltype(TT)::value, g = tt / 9, t = tt % 9, i = tt % 3, j = (tt + 2) % 3;
-            if constexpr (t == 0) {                                 // weights two groups ahead (buffer index = tap group)
-                if constexpr (g == 0) issue_b_group(cur.cg, cb, 2);
-                else issue_b_group(nxt.cg, ncb, g - 1);
+    if (wave >= 4) {
+        // =========================== producer waves ===========================================================
+        const int pt = tid - 256, pw = wave - 4;
+        const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+        const size_t plane = (size_t)p.Co_pad;
+        const int lane_off = h * (int)plane + l31;
+        // pieces of this thread: piece k = channels 4 * quad .. +3 (of the chunk's 16) of halo voxel (pt >> 2) + 64k; four
+        // neighbouring lanes fetch one voxel's 64 contiguous bytes
+        const int quad = pt & 3;
+        int pc_slot[NP], pc_rel[NP], pc_pos[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int v = (pt >> 2) + 64 * k, vc = min(v, HV - 1);
+            const int hz = vc / 100, r = vc % 100, hy = r / 10, hx = r % 10;
+            pc_slot[k] = (quad >> 1) * HV + hz * ZP + hy * HX + hx;    // half8 slot of the hi part in a halo buffer (lo: + 2 HV)
+            pc_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin + 4 * quad;
+            pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
+        }
+        f32x4 raw[NP], sc, sh, wreg[5];
+        const bool has_affine = p.in_scale != nullptr;
+        const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * 4u;   // halo voxel (1,1,1): always inside
+        // bit k: piece k of a brick's halo tile lies inside the volume
+        auto inside_mask = [&](const Work& w) {
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int hz = pc_pos[k] & 0xff, hy = (pc_pos[k] >> 8) & 0xff, hx = pc_pos[k] >> 16;
+                const bool in = pc_pos[k] >= 0 && (unsigned)(w.oz0 - 1 + hz) < (unsigned)p.ID && (unsigned)(w.oy0 - 1 + hy) < (unsigned)p.IH &&
+                                (unsigned)(w.ox0 - 1 + hx) < (unsigned)p.IW;
+                m |= (in ? 1u : 0u) << k;
             }
+            return m;
+        };
+        auto tile_base = [&](const Work& w, int cb) {               // wave-uniform: halo voxel (0,0,0), channel 16 cb (may lie
+            return p.in + ((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin + cb * 16;   // outside)
+        };
+        auto load_piece = [&](const float* base, unsigned mask, auto K) {      // outside pieces fetch an inside voxel (zeroed later)
+            constexpr int k = decltype(K)::value;
+            raw[k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * 4u : rel111);
+        };
+        auto load_affine = [&](const Work& w, int cb) {             // always two loads: the waits below count instructions
+            const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 : p.in;
+            const float* ph = has_affine ? p.in_shift + (size_t)w.n * p.Cin + cb * 16 : p.in;
+            sc = load16_untracked(ps, 16u * quad);
+            sh = load16_untracked(ph, 16u * quad);
+        };
+        // wait until all but the N youngest vector-memory operations are done; ties every load destination to the wait
+#define NM_PRODUCER_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" \
+            : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]), \
+              "+v"(raw[8]), "+v"(raw[9]), "+v"(sc), "+v"(sh), "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]), "+v"(wreg[3]), "+v"(wreg[4]) :: "memory")
+        auto convert = [&](int buf, unsigned mask, auto K) {        // activate, split, write piece k into halo buffer buf
+            constexpr int k = decltype(K)::value;
+            half4v hi4, lo4;
+            const float keep = ((mask >> k) & 1) ? 1.f : 0.f;       // padding is zero AFTER the activation
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                float v0 = raw[k][e], v1 = raw[k][e + 1];
+                if (has_affine) { v0 = __builtin_fmaf(v0, sc[e], sh[e]); v1 = __builtin_fmaf(v1, sc[e + 1], sh[e + 1]); }
+                // LeakyReLU (slope in (0, 1]) and the padding mask in two instructions per value: max(v, slope v) * keep
+                v0 = fmaxf(v0 * keep, (v0 * keep) * p.in_slope); v1 = fmaxf(v1 * keep, (v1 * keep) * p.in_slope);
+                half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
+                asm volatile("" : "+v"(hv));
+                const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
+                hi4[e] = hv[0]; hi4[e + 1] = hv[1];
+                lo4[e] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
+                lo4[e + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+            }
+            if (pc_pos[k] >= 0) {
+                half4v* dst = reinterpret_cast<half4v*>(ldh + buf * 4 * HV + pc_slot[k]) + (quad & 1);
+                dst[0] = hi4;
+                dst[4 * HV] = lo4;                                  // + 2 HV half8 slots
+            }
+        };
+        // direct-to-LDS copy of tap group g of (cout group cg, chunk cb) into weight buffer g: 18 one-KiB wave loads; every
+        // producer wave issues five (two are issued twice) so that the counted waits are the same in all of them.  The
+        // per-wave source / destination offsets inside a tap group are fixed: per call only a scalar base is computed.
+        unsigned dma_src[5], dma_dst[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int j = (i < 4) ? pw + 4 * i : min(pw + 16, 17), t = j >> 1;
+            dma_src[i] = (unsigned)(((size_t)t * C16 * 4 + (j & 1) * 2) * plane + lane_off) * 16u;       // bytes, + lane part
+            dma_dst[i] = (unsigned)(t * 128 + (j & 1) * 64 + lane) * 16u;
+        }
+        // Through registers, not direct-to-LDS: an LDS-DMA instruction holds the issuing wave for ~200 cycles in this kernel
+        // (15 per producer wave and step), a 16-byte load + ds_write_b128 pair a fraction of that.
+        auto load_b_group = [&](int cg, int cb, int g) {
+            const float* base = reinterpret_cast<const float*>(w8 + ((size_t)(9 * g) * C16 * 4 + (size_t)cb * 4) * plane + cg * 32);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) wreg[i] = load16_untracked(base, dma_src[i]);
+        };
+        auto store_b_group = [&](int g) {
+            char* lbase = reinterpret_cast<char*>(ldb + g * GB);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) *reinterpret_cast<f32x4*>(lbase + dma_dst[i]) = wreg[i];
+        };
+
+        // The input runs two steps ahead of the MFMA waves: during step s the tile of step s+1 (loaded during step s-1) is
+        // converted piece by piece, and each piece's registers are refilled at once with the load for step s+2.
+        Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+        int hb = 0;
+        Step s1 = cur; bool has1 = advance(s1);                     // step s+1 (= cur on the last step: staged, never read)
+        Step s2 = s1;  bool has2 = has1 && advance(s2);
+        unsigned m_cvt = inside_mask(cur.w), m_ld = m_cvt;
+        for (int c = pt; c < p.Cout; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
+        // prologue: first tile + first two weight groups in the open, loads of the second tile in flight
+        load_b_group(cur.w.cg, 0, 0);
+        load_affine(cur.w, 0);
+        { const float* b = tile_base(cur.w, 0); static_for<NP>([&](auto K) { load_piece(b, m_cvt, K); }); }
+        NM_PRODUCER_WAIT(0);
+        store_b_group(0);
+        load_b_group(cur.w.cg, 0, 1);
+        static_for<NP>([&](auto K) { convert(0, m_cvt, K); });
+        NM_PRODUCER_WAIT(0);
+        store_b_group(1);
+        m_cvt = inside_mask(s1.w);
+        load_affine(s1.w, s1.cb);
+        { const float* b = tile_base(s1.w, s1.cb); static_for<NP>([&](auto K) { load_piece(b, m_cvt, K); }); }
+        lds_barrier();
+        for (;;) {
+            // the tile being loaded (step s+2); its inside mask changes only with the brick
+            if (s2.w.n != s1.w.n || s2.w.oz0 != s1.w.oz0 || s2.w.oy0 != s1.w.oy0 || s2.w.ox0 != s1.w.ox0) m_ld = inside_mask(s2.w);
+            else m_ld = m_cvt;
+            const float* b2 = tile_base(s2.w, s2.cb);
+            NM_PSTAMP(0);
+            // tap group 0: weights of this step's group 2; pieces 0-3.  Everything older than the 5 weight loads has landed
+            // after the first wait (the tile of step s+1 and its affine were issued a step ago).
+            load_b_group(cur.w.cg, cur.cb, 2);
+            NM_PRODUCER_WAIT(5);
+            NM_PSTAMP(1);
+            static_for<4>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
+            NM_PRODUCER_WAIT(4);                                    // the weight loads (older than the 4 new piece loads)
+            store_b_group(2);
+            NM_PSTAMP(2);
+            lds_barrier();
+            NM_PSTAMP(3);
+            // tap group 1: weights of the next step's group 0; pieces 4-9; the halo tile is complete at this barrier
+            load_b_group(s1.w.cg, s1.cb, 0);
+            static_for<6>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 4>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 4>{}); });
+            load_affine(s2.w, s2.cb);                               // (sc / sh are free: piece 9 was their last user)
+            NM_PSTAMP(4);
+            NM_PRODUCER_WAIT(8);                                    // the weight loads: 6 piece + 2 affine loads are younger
+            store_b_group(0);
+            NM_PSTAMP(5);
+            lds_barrier();
+            NM_PSTAMP(6);
+            // tap group 2: weights of the next step's group 1
+            load_b_group(s1.w.cg, s1.cb, 1);
+            NM_PRODUCER_WAIT(0);                                    // (everything: the input loads are a group or more old)
+            store_b_group(1);
+            NM_PSTAMP(7);
+            lds_barrier();
+            NM_PSTAMP(8);
+            if (!has1) break;
+            cur = s1; s1 = s2; has1 = has2; has2 = has2 && advance(s2);
+            m_cvt = m_ld; hb ^= 1;
+#ifdef NM_DIAG
+            ++step_no;
+#endif
+        }
+        NM_PRODUCER_WAIT(0);                                        // loads still in flight for a step that does not exist
+        lds_barrier();                                              // the two barriers of the MFMA waves' drain
+        lds_barrier();
+        return;
+    }
+
+    // =============================== MFMA waves ===============================================================
+    __builtin_amdgcn_s_setprio(3);
+    // MFMA rows of this wave: tile mt = the 8(x) x 4(z) slab of brick row y = 2 * wave + mt
+    int arow0;
+    {
+        const int c = l31 >> 2;
+        const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
+        arow0 = z * ZP + (2 * wave) * HX + x;
+    }
+    f32x16 acc[2], accl[2], outv[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; accl[mt][r] = 0.f; outv[mt][r] = 0.f; }
+
+    // ---- epilogue of a finished brick, in pieces.  The MFMAs below take the weights as the first operand, so a lane holds
+    // one voxel (l31 -> x, z of the slab; tile mt -> brick row y) and its 16 registers the output channels
+    // (r & 3) + 8 (r >> 2) + 4 h: four consecutive channels per register quad -> 16-byte stores (a quarter of the store
+    // instructions of the channel-per-lane layout; vector-memory instruction issue is what this kernel runs out of first).
+    Work epi;                                                       // the brick whose outputs sit in outv
+    epi.n = 0; epi.oz0 = 0; epi.oy0 = 0; epi.ox0 = 0; epi.cg = 0;
+    const int vx = ((((0x96 >> (l31 >> 2)) & 1) << 2) + (l31 & 3)), vz = l31 >> 3;
+    auto epi_store = [&](auto E) {                                  // store e = 4 mt + k4 of the 8 per lane
+        constexpr int e = decltype(E)::value, mt = e >> 2, k4 = e & 3;
+        float* dst = p.out + ((((size_t)epi.n * p.OD + epi.oz0 + vz) * p.OH + epi.oy0 + 2 * wave + mt) * p.OW + epi.ox0 + vx) * (size_t)p.Cout +
+                     epi.cg * 32 + 8 * k4 + 4 * h;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{outv[mt][4 * k4], outv[mt][4 * k4 + 1], outv[mt][4 * k4 + 2], outv[mt][4 * k4 + 3]};
+    };
+    // GroupNorm partial sums, in place: outv[0][r] <- sum over the two tiles, outv[1][r] <- sum of squares; then over the 32
+    // voxels (lanes of one half) with DPP adds; rows 1 and 3 of the wave end up holding the totals
+    auto epi_sum_local = [&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const float a = outv[0][r], b = outv[1][r];
+        outv[0][r] = a + b;
+        outv[1][r] = a * a + b * b;
+    };
+    auto epi_sum_lanes = [&](auto I) {                              // DPP step (i >> 5) of value (i & 31) = 16 m + r: consecutive
+        constexpr int i = decltype(I)::value, st = i >> 5, v = i & 31, m = v >> 4, r = v & 15;    // pieces touch different registers
+        constexpr int ctrl = st == 0 ? 0xB1 : st == 1 ? 0x4E : st == 2 ? 0x141 : st == 3 ? 0x140 : 0x142;   // quad_perm [1,0,3,2], [2,3,0,1],
+        constexpr int rows = st == 4 ? 0xa : 0xf;                                                            // row_half_mirror, row_mirror, row_bcast15
+        const float x = outv[m][r];
+        outv[m][r] = x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rows, 0xf, true));
+    };
+    auto epi_red = [&](auto R) {                                    // lanes 16 / 48 park (sum, sum of squares) of channel c(r, h)
+        constexpr int r = decltype(R)::value;
+        if (p.part && l31 == 16) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * h;
+            *reinterpret_cast<f32x2*>(red + (wave * 32 + c) * 2) = f32x2{outv[0][r], outv[1][r]};
+        }
+    };
+    auto epi_part = [&]() {                                         // after a barrier: 32 threads sum the four wave partials
+        if (p.part && tid < 32) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a += red[(i * 32 + tid) * 2]; b += red[(i * 32 + tid) * 2 + 1]; }
+            const int br = ((epi.oz0 >> 2) * nby + (epi.oy0 >> 3)) * nbx + (epi.ox0 >> 3);
+            float* dst = p.part + (((size_t)epi.n * nbr + br) * p.Cout + epi.cg * 32 + tid) * 2;
+            dst[0] = a; dst[1] = b;
+        }
+    };
+    auto epi_take = [&](const Work& w) {                            // outputs of the brick just accumulated (64 VALU, exposed)
+        f32x4 b4[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) b4[k4] = *reinterpret_cast<const f32x4*>(lbias + w.cg * 32 + 8 * k4 + 4 * h);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) outv[mt][r] = (acc[mt][r] + accl[mt][r] * (1.0f / NM_SPLIT_SCALE)) + b4[r >> 2][r & 3];
+        epi = w;
+    };
+
+    Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+    int hb = 0;
+    lds_barrier();                                                  // the producers' prologue
+
+    // operand registers, three taps deep (index = tap % 3); LDS byte addresses of this lane's rows / weight column
+    const unsigned vb = (unsigned)(size_t)(ldb + h * 32 + l31);
+    constexpr int LO = 2 * HV * 16;                                 // hi -> lo plane of a halo tile, bytes
+    constexpr int YO = HX * 16;                                     // brick row 2 wave -> 2 wave + 1
+    half8 ah0[3], al0[3], ah1[3], al1[3], bhv[3], blv[3];
+    {
+        const unsigned va = (unsigned)(size_t)(ldh + h * HV + arow0);
+        ah0[0] = lds_read16_untracked<0>(va); al0[0] = lds_read16_untracked<LO>(va);
+        ah1[0] = lds_read16_untracked<YO>(va); al1[0] = lds_read16_untracked<LO + YO>(va);
+        ah0[1] = lds_read16_untracked<16>(va); al0[1] = lds_read16_untracked<LO + 16>(va);
+        ah1[1] = lds_read16_untracked<YO + 16>(va); al1[1] = lds_read16_untracked<LO + YO + 16>(va);
+        bhv[0] = lds_read16_untracked<0>(vb); blv[0] = lds_read16_untracked<64 * 16>(vb);
+        bhv[1] = lds_read16_untracked<128 * 16>(vb); blv[1] = lds_read16_untracked<192 * 16>(vb);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah0[0]), "+v"(al0[0]), "+v"(ah1[0]), "+v"(al1[0]), "+v"(ah0[1]), "+v"(al0[1]), "+v"(ah1[1]), "+v"(al1[1]),
+                       "+v"(bhv[0]), "+v"(blv[0]), "+v"(bhv[1]), "+v"(blv[1]) :: "memory");
+    }
+    bool pending = false;                                           // outv / epi hold a brick whose epilogue has not run
+    bool part_due = false;                                          // red[] holds that brick's partial sums
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (;;) {
+        Step nxt = cur;
+        const bool has_next = advance(nxt);
+        if (part_due) { epi_part(); part_due = false; }
+        const bool run_epi = pending;
+        // One read per MFMA gap, issued two taps (12 MFMAs, ~400 cycles) before its first use; before each MFMA "all but the
+        // 10 youngest LDS operations are done" covers both of its operands (other LDS traffic only makes that stricter).
+        const unsigned va = (unsigned)(size_t)(ldh + hb * 4 * HV + h * HV + arow0);          // this step's halo tile
+        const unsigned van = (unsigned)(size_t)(ldh + (hb ^ 1) * 4 * HV + h * HV + arow0);   // the next step's
+        NM_PSTAMP(0);
+        // two copies of the stream (with / without epilogue pieces): a branch per gap would cost more than the pieces
+        auto stream = [&](auto EPI) {
+        constexpr bool with_epi = decltype(EPI)::value;
+        static_for<27>([&](auto TT) {
+            constexpr int tt = decltype(TT)::value, t = tt % 9, i = tt % 3, j = (tt + 2) % 3;
             auto gap = [&](auto SUB) {
                 constexpr int sub = decltype(SUB)::value, q = tt * 6 + sub;
-#ifndef NM_EXP_BARE
-                if constexpr (q == 1) load_affine(nxt, ncb);
-                if constexpr (sub == 0 && tt < NP) load_piece(nxt, ncb, ic<(tt < NP ? tt : 0)>{});
-                if constexpr (WITH_EPI && tt < 7 && sub >= 1 && (tt * 5 + sub - 1) < 32) epi_store(ic<(tt * 5 + sub - 1) & 31>{});
-                if constexpr (WITH_EPI && q >= 54 && q < 70) epi_sum(ic<(q - 54) & 15>{});
-                if constexpr (WITH_EPI && q == 90) epi_red();
-                if constexpr (q >= 108 && q < 108 + NP * 5) convert_piece(hb ^ 1, ic<(q >= 108 && q < 108 + NP * 5) ? (q - 108) / 5 : 0>{}, ic<(q >= 108 ? q - 108 : 0) % 5>{});
-#endif
+                if constexpr (with_epi) {                           // <= 3 VALU or one memory instruction per gap
+                    if constexpr (q >= 2 && q < 18 && (q & 1) == 0) epi_store(ic<((q - 2) >> 1) & 7>{});
+                    if constexpr (q >= 18 && q < 34) epi_sum_local(ic<(q - 18) & 15>{});
+                    if constexpr (q >= 34 && q < 114) { epi_sum_lanes(ic<(2 * (q - 34)) % 160>{}); epi_sum_lanes(ic<(2 * (q - 34) + 1) % 160>{}); }
+                    if constexpr (q >= 116 && q < 132) epi_red(ic<(q - 116) & 15>{});
+                }
             };
             constexpr int u = tt + 2, ug = (u < 27) ? u / 9 : 0, ut = (u < 27) ? u % 9 : u - 27;
-            constexpr bool a_next = u < 27;                        // taps 25, 26: dummy A reads keep the one-read-per-gap count
-            constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;          // byte offsets of tap tt + 2
-            constexpr int BO = (ug * GB + ut * 128) * 16;
-#define NM_WAIT_OPERANDS(x, y) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(x), "+v"(y) :: "memory")   // ties the MFMA below to the wait
-
+            constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;          // byte offsets of tap tt + 2 (taps 25, 26: of the
+            constexpr int BO = (ug * GB + ut * 128) * 16;                           // next step's taps 0, 1)
+            const unsigned vau = (u < 27) ? va : van;
+#define NM_WAIT_OPERANDS(x, y) asm volatile("" : "+v"(x), "+v"(y))
+            // one wait per tap: this tap's six operands were issued during tap tt - 2; the six reads of tap tt - 1 are the only
+            // younger LDS operations (anything else in the gaps only makes the wait stricter)
+            asm volatile("s_waitcnt lgkmcnt(6)"
+                         : "+v"(ah0[i]), "+v"(al0[i]), "+v"(ah1[i]), "+v"(al1[i]), "+v"(bhv[i]), "+v"(blv[i]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(ah0[i], bhv[i]);
-            if constexpr (WITH_EPI && tt == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bhv[i], zero16, 0, 0, 0);
-            else acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bhv[i], acc[0], 0, 0, 0);
+            if constexpr (tt == 0 && with_epi) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], ah0[i], zero16, 0, 0, 0);
+            else acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], ah0[i], acc[0], 0, 0, 0);
             bhv[j] = lds_read16_untracked<BO>(vb);
             gap(ic<0>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(ah0[i], blv[i]);
-            if constexpr (WITH_EPI && tt == 0) accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], blv[i], zero16, 0, 0, 0);
-            else accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], blv[i], accl[0], 0, 0, 0);
-            ah0[j] = lds_read16_untracked<a_next ? AO : 0>(va0);
+            if constexpr (tt == 0 && with_epi) accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blv[i], ah0[i], zero16, 0, 0, 0);
+            else accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blv[i], ah0[i], accl[0], 0, 0, 0);
+            ah0[j] = lds_read16_untracked<AO>(vau);
             gap(ic<1>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(ah1[i], bhv[i]);
-            if constexpr (WITH_EPI && tt == 0) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bhv[i], zero16, 0, 0, 0);
-            else acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bhv[i], acc[1], 0, 0, 0);
+            if constexpr (tt == 0 && with_epi) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], ah1[i], zero16, 0, 0, 0);
+            else acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], ah1[i], acc[1], 0, 0, 0);
             blv[j] = lds_read16_untracked<BO + 64 * 16>(vb);
             gap(ic<2>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(ah1[i], blv[i]);
-            if constexpr (WITH_EPI && tt == 0) accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], blv[i], zero16, 0, 0, 0);
-            else accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], blv[i], accl[1], 0, 0, 0);
-            ah1[j] = lds_read16_untracked<a_next ? AO : 0>(va1);
+            if constexpr (tt == 0 && with_epi) accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blv[i], ah1[i], zero16, 0, 0, 0);
+            else accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blv[i], ah1[i], accl[1], 0, 0, 0);
+            ah1[j] = lds_read16_untracked<AO + YO>(vau);
             gap(ic<3>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(al0[i], bhv[i]);
-            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[i], bhv[i], accl[0], 0, 0, 0);
-            al0[j] = lds_read16_untracked<a_next ? AO + LO : 0>(va0);
+            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], al0[i], accl[0], 0, 0, 0);
+            al0[j] = lds_read16_untracked<AO + LO>(vau);
             gap(ic<4>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(al1[i], bhv[i]);
-            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[i], bhv[i], accl[1], 0, 0, 0);
-            al1[j] = lds_read16_untracked<a_next ? AO + LO : 0>(va1);
+            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], al1[i], accl[1], 0, 0, 0);
+            al1[j] = lds_read16_untracked<AO + LO + YO>(vau);
             gap(ic<5>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (t == 8) {
-                // group end.  g = 0: only the weight loads of tap 0 must have landed; younger in issue order are 2 affine +
-                // 9 piece loads (+ 32 stores).  g = 1: pieces and weights (they are converted / read next).  g = 2: weights.
-                NM_PSTAMP(1 + 3 * g);
-#ifdef NM_EXP_BARE
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-                if constexpr (g == 0) { if constexpr (WITH_EPI) asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
-                else if constexpr (g == 1) wait_loads();
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-                NM_PSTAMP(2 + 3 * g);
-                lds_barrier();
-                NM_PSTAMP(3 + 3 * g);
-                // the dummy reads of taps 25 / 26 land after they issue: their registers stay reserved up to here
-                if constexpr (g == 2)
-                    asm volatile("" :: "v"(ah0[0]), "v"(al0[0]), "v"(ah1[0]), "v"(al1[0]), "v"(ah0[1]), "v"(al0[1]), "v"(ah1[1]), "v"(al1[1]));
+                // tap-group end: the producers publish weights / the next tile.  No lgkmcnt wait here - these waves write no
+                // LDS the others read before a later barrier, and their operand reads are covered by the counted waits.
+                NM_PSTAMP(1 + 2 * (tt / 9));
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                NM_PSTAMP(2 + 2 * (tt / 9));
             }
         });
-    };
-
-    for (;;) {
-        int nid = id, ncb = cb + 1;
-        if (ncb == C16) { ncb = 0; nid = id + 1; }
-        const bool has_next = nid < id_last;
-        if (!has_next) { nid = id; ncb = cb; }                      // last step: stage a copy of itself (never read)
-        Work nxt = cur;
-        if (nid != id) nxt = decode(nid);
-        if (part_due) { epi_part(); part_due = false; }             // before this step's first weight load (vmcnt counts)
-        if (pending) { step(std::true_type{}, nxt, ncb); pending = false; part_due = true; }
-        else step(std::false_type{}, nxt, ncb);
-        NM_PSTAMP(10);
-        if (cb == C16 - 1) { epi_take(cur); pending = true; }
-        NM_PSTAMP(11); NM_PSTAMP(12);
+        // the operands of the next step's taps 0, 1 were read one / two gaps ago; the two copies of the stream may keep them in
+        // different registers, so they must have landed before the compiler moves them
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ah0[0]), "+v"(al0[0]), "+v"(ah1[0]), "+v"(al1[0]), "+v"(ah0[1]), "+v"(al0[1]), "+v"(ah1[1]), "+v"(al1[1]),
+                       "+v"(bhv[0]), "+v"(blv[0]), "+v"(bhv[1]), "+v"(blv[1]) :: "memory");
+        };
+        if (run_epi) stream(std::true_type{}); else stream(std::false_type{});
+        if (run_epi) { pending = false; part_due = true; }
+        if (cur.cb == C16 - 1) { epi_take(cur.w); pending = true; }
+        NM_PSTAMP(7);
         if (!has_next) break;
-        id = nid; cb = ncb; cur = nxt; hb ^= 1;
+        cur = nxt; hb ^= 1;
 #ifdef NM_DIAG
         ++step_no;
 #endif
@@ -1288,9 +1369,10 @@ __global__ __launch_bounds__(256, 1) void conv_f16p_kernel(ConvParams p) {
     // ---- drain: the last brick's epilogue in the open
     if (part_due) epi_part();
     lds_barrier();
-    static_for<32>([&](auto E) { epi_store(E); });
-    static_for<16>([&](auto E) { epi_sum(E); });
-    epi_red();
+    static_for<8>([&](auto E) { epi_store(E); });
+    static_for<16>([&](auto R) { epi_sum_local(R); });
+    static_for<160>([&](auto I) { epi_sum_lanes(I); });
+    static_for<16>([&](auto R) { epi_red(R); });
     lds_barrier();
     epi_part();
 }
@@ -1431,7 +1513,7 @@ int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream
         (void)hipEventRecord(rec.a, s);
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
-    hipLaunchKernelGGL((conv_f16p_kernel<UP2>), grid, dim3(256), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16p_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
@@ -1439,7 +1521,9 @@ int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream
 #ifdef NM_DIAG
 unsigned long long* g_stamps = nullptr;
 #endif
-int g_f16p = [] { const char* e = getenv("NM355_F16P"); return e ? atoi(e) : 1; }();    // 0: keep conv_f16s for every layer (diagnostic)
+// conv_f16p use: 0 never (conv_f16s everywhere), 1 every eligible layer, 2 (default) only Cout == 32 layers - with more cout
+// groups per brick it re-stages the input per group and measures a little slower than conv_f16s (A/B in one gpurun call)
+int g_f16p = [] { const char* e = getenv("NM355_F16P"); return e ? atoi(e) : 2; }();
 int g_stagger = [] { const char* e = getenv("NM355_STAGGER"); return e ? atoi(e) : 0; }();
 int g_conv_mode = 1;      // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
 
@@ -1534,10 +1618,10 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp; p.ZP = t.HY * t.HX;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
     if (g_conv_mode == 1 && g_f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
-        g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0) {
+        g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0 && (g_f16p == 1 || g.Cout == 32)) {
         const int work = in.N * (g.OD / 4) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 32);
         p.w = static_cast<const float*>(w_packed16);
-        const size_t lds_bytes = (size_t)8 * 600 * 16 + (size_t)3 * 9 * 4 * 32 * 16 + (size_t)4 * 2 * 32 * 2 * sizeof(float);
+        const size_t lds_bytes = (size_t)8 * 600 * 16 + (size_t)3 * 9 * 4 * 32 * 16 + (size_t)(256 + g.Cout) * sizeof(float);
         return launch_f16p<false>(p, lds_bytes, work, s);
     }
     if (g_conv_mode == 1 && w_packed16 && in.C % 16 == 0 && t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2 &&

@@ -30,10 +30,12 @@ for (Cin, Cout, size, N) in [(32, 32, 64, 16), (64, 64, 32, 16)]:
     s = stamps[: 256 * 64 * 8 * 16].view(256, 64, 8, 16).cpu().numpy().astype(np.float64)
     C16 = Cin // 16
     print(f"Cin={Cin} Cout={Cout} size={size}: {t0.elapsed_time(t1)*1e3:.0f} us")
-    for wv in (0, 3):
-        v = s[:, 2:40, wv, :]            # skip the first steps
-        ok = v[:, :, 12] > 0
-        d = lambda a, b_: ((v[:, :, b_] - v[:, :, a])[ok]).mean()
-        nxt = (s[:, 3:41, wv, 0] - s[:, 2:40, wv, 12])[ok & (s[:, 3:41, wv, 0] > 0)].mean()
-        print(f"  wave {wv}: g0 mfma {d(0,1):6.0f} wait {d(1,2):5.0f} bar {d(2,3):5.0f} | g1 mfma {d(3,4):6.0f} wait {d(4,5):5.0f} bar {d(5,6):5.0f} |"
-              f" g2 mfma {d(6,7):6.0f} wait {d(7,8):5.0f} bar {d(8,9):5.0f} | write {d(9,10):5.0f} epi(avg over steps) {d(10,11):5.0f} bar {d(11,12):5.0f} | to next step {nxt:5.0f} | step {d(0,12)+nxt:6.0f}")
+    first = s[:, 0, 0, 0]; lastv = s[:, :, 0, 7].max(axis=1)
+    span = (lastv - first)[first > 0]
+    print(f"  per-block span (step 0 start .. last stamped step end): mean {span.mean():.0f} ticks, max {span.max():.0f}; kernel {t0.elapsed_time(t1)*1e3:.0f} us -> {span.max()/(t0.elapsed_time(t1)*1e3):.0f} ticks/us; steps stamped {int((s[0,:,0,7]>0).sum())}")
+    v = s[:, 2:40, 0, :]; ok = v[:, :, 7] > 0
+    d = lambda a, b_: ((v[:, :, b_] - v[:, :, a])[ok]).mean()
+    nxt = (s[:, 3:41, 0, 0] - s[:, 2:40, 0, 7])[ok & (s[:, 3:41, 0, 0] > 0)].mean()
+    print(f"  mfma wave 0: g0 {d(0,1):6.0f} bar {d(1,2):5.0f} | g1 {d(2,3):6.0f} bar {d(3,4):5.0f} | g2 {d(4,5):6.0f} bar {d(5,6):5.0f} | tail {d(6,7):5.0f} next {nxt:5.0f} | step {d(0,7)+nxt:6.0f}")
+    v = s[:, 2:40, 4, :]; ok = v[:, :, 8] > 0
+    print(f"  producer 4 : issue {d(0,1):6.0f} cvt0-3 {d(1,2):6.0f} bar {d(2,3):5.0f} | cvt4-9 {d(3,4):6.0f} wait {d(4,5):5.0f} bar {d(5,6):5.0f} | g2 {d(6,7):6.0f} bar {d(7,8):5.0f}")
