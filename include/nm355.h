@@ -209,7 +209,9 @@ int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, i
  * mode 1 (default): layers with Cin % 16 == 0 run on the fp16 matrix cores with every fp32 operand split
  * into fp16 hi + lo*2^-11 and three products x_hi*w_hi + 2^-11 (x_hi*w_lo + x_lo*w_hi) accumulated in
  * fp32 — error within one fp32 rounding of the exact product, same tolerance class as the fp32 fma
- * chain, 16x/3 the MFMA rate.  Parity tests run in both modes. */
+ * chain, 16x/3 the MFMA rate.  mode 2 = mode 1 with the producer/consumer kernel (conv_f16p) on every layer it
+ * supports instead of the Cout == 32 layers only (same arithmetic; a test / measurement switch).  Parity tests run in
+ * all modes. */
 int nm_set_conv_mode(nm_ctx* ctx, int32_t mode);
 int nm_get_conv_mode(nm_ctx* ctx);
 

@@ -44,7 +44,7 @@ struct ConvParams {
     int HZ, HY, HX, HV, HVp;      // halo dims, voxels, padded plane stride (HVp % 8 == 2)
     int CVp;                      // up2: plane stride of the coarse LDS tile
     int ZP;                       // f16s: pitch between halo z-planes in LDS (>= HY*HX, = 4 mod 16)
-    int stagger;                  // f16s: shader cycles the second workgroup of a CU waits before its first brick
+    int st_z, st_y, st_x;         // f16s / f16p: XCD super-tile in bricks (0: bricks in linear order), see super_tile_item()
 #ifdef NM_DIAG
     unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
 #endif
@@ -510,6 +510,30 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, half8& hi
     }
 }
 
+// Which brick a persistent workgroup processes in its iteration tau.  The eight XCDs have separate L2s and a brick's
+// 6x10x10 halo is 2.3x its 4x8x8 outputs, so in linear order (each workgroup a contiguous run of bricks, the 32 CUs of an
+// XCD far apart in the volume) the input is fetched from HBM about twice; conv 64^3 x 32 channels moved 8-10 GB per
+// launch for 4.3 GB of tensors.  Here the workgroups of one XCD (blockIdx % 8 is the XCD label) take, at the same time,
+// the st_z x st_y x st_x bricks of one super-tile (one brick per workgroup, 64 or 32 of them), and consecutive iterations
+// walk neighbouring super-tiles of the same frame, so halos shared between neighbouring bricks are served by that L2.
+struct BrickPos { int n, bz, by, bx; };
+__device__ __forceinline__ BrickPos super_tile_item(const ConvParams& p, int b, int tau, int per, int nbz, int nby, int nbx) {
+    BrickPos r;
+    if (p.st_x == 0) {
+        const int nbr = nbz * nby * nbx, item = b * per + tau;
+        r.n = item / nbr; const int br = item % nbr;
+        r.bx = br % nbx; r.by = (br / nbx) % nby; r.bz = br / (nbx * nby);
+        return r;
+    }
+    const int l = b >> 3, S = (b & 7) * per + tau;
+    const int SX = nbx / p.st_x, SY = nby / p.st_y, stpf = SX * SY * (nbz / p.st_z);
+    r.n = S / stpf; const int si = S % stpf;
+    r.bx = (si % SX) * p.st_x + l % p.st_x;
+    r.by = ((si / SX) % SY) * p.st_y + (l / p.st_x) % p.st_y;
+    r.bz = (si / (SX * SY)) * p.st_z + l / (p.st_x * p.st_y);
+    return r;
+}
+
 // Brick = 4(z) x 8(y) x 8(x) output voxels, 256 GEMM rows.  Each 32-row MFMA tile is the 8(x) x 4(z) slab of one
 // brick row y: with the halo tile's plane pitch ZP = 4 (mod 16) slots, the four 16-lane groups of a ds_read_b128
 // then hit 16 distinct 16-B slots (conflict-free; the natural (y,x) tile order is a 3-way conflict and makes the
@@ -540,20 +564,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     // in time, and the ~10 us a short-lived workgroup spends being dispatched and retired is paid once).
     const int total_items = p.N * nblk;
     const int per = (total_items + (int)gridDim.x - 1) / (int)gridDim.x;
-    if (p.stagger > 0) {
-        // Two persistent workgroups share each CU and run the same stage / MFMA sequence: started together they stay
-        // in lockstep (both staging while the matrix pipe idles, then both contending for it).  The one whose waves
-        // sit in the odd wave slots starts late by about half a stage+MFMA period so the phases interleave.
-        const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_ID[3:0] = wave slot
-        if (hwid & 1) {
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            while (__builtin_readcyclecounter() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     const int item_end = min(total_items, ((int)blockIdx.x + 1) * per);
     for (int item = (int)blockIdx.x * per; item < item_end; ++item) {
-    const int n = item / nblk, br = item % nblk;
-    const int bxi = br % p.nbx, byi = (br / p.nbx) % p.nby, bzi = br / (p.nbx * p.nby);
+    const BrickPos bp = super_tile_item(p, (int)blockIdx.x, item - (int)blockIdx.x * per, per, p.nbz, p.nby, p.nbx);
+    const int n = bp.n, bxi = bp.bx, byi = bp.by, bzi = bp.bz;
+    const int br = (bzi * p.nby + byi) * p.nbx + bxi;
     const int oz0 = bzi << 2, oy0 = byi << 3, ox0 = bxi << 3;
     int arow[MT];
     {
@@ -932,11 +947,10 @@ __device__ __forceinline__ half8 lds_read16_untracked(unsigned base) {
     return r;
 }
 
-// the same with a wave-uniform 64-bit base (scalar registers) and a 32-bit per-lane byte offset
+// the same from a wave-uniform base and a 32-bit per-lane byte offset (one 64-bit VALU add; the scalar-base addressing form
+// needs the base in SGPRs, which the compiler does not guarantee for an inline-asm operand computed through VALU divisions)
 __device__ __forceinline__ f32x4 load16_untracked(const float* base, unsigned byte_off) {
-    f32x4 r;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(byte_off), "s"(base) : "memory");
-    return r;
+    return load16_untracked(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off));
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
@@ -984,15 +998,21 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
     if (id_first >= id_last) return;
 
     struct Work { int n, oz0, oy0, ox0, cg; };
+    const bool tiled = p.st_x != 0;                                 // XCD super-tile order (one cout group only), see super_tile_item
     auto decode = [&](int id) {
         Work w;
+        if (tiled) {
+            const BrickPos bp = super_tile_item(p, (int)blockIdx.x, id - id_first, per, nbz, nby, nbx);
+            w.cg = 0; w.n = bp.n; w.ox0 = bp.bx << 3; w.oy0 = bp.by << 3; w.oz0 = bp.bz << 2;
+            return w;
+        }
         w.cg = id % ncg; const int bid = id / ncg;
         w.n = bid / nbr; const int br = bid % nbr;
         w.ox0 = (br % nbx) << 3; w.oy0 = ((br / nbx) % nby) << 3; w.oz0 = (br / (nbx * nby)) << 2;
         return w;
     };
-    // the stream: both roles walk it in lockstep (three barriers per step)
-    auto next_work = [&](Work w) {                                  // id + 1 without the divisions of decode()
+    auto next_work = [&](Work w, int id) {                          // work item id from item id - 1 (linear order: no divisions)
+        if (tiled) return decode(id);
         if (++w.cg == ncg) {
             w.cg = 0;
             if ((w.ox0 += 8) == p.OW) { w.ox0 = 0; if ((w.oy0 += 8) == p.OH) { w.oy0 = 0; if ((w.oz0 += 4) == p.OD) { w.oz0 = 0; ++w.n; } } }
@@ -1003,7 +1023,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
     auto advance = [&](Step& st) {                                  // false (and st unchanged) on the block's last step
         if (st.cb + 1 < C16) { ++st.cb; return true; }
         if (st.id + 1 >= id_last) return false;
-        st.cb = 0; ++st.id; st.w = next_work(st.w);
+        st.cb = 0; ++st.id; st.w = next_work(st.w, st.id);
         return true;
     };
 #ifdef NM_DIAG
@@ -1469,8 +1489,23 @@ int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
     return nm_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
+int g_supertile = [] { const char* e = getenv("NM355_SUPERTILE"); return e ? atoi(e) : 1; }();   // 0: linear brick order (diagnostic)
+// XCD super-tile (see super_tile_item): the persistent grid must be 8 x (bricks per super-tile) workgroups, the brick grid
+// a multiple of the super-tile, and the super-tiles split evenly over the eight XCDs
+void choose_super_tile(ConvParams& p, int nblocks, int nbz, int nby, int nbx) {
+    p.st_z = p.st_y = p.st_x = 0;
+    if (!g_supertile || nblocks % 8) return;
+    const int gs = nblocks / 8;
+    const int sz = gs == 64 ? 4 : gs == 32 ? 2 : 0;
+    if (!sz || nbz % sz || nby % 4 || nbx % 4) return;
+    const long long st = (long long)p.N * (nbz / sz) * (nby / 4) * (nbx / 4);
+    if (st % 8 || st / 8 * nblocks != (long long)p.N * nbz * nby * nbx) return;
+    p.st_z = sz; p.st_y = 4; p.st_x = 4;
+}
+
 template <int MT, int NT, int KS, bool UP2>
-int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
+int launch_f16s(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t s) {
+    ConvParams p = p_in;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT, KS, UP2>),
@@ -1485,6 +1520,7 @@ int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) 
         (void)hipEventRecord(rec.a, s);
     }
     dim3 pgrid(min(grid.x, 512u), grid.y);                          // persistent: ~2 resident workgroups per CU
+    choose_super_tile(p, (int)pgrid.x, p.nbz, p.nby, p.nbx);
     hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2>), pgrid, dim3(256), t.lds_bytes, s, p);
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
@@ -1493,7 +1529,8 @@ int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) 
 int g_num_cus = 0;
 
 template <bool UP2>
-int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
+int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
+    ConvParams p = p_in;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2>),
@@ -1513,6 +1550,7 @@ int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream
         (void)hipEventRecord(rec.a, s);
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
+    if (p.Cout == 32) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
@@ -1524,16 +1562,16 @@ unsigned long long* g_stamps = nullptr;
 // conv_f16p use: 0 never (conv_f16s everywhere), 1 every eligible layer, 2 (default) only Cout == 32 layers - with more cout
 // groups per brick it re-stages the input per group and measures a little slower than conv_f16s (A/B in one gpurun call)
 int g_f16p = [] { const char* e = getenv("NM355_F16P"); return e ? atoi(e) : 2; }();
-int g_stagger = [] { const char* e = getenv("NM355_STAGGER"); return e ? atoi(e) : 0; }();
 int g_conv_mode = 1;      // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
+bool g_f16p_all = false;  // mode 2: split-fp16 with conv_f16p on every eligible layer (parity tests of its multi-cout-group path)
 
 }  // namespace
 
 #ifdef NM_DIAG
 extern "C" void nm_diag_set_stamps(void* p) { g_stamps = static_cast<unsigned long long*>(p); }
 #endif
-void nm_conv_set_mode(int mode) { g_conv_mode = mode; }
-int nm_conv_get_mode() { return g_conv_mode; }
+void nm_conv_set_mode(int mode) { g_conv_mode = mode ? 1 : 0; g_f16p_all = mode == 2; }
+int nm_conv_get_mode() { return g_conv_mode && g_f16p_all ? 2 : g_conv_mode; }
 
 int nm_launch_pack_conv_weight16(const float* w, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s) {
     if (Cin % 16 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("pack_conv_weight16: Cin=%d must be a multiple of 16", Cin); return NM_ERR_ARG; }
@@ -1611,14 +1649,14 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.bz_l2 = t.bz_l2; p.by_l2 = t.by_l2; p.bx_l2 = t.bx_l2; p.nbz = t.nbz; p.nby = t.nby; p.nbx = t.nbx;
     p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.up2 = g.up2 ? 1 : 0;
-    p.stagger = g_stagger;
+    p.st_z = p.st_y = p.st_x = 0;
 #ifdef NM_DIAG
     p.stamps = g_stamps;
 #endif
     p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp; p.ZP = t.HY * t.HX;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
     if (g_conv_mode == 1 && g_f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
-        g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0 && (g_f16p == 1 || g.Cout == 32)) {
+        g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0 && (g_f16p == 1 || g_f16p_all || g.Cout == 32)) {
         const int work = in.N * (g.OD / 4) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 32);
         p.w = static_cast<const float*>(w_packed16);
         const size_t lds_bytes = (size_t)8 * 600 * 16 + (size_t)3 * 9 * 4 * 32 * 16 + (size_t)(256 + g.Cout) * sizeof(float);

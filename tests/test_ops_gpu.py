@@ -69,7 +69,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "split16"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["fp32mfma", "split16", "split16-f16p"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "ci%d_co%d_k%d_s%d_d%d" % (c[0], c[1], c[2], c[3], c[5]))
 def test_conv3d(ctx, case, mode):
     from neural_marionette_amd import _lib
