@@ -927,6 +927,86 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     }   // persistent item loop
 }
 
+// ---- conv_pool_f16s: the k2 s2 p0 "pool" convs in split-fp16 ------------------------------------------------------------
+// Every input voxel feeds exactly one (output voxel, tap) pair, so nothing is shared between rows and nothing goes through
+// LDS: lane (row l31 = output voxel, half h) loads its own 8 channels of the tap's input voxel (32 contiguous bytes),
+// applies the pending GroupNorm affine + LeakyReLU, splits to hi / lo fp16 and feeds the MFMAs; the two lane halves and the
+// channel chunks of one wave read each 128-byte line completely, back to back.  The generic fp32 kernel staged these layers
+// 8-16 channels per pass with 512 workgroups in flight and fetched the 64^3 x 32 input 2.7x from HBM (PMC FETCH_SIZE).
+// The kernel is bound by that one read of the input; weights (8 taps, a few KB per chunk) come from L2.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
+    __shared__ float red[4 * NT * 32 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nblk = p.nbz * p.nby * p.nbx;
+    const int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
+    const int bxi = br % p.nbx, byi = (br / p.nbx) % p.nby, bzi = br / (p.nbx * p.nby);
+    const int oz0 = bzi << 2, oy0 = byi << 3, ox0 = bxi << 3;
+    const int co_base = blockIdx.y * (NT * 32);
+    const int C16 = p.Cin >> 4;
+    const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+    const size_t plane = (size_t)p.Co_pad;
+    const int lane_off = h * (int)plane + l31;
+    // rows: tile mt = the 8(x) x 4(z) slab of brick row y = 2 wave + mt (the layout epilogue_xz stores)
+    const int c = l31 >> 2;
+    const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
+    const float* src[2];
+    bool ok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int y = 2 * wave + mt;
+        ok[mt] = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
+        src[mt] = p.in + ((((size_t)n * p.ID + 2 * (oz0 + z)) * p.IH + 2 * (oy0 + y)) * p.IW + 2 * (ox0 + x)) * p.Cin + 8 * h;
+    }
+    f32x16 acc[2][NT], accl[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accl[mt][nt][r] = 0.f; }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < C16; ++cb) {
+        f32x4 sca = zero4, scb = zero4, sha = zero4, shb = zero4;
+        if (p.in_scale) {
+            const float* ps = p.in_scale + (size_t)n * p.Cin + cb * 16 + 8 * h; const float* ph = p.in_shift + (size_t)n * p.Cin + cb * 16 + 8 * h;
+            sca = *reinterpret_cast<const f32x4*>(ps); scb = *reinterpret_cast<const f32x4*>(ps + 4);
+            sha = *reinterpret_cast<const f32x4*>(ph); shb = *reinterpret_cast<const f32x4*>(ph + 4);
+        }
+        const half8* wq = w8 + (size_t)cb * 4 * plane + co_base;
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) {
+            const size_t toff = ((size_t)((tap >> 2) * p.IH + ((tap >> 1) & 1)) * p.IW + (tap & 1)) * p.Cin + cb * 16;
+            f32x4 ra[2], rb[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                ra[mt] = ok[mt] ? *reinterpret_cast<const f32x4*>(src[mt] + toff) : zero4;
+                rb[mt] = ok[mt] ? *reinterpret_cast<const f32x4*>(src[mt] + toff + 4) : zero4;
+            }
+            const half8* wt = wq + (size_t)tap * C16 * 4 * plane;
+            half8 bh[NT], bl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bh[nt] = wt[lane_off + nt * 32]; bl[nt] = (wt + 2 * plane)[lane_off + nt * 32]; }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                half8 ah, al;
+                split8(apply_act(p, ra[mt], sca, sha), apply_act(p, rb[mt], scb, shb), ah, al);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+                    accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], accl[mt][nt], 0, 0, 0);
+                    accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], accl[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    EpiArgs e;
+    e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
+    e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3; e.xz_tiles = 1;
+    epilogue_xz<2, NT>(e, red, acc, accl, n, br, nblk, oz0, oy0, ox0, co_base);
+}
+
 // 16-byte global load the compiler's wait-count tracking does not see.  hipcc waits vmcnt(0) at the first use of an
 // ordinary load result whenever an LDS-DMA is in flight, which would drain the weight pipeline of conv_f16p at the first
 // staging piece; the kernel instead waits explicitly (its group-end vmcnt(0)) before the results are used.
@@ -1526,6 +1606,19 @@ int launch_f16s(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t 
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
 }
 
+template <int NT>
+int launch_pool_f16s(const ConvParams& p, dim3 grid, hipStream_t s) {
+    ProfRec rec;
+    if (g_prof_on) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 8;
+        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 8.0;
+        (void)hipEventRecord(rec.a, s);
+    }
+    hipLaunchKernelGGL((conv_pool_f16s_kernel<NT>), grid, dim3(256), 0, s, p);
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    return nm_check_hip(hipGetLastError(), "conv_pool_f16s launch");
+}
+
 int g_num_cus = 0;
 
 template <bool UP2>
@@ -1559,6 +1652,7 @@ int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStr
 #ifdef NM_DIAG
 unsigned long long* g_stamps = nullptr;
 #endif
+int g_pool16 = [] { const char* e = getenv("NM355_POOL16"); return e ? atoi(e) : 1; }();   // 0: pool convs on the fp32 kernel (diagnostic)
 // conv_f16p use: 0 never (conv_f16s everywhere), 1 every eligible layer, 2 (default) only Cout == 32 layers - with more cout
 // groups per brick it re-stages the input per group and measures a little slower than conv_f16s (A/B in one gpurun call)
 int g_f16p = [] { const char* e = getenv("NM355_F16P"); return e ? atoi(e) : 2; }();
@@ -1655,6 +1749,11 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
 #endif
     p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp; p.ZP = t.HY * t.HX;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
+    if (g_conv_mode == 1 && g_pool16 && w_packed16 && in.C % 16 == 0 && g.ks == 2 && g.stride == 2 && g.pad == 0 && !g.up2 &&
+        t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2) {
+        p.w = static_cast<const float*>(w_packed16);
+        return t.NT == 2 ? launch_pool_f16s<2>(p, grid, s) : launch_pool_f16s<1>(p, grid, s);
+    }
     if (g_conv_mode == 1 && g_f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
         g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0 && (g_f16p == 1 || g_f16p_all || g.Cout == 32)) {
         const int work = in.N * (g.OD / 4) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 32);
