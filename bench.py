@@ -154,8 +154,7 @@ def main():
             traffic = None
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if pm.get("kernel") == name:
-                    traffic = pm["traffic_bytes_per_launch"]
+                traffic = pm["traffic_bytes_per_launch"].get(name)
             except Exception:
                 pass
             split = name.startswith("conv_f16") or name.startswith("conv_pool_f16")
