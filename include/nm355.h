@@ -110,6 +110,17 @@ int nm_get_affinity(nm_ctx* ctx, float* affinity);
 int nm_voxelize_clip(nm_ctx* ctx, const double* points, int32_t T, int64_t N, double scale, float* vox,
                      int32_t* idx_out);
 
+/* Evaluation metrics (utils/eval_utils.py).
+ * nm_eval_voxel_chamfer — voxel_chamfer_distance :29-55 for every frame of a batch: gt_vox, recon (B,T,1,G,G,G) fp32 on the
+ *   device (gt occupied = non-zero, recon occupied = value >= 0.5; neither is modified), per_frame (B*T) fp64 out =
+ *   mean_gt min_rec d^2 + mean_rec min_gt d^2 in the reference's [-1,1] coordinates (NaN when a set is empty).  Exact:
+ *   integer Euclidean distance transforms instead of the (N,M) distance matrix.
+ * nm_eval_semantic — the nearest-keypoint votes of semantic_scores :59-90: keypoints (BT,K,4), gt_keypoints (BT,Kg,3);
+ *   closest (BT,Kg) int32 out, counts (Kg,K) int64 ACCUMULATED (caller zeroes it for a new epoch). */
+int nm_eval_voxel_chamfer(nm_ctx* ctx, const float* gt_vox, const float* recon, int32_t B, int32_t T, int32_t G, double* per_frame);
+int nm_eval_semantic(nm_ctx* ctx, const float* keypoints, const float* gt_keypoints, int32_t BT, int32_t K, int32_t Kg,
+                     int32_t* closest, int64_t* counts);
+
 /* Skeleton handed to the VRNN entry points (result of process_affinity_glob,
  * utils/dyna_utils.py:6-171, computed on the host by neural_marionette_amd.skeleton):
  *  parents (K) int32, parents[root] == root;  order (K) int32 = priority.indices */

@@ -50,6 +50,8 @@ SIGNATURES = {
     "nm_decode_from_keypoints": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _P]),
     "nm_get_affinity": (C.c_int, [C.c_void_p, _P]),
     "nm_voxelize_clip": (C.c_int, [C.c_void_p, _P, _I, C.c_int64, C.c_double, _P, _P]),
+    "nm_eval_voxel_chamfer": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P]),
+    "nm_eval_semantic": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P]),
     "nm_vrnn_set_tree": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "nm_vrnn_offsets": (C.c_int, [C.c_void_p, _P, _I, _I, _P]),
     "nm_vrnn_encode": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

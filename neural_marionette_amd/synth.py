@@ -168,3 +168,15 @@ def make_eps(shape, seed: int) -> torch.Tensor:
     eps explicitly; CPU and GPU generator streams differ, SURVEY §7 'RNG')."""
     rng = np.random.default_rng(np.random.SeedSequence([seed, 0xE95]))
     return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+
+def eval_inputs(seed=7, B=2, T=3, G=32, K=24, Kg=17):
+    """Seeded inputs of the evaluation metrics (fixture g7 holds the reference's outputs on them)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vox = figure_clip(B, T, G, seed=seed)                                                # (B,T,1,G,G,G)
+    noise = torch.from_numpy(rng.random(vox.shape, dtype=np.float32))
+    recon = (0.75 * torch.roll(vox, shifts=(1, -1), dims=(-1, -2)) + 0.35 * noise).clamp(0, 1)   # a shifted, noisy volume
+    kp = torch.from_numpy(rng.uniform(-1, 1, size=(B, T, K, 4)).astype(np.float32))
+    kp[..., 3] = torch.from_numpy(rng.uniform(0, 1, size=(B, T, K)).astype(np.float32))          # intensities, some < 0.2
+    gt = torch.from_numpy(rng.uniform(-1, 1, size=(B, T, Kg, 3)).astype(np.float32))
+    return vox, recon, kp, gt

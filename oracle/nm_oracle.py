@@ -745,3 +745,44 @@ def sample_interpolation(sd: SD, opts, target_voxel: Tensor, sample_rate: int, s
     sel[0, :, :, -1] = sel[0, 0, :, -1]                                   # :133
     vox = decode_from_keypoints(sd, opts, sel, det["first_feature"], target_voxel[None, 0])[0]
     return dict(keypoints=sel, voxels=(vox >= 0.5).float(), voxels_raw=vox, picks=picks)
+
+
+# ---- evaluation metrics --------------------------------------------------------------------
+def voxel_chamfer_distance(gt_voxel, recon):
+    """utils/eval_utils.py:29-55 without the in-place thresholding: per-frame chamfer distances (B, T) float64.
+    gt_voxel, recon (B,T,1,G,G,G); occupied = non-zero / recon >= 0.5; coordinates idx / ((G-1)/2) - 1 in fp32."""
+    B, T, _, *X = gt_voxel.shape
+    gt = gt_voxel.squeeze(2)
+    rec = (recon.squeeze(2) >= 0.5).float()
+    out = torch.zeros(B, T, dtype=torch.float64)
+    for b in range(B):
+        for t in range(T):
+            a = torch.stack(torch.where(gt[b, t]), dim=-1) / ((X[0] - 1) / 2) - 1          # (N, 3)   :42
+            c = torch.stack(torch.where(rec[b, t]), dim=-1) / ((X[0] - 1) / 2) - 1         # (M, 3)   :43
+            d = (a[:, None] - c[None]).pow(2).sum(dim=-1)                                  # :44
+            out[b, t] = (d.min(dim=-1).values.mean() + d.min(dim=0).values.mean()).item()  # :45
+    return out
+
+
+def semantic_votes(keypoints, gt_keypoints):
+    """utils/eval_utils.py:59-84 up to the vote matrix: closest (B*T, K') int64 and this batch's counts (K', K) int64.
+    keypoints (B,T,K,4) (not modified), gt_keypoints (B,T,K',3)."""
+    kypt = keypoints.clone()
+    inval = torch.where(kypt[..., -1] < 0.2)                                               # :66
+    kypt[inval] = torch.tensor([1e4, 1e4, 1e4, 1.0])
+    det = kypt[:, :, None, :, :-1]                                                         # (B,T,1,K,3)
+    B, T, Kg, _ = gt_keypoints.shape
+    K = kypt.shape[2]
+    d = (gt_keypoints[:, :, :, None] - det).pow(2).sum(-1)                                 # (B,T,K',K)  :77
+    closest = d.min(dim=-1).indices.view(B * T, -1)                                        # :78
+    counts = torch.zeros(Kg, K, dtype=torch.int64)
+    for kd in range(Kg):
+        counts[kd] = torch.bincount(closest[:, kd], minlength=K)
+    return closest, counts
+
+
+def semantic_log(counts):
+    """scores_log of semantic_scores (:80-84): mean over k' of the largest vote share, float32."""
+    c = counts.to(torch.float64).numpy()
+    import numpy as _np
+    return _np.array([(row / row.sum()).max() for row in c], dtype=_np.float32).mean()

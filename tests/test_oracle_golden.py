@@ -143,3 +143,16 @@ def test_g6_learner_gradients(golden_dir):
         assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
         checked += 1
     assert checked == 21
+
+
+def test_g7_eval_metrics(golden_dir):
+    """oracle restatement of utils/eval_utils.py vs the reference's outputs on the seeded inputs"""
+    g = np.load(os.path.join(golden_dir, "g7_eval_metrics.npz"))
+    vox, recon, kp, gt = synth.eval_inputs(int(g["seed"]), int(g["B"]), int(g["T"]), int(g["G"]), int(g["K"]), int(g["Kg"]))
+    assert abs(recon.double().sum().item() - float(g["recon_checksum"])) < 1e-6
+    pf = O.voxel_chamfer_distance(vox, recon)
+    np.testing.assert_allclose(pf.mean(dim=1).numpy(), g["chamfer_scores"][:, 0], rtol=1e-12)
+    np.testing.assert_allclose(pf.mean().item(), float(g["chamfer_log"]), rtol=1e-12)
+    closest, counts = O.semantic_votes(kp, gt)
+    assert np.array_equal(counts.numpy(), g["semantic_scores"])
+    assert O.semantic_log(counts) == g["semantic_log"]

@@ -241,7 +241,20 @@ def case_g6():
     print("g6 ok", float(loss), sorted(k for k in out if k.startswith("g:"))[:3])
 
 
-CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6)
+def case_g7():
+    """utils/eval_utils.py on seeded inputs: voxel_chamfer_distance and semantic_scores of the reference."""
+    from utils import eval_utils as ref_eval
+    vox, recon, kp, gt = synth.eval_inputs()
+    ch = ref_eval.voxel_chamfer_distance(None, dict(voxel=vox.clone(), recon=recon.clone()))
+    se = ref_eval.semantic_scores(None, dict(keypoints=kp.clone(), gt_keypoints=gt.clone()))
+    np.savez_compressed(os.path.join(OUT, "g7_eval_metrics.npz"), seed=7, B=2, T=3, G=32, K=24, Kg=17,
+                        recon_checksum=np.float64(recon.double().sum().item()),
+                        chamfer_scores=np.array(ch["scores"], dtype=np.float64), chamfer_log=np.float64(ch["scores_log"]),
+                        semantic_scores=np.array(se["scores"], dtype=np.int64), semantic_log=np.float32(se["scores_log"]))
+    print("g7 ok", ch["scores_log"], se["scores_log"])
+
+
+CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6, g7=case_g7)
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
