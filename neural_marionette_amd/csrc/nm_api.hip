@@ -193,11 +193,11 @@ int nm_op_conv5_occ(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, const f
     const int Co_pad = (Cout + 31) & ~31;
     const size_t G3 = (size_t)G * G * G;
     const int nblk = nm_occ_blocks_per_frame(G);
-    const size_t fl = nm_packed_weight_floats(5, 8, Co_pad) + (size_t)128 * Co_pad + (size_t)Cout * 125 + G3 * (9 + Cout) + (size_t)N * nblk * Cout * 2;
+    const size_t fl = nm_packed_weight_floats(5, 8, Co_pad) + (size_t)256 * Co_pad + (size_t)Cout * 125 + G3 * (9 + Cout) + (size_t)N * nblk * Cout * 2;
     int rc = nm_ctx_reserve(ctx, fl * sizeof(float) + 16384);
     if (rc) return rc;
     ctx->ws.release(0);
-    float* wfull = ctx->ws.f(nm_packed_weight_floats(5, 8, Co_pad)); float* wocc = ctx->ws.f((size_t)128 * Co_pad);
+    float* wfull = ctx->ws.f(nm_packed_weight_floats(5, 8, Co_pad)); float* wocc = ctx->ws.f((size_t)256 * Co_pad);
     float* tmp = ctx->ws.f((size_t)Cout * 125); float* zero = ctx->ws.f(G3); float* packed_in = ctx->ws.f(G3 * 8);
     float* field = ctx->ws.f(G3 * Cout); float* part = ctx->ws.f((size_t)N * nblk * Cout * 2);
     hipStream_t s = ctx->stream;

@@ -348,6 +348,170 @@ __global__ void extract_occ_weight_kernel(const float* __restrict__ w, int Cout,
     if (i < Cout * 125) out[i] = w[(size_t)(i / 125) * 4 * 125 + i % 125];
 }
 
+// x + the values of the other lanes of its 32-lane half: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror, then
+// row_bcast15 into rows 1 and 3, whose lanes end up holding the totals of lanes 0-31 / 32-63
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWS, 0xf, true));
+}
+__device__ __forceinline__ float dpp_sum32(float x) {
+    x = dpp_add<0xB1, 0xf>(x); x = dpp_add<0x4E, 0xf>(x); x = dpp_add<0x141, 0xf>(x); x = dpp_add<0x140, 0xf>(x);
+    return dpp_add<0x142, 0xa>(x);
+}
+
+// The same layer on the fp16 matrix cores.  Voxel occupancy is 0/1 in the reference's data, exact in fp16, so the product
+// needs only occ * w_hi + occ * w_lo / 2^11: two f16 MFMAs at 16x the fp32-MFMA rate (the fp32 kernel above is bound by its
+// 128 fp32 MFMAs per wave).  A volume with other values takes a third MFMA with the lo part of the input (decided per
+// workgroup while staging), so the result is fp32-equivalent for any input.  K = taps: k-step ks, lane half h, element j
+// is tap 16 ks + 8 h + j (taps >= 125 carry zero weights).
+typedef _Float16 occ_half8 __attribute__((ext_vector_type(8)));
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
+    __shared__ _Float16 tile_h[8 * 12 * 12], tile_l[8 * 12 * 12];
+    __shared__ float red[512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nb = p.G >> 3, nbz = p.G >> 2;
+    const int nblk = nbz * nb * nb;
+    const int n = blockIdx.x % p.N, br = blockIdx.x / p.N;          // frame index fastest (see conv_k5occ_kernel)
+    const int oz0 = (br / (nb * nb)) << 2, oy0 = ((br / nb) % nb) << 3, ox0 = (br % nb) << 3;
+    const int co_base = blockIdx.y * (NT * 32);
+    const float* src = p.occ + (size_t)n * p.G * p.G * p.G;
+    int inexact = 0;
+    for (int i = tid; i < 8 * 12 * 12; i += 256) {
+        int hx = i % 12, hy = (i / 12) % 12, hz = i / 144;
+        int gz = oz0 - 2 + hz, gy = oy0 - 2 + hy, gx = ox0 - 2 + hx;
+        float v = 0.f;
+        if ((unsigned)gz < (unsigned)p.G && (unsigned)gy < (unsigned)p.G && (unsigned)gx < (unsigned)p.G)
+            v = src[((size_t)gz * p.G + gy) * p.G + gx];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * NM_SPLIT_SCALE);
+        tile_h[i] = hi; tile_l[i] = lo;
+        inexact |= (lo != (_Float16)0.f);
+    }
+    const bool need_lo = __syncthreads_or(inexact) != 0;            // (also the barrier after staging)
+    int arow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int m = (wave * 2 + mt) * 32 + l31;
+        arow[mt] = ((m >> 6) * 12 + ((m >> 3) & 7)) * 12 + (m & 7);
+    }
+    f32x16 acc[2][NT], accl[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accl[mt][nt][r] = 0.f; }
+    const occ_half8* __restrict__ wq = reinterpret_cast<const occ_half8*>(p.w + (size_t)128 * p.Co_pad) + (size_t)h * p.Co_pad + co_base + l31;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        occ_half8 bh[NT], bl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bh[nt] = wq[(size_t)(4 * ks) * p.Co_pad + nt * 32];
+            bl[nt] = wq[(size_t)(4 * ks + 2) * p.Co_pad + nt * 32];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            occ_half8 ah, al;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int off = h ? occ_tap_off(16 * ks + 8 + j) : occ_tap_off(16 * ks + j);
+                ah[j] = tile_h[arow[mt] + off];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah, acc[mt][nt], 0, 0, 0);
+                accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah, accl[mt][nt], 0, 0, 0);
+            }
+            if (need_lo) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int off = h ? occ_tap_off(16 * ks + 8 + j) : occ_tap_off(16 * ks + j);
+                    al[j] = tile_l[arow[mt] + off];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al, accl[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    // Epilogue on transposed accumulators (the MFMAs above take the weights first): a lane holds one voxel and, per N tile,
+    // the channels (r & 3) + 8 (r >> 2) + 4 h in its 16 registers - 16-byte field loads and stores.  With one channel per lane
+    // this layer spends its time issuing 64 dword loads / stores per lane (the fp32 and the f16 MFMA variant took the same
+    // 1.58 ms); GroupNorm partials by DPP row reductions (rows 1 and 3 of the wave end up with the totals).
+    const bool chan_ok = (p.Cout & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float s1[16], s2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = (wave * 2 + mt) * 32 + l31;
+            const int oz = oz0 + (m >> 6), oy = oy0 + ((m >> 3) & 7), ox = ox0 + (m & 7);
+            const size_t vo = (((size_t)oz * p.G + oy) * p.G + ox) * p.Cout;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int co = co_base + nt * 32 + 8 * k4 + 4 * h;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * k4 + e] + accl[mt][nt][4 * k4 + e] * (1.0f / NM_SPLIT_SCALE);
+                if (chan_ok && co + 4 <= p.Cout) {
+                    v += *reinterpret_cast<const f32x4*>(p.field + vo + co);
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)n * p.G * p.G * p.G * p.Cout + vo + co) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e < p.Cout) { v[e] += p.field[vo + co + e]; p.out[(size_t)n * p.G * p.G * p.G * p.Cout + vo + co + e] = v[e]; }
+                        else v[e] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[4 * k4 + e] += v[e]; s2[4 * k4 + e] += v[e] * v[e]; }
+            }
+        }
+        if (p.part) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = s1[r], b = s2[r];
+                a = dpp_sum32(a); b = dpp_sum32(b);
+                if (l31 == 16) {
+                    const int c = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    red[(wave * NT * 32 + c) * 2] = a; red[(wave * NT * 32 + c) * 2 + 1] = b;
+                }
+            }
+        }
+    }
+    if (p.part) {
+        __syncthreads();
+        if (tid < NT * 32) {
+            const int co = co_base + tid;
+            if (co < p.Cout) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { a += red[(wv * NT * 32 + tid) * 2]; b += red[(wv * NT * 32 + tid) * 2 + 1]; }
+                float* dst = p.part + (((size_t)n * nblk + br) * p.Cout + co) * 2;
+                dst[0] = a; dst[1] = b;
+            }
+        }
+    }
+}
+
+// (Cout, 125) occupancy-tap matrix -> split fp16 [k-step 8][hi h0 | hi h1 | lo h0 | lo h1][Co_pad][8]
+__global__ void pack_occ_weight16_kernel(const float* __restrict__ m, int Cout, int Co_pad, _Float16* __restrict__ packed) {
+    const int total = 8 * 2 * Co_pad * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 7, co = (i >> 3) % Co_pad, hh = ((i >> 3) / Co_pad) & 1, ks = (i >> 3) / (2 * Co_pad);
+        const int t = 16 * ks + 8 * hh + j;
+        const float v = (co < Cout && t < 125) ? m[(size_t)co * 125 + t] : 0.f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * NM_SPLIT_SCALE);
+        packed[(((size_t)ks * 4 + hh) * Co_pad + co) * 8 + j] = hi;
+        packed[(((size_t)ks * 4 + 2 + hh) * Co_pad + co) * 8 + j] = lo;
+    }
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     extern __shared__ f32x4 lds[];
@@ -1652,6 +1816,7 @@ int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStr
 #ifdef NM_DIAG
 unsigned long long* g_stamps = nullptr;
 #endif
+int g_occ16 = [] { const char* e = getenv("NM355_OCC16"); return e ? atoi(e) : 1; }();     // 0: first layer on the fp32 MFMA kernel (diagnostic)
 int g_pool16 = [] { const char* e = getenv("NM355_POOL16"); return e ? atoi(e) : 1; }();   // 0: pool convs on the fp32 kernel (diagnostic)
 // conv_f16p use: 0 never (conv_f16s everywhere), 1 every eligible layer, 2 (default) only Cout == 32 layers - with more cout
 // groups per brick it re-stages the input per group and measures a little slower than conv_f16s (A/B in one gpurun call)
@@ -1788,12 +1953,17 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
 
 int nm_occ_blocks_per_frame(int G) { return (G / 8) * (G / 8) * (G / 4); }
 
-// packs the occupancy-channel taps of a (Cout,4,5,5,5) weight into [32 tap-quads][Co_pad][4]; tmp: Cout*125 floats
+// packs the occupancy-channel taps of a (Cout,4,5,5,5) weight into [32 tap-quads][Co_pad][4] fp32 followed by the split-fp16
+// form (packed: 256 * Co_pad floats); tmp: Cout*125 floats
 int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s) {
     hipLaunchKernelGGL(extract_occ_weight_kernel, dim3((Cout * 125 + 255) / 256), dim3(256), 0, s, w_oidhw, Cout, tmp);
     int rc = nm_check_hip(hipGetLastError(), "extract_occ_weight launch");
     if (rc) return rc;
-    return nm_launch_pack_conv_weight(tmp, Cout, 125, 1, packed, 128, Co_pad, s);
+    rc = nm_launch_pack_conv_weight(tmp, Cout, 125, 1, packed, 128, Co_pad, s);
+    if (rc) return rc;
+    // second half of the buffer (another 128 * Co_pad floats): the split-fp16 form for conv_k5occ_f16_kernel
+    hipLaunchKernelGGL(pack_occ_weight16_kernel, dim3(64), dim3(256), 0, s, tmp, Cout, Co_pad, reinterpret_cast<_Float16*>(packed + (size_t)128 * Co_pad));
+    return nm_check_hip(hipGetLastError(), "pack_occ_weight16 launch");
 }
 
 int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
@@ -1808,7 +1978,10 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
         rec.flops = 2.0 * N * (double)G * G * G * Cout * 4.0 * 125.0;   // the reference's dense k5 layer over 4 input channels
         (void)hipEventRecord(rec.a, s);
     }
-    if (NT == 2) hipLaunchKernelGGL((conv_k5occ_kernel<2>), grid, dim3(256), 0, s, p);
+    if (g_conv_mode == 1 && g_occ16) {
+        if (NT == 2) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1>), grid, dim3(256), 0, s, p);
+    } else if (NT == 2) hipLaunchKernelGGL((conv_k5occ_kernel<2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_k5occ_kernel<1>), grid, dim3(256), 0, s, p);
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_k5occ launch");

@@ -40,7 +40,7 @@ struct UpW { int Cin = 0, Cout = 0; float* w = nullptr; float* bias = nullptr; N
 struct HourglassW { PoolW p1, p2, p3; ResW e1, e2, e3, d3, d2, d1, s1, s2, s3; UpW u3, u2, u1; };
 struct FeatNetW {
     ConvW c0; NormW n0; PoolW p1, p3; ResW r2, r5; HourglassW hg;
-    float* occ_w = nullptr;    // occupancy-channel taps of c0, packed [32 tap-quads][Co_pad][4]
+    float* occ_w = nullptr;    // occupancy-channel taps of c0: fp32 [32 tap-quads][Co_pad][4], then split fp16 [8 k-steps][4][Co_pad][8]
     float* field = nullptr;    // conv5(cat[0, coords]) + bias for one frame: [G^3][Cout]
 };
 struct LinearW { int in = 0, out = 0; float* w = nullptr; float* b = nullptr; };

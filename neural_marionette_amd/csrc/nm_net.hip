@@ -115,7 +115,7 @@ struct Loader {
         const size_t G3 = (size_t)G * G * G;
         const float* src = get(p + ".weight", (int64_t)Cout * 4 * 125);
         if (!src || !f.c0.wp) return;
-        f.occ_w = nm_ctx_weight_alloc(c, (size_t)128 * f.c0.Co_pad);
+        f.occ_w = nm_ctx_weight_alloc(c, (size_t)256 * f.c0.Co_pad);          // fp32 pack + split-fp16 pack
         f.field = nm_ctx_weight_alloc(c, G3 * Cout);
         float* tmp = nm_ctx_weight_alloc(c, (size_t)Cout * 125 + G3 * 9);      // freed with the other weights at the next update
         if (!f.occ_w || !f.field || !tmp) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return; }

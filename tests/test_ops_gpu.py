@@ -157,10 +157,13 @@ def test_conv3d_fused_upsample(ctx, Cin, Cout, size, prologue, mode):
 
 
 @pytest.mark.parametrize("G,Cout,N", [(16, 32, 3), (24, 64, 2), (32, 32, 1)])
-def test_conv5_occupancy_first_layer(ctx, G, Cout, N):
-    """Basic3DBlock(1+3 -> Cout, k5) on cat[occ, coords] as conv(occ) + constant field (kypt_detector.py:265)."""
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "split16"])
+def test_conv5_occupancy_first_layer(ctx, G, Cout, N, mode):
+    """Basic3DBlock(1+3 -> Cout, k5) on cat[occ, coords] as conv(occ) + constant field (kypt_detector.py:265).
+    split16: two f16 MFMAs per product for 0/1 volumes, a third (lo part of the input) for fractional occupancy."""
     from neural_marionette_amd import _lib
     from oracle import nm_oracle as O
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, mode), "set_conv_mode")
     g = torch.Generator().manual_seed(G + Cout)
     occ = (torch.rand(N, 1, G, G, G, generator=g) < 0.05).float()
     if N > 1:
