@@ -44,6 +44,7 @@ struct ConvParams {
     int HZ, HY, HX, HV, HVp;      // halo dims, voxels, padded plane stride (HVp % 8 == 2)
     int CVp;                      // up2: plane stride of the coarse LDS tile
     int ZP;                       // f16s: pitch between halo z-planes in LDS (>= HY*HX, = 4 mod 16)
+    const void* w16;              // conv_mfma_kernel<1,NT>: split-fp16 weights (null: fp32 MFMA core)
     int st_z, st_y, st_x;         // f16s / f16p: XCD super-tile in bricks (0: bricks in linear order), see super_tile_item()
 #ifdef NM_DIAG
     unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
@@ -99,6 +100,54 @@ __device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1
     i0 = (int)src;
     i1 = i0 + (i0 < I - 1 ? 1 : 0);
     l1 = src - (float)i0;
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// v = hi + lo * 2^-11 with hi = rne_f16(v), lo = rne_f16((v - hi) * 2^11).  v - hi is exact in fp32, so the lo part is
+// one v_fma_mix{lo,hi}_f16 of (hi, -2^11, v * 2^11): 2.5 VALU per value, none of them packed fp32 math.
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v0 = (j < 2) ? a[2 * j] : b[2 * j - 4], v1 = (j < 2) ? a[2 * j + 1] : b[2 * j - 3];
+        half2v hh = __builtin_convertvector(f32x2{v0, v1}, half2v);        // v_cvt_pk_f16_f32
+        asm volatile("" : "+v"(hh));                                         // keep the packed pair (no per-half re-conversion)
+        const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
+        hi[2 * j] = hh[0]; hi[2 * j + 1] = hh[1];
+        lo[2 * j] = (_Float16)__builtin_fmaf((float)hh[0], -NM_SPLIT_SCALE, t0);
+        lo[2 * j + 1] = (_Float16)__builtin_fmaf((float)hh[1], -NM_SPLIT_SCALE, t1);
+    }
+}
+
+// The same walk on the fp16 matrix cores for the small-volume layers (conv_mfma_kernel<1,NT> with Cin % 16 == 0): with 64 or
+// fewer voxels per frame a launch is one short wave of workgroups, each a serial chain of K/2 fp32 MFMAs of 64 cycles; the
+// split product (3 MFMAs of 32 cycles per 16 channels) cuts the chain ~4x.  The fp32 tile in LDS is split per tap (2 LDS
+// reads + 20 VALU per 3 NT MFMAs: the chain, not the throughput, is what these launches wait for).
+template <int NT>
+__device__ __forceinline__ void mfma_chunk16(const ConvParams& p, const f32x4* lds, const half8* __restrict__ wq, size_t tap_stride,
+                                             int taps, int h, int arow, f32x16 (&acc)[1][NT], f32x16 (&accl)[NT]) {
+    const size_t plane = (size_t)p.Co_pad;
+    int tx = 0, ty = 0, tz = 0;
+    for (int tap = 0; tap < taps; ++tap) {
+        const half8* wt = wq + (size_t)tap * tap_stride;
+        half8 bh[NT], bl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bh[nt] = wt[nt * 32]; bl[nt] = wt[2 * plane + nt * 32]; }
+        const int tapoff = (tz * p.HY + ty) * p.HX + tx;
+        const f32x4 a = lds[(2 * h) * p.HVp + arow + tapoff], b = lds[(2 * h + 1) * p.HVp + arow + tapoff];
+        half8 hi, lo;
+        split8(a, b, hi, lo);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bh[nt], acc[0][nt], 0, 0, 0);
+            accl[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bl[nt], accl[nt], 0, 0, 0);
+            accl[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bh[nt], accl[nt], 0, 0, 0);
+        }
+        if (++tx == p.ks) { tx = 0; if (++ty == p.ks) { ty = 0; ++tz; } }
+    }
 }
 
 // One LDS-resident channel chunk (NKQ octets of channels): walk the taps, B operand
@@ -536,12 +585,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     }
 
     f32x16 acc[MT][NT];
+    f32x16 accl[MT == 1 ? NT : 1];                                  // correction-term accumulators of the split-fp16 core (MT == 1 only)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < (MT == 1 ? NT : 1); ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accl[nt][r] = 0.f;
 
     const int Q = p.Cin >> 2;
     const int taps = p.ks * p.ks * p.ks;
@@ -609,6 +663,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         __syncthreads();
 
         // ---- MFMA over taps x channel octets -------------------------------------------
+        if constexpr (MT == 1) {
+            if (p.w16) {                                            // split-fp16 core (Cin % 16 == 0: every chunk is 16 wide)
+                const half8* w8 = reinterpret_cast<const half8*>(p.w16);
+                const size_t ts16 = (size_t)(p.Cin >> 4) * 4 * p.Co_pad;
+                for (int s0 = 0; s0 < kc; s0 += 16)
+                    mfma_chunk16<NT>(p, lds + (s0 >> 2) * p.HVp, w8 + ((size_t)((c0 + s0) >> 4) * 4 + h) * p.Co_pad + co_base + l31, ts16, taps, h,
+                                     arow[0], acc, accl);
+                continue;
+            }
+        }
         for (int s0 = 0; s0 < kc; s0 += 16) {
             const f32x4* wq = w4 + ((size_t)((c0 + s0) >> 2) + h) * p.Co_pad + co_base + l31;
             const f32x4* sub = lds + (s0 >> 2) * p.HVp;
@@ -617,6 +681,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         }
     }
 
+    if constexpr (MT == 1) {
+        if (p.w16) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][nt][r] += accl[nt][r] * (1.0f / NM_SPLIT_SCALE);
+        }
+    }
     EpiArgs e;
     e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
     e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = p.bz_l2; e.by_l2 = p.by_l2; e.bx_l2 = p.bx_l2; e.xz_tiles = 0;
@@ -654,26 +726,6 @@ int ceil_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // 3 MFMAs per k-step instead of 1, at 16x the rate.  Activations are split while they are staged into LDS (planes
 // [hi|lo][lane half][halo voxel] of 8 halves = 16 B), weights are split once per weight update
 // ([tap][Cin/16][hi|lo][lane half][Co_pad][8 halves]).  Requires Cin % 16 == 0; other layers use the fp32 kernel.
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// v = hi + lo * 2^-11 with hi = rne_f16(v), lo = rne_f16((v - hi) * 2^11).  v - hi is exact in fp32, so the lo part is
-// one v_fma_mix{lo,hi}_f16 of (hi, -2^11, v * 2^11): 2.5 VALU per value, none of them packed fp32 math.
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, half8& hi, half8& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float v0 = (j < 2) ? a[2 * j] : b[2 * j - 4], v1 = (j < 2) ? a[2 * j + 1] : b[2 * j - 3];
-        half2v hh = __builtin_convertvector(f32x2{v0, v1}, half2v);        // v_cvt_pk_f16_f32
-        asm volatile("" : "+v"(hh));                                         // keep the packed pair (no per-half re-conversion)
-        const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
-        hi[2 * j] = hh[0]; hi[2 * j + 1] = hh[1];
-        lo[2 * j] = (_Float16)__builtin_fmaf((float)hh[0], -NM_SPLIT_SCALE, t0);
-        lo[2 * j + 1] = (_Float16)__builtin_fmaf((float)hh[1], -NM_SPLIT_SCALE, t1);
-    }
-}
-
 // Which brick a persistent workgroup processes in its iteration tau.  The eight XCDs have separate L2s and a brick's
 // 6x10x10 halo is 2.3x its 4x8x8 outputs, so in linear order (each workgroup a contiguous run of bricks, the 32 CUs of an
 // XCD far apart in the volume) the input is fetched from HBM about twice; conv 64^3 x 32 channels moved 8-10 GB per
@@ -1816,6 +1868,7 @@ int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStr
 #ifdef NM_DIAG
 unsigned long long* g_stamps = nullptr;
 #endif
+int g_small16 = [] { const char* e = getenv("NM355_SMALL16"); return e ? atoi(e) : 1; }();   // 0: small volumes on the fp32 MFMA core (diagnostic)
 int g_occ16 = [] { const char* e = getenv("NM355_OCC16"); return e ? atoi(e) : 1; }();     // 0: first layer on the fp32 MFMA kernel (diagnostic)
 int g_pool16 = [] { const char* e = getenv("NM355_POOL16"); return e ? atoi(e) : 1; }();   // 0: pool convs on the fp32 kernel (diagnostic)
 // conv_f16p use: 0 never (conv_f16s everywhere), 1 every eligible layer, 2 (default) only Cout == 32 layers - with more cout
@@ -1909,6 +1962,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.up2 = g.up2 ? 1 : 0;
     p.st_z = p.st_y = p.st_x = 0;
+    p.w16 = (g_conv_mode == 1 && g_small16 && w_packed16 && in.C % 16 == 0 && !g.up2 && t.MT == 1) ? w_packed16 : nullptr;
 #ifdef NM_DIAG
     p.stamps = g_stamps;
 #endif
