@@ -1261,13 +1261,14 @@ template <int V> using ic = std::integral_constant<int, V>;
 // and the per-brick set-up of one workgroup overlap the other's MFMAs only by chance.  Here ONE workgroup owns the CU and
 // walks a flat stream of steps (4x8x8 brick, 32-channel cout group, 16-channel chunk), with two kinds of waves:
 //   * waves 0-3, one per SIMD, issue nothing but the step's 27 taps x 6 MFMAs, one LDS operand read per MFMA gap (three
-//     taps deep, exact lgkmcnt waits) and the previous brick's epilogue, cut into <= 4-instruction pieces pinned into the
-//     gaps (stores in taps 0-6, GroupNorm partial sums in taps 9-11); the accumulators never wait for anything else;
-//   * waves 4-7, the second wave of each SIMD, are producers: they fetch the raw input of step s+1 (16-byte pieces, four
-//     lanes per voxel), apply the pending GroupNorm affine + LeakyReLU, split to hi/lo fp16 and write the other halo
+//     taps deep, one exact lgkmcnt wait per tap) and the previous brick's epilogue, cut into <= 3-VALU pieces pinned into
+//     the gaps (eight 16-byte stores from transposed accumulators, then DPP partial sums for the GroupNorm); two copies of
+//     the stream, with / without epilogue pieces, instead of a branch per gap; the accumulators wait for nothing else;
+//   * waves 4-7, the second wave of each SIMD, are producers: they fetch the raw input two steps ahead (16-byte pieces,
+//     four lanes per voxel), apply the pending GroupNorm affine + LeakyReLU, split to hi/lo fp16 and write the other halo
 //     buffer - all before the second barrier of step s, so the MFMA waves read the first operands of step s+1 during the
 //     last two taps of step s - and stream the weights: 9-tap groups through LDS, three buffers (buffer g always holds tap
-//     group g), direct-to-LDS loads issued two groups ahead.
+//     group g), loaded through registers one group ahead of the barrier that publishes them.
 // Three barriers per step (tap-group ends).  Cout is processed 32 channels per step, the cout groups of a brick back to
 // back (its input stays in L2).
 //   LDS: halo [2 buffers][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [3][9 taps][4 planes][32] x 16 B, GroupNorm scratch.
