@@ -1694,6 +1694,328 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
     epi_part();
 }
 
+// ---- conv_f16p2: the producer / consumer kernel with 64 output channels per step -------------------------------------
+// Same machine mapping as conv_f16p (one persistent 512-thread workgroup per CU, MFMA waves 0-3 + producer waves 4-7, halo
+// tile double buffered, input two steps ahead), for the layers with Cout % 64 == 0.  A step is 27 taps x 12 MFMAs per wave:
+// the producers' work per step (one tile, 36 KB of weights per tap group) is the same as for 32 channels while the MFMA
+// waves have twice the time, so the producers stop being the bottleneck.  Differences forced by the budget:
+//   * registers: 128 accumulator registers leave no room for a deferred epilogue - the MFMA waves store a finished brick
+//     themselves (16-byte stores from transposed accumulators, DPP partial sums, one extra workgroup barrier per brick);
+//   * LDS: two weight buffers (2 x 36 KB) instead of three, so the B operands of a tap group's first tap are read after
+//     the barrier that publishes them; operands one tap (12 MFMAs) ahead, double buffered.
+//   LDS: halo [2][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [2][9 taps][4 planes][64] x 16 B, GroupNorm scratch, bias.
+template <bool UP2>
+__global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
+    constexpr int HV = 600, ZP = 100, HX = 10;
+    constexpr int GB = 9 * 4 * 64;                                  // half8 slots of one weight group
+    constexpr int NP = 10;                                          // 16-byte input pieces per producer thread and step (2400 / 256)
+    extern __shared__ f32x4 lds[];
+    half8* ldh = reinterpret_cast<half8*>(lds);                     // [2][4][HV]
+    half8* ldb = ldh + 8 * HV;                                      // [2][GB]
+    float* red = reinterpret_cast<float*>(ldb + 2 * GB);            // [4 waves][64 channels][2]
+    float* lbias = red + 512;                                       // [Cout] bias (zeros without one), written once by the producers
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int C16 = p.Cin >> 4;
+    const int ncg = p.Cout >> 6;
+    const int nbx = p.OW >> 3, nby = p.OH >> 3, nbz = p.OD >> 2, nbr = nbx * nby * nbz;
+    const int total = p.N * nbr * ncg;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int id_first = (int)blockIdx.x * per, id_last = min(total, id_first + per);
+    if (id_first >= id_last) return;
+
+    struct Work { int n, oz0, oy0, ox0, cg; };
+    const bool tiled = p.st_x != 0;                                 // XCD super-tile order (one cout group only), see super_tile_item
+    auto decode = [&](int id) {
+        Work w;
+        if (tiled) {
+            const BrickPos bp = super_tile_item(p, (int)blockIdx.x, id - id_first, per, nbz, nby, nbx);
+            w.cg = 0; w.n = bp.n; w.ox0 = bp.bx << 3; w.oy0 = bp.by << 3; w.oz0 = bp.bz << 2;
+            return w;
+        }
+        w.cg = id % ncg; const int bid = id / ncg;
+        w.n = bid / nbr; const int br = bid % nbr;
+        w.ox0 = (br % nbx) << 3; w.oy0 = ((br / nbx) % nby) << 3; w.oz0 = (br / (nbx * nby)) << 2;
+        return w;
+    };
+    auto next_work = [&](Work w, int id) {
+        if (tiled) return decode(id);
+        if (++w.cg == ncg) {
+            w.cg = 0;
+            if ((w.ox0 += 8) == p.OW) { w.ox0 = 0; if ((w.oy0 += 8) == p.OH) { w.oy0 = 0; if ((w.oz0 += 4) == p.OD) { w.oz0 = 0; ++w.n; } } }
+        }
+        return w;
+    };
+    struct Step { Work w; int id, cb; };
+    auto advance = [&](Step& st) {                                  // false (and st unchanged) on the block's last step
+        if (st.cb + 1 < C16) { ++st.cb; return true; }
+        if (st.id + 1 >= id_last) return false;
+        st.cb = 0; ++st.id; st.w = next_work(st.w, st.id);
+        return true;
+    };
+
+    if (wave >= 4) {
+        // =========================== producer waves ===========================================================
+        const int pt = tid - 256, pw = wave - 4;
+        const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+        const size_t plane = (size_t)p.Co_pad;
+        const int quad = pt & 3;
+        int pc_slot[NP], pc_rel[NP], pc_pos[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int v = (pt >> 2) + 64 * k, vc = min(v, HV - 1);
+            const int hz = vc / 100, r = vc % 100, hy = r / 10, hx = r % 10;
+            pc_slot[k] = (quad >> 1) * HV + hz * ZP + hy * HX + hx;
+            pc_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin + 4 * quad;
+            pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
+        }
+        f32x4 raw[NP], sc, sh, wreg[9];
+        const bool has_affine = p.in_scale != nullptr;
+        const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * 4u;   // halo voxel (1,1,1): always inside
+        auto inside_mask = [&](const Work& w) {
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int hz = pc_pos[k] & 0xff, hy = (pc_pos[k] >> 8) & 0xff, hx = pc_pos[k] >> 16;
+                const bool in = pc_pos[k] >= 0 && (unsigned)(w.oz0 - 1 + hz) < (unsigned)p.ID && (unsigned)(w.oy0 - 1 + hy) < (unsigned)p.IH &&
+                                (unsigned)(w.ox0 - 1 + hx) < (unsigned)p.IW;
+                m |= (in ? 1u : 0u) << k;
+            }
+            return m;
+        };
+        auto tile_base = [&](const Work& w, int cb) {
+            return p.in + ((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin + cb * 16;
+        };
+        auto load_piece = [&](const float* base, unsigned mask, auto K) {
+            constexpr int k = decltype(K)::value;
+            raw[k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * 4u : rel111);
+        };
+        auto load_affine = [&](const Work& w, int cb) {             // always two loads: the waits below count instructions
+            const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 : p.in;
+            const float* ph = has_affine ? p.in_shift + (size_t)w.n * p.Cin + cb * 16 : p.in;
+            sc = load16_untracked(ps, 16u * quad);
+            sh = load16_untracked(ph, 16u * quad);
+        };
+#define NM_PRODUCER2_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" \
+            : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]), \
+              "+v"(raw[8]), "+v"(raw[9]), "+v"(sc), "+v"(sh), "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]), "+v"(wreg[3]), "+v"(wreg[4]), \
+              "+v"(wreg[5]), "+v"(wreg[6]), "+v"(wreg[7]), "+v"(wreg[8]) :: "memory")
+        auto convert = [&](int buf, unsigned mask, auto K) {        // activate, split, write piece k into halo buffer buf
+            constexpr int k = decltype(K)::value;
+            half4v hi4, lo4;
+            const float keep = ((mask >> k) & 1) ? 1.f : 0.f;       // padding is zero AFTER the activation
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                float v0 = raw[k][e], v1 = raw[k][e + 1];
+                if (has_affine) { v0 = __builtin_fmaf(v0, sc[e], sh[e]); v1 = __builtin_fmaf(v1, sc[e + 1], sh[e + 1]); }
+                v0 = fmaxf(v0 * keep, (v0 * keep) * p.in_slope); v1 = fmaxf(v1 * keep, (v1 * keep) * p.in_slope);
+                half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
+                asm volatile("" : "+v"(hv));
+                const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
+                hi4[e] = hv[0]; hi4[e + 1] = hv[1];
+                lo4[e] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
+                lo4[e + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+            }
+            if (pc_pos[k] >= 0) {
+                half4v* dst = reinterpret_cast<half4v*>(ldh + buf * 4 * HV + pc_slot[k]) + (quad & 1);
+                dst[0] = hi4;
+                dst[4 * HV] = lo4;
+            }
+        };
+        // tap group g of (cout group cg, chunk cb): 36 one-KiB wave pieces (tap t, plane r, 64 channels), nine per producer wave
+        unsigned w_src[9], w_dst[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int j = pw + 4 * i, t = j >> 2, r = j & 3;
+            w_src[i] = (unsigned)(((size_t)t * C16 * 4 + r) * plane + lane) * 16u;
+            w_dst[i] = (unsigned)(t * 256 + r * 64 + lane) * 16u;
+        }
+        auto load_b_group = [&](int cg, int cb, int g) {
+            const float* base = reinterpret_cast<const float*>(w8 + ((size_t)(9 * g) * C16 * 4 + (size_t)cb * 4) * plane + cg * 64);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wreg[i] = load16_untracked(base, w_src[i]);
+        };
+        auto store_b_group = [&](int buf) {
+            char* lbase = reinterpret_cast<char*>(ldb + buf * GB);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(lbase + w_dst[i]) = wreg[i];
+        };
+
+        Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+        int hb = 0, gpar = 0;                                       // halo buffer of the step the MFMA waves run; weight buffer of its tap group
+        Step s1 = cur; bool has1 = advance(s1);
+        Step s2 = s1;  bool has2 = has1 && advance(s2);
+        unsigned m_cvt = inside_mask(cur.w), m_ld = m_cvt;
+        for (int c = pt; c < p.Cout; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
+        // prologue: first tile + first weight group in the open, loads of the second tile in flight
+        load_b_group(cur.w.cg, 0, 0);
+        load_affine(cur.w, 0);
+        { const float* b = tile_base(cur.w, 0); static_for<NP>([&](auto K) { load_piece(b, m_cvt, K); }); }
+        NM_PRODUCER2_WAIT(0);
+        store_b_group(0);
+        static_for<NP>([&](auto K) { convert(0, m_cvt, K); });
+        m_cvt = inside_mask(s1.w);
+        load_affine(s1.w, s1.cb);
+        { const float* b = tile_base(s1.w, s1.cb); static_for<NP>([&](auto K) { load_piece(b, m_cvt, K); }); }
+        lds_barrier();
+        for (;;) {
+            if (s2.w.n != s1.w.n || s2.w.oz0 != s1.w.oz0 || s2.w.oy0 != s1.w.oy0 || s2.w.ox0 != s1.w.ox0) m_ld = inside_mask(s2.w);
+            else m_ld = m_cvt;
+            const float* b2 = tile_base(s2.w, s2.cb);
+            // tap group 0: weights of this step's group 1 (into the buffer group 2 of the last step was read from); pieces 0-3.
+            // Everything older than the 9 weight loads has landed after the first wait.
+            load_b_group(cur.w.cg, cur.cb, 1);
+            NM_PRODUCER2_WAIT(9);
+            static_for<4>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
+            NM_PRODUCER2_WAIT(4);                                   // the weight loads (older than the 4 new piece loads)
+            store_b_group(gpar ^ 1);
+            lds_barrier(); gpar ^= 1;
+            // tap group 1: weights of this step's group 2; pieces 4-9; the halo tile is complete at this barrier
+            load_b_group(cur.w.cg, cur.cb, 2);
+            static_for<6>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 4>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 4>{}); });
+            load_affine(s2.w, s2.cb);
+            NM_PRODUCER2_WAIT(8);                                   // the weight loads: 6 piece + 2 affine loads are younger
+            store_b_group(gpar ^ 1);
+            lds_barrier(); gpar ^= 1;
+            // tap group 2: weights of the next step's group 0
+            load_b_group(s1.w.cg, s1.cb, 0);
+            NM_PRODUCER2_WAIT(0);
+            store_b_group(gpar ^ 1);
+            lds_barrier(); gpar ^= 1;
+            if (cur.cb == C16 - 1) lds_barrier();                   // the MFMA waves' epilogue barrier of a finished brick
+            if (!has1) break;
+            cur = s1; s1 = s2; has1 = has2; has2 = has2 && advance(s2);
+            m_cvt = m_ld; hb ^= 1;
+        }
+        NM_PRODUCER2_WAIT(0);                                       // loads still in flight for a step that does not exist
+        return;
+    }
+
+    // =============================== MFMA waves ===============================================================
+    __builtin_amdgcn_s_setprio(3);
+    int arow0;
+    {
+        const int c = l31 >> 2;
+        const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
+        arow0 = z * ZP + (2 * wave) * HX + x;
+    }
+    const int vx = ((((0x96 >> (l31 >> 2)) & 1) << 2) + (l31 & 3)), vz = l31 >> 3;
+    f32x16 acc[2][2], accl[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accl[mt][nt][r] = 0.f; }
+
+    Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+    int hb = 0, gpar = 0;
+    lds_barrier();                                                  // the producers' prologue
+
+    constexpr int LO = 2 * HV * 16;                                 // hi -> lo plane of a halo tile, bytes
+    constexpr int YO = HX * 16;                                     // brick row 2 wave -> 2 wave + 1
+    const unsigned vb0 = (unsigned)(size_t)(ldb + h * 64 + l31);    // weight buffer 0: plane h (hi), channel l31 of N tile 0
+    half8 ah0[2], al0[2], ah1[2], al1[2], bh0[2], bh1[2], bl0[2], bl1[2];      // operands, double buffered (index = tap & 1)
+    {
+        const unsigned va = (unsigned)(size_t)(ldh + h * HV + arow0);
+        ah0[0] = lds_read16_untracked<0>(va); al0[0] = lds_read16_untracked<LO>(va);
+        ah1[0] = lds_read16_untracked<YO>(va); al1[0] = lds_read16_untracked<LO + YO>(va);
+    }
+    for (;;) {
+        Step nxt = cur;
+        const bool has_next = advance(nxt);
+        const unsigned va = (unsigned)(size_t)(ldh + hb * 4 * HV + h * HV + arow0);          // this step's halo tile
+        const unsigned van = (unsigned)(size_t)(ldh + (hb ^ 1) * 4 * HV + h * HV + arow0);   // the next step's
+        const unsigned vbe = vb0 + (unsigned)(gpar * GB * 16), vbo = vb0 + (unsigned)((gpar ^ 1) * GB * 16);   // buffers of groups 0/2 and 1
+        static_for<27>([&](auto TT) {
+            constexpr int tt = decltype(TT)::value, g = tt / 9, t = tt % 9, i = tt & 1, j = i ^ 1;
+            const unsigned vb = (g & 1) ? vbo : vbe;
+            constexpr int BT = t * 256 * 16;                        // byte offset of this tap in its weight buffer
+            if constexpr (t == 0) {                                 // first tap of a group: its weights were published by the barrier
+                bh0[i] = lds_read16_untracked<BT>(vb); bh1[i] = lds_read16_untracked<BT + 32 * 16>(vb);
+                bl0[i] = lds_read16_untracked<BT + 128 * 16>(vb); bl1[i] = lds_read16_untracked<BT + 160 * 16>(vb);
+            }
+            // every operand of this tap has been requested (previous tap / just above): wait for all of them
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ah0[i]), "+v"(al0[i]), "+v"(ah1[i]), "+v"(al1[i]), "+v"(bh0[i]), "+v"(bh1[i]), "+v"(bl0[i]), "+v"(bl1[i]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int u = tt + 1, ug = (u < 27) ? u / 9 : 0, ut = (u < 27) ? u % 9 : 0;
+            constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;           // A byte offset of tap tt + 1 (tap 26: next step's tap 0)
+            const unsigned vau = (u < 27) ? va : van;
+            constexpr bool bnext = t < 8;                           // the next tap's weights are in this group's buffer
+            constexpr int BN = (t + 1) * 256 * 16;
+#define NM_MFMA2(ACC, B, A) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(B, A, ACC, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+            NM_MFMA2(acc[0][0], bh0[i], ah0[i]);  ah0[j] = lds_read16_untracked<AO>(vau);
+            NM_MFMA2(acc[0][1], bh1[i], ah0[i]);  al0[j] = lds_read16_untracked<AO + LO>(vau);
+            NM_MFMA2(accl[0][0], bl0[i], ah0[i]); ah1[j] = lds_read16_untracked<AO + YO>(vau);
+            NM_MFMA2(accl[0][1], bl1[i], ah0[i]); al1[j] = lds_read16_untracked<AO + LO + YO>(vau);
+            NM_MFMA2(accl[0][0], bh0[i], al0[i]); if constexpr (bnext) bh0[j] = lds_read16_untracked<BN>(vb);
+            NM_MFMA2(accl[0][1], bh1[i], al0[i]); if constexpr (bnext) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb);
+            NM_MFMA2(acc[1][0], bh0[i], ah1[i]);  if constexpr (bnext) bl0[j] = lds_read16_untracked<BN + 128 * 16>(vb);
+            NM_MFMA2(acc[1][1], bh1[i], ah1[i]);  if constexpr (bnext) bl1[j] = lds_read16_untracked<BN + 160 * 16>(vb);
+            NM_MFMA2(accl[1][0], bl0[i], ah1[i]);
+            NM_MFMA2(accl[1][1], bl1[i], ah1[i]);
+            NM_MFMA2(accl[1][0], bh0[i], al1[i]);
+            NM_MFMA2(accl[1][1], bh1[i], al1[i]);
+            if constexpr (t == 8) {
+                // tap-group end: the producers publish the next group's weights (and, at the second barrier, the next tile)
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        gpar ^= 1;                                                  // three groups per step
+        // 27 taps are an odd count: the A operands prefetched for the next step's first tap sit in slot 1; wait for them (the
+        // reads are untracked) and move them to slot 0
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah0[1]), "+v"(al0[1]), "+v"(ah1[1]), "+v"(al1[1]) :: "memory");
+        ah0[0] = ah0[1]; al0[0] = al0[1]; ah1[0] = ah1[1]; al1[0] = al1[1];
+        if (cur.cb == C16 - 1) {
+            // ---- epilogue of the finished brick (exposed): transposed accumulators -> 16-byte stores, DPP partial sums
+            const Work& w = cur.w;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float s1[16], s2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float* dst = p.out + ((((size_t)w.n * p.OD + w.oz0 + vz) * p.OH + w.oy0 + 2 * wave + mt) * p.OW + w.ox0 + vx) * (size_t)p.Cout +
+                                 w.cg * 64 + nt * 32 + 4 * h;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + w.cg * 64 + nt * 32 + 8 * k4 + 4 * h);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (acc[mt][nt][4 * k4 + e] + accl[mt][nt][4 * k4 + e] * (1.0f / NM_SPLIT_SCALE)) + b4[e];
+                            s1[4 * k4 + e] += v[e]; s2[4 * k4 + e] += v[e] * v[e];
+                            acc[mt][nt][4 * k4 + e] = 0.f; accl[mt][nt][4 * k4 + e] = 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(dst + 8 * k4) = v;
+                    }
+                }
+                if (p.part) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float a = dpp_sum32(s1[r]), b = dpp_sum32(s2[r]);
+                        if (l31 == 16) *reinterpret_cast<f32x2*>(red + (wave * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2) = f32x2{a, b};
+                    }
+                }
+            }
+            lds_barrier();                                          // (matched by the producers)
+            if (p.part && tid < 64) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a += red[(q * 64 + tid) * 2]; b += red[(q * 64 + tid) * 2 + 1]; }
+                const int br = ((w.oz0 >> 2) * nby + (w.oy0 >> 3)) * nbx + (w.ox0 >> 3);
+                float* dp = p.part + (((size_t)w.n * nbr + br) * p.Cout + w.cg * 64 + tid) * 2;
+                dp[0] = a; dp[1] = b;
+            }
+        }
+        if (!has_next) break;
+        cur = nxt; hb ^= 1;
+    }
+}
+
 // OIDHW fp32 -> split fp16 [tap][Cin/16][hi|lo][lane half][Co_pad][8]
 __global__ void pack_conv_weight16_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, _Float16* __restrict__ packed,
                                           int Co_pad) {
@@ -1866,12 +2188,41 @@ int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStr
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
 
+template <bool UP2>
+int launch_f16p2(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
+    ConvParams p = p_in;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p2_kernel<UP2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p2)");
+        attr_set = true;
+    }
+    if (g_num_cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nm_check_hip(hipErrorUnknown, "device query");
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    ProfRec rec;
+    if (g_prof_on) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 9;
+        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
+        (void)hipEventRecord(rec.a, s);
+    }
+    dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
+    if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
+    hipLaunchKernelGGL((conv_f16p2_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    return nm_check_hip(hipGetLastError(), "conv_f16p2 launch");
+}
+
 #ifdef NM_DIAG
 unsigned long long* g_stamps = nullptr;
 #endif
 int g_small16 = [] { const char* e = getenv("NM355_SMALL16"); return e ? atoi(e) : 1; }();   // 0: small volumes on the fp32 MFMA core (diagnostic)
 int g_occ16 = [] { const char* e = getenv("NM355_OCC16"); return e ? atoi(e) : 1; }();     // 0: first layer on the fp32 MFMA kernel (diagnostic)
 int g_pool16 = [] { const char* e = getenv("NM355_POOL16"); return e ? atoi(e) : 1; }();   // 0: pool convs on the fp32 kernel (diagnostic)
+int g_f16p2 = [] { const char* e = getenv("NM355_F16P2"); return e ? atoi(e) : 1; }();   // 0: Cout % 64 == 0 layers stay on conv_f16s (diagnostic)
 // conv_f16p use: 0 never (conv_f16s everywhere), 1 every eligible layer, 2 (default) only Cout == 32 layers - with more cout
 // groups per brick it re-stages the input per group and measures a little slower than conv_f16s (A/B in one gpurun call)
 int g_f16p = [] { const char* e = getenv("NM355_F16P"); return e ? atoi(e) : 2; }();
@@ -1973,6 +2324,13 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
         t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2) {
         p.w = static_cast<const float*>(w_packed16);
         return t.NT == 2 ? launch_pool_f16s<2>(p, grid, s) : launch_pool_f16s<1>(p, grid, s);
+    }
+    if (g_conv_mode == 1 && g_f16p2 && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
+        g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 64 == 0) {
+        const int work = in.N * (g.OD / 4) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 64);
+        p.w = static_cast<const float*>(w_packed16);
+        const size_t lds_bytes = (size_t)8 * 600 * 16 + (size_t)2 * 9 * 4 * 64 * 16 + (size_t)(512 + g.Cout) * sizeof(float);
+        return launch_f16p2<false>(p, lds_bytes, work, s);
     }
     if (g_conv_mode == 1 && g_f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
         g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0 && (g_f16p == 1 || g_f16p_all || g.Cout == 32)) {
