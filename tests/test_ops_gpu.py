@@ -117,14 +117,14 @@ def test_conv3d(ctx, case, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "split16"])
-@pytest.mark.parametrize("Cin,Cout,size,prologue", [(128, 64, 8, False), (64, 32, 12, True), (16, 32, 5, True)])
-def test_conv3d_fused_upsample(ctx, Cin, Cout, size, prologue, mode):
+@pytest.mark.parametrize("Cin,Cout,size,prologue,N", [(128, 64, 8, False, 2), (64, 32, 12, True, 2), (16, 32, 5, True, 2),
+                                                       (32, 32, 16, True, 5), (48, 32, 8, False, 40), (64, 64, 16, True, 3)])
+def test_conv3d_fused_upsample(ctx, Cin, Cout, size, prologue, N, mode):
     """Upsample(x2, trilinear, align_corners=False) -> Conv3d(k3) -> GroupNorm, the upsampling fused into the
     conv's staging (decoder layers .0/.1 and .7/.8 of kypt_detector.py:427-444)."""
     from neural_marionette_amd import _lib
     _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, mode), "set_conv_mode")
     g = torch.Generator().manual_seed(Cin + size)
-    N = 2
     x = torch.randn(N, Cin, size, size, size, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5
     b = torch.randn(Cout, generator=g) * 0.1
