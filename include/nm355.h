@@ -227,7 +227,8 @@ int nm_set_conv_mode(nm_ctx* ctx, int32_t mode);
 int nm_get_conv_mode(nm_ctx* ctx);
 
 /* ---- live kernel timing for bench.py's roofline leg -------------------------------------------
- * While enabled, every conv launch on the ctx stream is bracketed by a HIP event pair.
+ * While enabled, every conv launch on the ctx stream is bracketed by a HIP event pair (launches the library puts on its
+ * own side stream are not timed: they overlap the main stream, so their event-to-event time is not their own).
  * nm_prof_read sums duration and ALGORITHMIC flops (2*voxels*Cout*Cin*k^3, un-padded) of one
  * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2); 5,6 =
  * conv_f16s_kernel<2,1>/<2,2>, 7 = conv_f16p_kernel, 8 = conv_pool_f16s_kernel, 9 = conv_f16p2_kernel (algorithmic fp32-equivalent flops, i.e. 1/3 of the issued MFMA flops); 4 = the

@@ -117,7 +117,7 @@ int nm_get_conv_mode(nm_ctx* ctx) { (void)ctx; return nm_conv_get_mode(); }
 
 int nm_prof_enable(nm_ctx* ctx, int32_t on) {
     if (!ctx) { nm_set_error("prof_enable: null ctx"); return NM_ERR_ARG; }
-    nm_conv_prof_enable(on);
+    nm_conv_prof_enable(on, ctx->stream);
     if (on) nm_conv_prof_reset();
     return NM_OK;
 }

@@ -61,7 +61,7 @@ int nm_occ_blocks_per_frame(int G);
 int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s);
 int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
                          int Co_pad, float* part, hipStream_t s);
-void nm_conv_prof_enable(int on);
+void nm_conv_prof_enable(int on, hipStream_t stream);
 int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, long long* launches);
 void nm_conv_prof_reset();
 

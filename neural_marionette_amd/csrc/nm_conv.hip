@@ -2077,6 +2077,9 @@ Tiling choose_tiling(const ConvGeom& g, int Cin) {
 // ---- optional live timing of the conv launches (bench.py roofline leg) ---------------------------
 struct ProfRec { hipEvent_t a, b; int variant; double flops; };
 bool g_prof_on = false;
+hipStream_t g_prof_stream = nullptr;        // only launches on this stream are timed (side-stream launches overlap the main stream: their
+                                            // event-to-event time is not their own)
+#define NM_PROF_ON(s) (g_prof_on && (s) == g_prof_stream)
 std::vector<ProfRec> g_prof;                 // records of the current window
 std::vector<hipEvent_t> g_event_pool;
 
@@ -2097,14 +2100,14 @@ int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
         attr_set = true;
     }
     ProfRec rec;
-    if (g_prof_on) {
+    if (NM_PROF_ON(s)) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = (MT - 1) * 2 + (NT - 1);
         // algorithmic work: real channels and taps, no padding
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
         (void)hipEventRecord(rec.a, s);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(256), t.lds_bytes, s, p);
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
@@ -2133,7 +2136,7 @@ int launch_f16s(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t 
         attr_set = true;
     }
     ProfRec rec;
-    if (g_prof_on) {
+    if (NM_PROF_ON(s)) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 5 + (NT - 1);
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
         (void)hipEventRecord(rec.a, s);
@@ -2141,20 +2144,20 @@ int launch_f16s(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t 
     dim3 pgrid(min(grid.x, 512u), grid.y);                          // persistent: ~2 resident workgroups per CU
     choose_super_tile(p, (int)pgrid.x, p.nbz, p.nby, p.nbx);
     hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2>), pgrid, dim3(256), t.lds_bytes, s, p);
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
 }
 
 template <int NT>
 int launch_pool_f16s(const ConvParams& p, dim3 grid, hipStream_t s) {
     ProfRec rec;
-    if (g_prof_on) {
+    if (NM_PROF_ON(s)) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 8;
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 8.0;
         (void)hipEventRecord(rec.a, s);
     }
     hipLaunchKernelGGL((conv_pool_f16s_kernel<NT>), grid, dim3(256), 0, s, p);
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_pool_f16s launch");
 }
 
@@ -2176,7 +2179,7 @@ int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStr
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     ProfRec rec;
-    if (g_prof_on) {
+    if (NM_PROF_ON(s)) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 7;
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
         (void)hipEventRecord(rec.a, s);
@@ -2184,7 +2187,7 @@ int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStr
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 32) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
 
@@ -2204,7 +2207,7 @@ int launch_f16p2(const ConvParams& p_in, size_t lds_bytes, int work_items, hipSt
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     ProfRec rec;
-    if (g_prof_on) {
+    if (NM_PROF_ON(s)) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 9;
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
         (void)hipEventRecord(rec.a, s);
@@ -2212,7 +2215,7 @@ int launch_f16p2(const ConvParams& p_in, size_t lds_bytes, int work_items, hipSt
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p2_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p2 launch");
 }
 
@@ -2266,7 +2269,7 @@ int nm_conv_blocks_per_frame(const ConvGeom& g) {
     return t.nbz * t.nby * t.nbx;
 }
 
-void nm_conv_prof_enable(int on) { g_prof_on = on != 0; }
+void nm_conv_prof_enable(int on, hipStream_t stream) { g_prof_on = on != 0; g_prof_stream = stream; }
 
 // Sums the event-timed launches of one kernel variant recorded since the last reset.
 // variant = (MT-1)*2 + (NT-1).  Synchronises on the recorded events.
@@ -2386,7 +2389,7 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
     const int NT = (Co_pad % 64 == 0) ? 2 : 1;
     dim3 grid((unsigned)(N * nm_occ_blocks_per_frame(G)), (unsigned)(Co_pad / (NT * 32)));
     ProfRec rec;
-    if (g_prof_on) {
+    if (NM_PROF_ON(s)) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 4;
         rec.flops = 2.0 * N * (double)G * G * G * Cout * 4.0 * 125.0;   // the reference's dense k5 layer over 4 input channels
         (void)hipEventRecord(rec.a, s);
@@ -2396,6 +2399,6 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
         else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1>), grid, dim3(256), 0, s, p);
     } else if (NT == 2) hipLaunchKernelGGL((conv_k5occ_kernel<2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_k5occ_kernel<1>), grid, dim3(256), 0, s, p);
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_k5occ launch");
 }

@@ -138,8 +138,16 @@ def case_g2():
 def case_g3():
     """Skeleton trees: affinity (N,K,K,1) -> (A, parents, priority) for several seeds."""
     from utils.dyna_utils import process_affinity_glob
-    from oracle import nm_oracle as O
     K, N = 24, 2
+
+    def affinity_input(params):           # an (N,K,K,1) row-stochastic affinity with a zero diagonal (the fixture stores it)
+        P = torch.softmax(params, dim=-1)
+        W = torch.zeros(N, K, K, dtype=params.dtype)
+        for k in range(K):
+            W[:, k, :k] = P[:, k, :k]
+            W[:, k, k + 1:] = P[:, k, k:]
+        return W[..., None]
+
     affs, As, pars, ords, vals = [], [], [], [], []
     for seed in range(12):
         rng = np.random.default_rng([seed, 0x73EE])
@@ -149,7 +157,7 @@ def case_g3():
             params = torch.from_numpy(np.round(rng.standard_normal((N, K, K - 1)) * 2) / 2).float()  # many ties
         else:
             params = torch.from_numpy(rng.standard_normal((N, K, K - 1)) * (1 + seed % 3)).float()
-        aff = O.affinity_v3(params)
+        aff = affinity_input(params)
         A, pri, par = process_affinity_glob(aff)
         affs.append(_np(aff)); As.append(_np(A)); pars.append(_np(par))
         ords.append(_np(pri.indices)); vals.append(_np(pri.values))
@@ -213,7 +221,6 @@ def case_g6():
     """Learner-mode training gradients (pretrained_mode=1: detector frozen, train.py:146,177-181):
     d(1.0 * kypt_recon_loss + 0.003 * kl_kypt) / d(dyna_module parameters) by the reference's autograd,
     B=3, T=5, recorded eps.  Every gradient is stored as (sum, abs-sum, every 97th element)."""
-    from oracle import nm_oracle as O
     B, T, wseed, kseed, eseed = 3, 5, 13, 14, 15
     opt = _ref_opt(32)
     o = HotPathOptions.from_any(opt)
