@@ -168,22 +168,48 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TensorRef x, const fl
     __shared__ float kp[32 * 3];
     const int f = blockIdx.y, b = f / T;
     const size_t G3 = (size_t)G * G * G;
-    const size_t v = blockIdx.x * (size_t)256 + threadIdx.x;
+    const int C = x.C;
+    // C == 32 (the network's decoder): eight lanes fetch one voxel's 128 contiguous bytes, so a wave load covers 1 KB of
+    // consecutive voxels (a thread reading its own voxel's 32 channels touches 64 different lines per load instruction, eight
+    // times over); the eight 4-channel partial dot products are summed with DPP adds and lane l keeps the voxel
+    // 8 (l & 7) + (l >> 3) of its wave's 64.
+    const bool coop = (C == 32) && (G3 % 256 == 0);
+    const int lane = threadIdx.x & 63;
+    const size_t v = coop ? blockIdx.x * (size_t)256 + (threadIdx.x & ~63) + (lane & 7) * 8 + (lane >> 3)
+                          : blockIdx.x * (size_t)256 + threadIdx.x;
     if (keypoints && threadIdx.x < K * 3) kp[threadIdx.x] = keypoints[((size_t)f * K + threadIdx.x / 3) * 4 + threadIdx.x % 3];
     __syncthreads();
     float bce = 0.f, cham = 0.f, cnt = 0.f;
     if (v < G3) {
-        const int C = x.C;
-        const float* px = x.p + ((size_t)f * G3 + v) * C;
         float acc = 0.f;
-        for (int c = 0; c < C; c += 4) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(px + c);
-            f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + c);
-            f32x4 sh4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + c);
-            f32x4 wv = *reinterpret_cast<const f32x4*>(w14 + c);
-            a = a * sc + sh4;
+        if (coop) {
+            const int cq = (lane & 7) * 4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + cq);
+            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + cq);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w14 + cq);
+            const float* pw = x.p + ((size_t)f * G3 + blockIdx.x * (size_t)256 + (threadIdx.x & ~63) + (lane >> 3)) * C + cq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc += lrelu(a[j], x.slope) * wv[j];
+            for (int i = 0; i < 8; ++i) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(pw + (size_t)i * 8 * C);
+                float part4 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part4 += lrelu(a[j] * sc[j] + sh4[j], x.slope) * wv[j];
+                part4 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part4), 0xB1, 0xf, 0xf, true));
+                part4 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part4), 0x4E, 0xf, 0xf, true));
+                part4 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part4), 0x141, 0xf, 0xf, true));
+                acc = ((lane & 7) == i) ? part4 : acc;
+            }
+        } else {
+            const float* px = x.p + ((size_t)f * G3 + v) * C;
+            for (int c = 0; c < C; c += 4) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(px + c);
+                f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + c);
+                f32x4 sh4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + c);
+                f32x4 wv = *reinterpret_cast<const f32x4*>(w14 + c);
+                a = a * sc + sh4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += lrelu(a[j], x.slope) * wv[j];
+            }
         }
         acc += w14[C];
         const float ff = first_frames[((size_t)b * ff_stride_frames) * G3 + v];
