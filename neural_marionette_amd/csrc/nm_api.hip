@@ -169,12 +169,14 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     g.Cout = Cout; g.Co_pad = Co_pad;
     const int nblk = nm_conv_blocks_per_frame(g);
     const size_t wfl = nm_packed_weight_floats(ks, Cin_pad, Co_pad);
+    const bool want16 = Cin % 8 == 0 && Cin >= 16;
+    const size_t wfl16 = want16 ? nm_packed_weight_floats(ks, (Cin + 15) & ~15, Co_pad) : 0;
     const size_t pfl = (size_t)N * nblk * Cout * 2;
-    int rc = nm_ctx_reserve(ctx, (2 * wfl + pfl) * sizeof(float) + 8192);
+    int rc = nm_ctx_reserve(ctx, (wfl + wfl16 + pfl) * sizeof(float) + 8192);
     if (rc) return rc;
     ctx->ws.release(0);
     float* wp = ctx->ws.f(wfl);
-    float* wp16 = (Cin % 16 == 0) ? ctx->ws.f(wfl) : nullptr;
+    float* wp16 = want16 ? ctx->ws.f(wfl16) : nullptr;
     float* part = gn_groups > 0 ? ctx->ws.f(pfl) : nullptr;
     rc = nm_launch_pack_conv_weight(weight, Cout, Cin, ks, wp, Cin_pad, Co_pad, ctx->stream);
     if (rc) return rc;

@@ -611,13 +611,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         __syncthreads();
         // ---- stage the halo brick of channels [c0, c0+kc) ------------------------------
         if (!p.up2) {
-            for (int i = tid; i < p.HV * nq; i += 256) {
-                int q = i % nq, hv = i / nq;
+            // (split-fp16 core: 16-channel chunks; a trailing half chunk - Cin = 72 - is filled up with zeros)
+            const int nqs = (MT == 1 && p.w16) ? ((kc + 15) >> 4) << 2 : nq;
+            for (int i = tid; i < p.HV * nqs; i += 256) {
+                int q = i % nqs, hv = i / nqs;
                 int hx = hv % p.HX, t2 = hv / p.HX;
                 int hy = t2 % p.HY, hz = t2 / p.HY;
                 int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)gz < (unsigned)p.ID && (unsigned)gy < (unsigned)p.IH && (unsigned)gx < (unsigned)p.IW)
+                if (q < nq && (unsigned)gz < (unsigned)p.ID && (unsigned)gy < (unsigned)p.IH && (unsigned)gx < (unsigned)p.IW)
                     v = load_act(p, n, gz, gy, gx, c0 + 4 * q);
                 lds[q * p.HVp + hv] = v;
             }
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
         if constexpr (MT == 1) {
             if (p.w16) {                                            // split-fp16 core (Cin % 16 == 0: every chunk is 16 wide)
                 const half8* w8 = reinterpret_cast<const half8*>(p.w16);
-                const size_t ts16 = (size_t)(p.Cin >> 4) * 4 * p.Co_pad;
+                const size_t ts16 = (size_t)((p.Cin + 15) >> 4) * 4 * p.Co_pad;
                 for (int s0 = 0; s0 < kc; s0 += 16)
                     mfma_chunk16<NT>(p, lds + (s0 >> 2) * p.HVp, w8 + ((size_t)((c0 + s0) >> 4) * 4 + h) * p.Co_pad + co_base + l31, ts16, taps, h,
                                      arow[0], acc, accl);
@@ -2019,7 +2021,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
 // OIDHW fp32 -> split fp16 [tap][Cin/16][hi|lo][lane half][Co_pad][8]
 __global__ void pack_conv_weight16_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, _Float16* __restrict__ packed,
                                           int Co_pad) {
-    const int taps = ks * ks * ks, C16 = Cin >> 4;
+    const int taps = ks * ks * ks, C16 = (Cin + 15) >> 4;              // channels beyond Cin carry zero weights
     const size_t total = (size_t)taps * C16 * 2 * Co_pad * 8;          // (tap, cb, h, co, j): writes hi and lo
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int j = i & 7; size_t r = i >> 3;
@@ -2027,7 +2029,7 @@ __global__ void pack_conv_weight16_kernel(const float* __restrict__ w, int Cout,
         int hh = r & 1; r >>= 1;
         int cb = r % C16; int tap = r / C16;
         int ci = cb * 16 + hh * 8 + j;
-        float v = (co < Cout) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+        float v = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
         _Float16 hi = (_Float16)v;
         _Float16 lo = (_Float16)((v - (float)hi) * NM_SPLIT_SCALE);
         size_t base = ((((size_t)tap * C16 + cb) * 4) * Co_pad) * 8;
@@ -2241,8 +2243,8 @@ void nm_conv_set_mode(int mode) { g_conv_mode = mode ? 1 : 0; g_f16p_all = mode 
 int nm_conv_get_mode() { return g_conv_mode && g_f16p_all ? 2 : g_conv_mode; }
 
 int nm_launch_pack_conv_weight16(const float* w, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s) {
-    if (Cin % 16 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("pack_conv_weight16: Cin=%d must be a multiple of 16", Cin); return NM_ERR_ARG; }
-    size_t total = (size_t)ks * ks * ks * (Cin / 16) * 2 * Co_pad * 8;
+    if (Cin % 8 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("pack_conv_weight16: Cin=%d must be a multiple of 8", Cin); return NM_ERR_ARG; }
+    size_t total = (size_t)ks * ks * ks * ((Cin + 15) / 16) * 2 * Co_pad * 8;
     int blocks = (int)min((total + 255) / 256, (size_t)2048);
     hipLaunchKernelGGL(pack_conv_weight16_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, ks, reinterpret_cast<_Float16*>(packed), Co_pad);
     return nm_check_hip(hipGetLastError(), "pack_conv_weight16 launch");
@@ -2317,7 +2319,8 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.up2 = g.up2 ? 1 : 0;
     p.st_z = p.st_y = p.st_x = 0;
-    p.w16 = (g_conv_mode == 1 && g_small16 && w_packed16 && in.C % 16 == 0 && !g.up2 && t.MT == 1) ? w_packed16 : nullptr;
+    p.w16 = (g_conv_mode == 1 && g_small16 && w_packed16 && in.C % 8 == 0 && !g.up2 && t.MT == 1 && (t.KC % 16 == 0 || t.KC == in.C)) ? w_packed16 : nullptr;
+    if (p.w16) t.lds_bytes = max(t.lds_bytes, (size_t)(((t.KC + 15) & ~15) / 4) * (t.HVp + t.CVp) * 16);
 #ifdef NM_DIAG
     p.stamps = g_stamps;
 #endif

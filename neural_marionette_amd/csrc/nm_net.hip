@@ -55,8 +55,8 @@ struct Loader {
         w.wp = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, w.Cin_pad, w.Co_pad));
         if (!w.wp) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
         int r = nm_launch_pack_conv_weight(src, Cout, Cin, ks, w.wp, w.Cin_pad, w.Co_pad, c->stream);
-        if (!r && Cin % 16 == 0) {
-            w.wp16 = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, Cin, w.Co_pad));      // same byte count as fp32
+        if (!r && Cin % 8 == 0 && Cin >= 16) {                      // (Cin % 16 == 8: zero-padded, used by the small-volume core only)
+            w.wp16 = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, (Cin + 15) & ~15, w.Co_pad));      // same byte count as fp32
             if (!w.wp16) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
             r = nm_launch_pack_conv_weight16(src, Cout, Cin, ks, w.wp16, w.Co_pad, c->stream);
         }
