@@ -216,6 +216,26 @@ int nm_op_apply2(nm_ctx* ctx, const float* a, const float* a_scale, const float*
 int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out);
 int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out);
 int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out);
+/* Backward ops (detector-mode training, train.py:388-404 = autograd of the modules above; unit parity in
+ * tests/test_grad_ops_gpu.py).  Tensors are channels-last like the forward ops.
+ * nm_op_conv3d_backward: y = conv3d(up2 ? upsample2(a) : a, W) + b with a = lrelu(in*scale+shift) (vox_modules.py:12,27,31,53;
+ *   kypt_detector.py:427-445).  d_weight is OIDHW, d_bias = sum dy, d_in = dL/da for the first dgrad_channels input
+ *   channels [N][D][H][W][dgrad_channels] (NULL: skipped).  The data gradient is the forward conv kernel on flipped /
+ *   transposed weights (stride 1), the transposed-conv kernel (k2 s2), plus the adjoint of the trilinear upsampling (up2).
+ * nm_op_conv5_occ_backward: weight / bias gradients of the first layer conv5(cat[occ, coords]) (kypt_detector.py:265).
+ * nm_op_convT2_backward: ConvTranspose3d(k2, s2, output_padding) of vox_modules.py:68; weight IODHW.
+ * nm_op_gn_backward: GroupNorm(groups, eps 1e-5) + LeakyReLU(slope) on the raw tensor y: dy, dgamma, dbeta and sum_v dy. */
+int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                          const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
+                          int32_t ks, int32_t stride, int32_t pad, int32_t up2, const float* dy, float* d_in,
+                          int32_t dgrad_channels, float* d_weight, float* d_bias);
+int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, int32_t Cout, const float* dy,
+                             float* d_weight, float* d_bias);
+int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                          const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
+                          int32_t outpad, const float* dy, float* d_in, float* d_weight, float* d_bias);
+int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, int32_t C, int32_t groups, const float* gamma,
+                      const float* beta, float slope, const float* dA, float* dy, float* dgamma, float* dbeta, float* dbias);
 /* Conv arithmetic (process-wide).  mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for every conv.
  * mode 1 (default): layers with Cin % 16 == 0 run on the fp16 matrix cores with every fp32 operand split
  * into fp16 hi + lo*2^-11 and three products x_hi*w_hi + 2^-11 (x_hi*w_lo + x_lo*w_hi) accumulated in

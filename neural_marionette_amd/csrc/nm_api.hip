@@ -2,6 +2,7 @@
 // points used by the unit parity tests.  The network-level entry points live in
 // nm_net.hip / nm_vrnn.hip.
 #include "nm_ctx.h"
+#include "nm_grad.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -256,6 +257,138 @@ int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_
 int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out) {
     if (!ctx || !in || !out) { nm_set_error("op_cl_to_ncdhw: null argument"); return NM_ERR_ARG; }
     return nm_launch_cl_to_ncdhw(make_ref(in, nullptr, nullptr, 1.0f, N, 1, 1, voxels, C), out, ctx->stream);
+}
+
+// ---- backward ops (unit parity of the detector-mode training kernels) ----------------------------------------------------
+// Gradients of  y = conv3d(up2? upsample2(a) : a, W) + b  with  a = lrelu(in*scale + shift):
+//   d_weight (OIDHW), d_bias, and d_in = dL/da for the first `dgrad_channels` input channels (null: skipped).
+int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                          const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
+                          int32_t ks, int32_t stride, int32_t pad, int32_t up2, const float* dy, float* d_in,
+                          int32_t dgrad_channels, float* d_weight, float* d_bias) {
+    if (!ctx || !in || !weight || !dy || !d_weight || !d_bias) { nm_set_error("op_conv3d_backward: null argument"); return NM_ERR_ARG; }
+    if (Cout % 8) { nm_set_error("op_conv3d_backward: Cout %% 8 != 0"); return NM_ERR_ARG; }
+    const int Cin_pad = (Cin + 7) & ~7, us = up2 ? 2 : 1, taps = ks * ks * ks;
+    const int FD = us * D, FH = us * H, FW = us * W;
+    const int OD = (FD + 2 * pad - ks) / stride + 1, OH = (FH + 2 * pad - ks) / stride + 1, OW = (FW + 2 * pad - ks) / stride + 1;
+    const size_t fine = (size_t)N * FD * FH * FW, ov = (size_t)OD * OH * OW;
+    const int csel = dgrad_channels, co_pad2 = (csel + 31) & ~31;
+    const size_t wsf = nm_wgrad_ws_floats(N, OD, OH, OW, Cout, Cin_pad, ks, stride);
+    const int nbb = nm_gnb_blocks_per_frame((int)ov);
+    const size_t wfl2 = nm_packed_weight_floats(ks, Cout, co_pad2);
+    size_t need = wsf + (size_t)N * nbb * Cout * 2 + (up2 ? fine * Cin_pad : 0) + (size_t)csel * Cout * taps + 2 * wfl2 + co_pad2 +
+                  ((up2 && d_in) ? fine * csel : 0) + 16384;
+    int rc = nm_ctx_reserve(ctx, need * sizeof(float));
+    if (rc) return rc;
+    ctx->ws.release(0);
+    hipStream_t s = ctx->stream;
+    TensorRef a = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad);
+    TensorRef dyT = make_ref(dy, nullptr, nullptr, 1.0f, N, OD, OH, OW, Cout);
+    if (up2) {
+        float* up = ctx->ws.f(fine * Cin_pad);
+        if ((rc = nm_launch_upsample2(a, up, s))) return rc;
+        a = make_ref(up, nullptr, nullptr, 1.0f, N, FD, FH, FW, Cin_pad);
+    }
+    float* ws = ctx->ws.f(wsf);
+    if ((rc = nm_launch_wgrad(a, dyT, ks, stride, pad, Cin, ws, d_weight, s))) return rc;
+    float* bp = ctx->ws.f((size_t)N * nbb * Cout * 2);
+    if ((rc = nm_launch_gnb_partials(dy, dyT, bp, s))) return rc;
+    if ((rc = nm_launch_sum_partials(bp, N * nbb, Cout, d_bias, s))) return rc;
+    if (!d_in) return NM_OK;
+    if (csel <= 0 || csel % 8 || csel > Cin) { nm_set_error("op_conv3d_backward: dgrad_channels %d", csel); return NM_ERR_ARG; }
+    if (stride == 1) {
+        float* wf = ctx->ws.f((size_t)csel * Cout * taps);
+        float* wp = ctx->ws.f(wfl2); float* wp16 = ctx->ws.f(wfl2); float* zb = ctx->ws.f(co_pad2);
+        if ((rc = nm_launch_flip_weight(weight, Cout, Cin, csel, ks, wf, s))) return rc;
+        if ((rc = nm_launch_pack_conv_weight(wf, csel, Cout, ks, wp, Cout, co_pad2, s))) return rc;
+        const bool h16 = Cout % 16 == 0;
+        if (h16 && (rc = nm_launch_pack_conv_weight16(wf, csel, Cout, ks, wp16, co_pad2, s))) return rc;
+        if ((rc = nm_check_hip(hipMemsetAsync(zb, 0, co_pad2 * sizeof(float), s), "memset"))) return rc;
+        ConvGeom g; g.ks = ks; g.stride = 1; g.pad = ks - 1 - pad; g.OD = FD; g.OH = FH; g.OW = FW; g.Cout = csel; g.Co_pad = co_pad2;
+        float* dfine = up2 ? ctx->ws.f(fine * csel) : d_in;
+        if ((rc = nm_launch_conv(dyT, wp, zb, dfine, g, nullptr, s, Cout, h16 ? wp16 : nullptr))) return rc;
+        if (up2) rc = nm_launch_upsample2_adjoint(dfine, N, D, H, W, csel, d_in, s);
+        return rc;
+    }
+    if (stride == 2 && ks == 2 && pad == 0 && !up2) {
+        float* wt = ctx->ws.f((size_t)csel * Cout * 8); float* zb = ctx->ws.f(co_pad2);
+        if (csel != Cin) { nm_set_error("op_conv3d_backward: pool dgrad needs all input channels"); return NM_ERR_ARG; }
+        if ((rc = nm_launch_transpose_convT_weight(weight, Cout, Cin, wt, s))) return rc;
+        if ((rc = nm_check_hip(hipMemsetAsync(zb, 0, co_pad2 * sizeof(float), s), "memset"))) return rc;
+        return nm_launch_convT2(dyT, wt, zb, d_in, Cin, D, H, W, s);
+    }
+    nm_set_error("op_conv3d_backward: unsupported geometry"); return NM_ERR_UNSUPPORTED;
+}
+
+// first layer: dW [Cout][4][125] and d_bias of conv5(cat[occ, coords]) given dy
+int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, int32_t Cout, const float* dy,
+                             float* d_weight, float* d_bias) {
+    if (!ctx || !occ || !dy || !d_weight || !d_bias) { nm_set_error("op_conv5_occ_backward: null argument"); return NM_ERR_ARG; }
+    const size_t wsf = nm_wgrad_k5occ_ws_floats(N, G, Cout);
+    const int nbb = nm_gnb_blocks_per_frame(G * G * G);
+    int rc = nm_ctx_reserve(ctx, (wsf + (size_t)N * nbb * Cout * 2) * sizeof(float) + 8192);
+    if (rc) return rc;
+    ctx->ws.release(0);
+    TensorRef dyT = make_ref(dy, nullptr, nullptr, 1.0f, N, G, G, G, Cout);
+    float* ws = ctx->ws.f(wsf); float* bp = ctx->ws.f((size_t)N * nbb * Cout * 2);
+    if ((rc = nm_launch_wgrad_k5occ(occ, N, G, dyT, ws, d_weight, ctx->stream))) return rc;
+    if ((rc = nm_launch_gnb_partials(dy, dyT, bp, ctx->stream))) return rc;
+    return nm_launch_sum_partials(bp, N * nbb, Cout, d_bias, ctx->stream);
+}
+
+// Gradients of  y = convT3d_k2s2(a, W) + b  (a = lrelu(in*scale+shift)); weight IODHW
+int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                          const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
+                          int32_t outpad, const float* dy, float* d_in, float* d_weight, float* d_bias) {
+    if (!ctx || !in || !weight || !dy || !d_in || !d_weight || !d_bias) { nm_set_error("op_convT2_backward: null argument"); return NM_ERR_ARG; }
+    if (Cin % 8 || Cout % 8) { nm_set_error("op_convT2_backward: channels must be multiples of 8"); return NM_ERR_ARG; }
+    const int OD = 2 * D + outpad, OH = 2 * H + outpad, OW = 2 * W + outpad;
+    const size_t ov = (size_t)OD * OH * OW;
+    const int ci_pad = (Cin + 31) & ~31;
+    const size_t wsf = nm_wgrad_ws_floats(N, D, H, W, Cin, Cout, 2, 2);
+    const int nbb = nm_gnb_blocks_per_frame((int)ov);
+    const size_t wfl = nm_packed_weight_floats(2, Cout, ci_pad);
+    int rc = nm_ctx_reserve(ctx, (wsf + (size_t)N * nbb * Cout * 2 + 2 * wfl + ci_pad) * sizeof(float) + 16384);
+    if (rc) return rc;
+    ctx->ws.release(0);
+    hipStream_t s = ctx->stream;
+    TensorRef a = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin);
+    TensorRef dyT = make_ref(dy, nullptr, nullptr, 1.0f, N, OD, OH, OW, Cout);
+    float* ws = ctx->ws.f(wsf);
+    if ((rc = nm_launch_wgrad(dyT, a, 2, 2, 0, Cout, ws, d_weight, s))) return rc;       // roles swapped: [Cin][Cout][8] = IODHW
+    float* bp = ctx->ws.f((size_t)N * nbb * Cout * 2);
+    if ((rc = nm_launch_gnb_partials(dy, dyT, bp, s))) return rc;
+    if ((rc = nm_launch_sum_partials(bp, N * nbb, Cout, d_bias, s))) return rc;
+    float* wp = ctx->ws.f(wfl); float* wp16 = ctx->ws.f(wfl); float* zb = ctx->ws.f(ci_pad);
+    if ((rc = nm_launch_pack_conv_weight(weight, Cin, Cout, 2, wp, Cout, ci_pad, s))) return rc;   // IODHW read as OIDHW of the adjoint conv
+    const bool h16 = Cout % 16 == 0;
+    if (h16 && (rc = nm_launch_pack_conv_weight16(weight, Cin, Cout, 2, wp16, ci_pad, s))) return rc;
+    if ((rc = nm_check_hip(hipMemsetAsync(zb, 0, ci_pad * sizeof(float), s), "memset"))) return rc;
+    ConvGeom g; g.ks = 2; g.stride = 2; g.pad = 0; g.OD = D; g.OH = H; g.OW = W; g.Cout = Cin; g.Co_pad = ci_pad;
+    return nm_launch_conv(dyT, wp, zb, d_in, g, nullptr, s, Cout, h16 ? wp16 : nullptr);
+}
+
+// GroupNorm(groups) + LeakyReLU(slope) backward on a raw tensor y [N][voxels][C]: dy, dgamma, dbeta, and sum_v dy (the conv bias gradient)
+int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, int32_t C, int32_t groups, const float* gamma,
+                      const float* beta, float slope, const float* dA, float* dy, float* dgamma, float* dbeta, float* dbias) {
+    if (!ctx || !y || !gamma || !beta || !dA || !dy || !dgamma || !dbeta || !dbias) { nm_set_error("op_gn_backward: null argument"); return NM_ERR_ARG; }
+    const int nbf = nm_stats_blocks_per_frame(voxels), nbb = nm_gnb_blocks_per_frame(voxels);
+    int rc = nm_ctx_reserve(ctx, ((size_t)N * (nbf + nbb) * C * 2 + (size_t)N * C * 10) * sizeof(float) + 16384);
+    if (rc) return rc;
+    ctx->ws.release(0);
+    hipStream_t s = ctx->stream;
+    float* fpart = ctx->ws.f((size_t)N * nbf * C * 2); float* bpart = ctx->ws.f((size_t)N * nbb * C * 2);
+    float* scale = ctx->ws.f((size_t)N * C); float* shift = ctx->ws.f((size_t)N * C);
+    float* coef = ctx->ws.f((size_t)N * C * 4); float* dgn = ctx->ws.f((size_t)N * C * 4);
+    if ((rc = nm_launch_gn_partials(y, N, voxels, C, fpart, s))) return rc;
+    if ((rc = finish_gn(ctx, fpart, N, nbf, C, groups, (double)voxels * (C / groups), gamma, beta, scale, shift))) return rc;
+    TensorRef yT = make_ref(y, scale, shift, slope, N, 1, 1, voxels, C);
+    if ((rc = nm_launch_gnb_partials(dA, yT, bpart, s))) return rc;
+    if ((rc = nm_launch_gnb_finalize(bpart, nbb, fpart, nbf, N, C, groups, voxels, gamma, 1e-5f, coef, dgn, s))) return rc;
+    if ((rc = nm_launch_sum_frames(dgn, N, C, 4, 0, dgamma, s))) return rc;
+    if ((rc = nm_launch_sum_frames(dgn, N, C, 4, 1, dbeta, s))) return rc;
+    if ((rc = nm_launch_sum_frames(dgn, N, C, 4, 2, dbias, s))) return rc;
+    return nm_launch_gnb_apply(dA, yT, coef, dy, s);
 }
 
 }  // extern "C"

@@ -1,0 +1,38 @@
+// launchers of nm_grad.hip: backward kernels of the conv stack (detector-mode training)
+#pragma once
+#include "nm_common.h"
+
+// ---- weight gradients ------------------------------------------------------------------------------------------------
+// dW[m][c][tap] = sum_{n,v} dy[n, v, m] * act(in)[n, stride*v + tap - pad, c]      (torch OIDHW layout, fp32 MFMA, exact)
+// Both operands are lazy tensors (ConvTranspose3d weight gradients swap the roles: the activated input plays dy).
+// `ws` holds the per-workgroup partial tiles (nm_wgrad_ws_floats), reduced in a fixed order: deterministic, no atomics.
+size_t nm_wgrad_ws_floats(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride);
+int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride, int pad, int cin_real, float* ws,
+                    float* dW, hipStream_t s);
+// first layer (Basic3DBlock k5 on cat[occ, x1, x2, x3], kypt_detector.py:265): the input is rebuilt from the occupancy
+// grid while staging; dW is [Cout][4][5][5][5]
+size_t nm_wgrad_k5occ_ws_floats(int N, int G, int M);
+int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s);
+
+// ---- GroupNorm + LeakyReLU backward ------------------------------------------------------------------------------------
+// y: the raw conv output with its forward scale/shift/slope (lazy tensor);  dA: gradient w.r.t. the activated values.
+//   dz = dA * lrelu'(scale*y + shift);   partials: per (frame, block, channel) (sum dz, sum dz*y)
+int nm_gnb_blocks_per_frame(int voxels);
+int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s);
+// coef[n][c] = (c1, c2, c3, 0) with dy = c1*dz + c2*y + c3;  dgn[n][c] = (dgamma_n, dbeta_n, dbias_n, 0)
+// fpart: the forward partial sums (sum y, sum y^2) the conv epilogue left, [N][nblk_f][C][2]
+int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, int nblk_f, int N, int C, int groups, int voxels,
+                           const float* gamma, float eps, float* coef, float* dgn, hipStream_t s);
+// out[c] = sum_n src[(n*C + c)*stride + off]
+int nm_launch_sum_frames(const float* src, int N, int C, int stride, int off, float* out, hipStream_t s);
+// out[c] = sum_{n,blk} part[((n*nblk + blk)*C + c)*2]       (bias gradient of a conv without GroupNorm)
+int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipStream_t s);
+// dy = c1*dz + c2*y + c3 (coef) or dy = dz (coef == nullptr)
+int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s);
+
+// ---- misc --------------------------------------------------------------------------------------------------------------
+// adjoint of nn.Upsample(x2, trilinear, align_corners=False): dfine [N][2D][2H][2W][C] -> dcoarse [N][D][H][W][C]
+int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s);
+// OIDHW weights of the data-gradient convolution: out[ci][co][K-1-tap] = w[co][ci][tap], ci < csel
+int nm_launch_flip_weight(const float* w, int Cout, int Cin, int csel, int ks, float* out, hipStream_t s);
+int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s);      // dst += src

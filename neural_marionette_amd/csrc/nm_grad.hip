@@ -1,0 +1,476 @@
+// Backward kernels of the conv stack (detector-mode training step; reference: autograd of
+// modules/vox_modules.py:8-120 and model/kypt_detector.py:417-460 as driven by train.py:388-404).
+//
+//   wgrad_kernel         dW[m][c][tap] = sum_{n,v} dy[n,v,m] * act(in)[n, s*v + tap - pad, c]
+//                        An implicit GEMM whose K dimension is the voxels: M = 32 dy channels, N = 32 input channels per
+//                        workgroup, one 32x32 fp32-MFMA accumulator tile per tap kept in registers (taps dealt to the four
+//                        waves) while the workgroup walks its share of the bricks; the per-workgroup tiles go to a
+//                        scratch buffer and are summed in a fixed order (run-to-run identical, no float atomics).
+//                        v_mfma_f32_32x32x2_f32 takes one K element per lane, so both operands are read from a plain
+//                        [voxel][channel] LDS tile with conflict-free ds_read_b32 - no transposition of the
+//                        channels-last activations is needed.  Bound: fp32 MFMA (157 TFLOP/s), the same FLOPs as the
+//                        forward conv.
+//   gnb_*                GroupNorm + LeakyReLU backward as two passes over (dA, y): per-block partial sums, per-(frame,
+//                        group) coefficients, then dy = c1*dz + c2*y + c3.   HBM-bound.
+//   upsample2_adjoint    adjoint of the trilinear x2 upsampling (gather form, deterministic).  HBM-bound.
+#include "nm_grad.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float lin_coord(int i, int G) {
+    const float step = 2.0f / (float)(G - 1);
+    return i < G / 2 ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(G - 1 - i), 1.0f);
+}
+
+__device__ __forceinline__ f32x4 load_act4(const TensorRef& t, int n, int z, int y, int x, int c) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(t.p + ((((size_t)n * t.D + z) * t.H + y) * t.W + x) * t.C + c);
+    if (t.scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(t.scale + (size_t)n * t.C + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(t.shift + (size_t)n * t.C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+    }
+    if (t.slope != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = lrelu(v[j], t.slope);
+    }
+    return v;
+}
+
+struct WgradParams {
+    TensorRef in;            // MODE 0/1: activated on read; MODE 2: in.p = occupancy [N][G^3], in.D/H/W = G
+    TensorRef dy;            // [N][OD][OH][OW][dy.C] (lazy affine allowed)
+    float* part;
+    int ks, stride, pad;
+    int M, Nc;               // dy channels / input channels that take part
+    int BZ, BY, BX, nbz, nby, nbx, HZ, HY, HX;
+    int S, n_tiles, groups;  // split count, column tiles, tap groups per tile
+};
+
+// MODE 0: taps dealt to the waves (NTW per wave);  MODE 1: ks = 1, the waves split the voxels;
+// MODE 2: first layer, columns = (dx, channel) of cat[occ, x1, x2, x3], tap groups = (dz, dy)
+template <int MODE, int NTW>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+    extern __shared__ float lds[];
+    constexpr int CP = MODE == 2 ? 4 : 32;
+    const int BV = p.BZ * p.BY * p.BX, HV = p.HZ * p.HY * p.HX;
+    float* dys = lds;                    // [BV][32]
+    float* as = lds + (size_t)BV * 32;   // [HV][CP]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, w = tid >> 6;
+    const int tp = blockIdx.y, mt = tp / p.n_tiles, nt = tp % p.n_tiles, m0 = mt * 32, n0 = nt * 32;
+    const int OD = p.dy.D, OH = p.dy.H, OW = p.dy.W;
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    int toff[NTW];
+    bool tv[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int t = MODE == 1 ? 0 : w + 4 * j;
+        tv[j] = t < p.groups;
+        if (MODE == 2) toff[j] = ((t / 5) * p.HY + (t % 5)) * p.HX * CP;
+        else { const int dz = t / (p.ks * p.ks), dyy = (t / p.ks) % p.ks, dx = t % p.ks; toff[j] = ((dz * p.HY + dyy) * p.HX + dx) * CP; }
+    }
+    const int coloff = MODE == 2 ? (l31 < 20 ? l31 : 0) : l31;
+
+    const int per_frame = p.nbz * p.nby * p.nbx;
+    const int total = p.in.N * per_frame;
+    for (int b = blockIdx.x; b < total; b += p.S) {
+        const int n = b / per_frame; int r = b % per_frame;
+        const int bx = r % p.nbx; r /= p.nbx;
+        const int by = r % p.nby, bz = r / p.nby;
+        const int oz0 = bz * p.BZ, oy0 = by * p.BY, ox0 = bx * p.BX;
+        __syncthreads();
+        for (int i = tid; i < BV * 8; i += 256) {
+            const int k = i >> 3, q = i & 7;
+            const int x = k % p.BX, y = (k / p.BX) % p.BY, z = k / (p.BX * p.BY);
+            const int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x, m = m0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oz < OD && oy < OH && ox < OW && m < p.M) v = load_act4(p.dy, n, oz, oy, ox, m);
+            *reinterpret_cast<f32x4*>(dys + k * 32 + 4 * q) = v;
+        }
+        const int iz0 = oz0 * p.stride - p.pad, iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+        if (MODE == 2) {
+            const int G = p.in.D;
+            for (int hv = tid; hv < HV; hv += 256) {
+                const int hx = hv % p.HX, hy = (hv / p.HX) % p.HY, hz = hv / (p.HX * p.HY);
+                const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)gz < (unsigned)G && (unsigned)gy < (unsigned)G && (unsigned)gx < (unsigned)G) {
+                    v[0] = p.in.p[(((size_t)n * G + gz) * G + gy) * G + gx];
+                    v[1] = lin_coord(gz, G); v[2] = lin_coord(gy, G); v[3] = lin_coord(gx, G);
+                }
+                *reinterpret_cast<f32x4*>(as + hv * 4) = v;
+            }
+        } else {
+            for (int i = tid; i < HV * 8; i += 256) {
+                const int hv = i >> 3, q = i & 7;
+                const int hx = hv % p.HX, hy = (hv / p.HX) % p.HY, hz = hv / (p.HX * p.HY);
+                const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx, c = n0 + 4 * q;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && c < p.Nc)
+                    v = load_act4(p.in, n, gz, gy, gx, c);
+                *reinterpret_cast<f32x4*>(as + hv * 32 + 4 * q) = v;
+            }
+        }
+        __syncthreads();
+        int pair = 0;
+        for (int z = 0; z < p.BZ; ++z)
+            for (int y = 0; y < p.BY; ++y)
+                for (int x0 = 0; x0 < p.BX; x0 += 2, ++pair) {
+                    if (MODE == 1 && (pair & 3) != w) continue;
+                    const int k = (z * p.BY + y) * p.BX + x0 + lh;
+                    const float a = dys[k * 32 + l31];
+                    const int hb = (((z * p.stride) * p.HY + y * p.stride) * p.HX + (x0 + lh) * p.stride) * CP + coloff;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        if (tv[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, as[hb + toff[j]], acc[j], 0, 0, 0);
+                }
+    }
+    const int slot = MODE == 1 ? blockIdx.x * 4 + w : blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        if (!tv[j]) continue;
+        const int t = MODE == 1 ? 0 : w + 4 * j;
+        float* dst = p.part + (((size_t)slot * gridDim.y + tp) * p.groups + t) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][r];
+    }
+}
+
+// dW[m][c][tap] (+)= sum over slots; thread order: c fastest (coalesced partial reads)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int slots, int tiles, int n_tiles, int groups,
+                                                           int M, int Cin, int taps, int k5occ, float* __restrict__ dW) {
+    const int total = M * Cin * taps;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c = i % Cin, m = (i / Cin) % M, tap = i / (Cin * M);
+        int tile, grp, col;
+        if (k5occ) { tile = m >> 5; grp = tap / 5; col = (tap % 5) * 4 + c; }
+        else { tile = (m >> 5) * n_tiles + (c >> 5); grp = tap; col = c & 31; }
+        const float* src = part + ((size_t)tile * groups + grp) * 1024 + (m & 31) * 32 + col;
+        const size_t stride = (size_t)tiles * groups * 1024;
+        float s = 0.f;
+        for (int k = 0; k < slots; ++k) s += src[(size_t)k * stride];
+        dW[((size_t)m * Cin + c) * taps + tap] = s;
+    }
+}
+
+#define NM_GNB_VB 512
+// grid (nblk, N)
+__global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restrict__ dA, TensorRef y, int voxels, float* __restrict__ part) {
+    __shared__ float sh[256 * 2];
+    const int n = blockIdx.y, blk = blockIdx.x, C = y.C;
+    const int lanes = 256 / C;
+    const int c = threadIdx.x % C, vl = threadIdx.x / C;
+    float s1 = 0.f, s2 = 0.f;
+    if (vl < lanes) {
+        const float sc = y.scale ? y.scale[(size_t)n * C + c] : 1.0f, shf = y.scale ? y.shift[(size_t)n * C + c] : 0.f;
+        const int v0 = blk * NM_GNB_VB, v1 = min(voxels, v0 + NM_GNB_VB);
+        for (int v = v0 + vl; v < v1; v += lanes) {
+            const size_t o = ((size_t)n * voxels + v) * C + c;
+            const float yy = y.p[o];
+            const float z = fmaf(yy, sc, shf);
+            const float dz = dA[o] * (z > 0.f ? 1.0f : y.slope);
+            s1 += dz; s2 += dz * yy;
+        }
+    }
+    sh[threadIdx.x * 2] = s1; sh[threadIdx.x * 2 + 1] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < lanes; ++l) { a += sh[(l * C + c) * 2]; b += sh[(l * C + c) * 2 + 1]; }
+        float* dst = part + (((size_t)n * gridDim.x + blk) * C + c) * 2;
+        dst[0] = a; dst[1] = b;
+    }
+}
+
+// one block per (frame, group); cpg <= 64 channels per group
+__global__ __launch_bounds__(256) void gnb_finalize_kernel(const float* __restrict__ bpart, int nblk_b, const float* __restrict__ fpart,
+                                                           int nblk_f, int C, int groups, int voxels, const float* __restrict__ gamma,
+                                                           float eps, float* __restrict__ coef, float* __restrict__ dgn) {
+    __shared__ double red[256 * 4];
+    __shared__ double chan[64 * 4];      // per channel: sum y, sum y^2, S1, S2
+    const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups;
+    const int L = 256 / cpg;             // partial lanes per channel
+    const int cl = threadIdx.x % cpg, ln = threadIdx.x / cpg, c = g * cpg + cl;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (ln < L) {
+        for (int b = ln; b < nblk_f; b += L) { const float* q = fpart + (((size_t)n * nblk_f + b) * C + c) * 2; a0 += q[0]; a1 += q[1]; }
+        for (int b = ln; b < nblk_b; b += L) { const float* q = bpart + (((size_t)n * nblk_b + b) * C + c) * 2; a2 += q[0]; a3 += q[1]; }
+    }
+    red[threadIdx.x * 4] = a0; red[threadIdx.x * 4 + 1] = a1; red[threadIdx.x * 4 + 2] = a2; red[threadIdx.x * 4 + 3] = a3;
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+        double s[4] = {0, 0, 0, 0};
+        for (int l = 0; l < L; ++l)
+            for (int j = 0; j < 4; ++j) s[j] += red[(l * cpg + threadIdx.x) * 4 + j];
+        for (int j = 0; j < 4; ++j) chan[threadIdx.x * 4 + j] = s[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+        const double Mcount = (double)voxels * cpg;
+        double sy = 0, syy = 0;
+        for (int j = 0; j < cpg; ++j) { sy += chan[j * 4]; syy += chan[j * 4 + 1]; }
+        const double mean = sy / Mcount;
+        double var = syy / Mcount - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double r = 1.0 / sqrt(var + (double)eps);
+        double m1 = 0, m2 = 0;
+        for (int j = 0; j < cpg; ++j) {
+            const double gm = gamma[g * cpg + j];
+            m1 += gm * chan[j * 4 + 2];
+            m2 += gm * r * (chan[j * 4 + 3] - mean * chan[j * 4 + 2]);
+        }
+        m1 /= Mcount; m2 /= Mcount;
+        const double S1 = chan[cl * 4 + 2], S2 = chan[cl * 4 + 3], sumy = chan[cl * 4];
+        const double c1 = r * gamma[c], c2 = -r * r * m2, c3 = -r * m1 + r * r * m2 * mean;
+        float* co = coef + ((size_t)n * C + c) * 4;
+        co[0] = (float)c1; co[1] = (float)c2; co[2] = (float)c3; co[3] = 0.f;
+        float* d = dgn + ((size_t)n * C + c) * 4;
+        d[0] = (float)(r * (S2 - mean * S1));
+        d[1] = (float)S1;
+        d[2] = (float)(c1 * S1 + c2 * sumy + c3 * (double)voxels);    // sum_v dy: gradient of the conv bias
+        d[3] = 0.f;
+    }
+}
+
+__global__ void sum_frames_kernel(const float* __restrict__ src, int N, int C, int stride, int off, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += src[((size_t)n * C + c) * stride + off];
+    out[c] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) s += (double)part[((size_t)r * C + c) * 2];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) out[c] = (float)sh[0];
+}
+
+__global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict__ dA, TensorRef y, const float* __restrict__ coef,
+                                                        float* __restrict__ dy) {
+    const size_t per_frame = (size_t)y.D * y.H * y.W * y.C;
+    const size_t total4 = (size_t)y.N * per_frame / 4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * 4;
+        const size_t n = e / per_frame;
+        const int c = (int)(e % y.C);
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y.p + e);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dA + e);
+        if (y.slope != 1.0f) {
+            f32x4 z = yy;
+            if (y.scale) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(y.scale + n * y.C + c);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(y.shift + n * y.C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[j] = fmaf(yy[j], sc[j], sh[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = z[j] > 0.f ? d[j] : d[j] * y.slope;
+        }
+        if (coef) {
+            const float* cf = coef + (n * y.C + c) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = fmaf(cf[j * 4], d[j], fmaf(cf[j * 4 + 1], yy[j], cf[j * 4 + 2]));
+        }
+        *reinterpret_cast<f32x4*>(dy + e) = d;
+    }
+}
+
+__device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1) {
+    float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    i1 = i0 + (i0 < I - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+// weight of fine index f on coarse index j along one axis (0 if f does not touch j)
+__device__ __forceinline__ float up_w(int f, int j, int I) {
+    if (f < 0 || f >= 2 * I) return 0.f;
+    int i0, i1; float l;
+    up_idx(f, I, i0, i1, l);
+    return (i0 == j ? 1.f - l : 0.f) + (i1 == j ? l : 0.f);
+}
+
+__global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __restrict__ dfine, int N, int D, int H, int W, int C,
+                                                                float* __restrict__ dcoarse) {
+    const int cq = C / 4;
+    const size_t total = (size_t)N * D * H * W * cq;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % cq); size_t r = i / cq;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); r /= H;
+        const int z = (int)(r % D); const size_t n = r / D;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = -1; a <= 2; ++a) {
+            const int fz = 2 * z + a; const float wz = up_w(fz, z, D);
+            if (wz == 0.f) continue;
+            for (int b = -1; b <= 2; ++b) {
+                const int fy = 2 * y + b; const float wy = up_w(fy, y, H);
+                if (wy == 0.f) continue;
+                for (int cc = -1; cc <= 2; ++cc) {
+                    const int fx = 2 * x + cc; const float wx = up_w(fx, x, W);
+                    if (wx == 0.f) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(dfine + ((((size_t)n * 2 * D + fz) * 2 * H + fy) * 2 * W + fx) * C + q * 4);
+                    const float wt = wz * wy * wx;
+                    acc[0] += wt * v[0]; acc[1] += wt * v[1]; acc[2] += wt * v[2]; acc[3] += wt * v[3];
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(dcoarse + i * 4) = acc;
+    }
+}
+
+__global__ void flip_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int csel, int taps, float* __restrict__ out) {
+    const int total = csel * Cout * taps;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i % taps, co = (i / taps) % Cout, ci = i / (taps * Cout);
+        out[i] = w[((size_t)co * Cin + ci) * taps + (taps - 1 - t)];
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
+}
+
+int grid_for(size_t work_items) { return (int)min((work_items + 255) / 256, (size_t)(256 * 16)); }
+
+struct WgradPlan { WgradParams p; int mode, m_tiles, slots; size_t lds, ws_floats; };
+
+WgradPlan plan_wgrad(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride, bool k5occ) {
+    WgradPlan q;
+    WgradParams& p = q.p;
+    p.ks = ks; p.stride = stride; p.M = M; p.Nc = Nc;
+    q.mode = k5occ ? 2 : (ks == 1 ? 1 : 0);
+    int bz = 4, by = 8, bx = 8;
+    if (stride == 2) { bz = 2; by = 4; bx = 8; }
+    p.BX = min(bx, (OW + 1) & ~1); p.BY = min(by, OH); p.BZ = min(bz, OD);
+    p.nbx = (OW + p.BX - 1) / p.BX; p.nby = (OH + p.BY - 1) / p.BY; p.nbz = (OD + p.BZ - 1) / p.BZ;
+    p.HZ = (p.BZ - 1) * stride + ks; p.HY = (p.BY - 1) * stride + ks; p.HX = (p.BX - 1) * stride + ks;
+    q.m_tiles = (M + 31) / 32;
+    p.n_tiles = k5occ ? 1 : (Nc + 31) / 32;
+    p.groups = k5occ ? 25 : ks * ks * ks;
+    const int tiles = q.m_tiles * p.n_tiles;
+    const int total = N * p.nbz * p.nby * p.nbx;
+    p.S = max(1, min(total, 512 / tiles));
+    q.slots = q.mode == 1 ? p.S * 4 : p.S;
+    q.lds = ((size_t)p.BZ * p.BY * p.BX * 32 + (size_t)p.HZ * p.HY * p.HX * (k5occ ? 4 : 32)) * sizeof(float);
+    q.ws_floats = (size_t)q.slots * tiles * p.groups * 1024;
+    return q;
+}
+
+template <int MODE, int NTW>
+int launch_wgrad_t(const WgradPlan& q, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<MODE, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            nm_set_error("wgrad: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<MODE, NTW>), dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
+    return nm_check_hip(hipGetLastError(), "wgrad launch");
+}
+
+int run_wgrad(WgradPlan& q, float* ws, float* dW, int cin_real, int taps, hipStream_t s) {
+    if (q.lds > 160 * 1024) { nm_set_error("wgrad: LDS tile of %zu bytes", q.lds); return NM_ERR_UNSUPPORTED; }
+    q.p.part = ws;
+    int rc;
+    if (q.mode == 2) rc = launch_wgrad_t<2, 7>(q, s);
+    else if (q.mode == 1) rc = launch_wgrad_t<1, 1>(q, s);
+    else if (q.p.ks == 2) rc = launch_wgrad_t<0, 2>(q, s);
+    else if (q.p.ks == 3) rc = launch_wgrad_t<0, 7>(q, s);
+    else { nm_set_error("wgrad: ks=%d unsupported", q.p.ks); return NM_ERR_UNSUPPORTED; }
+    if (rc) return rc;
+    const int tiles = q.m_tiles * q.p.n_tiles;
+    const int total = q.p.M * cin_real * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min((total + 255) / 256, 4096)), dim3(256), 0, s, ws, q.slots, tiles, q.p.n_tiles,
+                       q.p.groups, q.p.M, cin_real, taps, q.mode == 2 ? 1 : 0, dW);
+    return nm_check_hip(hipGetLastError(), "wgrad reduce launch");
+}
+
+}  // namespace
+
+size_t nm_wgrad_ws_floats(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride) {
+    return plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false).ws_floats;
+}
+size_t nm_wgrad_k5occ_ws_floats(int N, int G, int M) { return plan_wgrad(N, G, G, G, M, 4, 5, 1, true).ws_floats; }
+
+int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride, int pad, int cin_real, float* ws, float* dW,
+                    hipStream_t s) {
+    if (in.C % 4 || dy.C % 4 || in.N != dy.N) { nm_set_error("wgrad: channel counts must be multiples of 4 and frame counts equal"); return NM_ERR_ARG; }
+    WgradPlan q = plan_wgrad(in.N, dy.D, dy.H, dy.W, dy.C, in.C, ks, stride, false);
+    q.p.in = in; q.p.dy = dy; q.p.pad = pad;
+    return run_wgrad(q, ws, dW, cin_real, ks * ks * ks, s);
+}
+
+int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s) {
+    if (dy.C % 4 || dy.D != G) { nm_set_error("wgrad_k5occ: bad dy"); return NM_ERR_ARG; }
+    WgradPlan q = plan_wgrad(N, G, G, G, dy.C, 4, 5, 1, true);
+    TensorRef in; in.p = occ; in.scale = in.shift = nullptr; in.slope = 1.0f; in.N = N; in.D = in.H = in.W = G; in.C = 1;
+    q.p.in = in; q.p.dy = dy; q.p.pad = 2;
+    return run_wgrad(q, ws, dW, 4, 125, s);
+}
+
+int nm_gnb_blocks_per_frame(int voxels) { return (voxels + NM_GNB_VB - 1) / NM_GNB_VB; }
+
+int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s) {
+    if (y.C > 256 || y.C <= 0) { nm_set_error("gnb_partials: C=%d unsupported", y.C); return NM_ERR_ARG; }
+    const int voxels = y.D * y.H * y.W;
+    hipLaunchKernelGGL(gnb_partials_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part);
+    return nm_check_hip(hipGetLastError(), "gnb_partials launch");
+}
+
+int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, int nblk_f, int N, int C, int groups, int voxels,
+                           const float* gamma, float eps, float* coef, float* dgn, hipStream_t s) {
+    if (groups <= 0 || C % groups || C / groups > 64) { nm_set_error("gnb_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
+    hipLaunchKernelGGL(gnb_finalize_kernel, dim3(N * groups), dim3(256), 0, s, bpart, nblk_b, fpart, nblk_f, C, groups, voxels, gamma,
+                       eps, coef, dgn);
+    return nm_check_hip(hipGetLastError(), "gnb_finalize launch");
+}
+
+int nm_launch_sum_frames(const float* src, int N, int C, int stride, int off, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_frames_kernel, dim3((C + 63) / 64), dim3(64), 0, s, src, N, C, stride, off, out);
+    return nm_check_hip(hipGetLastError(), "sum_frames launch");
+}
+
+int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(C), dim3(256), 0, s, part, rows, C, out);
+    return nm_check_hip(hipGetLastError(), "sum_partials launch");
+}
+
+int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s) {
+    if (y.C % 4) { nm_set_error("gnb_apply: C %% 4 != 0"); return NM_ERR_ARG; }
+    const size_t total4 = (size_t)y.N * y.D * y.H * y.W * y.C / 4;
+    hipLaunchKernelGGL(gnb_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dA, y, coef, dy);
+    return nm_check_hip(hipGetLastError(), "gnb_apply launch");
+}
+
+int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s) {
+    if (C % 4) { nm_set_error("upsample2_adjoint: C %% 4 != 0"); return NM_ERR_ARG; }
+    const size_t total = (size_t)N * D * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2_adjoint_kernel, dim3(grid_for(total)), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse);
+    return nm_check_hip(hipGetLastError(), "upsample2_adjoint launch");
+}
+
+int nm_launch_flip_weight(const float* w, int Cout, int Cin, int csel, int ks, float* out, hipStream_t s) {
+    const int taps = ks * ks * ks, total = csel * Cout * taps;
+    hipLaunchKernelGGL(flip_weight_kernel, dim3(min((total + 255) / 256, 4096)), dim3(256), 0, s, w, Cout, Cin, csel, taps, out);
+    return nm_check_hip(hipGetLastError(), "flip_weight launch");
+}
+
+int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, src, n);
+    return nm_check_hip(hipGetLastError(), "axpy launch");
+}

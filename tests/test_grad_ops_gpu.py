@@ -1,0 +1,154 @@
+"""Op-level parity of the backward kernels (detector-mode training): each HIP kernel family, called
+through the C ABI, against torch autograd of the same ATen CPU op the reference trains with (train.py:388-404).
+Tolerance 2e-5 relative to the gradient's max magnitude, as for the forward ops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_ops_gpu import ctx, to_cl, from_cl, relerr, dev  # noqa: F401  (ctx is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-5
+
+BWD_CASES = [
+    # Cin, Cout, ks, stride, pad, size, N, prologue, up2, dgrad_channels
+    (32, 32, 3, 1, 1, 16, 2, True, False, 32),
+    (64, 32, 3, 1, 1, 12, 3, True, False, 64),
+    (128, 64, 3, 1, 1, 8, 2, False, False, 128),
+    (48, 72, 3, 1, 1, 4, 3, True, False, 48),
+    (72, 72, 3, 1, 1, 2, 3, False, False, 72),
+    (72, 48, 3, 1, 1, 5, 2, True, False, 72),
+    (64, 128, 1, 1, 0, 8, 2, False, False, 64),
+    (128, 24, 1, 1, 0, 8, 2, True, False, 128),
+    (179, 128, 1, 1, 0, 6, 2, False, False, 176),
+    (32, 32, 2, 2, 0, 16, 2, True, False, 32),
+    (48, 48, 2, 2, 0, 5, 2, False, False, 48),
+    (64, 64, 2, 2, 0, 8, 3, True, False, 64),
+    (128, 64, 3, 1, 1, 6, 2, True, True, 128),
+    (64, 32, 3, 1, 1, 8, 2, True, True, 64),
+    (16, 32, 3, 1, 1, 5, 2, False, True, 16),
+]
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "split16"])
+@pytest.mark.parametrize("case", BWD_CASES, ids=lambda c: "ci%d_co%d_k%d_s%d_d%d%s" % (c[0], c[1], c[2], c[3], c[5], "_up" if c[8] else ""))
+def test_conv3d_backward(ctx, case, mode):
+    from neural_marionette_amd import _lib
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, mode), "set_conv_mode")
+    Cin, Cout, ks, stride, pad, size, N, prologue, up2, csel = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    dims = (size, size, size)
+    x = torch.randn(N, Cin, *dims, generator=g)
+    w = (torch.randn(Cout, Cin, ks, ks, ks, generator=g) / (Cin * ks ** 3) ** 0.5).requires_grad_(True)
+    b = (torch.randn(Cout, generator=g) * 0.1).requires_grad_(True)
+    cp = (Cin + 7) // 8 * 8
+    if prologue:
+        sc = torch.rand(N, Cin, generator=g) + 0.5
+        sh = torch.randn(N, Cin, generator=g) * 0.3
+        a = F.leaky_relu(x * sc[:, :, None, None, None] + sh[:, :, None, None, None], 0.01)
+        scp = torch.zeros(N, cp); scp[:, :Cin] = sc
+        shp = torch.zeros(N, cp); shp[:, :Cin] = sh
+        slope = 0.01
+    else:
+        a, scp, shp, slope = x.clone(), None, None, 1.0
+    a = a.detach().requires_grad_(True)
+    inp = F.interpolate(a, scale_factor=2, mode="trilinear", align_corners=False) if up2 else a
+    y = F.conv3d(inp, w, b, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    d_in = torch.full((N, *dims, csel), float("nan")).cuda()
+    d_w = torch.full(w.shape, float("nan")).cuda()
+    d_b = torch.full((Cout,), float("nan")).cuda()
+    xd, wd, scd, shd, dyd = to_cl(x), dev(w.detach()), dev(scp), dev(shp), to_cl(dy, Cout)
+    _lib.check(ctx.lib.nm_op_conv3d_backward(ctx.handle, _lib.ptr(xd), N, *dims, Cin, _lib.ptr(scd), _lib.ptr(shd), slope,
+                                             _lib.ptr(wd), Cout, ks, stride, pad, int(up2), _lib.ptr(dyd), _lib.ptr(d_in), csel,
+                                             _lib.ptr(d_w), _lib.ptr(d_b)), "op_conv3d_backward")
+    torch.cuda.synchronize()
+    for name, got, ref in (("d_weight", d_w.cpu(), w.grad), ("d_bias", d_b.cpu(), b.grad),
+                           ("d_in", from_cl(d_in, csel), a.grad[:, :csel])):
+        assert torch.isfinite(got).all(), f"{name}: unwritten / non-finite"
+        e = relerr(got, ref)
+        assert e < REL, f"{name} rel err {e:.3e}"
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, 1), "set_conv_mode")
+
+
+@pytest.mark.parametrize("Cout,G,N", [(32, 16, 2), (64, 12, 3), (32, 32, 1)])
+def test_conv5_occ_backward(ctx, Cout, G, N):
+    from neural_marionette_amd import _lib
+    g = torch.Generator().manual_seed(Cout * 7 + G)
+    occ = (torch.rand(N, 1, G, G, G, generator=g) < 0.05).float()
+    lin = torch.linspace(-1.0, 1.0, G)
+    zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
+    coords = torch.stack([zz, yy, xx])[None].expand(N, -1, -1, -1, -1)
+    inp = torch.cat([occ, coords], dim=1)
+    w = (torch.randn(Cout, 4, 5, 5, 5, generator=g) / 500 ** 0.5).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    y = F.conv3d(inp, w, b, padding=2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    d_w = torch.full(w.shape, float("nan")).cuda(); d_b = torch.full((Cout,), float("nan")).cuda()
+    occd, dyd = occ[:, 0].contiguous().cuda(), to_cl(dy, Cout)      # (named: the buffers must outlive the call)
+    _lib.check(ctx.lib.nm_op_conv5_occ_backward(ctx.handle, _lib.ptr(occd), N, G, Cout, _lib.ptr(dyd),
+                                                _lib.ptr(d_w), _lib.ptr(d_b)), "op_conv5_occ_backward")
+    torch.cuda.synchronize()
+    assert relerr(d_w.cpu(), w.grad) < REL
+    assert relerr(d_b.cpu(), b.grad) < REL
+
+
+@pytest.mark.parametrize("Cin,Cout,size,outpad,prologue,N", [(72, 48, 2, 0, True, 3), (48, 32, 4, 0, False, 2), (32, 64, 8, 0, True, 2),
+                                                             (72, 48, 2, 1, True, 2), (48, 32, 5, 1, False, 2)])
+def test_convT2_backward(ctx, Cin, Cout, size, outpad, prologue, N):
+    from neural_marionette_amd import _lib
+    g = torch.Generator().manual_seed(Cin * 3 + Cout + size + outpad)
+    dims = (size, size, size)
+    x = torch.randn(N, Cin, *dims, generator=g)
+    w = (torch.randn(Cin, Cout, 2, 2, 2, generator=g) / (Cin * 8) ** 0.5).requires_grad_(True)
+    b = (torch.randn(Cout, generator=g) * 0.1).requires_grad_(True)
+    if prologue:
+        sc = torch.rand(N, Cin, generator=g) + 0.5
+        sh = torch.randn(N, Cin, generator=g) * 0.3
+        a = F.leaky_relu(x * sc[:, :, None, None, None] + sh[:, :, None, None, None], 0.01)
+        slope = 0.01
+    else:
+        a, sc, sh, slope = x.clone(), None, None, 1.0
+    a = a.detach().requires_grad_(True)
+    y = F.conv_transpose3d(a, w, b, stride=2, output_padding=outpad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    d_in = torch.full((N, *dims, Cin), float("nan")).cuda()
+    d_w = torch.full(w.shape, float("nan")).cuda(); d_b = torch.full((Cout,), float("nan")).cuda()
+    xd, scd, shd, wd, dyd = to_cl(x), dev(sc), dev(sh), dev(w.detach()), to_cl(dy, Cout)
+    _lib.check(ctx.lib.nm_op_convT2_backward(ctx.handle, _lib.ptr(xd), N, *dims, Cin, _lib.ptr(scd), _lib.ptr(shd), slope,
+                                             _lib.ptr(wd), Cout, outpad, _lib.ptr(dyd), _lib.ptr(d_in),
+                                             _lib.ptr(d_w), _lib.ptr(d_b)), "op_convT2_backward")
+    torch.cuda.synchronize()
+    assert relerr(d_w.cpu(), w.grad) < REL
+    assert relerr(d_b.cpu(), b.grad) < REL
+    assert relerr(from_cl(d_in, Cin), a.grad) < REL
+
+
+@pytest.mark.parametrize("C,groups,size,N,slope", [(32, 2, 16, 2, 0.01), (64, 4, 8, 3, 0.01), (128, 8, 6, 2, 1.0), (72, 4, 2, 3, 0.01),
+                                                   (48, 3, 5, 2, 1.0), (256, 16, 4, 1, 0.01)])
+def test_gn_backward(ctx, C, groups, size, N, slope):
+    from neural_marionette_amd import _lib
+    g = torch.Generator().manual_seed(C + size)
+    y = (torch.randn(N, C, size, size, size, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gam = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    bet = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    out = F.leaky_relu(F.group_norm(y, groups, gam, bet, 1e-5), slope)
+    dA = torch.randn(out.shape, generator=g)
+    out.backward(dA)
+    V = size ** 3
+    dy = torch.full((N, size, size, size, C), float("nan")).cuda()
+    dg = torch.zeros(C).cuda(); db = torch.zeros(C).cuda(); dbias = torch.zeros(C).cuda()
+    yd, gd, bd, dAd = to_cl(y.detach(), C), dev(gam.detach()), dev(bet.detach()), to_cl(dA, C)
+    _lib.check(ctx.lib.nm_op_gn_backward(ctx.handle, _lib.ptr(yd), N, V, C, groups, _lib.ptr(gd),
+                                         _lib.ptr(bd), slope, _lib.ptr(dAd), _lib.ptr(dy), _lib.ptr(dg),
+                                         _lib.ptr(db), _lib.ptr(dbias)), "op_gn_backward")
+    torch.cuda.synchronize()
+    assert relerr(from_cl(dy, C), y.grad) < REL
+    assert relerr(dg.cpu(), gam.grad) < REL
+    assert relerr(db.cpu(), bet.grad) < REL
+    ref_bias = y.grad.sum(dim=(0, 2, 3, 4))
+    assert (dbias.cpu() - ref_bias).abs().max().item() < REL * max(y.grad.abs().sum(dim=(0, 2, 3, 4)).max().item(), 1e-30)
