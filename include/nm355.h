@@ -156,6 +156,22 @@ int nm_vrnn_encode_backward(nm_ctx* ctx, const float* dscal2, const nm_named_gra
 int nm_adam_step(nm_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                  int32_t step, float lr, float beta1, float beta2, float eps);
 
+/* ---- training, detector mode (pretrained_mode = 0: train.py:270-276, the detector trains on its 11 losses) ----
+ * nm_ctx_set_training(ctx, 1) makes nm_ctx_set_weights also pack the weights of the data-gradient convolutions
+ * (flipped / transposed copies); it invalidates the current weights, so call nm_ctx_set_weights afterwards.
+ * nm_detector_forward_train = nm_detector_forward, but every activation stays in a ctx-owned arena (sized once for
+ * forward + backward) together with a tape of the layer sequence.  The caller keeps vox, keypoints and recon alive
+ * and unchanged until the backward call.
+ * nm_detector_backward back-propagates L = sum_i dlosses11[i] * loss_i (dlosses11: DEVICE vector, the loss weights as
+ * autograd hands them over; order as losses11) through the decoder, the losses, the heads and both feature nets
+ * (= autograd of kypt_detector.py:81-169 under train.py:388-404) and overwrites the gradient buffers named like the
+ * reference's kypt_detector.* parameters (all 315 of them must be present; layouts as in the state_dict). */
+int nm_ctx_set_training(nm_ctx* ctx, int32_t on);
+int nm_detector_forward_train(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t affinity_on,
+                              float* keypoints, float* heatmaps, float* first_feature, float* recon,
+                              float* affinity, float* losses11);
+int nm_detector_backward(nm_ctx* ctx, const float* dlosses11, const nm_named_grad* grads, int32_t count);
+
 /* HSVRNNBVH.generate — model/hsvrnn_bvh.py:158-234.
  *  keypoints_cond (B,Tcond,K,4); eps_post (Tcond,S,B,Z); eps_prior (Ttot-Tcond,B,Z);
  *  out_cond (B,Tcond,K,4), out_gen (B,Ttot-Tcond,K,4); h_last (B,H) or NULL. */

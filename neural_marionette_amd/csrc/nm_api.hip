@@ -85,6 +85,8 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     for (void* p : ctx->owned) (void)hipFree(p);
     if (ctx->ws.base) (void)hipFree(ctx->ws.base);
     if (ctx->ws2.base) (void)hipFree(ctx->ws2.base);
+    if (ctx->ws_t.base) (void)hipFree(ctx->ws_t.base);
+    nm_net_free_tape(ctx);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side}) if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -106,6 +108,12 @@ int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t coun
     }
     (void)hipSetDevice(ctx->cfg.device);
     return nm_net_set_weights(ctx, sd);
+}
+
+int nm_ctx_set_training(nm_ctx* ctx, int32_t on) {
+    if (!ctx) { nm_set_error("set_training: null ctx"); return NM_ERR_ARG; }
+    if (ctx->training != (on != 0)) { ctx->training = on != 0; ctx->has_weights = false; }     // the next call needs nm_ctx_set_weights again
+    return NM_OK;
 }
 
 int nm_set_conv_mode(nm_ctx* ctx, int32_t mode) {

@@ -32,11 +32,20 @@ struct ConvW {
     float* wp = nullptr;      // fp32 packed [tap][Cin/4][Co_pad][4]
     void* wp16 = nullptr;     // split-fp16 packed (Cin % 16 == 0 only), see nm_conv.hip
     float* bias = nullptr;
+    // training (nm_ctx_set_training): state_dict key prefix and the weights of the data-gradient convolution
+    std::string key;
+    int csel = 0, cd_pad = 0;  // input channels that receive a gradient (Cin rounded down to 8) and their packed width
+    float* wd = nullptr;       // ks 1/3: flipped + transposed, fp32 packed [tap][Cout/4][cd_pad][4]
+    void* wd16 = nullptr;      //         same, split-fp16 (Cout % 16 == 0)
+    float* wt = nullptr;       // ks 2 (stride 2): [tap][Cout][Cin] for the transposed-conv kernel
 };
-struct NormW { int C = 0, groups = 0; float* gamma = nullptr; float* beta = nullptr; };
+struct NormW { int C = 0, groups = 0; float* gamma = nullptr; float* beta = nullptr; std::string key; };
 struct ResW { ConvW c1, c2, cs; NormW n1, n2, ns; bool has_skip = false; };
 struct PoolW { ConvW c; NormW n; };
-struct UpW { int Cin = 0, Cout = 0; float* w = nullptr; float* bias = nullptr; NormW n; };
+struct UpW {
+    int Cin = 0, Cout = 0; float* w = nullptr; float* bias = nullptr; NormW n;
+    std::string key; int cd_pad = 0; float* wd = nullptr; void* wd16 = nullptr;   // training: the adjoint k2 s2 conv (packed)
+};
 struct HourglassW { PoolW p1, p2, p3; ResW e1, e2, e3, d3, d2, d1, s1, s2, s3; UpW u3, u2, u1; };
 struct FeatNetW {
     ConvW c0; NormW n0; PoolW p1, p3; ResW r2, r5; HourglassW hg;
@@ -49,6 +58,7 @@ struct DetectorW {
     FeatNetW frame, clip;
     ConvW head, clip_head, adjust;
     float* prop = nullptr;                 // [w0, w1, b] of propagate_heatmaps (device)
+    float* zeros = nullptr;                // 512 zeros (bias of the data-gradient convolutions)
     ConvW d1, d4, d8, d11; NormW dn2, dn5, dn9, dn12;
     float* d14 = nullptr;                  // [32 weights, bias] of the final 1x1 conv (device)
     float* affinity_params = nullptr;      // (N,K,K-1)
@@ -74,6 +84,9 @@ struct nm_ctx {
     Arena ws2;                             // scratch of work issued on stream2 (VRNN beside the decoder)
     std::vector<void*> owned;              // weight allocations
     bool has_weights = false;
+    bool training = false;                 // nm_ctx_set_training: set_weights also packs the data-gradient weights
+    Arena ws_t;                            // activations retained between nm_detector_forward_train and nm_detector_backward
+    struct TrainTape* tape = nullptr;      // what the backward pass needs of the last training forward (nm_net.hip)
     DetectorW det;
     VrnnW vrnn;
 };
@@ -82,4 +95,5 @@ int nm_ctx_reserve(nm_ctx* ctx, size_t bytes);        // grow the workspace (syn
 float* nm_ctx_weight_alloc(nm_ctx* ctx, size_t floats);
 
 // nm_net.hip
+void nm_net_free_tape(nm_ctx* ctx);
 int nm_net_set_weights(nm_ctx* ctx, const std::map<std::string, std::pair<const float*, int64_t>>& sd);

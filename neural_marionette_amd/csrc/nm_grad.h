@@ -28,11 +28,19 @@ int nm_launch_sum_frames(const float* src, int N, int C, int stride, int off, fl
 // out[c] = sum_{n,blk} part[((n*nblk + blk)*C + c)*2]       (bias gradient of a conv without GroupNorm)
 int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipStream_t s);
 // dy = c1*dz + c2*y + c3 (coef) or dy = dz (coef == nullptr)
-int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s);
+// amax (optional): device word that receives max |dy| as float bits (integer atomicMax; zero it first)
+int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax = nullptr);
+// Power-of-two operand scaling of the data-gradient convolutions in the split-fp16 conv mode: gradients are often
+// below the fp16 normal range (6e-5), where the hi/lo split loses its low bits; dy is read as dy * 2^k through the lazy
+// affine of the conv kernels and the result is multiplied by 2^-k (exact).
+int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s);
+int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* sc2 /*[2^k, 2^-k]*/, hipStream_t s);
+int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s);
 
 // ---- misc --------------------------------------------------------------------------------------------------------------
 // adjoint of nn.Upsample(x2, trilinear, align_corners=False): dfine [N][2D][2H][2W][C] -> dcoarse [N][D][H][W][C]
-int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s);
+int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s,
+                                const float* mul = nullptr /* device scalar multiplied into the result */);
 // OIDHW weights of the data-gradient convolution: out[ci][co][K-1-tap] = w[co][ci][tap], ci < csel
 int nm_launch_flip_weight(const float* w, int Cout, int Cin, int csel, int ks, float* out, hipStream_t s);
 int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s);      // dst += src

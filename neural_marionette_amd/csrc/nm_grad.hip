@@ -258,8 +258,18 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     if (threadIdx.x == 0) out[c] = (float)sh[0];
 }
 
+// block max of |v| -> one integer atomicMax per block (non-negative floats order like their bit patterns: deterministic)
+__device__ __forceinline__ void block_absmax(float m, unsigned* amax) {
+    __shared__ float shm[256];
+    shm[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) shm[threadIdx.x] = fmaxf(shm[threadIdx.x], shm[threadIdx.x + st]); __syncthreads(); }
+    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(shm[0]));
+}
+
 __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict__ dA, TensorRef y, const float* __restrict__ coef,
-                                                        float* __restrict__ dy) {
+                                                        float* __restrict__ dy, unsigned* __restrict__ amax) {
+    float mx = 0.f;
     const size_t per_frame = (size_t)y.D * y.H * y.W * y.C;
     const size_t total4 = (size_t)y.N * per_frame / 4;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
@@ -285,6 +295,36 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
             for (int j = 0; j < 4; ++j) d[j] = fmaf(cf[j * 4], d[j], fmaf(cf[j * 4 + 1], yy[j], cf[j * 4 + 2]));
         }
         *reinterpret_cast<f32x4*>(dy + e) = d;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+    }
+    if (amax) block_absmax(mx, amax);
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ amax) {
+    float mx = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(x + i * 4);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+    }
+    block_absmax(mx, amax);
+}
+
+// scale[i] = 2^k with max * 2^k in (128, 256] (so that the fp16 hi/lo split of the data-gradient conv sees O(100) operands,
+// far from the fp16 denormal range); sc2[0] = 2^k, sc2[1] = 2^-k
+__global__ void make_scale_kernel(const unsigned* __restrict__ amax, int count, float* __restrict__ scale, float* __restrict__ sc2) {
+    const float mx = __uint_as_float(*amax);
+    float sc = 1.0f;
+    if (mx > 0.f && mx < INFINITY) { int e; frexpf(mx, &e); sc = ldexpf(1.0f, 8 - e); }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) scale[i] = sc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc2[0] = sc; sc2[1] = 1.0f / sc; }
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ x, size_t n4, const float* __restrict__ mul) {
+    const float m = *mul;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 d = *reinterpret_cast<f32x4*>(x + i * 4);
+        d[0] *= m; d[1] *= m; d[2] *= m; d[3] *= m;
+        *reinterpret_cast<f32x4*>(x + i * 4) = d;
     }
 }
 
@@ -304,7 +344,8 @@ __device__ __forceinline__ float up_w(int f, int j, int I) {
 }
 
 __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __restrict__ dfine, int N, int D, int H, int W, int C,
-                                                                float* __restrict__ dcoarse) {
+                                                                float* __restrict__ dcoarse, const float* __restrict__ mul) {
+    const float mm = mul ? *mul : 1.0f;
     const int cq = C / 4;
     const size_t total = (size_t)N * D * H * W * cq;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -328,6 +369,7 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __r
                 }
             }
         }
+        acc[0] *= mm; acc[1] *= mm; acc[2] *= mm; acc[3] *= mm;
         *reinterpret_cast<f32x4*>(dcoarse + i * 4) = acc;
     }
 }
@@ -450,17 +492,34 @@ int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipSt
     return nm_check_hip(hipGetLastError(), "sum_partials launch");
 }
 
-int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s) {
+int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax) {
     if (y.C % 4) { nm_set_error("gnb_apply: C %% 4 != 0"); return NM_ERR_ARG; }
     const size_t total4 = (size_t)y.N * y.D * y.H * y.W * y.C / 4;
-    hipLaunchKernelGGL(gnb_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dA, y, coef, dy);
+    hipLaunchKernelGGL(gnb_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dA, y, coef, dy, amax);
     return nm_check_hip(hipGetLastError(), "gnb_apply launch");
 }
 
-int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s) {
+int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s) {
+    if (n % 4) { nm_set_error("absmax: n %% 4 != 0"); return NM_ERR_ARG; }
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, amax);
+    return nm_check_hip(hipGetLastError(), "absmax launch");
+}
+
+int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* sc2, hipStream_t s) {
+    hipLaunchKernelGGL(make_scale_kernel, dim3((count + 255) / 256), dim3(256), 0, s, amax, count, scale, sc2);
+    return nm_check_hip(hipGetLastError(), "make_scale launch");
+}
+
+int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s) {
+    if (n % 4) { nm_set_error("scale_by: n %% 4 != 0"); return NM_ERR_ARG; }
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, mul);
+    return nm_check_hip(hipGetLastError(), "scale_by launch");
+}
+
+int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s, const float* mul) {
     if (C % 4) { nm_set_error("upsample2_adjoint: C %% 4 != 0"); return NM_ERR_ARG; }
     const size_t total = (size_t)N * D * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2_adjoint_kernel, dim3(grid_for(total)), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse);
+    hipLaunchKernelGGL(upsample2_adjoint_kernel, dim3(grid_for(total)), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse, mul);
     return nm_check_hip(hipGetLastError(), "upsample2_adjoint launch");
 }
 

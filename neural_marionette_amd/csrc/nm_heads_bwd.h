@@ -1,0 +1,25 @@
+// launchers of nm_heads_bwd.hip (adjoints of nm_heads.hip); `dloss` = device vector d(total)/d(loss_i), i < 11
+#pragma once
+#include "nm_common.h"
+
+int nm_tail_bwd_blocks(int G);
+// dA [F][G^3][C] = gradient w.r.t. the activated decoder output; part [F][blocks][C+1] -> (d w14, d b14) via nm_launch_sum_rows
+int nm_launch_decoder_tail_bwd(const TensorRef& x, const float* w14, const float* target, const float* recon, const float* dloss, int G,
+                               float* dA, float* part, hipStream_t s);
+int nm_launch_sum_rows(const float* part, int rows, int cols, float* out, hipStream_t s);
+int nm_chamfer_bwd_blocks(int G);
+// ws: F * blocks * K * 3 floats; dkp [F][K][4] is accumulated into
+int nm_launch_chamfer_bwd(const float* target, const float* keypoints, const float* tail_part, int tail_blocks, const float* dloss, int F,
+                          int K, int G, float* ws, float* dkp, hipStream_t s);
+// dcomb [F][g^3][Cd] (channels [0,K) gauss_t | [K,K+Fd) first feature | [K+Fd,2K+Fd) gauss_0); ws: F*K*8 floats
+int nm_launch_combined_bwd(const float* dcomb, int Cd, const float* table, const float* keypoints, int B, int T, int K, int Fd, int g,
+                           float width, float* ws, float* dfeat, float* dkp, hipStream_t s);
+size_t nm_heat_bwd_ws_floats(int F, int K, int g);
+int nm_launch_heat_bwd(const float* head, const float* clip_head, const float* prop, const float* heat_part, const float* heat_mean,
+                       const float* keypoints, const float* dkp, const float* dloss, int B, int T, int K, int g, float* ws, float* dhead,
+                       float* dchead_t, float* dclip_head, float* dprop, hipStream_t s);
+// dinfl [B][K][K] (written when affinity != nullptr)
+int nm_launch_clip_loss_bwd(const float* keypoints, const float* affinity, const float* dloss, int B, int T, int K, int N, float sep_sigma,
+                            int use_traj, float* dkp, float* dinfl, hipStream_t s);
+int nm_launch_affinity_bwd(const float* params, const float* affinity, const float* dinfl, const float* dloss, int B, int N, int K,
+                           float* dparams, hipStream_t s);

@@ -12,8 +12,36 @@
 // modules/vox_modules.py:8-120.
 #include "nm_ctx.h"
 #include "nm_heads.h"
+#include "nm_grad.h"
+#include "nm_heads_bwd.h"
 #include <cmath>
 #include <functional>
+
+// ---- what a training forward leaves behind for nm_detector_backward (all pointers into ctx->ws_t or caller buffers) --------
+struct ConvRec {
+    const ConvW* w = nullptr; const NormW* gn = nullptr;
+    TensorRef in{}, out{};                       // lazy input / lazy output (raw conv result + pending GN affine + slope)
+    const float* fpart = nullptr; int nblk = 0;  // forward GroupNorm partial sums of the conv epilogue
+    int stride = 1, pad = 0; bool up2 = false;
+};
+struct ResRec { ConvRec c1, c2, cs; bool has_skip = false; };
+struct UpRec { const UpW* w = nullptr; TensorRef in{}, out{}; const float* fpart = nullptr; int nblk = 0; };
+struct HgRec { ResRec s1, e1, s2, e2, s3, e3, d3, d2, d1; ConvRec p1, p2, p3; UpRec u3, u2, u1; };
+struct FeatRec {
+    const FeatNetW* w = nullptr; const float* occ = nullptr; int N = 0, G = 0;
+    TensorRef first{}; const float* fpart0 = nullptr; int nblk0 = 0;
+    ConvRec p1, p3; ResRec r2, r5; HgRec hg;
+};
+struct TrainTape {
+    bool valid = false;
+    int B = 0, T = 0, affinity_on = 0;
+    FeatRec frame, clip;
+    ConvRec head, clip_head, adjust, d1, d4, d8, d11;
+    const float *vox = nullptr, *feat = nullptr, *head_out = nullptr, *clip_head_out = nullptr, *heat_part = nullptr, *heat_mean = nullptr;
+    const float *tail_part = nullptr, *aff = nullptr, *table = nullptr, *clip_in = nullptr;
+    const float *keypoints = nullptr, *recon = nullptr;       // caller buffers (kept alive by the Python autograd node)
+    size_t fwd_top = 0;                                       // ws_t high-water mark of the forward
+};
 
 namespace {
 
@@ -48,7 +76,7 @@ struct Loader {
         return dst;
     }
     ConvW conv(const std::string& p, int Cout, int Cin, int ks) {
-        ConvW w; w.Cin = Cin; w.Cout = Cout; w.ks = ks; w.Cin_pad = (Cin + 7) & ~7; w.Co_pad = (Cout + 31) & ~31;
+        ConvW w; w.Cin = Cin; w.Cout = Cout; w.ks = ks; w.Cin_pad = (Cin + 7) & ~7; w.Co_pad = (Cout + 31) & ~31; w.key = p;
         const float* src = get(p + ".weight", (int64_t)Cout * Cin * ks * ks * ks);
         w.bias = copy(p + ".bias", Cout);
         if (!src) return w;
@@ -60,11 +88,35 @@ struct Loader {
             if (!w.wp16) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
             r = nm_launch_pack_conv_weight16(src, Cout, Cin, ks, w.wp16, w.Co_pad, c->stream);
         }
+        if (!r && c->training && ks != 5) r = dgrad_packs(src, w);
         if (r && !rc) rc = r;
         return w;
     }
+    // weights of the data-gradient convolution (training only): dX = conv(dY, flip/transpose(W)) for ks 1/3 (stride 1),
+    // dX = convT2(dY, W) for the k2 s2 pool convs
+    int dgrad_packs(const float* src, ConvW& w) {
+        const int taps = w.ks * w.ks * w.ks;
+        w.csel = w.Cin & ~7; w.cd_pad = (w.csel + 31) & ~31;
+        if (w.ks == 2) {
+            w.wt = nm_ctx_weight_alloc(c, (size_t)w.Cin * w.Cout * 8);
+            if (!w.wt) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
+            return nm_launch_transpose_convT_weight(src, w.Cout, w.Cin, w.wt, c->stream);
+        }
+        float* wf = nm_ctx_weight_alloc(c, (size_t)w.csel * w.Cout * taps);
+        const size_t fl = nm_packed_weight_floats(w.ks, w.Cout, w.cd_pad);
+        w.wd = nm_ctx_weight_alloc(c, fl);
+        if (!wf || !w.wd) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
+        int r = nm_launch_flip_weight(src, w.Cout, w.Cin, w.csel, w.ks, wf, c->stream);
+        if (!r) r = nm_launch_pack_conv_weight(wf, w.csel, w.Cout, w.ks, w.wd, w.Cout, w.cd_pad, c->stream);
+        if (!r && w.Cout % 16 == 0) {
+            w.wd16 = nm_ctx_weight_alloc(c, fl);
+            if (!w.wd16) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
+            r = nm_launch_pack_conv_weight16(wf, w.csel, w.Cout, w.ks, w.wd16, w.cd_pad, c->stream);
+        }
+        return r;
+    }
     NormW norm(const std::string& p, int C) {
-        NormW n; n.C = C; n.groups = C / 16;
+        NormW n; n.C = C; n.groups = C / 16; n.key = p;
         n.gamma = copy(p + ".weight", C); n.beta = copy(p + ".bias", C);
         return n;
     }
@@ -80,10 +132,21 @@ struct Loader {
         PoolW w; w.c = conv(p + ".stride_conv.0", C, C, 2); w.n = norm(p + ".stride_conv.1", C); return w;
     }
     UpW up(const std::string& p, int ci, int co) {
-        UpW u; u.Cin = ci; u.Cout = co;
+        UpW u; u.Cin = ci; u.Cout = co; u.key = p + ".block.0";
         const float* src = get(p + ".block.0.weight", (int64_t)ci * co * 8);
         u.w = nm_ctx_weight_alloc(c, (size_t)ci * co * 8);
         if (src && u.w) { int r = nm_launch_transpose_convT_weight(src, ci, co, u.w, c->stream); if (r && !rc) rc = r; }
+        if (src && c->training) {      // the adjoint of the transposed conv is the k2 s2 conv with (Cin, Cout, taps) read as OIDHW
+            u.cd_pad = (ci + 31) & ~31;
+            const size_t fl = nm_packed_weight_floats(2, co, u.cd_pad);
+            u.wd = nm_ctx_weight_alloc(c, fl);
+            int r = u.wd ? nm_launch_pack_conv_weight(src, ci, co, 2, u.wd, co, u.cd_pad, c->stream) : NM_ERR_HIP;
+            if (!r && co % 16 == 0) {
+                u.wd16 = nm_ctx_weight_alloc(c, fl);
+                r = u.wd16 ? nm_launch_pack_conv_weight16(src, ci, co, 2, u.wd16, u.cd_pad, c->stream) : NM_ERR_HIP;
+            }
+            if (r && !rc) rc = r;
+        }
         u.bias = copy(p + ".block.0.bias", co);
         u.n = norm(p + ".block.1", co);
         return u;
@@ -146,8 +209,10 @@ __global__ void pack_small_kernel(const float* a, int na, const float* b, int nb
 // ------------------------------------------------------------------------------------------
 struct Net {
     nm_ctx* c; hipStream_t s; Arena& ws; int rc = NM_OK;
+    bool keep = false;                 // training forward: nothing is released, every activation stays for the backward pass
     explicit Net(nm_ctx* ctx) : c(ctx), s(ctx->stream), ws(ctx->ws) {}
     Net(nm_ctx* ctx, hipStream_t stream) : c(ctx), s(stream), ws(ctx->ws) {}
+    void release(size_t m) { if (!keep) ws.release(m); }
     bool ok() const { return rc == NM_OK; }
     bool live() const { return rc == NM_OK && !ws.dry; }
     void run(int r) { if (r && !rc) rc = r; }
@@ -166,7 +231,7 @@ size_t vox(const TensorRef& t) { return (size_t)t.D * t.H * t.W; }
 // conv (+ optional GroupNorm statistics): returns the lazy output
 // (up2: `in` is stored at half resolution and its trilinear x2 upsampling is what gets convolved)
 TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, int stride, int pad, float slope_after,
-                  float* out_buf = nullptr, bool up2 = false) {
+                  float* out_buf = nullptr, bool up2 = false, ConvRec* rec = nullptr) {
     ConvGeom g; g.ks = w.ks; g.stride = stride; g.pad = pad; g.up2 = up2 ? 1 : 0;
     const int us = up2 ? 2 : 1;
     g.OD = (us * in.D + 2 * pad - w.ks) / stride + 1; g.OH = (us * in.H + 2 * pad - w.ks) / stride + 1; g.OW = (us * in.W + 2 * pad - w.ks) / stride + 1;
@@ -187,7 +252,9 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
                                                 gn->gamma, gn->beta, 1e-5f, scale, shift, n.s));
         }
     }
-    return mk(out, in.N, g.OD, g.OH, g.OW, w.Cout, scale, shift, slope_after);
+    TensorRef o = mk(out, in.N, g.OD, g.OH, g.OW, w.Cout, scale, shift, slope_after);
+    if (rec) { rec->w = &w; rec->gn = gn; rec->in = in; rec->out = o; rec->fpart = part; rec->nblk = nblk; rec->stride = stride; rec->pad = pad; rec->up2 = up2; }
+    return o;
 }
 
 TensorRef add2(Net& n, const TensorRef& a, const TensorRef* b, float* out_buf = nullptr) {
@@ -198,21 +265,24 @@ TensorRef add2(Net& n, const TensorRef& a, const TensorRef* b, float* out_buf = 
 
 // Res3DBlock (vox_modules.py:22-47): GN(conv3(lrelu(GN(conv3 x)))) + skip(x); the trailing
 // F.leaky_relu(., True) is the identity.
-TensorRef res(Net& n, const TensorRef& x, const ResW& w, float* out_buf = nullptr) {
+TensorRef res(Net& n, const TensorRef& x, const ResW& w, float* out_buf = nullptr, ResRec* rec = nullptr) {
     float* out = out_buf ? out_buf : n.alloc((size_t)x.N * vox(x) * w.c2.Cout);
     const size_t m = n.ws.mark();
-    TensorRef r1 = conv_gn(n, x, w.c1, &w.n1, 1, 1, LRELU);
-    TensorRef r2 = conv_gn(n, r1, w.c2, &w.n2, 1, 1, 1.0f);
-    TensorRef sk = w.has_skip ? conv_gn(n, x, w.cs, &w.ns, 1, 0, 1.0f) : x;
+    TensorRef r1 = conv_gn(n, x, w.c1, &w.n1, 1, 1, LRELU, nullptr, false, rec ? &rec->c1 : nullptr);
+    TensorRef r2 = conv_gn(n, r1, w.c2, &w.n2, 1, 1, 1.0f, nullptr, false, rec ? &rec->c2 : nullptr);
+    TensorRef sk = w.has_skip ? conv_gn(n, x, w.cs, &w.ns, 1, 0, 1.0f, nullptr, false, rec ? &rec->cs : nullptr) : x;
+    if (rec) rec->has_skip = w.has_skip;
     TensorRef o = add2(n, r2, &sk, out);
-    n.ws.release(m);
+    n.release(m);
     return o;
 }
 
-TensorRef pool(Net& n, const TensorRef& x, const PoolW& w) { return conv_gn(n, x, w.c, &w.n, 2, 0, LRELU); }
+TensorRef pool(Net& n, const TensorRef& x, const PoolW& w, ConvRec* rec = nullptr) {
+    return conv_gn(n, x, w.c, &w.n, 2, 0, LRELU, nullptr, false, rec);
+}
 
 // Upsample3DBlock (vox_modules.py:63-75): ConvTranspose3d(k2,s2,output_padding) -> GN -> LeakyReLU (lazy)
-TensorRef up(Net& n, const TensorRef& x, const UpW& w, int outpad) {
+TensorRef up(Net& n, const TensorRef& x, const UpW& w, int outpad, UpRec* rec = nullptr) {
     const int OD = 2 * x.D + outpad, OH = 2 * x.H + outpad, OW = 2 * x.W + outpad;
     const size_t ov = (size_t)OD * OH * OW;
     float* out = n.alloc((size_t)x.N * ov * w.Cout);
@@ -225,30 +295,32 @@ TensorRef up(Net& n, const TensorRef& x, const UpW& w, int outpad) {
         n.run(nm_launch_gn_finalize(part, x.N, nblk, w.Cout, w.n.groups, (double)ov * (w.Cout / w.n.groups), w.n.gamma,
                                     w.n.beta, 1e-5f, scale, shift, n.s));
     }
-    return mk(out, x.N, OD, OH, OW, w.Cout, scale, shift, LRELU);
+    TensorRef o = mk(out, x.N, OD, OH, OW, w.Cout, scale, shift, LRELU);
+    if (rec) { rec->w = &w; rec->in = x; rec->out = o; rec->fpart = part; rec->nblk = nblk; }
+    return o;
 }
 
 // HG (vox_modules.py:78-120)
-TensorRef hourglass(Net& n, const TensorRef& x0, const HourglassW& w, int Ng) {
+TensorRef hourglass(Net& n, const TensorRef& x0, const HourglassW& w, int Ng, HgRec* r = nullptr) {
     const int op3 = (Ng / 4) % 2, op2 = (Ng / 2) % 2, op1 = Ng % 2;
-    TensorRef s1 = res(n, x0, w.s1);
-    TensorRef x = res(n, pool(n, x0, w.p1), w.e1);
-    TensorRef s2 = res(n, x, w.s2);
-    x = res(n, pool(n, x, w.p2), w.e2);
-    TensorRef s3 = res(n, x, w.s3);
-    x = res(n, pool(n, x, w.p3), w.e3);
-    x = res(n, x, w.d3);
-    TensorRef u = up(n, x, w.u3, op3); x = add2(n, u, &s3);
-    x = res(n, x, w.d2);
-    u = up(n, x, w.u2, op2); x = add2(n, u, &s2);
-    x = res(n, x, w.d1);
-    u = up(n, x, w.u1, op1); x = add2(n, u, &s1);
+    TensorRef s1 = res(n, x0, w.s1, nullptr, r ? &r->s1 : nullptr);
+    TensorRef x = res(n, pool(n, x0, w.p1, r ? &r->p1 : nullptr), w.e1, nullptr, r ? &r->e1 : nullptr);
+    TensorRef s2 = res(n, x, w.s2, nullptr, r ? &r->s2 : nullptr);
+    x = res(n, pool(n, x, w.p2, r ? &r->p2 : nullptr), w.e2, nullptr, r ? &r->e2 : nullptr);
+    TensorRef s3 = res(n, x, w.s3, nullptr, r ? &r->s3 : nullptr);
+    x = res(n, pool(n, x, w.p3, r ? &r->p3 : nullptr), w.e3, nullptr, r ? &r->e3 : nullptr);
+    x = res(n, x, w.d3, nullptr, r ? &r->d3 : nullptr);
+    TensorRef u = up(n, x, w.u3, op3, r ? &r->u3 : nullptr); x = add2(n, u, &s3);
+    x = res(n, x, w.d2, nullptr, r ? &r->d2 : nullptr);
+    u = up(n, x, w.u2, op2, r ? &r->u2 : nullptr); x = add2(n, u, &s2);
+    x = res(n, x, w.d1, nullptr, r ? &r->d1 : nullptr);
+    u = up(n, x, w.u1, op1, r ? &r->u1 : nullptr); x = add2(n, u, &s1);
     return x;
 }
 
 // Basic3DBlock(k5) on cat[occ, x1, x2, x3] (kypt_detector.py:265, kypt_detector_utils.py:4-26): only the occupancy
 // channel is convolved per frame, the coordinate channels' contribution (+ bias) is the weight-only `field`.
-TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w) {
+TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w, FeatRec* rec = nullptr) {
     const int Cout = w.c0.Cout;
     const size_t G3 = (size_t)G * G * G;
     float* out = n.alloc((size_t)N * G3 * Cout);
@@ -260,19 +332,21 @@ TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w)
         n.run(nm_launch_gn_finalize(part, N, nblk, Cout, w.n0.groups, (double)G3 * (Cout / w.n0.groups), w.n0.gamma, w.n0.beta,
                                     1e-5f, scale, shift, n.s));
     }
-    return mk(out, N, G, G, G, Cout, scale, shift, LRELU);
+    TensorRef o = mk(out, N, G, G, G, Cout, scale, shift, LRELU);
+    if (rec) { rec->w = &w; rec->occ = occ; rec->N = N; rec->G = G; rec->first = o; rec->fpart0 = part; rec->nblk0 = nblk; }
+    return o;
 }
 
 // _build_feature_net (kypt_detector.py:264-272); `occ` is the occupancy [N][G][G][G]
-void feature_net(Net& n, const float* occ, int N, int G, const FeatNetW& w, int g, float* out_buf) {
+void feature_net(Net& n, const float* occ, int N, int G, const FeatNetW& w, int g, float* out_buf, FeatRec* r = nullptr) {
     const size_t m = n.ws.mark();
-    TensorRef x = first_layer(n, occ, N, G, w);
-    x = pool(n, x, w.p1);
-    x = res(n, x, w.r2);
-    x = pool(n, x, w.p3);
-    x = hourglass(n, x, w.hg, g);
-    res(n, x, w.r5, out_buf);
-    n.ws.release(m);
+    TensorRef x = first_layer(n, occ, N, G, w, r);
+    x = pool(n, x, w.p1, r ? &r->p1 : nullptr);
+    x = res(n, x, w.r2, nullptr, r ? &r->r2 : nullptr);
+    x = pool(n, x, w.p3, r ? &r->p3 : nullptr);
+    x = hourglass(n, x, w.hg, g, r ? &r->hg : nullptr);
+    res(n, x, w.r5, out_buf, r ? &r->r5 : nullptr);
+    n.release(m);
 }
 
 // KyptToVoxNet for a batch of frames (kypt_detector.py:388-460).
@@ -280,7 +354,8 @@ void feature_net(Net& n, const float* occ, int N, int G, const FeatNetW& w, int 
 //   first_frames: occupancy of each clip's first frame (frame stride ff_stride);
 //   target/tail_part/chamfer only for the training-style forward.
 void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int feat_frame_stride, const float* first_frames,
-                   int ff_stride, int B, int T, const float* target, bool chamfer, float* recon, float* tail_part) {
+                   int ff_stride, int B, int T, const float* target, bool chamfer, float* recon, float* tail_part,
+                   TrainTape* tape = nullptr) {
     nm_ctx* c = n.c;
     const DetectorW& d = c->det;
     const int K = c->cfg.nkeypoints, G = c->cfg.grid_size, g = G / 4, F = B * T;
@@ -292,7 +367,8 @@ void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int fea
     if (n.live()) n.run(nm_launch_gauss_table(keypoints, F * K, g, (float)width_d, table, n.s));
     const int tb = nm_tail_blocks(G);
     // whole clips per pass so that frame 0 of every clip in the pass is addressable
-    const int clips_per_pass = (int)(FRAME_CHUNK / (size_t)T) > 0 ? (int)(FRAME_CHUNK / (size_t)T) : 1;
+    const int clips_per_pass = tape ? B : ((int)(FRAME_CHUNK / (size_t)T) > 0 ? (int)(FRAME_CHUNK / (size_t)T) : 1);
+    if (tape) tape->table = table;
     for (int b0 = 0; b0 < B; b0 += clips_per_pass) {
         const int nb = (B - b0) < clips_per_pass ? (B - b0) : clips_per_pass;
         const int f0 = b0 * T, nf = nb * T;
@@ -303,27 +379,28 @@ void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int fea
                                      feat_cl + (size_t)b0 * feat_frame_stride * g3 * FEAT, feat_frame_stride, nf, T, K, FEAT, g,
                                      Cc, comb, n.s));
         TensorRef x = mk(comb, nf, g, g, g, Cc);
-        x = conv_gn(n, x, d.adjust, nullptr, 1, 0, LRELU);
-        x = conv_gn(n, x, d.d1, &d.dn2, 1, 1, LRELU, nullptr, true);    // Upsample(x2, trilinear) fused into the staging
-        x = conv_gn(n, x, d.d4, &d.dn5, 1, 1, LRELU);
-        x = conv_gn(n, x, d.d8, &d.dn9, 1, 1, LRELU, nullptr, true);    // second Upsample(x2) likewise
-        x = conv_gn(n, x, d.d11, &d.dn12, 1, 1, LRELU);
+        x = conv_gn(n, x, d.adjust, nullptr, 1, 0, LRELU, nullptr, false, tape ? &tape->adjust : nullptr);
+        x = conv_gn(n, x, d.d1, &d.dn2, 1, 1, LRELU, nullptr, true, tape ? &tape->d1 : nullptr);    // Upsample(x2, trilinear) fused into the staging
+        x = conv_gn(n, x, d.d4, &d.dn5, 1, 1, LRELU, nullptr, false, tape ? &tape->d4 : nullptr);
+        x = conv_gn(n, x, d.d8, &d.dn9, 1, 1, LRELU, nullptr, true, tape ? &tape->d8 : nullptr);    // second Upsample(x2) likewise
+        x = conv_gn(n, x, d.d11, &d.dn12, 1, 1, LRELU, nullptr, false, tape ? &tape->d11 : nullptr);
         if (n.live())
             n.run(nm_launch_decoder_tail(x, d.d14, first_frames + (size_t)b0 * ff_stride * G3, ff_stride, T,
                                          target ? target + (size_t)f0 * G3 : nullptr,
                                          (target && chamfer) ? keypoints + (size_t)f0 * K * 4 : nullptr, K, G,
                                          recon + (size_t)f0 * G3, tail_part ? tail_part + (size_t)f0 * tb * 3 : nullptr, n.s));
-        n.ws.release(m1);
+        n.release(m1);
     }
-    n.ws.release(m0);
+    n.release(m0);
 }
 
 // `after_keypoints` (optional) is called once the keypoints kernel has been enqueued, in the live pass only: the
 // fused forward uses it to start the VRNN on the side stream while the decoder runs.
 int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on, float* keypoints, float* heatmaps,
                    float* first_feature, float* recon, float* affinity, float* losses,
-                   const std::function<int()>* after_keypoints = nullptr) {
+                   const std::function<int()>* after_keypoints = nullptr, TrainTape* tape = nullptr) {
     Net n(c);
+    n.keep = tape != nullptr;
     const DetectorW& d = c->det;
     const int K = c->cfg.nkeypoints, G = c->cfg.grid_size, g = G / 4, F = B * T, N = c->cfg.nneighbor;
     const size_t g3 = (size_t)g * g * g, G3 = (size_t)G * G * G;
@@ -341,6 +418,7 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
         // small, latency-bound launches: issued on the side stream so that it runs beside the per-frame encoder.  Its
         // scratch stays allocated (no release) until the call ends because the two streams run concurrently.
         Net n2(c, c->stream2);
+        n2.keep = n.keep;
         if (n.live()) {
             n.run(nm_check_hip(hipEventRecord(c->ev_fork, n.s), "fork event"));
             n.run(nm_check_hip(hipStreamWaitEvent(c->stream2, c->ev_fork, 0), "side stream wait"));
@@ -350,38 +428,46 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
         if (n2.live()) n2.run(nm_launch_mean_t(vox_in, B, T, G3, in, n2.s));
         const size_t saved_peak = n2.ws.peak;
         n2.ws.peak = n2.ws.top;
-        feature_net(n2, in, B, G, d.clip, g, fclip);
+        feature_net(n2, in, B, G, d.clip, g, fclip, tape ? &tape->clip : nullptr);
         const size_t local_peak = n2.ws.peak;                        // high-water mark of the clip net's scratch
         n2.ws.peak = saved_peak > local_peak ? saved_peak : local_peak;
         n2.ws.top = local_peak;                                      // keep that scratch out of reach of the main stream
-        conv_gn(n2, mk(fclip, B, g, g, g, 2 * FEAT), d.clip_head, nullptr, 1, 0, 1.0f, clip_head);
+        conv_gn(n2, mk(fclip, B, g, g, g, 2 * FEAT), d.clip_head, nullptr, 1, 0, 1.0f, clip_head, false, tape ? &tape->clip_head : nullptr);
+        if (tape) tape->clip_in = in;
         if (n2.live()) n2.run(nm_check_hip(hipEventRecord(c->ev_clip, c->stream2), "clip event"));
         n.run(n2.rc);
     }
-    for (size_t f0 = 0; f0 < (size_t)F; f0 += FRAME_CHUNK) {   // per-frame encoder (kypt_detector.py:330-336)
-        const int nf = (int)(((size_t)F - f0) < FRAME_CHUNK ? ((size_t)F - f0) : FRAME_CHUNK);
+    const size_t chunk = tape ? (size_t)F : FRAME_CHUNK;       // training keeps every activation: one pass over all frames
+    for (size_t f0 = 0; f0 < (size_t)F; f0 += chunk) {   // per-frame encoder (kypt_detector.py:330-336)
+        const int nf = (int)(((size_t)F - f0) < chunk ? ((size_t)F - f0) : chunk);
         const size_t m = n.ws.mark();
-        feature_net(n, vox_in + f0 * G3, nf, G, d.frame, g, feat + f0 * g3 * FEAT);
-        n.ws.release(m);
+        feature_net(n, vox_in + f0 * G3, nf, G, d.frame, g, feat + f0 * g3 * FEAT, tape ? &tape->frame : nullptr);
+        n.release(m);
     }
     {   // heads -> heat-maps -> keypoints (kypt_detector.py:336-347)
         const size_t m = n.ws.mark();
         float* head = n.alloc((size_t)F * g3 * K);
-        conv_gn(n, mk(feat, F, g, g, g, FEAT), d.head, nullptr, 1, 0, 1.0f, head);
+        conv_gn(n, mk(feat, F, g, g, g, FEAT), d.head, nullptr, 1, 0, 1.0f, head, false, tape ? &tape->head : nullptr);
         if (n.live()) {
             n.run(nm_check_hip(hipStreamWaitEvent(n.s, c->ev_clip, 0), "join clip net"));
             n.run(nm_launch_heatmap(head, clip_head, d.prop, F, T, K, g, heatmaps, heat_part, n.s));
             n.run(nm_launch_keypoints(heat_part, F, K, g, keypoints, heat_mean, n.s));
             if (after_keypoints && n.ok()) n.run((*after_keypoints)());
         }
-        n.ws.release(m);
+        if (tape) { tape->head_out = head; }
+        n.release(m);
     }
     if (n.live()) {   // first_feature output: frame 0 of every clip, NCDHW
         TensorRef ff = mk(feat, B, g, g, g, FEAT);
         n.run(nm_launch_cl_to_ncdhw_strided(ff, T, first_feature, n.s));
         if (affinity_on) n.run(nm_launch_affinity(d.affinity_params, N, K, aff, n.s));
     }
-    decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer != 0, recon, tail_part);
+    decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer != 0, recon, tail_part, tape);
+    if (tape) {
+        tape->B = B; tape->T = T; tape->affinity_on = affinity_on; tape->vox = vox_in; tape->feat = feat; tape->clip_head_out = clip_head;
+        tape->heat_part = heat_part; tape->heat_mean = heat_mean; tape->tail_part = tail_part; tape->aff = aff;
+        tape->keypoints = keypoints; tape->recon = recon;
+    }
     if (n.live()) {
         n.run(nm_launch_clip_loss(keypoints, aff, B, T, K, N, c->cfg.sep_sigma, clip_part, n.s));
         n.run(nm_launch_loss_finalize(tail_part, tb, B, T, K, N, G, heat_mean, clip_part, aff, c->cfg.vol_fit_chamfer,
@@ -400,6 +486,305 @@ int decode_graph(nm_ctx* c, const float* keypoints, const float* first_feature, 
     if (n.live()) n.run(nm_launch_ncdhw_to_cl(first_feature, B, (int)g3, FEAT, feat_cl, n.s));
     decode_frames(n, keypoints, feat_cl, 1, first_frame, 1, B, Tg, nullptr, false, gen, nullptr);
     return n.rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward graph (detector-mode training, train.py:388-404): the reverse walk over the tape
+// ------------------------------------------------------------------------------------------
+struct Bwd {
+    nm_ctx* c; hipStream_t s; Arena& ws; int rc = NM_OK;
+    const std::map<std::string, std::pair<float*, int64_t>>* grads;     // nullptr in the sizing pass
+    float* zb = nullptr;                                                  // 512 zeros: bias of the data-gradient convolutions
+    Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g) : c(ctx), s(ctx->stream), ws(ctx->ws), grads(g) {}
+    bool live() const { return rc == NM_OK && !ws.dry; }
+    void run(int r) { if (r && !rc) rc = r; }
+    float* alloc(size_t n) {
+        float* p = ws.f(n);
+        if (!p && !rc) { nm_set_error("backward workspace overflow (needed > %zu bytes)", ws.cap); rc = NM_ERR_STATE; }
+        return p;
+    }
+    float* grad(const std::string& key, int64_t numel) {
+        if (ws.dry || !grads) return reinterpret_cast<float*>((uintptr_t)256);
+        auto it = grads->find(key);
+        if (it == grads->end()) { if (!rc) { nm_set_error("detector_backward: no gradient buffer for '%s'", key.c_str()); rc = NM_ERR_ARG; } return nullptr; }
+        if (it->second.second != numel) {
+            if (!rc) { nm_set_error("detector_backward: '%s' has %lld elements, expected %lld", key.c_str(), (long long)it->second.second, (long long)numel); rc = NM_ERR_ARG; }
+            return nullptr;
+        }
+        return it->second.first;
+    }
+};
+
+size_t numel_of(const TensorRef& t) { return (size_t)t.N * t.D * t.H * t.W * t.C; }
+TensorRef plain(const float* p, const TensorRef& like) { return mk(p, like.N, like.D, like.H, like.W, like.C); }
+
+// GroupNorm(+LeakyReLU) backward of a lazy tensor: returns dy (gradient of the raw conv output) and writes the gradients of
+// gamma / beta and of the bias of the producing conv
+// (amax, optional: device word that ends up holding max |dy|, for the operand scaling of the data-gradient conv)
+const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float* fpart, int nblk_f, const std::string& bias_key,
+                      const float* dA, unsigned* amax = nullptr) {
+    const int N = out.N, C = out.C, V = out.D * out.H * out.W;
+    const int nbb = nm_gnb_blocks_per_frame(V);
+    float* dy = nullptr;
+    if (gn) {
+        dy = b.alloc(numel_of(out));
+        const size_t m = b.ws.mark();
+        float* bpart = b.alloc((size_t)N * nbb * C * 2);
+        float* coef = b.alloc((size_t)N * C * 4); float* dgn = b.alloc((size_t)N * C * 4);
+        float* gg = b.grad(gn->key + ".weight", C); float* gb = b.grad(gn->key + ".bias", C); float* gbias = b.grad(bias_key, C);
+        if (b.live()) {
+            b.run(nm_launch_gnb_partials(dA, out, bpart, b.s));
+            b.run(nm_launch_gnb_finalize(bpart, nbb, fpart, nblk_f, N, C, gn->groups, V, gn->gamma, 1e-5f, coef, dgn, b.s));
+            b.run(nm_launch_sum_frames(dgn, N, C, 4, 0, gg, b.s));
+            b.run(nm_launch_sum_frames(dgn, N, C, 4, 1, gb, b.s));
+            b.run(nm_launch_sum_frames(dgn, N, C, 4, 2, gbias, b.s));
+            b.run(nm_launch_gnb_apply(dA, out, coef, dy, b.s, amax));
+        }
+        b.ws.release(m);
+        return dy;
+    }
+    const float* res = dA;
+    if (out.slope != 1.0f) {
+        dy = b.alloc(numel_of(out));
+        if (b.live()) b.run(nm_launch_gnb_apply(dA, out, nullptr, dy, b.s, amax));
+        res = dy;
+    } else if (amax && b.live()) b.run(nm_launch_absmax(dA, numel_of(out), amax, b.s));
+    const size_t m = b.ws.mark();
+    float* bpart = b.alloc((size_t)N * nbb * C * 2);
+    float* gbias = b.grad(bias_key, C);
+    if (b.live()) {
+        b.run(nm_launch_gnb_partials(res, plain(res, out), bpart, b.s));
+        b.run(nm_launch_sum_partials(bpart, N * nbb, C, gbias, b.s));
+    }
+    b.ws.release(m);
+    return res;
+}
+
+// conv (+GN +LeakyReLU) backward.  dA: gradient w.r.t. the activated output.  Returns the gradient w.r.t. the activated input
+// ([N][D][H][W][csel], csel = Cin rounded down to 8) or nullptr when need_din is false.
+// Operand scaling of a data-gradient conv that runs on the split-fp16 kernels (nm_grad.h): dy is read as dy * 2^k.
+struct DyScale {
+    unsigned* amax = nullptr; float* scale = nullptr; float* shift = nullptr; float* sc2 = nullptr;
+    void prepare(Bwd& b, bool on, int count) {
+        if (!on) return;
+        amax = reinterpret_cast<unsigned*>(b.alloc(64)); scale = b.alloc(count); shift = b.alloc(count); sc2 = b.alloc(64);
+        if (b.live()) {
+            b.run(nm_check_hip(hipMemsetAsync(amax, 0, sizeof(unsigned), b.s), "backward: memset"));
+            b.run(nm_check_hip(hipMemsetAsync(shift, 0, (size_t)count * sizeof(float), b.s), "backward: memset"));
+        }
+    }
+    TensorRef apply(Bwd& b, const TensorRef& dyT) {
+        if (!amax) return dyT;
+        if (b.live()) b.run(nm_launch_make_scale(amax, dyT.N * dyT.C, scale, sc2, b.s));
+        TensorRef t = dyT; t.scale = scale; t.shift = shift;
+        return t;
+    }
+    const float* inv() const { return amax ? sc2 + 1 : nullptr; }
+};
+
+float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din) {
+    const ConvW& w = *r.w;
+    const TensorRef& in = r.in;
+    float* din = need_din ? b.alloc((size_t)in.N * in.D * in.H * in.W * w.csel) : nullptr;
+    const size_t m = b.ws.mark();
+    DyScale ds;
+    ds.prepare(b, need_din && r.stride == 1 && w.wd16 && nm_conv_get_mode() != 0, r.out.N * r.out.C);
+    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, w.key + ".bias", dA, ds.amax);
+    const TensorRef dyT = plain(dy, r.out);
+    {   // weight gradient
+        const size_t m2 = b.ws.mark();
+        TensorRef a = in;
+        if (r.up2) {
+            float* upb = b.alloc(numel_of(in) * 8);
+            if (b.live()) b.run(nm_launch_upsample2(in, upb, b.s));
+            a = mk(upb, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C);
+        }
+        float* wsb = b.alloc(nm_wgrad_ws_floats(in.N, r.out.D, r.out.H, r.out.W, w.Cout, in.C, w.ks, r.stride));
+        float* gw = b.grad(w.key + ".weight", (int64_t)w.Cout * w.Cin * w.ks * w.ks * w.ks);
+        if (b.live()) b.run(nm_launch_wgrad(a, dyT, w.ks, r.stride, r.pad, w.Cin, wsb, gw, b.s));
+        b.ws.release(m2);
+    }
+    if (need_din) {
+        if (r.stride == 1) {
+            const int us = r.up2 ? 2 : 1;
+            ConvGeom g; g.ks = w.ks; g.stride = 1; g.pad = w.ks - 1 - r.pad; g.OD = us * in.D; g.OH = us * in.H; g.OW = us * in.W;
+            g.Cout = w.csel; g.Co_pad = w.cd_pad;
+            float* dfine = r.up2 ? b.alloc((size_t)in.N * g.OD * g.OH * g.OW * w.csel) : din;
+            if (b.live()) {
+                if (!w.wd) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
+            }
+            const TensorRef dyS = ds.apply(b, dyT);
+            if (b.live()) {
+                b.run(nm_launch_conv(dyS, w.wd, b.zb, dfine, g, nullptr, b.s, w.Cout, w.wd16));
+                if (r.up2) b.run(nm_launch_upsample2_adjoint(dfine, in.N, in.D, in.H, in.W, w.csel, din, b.s, ds.inv()));
+                else if (ds.inv()) b.run(nm_launch_scale_by(din, (size_t)in.N * in.D * in.H * in.W * w.csel, ds.inv(), b.s));
+            }
+        } else if (b.live()) {      // k2 s2 pool conv: the transposed conv
+            if (!w.wt) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
+            else b.run(nm_launch_convT2(dyT, w.wt, b.zb, din, w.Cin, in.D, in.H, in.W, b.s));
+        }
+    }
+    b.ws.release(m);
+    return din;
+}
+
+void add_into(Bwd& b, float* dst, const float* src, size_t n) { if (b.live()) b.run(nm_launch_axpy(dst, src, n, b.s)); }
+
+// Res3DBlock backward: dOut is the gradient of the (materialised) block output; returns the gradient of the activated input
+float* res_bwd(Bwd& b, const ResRec& r, const float* dOut) {
+    float* d1 = conv_bwd(b, r.c2, dOut, true);
+    float* dx = conv_bwd(b, r.c1, d1, true);
+    const size_t n = numel_of(r.c1.in);
+    if (r.has_skip) { float* d2 = conv_bwd(b, r.cs, dOut, true); add_into(b, dx, d2, n); }
+    else add_into(b, dx, dOut, n);
+    return dx;
+}
+
+// Upsample3DBlock (ConvTranspose3d k2 s2 + GN + LeakyReLU) backward
+float* up_bwd(Bwd& b, const UpRec& r, const float* dA) {
+    const UpW& w = *r.w;
+    const TensorRef& in = r.in;
+    float* din = b.alloc(numel_of(in));
+    const size_t m = b.ws.mark();
+    DyScale ds;
+    ds.prepare(b, w.wd16 && nm_conv_get_mode() != 0, r.out.N * r.out.C);
+    const float* dy = norm_bwd(b, r.out, &w.n, r.fpart, r.nblk, w.key + ".bias", dA, ds.amax);
+    const TensorRef dyT = plain(dy, r.out);
+    float* wsb = b.alloc(nm_wgrad_ws_floats(in.N, in.D, in.H, in.W, w.Cin, w.Cout, 2, 2));
+    float* gw = b.grad(w.key + ".weight", (int64_t)w.Cin * w.Cout * 8);
+    ConvGeom g; g.ks = 2; g.stride = 2; g.pad = 0; g.OD = in.D; g.OH = in.H; g.OW = in.W; g.Cout = w.Cin; g.Co_pad = w.cd_pad;
+    if (b.live()) {
+        if (!w.wd) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
+        else b.run(nm_launch_wgrad(dyT, in, 2, 2, 0, w.Cout, wsb, gw, b.s));      // roles swapped: [Cin][Cout][8] = IODHW
+    }
+    const TensorRef dyS = ds.apply(b, dyT);
+    if (b.live()) {
+        b.run(nm_launch_conv(dyS, w.wd, b.zb, din, g, nullptr, b.s, w.Cout, w.wd16));
+        if (ds.inv()) b.run(nm_launch_scale_by(din, numel_of(in), ds.inv(), b.s));
+    }
+    b.ws.release(m);
+    return din;
+}
+
+float* hourglass_bwd(Bwd& b, const HgRec& h, const float* dOut) {
+    float* d_xd1 = up_bwd(b, h.u1, dOut);
+    float* d_xa2 = res_bwd(b, h.d1, d_xd1);
+    float* d_xd2 = up_bwd(b, h.u2, d_xa2);
+    float* d_xa3 = res_bwd(b, h.d2, d_xd2);
+    float* d_xd3 = up_bwd(b, h.u3, d_xa3);
+    float* d_xe3 = res_bwd(b, h.d3, d_xd3);
+    float* d_p3 = res_bwd(b, h.e3, d_xe3);
+    float* d_xe2 = conv_bwd(b, h.p3, d_p3, true);
+    add_into(b, d_xe2, res_bwd(b, h.s3, d_xa3), numel_of(h.p3.in));
+    float* d_p2 = res_bwd(b, h.e2, d_xe2);
+    float* d_xe1 = conv_bwd(b, h.p2, d_p2, true);
+    add_into(b, d_xe1, res_bwd(b, h.s2, d_xa2), numel_of(h.p2.in));
+    float* d_p1 = res_bwd(b, h.e1, d_xe1);
+    float* d_x0 = conv_bwd(b, h.p1, d_p1, true);
+    add_into(b, d_x0, res_bwd(b, h.s1, dOut), numel_of(h.p1.in));
+    return d_x0;
+}
+
+void feature_net_bwd(Bwd& b, const FeatRec& r, const float* dFeat) {
+    const size_t m = b.ws.mark();
+    float* d_hg = res_bwd(b, r.r5, dFeat);
+    float* d_p3 = hourglass_bwd(b, r.hg, d_hg);
+    float* d_r2 = conv_bwd(b, r.p3, d_p3, true);
+    float* d_p1 = res_bwd(b, r.r2, d_r2);
+    float* d_first = conv_bwd(b, r.p1, d_p1, true);
+    // first layer: GroupNorm backward, then the weight gradient against cat[occ, coords] rebuilt from the occupancy
+    const FeatNetW& w = *r.w;
+    const float* dy = norm_bwd(b, r.first, &w.n0, r.fpart0, r.nblk0, w.c0.key + ".bias", d_first);
+    float* wsb = b.alloc(nm_wgrad_k5occ_ws_floats(r.N, r.G, w.c0.Cout));
+    float* gw = b.grad(w.c0.key + ".weight", (int64_t)w.c0.Cout * 4 * 125);
+    if (b.live()) b.run(nm_launch_wgrad_k5occ(r.occ, r.N, r.G, plain(dy, r.first), wsb, gw, b.s));
+    b.ws.release(m);
+}
+
+int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std::map<std::string, std::pair<float*, int64_t>>* grads) {
+    Bwd b(c, grads);
+    const DetectorW& d = c->det;
+    const int K = c->cfg.nkeypoints, G = c->cfg.grid_size, g = G / 4, B = t.B, T = t.T, F = B * T, N = c->cfg.nneighbor;
+    const size_t g3 = (size_t)g * g * g, G3 = (size_t)G * G * G;
+    const double width_d = 2.0 * std::pow((double)c->cfg.gaussian_sigma / (double)g, 2.0);
+    const std::string k2v = "kypt_detector.kypt_to_vox", v2k = "kypt_detector.vox_to_kypt";
+    float* dkp = b.alloc((size_t)F * K * 4);
+    float* dfeat = b.alloc((size_t)F * g3 * FEAT);
+    b.zb = b.alloc(512);
+    if (b.live()) {
+        b.run(nm_check_hip(hipMemsetAsync(dkp, 0, (size_t)F * K * 4 * sizeof(float), b.s), "backward: memset"));
+        b.run(nm_check_hip(hipMemsetAsync(b.zb, 0, 512 * sizeof(float), b.s), "backward: memset"));
+    }
+
+    {   // decoder: tail -> d11 -> d8 -> d4 -> d1 -> adjust -> combined representation
+        const size_t m = b.ws.mark();
+        const TensorRef& x = t.d11.out;
+        const int tb = nm_tail_bwd_blocks(G), C = x.C;
+        float* dA = b.alloc((size_t)F * G3 * C);
+        float* part = b.alloc((size_t)F * tb * (C + 1));
+        float* g14 = b.alloc(C + 1);
+        float* gw14 = b.grad(k2v + ".decode_voxel_from_combined_representation.14.weight", C);
+        float* gb14 = b.grad(k2v + ".decode_voxel_from_combined_representation.14.bias", 1);
+        if (b.live()) {
+            b.run(nm_launch_decoder_tail_bwd(x, d.d14, t.vox, t.recon, dloss, G, dA, part, b.s));
+            b.run(nm_launch_sum_rows(part, F * tb, C + 1, g14, b.s));
+            b.run(nm_check_hip(hipMemcpyAsync(gw14, g14, C * sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
+            b.run(nm_check_hip(hipMemcpyAsync(gb14, g14 + C, sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
+        }
+        float* dx = conv_bwd(b, t.d11, dA, true);
+        dx = conv_bwd(b, t.d8, dx, true);
+        dx = conv_bwd(b, t.d4, dx, true);
+        dx = conv_bwd(b, t.d1, dx, true);
+        float* dcomb = conv_bwd(b, t.adjust, dx, true);                 // [F][g^3][csel = 2K + FEAT]
+        float* gws = b.alloc((size_t)F * K * 8);
+        if (b.live()) {
+            b.run(nm_check_hip(hipMemsetAsync(dfeat, 0, (size_t)F * g3 * FEAT * sizeof(float), b.s), "backward: memset"));
+            b.run(nm_launch_combined_bwd(dcomb, d.adjust.csel, t.table, t.keypoints, B, T, K, FEAT, g, (float)width_d, gws, dfeat, dkp, b.s));
+        }
+        b.ws.release(m);
+    }
+    float* dinfl = t.affinity_on ? b.alloc((size_t)B * K * K) : nullptr;
+    {   // keypoint-only losses
+        const size_t m = b.ws.mark();
+        float* cws = b.alloc((size_t)F * nm_chamfer_bwd_blocks(G) * K * 3);
+        float* gaff = b.grad("kypt_detector.affinity_params", (int64_t)N * K * (K - 1));
+        if (b.live()) {
+            if (c->cfg.vol_fit_chamfer)
+                b.run(nm_launch_chamfer_bwd(t.vox, t.keypoints, t.tail_part, nm_tail_blocks(G), dloss, F, K, G, cws, dkp, b.s));
+            b.run(nm_launch_clip_loss_bwd(t.keypoints, t.affinity_on ? t.aff : nullptr, dloss, B, T, K, N, c->cfg.sep_sigma, c->cfg.use_graph_traj,
+                                          dkp, dinfl, b.s));
+            if (t.affinity_on) b.run(nm_launch_affinity_bwd(d.affinity_params, t.aff, dinfl, dloss, B, N, K, gaff, b.s));
+            else b.run(nm_check_hip(hipMemsetAsync(gaff, 0, (size_t)N * K * (K - 1) * sizeof(float), b.s), "backward: memset"));
+        }
+        b.ws.release(m);
+    }
+    float* dchead = b.alloc((size_t)B * g3 * K);
+    {   // keypoints <- heat-maps <- heads; head conv back into the frame features
+        const size_t m = b.ws.mark();
+        float* dhead = b.alloc((size_t)F * g3 * K);
+        float* dchead_t = b.alloc((size_t)F * g3 * K);
+        float* hws = b.alloc(nm_heat_bwd_ws_floats(F, K, g));
+        float* gprop = b.alloc(4);
+        float* gpw = b.grad(v2k + ".propagate_heatmaps.0.weight", 2);
+        float* gpb = b.grad(v2k + ".propagate_heatmaps.0.bias", 1);
+        if (b.live()) {
+            b.run(nm_launch_heat_bwd(t.head_out, t.clip_head_out, d.prop, t.heat_part, t.heat_mean, t.keypoints, dkp, dloss, B, T, K, g, hws,
+                                     dhead, dchead_t, dchead, gprop, b.s));
+            b.run(nm_check_hip(hipMemcpyAsync(gpw, gprop, 2 * sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
+            b.run(nm_check_hip(hipMemcpyAsync(gpb, gprop + 2, sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
+        }
+        float* dfh = conv_bwd(b, t.head, dhead, true);
+        add_into(b, dfeat, dfh, (size_t)F * g3 * FEAT);
+        b.ws.release(m);
+    }
+    feature_net_bwd(b, t.frame, dfeat);
+    {   // spatio-temporal net of the clip mean
+        const size_t m = b.ws.mark();
+        float* dfclip = conv_bwd(b, t.clip_head, dchead, true);
+        feature_net_bwd(b, t.clip, dfclip);
+        b.ws.release(m);
+    }
+    return b.rc;
 }
 
 template <class Fn>
@@ -422,7 +807,10 @@ int check_ready(nm_ctx* c, const char* who) {
 
 }  // namespace
 
+void nm_net_free_tape(nm_ctx* c) { delete c->tape; c->tape = nullptr; }
+
 int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const float*, int64_t>>& sd) {
+    if (c->tape) c->tape->valid = false;
     int rc = nm_check_hip(hipStreamSynchronize(c->stream), "set_weights: sync");
     if (rc) return rc;
     for (void* p : c->owned) (void)hipFree(p);
@@ -434,6 +822,8 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
     const std::string v = "kypt_detector.vox_to_kypt", k2v = "kypt_detector.kypt_to_vox";
     const std::string dec = k2v + ".decode_voxel_from_combined_representation";
     d.affinity_params = L.copy("kypt_detector.affinity_params", (int64_t)N * K * (K - 1));
+    d.zeros = nm_ctx_weight_alloc(c, 512);
+    if (d.zeros) (void)hipMemsetAsync(d.zeros, 0, 512 * sizeof(float), c->stream);
     d.frame = L.featnet(v + ".extract_features", FEAT);
     d.head = L.conv(v + ".extract_heatmaps_from_features.0", K, FEAT, 1);
     d.clip = L.featnet(v + ".extract_spatio_temporal_features", 2 * FEAT);
@@ -538,6 +928,50 @@ int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* fir
         nm_set_error("decode_from_keypoints: null / non-positive argument"); return NM_ERR_ARG;
     }
     return with_workspace(c, [&]() { return decode_graph(c, keypoints, first_feature, first_frame, B, Tg, gen); });
+}
+
+int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints,
+                              float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) {
+    int rc = check_ready(c, "detector_forward_train");
+    if (rc) return rc;
+    if (!c->training) { nm_set_error("detector_forward_train: call nm_ctx_set_training(ctx, 1) and nm_ctx_set_weights first"); return NM_ERR_STATE; }
+    if (!vox || !keypoints || !heatmaps || !first_feature || !recon || !losses11 || B <= 0 || T <= 0) {
+        nm_set_error("detector_forward_train: null / non-positive argument"); return NM_ERR_ARG;
+    }
+    if (!c->tape) c->tape = new TrainTape();
+    TrainTape& t = *c->tape;
+    t.valid = false;
+    std::swap(c->ws, c->ws_t);
+    // sizing pass over forward + backward (the arena must not move between the two calls), then the forward proper
+    c->ws.dry = true; c->ws.peak = 0; c->ws.overflow = false;
+    rc = detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11, nullptr, &t);
+    if (!rc) rc = backward_graph(c, t, nullptr, nullptr);
+    c->ws.dry = false;
+    if (!rc) rc = nm_ctx_reserve(c, c->ws.peak + 4096);
+    if (!rc) rc = detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11, nullptr, &t);
+    t.fwd_top = c->ws.top;
+    std::swap(c->ws, c->ws_t);
+    t.valid = rc == NM_OK;
+    return rc;
+}
+
+int nm_detector_backward(nm_ctx* c, const float* dlosses11, const nm_named_grad* grads, int32_t count) {
+    int rc = check_ready(c, "detector_backward");
+    if (rc) return rc;
+    if (!c->tape || !c->tape->valid) { nm_set_error("detector_backward: no training forward to back-propagate (or the weights changed since)"); return NM_ERR_STATE; }
+    if (!dlosses11 || !grads || count <= 0) { nm_set_error("detector_backward: null argument"); return NM_ERR_ARG; }
+    std::map<std::string, std::pair<float*, int64_t>> gm;
+    for (int i = 0; i < count; ++i) {
+        if (!grads[i].name || !grads[i].data) { nm_set_error("detector_backward: entry %d is null", i); return NM_ERR_ARG; }
+        gm[grads[i].name] = std::make_pair(grads[i].data, grads[i].numel);
+    }
+    TrainTape& t = *c->tape;
+    std::swap(c->ws, c->ws_t);
+    c->ws.top = t.fwd_top;
+    rc = backward_graph(c, t, dlosses11, &gm);
+    std::swap(c->ws, c->ws_t);
+    t.valid = false;
+    return rc;
 }
 
 int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, double scale, float* vox, int32_t* idx_out) {

@@ -60,6 +60,7 @@ class Engine:
         self._named = None
         # conv arithmetic: 1 = split-fp16 MFMA with fp32-equivalent accuracy (default), 0 = exact fp32 MFMA
         self.conv_mode = 0 if os.environ.get("NM355_CONV_MODE", "split16").lower() in ("fp32", "0", "exact") else 1
+        self.training_packs = False     # detector-mode training: set_weights also packs the data-gradient weights
 
     # -- plumbing ---------------------------------------------------------------------------
     def _device(self) -> torch.device:
@@ -80,10 +81,19 @@ class Engine:
                                 use_graph_traj=int(o.graph_traj_weight > 0))
             self.ctx = _lib.Context(cfg)
             self._stamp = None
+        _lib.check(self.ctx.lib.nm_ctx_set_training(self.ctx.handle, int(self.training_packs)), "set_training")
         self.ctx.bind_stream()
         _lib.check(self.ctx.lib.nm_set_conv_mode(self.ctx.handle, self.conv_mode), "set_conv_mode")
         self._sync_weights()
         return self.ctx
+
+    def set_training(self, on: bool) -> None:
+        """Detector-mode training needs the flipped / transposed weight packs: toggling forces a re-upload."""
+        if on != self.training_packs:
+            self.training_packs = on
+            self._stamp = None
+        if self.ctx is not None:
+            _lib.check(self.ctx.lib.nm_ctx_set_training(self.ctx.handle, int(on)), "set_training")
 
     def _sync_weights(self) -> None:
         if self._named is None:
@@ -117,6 +127,51 @@ def _f32(t: torch.Tensor, dev) -> torch.Tensor:
 # ==========================================================================================
 # detector
 # ==========================================================================================
+class _DetectorTrain(torch.autograd.Function):
+    """KyptDetector.forward with a backward pass (detector mode, train.py:388-404): forward = nm_detector_forward_train
+    (activations retained in the library), backward = nm_detector_backward (HIP kernels of nm_grad.hip /
+    nm_heads_bwd.hip).  Only the 11 loss scalars carry gradients — exactly what the reference's training loss
+    consumes; keypoints reach the learner detached (neural_marionette.py:53)."""
+
+    @staticmethod
+    def forward(ctx, module, vox, names, *params):
+        eng = module._eng()
+        eng.set_training(True)
+        c = eng.ready()
+        dev = c.device
+        B, T = int(vox.shape[0]), int(vox.shape[1])
+        G, K, g = module.grid_size, module.nkeypoints, module.grid_size // 4
+        kp = torch.empty(B, T, K, 4, device=dev)
+        hm = torch.empty(B, T, K, g, g, g, device=dev)
+        ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev)
+        recon = torch.empty(B, T, 1, G, G, G, device=dev)
+        aff = torch.empty(module.nneighbor, K, K, 1, device=dev) if module.affinity_start else torch.empty(0, device=dev)
+        losses = torch.empty(len(DETECTOR_LOSS_KEYS), device=dev)
+        eng.call("nm_detector_forward_train", _lib.ptr(vox), B, T, int(module.affinity_start), _lib.ptr(kp), _lib.ptr(hm),
+                 _lib.ptr(ff), _lib.ptr(recon), _lib.ptr(aff) if module.affinity_start else None, _lib.ptr(losses))
+        ctx.module, ctx.names = module, names
+        ctx.shapes = [p.shape for p in params]
+        ctx.keep = (vox, kp, recon)           # the library reads them again in the backward pass
+        ctx.mark_non_differentiable(kp, hm, ff, recon, aff)
+        return losses, kp, hm, ff, recon, aff
+
+    @staticmethod
+    def backward(ctx, dlosses, *unused):
+        eng = ctx.module._eng()
+        c = eng.ready()
+        dev = c.device
+        dl = (dlosses if dlosses is not None else torch.zeros(len(DETECTOR_LOSS_KEYS), device=dev)).float().contiguous()
+        grads = [torch.empty(shp, device=dev) for shp in ctx.shapes]
+        arr = (_lib.NmNamedTensor * len(grads))()
+        keep = []
+        for i, (n, g) in enumerate(zip(ctx.names, grads)):
+            keep.append(n.encode())
+            arr[i].name, arr[i].data, arr[i].numel = keep[-1], g.data_ptr(), g.numel()
+        eng.call("nm_detector_backward", _lib.ptr(dl), arr, len(grads))
+        ctx.keep = None
+        return (None, None, None, *grads)
+
+
 class KyptDetector(_Node):
     """model/kypt_detector.py:10-241."""
 
@@ -169,14 +224,21 @@ class KyptDetector(_Node):
         if tuple(seq.shape[2:]) != (1, G, G, G):
             raise ValueError(f"expected seq of shape (B,T,1,{G},{G},{G}), got {tuple(seq.shape)}")
         vox = _f32(seq, dev)
-        kp = torch.empty(B, T, K, 4, device=dev)
-        hm = torch.empty(B, T, K, g, g, g, device=dev)
-        ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev)
-        recon = torch.empty(B, T, 1, G, G, G, device=dev)
-        aff = torch.empty(self.nneighbor, K, K, 1, device=dev) if self.affinity_start else None
-        losses = torch.empty(len(DETECTOR_LOSS_KEYS), device=dev)
-        eng.call("nm_detector_forward", _lib.ptr(vox), B, T, int(self.affinity_start), _lib.ptr(kp), _lib.ptr(hm),
-                 _lib.ptr(ff), _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses))
+        named = [(k, p) for k, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for _, p in named):
+            # detector-mode training (train.py:388): the 11 losses are differentiable w.r.t. every kypt_detector parameter
+            names = ["kypt_detector." + k for k, _ in named]
+            losses, kp, hm, ff, recon, aff = _DetectorTrain.apply(self, vox, names, *[p for _, p in named])
+            aff = aff if self.affinity_start else None
+        else:
+            kp = torch.empty(B, T, K, 4, device=dev)
+            hm = torch.empty(B, T, K, g, g, g, device=dev)
+            ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev)
+            recon = torch.empty(B, T, 1, G, G, G, device=dev)
+            aff = torch.empty(self.nneighbor, K, K, 1, device=dev) if self.affinity_start else None
+            losses = torch.empty(len(DETECTOR_LOSS_KEYS), device=dev)
+            eng.call("nm_detector_forward", _lib.ptr(vox), B, T, int(self.affinity_start), _lib.ptr(kp), _lib.ptr(hm),
+                     _lib.ptr(ff), _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses))
         out = dict(recon=recon, keypoints=kp, heatmaps=hm, affinity=aff)
         for i, name in enumerate(DETECTOR_LOSS_KEYS):
             out[name] = losses[i]
@@ -582,10 +644,14 @@ class NeuralMarionette(nn.Module):
         keypoints = affinity = None
         d, det_m = self.dyna_module, self.kypt_detector
         if module_actives["learner"] and d.A is not None and det_m.affinity_start and not \
-                (torch.is_grad_enabled() and any(p.requires_grad for p in d.parameters())):
+                (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             return self._forward_fused(vox_seq, eps)
         if module_actives["detector"] or module_actives["learner"]:
-            det = self.kypt_detector(vox_seq)
+            if module_actives["detector"]:
+                det = self.kypt_detector(vox_seq)
+            else:
+                with torch.no_grad():           # neural_marionette.py:45-47
+                    det = self.kypt_detector(vox_seq)
             keypoints, affinity = det["keypoints"], det.get("affinity")
             log.update(det)
         if module_actives["learner"]:

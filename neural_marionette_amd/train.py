@@ -1,4 +1,10 @@
-"""Learner-mode training step (first half).
+"""Training steps of the reference's two regimes.
+
+Detector mode (`pretrained_mode = 0`, train.py:270-276): `DetectorTrainer` — the keypoint detector trains on its 11 losses
+with the AIST weights (train.py:177-181); forward = nm_detector_forward_train, backward = nm_detector_backward (HIP kernels),
+one flat-bucket gradient all-reduce (8.56 M floats = 34 MB), fused Adam.
+
+Learner mode:
 
 The reference's `pretrained_mode = 1` regime (train.py:146, 270-276; the mode stored in
 pretrained/aist/opt.pickle): the keypoint detector is frozen and only the dynamics module
@@ -11,7 +17,7 @@ trains, on `keypoints.detach()` (neural_marionette.py:53).  One step of train.py
 Here the forward and the back-propagation through time run in libnm355.so, the gradient
 all-reduce (clip-sharded data parallelism) goes through `torch.distributed` — backend "nccl" is
 RCCL over xGMI on the GPU box — as ONE flat bucket of 1.53 M floats (6.1 MB), and Adam is the
-library's fused kernel.  Detector-mode training (conv backward) is not built yet.
+library's fused kernel.
 """
 from __future__ import annotations
 
@@ -76,3 +82,54 @@ class LearnerTrainer:
                 p.add_(0)      # the kernel updated the storage behind autograd's back: bump the version counter so that
                                # Engine._sync_weights re-uploads / re-packs the weights before the next forward
         return {"loss": float(loss), **{k: float(log[k]) for k in self.weights}}
+
+
+# AIST loss weights of the reference for the detector losses (train.py:177-181 / opt.pickle)
+DETECTOR_LOSS_WEIGHTS = {"recon_loss": 100.0, "sparsity_loss": 5.0, "separation_loss": 0.1, "vol_fit_reg": 10.0,
+                         "kypt_const_loss": 0.0, "local_const_loss": 1e-3, "time_const_loss": 1.0, "sparsity_const_loss": 0.01,
+                         "intensity_const_loss": 0.01, "graph_traj_loss": 1.0, "graph_vol_loss": 0.0}
+
+
+class DetectorTrainer:
+    """One step of train.py:376-412 in detector mode: log = network(voxel, {'detector': True, 'learner': False});
+    loss = sum_k weight[k] * log[k]; loss.backward(); Adam(lr 4e-4).  `nepoch` drives KyptDetector.anneal (affinity start)."""
+
+    def __init__(self, net, lr: float = 4e-4, weights: Optional[Dict[str, float]] = None, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.net = net
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.weights = dict(DETECTOR_LOSS_WEIGHTS if weights is None else weights)
+        self.acts = {"detector": True, "learner": False}
+        net.control_active(self.acts)
+        self.reset_optimizer()
+
+    def _params(self):
+        return [p for p in self.net.kypt_detector.parameters() if p.requires_grad]
+
+    def reset_optimizer(self) -> None:
+        """The reference re-instantiates Adam at every epoch (train.py:366-374): state starts from zero."""
+        self.t = 0
+        self.state = {}
+
+    def step(self, vox) -> Dict[str, float]:
+        net = self.net
+        params = self._params()
+        for p in net.kypt_detector.parameters():
+            p.grad = None
+        log = net(vox, self.acts)
+        loss = sum(w * log[k] for k, w in self.weights.items())
+        loss.backward()
+        params = [p for p in params if p.grad is not None]
+        grads = [p.grad for p in params]
+        allreduce_mean_(grads)
+        eng = net._engine
+        eng.ready()
+        self.t += 1
+        with torch.no_grad():
+            for p, g in zip(params, grads):
+                st = self.state.get(id(p))
+                if st is None:
+                    st = self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
+                eng.call("nm_adam_step", _lib.ptr(p.data), _lib.ptr(g.contiguous()), _lib.ptr(st[0]), _lib.ptr(st[1]), p.numel(), self.t,
+                         self.lr, self.betas[0], self.betas[1], self.eps)
+                p.add_(0)      # bump the version counter: the engine re-uploads / re-packs the weights before the next forward
+        return {"loss": float(loss.detach()), **{k: float(log[k].detach()) for k in self.weights}}

@@ -28,6 +28,15 @@ BWD_CASES = [
     (128, 64, 3, 1, 1, 6, 2, True, True, 128),
     (64, 32, 3, 1, 1, 8, 2, True, True, 64),
     (16, 32, 3, 1, 1, 5, 2, False, True, 16),
+    (128, 128, 3, 1, 1, 8, 8, True, False, 128),
+    (64, 128, 3, 1, 1, 8, 8, True, False, 64),
+    (64, 128, 1, 1, 0, 8, 8, True, False, 64),
+    # hourglass floor of a 32^3 grid: 1^3 and 2^3 volumes
+    (72, 72, 3, 1, 1, 1, 8, True, False, 72),
+    (48, 72, 1, 1, 0, 1, 8, False, False, 48),
+    (48, 48, 2, 2, 0, 2, 8, True, False, 48),
+    (32, 32, 2, 2, 0, 4, 8, True, False, 32),
+    (32, 48, 3, 1, 1, 2, 8, True, False, 32),
 ]
 
 
@@ -96,7 +105,7 @@ def test_conv5_occ_backward(ctx, Cout, G, N):
     assert relerr(d_b.cpu(), b.grad) < REL
 
 
-@pytest.mark.parametrize("Cin,Cout,size,outpad,prologue,N", [(72, 48, 2, 0, True, 3), (48, 32, 4, 0, False, 2), (32, 64, 8, 0, True, 2),
+@pytest.mark.parametrize("Cin,Cout,size,outpad,prologue,N", [(72, 48, 1, 0, True, 8), (72, 48, 2, 0, True, 3), (48, 32, 4, 0, False, 2), (32, 64, 8, 0, True, 2),
                                                              (72, 48, 2, 1, True, 2), (48, 32, 5, 1, False, 2)])
 def test_convT2_backward(ctx, Cin, Cout, size, outpad, prologue, N):
     from neural_marionette_amd import _lib
@@ -129,7 +138,7 @@ def test_convT2_backward(ctx, Cin, Cout, size, outpad, prologue, N):
 
 
 @pytest.mark.parametrize("C,groups,size,N,slope", [(32, 2, 16, 2, 0.01), (64, 4, 8, 3, 0.01), (128, 8, 6, 2, 1.0), (72, 4, 2, 3, 0.01),
-                                                   (48, 3, 5, 2, 1.0), (256, 16, 4, 1, 0.01)])
+                                                   (48, 3, 5, 2, 1.0), (256, 16, 4, 1, 0.01), (72, 4, 1, 8, 0.01), (48, 3, 2, 8, 1.0)])
 def test_gn_backward(ctx, C, groups, size, N, slope):
     from neural_marionette_amd import _lib
     g = torch.Generator().manual_seed(C + size)
