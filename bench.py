@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["forward", "train"], default="forward",
+                    help="forward (default, BASELINE configs[1]): full NeuralMarionette.forward; train (configs[2] shape, fp32): one "
+                         "detector-mode training step = forward + backward + gradient all-reduce + Adam")
     ap.add_argument("--conv-mode", choices=["split16", "fp32"], default="split16",
                     help="split16: fp32-equivalent 3x f16 MFMA products (default); fp32: exact fp32 MFMA everywhere")
     args = ap.parse_args()
@@ -120,15 +123,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    if args.workload == "train":
+        from neural_marionette_amd.train import DetectorTrainer
+        net.train()
+        trainer = DetectorTrainer(net, lr=4e-4)
+        step = lambda: trainer.step(vox)
+    else:
+        step = lambda: net(vox, acts, eps=eps)
     for _ in range(args.warmup):
-        net(vox, acts, eps=eps)
+        step()
     eng = net._engine
     lib, h = eng.ctx.lib, eng.ctx.handle
     _lib.check(lib.nm_prof_enable(h, 1), "prof_enable")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        net(vox, acts, eps=eps)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     _lib.check(lib.nm_prof_enable(h, 0), "prof_enable")
@@ -170,7 +180,7 @@ def main():
                 roof["frac_issued"] = 3.0 * ach / peak
                 roof["algorithmic_vs_fp32_mfma_peak"] = ach / FP32_MFMA_PEAK_TFLOPS
         cpu, l2 = (None, None)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "forward":
             cpu, l2 = cpu_baseline(sd, opts, net, dev)
         line = dict(
             metric="voxel-frames/sec (64^3, T=16)", value=frames / dt, unit="voxel-frames/s",
@@ -179,8 +189,10 @@ def main():
             dtype=("f32 (conv products as 3x f16-split MFMA with f32 accumulate, fp32-equivalent; everything else f32)"
                    if eng.conv_mode == 1 else "f32"),
             data="synthetic",
-            config=dict(workload="AIST++-shaped synthetic clips 64^3 T=16 B=4/GPU, full NeuralMarionette.forward "
-                                 "(detector + 11 losses + HSVRNNBVH.encode, best-of-10), fp32, random-init weights",
+            config=dict(workload=("AIST++-shaped synthetic clips 64^3 T=16 B=4/GPU, full NeuralMarionette.forward "
+                                  "(detector + 11 losses + HSVRNNBVH.encode, best-of-10), fp32, random-init weights") if args.workload == "forward" else
+                                 ("AIST++-shaped synthetic clips 64^3 T=16 B=4/GPU, detector-mode training step (forward + backward of the "
+                                  "11 weighted losses + flat-bucket gradient all-reduce + Adam), fp32, random-init weights"),
                         grid=G, T=T, clips_per_gpu=B_PER_GPU, global_clips=world * B_PER_GPU, conv_mode=args.conv_mode,
                         parallelism=f"clip-sharded x{world} (no data-path collective)"),
             roofline=roof, cpu_baseline=cpu, kypt_l2_vs_cpu=l2,

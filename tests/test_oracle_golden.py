@@ -145,6 +145,34 @@ def test_g6_learner_gradients(golden_dir):
     assert checked == 21
 
 
+def test_g8_detector_gradients(golden_dir):
+    """Detector-mode training gradients (train.py:388-404, AIST loss weights): autograd of the oracle against the
+    reference's own autograd (fixture G8: sum, abs-sum, max-abs and every 997th element of each of the 315 gradients)."""
+    g = _load(golden_dir, "g8_detector_grads.npz")
+    G, B, T, seed = [int(v) for v in g["meta"]]
+    o = HotPathOptions(grid_size=G)
+    sd = synth.make_state_dict(o, seed=seed, variant="peaky")
+    gen = torch.Generator().manual_seed(seed + 1)
+    sd["kypt_detector.affinity_params"] = torch.randn(sd["kypt_detector.affinity_params"].shape, generator=gen)
+    vox = synth.figure_clip(B, T, G, seed=seed + 2)
+    names = [k for k in sd if k.startswith("kypt_detector.")]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sd2 = dict(sd); sd2.update(leaf)
+    out = O.detector_forward(sd2, o, vox, affinity_on=True)
+    for i, k in enumerate(DETECTOR_LOSS_KEYS):
+        assert abs(float(out[k]) - float(g["losses"][i])) <= 1e-5 * max(1.0, abs(float(g["losses"][i]))), k
+    loss = sum(float(w) * out[k] for k, w in zip(DETECTOR_LOSS_KEYS, g["weights"]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    grads = torch.autograd.grad(loss, [leaf[k] for k in names])
+    assert len(names) == 315
+    for k, gr in zip(names, grads):
+        ref = g["g:" + k[len("kypt_detector."):]]
+        flat = gr.reshape(-1).double()
+        mine = np.concatenate([[flat.sum().item(), flat.abs().sum().item(), flat.abs().max().item()], flat[::997].numpy()])
+        scale = max(ref[2], 1e-12)
+        assert np.abs(mine[2:] - ref[2:]).max() <= 1e-4 * scale, (k, np.abs(mine[2:] - ref[2:]).max() / scale)
+
+
 def test_g7_eval_metrics(golden_dir):
     """oracle restatement of utils/eval_utils.py vs the reference's outputs on the seeded inputs"""
     g = np.load(os.path.join(golden_dir, "g7_eval_metrics.npz"))

@@ -103,6 +103,30 @@ def test_detector_gradients_vs_oracle_autograd(which):
     _compare(ref, got, tol=TOL)
 
 
+def test_detector_gradients_vs_reference_fixture(golden_dir):
+    """The reference's own autograd on the same seeded case (tests/golden/g8_detector_grads.npz, tools/make_golden.py g8): every
+    997th element and the max-abs of each of the 315 gradients."""
+    import os
+    g = np.load(os.path.join(golden_dir, "g8_detector_grads.npz"))
+    G, B, T, seed = [int(v) for v in g["meta"]]
+    o, sd, vox = _setup(G=G, B=B, T=T, seed=seed)
+    w = {k: float(v) for k, v in zip(DETECTOR_LOSS_KEYS, g["weights"])}
+    loss, got, out = _hip_grads(o, sd, vox, w)
+    assert abs(loss - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    for i, k in enumerate(DETECTOR_LOSS_KEYS):
+        assert abs(float(out[k]) - float(g["losses"][i])) <= 2e-5 * max(1.0, abs(float(g["losses"][i]))), k
+    gmax = max(float(g[f][2]) for f in g.files if f.startswith("g:"))
+    worst = 0.0
+    for name, gr in got.items():
+        ref = g["g:" + name[len("kypt_detector."):]]
+        flat = gr.reshape(-1).double()
+        scale = max(float(ref[2]), 1e-6 * gmax)
+        e = np.abs(flat[::997].numpy() - ref[3:]).max() / scale
+        worst = max(worst, e)
+        assert e < 3e-3, (name, e)      # both sides are fp32: the fixture itself is up to 1e-3 from the fp64 gradient
+    print("worst relative difference to the reference's gradients %.2e" % worst)
+
+
 def test_detector_gradients_exact_fp32_mode():
     """Exact fp32-MFMA convolutions everywhere (conv mode 'fp32'): under the training weighting the HIP gradients sit closer to the
     fp64 gradients than the fp32 oracle does.  (The single-loss weightings are not run in this mode: a keypoint-only loss sends

@@ -261,7 +261,42 @@ def case_g7():
     print("g7 ok", ch["scores_log"], se["scores_log"])
 
 
-CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6, g7=case_g7)
+def case_g8():
+    """Detector-mode training gradients (pretrained_mode=0, train.py:270-276,388-404): d(sum_k w_k * loss_k) / d(kypt_detector
+    parameters) by the reference's autograd with the AIST loss weights (train.py:177-181), 32^3, B=2, T=4, 'peaky' weights and
+    random affinity logits.  Every gradient is stored as (sum, abs-sum, max-abs, every 997th element)."""
+    G, B, T, seed = 32, 2, 4, 11
+    opt = _ref_opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=seed, variant="peaky")
+    gen = torch.Generator().manual_seed(seed + 1)
+    sd["kypt_detector.affinity_params"] = torch.randn(sd["kypt_detector.affinity_params"].shape, generator=gen)
+    vox = synth.figure_clip(B, T, G, seed=seed + 2)
+    net = _ref_net(opt, sd).train()
+    acts = {"detector": True, "learner": False}
+    net.control_active(acts)
+    for p in net.parameters():
+        p.grad = None
+    log = net(vox, acts)
+    w = dict(recon_loss=opt.recon_weight, sparsity_loss=opt.sparse_weight, separation_loss=opt.sep_weight, vol_fit_reg=opt.vol_reg_weight,
+             kypt_const_loss=opt.kypt_const_weight, local_const_loss=opt.local_const_weight, time_const_loss=opt.time_const_weight,
+             sparsity_const_loss=opt.sparsity_const_weight, intensity_const_loss=opt.intensity_const_weight,
+             graph_traj_loss=opt.graph_traj_weight, graph_vol_loss=opt.graph_vol_weight)
+    loss = sum(float(w[k]) * log[k] for k in DETECTOR_LOSS_KEYS)
+    loss.backward()
+    out = dict(meta=np.array([G, B, T, seed]), loss=np.array(float(loss)), weights=np.array([float(w[k]) for k in DETECTOR_LOSS_KEYS]),
+               losses=np.array([float(log[k]) for k in DETECTOR_LOSS_KEYS]))
+    n = 0
+    for name, p in net.kypt_detector.named_parameters():
+        assert p.grad is not None, name
+        gflat = p.grad.reshape(-1).double()
+        out["g:" + name] = np.concatenate([[gflat.sum().item(), gflat.abs().sum().item(), gflat.abs().max().item()], gflat[::997].numpy()])
+        n += 1
+    np.savez_compressed(os.path.join(OUT, "g8_detector_grads.npz"), **out)
+    print("g8 ok", float(loss), n, "tensors")
+
+
+CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6, g7=case_g7, g8=case_g8)
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
