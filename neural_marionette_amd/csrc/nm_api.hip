@@ -298,7 +298,7 @@ int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
         a = make_ref(up, nullptr, nullptr, 1.0f, N, FD, FH, FW, Cin_pad);
     }
     float* ws = ctx->ws.f(wsf);
-    if ((rc = nm_launch_wgrad(a, dyT, ks, stride, pad, Cin, ws, d_weight, s))) return rc;
+    if ((rc = nm_launch_wgrad(a, dyT, ks, stride, pad, Cin, ws, d_weight, s, nullptr, nm_conv_get_mode() != 0))) return rc;
     float* bp = ctx->ws.f((size_t)N * nbb * Cout * 2);
     if ((rc = nm_launch_gnb_partials(dy, dyT, bp, s))) return rc;
     if ((rc = nm_launch_sum_partials(bp, N * nbb, Cout, d_bias, s))) return rc;

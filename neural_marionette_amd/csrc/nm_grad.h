@@ -7,8 +7,10 @@
 // Both operands are lazy tensors (ConvTranspose3d weight gradients swap the roles: the activated input plays dy).
 // `ws` holds the per-workgroup partial tiles (nm_wgrad_ws_floats), reduced in a fixed order: deterministic, no atomics.
 size_t nm_wgrad_ws_floats(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride);
+// mul (optional): device scalar multiplied into the result (dy was read pre-scaled by its inverse, see nm_launch_make_scale);
+// allow_f16: 3x3x3 stride-1 layers whose extents fit the 2x8x8 brick run on the split-fp16 MFMA kernel (fp32-equivalent products)
 int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride, int pad, int cin_real, float* ws,
-                    float* dW, hipStream_t s);
+                    float* dW, hipStream_t s, const float* mul = nullptr, int allow_f16 = 0);
 // first layer (Basic3DBlock k5 on cat[occ, x1, x2, x3], kypt_detector.py:265): the input is rebuilt from the occupancy
 // grid while staging; dW is [Cout][4][5][5][5]
 size_t nm_wgrad_k5occ_ws_floats(int N, int G, int M);

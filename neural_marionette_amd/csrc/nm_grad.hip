@@ -142,9 +142,151 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+// ---- split-fp16 weight gradient for the 3x3x3 stride-1 convolutions (the bulk of the backward FLOPs) ---------------------------
+// Same implicit GEMM (K = voxels) on v_mfma_f32_32x32x16_f16 with every fp32 operand split into fp16 hi + lo * 2^-11 and three
+// products hi*hi + 2^-11 (hi*lo + lo*hi), fp32 accumulate (the forward's arithmetic, nm_conv.hip).  This MFMA wants 8
+// consecutive K elements per lane, i.e. 8 voxels of one channel, so the staging transposes the channels-last tiles into
+// [channel][row][x] fp16 planes (one row = the brick's 8 x positions, 10 with the halo).  The tap's x shift (dx = 0, 1, 2) is
+// taken in registers: a lane reads the 10 halves of its halo row once (16 B + 4 B, aligned) and forms the three shifted
+// operands with v_alignbit, so one pair of LDS reads serves three taps; the nine (dz, dy) row groups are dealt to the four waves
+// (3, 2, 2, 2).  Brick 2 x 8 x 8 voxels; LDS 98 KB: A planes [32 ch][40 rows][32 B] + dY planes [32 ch][16 rows][16 B], channel
+// pitch + 16 B (conflict-free 16-B operand reads).  dy arrives pre-scaled by a power of two (DyScale) - gradients sit below the
+// fp16 normal range otherwise - and the reduce multiplies by its inverse.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define W16_PA (40 * 32 + 16)
+#define W16_PD (16 * 16 + 16)
+#define W16_LDS (2 * 32 * W16_PA + 2 * 32 * W16_PD)
+#define W16_SPLIT 2048.0f
+
+__device__ __forceinline__ unsigned pack_split(float v0, float v1, unsigned& lo_out) {
+    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+    const _Float16 l0 = (_Float16)((v0 - (float)h0) * W16_SPLIT), l1 = (_Float16)((v1 - (float)h1) * W16_SPLIT);
+    lo_out = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void wgrad16_kernel(WgradParams p) {
+    extern __shared__ char lds8[];
+    char* A_hi = lds8; char* A_lo = A_hi + 32 * W16_PA; char* D_hi = A_lo + 32 * W16_PA; char* D_lo = D_hi + 32 * W16_PD;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, w = tid >> 6;
+    const int tp = blockIdx.y, mt = tp / p.n_tiles, nt = tp % p.n_tiles, m0 = mt * 32, n0 = nt * 32;
+    const int OD = p.dy.D, OH = p.dy.H, OW = p.dy.W;
+    f32x16 acc[3][3], accl[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[j][d][r] = 0.f; accl[j][d][r] = 0.f; }
+    int goff[3]; bool gv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int g = w + 4 * j;
+        gv[j] = g < 9;
+        goff[j] = ((g / 3) * 10 + (g % 3)) * 32;          // byte offset of the (dz, dy) row shift inside a channel's plane
+    }
+    const int per_frame = p.nbz * p.nby * p.nbx;
+    const int total = p.in.N * per_frame;
+    for (int b = blockIdx.x; b < total; b += p.S) {
+        const int n = b / per_frame; int r = b % per_frame;
+        const int bx = r % p.nbx; r /= p.nbx;
+        const int by = r % p.nby, bz = r / p.nby;
+        const int oz0 = bz * 2, oy0 = by * 8, ox0 = bx * 8;
+        __syncthreads();
+        for (int task = tid; task < 448; task += 256) {
+            if (task < 320) {               // halo row (hz, hy) of input channels [c, c+4): 10 x positions
+                const int row = task >> 3, q = task & 7, c = n0 + 4 * q;
+                const int gz = oz0 - 1 + row / 10, gy = oy0 - 1 + row % 10;
+                const bool rin = (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && c < p.Nc;
+                f32x4 v[10];
+#pragma unroll
+                for (int x = 0; x < 10; ++x) {
+                    const int gx = ox0 - 1 + x;
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    if (rin && (unsigned)gx < (unsigned)p.in.W) t = load_act4(p.in, n, gz, gy, gx, c);
+                    v[x] = t;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned hi[5], lo[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) hi[i] = pack_split(v[2 * i][j], v[2 * i + 1][j], lo[i]);
+                    char* dh = A_hi + (4 * q + j) * W16_PA + row * 32; char* dl = A_lo + (4 * q + j) * W16_PA + row * 32;
+                    *reinterpret_cast<u32x4*>(dh) = u32x4{hi[0], hi[1], hi[2], hi[3]}; *reinterpret_cast<unsigned*>(dh + 16) = hi[4];
+                    *reinterpret_cast<u32x4*>(dl) = u32x4{lo[0], lo[1], lo[2], lo[3]}; *reinterpret_cast<unsigned*>(dl + 16) = lo[4];
+                }
+            } else {                        // dY row (z, y) of channels [m, m+4): 8 x positions
+                const int t2 = task - 320, row = t2 >> 3, q = t2 & 7, m = m0 + 4 * q;
+                const int oz = oz0 + (row >> 3), oy = oy0 + (row & 7);
+                f32x4 v[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    if (m < p.M) t = load_act4(p.dy, n, oz, oy, ox0 + x, m);
+                    v[x] = t;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned hi[4], lo[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hi[i] = pack_split(v[2 * i][j], v[2 * i + 1][j], lo[i]);
+                    *reinterpret_cast<u32x4*>(D_hi + (4 * q + j) * W16_PD + row * 16) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                    *reinterpret_cast<u32x4*>(D_lo + (4 * q + j) * W16_PD + row * 16) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+                }
+            }
+        }
+        __syncthreads();
+        const char* ah_base = D_hi + l31 * W16_PD; const char* al_base = D_lo + l31 * W16_PD;
+        const char* bh_base = A_hi + l31 * W16_PA; const char* bl_base = A_lo + l31 * W16_PA;
+#pragma unroll 2
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int row = 2 * s8 + lh;
+            const half8 ah = *reinterpret_cast<const half8*>(ah_base + row * 16);
+            const half8 al = *reinterpret_cast<const half8*>(al_base + row * 16);
+            const int brow = ((row >> 3) * 10 + (row & 7)) * 32;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (!gv[j]) continue;
+                const u32x4 qh = *reinterpret_cast<const u32x4*>(bh_base + brow + goff[j]);
+                const unsigned eh = *reinterpret_cast<const unsigned*>(bh_base + brow + goff[j] + 16);
+                const u32x4 ql = *reinterpret_cast<const u32x4*>(bl_base + brow + goff[j]);
+                const unsigned el = *reinterpret_cast<const unsigned*>(bl_base + brow + goff[j] + 16);
+                half8 bh[3], bl[3];
+                bh[0] = __builtin_bit_cast(half8, qh); bl[0] = __builtin_bit_cast(half8, ql);
+                bh[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(qh[1], qh[0], 16), __builtin_amdgcn_alignbit(qh[2], qh[1], 16),
+                                                        __builtin_amdgcn_alignbit(qh[3], qh[2], 16), __builtin_amdgcn_alignbit(eh, qh[3], 16)});
+                bl[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(ql[1], ql[0], 16), __builtin_amdgcn_alignbit(ql[2], ql[1], 16),
+                                                        __builtin_amdgcn_alignbit(ql[3], ql[2], 16), __builtin_amdgcn_alignbit(el, ql[3], 16)});
+                bh[2] = __builtin_bit_cast(half8, u32x4{qh[1], qh[2], qh[3], eh}); bl[2] = __builtin_bit_cast(half8, u32x4{ql[1], ql[2], ql[3], el});
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    acc[j][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[d], acc[j][d], 0, 0, 0);
+                    accl[j][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[d], accl[j][d], 0, 0, 0);
+                    accl[j][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[d], accl[j][d], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (!gv[j]) continue;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int t = (w + 4 * j) * 3 + d;
+            float* dst = p.part + (((size_t)blockIdx.x * gridDim.y + tp) * 27 + t) * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][d][r] + accl[j][d][r] * (1.0f / W16_SPLIT);
+        }
+    }
+}
+
 // dW[m][c][tap] (+)= sum over slots; thread order: c fastest (coalesced partial reads)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int slots, int tiles, int n_tiles, int groups,
-                                                           int M, int Cin, int taps, int k5occ, float* __restrict__ dW) {
+                                                           int M, int Cin, int taps, int k5occ, const float* __restrict__ mul,
+                                                           float* __restrict__ dW) {
+    const float mm = mul ? *mul : 1.0f;
     const int total = M * Cin * taps;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int c = i % Cin, m = (i / Cin) % M, tap = i / (Cin * M);
@@ -155,7 +297,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const size_t stride = (size_t)tiles * groups * 1024;
         float s = 0.f;
         for (int k = 0; k < slots; ++k) s += src[(size_t)k * stride];
-        dW[((size_t)m * Cin + c) * taps + tap] = s;
+        dW[((size_t)m * Cin + c) * taps + tap] = s * mm;
     }
 }
 
@@ -390,12 +532,26 @@ int grid_for(size_t work_items) { return (int)min((work_items + 255) / 256, (siz
 
 struct WgradPlan { WgradParams p; int mode, m_tiles, slots; size_t lds, ws_floats; };
 
-WgradPlan plan_wgrad(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride, bool k5occ) {
+// split-fp16 kernel: 3x3x3, stride 1, "same" padding, output extents multiples of the 2 x 8 x 8 brick
+bool wgrad16_eligible(int OD, int OH, int OW, int ks, int stride) {
+    return ks == 3 && stride == 1 && OD % 2 == 0 && OH % 8 == 0 && OW % 8 == 0;
+}
+
+WgradPlan plan_wgrad(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride, bool k5occ, bool f16 = false) {
     WgradPlan q;
     WgradParams& p = q.p;
     p.ks = ks; p.stride = stride; p.M = M; p.Nc = Nc;
     q.mode = k5occ ? 2 : (ks == 1 ? 1 : 0);
     int bz = 4, by = 8, bx = 8;
+    if (f16) {
+        q.mode = 3;
+        p.BZ = 2; p.BY = 8; p.BX = 8; p.nbz = OD / 2; p.nby = OH / 8; p.nbx = OW / 8; p.HZ = 4; p.HY = 10; p.HX = 10;
+        q.m_tiles = (M + 31) / 32; p.n_tiles = (Nc + 31) / 32; p.groups = 27;
+        const int tiles = q.m_tiles * p.n_tiles, total = N * p.nbz * p.nby * p.nbx;
+        p.S = max(1, min(total, 256 / tiles));
+        q.slots = p.S; q.lds = W16_LDS; q.ws_floats = (size_t)q.slots * tiles * 27 * 1024;
+        return q;
+    }
     if (stride == 2) { bz = 2; by = 4; bx = 8; }
     p.BX = min(bx, (OW + 1) & ~1); p.BY = min(by, OH); p.BZ = min(bz, OD);
     p.nbx = (OW + p.BX - 1) / p.BX; p.nby = (OH + p.BY - 1) / p.BY; p.nbz = (OD + p.BZ - 1) / p.BZ;
@@ -425,11 +581,24 @@ int launch_wgrad_t(const WgradPlan& q, hipStream_t s) {
     return nm_check_hip(hipGetLastError(), "wgrad launch");
 }
 
-int run_wgrad(WgradPlan& q, float* ws, float* dW, int cin_real, int taps, hipStream_t s) {
+int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            nm_set_error("wgrad16: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad16_kernel, dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
+    return nm_check_hip(hipGetLastError(), "wgrad16 launch");
+}
+
+int run_wgrad(WgradPlan& q, float* ws, float* dW, int cin_real, int taps, hipStream_t s, const float* mul = nullptr) {
     if (q.lds > 160 * 1024) { nm_set_error("wgrad: LDS tile of %zu bytes", q.lds); return NM_ERR_UNSUPPORTED; }
     q.p.part = ws;
     int rc;
-    if (q.mode == 2) rc = launch_wgrad_t<2, 7>(q, s);
+    if (q.mode == 3) rc = launch_wgrad16(q, s);
+    else if (q.mode == 2) rc = launch_wgrad_t<2, 7>(q, s);
     else if (q.mode == 1) rc = launch_wgrad_t<1, 1>(q, s);
     else if (q.p.ks == 2) rc = launch_wgrad_t<0, 2>(q, s);
     else if (q.p.ks == 3) rc = launch_wgrad_t<0, 7>(q, s);
@@ -438,23 +607,26 @@ int run_wgrad(WgradPlan& q, float* ws, float* dW, int cin_real, int taps, hipStr
     const int tiles = q.m_tiles * q.p.n_tiles;
     const int total = q.p.M * cin_real * taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min((total + 255) / 256, 4096)), dim3(256), 0, s, ws, q.slots, tiles, q.p.n_tiles,
-                       q.p.groups, q.p.M, cin_real, taps, q.mode == 2 ? 1 : 0, dW);
+                       q.p.groups, q.p.M, cin_real, taps, q.mode == 2 ? 1 : 0, mul, dW);
     return nm_check_hip(hipGetLastError(), "wgrad reduce launch");
 }
 
 }  // namespace
 
 size_t nm_wgrad_ws_floats(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride) {
-    return plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false).ws_floats;
+    size_t a = plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false).ws_floats;
+    if (wgrad16_eligible(OD, OH, OW, ks, stride)) a = max(a, plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false, true).ws_floats);
+    return a;
 }
 size_t nm_wgrad_k5occ_ws_floats(int N, int G, int M) { return plan_wgrad(N, G, G, G, M, 4, 5, 1, true).ws_floats; }
 
 int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride, int pad, int cin_real, float* ws, float* dW,
-                    hipStream_t s) {
+                    hipStream_t s, const float* mul, int allow_f16) {
     if (in.C % 4 || dy.C % 4 || in.N != dy.N) { nm_set_error("wgrad: channel counts must be multiples of 4 and frame counts equal"); return NM_ERR_ARG; }
-    WgradPlan q = plan_wgrad(in.N, dy.D, dy.H, dy.W, dy.C, in.C, ks, stride, false);
+    const bool f16 = allow_f16 && pad == 1 && wgrad16_eligible(dy.D, dy.H, dy.W, ks, stride) && in.D == dy.D && in.H == dy.H && in.W == dy.W;
+    WgradPlan q = plan_wgrad(in.N, dy.D, dy.H, dy.W, dy.C, in.C, ks, stride, false, f16);
     q.p.in = in; q.p.dy = dy; q.p.pad = pad;
-    return run_wgrad(q, ws, dW, cin_real, ks * ks * ks, s);
+    return run_wgrad(q, ws, dW, cin_real, ks * ks * ks, s, mul);
 }
 
 int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s) {

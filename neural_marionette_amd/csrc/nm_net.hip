@@ -587,10 +587,12 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din) {
     const TensorRef& in = r.in;
     float* din = need_din ? b.alloc((size_t)in.N * in.D * in.H * in.W * w.csel) : nullptr;
     const size_t m = b.ws.mark();
+    const bool split = nm_conv_get_mode() != 0;          // split-fp16 kernels: dy is read pre-scaled by a power of two
     DyScale ds;
-    ds.prepare(b, need_din && r.stride == 1 && w.wd16 && nm_conv_get_mode() != 0, r.out.N * r.out.C);
+    ds.prepare(b, split && r.stride == 1 && (w.ks == 3 || (need_din && w.wd16)), r.out.N * r.out.C);
     const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, w.key + ".bias", dA, ds.amax);
     const TensorRef dyT = plain(dy, r.out);
+    const TensorRef dyS = ds.apply(b, dyT);
     {   // weight gradient
         const size_t m2 = b.ws.mark();
         TensorRef a = in;
@@ -601,7 +603,7 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din) {
         }
         float* wsb = b.alloc(nm_wgrad_ws_floats(in.N, r.out.D, r.out.H, r.out.W, w.Cout, in.C, w.ks, r.stride));
         float* gw = b.grad(w.key + ".weight", (int64_t)w.Cout * w.Cin * w.ks * w.ks * w.ks);
-        if (b.live()) b.run(nm_launch_wgrad(a, dyT, w.ks, r.stride, r.pad, w.Cin, wsb, gw, b.s));
+        if (b.live()) b.run(nm_launch_wgrad(a, dyS, w.ks, r.stride, r.pad, w.Cin, wsb, gw, b.s, ds.inv(), split ? 1 : 0));
         b.ws.release(m2);
     }
     if (need_din) {
@@ -613,7 +615,6 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din) {
             if (b.live()) {
                 if (!w.wd) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
             }
-            const TensorRef dyS = ds.apply(b, dyT);
             if (b.live()) {
                 b.run(nm_launch_conv(dyS, w.wd, b.zb, dfine, g, nullptr, b.s, w.Cout, w.wd16));
                 if (r.up2) b.run(nm_launch_upsample2_adjoint(dfine, in.N, in.D, in.H, in.W, w.csel, din, b.s, ds.inv()));

@@ -31,6 +31,12 @@ BWD_CASES = [
     (128, 128, 3, 1, 1, 8, 8, True, False, 128),
     (64, 128, 3, 1, 1, 8, 8, True, False, 64),
     (64, 128, 1, 1, 0, 8, 8, True, False, 64),
+    # split-fp16 weight-gradient kernel (2x8x8 bricks): several bricks per workgroup, 2 / 4 / 8 tile pairs, ragged channel tiles
+    (32, 32, 3, 1, 1, 16, 6, True, False, 32),
+    (64, 64, 3, 1, 1, 16, 3, False, False, 64),
+    (128, 64, 3, 1, 1, 8, 5, True, False, 128),
+    (48, 72, 3, 1, 1, 8, 3, True, False, 48),
+    (64, 32, 3, 1, 1, 8, 2, True, True, 64),
     # hourglass floor of a 32^3 grid: 1^3 and 2^3 volumes
     (72, 72, 3, 1, 1, 1, 8, True, False, 72),
     (48, 72, 1, 1, 0, 1, 8, False, False, 48),
