@@ -14,6 +14,7 @@
 //                        group) coefficients, then dy = c1*dz + c2*y + c3.   HBM-bound.
 //   upsample2_adjoint    adjoint of the trilinear x2 upsampling (gather form, deterministic).  HBM-bound.
 #include "nm_grad.h"
+#include <cstdlib>
 
 namespace {
 
@@ -46,6 +47,7 @@ struct WgradParams {
     int M, Nc;               // dy channels / input channels that take part
     int BZ, BY, BX, nbz, nby, nbx, HZ, HY, HX;
     int S, n_tiles, groups;  // split count, column tiles, tap groups per tile
+    int dbg;                 // diagnostics (NM355_W16_DBG): 1 no MFMA phase, 2 no global loads, 3 no loads / LDS stores, 4 LDS stores only
 };
 
 // MODE 0: taps dealt to the waves (NTW per wave);  MODE 1: ks = 1, the waves split the voxels;
@@ -158,127 +160,188 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define W16_LDS (2 * 32 * W16_PA + 2 * 32 * W16_PD)
 #define W16_SPLIT 2048.0f
 
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (v0, v1) -> packed fp16 hi pair (v_cvt_pk_f16_f32) and packed lo pair, lo = fp16((v - hi) * 2^11) as one fma each (v_fma_mix)
 __device__ __forceinline__ unsigned pack_split(float v0, float v1, unsigned& lo_out) {
-    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-    const _Float16 l0 = (_Float16)((v0 - (float)h0) * W16_SPLIT), l1 = (_Float16)((v1 - (float)h1) * W16_SPLIT);
-    lo_out = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-    return (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    half2v hh = __builtin_convertvector(f32x2{v0, v1}, half2v);
+    asm volatile("" : "+v"(hh));                 // keep the packed pair (no per-half re-conversion)
+    half2v ll;
+    ll[0] = (_Float16)__builtin_fmaf((float)hh[0], -W16_SPLIT, v0 * W16_SPLIT);
+    ll[1] = (_Float16)__builtin_fmaf((float)hh[1], -W16_SPLIT, v1 * W16_SPLIT);
+    lo_out = __builtin_bit_cast(unsigned, ll);
+    return __builtin_bit_cast(unsigned, hh);
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// one staging task: the 10 (halo row) or 8 (dY row) voxels x 4 channels a thread fetches for the next brick
+struct W16Task { const float* p; const float* sc; const float* sh; float slope; int stride; unsigned mask; };
+
+__device__ __forceinline__ void w16_fetch(const W16Task& t, f32x4 (&v)[10]) {
+#pragma unroll
+    for (int x = 0; x < 10; ++x) {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if ((t.mask >> x) & 1u) r = *reinterpret_cast<const f32x4*>(t.p + (size_t)x * t.stride);
+        v[x] = r;
+    }
+}
+// activation + fp16 hi/lo split + 16-B rows into the hi / lo planes
+template <int NX>
+__device__ __forceinline__ void w16_store(const W16Task& t, const f32x4 (&v)[10], char* hi_plane, char* lo_plane, int pitch, int q, int row_off) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (t.sc) { sc = *reinterpret_cast<const f32x4*>(t.sc); sh = *reinterpret_cast<const f32x4*>(t.sh); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned hi[NX / 2], lo[NX / 2];
+#pragma unroll
+        for (int i = 0; i < NX / 2; ++i) {
+            float a0 = v[2 * i][j], a1 = v[2 * i + 1][j];
+            if (t.sc) { a0 = fmaf(a0, sc[j], sh[j]); a1 = fmaf(a1, sc[j], sh[j]); }
+            if (t.slope != 1.0f) { a0 = fmaxf(a0, a0 * t.slope); a1 = fmaxf(a1, a1 * t.slope); }
+            if (!((t.mask >> (2 * i)) & 1u)) a0 = 0.f;             // outside the volume: zero padding, not act(0)
+            if (!((t.mask >> (2 * i + 1)) & 1u)) a1 = 0.f;
+            hi[i] = pack_split(a0, a1, lo[i]);
+        }
+        char* dh = hi_plane + (4 * q + j) * pitch + row_off; char* dl = lo_plane + (4 * q + j) * pitch + row_off;
+        *reinterpret_cast<u32x4*>(dh) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(dl) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        if (NX == 10) { *reinterpret_cast<unsigned*>(dh + 16) = hi[4]; *reinterpret_cast<unsigned*>(dl + 16) = lo[4]; }
+    }
+}
+
+// raw LDS words of one (dz, dy) row group for one k-step: 10 halves of the hi and lo planes
+struct W16Raw { u32x4 qh, ql; unsigned eh, el; };
+__device__ __forceinline__ W16Raw w16_read(const char* bh, const char* bl, int off) {
+    W16Raw r;
+    r.qh = *reinterpret_cast<const u32x4*>(bh + off); r.eh = *reinterpret_cast<const unsigned*>(bh + off + 16);
+    r.ql = *reinterpret_cast<const u32x4*>(bl + off); r.el = *reinterpret_cast<const unsigned*>(bl + off + 16);
+    return r;
+}
+template <int DX>
+__device__ __forceinline__ half8 w16_shift(const u32x4& q, unsigned e) {
+    if (DX == 0) return __builtin_bit_cast(half8, q);
+    if (DX == 2) return __builtin_bit_cast(half8, u32x4{q[1], q[2], q[3], e});
+    return __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                                           __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(e, q[3], 16)});
+}
+#define W16_MMA(ACC, ACCL, AH, AL, BH, BL)                                   \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);      \
+    ACCL = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, ACCL, 0, 0, 0);    \
+    ACCL = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, ACCL, 0, 0, 0);
+
+// Taps per wave: two full (dz, dy) row groups {w, w + 4} (3 dx taps each, one LDS read pair per group) and, for waves 1..3, the tap
+// dx = w - 1 of the ninth group: 6, 7, 7, 7 taps.  The global loads of the next brick are issued before the MFMA phase of the
+// current one (the only wave on its SIMD has nothing else to hide them behind) and converted / written to LDS after it.
 __global__ __launch_bounds__(256) void wgrad16_kernel(WgradParams p) {
     extern __shared__ char lds8[];
     char* A_hi = lds8; char* A_lo = A_hi + 32 * W16_PA; char* D_hi = A_lo + 32 * W16_PA; char* D_lo = D_hi + 32 * W16_PD;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, w = tid >> 6;
     const int tp = blockIdx.y, mt = tp / p.n_tiles, nt = tp % p.n_tiles, m0 = mt * 32, n0 = nt * 32;
-    const int OD = p.dy.D, OH = p.dy.H, OW = p.dy.W;
-    f32x16 acc[3][3], accl[3][3];
+    f32x16 acc[7], accl[7];           // [0..2] group w, [3..5] group w + 4, [6] the single tap of group 8
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[j][d][r] = 0.f; accl[j][d][r] = 0.f; }
-    int goff[3]; bool gv[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int g = w + 4 * j;
-        gv[j] = g < 9;
-        goff[j] = ((g / 3) * 10 + (g % 3)) * 32;          // byte offset of the (dz, dy) row shift inside a channel's plane
-    }
+        for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accl[j][r] = 0.f; }
+    const int g0 = w, g1 = w + 4;
+    const int off0 = ((g0 / 3) * 10 + (g0 % 3)) * 32, off1 = ((g1 / 3) * 10 + (g1 % 3)) * 32, off2 = (2 * 10 + 2) * 32;
+
     const int per_frame = p.nbz * p.nby * p.nbx;
     const int total = p.in.N * per_frame;
-    for (int b = blockIdx.x; b < total; b += p.S) {
+    // staging roles: every thread one halo row task (rows 0..31 x 8 channel quads); second slot: wave 0 the halo rows 32..39,
+    // waves 1-2 the 16 dY rows, wave 3 none
+    const int qa = tid & 7, rowa = tid >> 3;
+    const int rowb = w == 0 ? 32 + (tid >> 3) : ((tid - 64) >> 3);
+    W16Task ta, tb;
+    f32x4 va[10], vb[10];
+    auto setup = [&](int b) __attribute__((always_inline)) {
         const int n = b / per_frame; int r = b % per_frame;
         const int bx = r % p.nbx; r /= p.nbx;
         const int by = r % p.nby, bz = r / p.nby;
         const int oz0 = bz * 2, oy0 = by * 8, ox0 = bx * 8;
+        auto halo_task = [&](int row, W16Task& t) __attribute__((always_inline)) {
+            const int c = n0 + 4 * qa;
+            const int gz = oz0 - 1 + row / 10, gy = oy0 - 1 + row % 10;
+            const bool rin = (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && c < p.Nc;
+            unsigned mask = 0;
+#pragma unroll
+            for (int x = 0; x < 10; ++x) if (rin && (unsigned)(ox0 - 1 + x) < (unsigned)p.in.W) mask |= 1u << x;
+            t.mask = mask; t.stride = p.in.C; t.slope = p.in.slope;
+            t.p = p.in.p + ((((size_t)n * p.in.D + (rin ? gz : 0)) * p.in.H + (rin ? gy : 0)) * p.in.W + (ox0 - 1)) * p.in.C + (rin ? c : 0);
+            t.sc = p.in.scale ? p.in.scale + (size_t)n * p.in.C + (rin ? c : 0) : nullptr;
+            t.sh = p.in.scale ? p.in.shift + (size_t)n * p.in.C + (rin ? c : 0) : nullptr;
+        };
+        halo_task(rowa, ta);
+        if (w == 0) halo_task(rowb, tb);
+        else if (w < 3) {
+            const int m = m0 + 4 * qa;
+            const bool in = m < p.M;
+            tb.mask = in ? 0xffu : 0u; tb.stride = p.dy.C; tb.slope = p.dy.slope;
+            tb.p = p.dy.p + ((((size_t)n * p.dy.D + oz0 + (rowb >> 3)) * p.dy.H + oy0 + (rowb & 7)) * p.dy.W + ox0) * p.dy.C + (in ? m : 0);
+            tb.sc = p.dy.scale ? p.dy.scale + (size_t)n * p.dy.C + (in ? m : 0) : nullptr;
+            tb.sh = p.dy.scale ? p.dy.shift + (size_t)n * p.dy.C + (in ? m : 0) : nullptr;
+        } else tb.mask = 0;
+    };
+    int b = blockIdx.x;
+    if (b < total) {
+        setup(b); w16_fetch(ta, va); if (w < 3) w16_fetch(tb, vb);
+    }
+    const char* ah_base = D_hi + l31 * W16_PD; const char* al_base = D_lo + l31 * W16_PD;
+    const char* bh_base = A_hi + l31 * W16_PA; const char* bl_base = A_lo + l31 * W16_PA;
+    for (; b < total; b += p.S) {
         __syncthreads();
-        for (int task = tid; task < 448; task += 256) {
-            if (task < 320) {               // halo row (hz, hy) of input channels [c, c+4): 10 x positions
-                const int row = task >> 3, q = task & 7, c = n0 + 4 * q;
-                const int gz = oz0 - 1 + row / 10, gy = oy0 - 1 + row % 10;
-                const bool rin = (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && c < p.Nc;
-                f32x4 v[10];
-#pragma unroll
-                for (int x = 0; x < 10; ++x) {
-                    const int gx = ox0 - 1 + x;
-                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                    if (rin && (unsigned)gx < (unsigned)p.in.W) t = load_act4(p.in, n, gz, gy, gx, c);
-                    v[x] = t;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned hi[5], lo[5];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) hi[i] = pack_split(v[2 * i][j], v[2 * i + 1][j], lo[i]);
-                    char* dh = A_hi + (4 * q + j) * W16_PA + row * 32; char* dl = A_lo + (4 * q + j) * W16_PA + row * 32;
-                    *reinterpret_cast<u32x4*>(dh) = u32x4{hi[0], hi[1], hi[2], hi[3]}; *reinterpret_cast<unsigned*>(dh + 16) = hi[4];
-                    *reinterpret_cast<u32x4*>(dl) = u32x4{lo[0], lo[1], lo[2], lo[3]}; *reinterpret_cast<unsigned*>(dl + 16) = lo[4];
-                }
-            } else {                        // dY row (z, y) of channels [m, m+4): 8 x positions
-                const int t2 = task - 320, row = t2 >> 3, q = t2 & 7, m = m0 + 4 * q;
-                const int oz = oz0 + (row >> 3), oy = oy0 + (row & 7);
-                f32x4 v[8];
-#pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                    if (m < p.M) t = load_act4(p.dy, n, oz, oy, ox0 + x, m);
-                    v[x] = t;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned hi[4], lo[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) hi[i] = pack_split(v[2 * i][j], v[2 * i + 1][j], lo[i]);
-                    *reinterpret_cast<u32x4*>(D_hi + (4 * q + j) * W16_PD + row * 16) = u32x4{hi[0], hi[1], hi[2], hi[3]};
-                    *reinterpret_cast<u32x4*>(D_lo + (4 * q + j) * W16_PD + row * 16) = u32x4{lo[0], lo[1], lo[2], lo[3]};
-                }
-            }
+        if (!(p.dbg == 3 && b != (int)blockIdx.x)) {
+            w16_store<10>(ta, va, A_hi, A_lo, W16_PA, qa, rowa * 32);
+            if (w == 0) w16_store<10>(tb, vb, A_hi, A_lo, W16_PA, qa, rowb * 32);
+            else if (w < 3) w16_store<8>(tb, vb, D_hi, D_lo, W16_PD, qa, rowb * 16);
         }
         __syncthreads();
-        const char* ah_base = D_hi + l31 * W16_PD; const char* al_base = D_lo + l31 * W16_PD;
-        const char* bh_base = A_hi + l31 * W16_PA; const char* bl_base = A_lo + l31 * W16_PA;
-#pragma unroll 2
-        for (int s8 = 0; s8 < 8; ++s8) {
-            const int row = 2 * s8 + lh;
-            const half8 ah = *reinterpret_cast<const half8*>(ah_base + row * 16);
-            const half8 al = *reinterpret_cast<const half8*>(al_base + row * 16);
-            const int brow = ((row >> 3) * 10 + (row & 7)) * 32;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (!gv[j]) continue;
-                const u32x4 qh = *reinterpret_cast<const u32x4*>(bh_base + brow + goff[j]);
-                const unsigned eh = *reinterpret_cast<const unsigned*>(bh_base + brow + goff[j] + 16);
-                const u32x4 ql = *reinterpret_cast<const u32x4*>(bl_base + brow + goff[j]);
-                const unsigned el = *reinterpret_cast<const unsigned*>(bl_base + brow + goff[j] + 16);
-                half8 bh[3], bl[3];
-                bh[0] = __builtin_bit_cast(half8, qh); bl[0] = __builtin_bit_cast(half8, ql);
-                bh[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(qh[1], qh[0], 16), __builtin_amdgcn_alignbit(qh[2], qh[1], 16),
-                                                        __builtin_amdgcn_alignbit(qh[3], qh[2], 16), __builtin_amdgcn_alignbit(eh, qh[3], 16)});
-                bl[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(ql[1], ql[0], 16), __builtin_amdgcn_alignbit(ql[2], ql[1], 16),
-                                                        __builtin_amdgcn_alignbit(ql[3], ql[2], 16), __builtin_amdgcn_alignbit(el, ql[3], 16)});
-                bh[2] = __builtin_bit_cast(half8, u32x4{qh[1], qh[2], qh[3], eh}); bl[2] = __builtin_bit_cast(half8, u32x4{ql[1], ql[2], ql[3], el});
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    acc[j][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[d], acc[j][d], 0, 0, 0);
-                    accl[j][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[d], accl[j][d], 0, 0, 0);
-                    accl[j][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[d], accl[j][d], 0, 0, 0);
-                }
+        const bool has_next = b + p.S < total;
+        if (has_next && p.dbg < 2) { setup(b + p.S); w16_fetch(ta, va); if (w < 3) w16_fetch(tb, vb); }
+        if (p.dbg == 1 || p.dbg == 4) continue;
+        // k-steps of 16 voxels (two brick rows).  LDS reads run one row group ahead of the MFMAs that consume them: group 1 is
+        // requested before the 9 MFMAs of group 0, group 2 / the next step's dY operand / the next step's group 0 before those of
+        // group 1 (a wave is alone on its SIMD: nothing else covers the LDS latency).
+        auto row_off = [&](int s8) __attribute__((always_inline)) { const int row = 2 * s8 + lh; return ((row >> 3) * 10 + (row & 7)) * 32; };
+        half8 ah = *reinterpret_cast<const half8*>(ah_base + lh * 16), al = *reinterpret_cast<const half8*>(al_base + lh * 16);
+        W16Raw r0 = w16_read(bh_base, bl_base, row_off(0) + off0), r1, r2;
+        auto kstep = [&](int s8, int chunk) __attribute__((always_inline)) {
+            const int brow = row_off(s8);
+            r1 = w16_read(bh_base, bl_base, brow + off1);
+            __builtin_amdgcn_sched_barrier(0);
+            W16_MMA(acc[0], accl[0], ah, al, w16_shift<0>(r0.qh, r0.eh), w16_shift<0>(r0.ql, r0.el))
+            W16_MMA(acc[1], accl[1], ah, al, w16_shift<1>(r0.qh, r0.eh), w16_shift<1>(r0.ql, r0.el))
+            W16_MMA(acc[2], accl[2], ah, al, w16_shift<2>(r0.qh, r0.eh), w16_shift<2>(r0.ql, r0.el))
+            __builtin_amdgcn_sched_barrier(0);
+            half8 nh = ah, nl = al;
+            if (w > 0) r2 = w16_read(bh_base, bl_base, brow + off2);
+            if (s8 < 7) {
+                const int nrow = 2 * (s8 + 1) + lh;
+                nh = *reinterpret_cast<const half8*>(ah_base + nrow * 16); nl = *reinterpret_cast<const half8*>(al_base + nrow * 16);
+                r0 = w16_read(bh_base, bl_base, row_off(s8 + 1) + off0);
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);
+            W16_MMA(acc[3], accl[3], ah, al, w16_shift<0>(r1.qh, r1.eh), w16_shift<0>(r1.ql, r1.el))
+            W16_MMA(acc[4], accl[4], ah, al, w16_shift<1>(r1.qh, r1.eh), w16_shift<1>(r1.ql, r1.el))
+            W16_MMA(acc[5], accl[5], ah, al, w16_shift<2>(r1.qh, r1.eh), w16_shift<2>(r1.ql, r1.el))
+            if (w == 1) { W16_MMA(acc[6], accl[6], ah, al, w16_shift<0>(r2.qh, r2.eh), w16_shift<0>(r2.ql, r2.el)) }
+            else if (w == 2) { W16_MMA(acc[6], accl[6], ah, al, w16_shift<1>(r2.qh, r2.eh), w16_shift<1>(r2.ql, r2.el)) }
+            else if (w == 3) { W16_MMA(acc[6], accl[6], ah, al, w16_shift<2>(r2.qh, r2.eh), w16_shift<2>(r2.ql, r2.el)) }
+            __builtin_amdgcn_sched_barrier(0);
+            ah = nh; al = nl;
+        };
+#pragma unroll 1
+        for (int s8 = 0; s8 < 8; ++s8) kstep(s8, -1);
+        // (converting the next brick's values between the MFMAs of the last k-steps was tried: it needs unrolled copies of the step to
+        //  keep the register indices static, which pushes the kernel over the 256 + 256 register file - 450 spills)
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (!gv[j]) continue;
+    for (int j = 0; j < 7; ++j) {
+        if (j == 6 && w == 0) continue;
+        const int t = j < 3 ? g0 * 3 + j : (j < 6 ? g1 * 3 + (j - 3) : 24 + (w - 1));
+        float* dst = p.part + (((size_t)blockIdx.x * gridDim.y + tp) * 27 + t) * 1024;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int t = (w + 4 * j) * 3 + d;
-            float* dst = p.part + (((size_t)blockIdx.x * gridDim.y + tp) * 27 + t) * 1024;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][d][r] + accl[j][d][r] * (1.0f / W16_SPLIT);
-        }
+        for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][r] + accl[j][r] * (1.0f / W16_SPLIT);
     }
 }
 
@@ -626,6 +689,8 @@ int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride
     const bool f16 = allow_f16 && pad == 1 && wgrad16_eligible(dy.D, dy.H, dy.W, ks, stride) && in.D == dy.D && in.H == dy.H && in.W == dy.W;
     WgradPlan q = plan_wgrad(in.N, dy.D, dy.H, dy.W, dy.C, in.C, ks, stride, false, f16);
     q.p.in = in; q.p.dy = dy; q.p.pad = pad;
+    static const int dbg = getenv("NM355_W16_DBG") ? atoi(getenv("NM355_W16_DBG")) : 0;
+    q.p.dbg = dbg;
     return run_wgrad(q, ws, dW, cin_real, ks * ks * ks, s, mul);
 }
 
