@@ -194,3 +194,65 @@ def test_detector_training_trajectory_vs_oracle():
         num += (p.detach().cpu() - r).abs().sum().item(); den += r.numel()
     print("mean weight difference after 3 steps %.2e (lr 4e-4, each weight moved ~1e-3)" % (num / den))
     assert num / den < 2e-5
+
+
+def test_joint_step_detector_and_learner_active():
+    """Both modules active in one step (detector_time and learner_time overlapping, train.py:177-199): the detector trains on its
+    11 losses, the learner on keypoints.detach() (neural_marionette.py:53); every one of the 336 trainable tensors gets the
+    gradient the oracle's autograd gives for the same total loss."""
+    from neural_marionette_amd.train import DETECTOR_LOSS_WEIGHTS, LEARNER_LOSS_WEIGHTS
+    o, sd, vox = _setup(seed=51)
+    B, T = vox.shape[:2]
+    eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=52)
+    # oracle
+    names = [k for k in sd if k != "dyna_module.offset_param"]
+    leaf = {k: sd[k].clone().double().requires_grad_(True) for k in names}
+    sd2 = {k: v.double() for k, v in sd.items()}; sd2.update(leaf)
+    det = O.detector_forward(sd2, o, vox.double(), affinity_on=True)
+    net = NeuralMarionette(o)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    net.anneal(1)
+    acts = {"detector": True, "learner": True}
+    net.control_active(acts)
+    net.zero_grad()
+    out = net(vox.cuda(), acts, eps=eps.cuda())
+    order, parents = net.dyna_module.priority.indices.cpu().numpy(), net.dyna_module.parents.cpu().numpy()
+    enc = O.vrnn_encode(sd2, o, det["keypoints"].detach(), order, parents, eps.double())
+    ref_loss = sum(w * det[k] for k, w in DETECTOR_LOSS_WEIGHTS.items()) + sum(w * enc[k] for k, w in LEARNER_LOSS_WEIGHTS.items())
+    ref = dict(zip(names, torch.autograd.grad(ref_loss, [leaf[k] for k in names], allow_unused=True)))
+    loss = sum(w * out[k] for k, w in DETECTOR_LOSS_WEIGHTS.items()) + sum(w * out[k] for k, w in LEARNER_LOSS_WEIGHTS.items())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * abs(float(ref_loss.detach()))
+    got = {n: p.grad for n, p in net.named_parameters()}
+    assert got["dyna_module.offset_param"] is None or float(got["dyna_module.offset_param"].abs().max()) == 0.0
+    checked = 0
+    for k, r in ref.items():
+        assert r is not None and got[k] is not None, k
+        e = (got[k].cpu().double() - r).abs().max().item() / max(r.abs().max().item(), 1e-12)
+        assert e < 3e-3, (k, e)
+        checked += 1
+    assert checked == 336
+
+
+def test_training_api_misuse_is_reported():
+    """nm_detector_backward without a training forward, and a training forward without the training weight packs, fail loudly."""
+    from neural_marionette_amd import _lib
+    o, sd, vox = _setup(seed=61)
+    net = NeuralMarionette(o)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    net.anneal(1)
+    with torch.no_grad():
+        net(vox.cuda(), {"detector": True, "learner": False})
+    eng = net._engine
+    dl = torch.ones(len(DETECTOR_LOSS_KEYS), device="cuda")
+    g = torch.zeros(3, device="cuda")
+    arr = (_lib.NmNamedTensor * 1)()
+    arr[0].name, arr[0].data, arr[0].numel = b"kypt_detector.affinity_params", g.data_ptr(), g.numel()
+    with pytest.raises(_lib.NmError, match="no training forward"):
+        eng.call("nm_detector_backward", _lib.ptr(dl), arr, 1)
+    kp = torch.empty(2, 4, o.nkeypoints, 4, device="cuda")
+    with pytest.raises(_lib.NmError, match="nm_ctx_set_training"):
+        eng.call("nm_detector_forward_train", _lib.ptr(vox.cuda()), 2, 4, 1, _lib.ptr(kp), _lib.ptr(kp), _lib.ptr(kp), _lib.ptr(kp), None, _lib.ptr(kp))
