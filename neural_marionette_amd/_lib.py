@@ -76,7 +76,7 @@ SIGNATURES = {
     "nm_op_pack_input": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _P]),
     "nm_op_cl_to_ncdhw": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P]),
     "nm_op_conv3d_backward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
-    "nm_op_conv5_occ_backward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _P, _P]),
+    "nm_op_conv5_occ_backward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _P, _P, _I]),
     "nm_op_convT2_backward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P, _P, _P, _P]),
     "nm_op_gn_backward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "nm_set_conv_mode": (C.c_int, [C.c_void_p, _I]),

@@ -330,7 +330,7 @@ int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
 
 // first layer: dW [Cout][4][125] and d_bias of conv5(cat[occ, coords]) given dy
 int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, int32_t Cout, const float* dy,
-                             float* d_weight, float* d_bias) {
+                             float* d_weight, float* d_bias, int32_t sparse_occ) {
     if (!ctx || !occ || !dy || !d_weight || !d_bias) { nm_set_error("op_conv5_occ_backward: null argument"); return NM_ERR_ARG; }
     const size_t wsf = nm_wgrad_k5occ_ws_floats(N, G, Cout);
     const int nbb = nm_gnb_blocks_per_frame(G * G * G);
@@ -339,7 +339,7 @@ int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G
     ctx->ws.release(0);
     TensorRef dyT = make_ref(dy, nullptr, nullptr, 1.0f, N, G, G, G, Cout);
     float* ws = ctx->ws.f(wsf); float* bp = ctx->ws.f((size_t)N * nbb * Cout * 2);
-    if ((rc = nm_launch_wgrad_k5occ(occ, N, G, dyT, ws, d_weight, ctx->stream))) return rc;
+    if ((rc = nm_launch_wgrad_k5occ(occ, N, G, dyT, ws, d_weight, ctx->stream, sparse_occ))) return rc;
     if ((rc = nm_launch_gnb_partials(dy, dyT, bp, ctx->stream))) return rc;
     return nm_launch_sum_partials(bp, N * nbb, Cout, d_bias, ctx->stream);
 }

@@ -345,6 +345,79 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(WgradParams p) {
     }
 }
 
+// ---- first layer, sparse form ----------------------------------------------------------------------------------------------------
+// dW[co][c][tap] of conv5(cat[occ, x1, x2, x3]): the three coordinate channels do not depend on the frame, so their gradient is
+// the dense kernel (MODE 2) on ONE frame holding sum_n dy[n]; the occupancy channel is 1-3 % dense, so its gradient is a gather:
+// every occupied voxel u adds occ[u] * dy[n, u - tap + 2, :] to the 125 tap rows.  Block = one chunk of one frame; thread =
+// (output channel, tap group); the occupied voxels of a 256-voxel group are found with one ballot per wave and visited in index
+// order by the whole block (uniform), per-block partials, fixed-order reduce: deterministic.
+#define K5S_CHUNK 8192
+template <int COUT>
+__global__ __launch_bounds__(256) void wgrad_k5occ_sparse_kernel(const float* __restrict__ occ, const float* __restrict__ dy, int G, int chunks,
+                                                                 float* __restrict__ part) {
+    constexpr int TG = 256 / COUT, KT = (125 + TG - 1) / TG;
+    __shared__ float sval[256];
+    __shared__ unsigned long long smask[4];
+    const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int co = threadIdx.x % COUT, tg = threadIdx.x / COUT;
+    const size_t G3 = (size_t)G * G * G;
+    float acc[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc[k] = 0.f;
+    const size_t v0 = (size_t)ch * K5S_CHUNK, v1 = min(G3, v0 + K5S_CHUNK);
+    for (size_t base = v0; base < v1; base += 256) {
+        const size_t v = base + threadIdx.x;
+        const float val = v < v1 ? occ[(size_t)n * G3 + v] : 0.f;
+        __syncthreads();
+        sval[threadIdx.x] = val;
+        const unsigned long long m = __ballot(val != 0.f);
+        if ((threadIdx.x & 63) == 0) smask[threadIdx.x >> 6] = m;
+        __syncthreads();
+        for (int wv = 0; wv < 4; ++wv) {
+            unsigned long long mask = smask[wv];
+            while (mask) {
+                const int i = wv * 64 + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float a = sval[i];
+                const size_t u = base + i;
+                const int ux = (int)(u % G), uy = (int)((u / G) % G), uz = (int)(u / ((size_t)G * G));
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const int tap = tg + TG * k;
+                    if (tap < 125) {
+                        const int oz = uz - tap / 25 + 2, oy = uy - (tap / 5) % 5 + 2, ox = ux - tap % 5 + 2;
+                        if ((unsigned)oz < (unsigned)G && (unsigned)oy < (unsigned)G && (unsigned)ox < (unsigned)G)
+                            acc[k] = fmaf(a, dy[((size_t)n * G3 + ((size_t)oz * G + oy) * G + ox) * COUT + co], acc[k]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int tap = tg + TG * k;
+        if (tap < 125) part[((size_t)blockIdx.x * 125 + tap) * COUT + co] = acc[k];
+    }
+}
+// dW[co][0][tap] = sum_blocks part[blk][tap][co]
+__global__ __launch_bounds__(256) void wgrad_k5occ_sparse_reduce_kernel(const float* __restrict__ part, int blocks, int Cout, float* __restrict__ dW) {
+    const int total = 125 * Cout;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int co = i % Cout, tap = i / Cout;
+        float s = 0.f;
+        for (int b = 0; b < blocks; ++b) s += part[(size_t)b * total + i];
+        dW[((size_t)co * 4) * 125 + tap] = s;
+    }
+}
+// out[i] = sum_n x[n*per + i]
+__global__ __launch_bounds__(256) void sum_frames4_kernel(const float* __restrict__ x, int N, size_t per4, float* __restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per4; i += (size_t)gridDim.x * 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < N; ++n) s += *reinterpret_cast<const f32x4*>(x + ((size_t)n * per4 + i) * 4);
+        *reinterpret_cast<f32x4*>(out + i * 4) = s;
+    }
+}
+
 // dW[m][c][tap] (+)= sum over slots; thread order: c fastest (coalesced partial reads)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int slots, int tiles, int n_tiles, int groups,
                                                            int M, int Cin, int taps, int k5occ, const float* __restrict__ mul,
@@ -681,7 +754,13 @@ size_t nm_wgrad_ws_floats(int N, int OD, int OH, int OW, int M, int Nc, int ks, 
     if (wgrad16_eligible(OD, OH, OW, ks, stride)) a = max(a, plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false, true).ws_floats);
     return a;
 }
-size_t nm_wgrad_k5occ_ws_floats(int N, int G, int M) { return plan_wgrad(N, G, G, G, M, 4, 5, 1, true).ws_floats; }
+static int k5s_chunks(int G) { return (int)(((size_t)G * G * G + K5S_CHUNK - 1) / K5S_CHUNK); }
+size_t nm_wgrad_k5occ_ws_floats(int N, int G, int M) {
+    const size_t G3 = (size_t)G * G * G;
+    const size_t dense = plan_wgrad(N, G, G, G, M, 4, 5, 1, true).ws_floats;                      // exact-shape fallback (other Cout)
+    const size_t sparse = G3 * M + G3 + 64 + plan_wgrad(1, G, G, G, M, 4, 5, 1, true).ws_floats + (size_t)N * k5s_chunks(G) * 125 * M + 256;
+    return max(dense, sparse);
+}
 
 int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride, int pad, int cin_real, float* ws, float* dW,
                     hipStream_t s, const float* mul, int allow_f16) {
@@ -694,12 +773,33 @@ int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride
     return run_wgrad(q, ws, dW, cin_real, ks * ks * ks, s, mul);
 }
 
-int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s) {
+int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s, int sparse_occ) {
     if (dy.C % 4 || dy.D != G) { nm_set_error("wgrad_k5occ: bad dy"); return NM_ERR_ARG; }
-    WgradPlan q = plan_wgrad(N, G, G, G, dy.C, 4, 5, 1, true);
     TensorRef in; in.p = occ; in.scale = in.shift = nullptr; in.slope = 1.0f; in.N = N; in.D = in.H = in.W = G; in.C = 1;
-    q.p.in = in; q.p.dy = dy; q.p.pad = 2;
-    return run_wgrad(q, ws, dW, 4, 125, s);
+    const bool sparse = sparse_occ && (dy.C == 32 || dy.C == 64) && !dy.scale && dy.slope == 1.0f;
+    if (!sparse) {
+        WgradPlan q = plan_wgrad(N, G, G, G, dy.C, 4, 5, 1, true);
+        q.p.in = in; q.p.dy = dy; q.p.pad = 2;
+        return run_wgrad(q, ws, dW, 4, 125, s);
+    }
+    const size_t G3 = (size_t)G * G * G;
+    const int C = dy.C, chunks = k5s_chunks(G);
+    float* dysum = ws; float* zocc = dysum + G3 * C; float* dense_ws = zocc + ((G3 + 63) & ~(size_t)63);
+    WgradPlan q = plan_wgrad(1, G, G, G, C, 4, 5, 1, true);
+    float* part = dense_ws + ((q.ws_floats + 63) & ~(size_t)63);
+    // coordinate channels: one frame holding the sum of dy over the frames, empty occupancy
+    hipLaunchKernelGGL(sum_frames4_kernel, dim3(grid_for(G3 * C / 4)), dim3(256), 0, s, dy.p, N, G3 * C / 4, dysum);
+    int rc = nm_check_hip(hipMemsetAsync(zocc, 0, G3 * sizeof(float), s), "wgrad_k5occ: memset");
+    if (rc) return rc;
+    TensorRef in1 = in; in1.p = zocc; in1.N = 1;
+    TensorRef dy1 = dy; dy1.p = dysum; dy1.N = 1;
+    q.p.in = in1; q.p.dy = dy1; q.p.pad = 2;
+    if ((rc = run_wgrad(q, dense_ws, dW, 4, 125, s))) return rc;
+    // occupancy channel: gather over the occupied voxels
+    if (C == 32) hipLaunchKernelGGL((wgrad_k5occ_sparse_kernel<32>), dim3(N * chunks), dim3(256), 0, s, occ, dy.p, G, chunks, part);
+    else hipLaunchKernelGGL((wgrad_k5occ_sparse_kernel<64>), dim3(N * chunks), dim3(256), 0, s, occ, dy.p, G, chunks, part);
+    hipLaunchKernelGGL(wgrad_k5occ_sparse_reduce_kernel, dim3((125 * C + 255) / 256), dim3(256), 0, s, part, N * chunks, C, dW);
+    return nm_check_hip(hipGetLastError(), "wgrad_k5occ sparse launch");
 }
 
 int nm_gnb_blocks_per_frame(int voxels) { return (voxels + NM_GNB_VB - 1) / NM_GNB_VB; }

@@ -686,7 +686,7 @@ float* hourglass_bwd(Bwd& b, const HgRec& h, const float* dOut) {
     return d_x0;
 }
 
-void feature_net_bwd(Bwd& b, const FeatRec& r, const float* dFeat) {
+void feature_net_bwd(Bwd& b, const FeatRec& r, const float* dFeat, bool sparse_occ) {
     const size_t m = b.ws.mark();
     float* d_hg = res_bwd(b, r.r5, dFeat);
     float* d_p3 = hourglass_bwd(b, r.hg, d_hg);
@@ -698,7 +698,7 @@ void feature_net_bwd(Bwd& b, const FeatRec& r, const float* dFeat) {
     const float* dy = norm_bwd(b, r.first, &w.n0, r.fpart0, r.nblk0, w.c0.key + ".bias", d_first);
     float* wsb = b.alloc(nm_wgrad_k5occ_ws_floats(r.N, r.G, w.c0.Cout));
     float* gw = b.grad(w.c0.key + ".weight", (int64_t)w.c0.Cout * 4 * 125);
-    if (b.live()) b.run(nm_launch_wgrad_k5occ(r.occ, r.N, r.G, plain(dy, r.first), wsb, gw, b.s));
+    if (b.live()) b.run(nm_launch_wgrad_k5occ(r.occ, r.N, r.G, plain(dy, r.first), wsb, gw, b.s, sparse_occ ? 1 : 0));
     b.ws.release(m);
 }
 
@@ -778,11 +778,11 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         add_into(b, dfeat, dfh, (size_t)F * g3 * FEAT);
         b.ws.release(m);
     }
-    feature_net_bwd(b, t.frame, dfeat);
+    feature_net_bwd(b, t.frame, dfeat, true);
     {   // spatio-temporal net of the clip mean
         const size_t m = b.ws.mark();
         float* dfclip = conv_bwd(b, t.clip_head, dchead, true);
-        feature_net_bwd(b, t.clip, dfclip);
+        feature_net_bwd(b, t.clip, dfclip, false);       // the clip-mean grid is the union of T frames: not sparse
         b.ws.release(m);
     }
     return b.rc;

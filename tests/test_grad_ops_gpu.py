@@ -88,11 +88,15 @@ def test_conv3d_backward(ctx, case, mode):
     _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, 1), "set_conv_mode")
 
 
-@pytest.mark.parametrize("Cout,G,N", [(32, 16, 2), (64, 12, 3), (32, 32, 1)])
-def test_conv5_occ_backward(ctx, Cout, G, N):
+@pytest.mark.parametrize("sparse", [1, 0], ids=["gather", "dense"])
+@pytest.mark.parametrize("Cout,G,N,frac", [(32, 16, 2, False), (64, 12, 3, False), (32, 32, 1, False), (64, 24, 5, True), (32, 40, 3, True),
+                                             (48, 16, 2, False)])
+def test_conv5_occ_backward(ctx, Cout, G, N, frac, sparse):
     from neural_marionette_amd import _lib
     g = torch.Generator().manual_seed(Cout * 7 + G)
     occ = (torch.rand(N, 1, G, G, G, generator=g) < 0.05).float()
+    if frac:        # the clip-mean net sees fractional occupancy (kypt_detector.py:312)
+        occ = occ * torch.rand(N, 1, G, G, G, generator=g)
     lin = torch.linspace(-1.0, 1.0, G)
     zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
     coords = torch.stack([zz, yy, xx])[None].expand(N, -1, -1, -1, -1)
@@ -105,7 +109,7 @@ def test_conv5_occ_backward(ctx, Cout, G, N):
     d_w = torch.full(w.shape, float("nan")).cuda(); d_b = torch.full((Cout,), float("nan")).cuda()
     occd, dyd = occ[:, 0].contiguous().cuda(), to_cl(dy, Cout)      # (named: the buffers must outlive the call)
     _lib.check(ctx.lib.nm_op_conv5_occ_backward(ctx.handle, _lib.ptr(occd), N, G, Cout, _lib.ptr(dyd),
-                                                _lib.ptr(d_w), _lib.ptr(d_b)), "op_conv5_occ_backward")
+                                                _lib.ptr(d_w), _lib.ptr(d_b), sparse), "op_conv5_occ_backward")
     torch.cuda.synchronize()
     assert relerr(d_w.cpu(), w.grad) < REL
     assert relerr(d_b.cpu(), b.grad) < REL
