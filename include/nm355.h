@@ -155,6 +155,10 @@ int nm_vrnn_encode_train(nm_ctx* ctx, const float* keypoints, const float* eps, 
 int nm_vrnn_encode_backward(nm_ctx* ctx, const float* dscal2, const nm_named_grad* grads, int32_t count);
 int nm_adam_step(nm_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
                  int32_t step, float lr, float beta1, float beta2, float eps);
+/* the same update for `count` tensors in ONE launch (host arrays of device pointers; torch.optim.Adam semantics per tensor) */
+int nm_adam_step_multi(nm_ctx* ctx, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numels, int32_t count, int32_t step, float lr,
+                       float beta1, float beta2, float eps);
 
 /* ---- training, detector mode (pretrained_mode = 0: train.py:270-276, the detector trains on its 11 losses) ----
  * nm_ctx_set_training(ctx, 1) makes nm_ctx_set_weights also pack the weights of the data-gradient convolutions

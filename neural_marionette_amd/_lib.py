@@ -61,6 +61,8 @@ SIGNATURES = {
     "nm_ctx_set_training": (C.c_int, [C.c_void_p, _I]),
     "nm_detector_forward_train": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "nm_detector_backward": (C.c_int, [C.c_void_p, _P, C.POINTER(NmNamedTensor), _I]),
+    "nm_adam_step_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_int64), _I, _I, _F, _F, _F, _F]),
     "nm_vrnn_generate": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "nm_vrnn_step": (C.c_int, [C.c_void_p, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "nm_rows_argmin_dist": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P]),

@@ -30,6 +30,7 @@ int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, i
                            const float* gamma, float eps, float* coef, float* dgn, hipStream_t s);
 // out[c] = sum_n src[(n*C + c)*stride + off]
 int nm_launch_sum_frames(const float* src, int N, int C, int stride, int off, float* out, hipStream_t s);
+int nm_launch_sum_frames3(const float* dgn, int N, int C, float* dgamma, float* dbeta, float* dbias, hipStream_t s);
 // out[c] = sum_{n,blk} part[((n*nblk + blk)*C + c)*2]       (bias gradient of a conv without GroupNorm)
 int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipStream_t s);
 // dy = c1*dz + c2*y + c3 (coef) or dy = dz (coef == nullptr)

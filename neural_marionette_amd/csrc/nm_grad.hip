@@ -525,6 +525,15 @@ __global__ void sum_frames_kernel(const float* __restrict__ src, int N, int C, i
     out[c] = s;
 }
 
+// dgn[n][c] = (dgamma_n, dbeta_n, dbias_n, .) -> the three per-channel gradients in one launch
+__global__ void sum_frames3_kernel(const float* __restrict__ dgn, int N, int C, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int n = 0; n < N; ++n) { const float* d = dgn + ((size_t)n * C + c) * 4; s0 += d[0]; s1 += d[1]; s2 += d[2]; }
+    o0[c] = s0; o1[c] = s1; o2[c] = s2;
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out) {
     __shared__ double sh[256];
     const int c = blockIdx.x;
@@ -822,6 +831,11 @@ int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, i
 int nm_launch_sum_frames(const float* src, int N, int C, int stride, int off, float* out, hipStream_t s) {
     hipLaunchKernelGGL(sum_frames_kernel, dim3((C + 63) / 64), dim3(64), 0, s, src, N, C, stride, off, out);
     return nm_check_hip(hipGetLastError(), "sum_frames launch");
+}
+
+int nm_launch_sum_frames3(const float* dgn, int N, int C, float* dgamma, float* dbeta, float* dbias, hipStream_t s) {
+    hipLaunchKernelGGL(sum_frames3_kernel, dim3((C + 63) / 64), dim3(64), 0, s, dgn, N, C, dgamma, dbeta, dbias);
+    return nm_check_hip(hipGetLastError(), "sum_frames3 launch");
 }
 
 int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipStream_t s) {

@@ -535,9 +535,7 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
         if (b.live()) {
             b.run(nm_launch_gnb_partials(dA, out, bpart, b.s));
             b.run(nm_launch_gnb_finalize(bpart, nbb, fpart, nblk_f, N, C, gn->groups, V, gn->gamma, 1e-5f, coef, dgn, b.s));
-            b.run(nm_launch_sum_frames(dgn, N, C, 4, 0, gg, b.s));
-            b.run(nm_launch_sum_frames(dgn, N, C, 4, 1, gb, b.s));
-            b.run(nm_launch_sum_frames(dgn, N, C, 4, 2, gbias, b.s));
+            b.run(nm_launch_sum_frames3(dgn, N, C, gg, gb, gbias, b.s));
             b.run(nm_launch_gnb_apply(dA, out, coef, dy, b.s, amax));
         }
         b.ws.release(m);

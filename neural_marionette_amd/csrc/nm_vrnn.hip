@@ -558,6 +558,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// the same update for a list of tensors in one launch: block b works on chunk b of the concatenation (table on the device)
+struct AdamItem { float* p; const float* g; float* m; float* v; long long numel; long long chunk0; };
+#define ADAM_CHUNK 4096
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restrict__ items, int n, float lr, float b1, float b2, float eps,
+                                                         float bc1, float bc2) {
+    int lo = 0, hi = n - 1;                   // last item whose first chunk is <= blockIdx.x
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].chunk0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const AdamItem it = items[lo];
+    const long long i0 = ((long long)blockIdx.x - it.chunk0) * ADAM_CHUNK, i1 = min(it.numel, i0 + ADAM_CHUNK);
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float gi = it.g[i];
+        const float mi = it.m[i] = b1 * it.m[i] + (1.f - b1) * gi;
+        const float vi = it.v[i] = b2 * it.v[i] + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        it.p[i] = it.p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
 struct StepBufs {
     float *hid_prior, *hid_post, *rh, *jh, *gh, *pmu, *psig, *qmu, *qsig, *z, *hr, *hj, *rootout, *rot;
 };
@@ -933,6 +951,29 @@ int nm_adam_step(nm_ctx* c, float* param, const float* grad, float* exp_avg, flo
     int blocks = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, c->stream, param, grad, exp_avg, exp_avg_sq, (size_t)numel, lr, beta1, beta2, eps, bc1, bc2);
     return nm_check_hip(hipGetLastError(), "adam launch");
+}
+
+int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps) {
+    if (!c || !params || !grads || !exp_avg || !exp_avg_sq || !numels || count <= 0 || step <= 0) { nm_set_error("adam_step_multi: bad argument"); return NM_ERR_ARG; }
+    c->host_table.resize((size_t)count * sizeof(AdamItem));
+    AdamItem* items = reinterpret_cast<AdamItem*>(c->host_table.data());
+    long long chunks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numels[i] <= 0) { nm_set_error("adam_step_multi: entry %d is null / empty", i); return NM_ERR_ARG; }
+        items[i] = AdamItem{params[i], grads[i], exp_avg[i], exp_avg_sq[i], (long long)numels[i], chunks};
+        chunks += (numels[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+    }
+    int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
+    if (rc) return rc;
+    const size_t bytes = (size_t)count * sizeof(AdamItem);
+    if ((rc = nm_ctx_reserve(c, bytes + 4096))) return rc;
+    c->ws.release(0);
+    AdamItem* dev = static_cast<AdamItem*>(c->ws.alloc_bytes(bytes));
+    if ((rc = nm_check_hip(hipMemcpyAsync(dev, items, bytes, hipMemcpyHostToDevice, c->stream), "adam_step_multi: table upload"))) return rc;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, c->stream, dev, count, lr, beta1, beta2, eps, bc1, bc2);
+    return nm_check_hip(hipGetLastError(), "adam_multi launch");
 }
 
 int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_post, const float* eps_prior, int32_t B,

@@ -47,6 +47,19 @@ def allreduce_mean_(tensors, world: Optional[int] = None) -> None:
         off += n
 
 
+def adam_step_(eng, params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps) -> None:
+    """torch.optim.Adam's update for a list of tensors in one library launch (nm_adam_step_multi); bumps the version counters so
+    that the engine re-uploads / re-packs the weights before the next forward."""
+    import ctypes as C
+    n = len(params)
+    arr = lambda ts: (C.c_void_p * n)(*[_lib.ptr(t) for t in ts])
+    gs = [g.contiguous() for g in grads]
+    with torch.no_grad():
+        eng.call("nm_adam_step_multi", arr([p.data for p in params]), arr(gs), arr(exp_avg), arr(exp_avg_sq),
+                 (C.c_int64 * n)(*[p.numel() for p in params]), n, step, lr, betas[0], betas[1], eps)
+        torch._foreach_add_(list(params), 0.0)
+
+
 class LearnerTrainer:
     def __init__(self, net, lr: float = 4e-4, weights: Optional[Dict[str, float]] = None,
                  betas=(0.9, 0.999), eps: float = 1e-8):
@@ -75,12 +88,7 @@ class LearnerTrainer:
         eng = net._engine
         eng.ready()
         self.t += 1
-        with torch.no_grad():
-            for p, g, m, v in zip(self.params, grads, self.m, self.v):
-                eng.call("nm_adam_step", _lib.ptr(p.data), _lib.ptr(g.contiguous()), _lib.ptr(m), _lib.ptr(v), p.numel(), self.t,
-                         self.lr, self.betas[0], self.betas[1], self.eps)
-                p.add_(0)      # the kernel updated the storage behind autograd's back: bump the version counter so that
-                               # Engine._sync_weights re-uploads / re-packs the weights before the next forward
+        adam_step_(eng, self.params, grads, self.m, self.v, self.t, self.lr, self.betas, self.eps)
         return {"loss": float(loss), **{k: float(log[k]) for k in self.weights}}
 
 
@@ -124,12 +132,9 @@ class DetectorTrainer:
         eng = net._engine
         eng.ready()
         self.t += 1
-        with torch.no_grad():
-            for p, g in zip(params, grads):
-                st = self.state.get(id(p))
-                if st is None:
-                    st = self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
-                eng.call("nm_adam_step", _lib.ptr(p.data), _lib.ptr(g.contiguous()), _lib.ptr(st[0]), _lib.ptr(st[1]), p.numel(), self.t,
-                         self.lr, self.betas[0], self.betas[1], self.eps)
-                p.add_(0)      # bump the version counter: the engine re-uploads / re-packs the weights before the next forward
+        for p in params:
+            if id(p) not in self.state:
+                self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
+        adam_step_(eng, params, grads, [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params], self.t,
+                   self.lr, self.betas, self.eps)
         return {"loss": float(loss.detach()), **{k: float(log[k].detach()) for k in self.weights}}
