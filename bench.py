@@ -67,7 +67,8 @@ def cpu_baseline(sd, opts, net, dev):
     times.sort()
     med = times[len(times) // 2]
     # parity of the GPU path on exactly this sample (keypoint L2 vs the CPU reference port)
-    out = net(vox.to(dev), {"detector": True, "learner": True}, eps=eps.to(dev))
+    with torch.no_grad():
+        out = net(vox.to(dev), {"detector": True, "learner": True}, eps=eps.to(dev))
     torch.cuda.synchronize(dev)
     d = (out["keypoints"][..., :3].cpu() - ref["keypoints"][..., :3]).double()
     l2 = d.pow(2).sum(-1).sqrt().max().item()
@@ -129,7 +130,9 @@ def main():
         trainer = DetectorTrainer(net, lr=4e-4)
         step = lambda: trainer.step(vox)
     else:
-        step = lambda: net(vox, acts, eps=eps)
+        def step():                      # inference forward, as the reference runs it outside training (train.py:441, vis_*.py)
+            with torch.no_grad():
+                return net(vox, acts, eps=eps)
     for _ in range(args.warmup):
         step()
     eng = net._engine
