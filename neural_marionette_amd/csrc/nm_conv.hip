@@ -45,6 +45,7 @@ struct ConvParams {
     int CVp;                      // up2: plane stride of the coarse LDS tile
     int ZP;                       // f16s: pitch between halo z-planes in LDS (>= HY*HX, = 4 mod 16)
     const void* w16;              // conv_mfma_kernel<1,NT>: split-fp16 weights (null: fp32 MFMA core)
+    int ksplit;                   // conv_mfma_kernel<1,NT> + w16: the taps are dealt to 2 / 4 waves that share a row tile (tiny volumes)
     int st_z, st_y, st_x;         // f16s / f16p: XCD super-tile in bricks (0: bricks in linear order), see super_tile_item()
 #ifdef NM_DIAG
     unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
@@ -128,10 +129,11 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, half8& hi
 // reads + 20 VALU per 3 NT MFMAs: the chain, not the throughput, is what these launches wait for).
 template <int NT>
 __device__ __forceinline__ void mfma_chunk16(const ConvParams& p, const f32x4* lds, const half8* __restrict__ wq, size_t tap_stride,
-                                             int taps, int h, int arow, f32x16 (&acc)[1][NT], f32x16 (&accl)[NT]) {
+                                             int taps, int h, int arow, f32x16 (&acc)[1][NT], f32x16 (&accl)[NT], int tap0 = 0, int tstep = 1) {
     const size_t plane = (size_t)p.Co_pad;
-    int tx = 0, ty = 0, tz = 0;
-    for (int tap = 0; tap < taps; ++tap) {
+    const int k2 = p.ks * p.ks;
+    for (int tap = tap0; tap < taps; tap += tstep) {
+        const int tz = tap / k2, ty = (tap / p.ks) % p.ks, tx = tap % p.ks;
         const half8* wt = wq + (size_t)tap * tap_stride;
         half8 bh[NT], bl[NT];
 #pragma unroll
@@ -146,7 +148,6 @@ __device__ __forceinline__ void mfma_chunk16(const ConvParams& p, const f32x4* l
             accl[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bl[nt], accl[nt], 0, 0, 0);
             accl[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bh[nt], accl[nt], 0, 0, 0);
         }
-        if (++tx == p.ks) { tx = 0; if (++ty == p.ks) { ty = 0; ++tz; } }
     }
 }
 
@@ -576,9 +577,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
 
     // LDS voxel offset of each of this lane's A rows (row m -> brick (z,y,x))
     int arow[MT];
+    // (tap-split mode, tiny volumes: the 4 / ksplit row tiles that hold voxels are computed by ksplit waves each, on disjoint taps)
+    const bool tsplit = MT == 1 && p.w16 && p.ksplit > 1;
+    const int cwave = tsplit ? (p.ksplit == 4 ? 0 : (wave & 1)) : wave;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        int m = (wave * MT + mt) * 32 + l31;
+        int m = (cwave * MT + mt) * 32 + l31;
         int x = m & BXm, y = (m >> p.bx_l2) & BYm, z = m >> (p.bx_l2 + p.by_l2);
         bool ok = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
         arow[mt] = ok ? ((z * p.stride) * p.HY + y * p.stride) * p.HX + x * p.stride : 0;
@@ -669,9 +673,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             if (p.w16) {                                            // split-fp16 core (Cin % 16 == 0: every chunk is 16 wide)
                 const half8* w8 = reinterpret_cast<const half8*>(p.w16);
                 const size_t ts16 = (size_t)((p.Cin + 15) >> 4) * 4 * p.Co_pad;
+                const int tap0 = tsplit ? (p.ksplit == 4 ? wave : (wave >> 1)) : 0;
                 for (int s0 = 0; s0 < kc; s0 += 16)
                     mfma_chunk16<NT>(p, lds + (s0 >> 2) * p.HVp, w8 + ((size_t)((c0 + s0) >> 4) * 4 + h) * p.Co_pad + co_base + l31, ts16, taps, h,
-                                     arow[0], acc, accl);
+                                     arow[0], acc, accl, tap0, tsplit ? p.ksplit : 1);
                 continue;
             }
         }
@@ -689,6 +694,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][nt][r] += accl[nt][r] * (1.0f / NM_SPLIT_SCALE);
+            if (tsplit) {           // sum the tap groups: the waves whose own row tile holds voxels collect, the others end with zeros
+                __syncthreads();
+                float* r2 = reinterpret_cast<float*>(lds);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) r2[((wave * NT + nt) * 16 + r) * 64 + lane] = acc[0][nt][r];
+                __syncthreads();
+                const int rw = 4 / p.ksplit;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float sum = 0.f;
+                        if (wave < rw) for (int g = 0; g < p.ksplit; ++g) sum += r2[(((wave + g * rw) * NT + nt) * 16 + r) * 64 + lane];
+                        acc[0][nt][r] = sum;
+                    }
+            }
         }
     }
     EpiArgs e;
@@ -2225,6 +2248,7 @@ int launch_f16p2(const ConvParams& p_in, size_t lds_bytes, int work_items, hipSt
 unsigned long long* g_stamps = nullptr;
 #endif
 int g_small16 = [] { const char* e = getenv("NM355_SMALL16"); return e ? atoi(e) : 1; }();   // 0: small volumes on the fp32 MFMA core (diagnostic)
+int g_ksplit = [] { const char* e = getenv("NM355_KSPLIT"); return e ? atoi(e) : 1; }();     // 0: no tap split on the tiny volumes (diagnostic)
 int g_occ16 = [] { const char* e = getenv("NM355_OCC16"); return e ? atoi(e) : 1; }();     // 0: first layer on the fp32 MFMA kernel (diagnostic)
 int g_pool16 = [] { const char* e = getenv("NM355_POOL16"); return e ? atoi(e) : 1; }();   // 0: pool convs on the fp32 kernel (diagnostic)
 int g_f16p2 = [] { const char* e = getenv("NM355_F16P2"); return e ? atoi(e) : 1; }();   // 0: Cout % 64 == 0 layers stay on conv_f16s (diagnostic)
@@ -2321,6 +2345,13 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.st_z = p.st_y = p.st_x = 0;
     p.w16 = (g_conv_mode == 1 && g_small16 && w_packed16 && in.C % 8 == 0 && !g.up2 && t.MT == 1 && (t.KC % 16 == 0 || t.KC == in.C)) ? w_packed16 : nullptr;
     if (p.w16) t.lds_bytes = max(t.lds_bytes, (size_t)(((t.KC + 15) & ~15) / 4) * (t.HVp + t.CVp) * 16);
+    p.ksplit = 1;
+    if (p.w16 && g_ksplit) {       // tiny volumes: how many of the 4 row tiles (32 rows each) of the brick hold voxels at all
+        const int top = ((min(g.OD, 1 << t.bz_l2) - 1) << (t.bx_l2 + t.by_l2)) + ((min(g.OH, 1 << t.by_l2) - 1) << t.bx_l2) + min(g.OW, 1 << t.bx_l2) - 1;
+        const int rw = top / 32 + 1;
+        p.ksplit = rw == 1 ? 4 : (rw == 2 ? 2 : 1);
+        if (p.ksplit > 1) t.lds_bytes = max(t.lds_bytes, (size_t)4 * t.NT * 16 * 64 * sizeof(float));
+    }
 #ifdef NM_DIAG
     p.stamps = g_stamps;
 #endif
