@@ -2267,7 +2267,7 @@ void nm_conv_set_mode(int mode) { g_conv_mode = mode ? 1 : 0; g_f16p_all = mode 
 int nm_conv_get_mode() { return g_conv_mode && g_f16p_all ? 2 : g_conv_mode; }
 
 int nm_launch_pack_conv_weight16(const float* w, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s) {
-    if (Cin % 8 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("pack_conv_weight16: Cin=%d must be a multiple of 8", Cin); return NM_ERR_ARG; }
+    if (Co_pad % 32 || Cout > Co_pad) { nm_set_error("pack_conv_weight16: bad padding Cout=%d/%d", Cout, Co_pad); return NM_ERR_ARG; }   // (channels beyond Cin: zero)
     size_t total = (size_t)ks * ks * ks * ((Cin + 15) / 16) * 2 * Co_pad * 8;
     int blocks = (int)min((total + 255) / 256, (size_t)2048);
     hipLaunchKernelGGL(pack_conv_weight16_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, ks, reinterpret_cast<_Float16*>(packed), Co_pad);

@@ -79,36 +79,47 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ 
     }
 }
 
-// one block per frame, thread k < K finishes keypoint k
-__global__ __launch_bounds__(64) void keypoints_kernel(const float* __restrict__ part, int K, int g,
-                                                       float* __restrict__ keypoints, float* __restrict__ heat_mean) {
-    __shared__ float means[64];
-    const int f = blockIdx.x, k = threadIdx.x;
+// one block per frame.  Phase 1: the K*3*g marginal weights w[k][d][j] in parallel (axis 0: the plane sums, axes 1/2: sums of the
+// row / column partials over z, in z order); phase 2: thread (k, d) normalises and takes the expectation in j order - the same
+// arithmetic, in the same order, as one thread per keypoint walking everything (which took 137 us of dependent loads per launch)
+__global__ __launch_bounds__(256) void keypoints_kernel(const float* __restrict__ part, int K, int g,
+                                                        float* __restrict__ keypoints, float* __restrict__ heat_mean) {
+    extern __shared__ float wbuf[];          // [K][3][g] weights, then [K] means, [K][3] coordinates
+    float* means = wbuf + K * 3 * g;
+    float* coord = means + K;
+    const int f = blockIdx.x;
     const int stride = 2 * g + 2;
-    float mean = 0.f, c[3] = {0.f, 0.f, 0.f};
-    if (k < K) {
+    for (int item = threadIdx.x; item < K * 3 * g; item += 256) {
+        const int j = item % g, d = (item / g) % 3, k = item / (3 * g);
         const float* p = part + ((size_t)f * K + k) * g * stride;
-        float tot = 0.f, tot6 = 0.f;
-        for (int z = 0; z < g; ++z) { tot += p[z * stride + 2 * g]; tot6 += p[z * stride + 2 * g + 1]; }
-        mean = tot / (float)(g * g * g);
-        // axis 0 (z): weights are the plane sums
-        { float cz = 0.f; for (int z = 0; z < g; ++z) cz += (p[z * stride + 2 * g + 1] / tot6) * lin_coord(z, g); c[0] = cz; }
-        for (int d = 1; d < 3; ++d) {
-            float S = 0.f;
-            for (int j = 0; j < g; ++j) { float w = 0.f; for (int z = 0; z < g; ++z) w += p[z * stride + (d - 1) * g + j]; S += w; }
-            float cd = 0.f;
-            for (int j = 0; j < g; ++j) { float w = 0.f; for (int z = 0; z < g; ++z) w += p[z * stride + (d - 1) * g + j]; cd += (w / S) * lin_coord(j, g); }
-            c[d] = cd;
-        }
+        float w;
+        if (d == 0) w = p[j * stride + 2 * g + 1];
+        else { w = 0.f; for (int z = 0; z < g; ++z) w += p[z * stride + (d - 1) * g + j]; }
+        wbuf[item] = w;
+    }
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float* p = part + ((size_t)f * K + k) * g * stride;
+        float tot = 0.f;
+        for (int z = 0; z < g; ++z) tot += p[z * stride + 2 * g];
+        const float mean = tot / (float)(g * g * g);
+        means[k] = mean;
         heat_mean[(size_t)f * K + k] = mean;
     }
-    means[threadIdx.x] = (k < K) ? mean : -INFINITY;
     __syncthreads();
-    if (k < K) {
+    for (int kd = threadIdx.x; kd < K * 3; kd += 256) {
+        const float* w = wbuf + kd * g;
+        float S = 0.f;
+        for (int j = 0; j < g; ++j) S += w[j];
+        float c = 0.f;
+        for (int j = 0; j < g; ++j) c += (w[j] / S) * lin_coord(j, g);
+        coord[kd] = c;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) {
         float mx = -INFINITY;
         for (int j = 0; j < K; ++j) mx = fmaxf(mx, means[j]);
         float* o = keypoints + ((size_t)f * K + k) * 4;
-        o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = mean / (mx + 1e-6f);
+        o[0] = coord[k * 3]; o[1] = coord[k * 3 + 1]; o[2] = coord[k * 3 + 2]; o[3] = means[k] / (mx + 1e-6f);
     }
 }
 
@@ -157,6 +168,16 @@ __global__ __launch_bounds__(256) void combined_kernel(const float* __restrict__
         }
         *reinterpret_cast<f32x4*>(out + i * 4) = o;
     }
+}
+
+// three block sums at once: xor-shuffle tree inside each wave, the four wave results through LDS (fixed order); valid in every thread
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* sh /* >= 12 floats */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { float* d = sh + (threadIdx.x >> 6) * 3; d[0] = a; d[1] = b; d[2] = c; }
+    __syncthreads();
+    a = (sh[0] + sh[3]) + (sh[6] + sh[9]); b = (sh[1] + sh[4]) + (sh[7] + sh[10]); c = (sh[2] + sh[5]) + (sh[8] + sh[11]);
 }
 
 // grid (ceil(G3/256), F).  x: raw 32-channel tensor with pending GN affine + lrelu.
@@ -338,8 +359,21 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
     }
 }
 
+// grid F: frame_sums[f] = (sum BCE, sum chamfer, occupied count) over the frame's tail partials
+__global__ __launch_bounds__(256) void tail_sums_kernel(const float* __restrict__ tail_part, int tail_blocks, float* __restrict__ frame_sums) {
+    __shared__ float sh[12];
+    const int f = blockIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int j = threadIdx.x; j < tail_blocks; j += 256) {
+        const float* p = tail_part + ((size_t)f * tail_blocks + j) * 3;
+        s0 += p[0]; s1 += p[1]; s2 += p[2];
+    }
+    block_sum3(s0, s1, s2, sh);
+    if (threadIdx.x == 0) { float* o = frame_sums + (size_t)f * 3; o[0] = s0; o[1] = s1; o[2] = s2; }
+}
+
 // single block: the 11 scalar means of KyptDetector.forward (kypt_detector.py:155-165)
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ tail_part, int tail_blocks, int B, int T,
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ frame_sums, int B, int T,
                                                             int K, int N, int G, const float* __restrict__ heat_mean,
                                                             const float* __restrict__ clip_part, const float* __restrict__ affinity,
                                                             int chamfer, int use_traj, float* __restrict__ losses) {
@@ -348,13 +382,9 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     const float G3 = (float)G * (float)G * (float)G;
     float rec = 0.f, vol = 0.f, sp = 0.f;
     for (int f = threadIdx.x; f < F; f += 256) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int j = 0; j < tail_blocks; ++j) {
-            const float* p = tail_part + ((size_t)f * tail_blocks + j) * 3;
-            s0 += p[0]; s1 += p[1]; s2 += p[2];
-        }
-        rec += s0 / G3;
-        vol += s1 / s2;
+        const float* fs = frame_sums + (size_t)f * 3;
+        rec += fs[0] / G3;
+        vol += fs[1] / fs[2];
         float a = 0.f;
         for (int k = 0; k < K; ++k) a += fabsf(heat_mean[(size_t)f * K + k]);
         sp += a / (float)K;
@@ -422,7 +452,7 @@ int nm_launch_heatmap(const float* head, const float* clip_head, const float* pr
 }
 
 int nm_launch_keypoints(const float* part, int F, int K, int g, float* keypoints, float* heat_mean, hipStream_t s) {
-    hipLaunchKernelGGL(keypoints_kernel, dim3(F), dim3(64), 0, s, part, K, g, keypoints, heat_mean);
+    hipLaunchKernelGGL(keypoints_kernel, dim3(F), dim3(256), (size_t)(K * 3 * g + 4 * K) * sizeof(float), s, part, K, g, keypoints, heat_mean);
     return nm_check_hip(hipGetLastError(), "keypoints launch");
 }
 
@@ -461,8 +491,9 @@ int nm_launch_clip_loss(const float* keypoints, const float* affinity, int B, in
 
 int nm_launch_loss_finalize(const float* tail_part, int tail_blocks, int B, int T, int K, int N, int G,
                             const float* heat_mean, const float* clip_part, const float* affinity, int chamfer,
-                            int use_traj, float* losses, hipStream_t s) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, tail_part, tail_blocks, B, T, K, N, G, heat_mean,
+                            int use_traj, float* frame_sums, float* losses, hipStream_t s) {
+    hipLaunchKernelGGL(tail_sums_kernel, dim3(B * T), dim3(256), 0, s, tail_part, tail_blocks, frame_sums);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, frame_sums, B, T, K, N, G, heat_mean,
                        clip_part, affinity, chamfer, use_traj, losses);
     return nm_check_hip(hipGetLastError(), "loss_finalize launch");
 }

@@ -75,15 +75,17 @@ struct Loader {
         if (r && !rc) rc = r;
         return dst;
     }
-    ConvW conv(const std::string& p, int Cout, int Cin, int ks) {
-        ConvW w; w.Cin = Cin; w.Cout = Cout; w.ks = ks; w.Cin_pad = (Cin + 7) & ~7; w.Co_pad = (Cout + 31) & ~31; w.key = p;
+    // pad16: the layer's input tensor is built by the library itself with Cin rounded up to 16 (the decoder's 179-channel combined
+    // representation), which puts the layer on the split-fp16 kernels
+    ConvW conv(const std::string& p, int Cout, int Cin, int ks, bool pad16 = false) {
+        ConvW w; w.Cin = Cin; w.Cout = Cout; w.ks = ks; w.Cin_pad = pad16 ? ((Cin + 15) & ~15) : ((Cin + 7) & ~7); w.Co_pad = (Cout + 31) & ~31; w.key = p;
         const float* src = get(p + ".weight", (int64_t)Cout * Cin * ks * ks * ks);
         w.bias = copy(p + ".bias", Cout);
         if (!src) return w;
         w.wp = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, w.Cin_pad, w.Co_pad));
         if (!w.wp) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
         int r = nm_launch_pack_conv_weight(src, Cout, Cin, ks, w.wp, w.Cin_pad, w.Co_pad, c->stream);
-        if (!r && Cin % 8 == 0 && Cin >= 16) {                      // (Cin % 16 == 8: zero-padded, used by the small-volume core only)
+        if (!r && (Cin % 8 == 0 || pad16) && Cin >= 16) {          // (Cin % 16 == 8: zero-padded, used by the small-volume core only)
             w.wp16 = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, (Cin + 15) & ~15, w.Co_pad));      // same byte count as fp32
             if (!w.wp16) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
             r = nm_launch_pack_conv_weight16(src, Cout, Cin, ks, w.wp16, w.Co_pad, c->stream);
@@ -412,6 +414,7 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
     float* clip_part = n.alloc((size_t)B * 5);
     const int tb = nm_tail_blocks(G);
     float* tail_part = n.alloc((size_t)F * tb * 3);
+    float* frame_sums = n.alloc((size_t)F * 3);
     float* aff = affinity_on ? (affinity ? affinity : n.alloc((size_t)N * K * K)) : nullptr;
 
     {   // spatio-temporal heat-map from the clip mean, once per clip (kypt_detector.py:311-316).  Only B frames of
@@ -471,7 +474,7 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
     if (n.live()) {
         n.run(nm_launch_clip_loss(keypoints, aff, B, T, K, N, c->cfg.sep_sigma, clip_part, n.s));
         n.run(nm_launch_loss_finalize(tail_part, tb, B, T, K, N, G, heat_mean, clip_part, aff, c->cfg.vol_fit_chamfer,
-                                      c->cfg.use_graph_traj, losses, n.s));
+                                      c->cfg.use_graph_traj, frame_sums, losses, n.s));
     }
     return n.rc;
 }
@@ -833,7 +836,7 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
         d.prop = nm_ctx_weight_alloc(c, 3);
         if (pw && pb && d.prop) hipLaunchKernelGGL(pack_small_kernel, dim3(1), dim3(64), 0, c->stream, pw, 2, pb, 1, d.prop);
     }
-    d.adjust = L.conv(k2v + ".adjust_combined_representation.0", FEAT, FEAT + 2 * K + 3, 1);
+    d.adjust = L.conv(k2v + ".adjust_combined_representation.0", FEAT, FEAT + 2 * K + 3, 1);       // (pad16 = true puts it on conv_f16s: measured 648 us vs 319 us on the fp32 kernel, which stages all 184 channels per pass; a 1-tap layer has 6 MFMAs per staged 16-channel chunk)
     d.d1 = L.conv(dec + ".1", FEAT / 2, FEAT, 3); d.dn2 = L.norm(dec + ".2", FEAT / 2);
     d.d4 = L.conv(dec + ".4", FEAT / 2, FEAT / 2, 3); d.dn5 = L.norm(dec + ".5", FEAT / 2);
     d.d8 = L.conv(dec + ".8", FEAT / 4, FEAT / 2, 3); d.dn9 = L.norm(dec + ".9", FEAT / 4);
