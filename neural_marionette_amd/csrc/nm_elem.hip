@@ -130,6 +130,52 @@ __global__ __launch_bounds__(256) void convT2_kernel(TensorRef in, const float* 
     }
 }
 
+// Same op for the large launches (the data gradient of the k2 s2 pool convs: 32 ch -> 64^3 is 2.1 GB of output): grid (chunks, 8
+// taps); the tap's [ci][co] weight slice sits in LDS (the kernel above re-fetches 4 weight vectors per 16 FMAs through the
+// texture path: 2.7 ms for that launch, load-issue bound), a thread owns (coarse voxel, 4 output channels) and walks the chunk.
+__global__ __launch_bounds__(256) void convT2_lds_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int Cout, int OD, int OH, int OW, int vox_per_block) {
+    extern __shared__ float wl[];            // [Cin][Cout]
+    const int tap = blockIdx.y, cq = Cout / 4, q = threadIdx.x % cq, vl = threadIdx.x / cq, vpi = 256 / cq;
+    for (int i = threadIdx.x; i < in.C * Cout / 4; i += 256)
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w + (size_t)tap * in.C * Cout)[i];
+    __syncthreads();
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + q * 4);
+    const size_t cvox = (size_t)in.D * in.H * in.W, total = (size_t)in.N * cvox;
+    const size_t v0 = (size_t)blockIdx.x * vox_per_block, v1 = min(total, v0 + vox_per_block);
+    const int az = tap >> 2, ay = (tap >> 1) & 1, ax = tap & 1;
+    // four coarse voxels per pass: one LDS weight read feeds 4 x 4 FMAs
+    for (size_t vb = v0 + (size_t)vl * 4; vb < v1; vb += (size_t)vpi * 4) {
+        size_t vo[4], oo[4]; size_t nn[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t v = vb + u;
+            ok[u] = v < v1;
+            const size_t vv = ok[u] ? v : v0;
+            const size_t n = vv / cvox; size_t r = vv % cvox;
+            const int ix = (int)(r % in.W); r /= in.W;
+            const int iy = (int)(r % in.H), iz = (int)(r / in.H);
+            nn[u] = n;
+            vo[u] = (((size_t)iz * in.H + iy) * in.W + ix) * in.C;
+            oo[u] = ((((size_t)n * OD + 2 * iz + az) * OH + 2 * iy + ay) * OW + 2 * ix + ax) * Cout + q * 4;
+        }
+        f32x4 acc[4] = {bv, bv, bv, bv};
+        for (int c = 0; c < in.C; c += 4) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = load_t(in, nn[u], vo[u] + c, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (size_t)(c + j) * Cout + q * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc[u][0] += x[u][j] * wv[0]; acc[u][1] += x[u][j] * wv[1]; acc[u][2] += x[u][j] * wv[2]; acc[u][3] += x[u][j] * wv[3]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (ok[u]) *reinterpret_cast<f32x4*>(out + oo[u]) = acc[u];
+    }
+}
+
 // trilinear x2, align_corners=False: src = (dst + 0.5) / 2 - 0.5 clamped at 0
 __device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1) {
     float src = 0.5f * ((float)o + 0.5f) - 0.5f;
@@ -304,6 +350,13 @@ int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, flo
         nm_set_error("convT2: bad output size"); return NM_ERR_ARG;
     }
     size_t total = (size_t)in.N * OD * OH * OW * (Cout / 4);
+    const size_t cvox = (size_t)in.N * in.D * in.H * in.W;
+    if (OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && 256 % (Cout / 4) == 0 && (size_t)in.C * Cout * 4 <= 48 * 1024 && cvox >= 65536) {
+        const int vpb = 2048;
+        hipLaunchKernelGGL(convT2_lds_kernel, dim3((unsigned)((cvox + vpb - 1) / vpb), 8), dim3(256), (size_t)in.C * Cout * sizeof(float), s, in, w, bias,
+                           out, Cout, OD, OH, OW, vpb);
+        return nm_check_hip(hipGetLastError(), "convT2_lds launch");
+    }
     hipLaunchKernelGGL(convT2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w, bias, out, Cout, OD, OH, OW);
     return nm_check_hip(hipGetLastError(), "convT2 launch");
 }

@@ -37,6 +37,9 @@ BWD_CASES = [
     (128, 64, 3, 1, 1, 8, 5, True, False, 128),
     (48, 72, 3, 1, 1, 8, 3, True, False, 48),
     (64, 32, 3, 1, 1, 8, 2, True, True, 64),
+    # pool data gradient on the LDS-weight transposed-conv kernel (>= 65536 coarse voxels)
+    (32, 32, 2, 2, 0, 32, 5, True, False, 32),
+    (64, 64, 2, 2, 0, 32, 3, False, False, 64),
     # hourglass floor of a 32^3 grid: 1^3 and 2^3 volumes
     (72, 72, 3, 1, 1, 1, 8, True, False, 72),
     (48, 72, 1, 1, 0, 1, 8, False, False, 48),

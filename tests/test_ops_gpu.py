@@ -189,7 +189,7 @@ def test_conv5_occupancy_first_layer(ctx, G, Cout, N, mode):
     assert e < REL, f"GroupNorm rel err {e:.3e}"
 
 
-@pytest.mark.parametrize("Cin,Cout,size,outpad,groups", [(72, 48, 2, 0, 3), (48, 32, 5, 1, 2), (32, 64, 8, 0, 4), (32, 128, 3, 1, 8)])
+@pytest.mark.parametrize("Cin,Cout,size,outpad,groups", [(72, 48, 2, 0, 3), (48, 32, 5, 1, 2), (32, 64, 8, 0, 4), (32, 128, 3, 1, 8), (32, 64, 32, 0, 4)])
 def test_convT2(ctx, Cin, Cout, size, outpad, groups):
     from neural_marionette_amd import _lib
     g = torch.Generator().manual_seed(Cin * 131 + Cout)
