@@ -154,7 +154,7 @@ def main():
         frames = world * B_PER_GPU * T * args.steps
         # dominant kernel = the conv variant with the largest event-timed total
         best = None
-        for v in range(10):
+        for v in range(12):
             ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
             _lib.check(lib.nm_prof_read(h, v, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
             if n.value and (best is None or ms.value > best[1]):

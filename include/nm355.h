@@ -271,7 +271,8 @@ int nm_get_conv_mode(nm_ctx* ctx);
  * own side stream are not timed: they overlap the main stream, so their event-to-event time is not their own).
  * nm_prof_read sums duration and ALGORITHMIC flops (2*voxels*Cout*Cin*k^3, un-padded) of one
  * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2); 5,6 =
- * conv_f16s_kernel<2,1>/<2,2>, 7 = conv_f16p_kernel, 8 = conv_pool_f16s_kernel, 9 = conv_f16p2_kernel (algorithmic fp32-equivalent flops, i.e. 1/3 of the issued MFMA flops); 4 = the
+ * conv_f16s_kernel<2,1>/<2,2> (k1 / k3 without upsampling), 10,11 = the same kernel with the fused trilinear upsampling (NT = 1 / 2),
+ * 7 = conv_f16p_kernel, 8 = conv_pool_f16s_kernel, 9 = conv_f16p2_kernel (algorithmic fp32-equivalent flops, i.e. 1/3 of the issued MFMA flops); 4 = the
  * first-layer occupancy kernel conv_k5occ_kernel, credited with the reference's dense 4-channel k5 work). */
 int nm_prof_enable(nm_ctx* ctx, int32_t on);
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches);

@@ -2162,7 +2162,7 @@ int launch_f16s(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t 
     }
     ProfRec rec;
     if (NM_PROF_ON(s)) {
-        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 5 + (NT - 1);
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = UP2 ? 10 + (NT - 1) : 5 + (NT - 1);      // the fused-upsample layers are families of their own
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
         (void)hipEventRecord(rec.a, s);
     }
@@ -2298,7 +2298,7 @@ int nm_conv_blocks_per_frame(const ConvGeom& g) {
 void nm_conv_prof_enable(int on, hipStream_t stream) { g_prof_on = on != 0; g_prof_stream = stream; }
 
 // Sums the event-timed launches of one kernel variant recorded since the last reset.
-// variant = (MT-1)*2 + (NT-1).  Synchronises on the recorded events.
+// variant: see nm_prof_kernel_name.  Synchronises on the recorded events.
 int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, long long* launches) {
     double ms = 0.0, fl = 0.0; long long n = 0;
     for (const ProfRec& r : g_prof) {
