@@ -1058,6 +1058,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
         if (BLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weight group 0 has landed in LDS
         lds_barrier();
         if (cb < 2) NM_STAMP(3 + cb * 4);
+        __builtin_amdgcn_s_setprio(2);       // MFMA phase: ahead of the co-resident workgroup's staging VALU
 
         if (BLDS) {
             // One software-pipelined pass over the 27 taps.  Left to itself the scheduler sinks every ds_read next to its
@@ -1156,6 +1157,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (cb < 2) NM_STAMP(4 + cb * 4);
     }
     NM_STAMP(9);
