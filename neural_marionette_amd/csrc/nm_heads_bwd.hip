@@ -77,6 +77,59 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TensorRef x, const float*
     }
 }
 
+// The network's decoder (C = 32): the voxel's activated channels stay in registers between the dot product and the outer
+// product, and the per-thread partial sums of d w14 live in registers too (the generic kernel above keeps them in LDS: 33
+// read-modify-writes per voxel), reduced once per block.
+__global__ __launch_bounds__(256) void tail_bwd32_kernel(TensorRef x, const float* __restrict__ w14, const float* __restrict__ target,
+                                                         const float* __restrict__ recon, const float* __restrict__ dloss, float inv_count,
+                                                         size_t G3, float* __restrict__ dA, float* __restrict__ part) {
+    constexpr int C = 32;
+    __shared__ float sh[256 * 33];
+    const int f = blockIdx.y;
+    const float coef = dloss[0] * inv_count;
+    float sc[C], sf[C], w[C], acc[C + 1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { sc[c] = x.scale[(size_t)f * C + c]; sf[c] = x.shift[(size_t)f * C + c]; w[c] = w14[c]; acc[c] = 0.f; }
+    acc[C] = 0.f;
+    const float bias = w14[C];
+    const size_t v0 = blockIdx.x * (size_t)NM_TAILB_VPB;
+    for (int it = 0; it < NM_TAILB_VPB / 256; ++it) {
+        const size_t v = v0 + it * 256 + threadIdx.x;
+        if (v >= G3) break;
+        const float* px = x.p + ((size_t)f * G3 + v) * C;
+        float a[C];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(px + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[c + j] = lrelu(fmaf(r[j], sc[c + j], sf[c + j]), x.slope); dot += a[c + j] * w[c + j]; }
+        }
+        dot += bias;
+        const float th = tanhf(dot);
+        const float p = recon[(size_t)f * G3 + v], y = target[(size_t)f * G3 + v];
+        const float pq = (1.0f - p) * p;
+        const float dv = coef * ((p - y) / fmaxf(pq, 1e-12f)) * pq * 10.0f * (1.0f - th * th);
+        float* pd = dA + ((size_t)f * G3 + v) * C;
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[c + j] += dv * a[c + j]; o[j] = dv * w[c + j]; }
+            *reinterpret_cast<f32x4*>(pd + c) = o;
+        }
+        acc[C] += dv;
+    }
+#pragma unroll
+    for (int c = 0; c <= C; ++c) sh[threadIdx.x * 33 + c] = acc[c];
+    __syncthreads();
+    for (int c = threadIdx.x; c <= C; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < 256; ++t) s += sh[t * 33 + c];
+        part[((size_t)f * gridDim.x + blockIdx.x) * 33 + c] = s;
+    }
+}
+
 // out[j] = sum_r part[r*cols + j]   (one block per column)
 __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out) {
     __shared__ double sh[256];
@@ -489,6 +542,11 @@ int nm_launch_decoder_tail_bwd(const TensorRef& x, const float* w14, const float
                                float* dA, float* part, hipStream_t s) {
     if (x.C % 4 || !x.scale || x.C > 60) { nm_set_error("decoder_tail_bwd: needs a lazy GN input with C %% 4 == 0, C <= 60"); return NM_ERR_ARG; }
     const size_t G3 = (size_t)G * G * G;
+    if (x.C == 32) {
+        hipLaunchKernelGGL(tail_bwd32_kernel, dim3(nm_tail_bwd_blocks(G), x.N), dim3(256), 0, s, x, w14, target, recon, dloss,
+                           1.0f / ((float)x.N * (float)G3), G3, dA, part);
+        return nm_check_hip(hipGetLastError(), "decoder_tail_bwd launch");
+    }
     const size_t lds = (size_t)256 * (x.C + 1) * sizeof(float);
     hipLaunchKernelGGL(tail_bwd_kernel, dim3(nm_tail_bwd_blocks(G), x.N), dim3(256), lds, s, x, w14, target, recon, dloss,
                        1.0f / ((float)x.N * (float)G3), G3, dA, part);
