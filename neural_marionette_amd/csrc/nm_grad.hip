@@ -615,19 +615,11 @@ __global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ x, si
     }
 }
 
-__device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1) {
-    float src = 0.5f * ((float)o + 0.5f) - 0.5f;
-    if (src < 0.f) src = 0.f;
-    i0 = (int)src;
-    i1 = i0 + (i0 < I - 1 ? 1 : 0);
-    l1 = src - (float)i0;
-}
-// weight of fine index f on coarse index j along one axis (0 if f does not touch j)
-__device__ __forceinline__ float up_w(int f, int j, int I) {
-    if (f < 0 || f >= 2 * I) return 0.f;
-    int i0, i1; float l;
-    up_idx(f, I, i0, i1, l);
-    return (i0 == j ? 1.f - l : 0.f) + (i1 == j ? l : 0.f);
+// per axis the fine indices 2j-1 .. 2j+2 touch coarse j with weights 0.25, 0.75, 0.75, 0.25; at the borders the clamped
+// interpolation folds the missing neighbour's share onto the edge voxel: j = 0 -> (none, 1, 0.75, 0.25), j = I-1 -> (0.25, 0.75, 1, none)
+__device__ __forceinline__ void up_adj_w(int j, int I, float (&w)[4]) {
+    w[0] = j > 0 ? 0.25f : 0.f; w[1] = j > 0 ? 0.75f : 1.0f;
+    w[2] = j < I - 1 ? 0.75f : 1.0f; w[3] = j < I - 1 ? 0.25f : 0.f;
 }
 
 __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __restrict__ dfine, int N, int D, int H, int W, int C,
@@ -640,18 +632,24 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __r
         const int x = (int)(r % W); r /= W;
         const int y = (int)(r % H); r /= H;
         const int z = (int)(r % D); const size_t n = r / D;
+        float wz[4], wy[4], wx[4];
+        up_adj_w(z, D, wz); up_adj_w(y, H, wy); up_adj_w(x, W, wx);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int a = -1; a <= 2; ++a) {
-            const int fz = 2 * z + a; const float wz = up_w(fz, z, D);
-            if (wz == 0.f) continue;
-            for (int b = -1; b <= 2; ++b) {
-                const int fy = 2 * y + b; const float wy = up_w(fy, y, H);
-                if (wy == 0.f) continue;
-                for (int cc = -1; cc <= 2; ++cc) {
-                    const int fx = 2 * x + cc; const float wx = up_w(fx, x, W);
-                    if (wx == 0.f) continue;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(dfine + ((((size_t)n * 2 * D + fz) * 2 * H + fy) * 2 * W + fx) * C + q * 4);
-                    const float wt = wz * wy * wx;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (wz[a] == 0.f) continue;
+            const size_t fz = (size_t)(2 * z + a - 1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (wy[b] == 0.f) continue;
+                const size_t fy = (size_t)(2 * y + b - 1);
+                const float wzy = wz[a] * wy[b];
+                const float* row = dfine + (((n * 2 * D + fz) * 2 * H + fy) * 2 * W) * C + q * 4;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (wx[cc] == 0.f) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(row + (size_t)(2 * x + cc - 1) * C);
+                    const float wt = wzy * wx[cc];
                     acc[0] += wt * v[0]; acc[1] += wt * v[1]; acc[2] += wt * v[2]; acc[3] += wt * v[3];
                 }
             }

@@ -1,7 +1,8 @@
-"""Diagnostic: detector-mode gradients of the HIP path vs the CPU oracle in fp64 (and the fp32 oracle's own error)."""
+"""Diagnostic (lives under tests/ because it uses the oracle as the checker): detector-mode gradients of the HIP path vs the CPU
+oracle in fp64, and the fp32 oracle's own distance to it.   python tests/diag_train_grads.py G B T seed weighting [modes...]"""
 import sys, os, importlib.util
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repo root (this file sits in tests/)
 sys.path.insert(0, ROOT)
 spec = importlib.util.spec_from_file_location("t", os.path.join(ROOT, "tests", "test_train_detector_gpu.py"))
 m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
