@@ -173,6 +173,15 @@ def test_g8_detector_gradients(golden_dir):
         assert np.abs(mine[2:] - ref[2:]).max() <= 1e-4 * scale, (k, np.abs(mine[2:] - ref[2:]).max() / scale)
 
 
+def test_trainer_loss_weights_are_the_references(golden_dir):
+    """DetectorTrainer / LearnerTrainer defaults = the AIST weights of the reference's opt.pickle (recorded by make_golden.py g8 / g6)."""
+    from neural_marionette_amd.train import DETECTOR_LOSS_WEIGHTS, LEARNER_LOSS_WEIGHTS
+    g = _load(golden_dir, "g8_detector_grads.npz")
+    for k, w in zip(DETECTOR_LOSS_KEYS, g["weights"]):
+        assert abs(DETECTOR_LOSS_WEIGHTS[k] - float(w)) < 1e-12, k
+    assert LEARNER_LOSS_WEIGHTS == {"kypt_recon_loss": 1.0, "kl_kypt": 0.003}
+
+
 def test_g7_eval_metrics(golden_dir):
     """oracle restatement of utils/eval_utils.py vs the reference's outputs on the seeded inputs"""
     g = np.load(os.path.join(golden_dir, "g7_eval_metrics.npz"))
