@@ -418,7 +418,7 @@ class HSVRNNBVH(_Node):
             names = ["dyna_module." + n for n, _ in named]
             kl, rl, rec, R, z, h, best = _EncodeTrain.apply(self, kp, e, S, names, *[p for _, p in named])
             return dict(kypt_recon=rec, R=R, z_kypts=z, h_kypts=h, kl_kypt=kl, kypt_recon_loss=rl,
-                        gae_recon_loss=torch.tensor(0).to(dev), topo_recon_loss=torch.tensor(0).to(dev), best_idx=best)
+                        gae_recon_loss=torch.zeros((), dtype=torch.int64, device=dev), topo_recon_loss=torch.zeros((), dtype=torch.int64, device=dev), best_idx=best)
         rec = torch.empty(B, T, K, 4, device=dev)
         R = torch.empty(B, T, K, 3, 3, device=dev)
         z = torch.empty(B, T, Z, device=dev)
@@ -428,7 +428,7 @@ class HSVRNNBVH(_Node):
         eng.call("nm_vrnn_encode", _lib.ptr(kp), _lib.ptr(e), B, T, S, _lib.ptr(rec), _lib.ptr(R), _lib.ptr(z),
                  _lib.ptr(h), _lib.ptr(sc), _lib.ptr(best))
         return dict(kypt_recon=rec, R=R, z_kypts=z, h_kypts=h, kl_kypt=sc[0], kypt_recon_loss=sc[1],
-                    gae_recon_loss=torch.tensor(0).to(dev), topo_recon_loss=torch.tensor(0).to(dev),
+                    gae_recon_loss=torch.zeros((), dtype=torch.int64, device=dev), topo_recon_loss=torch.zeros((), dtype=torch.int64, device=dev),
                     best_idx=best)
 
     def generate(self, keypoints_cond, affinity=None, Ttot=10, Tcond=3, SAMPLE_NUM=10, eps_post=None, eps_prior=None):
@@ -687,7 +687,7 @@ class NeuralMarionette(nn.Module):
             log[name] = losses[i]
         log["first_feature"] = ff
         log.update(kypt_recon=rec, R=R, z_kypts=z, h_kypts=h, kl_kypt=sc[0], kypt_recon_loss=sc[1],
-                   gae_recon_loss=torch.tensor(0).to(dev), topo_recon_loss=torch.tensor(0).to(dev), best_idx=best)
+                   gae_recon_loss=torch.zeros((), dtype=torch.int64, device=dev), topo_recon_loss=torch.zeros((), dtype=torch.int64, device=dev), best_idx=best)
         return log
 
     def generate(self, vox_seq, module_actives=None, eps_post=None, eps_prior=None):
