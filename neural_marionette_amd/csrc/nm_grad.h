@@ -23,7 +23,8 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
 // y: the raw conv output with its forward scale/shift/slope (lazy tensor);  dA: gradient w.r.t. the activated values.
 //   dz = dA * lrelu'(scale*y + shift);   partials: per (frame, block, channel) (sum dz, sum dz*y)
 int nm_gnb_blocks_per_frame(int voxels);
-int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s);
+// dA_mul (optional, here and in gnb_apply / absmax): device scalar dA is multiplied by on read (the producer left it scaled by 2^k)
+int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul = nullptr);
 // coef[n][c] = (c1, c2, c3, 0) with dy = c1*dz + c2*y + c3;  dgn[n][c] = (dgamma_n, dbeta_n, dbias_n, 0)
 // fpart: the forward partial sums (sum y, sum y^2) the conv epilogue left, [N][nblk_f][C][2]
 int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, int nblk_f, int N, int C, int groups, int voxels,
@@ -35,11 +36,12 @@ int nm_launch_sum_frames3(const float* dgn, int N, int C, float* dgamma, float* 
 int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipStream_t s);
 // dy = c1*dz + c2*y + c3 (coef) or dy = dz (coef == nullptr)
 // amax (optional): device word that receives max |dy| as float bits (integer atomicMax; zero it first)
-int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax = nullptr);
+int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax = nullptr,
+                        const float* dA_mul = nullptr);
 // Power-of-two operand scaling of the data-gradient convolutions in the split-fp16 conv mode: gradients are often
 // below the fp16 normal range (6e-5), where the hi/lo split loses its low bits; dy is read as dy * 2^k through the lazy
 // affine of the conv kernels and the result is multiplied by 2^-k (exact).
-int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s);
+int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s, const float* mul = nullptr);
 int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* sc2 /*[2^k, 2^-k]*/, hipStream_t s);
 int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s);
 

@@ -439,8 +439,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 #define NM_GNB_VB 512
 // grid (nblk, N)
-__global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restrict__ dA, TensorRef y, int voxels, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restrict__ dA, TensorRef y, int voxels, float* __restrict__ part,
+                                                           const float* __restrict__ dmul) {
     __shared__ float sh[256 * 2];
+    const float mm = dmul ? *dmul : 1.0f;          // dA arrives scaled by a power of two (nm_launch_make_scale): undone on read
     const int n = blockIdx.y, blk = blockIdx.x, C = y.C;
     const int lanes = 256 / C;
     const int c = threadIdx.x % C, vl = threadIdx.x / C;
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restri
             const size_t o = ((size_t)n * voxels + v) * C + c;
             const float yy = y.p[o];
             const float z = fmaf(yy, sc, shf);
-            const float dz = dA[o] * (z > 0.f ? 1.0f : y.slope);
+            const float dz = (dA[o] * mm) * (z > 0.f ? 1.0f : y.slope);
             s1 += dz; s2 += dz * yy;
         }
     }
@@ -555,8 +557,9 @@ __device__ __forceinline__ void block_absmax(float m, unsigned* amax) {
 }
 
 __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict__ dA, TensorRef y, const float* __restrict__ coef,
-                                                        float* __restrict__ dy, unsigned* __restrict__ amax) {
+                                                        float* __restrict__ dy, unsigned* __restrict__ amax, const float* __restrict__ dmul) {
     float mx = 0.f;
+    const float mm = dmul ? *dmul : 1.0f;
     const size_t per_frame = (size_t)y.D * y.H * y.W * y.C;
     const size_t total4 = (size_t)y.N * per_frame / 4;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
@@ -565,6 +568,7 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
         const int c = (int)(e % y.C);
         const f32x4 yy = *reinterpret_cast<const f32x4*>(y.p + e);
         f32x4 d = *reinterpret_cast<const f32x4*>(dA + e);
+        d[0] *= mm; d[1] *= mm; d[2] *= mm; d[3] *= mm;
         if (y.slope != 1.0f) {
             f32x4 z = yy;
             if (y.scale) {
@@ -587,13 +591,14 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
     if (amax) block_absmax(mx, amax);
 }
 
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ amax) {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ amax, const float* __restrict__ dmul) {
+    const float mm = dmul ? fabsf(*dmul) : 1.0f;
     float mx = 0.f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const f32x4 d = *reinterpret_cast<const f32x4*>(x + i * 4);
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
     }
-    block_absmax(mx, amax);
+    block_absmax(mx * mm, amax);
 }
 
 // scale[i] = 2^k with max * 2^k in (128, 256] (so that the fp16 hi/lo split of the data-gradient conv sees O(100) operands,
@@ -811,10 +816,10 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
 
 int nm_gnb_blocks_per_frame(int voxels) { return (voxels + NM_GNB_VB - 1) / NM_GNB_VB; }
 
-int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s) {
+int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul) {
     if (y.C > 256 || y.C <= 0) { nm_set_error("gnb_partials: C=%d unsupported", y.C); return NM_ERR_ARG; }
     const int voxels = y.D * y.H * y.W;
-    hipLaunchKernelGGL(gnb_partials_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part);
+    hipLaunchKernelGGL(gnb_partials_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul);
     return nm_check_hip(hipGetLastError(), "gnb_partials launch");
 }
 
@@ -841,16 +846,16 @@ int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipSt
     return nm_check_hip(hipGetLastError(), "sum_partials launch");
 }
 
-int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax) {
+int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax, const float* dA_mul) {
     if (y.C % 4) { nm_set_error("gnb_apply: C %% 4 != 0"); return NM_ERR_ARG; }
     const size_t total4 = (size_t)y.N * y.D * y.H * y.W * y.C / 4;
-    hipLaunchKernelGGL(gnb_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dA, y, coef, dy, amax);
+    hipLaunchKernelGGL(gnb_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul);
     return nm_check_hip(hipGetLastError(), "gnb_apply launch");
 }
 
-int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s) {
+int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s, const float* mul) {
     if (n % 4) { nm_set_error("absmax: n %% 4 != 0"); return NM_ERR_ARG; }
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, amax);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, amax, mul);
     return nm_check_hip(hipGetLastError(), "absmax launch");
 }
 

@@ -525,7 +525,7 @@ TensorRef plain(const float* p, const TensorRef& like) { return mk(p, like.N, li
 // gamma / beta and of the bias of the producing conv
 // (amax, optional: device word that ends up holding max |dy|, for the operand scaling of the data-gradient conv)
 const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float* fpart, int nblk_f, const std::string& bias_key,
-                      const float* dA, unsigned* amax = nullptr) {
+                      const float* dA, unsigned* amax = nullptr, const float* dA_mul = nullptr) {
     const int N = out.N, C = out.C, V = out.D * out.H * out.W;
     const int nbb = nm_gnb_blocks_per_frame(V);
     float* dy = nullptr;
@@ -536,18 +536,18 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
         float* coef = b.alloc((size_t)N * C * 4); float* dgn = b.alloc((size_t)N * C * 4);
         float* gg = b.grad(gn->key + ".weight", C); float* gb = b.grad(gn->key + ".bias", C); float* gbias = b.grad(bias_key, C);
         if (b.live()) {
-            b.run(nm_launch_gnb_partials(dA, out, bpart, b.s));
+            b.run(nm_launch_gnb_partials(dA, out, bpart, b.s, dA_mul));
             b.run(nm_launch_gnb_finalize(bpart, nbb, fpart, nblk_f, N, C, gn->groups, V, gn->gamma, 1e-5f, coef, dgn, b.s));
             b.run(nm_launch_sum_frames3(dgn, N, C, gg, gb, gbias, b.s));
-            b.run(nm_launch_gnb_apply(dA, out, coef, dy, b.s, amax));
+            b.run(nm_launch_gnb_apply(dA, out, coef, dy, b.s, amax, dA_mul));
         }
         b.ws.release(m);
         return dy;
     }
     const float* res = dA;
-    if (out.slope != 1.0f) {
+    if (out.slope != 1.0f || dA_mul) {
         dy = b.alloc(numel_of(out));
-        if (b.live()) b.run(nm_launch_gnb_apply(dA, out, nullptr, dy, b.s, amax));
+        if (b.live()) b.run(nm_launch_gnb_apply(dA, out, nullptr, dy, b.s, amax, dA_mul));
         res = dy;
     } else if (amax && b.live()) b.run(nm_launch_absmax(dA, numel_of(out), amax, b.s));
     const size_t m = b.ws.mark();
@@ -566,9 +566,9 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
 // Operand scaling of a data-gradient conv that runs on the split-fp16 kernels (nm_grad.h): dy is read as dy * 2^k.
 struct DyScale {
     unsigned* amax = nullptr; float* scale = nullptr; float* shift = nullptr; float* sc2 = nullptr;
-    void prepare(Bwd& b, bool on, int count) {
+    void prepare(Bwd& b, bool on, int count, float* sc2_keep = nullptr) {
         if (!on) return;
-        amax = reinterpret_cast<unsigned*>(b.alloc(64)); scale = b.alloc(count); shift = b.alloc(count); sc2 = b.alloc(64);
+        amax = reinterpret_cast<unsigned*>(b.alloc(64)); scale = b.alloc(count); shift = b.alloc(count); sc2 = sc2_keep ? sc2_keep : b.alloc(64);
         if (b.live()) {
             b.run(nm_check_hip(hipMemsetAsync(amax, 0, sizeof(unsigned), b.s), "backward: memset"));
             b.run(nm_check_hip(hipMemsetAsync(shift, 0, (size_t)count * sizeof(float), b.s), "backward: memset"));
@@ -583,15 +583,20 @@ struct DyScale {
     const float* inv() const { return amax ? sc2 + 1 : nullptr; }
 };
 
-float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din) {
+// dA_mul: device scalar the incoming dA still has to be multiplied by (the producing conv_bwd left its power-of-two scale in).
+// out_mul (optional): the caller feeds the result straight into the next conv_bwd as dA + dA_mul; then the un-scaling pass over
+// the returned tensor is skipped and *out_mul is the scalar to hand on (nullptr when the result is already unscaled).
+float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const float* dA_mul = nullptr, const float** out_mul = nullptr) {
     const ConvW& w = *r.w;
     const TensorRef& in = r.in;
     float* din = need_din ? b.alloc((size_t)in.N * in.D * in.H * in.W * w.csel) : nullptr;
+    float* sc2_keep = out_mul ? b.alloc(64) : nullptr;           // outlives this call (allocated below the mark)
+    if (out_mul) *out_mul = nullptr;
     const size_t m = b.ws.mark();
     const bool split = nm_conv_get_mode() != 0;          // split-fp16 kernels: dy is read pre-scaled by a power of two
     DyScale ds;
-    ds.prepare(b, split && r.stride == 1 && (w.ks == 3 || (need_din && w.wd16)), r.out.N * r.out.C);
-    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, w.key + ".bias", dA, ds.amax);
+    ds.prepare(b, split && r.stride == 1 && (w.ks == 3 || (need_din && w.wd16)), r.out.N * r.out.C, sc2_keep);
+    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, w.key + ".bias", dA, ds.amax, dA_mul);
     const TensorRef dyT = plain(dy, r.out);
     const TensorRef dyS = ds.apply(b, dyT);
     {   // weight gradient
@@ -619,8 +624,9 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din) {
             if (b.live()) {
                 b.run(nm_launch_conv(dyS, w.wd, b.zb, dfine, g, nullptr, b.s, w.Cout, w.wd16));
                 if (r.up2) b.run(nm_launch_upsample2_adjoint(dfine, in.N, in.D, in.H, in.W, w.csel, din, b.s, ds.inv()));
-                else if (ds.inv()) b.run(nm_launch_scale_by(din, (size_t)in.N * in.D * in.H * in.W * w.csel, ds.inv(), b.s));
+                else if (ds.inv() && !out_mul) b.run(nm_launch_scale_by(din, (size_t)in.N * in.D * in.H * in.W * w.csel, ds.inv(), b.s));
             }
+            if (out_mul && !r.up2) *out_mul = ds.inv();
         } else if (b.live()) {      // k2 s2 pool conv: the transposed conv
             if (!w.wt) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
             else b.run(nm_launch_convT2(dyT, w.wt, b.zb, din, w.Cin, in.D, in.H, in.W, b.s));
@@ -634,8 +640,9 @@ void add_into(Bwd& b, float* dst, const float* src, size_t n) { if (b.live()) b.
 
 // Res3DBlock backward: dOut is the gradient of the (materialised) block output; returns the gradient of the activated input
 float* res_bwd(Bwd& b, const ResRec& r, const float* dOut) {
-    float* d1 = conv_bwd(b, r.c2, dOut, true);
-    float* dx = conv_bwd(b, r.c1, d1, true);
+    const float* m1 = nullptr;
+    float* d1 = conv_bwd(b, r.c2, dOut, true, nullptr, &m1);      // its power-of-two scale is undone by c1's GroupNorm backward
+    float* dx = conv_bwd(b, r.c1, d1, true, m1);
     const size_t n = numel_of(r.c1.in);
     if (r.has_skip) { float* d2 = conv_bwd(b, r.cs, dOut, true); add_into(b, dx, d2, n); }
     else add_into(b, dx, dOut, n);
@@ -733,10 +740,11 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
             b.run(nm_check_hip(hipMemcpyAsync(gw14, g14, C * sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
             b.run(nm_check_hip(hipMemcpyAsync(gb14, g14 + C, sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
         }
-        float* dx = conv_bwd(b, t.d11, dA, true);
-        dx = conv_bwd(b, t.d8, dx, true);
-        dx = conv_bwd(b, t.d4, dx, true);
-        dx = conv_bwd(b, t.d1, dx, true);
+        const float *m11 = nullptr, *m4 = nullptr;
+        float* dx = conv_bwd(b, t.d11, dA, true, nullptr, &m11);
+        dx = conv_bwd(b, t.d8, dx, true, m11);
+        dx = conv_bwd(b, t.d4, dx, true, nullptr, &m4);
+        dx = conv_bwd(b, t.d1, dx, true, m4);
         float* dcomb = conv_bwd(b, t.adjust, dx, true);                 // [F][g^3][csel = 2K + FEAT]
         float* gws = b.alloc((size_t)F * K * 8);
         if (b.live()) {
