@@ -227,6 +227,53 @@ __global__ __launch_bounds__(256) void upsample2_kernel(TensorRef in, float* __r
     }
 }
 
+// The same with the 3x3x3 neighbourhoods shared through LDS: a block owns 2 x 4 x 4 coarse cells and 32 channels; the clamped
+// 4 x 6 x 6 coarse halo is loaded and activated once (4.5 loads per cell instead of 27), every thread then interpolates its cell's
+// eight children from LDS and writes 128-byte voxel rows.  Used when C % 32 == 0 and the extents are multiples of the tile.
+__global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float* __restrict__ out, int tz, int ty, int tx) {
+    __shared__ f32x4 tile[4 * 6 * 6 * 8];          // [hz][hy][hx][quad]
+    const int D = in.D, H = in.H, W = in.W, chunks = in.C / 32;
+    int b = blockIdx.x;
+    const int ch = b % chunks; b /= chunks;
+    const int bx = b % tx; b /= tx;
+    const int by = b % ty; b /= ty;
+    const int bz = b % tz; const size_t n = b / tz;
+    const int z0 = bz * 2, y0 = by * 4, x0 = bx * 4, c0 = ch * 32;
+    for (int i = threadIdx.x; i < 4 * 6 * 6 * 8; i += 256) {
+        const int q = i & 7; int v = i >> 3;
+        const int hx = v % 6, hy = (v / 6) % 6, hz = v / 36;
+        const int gz = min(max(z0 - 1 + hz, 0), D - 1), gy = min(max(y0 - 1 + hy, 0), H - 1), gx = min(max(x0 - 1 + hx, 0), W - 1);
+        tile[i] = load_t(in, n, (((size_t)gz * H + gy) * W + gx) * in.C + c0 + 4 * q, c0 + 4 * q);
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 7, cell = threadIdx.x >> 3;
+    const int cx = cell & 3, cy = (cell >> 2) & 3, cz = cell >> 4;
+    f32x4 fx[3][3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+            const f32x4* row = tile + (((cz + a) * 6 + (cy + bb)) * 6 + cx) * 8 + q;
+            const f32x4 v0 = row[0], v1 = row[8], v2 = row[16];
+            fx[a][bb][0] = 0.25f * v0 + 0.75f * v1; fx[a][bb][1] = 0.75f * v1 + 0.25f * v2;
+        }
+    const int OH = 2 * H, OW = 2 * W;
+    const int z = z0 + cz, y = y0 + cy, x = x0 + cx;
+#pragma unroll
+    for (int kx = 0; kx < 2; ++kx) {
+        f32x4 fy[3][2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { fy[a][0] = 0.25f * fx[a][0][kx] + 0.75f * fx[a][1][kx]; fy[a][1] = 0.75f * fx[a][1][kx] + 0.25f * fx[a][2][kx]; }
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky) {
+            const f32x4 o0 = 0.25f * fy[0][ky] + 0.75f * fy[1][ky], o1 = 0.75f * fy[1][ky] + 0.25f * fy[2][ky];
+            const size_t base = ((((size_t)n * 2 * D + 2 * z) * OH + 2 * y + ky) * OW + 2 * x + kx) * in.C + c0 + 4 * q;
+            *reinterpret_cast<f32x4*>(out + base) = o0;
+            *reinterpret_cast<f32x4*>(out + base + (size_t)OH * OW * in.C) = o1;
+        }
+    }
+}
+
 __device__ __forceinline__ float lin_coord(int i, int G) {
     // torch.linspace(-1, 1, G) in fp32: symmetric evaluation from both ends, one rounding (fma)
     const float step = 2.0f / (float)(G - 1);
@@ -363,6 +410,11 @@ int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, flo
 
 int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s) {
     if (in.C % 4) { nm_set_error("upsample2: C %% 4 != 0"); return NM_ERR_ARG; }
+    if (in.C % 32 == 0 && in.D % 2 == 0 && in.H % 4 == 0 && in.W % 4 == 0) {
+        const int tz = in.D / 2, ty = in.H / 4, tx = in.W / 4;
+        hipLaunchKernelGGL(upsample2_tile_kernel, dim3((unsigned)((size_t)in.N * tz * ty * tx * (in.C / 32))), dim3(256), 0, s, in, out, tz, ty, tx);
+        return nm_check_hip(hipGetLastError(), "upsample2 launch");
+    }
     size_t total = (size_t)in.N * in.D * in.H * in.W * (in.C / 4);
     hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out);
     return nm_check_hip(hipGetLastError(), "upsample2 launch");

@@ -238,7 +238,7 @@ def test_apply2(ctx):
     assert torch.equal(out.cpu(), a)
 
 
-@pytest.mark.parametrize("size,Cc", [(4, 16), (5, 8), (8, 128)])
+@pytest.mark.parametrize("size,Cc", [(4, 16), (5, 8), (8, 128), (12, 64), (4, 32), (6, 32)])
 def test_upsample2(ctx, size, Cc):
     from neural_marionette_amd import _lib
     g = torch.Generator().manual_seed(size)
