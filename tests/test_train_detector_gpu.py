@@ -31,8 +31,8 @@ WEIGHTINGS = {
 }
 
 
-def _setup(G=32, B=2, T=4, seed=11, variant="peaky"):
-    o = HotPathOptions(grid_size=G)
+def _setup(G=32, B=2, T=4, seed=11, variant="peaky", K=24):
+    o = HotPathOptions(grid_size=G, nkeypoints=K)
     sd = synth.make_state_dict(o, seed=seed, variant=variant)
     gen = torch.Generator().manual_seed(seed + 1)
     sd["kypt_detector.affinity_params"] = torch.randn(sd["kypt_detector.affinity_params"].shape, generator=gen)
@@ -152,6 +152,16 @@ def test_detector_gradients_before_affinity_start():
 def test_detector_gradients_odd_hourglass_40():
     """G = 40: hourglass sizes 10 -> 5 -> 2 -> 1 with output_padding in the transposed convs (vox_modules.py:81)."""
     o, sd, vox = _setup(G=40, B=1, T=3, seed=31)
+    ref_loss, ref, _ = _oracle_grads(o, sd, vox, AIST, double=True)
+    loss, got, _ = _hip_grads(o, sd, vox, AIST)
+    assert abs(loss - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss))
+    _compare(ref, got, tol=TOL)
+
+
+@pytest.mark.parametrize("K", [16, 32])
+def test_detector_gradients_other_keypoint_counts(K):
+    """K = 16 / 32 keypoints (the combined representation has 2K + 131 channels, the heads K)."""
+    o, sd, vox = _setup(G=32, B=1, T=3, seed=71 + K, K=K)
     ref_loss, ref, _ = _oracle_grads(o, sd, vox, AIST, double=True)
     loss, got, _ = _hip_grads(o, sd, vox, AIST)
     assert abs(loss - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss))
