@@ -266,3 +266,25 @@ def test_training_api_misuse_is_reported():
     kp = torch.empty(2, 4, o.nkeypoints, 4, device="cuda")
     with pytest.raises(_lib.NmError, match="nm_ctx_set_training"):
         eng.call("nm_detector_forward_train", _lib.ptr(vox.cuda()), 2, 4, 1, _lib.ptr(kp), _lib.ptr(kp), _lib.ptr(kp), _lib.ptr(kp), None, _lib.ptr(kp))
+
+
+def test_detector_gradients_batch_additivity_at_64cubed():
+    """Full-size property (64^3, the bench grid), no oracle needed: every loss is a mean over clips and GroupNorm is per frame, so the
+    gradient of a two-clip batch is the average of the two single-clip gradients."""
+    o, sd, vox = _setup(G=64, B=2, T=4, seed=81)
+    _, g_ab, _ = _hip_grads(o, sd, vox, AIST)
+    _, g_a, _ = _hip_grads(o, sd, vox[:1].contiguous(), AIST)
+    _, g_b, _ = _hip_grads(o, sd, vox[1:].contiguous(), AIST)
+    gmax = max(v.abs().max().item() for v in g_ab.values())
+    worst = 0.0
+    for k, v in g_ab.items():
+        avg = 0.5 * (g_a[k].double() + g_b[k].double())
+        scale = max(avg.abs().max().item(), 1e-6 * gmax)
+        e = (v.double() - avg).abs().max().item() / scale
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    print("batch additivity at 64^3: worst relative deviation %.2e" % worst)
+    # run-to-run identical (fixed-order reductions everywhere, integer atomics only for the abs-max)
+    _, g_ab2, _ = _hip_grads(o, sd, vox, AIST)
+    for k, v in g_ab.items():
+        assert torch.equal(v, g_ab2[k]), f"{k}: gradients differ between two runs"
