@@ -499,6 +499,7 @@ struct Bwd {
     const std::map<std::string, std::pair<float*, int64_t>>* grads;     // nullptr in the sizing pass
     float* zb = nullptr;                                                  // 512 zeros: bias of the data-gradient convolutions
     Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g) : c(ctx), s(ctx->stream), ws(ctx->ws), grads(g) {}
+    Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g, hipStream_t stream) : c(ctx), s(stream), ws(ctx->ws), grads(g) {}
     bool live() const { return rc == NM_OK && !ws.dry; }
     void run(int r) { if (r && !rc) rc = r; }
     float* alloc(size_t n) {
@@ -787,13 +788,28 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         add_into(b, dfeat, dfh, (size_t)F * g3 * FEAT);
         b.ws.release(m);
     }
-    feature_net_bwd(b, t.frame, dfeat, true);
-    {   // spatio-temporal net of the clip mean
-        const size_t m = b.ws.mark();
-        float* dfclip = conv_bwd(b, t.clip_head, dchead, true);
-        feature_net_bwd(b, t.clip, dfclip, false);       // the clip-mean grid is the union of T frames: not sparse
-        b.ws.release(m);
+    {   // spatio-temporal net of the clip mean: B frames of small, latency-bound launches, issued on the side stream so that they
+        // run beside the per-frame net's backward.  Their scratch stays out of reach of the main stream (the arena top is left at
+        // this block's high-water mark), exactly as in the forward.
+        Bwd b2(c, grads, c->stream2);
+        b2.zb = b.zb;
+        if (b.live()) {
+            b.run(nm_check_hip(hipEventRecord(c->ev_fork, b.s), "backward: fork event"));
+            b.run(nm_check_hip(hipStreamWaitEvent(c->stream2, c->ev_fork, 0), "backward: side stream wait"));
+        }
+        b2.rc = b.rc;
+        const size_t saved_peak = b2.ws.peak;
+        b2.ws.peak = b2.ws.top;
+        float* dfclip = conv_bwd(b2, t.clip_head, dchead, true);
+        feature_net_bwd(b2, t.clip, dfclip, false);       // the clip-mean grid is the union of T frames: not sparse
+        const size_t local_peak = b2.ws.peak;
+        b2.ws.peak = saved_peak > local_peak ? saved_peak : local_peak;
+        b2.ws.top = local_peak;
+        if (b2.live()) b2.run(nm_check_hip(hipEventRecord(c->ev_side, c->stream2), "backward: side event"));
+        b.run(b2.rc);
     }
+    feature_net_bwd(b, t.frame, dfeat, true);
+    if (b.live()) b.run(nm_check_hip(hipStreamWaitEvent(b.s, c->ev_side, 0), "backward: join side stream"));
     return b.rc;
 }
 
