@@ -128,7 +128,7 @@ def main():
         from neural_marionette_amd.train import DetectorTrainer
         net.train()
         trainer = DetectorTrainer(net, lr=4e-4)
-        step = lambda: trainer.step(vox)
+        step = lambda: trainer.step(vox, sync=False)
     else:
         def step():                      # inference forward, as the reference runs it outside training (train.py:441, vis_*.py)
             with torch.no_grad():

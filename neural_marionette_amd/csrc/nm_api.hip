@@ -34,10 +34,20 @@ int nm_ctx_reserve(nm_ctx* ctx, size_t bytes) {
     return NM_OK;
 }
 
+// Weight buffers are handed out in call order.  A repeated set_weights (every optimizer step) asks for the same sizes in the same
+// order and gets the same buffers back - no hipFree / hipMalloc, hence no synchronisation: the pack kernels that overwrite them are
+// stream-ordered behind the previous step's readers.  On the first mismatch the tail of the list is released (after a sync).
 float* nm_ctx_weight_alloc(nm_ctx* ctx, size_t floats) {
+    const size_t bytes = (floats ? floats : 1) * sizeof(float);
+    if (ctx->owned_cursor < ctx->owned.size()) {
+        if (ctx->owned_bytes[ctx->owned_cursor] == bytes) return static_cast<float*>(ctx->owned[ctx->owned_cursor++]);
+        (void)hipDeviceSynchronize();
+        for (size_t i = ctx->owned_cursor; i < ctx->owned.size(); ++i) (void)hipFree(ctx->owned[i]);
+        ctx->owned.resize(ctx->owned_cursor); ctx->owned_bytes.resize(ctx->owned_cursor);
+    }
     void* p = nullptr;
-    if (hipMalloc(&p, (floats ? floats : 1) * sizeof(float)) != hipSuccess) return nullptr;
-    ctx->owned.push_back(p);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    ctx->owned.push_back(p); ctx->owned_bytes.push_back(bytes); ctx->owned_cursor = ctx->owned.size();
     return static_cast<float*>(p);
 }
 

@@ -83,6 +83,8 @@ struct nm_ctx {
     Arena ws;                              // activations / scratch, reset per call
     Arena ws2;                             // scratch of work issued on stream2 (VRNN beside the decoder)
     std::vector<void*> owned;              // weight allocations
+    std::vector<size_t> owned_bytes;       // their sizes: a repeated nm_ctx_set_weights walks the same sequence and reuses them (no sync)
+    size_t owned_cursor = 0;
     bool has_weights = false;
     bool training = false;                 // nm_ctx_set_training: set_weights also packs the data-gradient weights
     Arena ws_t;                            // activations retained between nm_detector_forward_train and nm_detector_backward

@@ -837,10 +837,8 @@ void nm_net_free_tape(nm_ctx* c) { delete c->tape; c->tape = nullptr; }
 
 int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const float*, int64_t>>& sd) {
     if (c->tape) c->tape->valid = false;
-    int rc = nm_check_hip(hipStreamSynchronize(c->stream), "set_weights: sync");
-    if (rc) return rc;
-    for (void* p : c->owned) (void)hipFree(p);
-    c->owned.clear();
+    int rc = NM_OK;
+    c->owned_cursor = 0;                   // buffers are reused in call order (nm_ctx_weight_alloc): no free, no sync
     c->has_weights = false;
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, N = c->cfg.nneighbor, S4 = K * 4;
     Loader L{c, sd};
@@ -892,8 +890,12 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
     if (L.rc) return L.rc;
     rc = nm_check_hip(hipGetLastError(), "set_weights: pack kernels");
     if (rc) return rc;
-    rc = nm_check_hip(hipStreamSynchronize(c->stream), "set_weights: final sync");
-    if (rc) return rc;
+    if (c->owned_cursor < c->owned.size()) {           // fewer buffers than last time (training packs switched off): drop the rest
+        (void)hipDeviceSynchronize();
+        for (size_t i = c->owned_cursor; i < c->owned.size(); ++i) (void)hipFree(c->owned[i]);
+        c->owned.resize(c->owned_cursor); c->owned_bytes.resize(c->owned_cursor);
+    }
+    // (no final sync: the pack kernels read the caller's tensors in stream order, before anything the caller enqueues afterwards)
     c->has_weights = true;
     return NM_OK;
 }

@@ -118,7 +118,9 @@ class DetectorTrainer:
         self.t = 0
         self.state = {}
 
-    def step(self, vox) -> Dict[str, float]:
+    def step(self, vox, sync: bool = True):
+        """One training step.  sync=True returns python floats (waits for the device); sync=False returns 0-dim device tensors and
+        lets the host run ahead into the next step."""
         net = self.net
         params = self._params()
         for p in net.kypt_detector.parameters():
@@ -137,4 +139,6 @@ class DetectorTrainer:
                 self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
         adam_step_(eng, params, grads, [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params], self.t,
                    self.lr, self.betas, self.eps)
+        if not sync:
+            return {"loss": loss.detach(), **{k: log[k].detach() for k in self.weights}}
         return {"loss": float(loss.detach()), **{k: float(log[k].detach()) for k in self.weights}}
