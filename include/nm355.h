@@ -66,7 +66,10 @@ int nm_ctx_destroy(nm_ctx* ctx);
 int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream);
 /* Replaces NeuralMarionette.load_state_dict / .cuda() for the HIP path: copies every
  * tensor and re-packs conv weights into the MFMA layout.  Must be called again after an
- * optimizer step.  All 337 keys of the reference state_dict are required. */
+ * optimizer step.  All 337 keys of the reference state_dict are required.  Asynchronous on the ctx
+ * stream: the source tensors are read in stream order (keep them alive and unmodified until work enqueued
+ * before the call's return has drained - PyTorch's stream-ordered allocator guarantees that for tensors of
+ * the same stream); a repeated call reuses the ctx-owned buffers and does not synchronise the host. */
 int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count);
 /* Bytes of ctx-owned workspace a (B, T) call needs (allocated lazily, grown on demand). */
 size_t nm_workspace_bytes(nm_ctx* ctx, int32_t B, int32_t T);
