@@ -96,6 +96,7 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     if (ctx->ws.base) (void)hipFree(ctx->ws.base);
     if (ctx->ws2.base) (void)hipFree(ctx->ws2.base);
     if (ctx->ws_t.base) (void)hipFree(ctx->ws_t.base);
+    if (ctx->copy_table) (void)hipFree(ctx->copy_table);
     nm_net_free_tape(ctx);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side}) if (e) (void)hipEventDestroy(e);

@@ -88,6 +88,8 @@ struct nm_ctx {
     bool has_weights = false;
     bool training = false;                 // nm_ctx_set_training: set_weights also packs the data-gradient weights
     Arena ws_t;                            // activations retained between nm_detector_forward_train and nm_detector_backward
+    std::vector<char> host_table2;         // host staging of set_weights' copy table
+    void* copy_table = nullptr; size_t copy_table_cap = 0;      // its device copy
     std::vector<char> host_table;          // host staging of nm_adam_step_multi's pointer table (kept alive across the async copy)
     struct TrainTape* tape = nullptr;      // what the backward pass needs of the last training forward (nm_net.hip)
     DetectorW det;

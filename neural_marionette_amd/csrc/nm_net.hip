@@ -52,10 +52,40 @@ const size_t FRAME_CHUNK = 64;     // frames per pass through the conv stacks (b
 // ------------------------------------------------------------------------------------------
 // weights
 // ------------------------------------------------------------------------------------------
+struct CopyItem { float* dst; const float* src; long long numel; long long chunk0; };
+#define COPY_CHUNK 1024
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyItem* __restrict__ items, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].chunk0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const CopyItem it = items[lo];
+    const long long i0 = ((long long)blockIdx.x - it.chunk0) * COPY_CHUNK, i1 = min(it.numel, i0 + COPY_CHUNK);
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) it.dst[i] = it.src[i];
+}
+
 struct Loader {
     nm_ctx* c;
     const std::map<std::string, std::pair<const float*, int64_t>>& sd;
     int rc = NM_OK;
+    std::vector<CopyItem> copies;
+
+    // one launch for all the plain copies (biases, GroupNorm affine, VRNN matrices ...)
+    int flush_copies() {
+        if (copies.empty()) return NM_OK;
+        long long chunks = 0;
+        for (CopyItem& it : copies) { it.chunk0 = chunks; chunks += (it.numel + COPY_CHUNK - 1) / COPY_CHUNK; }
+        const size_t bytes = copies.size() * sizeof(CopyItem);
+        c->host_table2.assign(reinterpret_cast<const char*>(copies.data()), reinterpret_cast<const char*>(copies.data()) + bytes);
+        if (c->copy_table_cap < bytes) {
+            if (c->copy_table) { (void)hipDeviceSynchronize(); (void)hipFree(c->copy_table); }
+            c->copy_table = nullptr; c->copy_table_cap = 0;
+            if (hipMalloc(&c->copy_table, bytes) != hipSuccess) { nm_set_error("set_weights: hipMalloc(copy table) failed"); return NM_ERR_HIP; }
+            c->copy_table_cap = bytes;
+        }
+        int r = nm_check_hip(hipMemcpyAsync(c->copy_table, c->host_table2.data(), bytes, hipMemcpyHostToDevice, c->stream), "set_weights: copy table");
+        if (r) return r;
+        hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)chunks), dim3(256), 0, c->stream, static_cast<const CopyItem*>(c->copy_table), (int)copies.size());
+        return nm_check_hip(hipGetLastError(), "set_weights: multi copy");
+    }
 
     const float* get(const std::string& name, int64_t numel) {
         auto it = sd.find(name);
@@ -71,8 +101,7 @@ struct Loader {
         if (!src) return nullptr;
         float* dst = nm_ctx_weight_alloc(c, numel);
         if (!dst) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return nullptr; }
-        int r = nm_check_hip(hipMemcpyAsync(dst, src, numel * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "set_weights: copy");
-        if (r && !rc) rc = r;
+        copies.push_back(CopyItem{dst, src, (long long)numel, 0});      // ~240 small tensors: copied by ONE kernel at the end (flush_copies)
         return dst;
     }
     // pad16: the layer's input tensor is built by the library itself with Cin rounded up to 16 (the decoder's 179-channel combined
@@ -191,7 +220,8 @@ struct Loader {
         if (!r) {
             TensorRef t; t.p = packed_in; t.scale = nullptr; t.shift = nullptr; t.slope = 1.0f; t.N = 1; t.D = t.H = t.W = G; t.C = 8;
             ConvGeom g; g.ks = 5; g.stride = 1; g.pad = 2; g.OD = g.OH = g.OW = G; g.Cout = Cout; g.Co_pad = f.c0.Co_pad;
-            r = nm_launch_conv(t, f.c0.wp, f.c0.bias, f.field, g, nullptr, c->stream, 4);
+            // (the caller's bias tensor: the ctx-owned copy is filled by the batched copy at the end of set_weights)
+            r = nm_launch_conv(t, f.c0.wp, get(p + ".bias", Cout), f.field, g, nullptr, c->stream, 4);
         }
         if (r && !rc) rc = r;
     }
@@ -888,6 +918,7 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
         }
     }
     if (L.rc) return L.rc;
+    if ((rc = L.flush_copies())) return rc;
     rc = nm_check_hip(hipGetLastError(), "set_weights: pack kernels");
     if (rc) return rc;
     if (c->owned_cursor < c->owned.size()) {           // fewer buffers than last time (training packs switched off): drop the rest
