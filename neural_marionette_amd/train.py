@@ -76,7 +76,8 @@ class LearnerTrainer:
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
 
-    def step(self, vox, eps=None) -> Dict[str, float]:
+    def step(self, vox, eps=None, sync: bool = True):
+        """One training step.  sync=True returns python floats (waits for the device); sync=False returns 0-dim device tensors."""
         net = self.net
         for p in self.params:
             p.grad = None
@@ -89,7 +90,9 @@ class LearnerTrainer:
         eng.ready()
         self.t += 1
         adam_step_(eng, self.params, grads, self.m, self.v, self.t, self.lr, self.betas, self.eps)
-        return {"loss": float(loss), **{k: float(log[k]) for k in self.weights}}
+        if not sync:
+            return {"loss": loss.detach(), **{k: log[k].detach() for k in self.weights}}
+        return {"loss": float(loss.detach()), **{k: float(log[k].detach()) for k in self.weights}}
 
 
 # AIST loss weights of the reference for the detector losses (train.py:177-181 / opt.pickle)
