@@ -11,8 +11,14 @@ Parameters are ordinary ``nn.Parameter`` objects stored under the reference's ke
 (checkpoints load unchanged); the engine re-uploads / re-packs them into the library's
 MFMA layouts whenever their version counters change (load_state_dict, optimizer step).
 
-Round-1 scope: inference / forward values.  The returned tensors carry no autograd
-graph (the training step is the next row of SURVEY §8(f)).
+The module tree itself (holders.py) is built from subclasses of the torch layer types in the reference's
+construction order, so a freshly constructed network carries torch's default initialisation and
+``network.apply(weights_init)`` (train.py:262,268) acts on it exactly as on the reference; a seeded
+construction gives a bit-identical ``state_dict``.
+
+Under ``torch.enable_grad()`` with trainable parameters the 11 detector losses and the two VRNN losses are
+differentiable w.r.t. the parameters (autograd bridges over nm_detector_backward / nm_vrnn_encode_backward);
+every other returned tensor is detached, which is all the reference's training loss consumes.
 """
 from __future__ import annotations
 
@@ -25,36 +31,23 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, holders
 from .skeleton import build_skeleton
-from .spec import DETECTOR_LOSS_KEYS, FEAT_DIM, FROZEN_KEYS, HotPathOptions, param_spec
+from .spec import DETECTOR_LOSS_KEYS, FEAT_DIM, HotPathOptions, param_spec
 
 Priority = namedtuple("Priority", ["values", "indices"])   # what torch.topk returns in the reference
-
-
-class _Node(nn.Module):
-    """Container whose only job is to hold parameters / children under given names."""
-
-    def forward(self, *a, **k):  # pragma: no cover - containers are never called
-        raise RuntimeError("parameter container; the computation lives in libnm355.so")
-
-
-def _plant(root: nn.Module, dotted: str, shape, requires_grad: bool = True) -> None:
-    parts = dotted.split(".")
-    node = root
-    for p in parts[:-1]:
-        if p not in node._modules:
-            node.add_module(p, _Node())
-        node = node._modules[p]
-    node.register_parameter(parts[-1], nn.Parameter(torch.zeros(*shape), requires_grad=requires_grad))
 
 
 class Engine:
     """One nm_ctx + weight synchronisation for a NeuralMarionette instance."""
 
-    def __init__(self, opts: HotPathOptions, owner: nn.Module):
+    def __init__(self, opts: HotPathOptions, owner: nn.Module, prefix: str = ""):
         self.opts = opts
-        self.owner = owner          # module whose state_dict has the reference's 337 keys
+        self.owner = owner          # module whose state_dict (under ``prefix``) has the reference's keys
+        # a stand-alone KyptDetector / HSVRNNBVH owns only its half of the 337 tensors ('kypt_detector.' /
+        # 'dyna_module.'); the library context wants all of them, so the other half is uploaded as zeros and is
+        # never reached (the stand-alone object has no method that calls the other half's entry points)
+        self.prefix = prefix
         self.ctx: Optional[_lib.Context] = None
         self._stamp = None
         self._named = None
@@ -81,6 +74,7 @@ class Engine:
                                 use_graph_traj=int(o.graph_traj_weight > 0))
             self.ctx = _lib.Context(cfg)
             self._stamp = None
+            self._named = None
         _lib.check(self.ctx.lib.nm_ctx_set_training(self.ctx.handle, int(self.training_packs)), "set_training")
         self.ctx.bind_stream()
         _lib.check(self.ctx.lib.nm_set_conv_mode(self.ctx.handle, self.conv_mode), "set_conv_mode")
@@ -97,7 +91,10 @@ class Engine:
 
     def _sync_weights(self) -> None:
         if self._named is None:
-            self._named = list(self.owner.state_dict(keep_vars=True).items())   # Parameter objects persist
+            own = [(self.prefix + k, t) for k, t in self.owner.state_dict(keep_vars=True).items()]   # Parameter objects persist
+            have = {k for k, _ in own}
+            dev = self.ctx.device
+            self._named = own + [(k, torch.zeros(*shape, device=dev)) for k, shape in param_spec(self.opts) if k not in have]
         sd = self._named
         stamp = tuple((t.data_ptr(), t._version) for _, t in sd)
         if stamp == self._stamp:
@@ -151,7 +148,7 @@ class _DetectorTrain(torch.autograd.Function):
                  _lib.ptr(ff), _lib.ptr(recon), _lib.ptr(aff) if module.affinity_start else None, _lib.ptr(losses))
         ctx.module, ctx.names = module, names
         ctx.shapes = [p.shape for p in params]
-        ctx.keep = (vox, kp, recon)           # the library reads them again in the backward pass
+        ctx.keep = (vox, kp, recon, aff)      # the library reads them again in the backward pass (the tape holds raw pointers)
         ctx.mark_non_differentiable(kp, hm, ff, recon, aff)
         return losses, kp, hm, ff, recon, aff
 
@@ -172,8 +169,8 @@ class _DetectorTrain(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-class KyptDetector(_Node):
-    """model/kypt_detector.py:10-241."""
+class KyptDetector(nn.Module):
+    """model/kypt_detector.py:10-241.  Stand-alone construction (``KyptDetector(opt)``) gets its own library context."""
 
     def __init__(self, options, _engine: Optional[Engine] = None):
         super().__init__()
@@ -195,15 +192,17 @@ class KyptDetector(_Node):
         self.sep_sigma = o.sep_sigma
         self.affinity_anneal = o.affinity_anneal
         self.affinity_start = False
-        for key, shape in param_spec(o):
-            if key.startswith("kypt_detector."):
-                _plant(self, key[len("kypt_detector."):], shape)
-        object.__setattr__(self, "_engine", _engine)
+        # same creation order as kypt_detector.py:44-68 (the RNG stream of a seeded construction matches)
+        self.vox_to_kypt = holders.VoxToKyptNet(grid_size=o.grid_size, nkeypoints=o.nkeypoints, input_dim=o.input_dim,
+                                                sigmas=self.sigmas, fixed_sigma=bool(o.fixed_sigma),
+                                                const_intensity=o.const_intensity)
+        self.kypt_to_vox = holders.KyptToVoxNet(grid_size=o.grid_size, nkeypoints=o.nkeypoints, input_dim=o.input_dim,
+                                                gaussian_cat_type=o.gaussian_cat_type)
+        K, N = o.nkeypoints, o.nneighbor
+        self.affinity_params = nn.Parameter(torch.randn(N, K, K - 1) if o.graph_random_init else torch.ones(N, K, K - 1))
+        object.__setattr__(self, "_engine", _engine if _engine is not None else Engine(o, self, prefix="kypt_detector."))
 
     def _eng(self) -> Engine:
-        if self._engine is None:
-            raise _lib.NmError("KyptDetector must be created through NeuralMarionette (the library context "
-                               "needs the full 337-tensor state_dict)")
         return self._engine
 
     def anneal(self, nepoch):
@@ -269,11 +268,12 @@ class KyptDetector(_Node):
 # ==========================================================================================
 # VRNN
 # ==========================================================================================
-class _Mlp(_Node):
-    """nn.Sequential(Linear, LeakyReLU, Linear[, Tanh]) stand-in (hsvrnn_bvh.py:29-54): parameters under '0' / '2'."""
+class _Mlp(nn.Sequential):
+    """nn.Sequential(Linear, LeakyReLU, Linear[, Tanh]) of hsvrnn_bvh.py:29-54: parameters under '0' / '2', callable
+    like the reference's (vis_generation.py:97-127 calls the four MLPs directly) — through nm_vrnn_mlp."""
 
-    def __init__(self, which: int, nout: int, owner: "HSVRNNBVH"):
-        super().__init__()
+    def __init__(self, which: int, nin: int, nout: int, owner: "HSVRNNBVH"):
+        super().__init__(*holders.vrnn_mlp_layers(nin, nout, tanh=(which == 2)))
         self._which, self._nout = which, nout
         object.__setattr__(self, "_owner", owner)
 
@@ -288,11 +288,11 @@ class _Mlp(_Node):
         return y.reshape(*lead, self._nout)
 
 
-class _Gru(_Node):
-    """nn.GRUCell stand-in (hsvrnn_bvh.py:57)."""
+class GRUCell(nn.GRUCell):
+    """nn.GRUCell of hsvrnn_bvh.py:57 (torch's parameters and default init), computed by nm_vrnn_gru."""
 
-    def __init__(self, owner: "HSVRNNBVH"):
-        super().__init__()
+    def __init__(self, input_size: int, hidden_size: int, owner: "HSVRNNBVH"):
+        super().__init__(input_size, hidden_size)
         object.__setattr__(self, "_owner", owner)
 
     def forward(self, x, h):
@@ -344,8 +344,8 @@ class _EncodeTrain(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
-class HSVRNNBVH(_Node):
-    """model/hsvrnn_bvh.py:10-286."""
+class HSVRNNBVH(nn.Module):
+    """model/hsvrnn_bvh.py:10-286.  Stand-alone construction (``HSVRNNBVH(opt)``) gets its own library context."""
 
     def __init__(self, options, _engine: Optional[Engine] = None):
         super().__init__()
@@ -359,23 +359,22 @@ class HSVRNNBVH(_Node):
         self.transition_type = o.transition_type
         self.state_mode = o.state_mode
         self.action_mode = o.action_mode
-        K, Z = o.nkeypoints, o.nlatent_kypt
-        self.add_module("extract_post_dist", _Mlp(0, 2 * Z, self))
-        self.add_module("extract_prior_dist", _Mlp(1, 2 * Z, self))
-        self.add_module("root_intensity_decoder", _Mlp(2, 3 + K, self))
-        self.add_module("joint_matrix_decoder", _Mlp(3, 6 * K, self))
-        self.add_module("kypt_rnn_cell", _Gru(self))
-        for key, shape in param_spec(o):
-            if key.startswith("dyna_module."):
-                _plant(self, key[len("dyna_module."):], shape, requires_grad=key not in FROZEN_KEYS)
+        K, Z, H = o.nkeypoints, o.nlatent_kypt, o.nhidden_kypt
+        state_dim = K * (o.input_dim + 1)
+        # same creation order as hsvrnn_bvh.py:29-65 (the RNG stream of a seeded construction matches)
+        self.extract_post_dist = _Mlp(0, H + state_dim, 2 * Z, self)
+        self.extract_prior_dist = _Mlp(1, H, 2 * Z, self)
+        self.root_intensity_decoder = _Mlp(2, H + Z, 3 + K, self)
+        self.joint_matrix_decoder = _Mlp(3, H + Z, 6 * K, self)
+        self.kypt_rnn_cell = GRUCell(state_dim + Z, H, self)
+        self.init_kypt_rnn_state = nn.Parameter(torch.randn(1, H))
         self.A, self.priority, self.parents = None, None, None
-        object.__setattr__(self, "_engine", _engine)
+        self.offset_param = nn.Parameter(torch.randn(K, 3))
+        self.offset_param.requires_grad = False
+        object.__setattr__(self, "_engine", _engine if _engine is not None else Engine(o, self, prefix="dyna_module."))
         object.__setattr__(self, "_tree_key", None)
 
     def _eng(self) -> Engine:
-        if self._engine is None:
-            raise _lib.NmError("HSVRNNBVH must be created through NeuralMarionette (the library context needs "
-                               "the full 337-tensor state_dict)")
         return self._engine
 
     # -- skeleton ---------------------------------------------------------------------------

@@ -32,8 +32,12 @@ def make_state_dict(opts: HotPathOptions, seed: int = 0, variant: str = "default
                    random affinity logits.
       ``peaky``    like ``default`` but the heat-map heads are scaled up so the
                    detected keypoints spread over [-1, 1] instead of hugging 0.
-      ``small``    ``weights_init``-like (utils/train_utils.py:248-264 of the
-                   reference): conv weights N(0, 0.02), biases 0.
+      ``winit``    what a from-scratch detector run starts from (train.py:262,268 ->
+                   utils/train_utils.py:248-264 of the reference): convs inside the
+                   ``*Block`` containers (both feature nets) N(0, 0.001), the other convs
+                   (heads, combined-representation adjust, decoder) N(0, 0.02), conv biases 0,
+                   GroupNorm affine exactly 1 / 0, VRNN at torch's default scale; the
+                   affinity logits stay random (the all-ones init is a tree of ties, fixture G3).
     """
     rng = np.random.default_rng(np.random.SeedSequence([seed, 0x4E4D]))
     sd: Dict[str, torch.Tensor] = {}
@@ -44,11 +48,13 @@ def make_state_dict(opts: HotPathOptions, seed: int = 0, variant: str = "default
             a = rng.standard_normal(shape)
         elif name.endswith("init_kypt_rnn_state") or name.endswith("offset_param"):
             a = rng.standard_normal(shape)
+        elif is_norm and variant == "winit":
+            a = np.ones(shape) if leaf == "weight" else np.zeros(shape)
         elif is_norm:
             a = (1.0 + 0.1 * rng.standard_normal(shape)) if leaf == "weight" else 0.1 * rng.standard_normal(shape)
-        elif variant == "small" and len(shape) == 5:
-            a = 0.02 * rng.standard_normal(shape)
-        elif variant == "small" and leaf == "bias" and not name.startswith("dyna_module"):
+        elif variant == "winit" and len(shape) == 5:
+            a = (0.001 if _in_block(name) else 0.02) * rng.standard_normal(shape)
+        elif variant == "winit" and leaf == "bias" and not name.startswith("dyna_module"):
             a = np.zeros(shape)
         else:
             if leaf.startswith("bias"):
@@ -62,6 +68,12 @@ def make_state_dict(opts: HotPathOptions, seed: int = 0, variant: str = "default
             a = a * 12.0
         sd[name] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
     return sd
+
+
+def _in_block(name: str) -> bool:
+    """True for the convs below a Basic3DBlock / Res3DBlock / Pool3DBlock / Upsample3DBlock, i.e. everything in the two
+    feature nets (kypt_detector.py:264-272); the heads, the adjust conv and the decoder are plain nn.Conv3d."""
+    return ".extract_features." in name or ".extract_spatio_temporal_features." in name
 
 
 def _is_norm_key(name: str) -> bool:

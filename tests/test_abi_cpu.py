@@ -62,6 +62,39 @@ def test_state_dict_layout_and_loading():
     assert net.kypt_detector.affinity_start is True
 
 
+def test_fresh_network_is_initialised_like_torch_layers():
+    """A from-scratch network (train.py:233 of the reference, before any checkpoint) must not be all zeros: the holders
+    are torch layer subclasses (default init), found by class name / isinstance the way utils/train_utils.py:248-264
+    looks for them.  (Bit equality with the reference tree: tests/test_oracle_vs_reference.py.)"""
+    from torch import nn
+    from neural_marionette_amd.modules import KyptDetector, HSVRNNBVH
+    o = HotPathOptions(grid_size=32)
+    torch.manual_seed(0)
+    net = NeuralMarionette(o)
+    sd = net.state_dict()
+    assert torch.equal(sd["kypt_detector.affinity_params"], torch.ones(2, 24, 23))
+    for k, v in sd.items():
+        if v.dim() >= 2 and not k.endswith("affinity_params"):
+            assert float(v.abs().max()) > 0 and float(v.std()) > 0, k
+    gn = [m for m in net.modules() if isinstance(m, nn.GroupNorm)]
+    assert len(gn) == 2 * 36 + 4 and all(bool((m.weight == 1).all()) and bool((m.bias == 0).all()) for m in gn)
+    names = [type(m).__name__ for m in net.modules()]
+    for cls, n in (("Basic3DBlock", 2), ("Pool3DBlock", 10), ("Res3DBlock", 22), ("Upsample3DBlock", 6), ("HG", 2)):
+        assert names.count(cls) == n, (cls, names.count(cls))
+    convs = [m for m in net.modules() if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d))]
+    assert len(convs) == 2 * 36 + 3 + 1 + 5 and all("Conv" in type(m).__name__ for m in convs)
+    assert isinstance(net.dyna_module.kypt_rnn_cell, nn.GRUCell) and isinstance(net.dyna_module.extract_post_dist[0], nn.Linear)
+    # holders never compute (no silent PyTorch path)
+    with pytest.raises(_lib.NmError):
+        net.kypt_detector.vox_to_kypt.extract_features(torch.zeros(1, 4, 32, 32, 32))
+    with pytest.raises(_lib.NmError):
+        convs[0](torch.zeros(1, 4, 8, 8, 8))
+    # stand-alone halves construct with their own engines and the reference's sub-dict keys
+    det, dyn = KyptDetector(o), HSVRNNBVH(o)
+    assert ["kypt_detector." + k for k in det.state_dict()] + ["dyna_module." + k for k in dyn.state_dict()] == list(sd)
+    assert det._eng() is not net._engine and dyn._eng().prefix == "dyna_module."
+
+
 def test_no_cpu_fallback():
     net = NeuralMarionette(HotPathOptions(grid_size=32))
     with pytest.raises(_lib.NmError):

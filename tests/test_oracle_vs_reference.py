@@ -57,7 +57,49 @@ def test_trees_many_seeds(ref_modules):
         assert int(pri.indices[0]) == int(order[0])
 
 
-@pytest.mark.parametrize("variant,clip", [("peaky", "figure"), ("default", "bernoulli")])
+@pytest.mark.parametrize("G", [64, 40])
+def test_shell_initialisation_matches_reference(ref_modules, G):
+    """train.py:233,262-268 of the reference: ``NeuralMarionette(opt)`` then ``network.apply(weights_init)``.  The shells
+    are built from torch layer subclasses in the reference's creation order under the reference's class names, so the
+    same seed gives a bit-identical state_dict before AND after the reference's own ``weights_init``, consumes the same
+    amount of the RNG stream, and leaves the same requires_grad flags.  Also stand-alone KyptDetector / HSVRNNBVH."""
+    NeuralMarionette, _ = ref_modules
+    from model.kypt_detector import KyptDetector as RefDetector
+    from model.hsvrnn_bvh import HSVRNNBVH as RefLearner
+    from utils.train_utils import weights_init
+    import neural_marionette_amd as nm
+    from neural_marionette_amd.modules import KyptDetector, HSVRNNBVH
+    opt = _opt(G)
+
+    def same(a, b):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa) == list(sb)
+        bad = [k for k in sa if not torch.equal(sa[k], sb[k])]
+        assert not bad, bad[:5]
+        assert [(n, p.requires_grad) for n, p in a.named_parameters()] == [(n, p.requires_grad) for n, p in b.named_parameters()]
+
+    torch.manual_seed(7); ref = NeuralMarionette(opt); tail_ref = torch.rand(4)
+    torch.manual_seed(7); net = nm.NeuralMarionette(opt); tail = torch.rand(4)
+    same(ref, net)
+    assert torch.equal(tail, tail_ref)
+    assert not any(bool((v == 0).all()) for k, v in net.state_dict().items() if k.endswith("weight"))
+    torch.manual_seed(8); ref.apply(weights_init); tail_ref = torch.rand(4)
+    torch.manual_seed(8); net.apply(weights_init); tail = torch.rand(4)
+    same(ref, net)
+    assert torch.equal(tail, tail_ref)
+    w = net.state_dict()
+    assert 5e-4 < float(w["kypt_detector.vox_to_kypt.extract_features.2.res_branch.0.weight"].std()) < 2e-3
+    assert 1e-2 < float(w["kypt_detector.kypt_to_vox.decode_voxel_from_combined_representation.4.weight"].std()) < 4e-2
+    # the module walk weights_init sees: same class names in the same order
+    strip = lambda m: [type(x).__name__ for x in m.modules() if any(True for _ in x.parameters(recurse=False))]
+    assert strip(ref) == strip(net)
+    torch.manual_seed(3); a = RefDetector(opt); torch.manual_seed(3); b = KyptDetector(opt)
+    same(a, b)
+    torch.manual_seed(3); a = RefLearner(opt); torch.manual_seed(3); b = HSVRNNBVH(opt)
+    same(a, b)
+
+
+@pytest.mark.parametrize("variant,clip", [("peaky", "figure"), ("default", "bernoulli"), ("winit", "figure")])
 def test_full_forward_32(ref_modules, variant, clip):
     NeuralMarionette, _ = ref_modules
     import torch.distributions.normal as tdn
