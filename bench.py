@@ -154,7 +154,7 @@ def main():
         frames = world * B_PER_GPU * T * args.steps
         # dominant kernel = the conv variant with the largest event-timed total
         best = None
-        for v in range(12):
+        for v in range(13):
             ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
             _lib.check(lib.nm_prof_read(h, v, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
             if n.value and (best is None or ms.value > best[1]):
@@ -170,7 +170,7 @@ def main():
                 traffic = pm["traffic_bytes_per_launch"].get(name)
             except Exception:
                 pass
-            split = name.startswith("conv_f16") or name.startswith("conv_pool_f16")
+            split = name.startswith("conv_f16") or name.startswith("conv_pool_f16") or name.startswith("conv_up2c")
             peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
             roof = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=traffic,
                         kernel=name, launches=n, avg_launch_ms=ms / n, kernel_time_share=ms * 1e-3 / dt,

@@ -63,6 +63,9 @@ const char* nm_last_error(void);
 
 int nm_ctx_create(nm_ctx** out, const nm_config* cfg);
 int nm_ctx_destroy(nm_ctx* ctx);
+/* Binds the stream every later call is enqueued on (torch.cuda.current_stream() in the shells).  A ctx works on ONE stream
+ * at a time; when the handle changes, the new stream is made to wait (event) for everything the ctx queued on the old one
+ * and on its own side stream, so ctx-owned weights / workspaces are never overwritten under a running kernel. */
 int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream);
 /* Replaces NeuralMarionette.load_state_dict / .cuda() for the HIP path: copies every
  * tensor and re-packs conv weights into the MFMA layout.  Must be called again after an

@@ -3,6 +3,7 @@
 // nm_net.hip / nm_vrnn.hip.
 #include "nm_ctx.h"
 #include "nm_grad.h"
+#include "nm_up2c.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -98,6 +99,7 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     if (ctx->ws_t.base) (void)hipFree(ctx->ws_t.base);
     if (ctx->copy_table) (void)hipFree(ctx->copy_table);
     nm_net_free_tape(ctx);
+    nm_vrnn_free_tape(ctx);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side}) if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -106,7 +108,19 @@ int nm_ctx_destroy(nm_ctx* ctx) {
 
 int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) {
     if (!ctx) { nm_set_error("set_stream: null ctx"); return NM_ERR_ARG; }
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t ns = static_cast<hipStream_t>(hip_stream);
+    if (ns != ctx->stream && ctx->stream_bound) {
+        // ctx-owned state (packed weights, workspaces, tapes) may still be in use by work queued on the old stream (and on the
+        // side stream it forked): the new stream starts behind it
+        (void)hipSetDevice(ctx->cfg.device);
+        int rc = nm_check_hip(hipEventRecord(ctx->ev_fork, ctx->stream), "set_stream: record on the old stream");
+        if (!rc) rc = nm_check_hip(hipStreamWaitEvent(ns, ctx->ev_fork, 0), "set_stream: new stream waits for the old one");
+        if (!rc) rc = nm_check_hip(hipEventRecord(ctx->ev_fork, ctx->stream2), "set_stream: record on the side stream");
+        if (!rc) rc = nm_check_hip(hipStreamWaitEvent(ns, ctx->ev_fork, 0), "set_stream: new stream waits for the side stream");
+        if (rc) return rc;
+    }
+    ctx->stream = ns;
+    ctx->stream_bound = true;
     return NM_OK;
 }
 
@@ -143,7 +157,7 @@ int nm_prof_enable(nm_ctx* ctx, int32_t on) {
 }
 
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) {
-    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 11) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
+    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 12) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
     long long n = 0;
     int rc = nm_conv_prof_collect(variant, ms_total, flops_total, &n);
     if (rc) { nm_set_error("prof_read: event query failed"); return rc; }
@@ -152,10 +166,11 @@ int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_t
 }
 
 const char* nm_prof_kernel_name(int32_t variant) {
-    static const char* names[12] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
+    static const char* names[13] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
                                    "conv_k5occ_kernel", "conv_f16s_kernel<2,1>", "conv_f16s_kernel<2,2>", "conv_f16p_kernel",
-                                   "conv_pool_f16s_kernel", "conv_f16p2_kernel", "conv_f16s_kernel<2,1,3,up2>", "conv_f16s_kernel<2,2,3,up2>"};
-    return (variant >= 0 && variant < 12) ? names[variant] : "";
+                                   "conv_pool_f16s_kernel", "conv_f16p2_kernel", "conv_f16s_kernel<2,1,3,up2>", "conv_f16s_kernel<2,2,3,up2>",
+                                   "conv_up2c_kernel"};
+    return (variant >= 0 && variant < 13) ? names[variant] : "";
 }
 
 int nm_host_linspace(int32_t n, float* out) {
@@ -187,20 +202,26 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     ConvGeom g; g.ks = ks; g.stride = stride; g.pad = pad; g.up2 = up2 ? 1 : 0;
     g.OD = (us * D + 2 * pad - ks) / stride + 1; g.OH = (us * H + 2 * pad - ks) / stride + 1; g.OW = (us * W + 2 * pad - ks) / stride + 1;
     g.Cout = Cout; g.Co_pad = Co_pad;
-    const int nblk = nm_conv_blocks_per_frame(g);
+    const bool want_up2c = up2 && nm_up2c_eligible(D, H, W, Cin, Cout, ks, stride, pad);
+    const size_t wflu = want_up2c ? nm_up2c_weight_floats(Cin, Co_pad) : 0;
+    if (want_up2c) g.up2c = reinterpret_cast<const void*>((uintptr_t)256);      // (placeholder while sizing; the real pointer follows)
+    const int nblk = nm_conv_blocks_per_frame(g, Cin_pad);
     const size_t wfl = nm_packed_weight_floats(ks, Cin_pad, Co_pad);
     const bool want16 = Cin % 8 == 0 && Cin >= 16;
     const size_t wfl16 = want16 ? nm_packed_weight_floats(ks, (Cin + 15) & ~15, Co_pad) : 0;
     const size_t pfl = (size_t)N * nblk * Cout * 2;
-    int rc = nm_ctx_reserve(ctx, (wfl + wfl16 + pfl) * sizeof(float) + 8192);
+    int rc = nm_ctx_reserve(ctx, (wfl + wfl16 + wflu + pfl) * sizeof(float) + 8192);
     if (rc) return rc;
     ctx->ws.release(0);
     float* wp = ctx->ws.f(wfl);
     float* wp16 = want16 ? ctx->ws.f(wfl16) : nullptr;
+    float* wup = want_up2c ? ctx->ws.f(wflu) : nullptr;
     float* part = gn_groups > 0 ? ctx->ws.f(pfl) : nullptr;
     rc = nm_launch_pack_conv_weight(weight, Cout, Cin, ks, wp, Cin_pad, Co_pad, ctx->stream);
     if (rc) return rc;
     if (wp16 && (rc = nm_launch_pack_conv_weight16(weight, Cout, Cin, ks, wp16, Co_pad, ctx->stream))) return rc;
+    if (wup && (rc = nm_launch_up2c_compose(weight, Cout, Cin, Co_pad, wup, ctx->stream))) return rc;
+    g.up2c = wup;
     TensorRef t = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad);
     rc = nm_launch_conv(t, wp, bias, out, g, part, ctx->stream, Cin, wp16);
     if (rc) return rc;

@@ -36,6 +36,7 @@ struct ConvGeom {
     int Cout;      // real output channels (multiple of 8, or 24 for the heat-map heads)
     int Co_pad;    // packed weight columns (multiple of 32)
     int up2 = 0;   // the input tensor is stored at half resolution; its trilinear x2 upsampling is convolved
+    const void* up2c = nullptr;   // up2: composite weight sets of nm_up2c.hip (null: the layer stays on conv_f16s<.., UP2>)
 };
 
 void nm_set_error(const char* fmt, ...);
@@ -47,7 +48,7 @@ size_t nm_packed_weight_floats(int ks, int Cin_pad, int Co_pad);
 int nm_launch_pack_conv_weight(const float* w_oidhw, int Cout, int Cin, int ks, float* packed,
                                int Cin_pad, int Co_pad, hipStream_t s);
 // number of per-frame partial blocks the conv epilogue writes (for sizing `part`)
-int nm_conv_blocks_per_frame(const ConvGeom& g);
+int nm_conv_blocks_per_frame(const ConvGeom& g, int Cin = 16 /* decides the kernel for up2 layers */);
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
                    const ConvGeom& g, float* part /*[N][nblk][Cout][2] or null*/, hipStream_t s,
                    int cin_real = 0 /* un-padded Cin, for the profiler's FLOP count */,

@@ -22,6 +22,7 @@
 //   sum / sum-of-squares partials for the following GroupNorm (deterministic: no float
 //   atomics).
 #include "nm_common.h"
+#include "nm_up2c.h"
 #include <utility>
 #include <vector>
 
@@ -2292,7 +2293,12 @@ int nm_launch_pack_conv_weight(const float* w, int Cout, int Cin, int ks, float*
     return nm_check_hip(hipGetLastError(), "pack_conv_weight launch");
 }
 
-int nm_conv_blocks_per_frame(const ConvGeom& g) {
+static bool use_up2c(const ConvGeom& g, int Cin) {
+    return g.up2 && g.up2c && g_conv_mode == 1 && nm_up2c_eligible(g.OD / 2, g.OH / 2, g.OW / 2, Cin, g.Cout, g.ks, g.stride, g.pad);
+}
+
+int nm_conv_blocks_per_frame(const ConvGeom& g, int Cin) {
+    if (use_up2c(g, Cin)) return nm_up2c_blocks_per_frame(g.OD / 2, g.OH / 2, g.OW / 2);
     Tiling t = choose_tiling(g, 16);
     return t.nbz * t.nby * t.nbx;
 }
@@ -2333,6 +2339,18 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
         return NM_ERR_ARG;
     }
     if ((in.scale == nullptr) != (in.shift == nullptr)) { nm_set_error("conv: scale/shift must come together"); return NM_ERR_ARG; }
+    if (use_up2c(g, in.C)) {
+        // the fused-upsample layers on the coarse grid with composite weights (nm_up2c.hip): main + shell launch, timed together
+        ProfRec rec;
+        if (NM_PROF_ON(s)) {
+            rec.a = prof_event(); rec.b = prof_event(); rec.variant = 12;
+            rec.flops = 2.0 * in.N * (double)g.OD * g.OH * g.OW * g.Cout * (double)(cin_real > 0 ? cin_real : in.C) * 27.0;
+            (void)hipEventRecord(rec.a, s);
+        }
+        const int rc = nm_launch_conv_up2c(in, g.up2c, bias, out, g.Cout, g.Co_pad, part, s);
+        if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+        return rc;
+    }
     Tiling t = choose_tiling(g, in.C);
     if (t.lds_bytes > 160 * 1024) { nm_set_error("conv: LDS tile %zu B too large", t.lds_bytes); return NM_ERR_UNSUPPORTED; }
     ConvParams p;

@@ -32,6 +32,7 @@ struct ConvW {
     float* wp = nullptr;      // fp32 packed [tap][Cin/4][Co_pad][4]
     void* wp16 = nullptr;     // split-fp16 packed (Cin % 16 == 0 only), see nm_conv.hip
     float* bias = nullptr;
+    void* wup = nullptr;      // fused-upsample layers: composite weight sets of nm_up2c.hip
     // training (nm_ctx_set_training): state_dict key prefix and the weights of the data-gradient convolution
     std::string key;
     int csel = 0, cd_pad = 0;  // input channels that receive a gradient (Cin rounded down to 8) and their packed width
@@ -78,6 +79,7 @@ struct VrnnW {
 struct nm_ctx {
     nm_config cfg;
     hipStream_t stream = nullptr;
+    bool stream_bound = false;             // nm_ctx_set_stream has been called (nullptr = the legacy default stream is a valid choice)
     hipStream_t stream2 = nullptr;         // ctx-owned side stream: clip-mean net / VRNN run beside the frame stack
     hipEvent_t ev_fork = nullptr, ev_clip = nullptr, ev_kp = nullptr, ev_side = nullptr;
     Arena ws;                              // activations / scratch, reset per call
@@ -92,6 +94,7 @@ struct nm_ctx {
     void* copy_table = nullptr; size_t copy_table_cap = 0;      // its device copy
     std::vector<char> host_table;          // host staging of nm_adam_step_multi's pointer table (kept alive across the async copy)
     struct TrainTape* tape = nullptr;      // what the backward pass needs of the last training forward (nm_net.hip)
+    void* vtape = nullptr;                 // VrnnTape of the last nm_vrnn_encode_train (nm_vrnn.hip)
     DetectorW det;
     VrnnW vrnn;
 };
@@ -99,6 +102,9 @@ struct nm_ctx {
 int nm_ctx_reserve(nm_ctx* ctx, size_t bytes);        // grow the workspace (synchronises)
 float* nm_ctx_weight_alloc(nm_ctx* ctx, size_t floats);
 
+// nm_vrnn.hip
+void nm_vrnn_free_tape(nm_ctx* ctx);
+void nm_vrnn_invalidate_tape(nm_ctx* ctx);
 // nm_net.hip
 void nm_net_free_tape(nm_ctx* ctx);
 int nm_net_set_weights(nm_ctx* ctx, const std::map<std::string, std::pair<const float*, int64_t>>& sd);

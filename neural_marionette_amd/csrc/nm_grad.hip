@@ -606,7 +606,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 __global__ void make_scale_kernel(const unsigned* __restrict__ amax, int count, float* __restrict__ scale, float* __restrict__ sc2) {
     const float mx = __uint_as_float(*amax);
     float sc = 1.0f;
-    if (mx > 0.f && mx < INFINITY) { int e; frexpf(mx, &e); sc = ldexpf(1.0f, 8 - e); }
+    // exponent clamped to +-100: for a vanishing (denormal-sized) or huge gradient the scale and its reciprocal must both stay finite
+    if (mx > 0.f && mx < INFINITY) { int e; frexpf(mx, &e); sc = ldexpf(1.0f, min(max(8 - e, -100), 100)); }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) scale[i] = sc;
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc2[0] = sc; sc2[1] = 1.0f / sc; }
 }

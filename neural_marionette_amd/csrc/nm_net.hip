@@ -14,6 +14,7 @@
 #include "nm_heads.h"
 #include "nm_grad.h"
 #include "nm_heads_bwd.h"
+#include "nm_up2c.h"
 #include <cmath>
 #include <functional>
 
@@ -146,6 +147,15 @@ struct Loader {
         }
         return r;
     }
+    // composite weight sets of the fused-upsample layers (nm_up2c.hip); a null wup leaves the layer on conv_f16s<.., UP2>
+    void up2_sets(const std::string& p, ConvW& w) {
+        const float* src = get(p + ".weight", (int64_t)w.Cout * w.Cin * 27);
+        if (!src || w.ks != 3 || w.Cin % 16) return;
+        w.wup = nm_ctx_weight_alloc(c, nm_up2c_weight_floats(w.Cin, w.Co_pad));
+        if (!w.wup) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return; }
+        const int r = nm_launch_up2c_compose(src, w.Cout, w.Cin, w.Co_pad, w.wup, c->stream);
+        if (r && !rc) rc = r;
+    }
     NormW norm(const std::string& p, int C) {
         NormW n; n.C = C; n.groups = C / 16; n.key = p;
         n.gamma = copy(p + ".weight", C); n.beta = copy(p + ".bias", C);
@@ -267,11 +277,11 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
     ConvGeom g; g.ks = w.ks; g.stride = stride; g.pad = pad; g.up2 = up2 ? 1 : 0;
     const int us = up2 ? 2 : 1;
     g.OD = (us * in.D + 2 * pad - w.ks) / stride + 1; g.OH = (us * in.H + 2 * pad - w.ks) / stride + 1; g.OW = (us * in.W + 2 * pad - w.ks) / stride + 1;
-    g.Cout = w.Cout; g.Co_pad = w.Co_pad;
+    g.Cout = w.Cout; g.Co_pad = w.Co_pad; g.up2c = up2 ? w.wup : nullptr;
     const size_t ov = (size_t)g.OD * g.OH * g.OW;
     float* out = out_buf ? out_buf : n.alloc((size_t)in.N * ov * w.Cout);
     float *part = nullptr, *scale = nullptr, *shift = nullptr;
-    const int nblk = nm_conv_blocks_per_frame(g);
+    const int nblk = nm_conv_blocks_per_frame(g, in.C);
     if (gn) {
         part = n.alloc((size_t)in.N * nblk * w.Cout * 2);
         scale = n.alloc((size_t)in.N * w.Cout); shift = n.alloc((size_t)in.N * w.Cout);
@@ -867,6 +877,7 @@ void nm_net_free_tape(nm_ctx* c) { delete c->tape; c->tape = nullptr; }
 
 int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const float*, int64_t>>& sd) {
     if (c->tape) c->tape->valid = false;
+    nm_vrnn_invalidate_tape(c);
     int rc = NM_OK;
     c->owned_cursor = 0;                   // buffers are reused in call order (nm_ctx_weight_alloc): no free, no sync
     c->has_weights = false;
@@ -889,9 +900,9 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
         if (pw && pb && d.prop) hipLaunchKernelGGL(pack_small_kernel, dim3(1), dim3(64), 0, c->stream, pw, 2, pb, 1, d.prop);
     }
     d.adjust = L.conv(k2v + ".adjust_combined_representation.0", FEAT, FEAT + 2 * K + 3, 1);       // (pad16 = true puts it on conv_f16s: measured 648 us vs 319 us on the fp32 kernel, which stages all 184 channels per pass; a 1-tap layer has 6 MFMAs per staged 16-channel chunk)
-    d.d1 = L.conv(dec + ".1", FEAT / 2, FEAT, 3); d.dn2 = L.norm(dec + ".2", FEAT / 2);
+    d.d1 = L.conv(dec + ".1", FEAT / 2, FEAT, 3); L.up2_sets(dec + ".1", d.d1); d.dn2 = L.norm(dec + ".2", FEAT / 2);
     d.d4 = L.conv(dec + ".4", FEAT / 2, FEAT / 2, 3); d.dn5 = L.norm(dec + ".5", FEAT / 2);
-    d.d8 = L.conv(dec + ".8", FEAT / 4, FEAT / 2, 3); d.dn9 = L.norm(dec + ".9", FEAT / 4);
+    d.d8 = L.conv(dec + ".8", FEAT / 4, FEAT / 2, 3); L.up2_sets(dec + ".8", d.d8); d.dn9 = L.norm(dec + ".9", FEAT / 4);
     d.d11 = L.conv(dec + ".11", FEAT / 4, FEAT / 4, 3); d.dn12 = L.norm(dec + ".12", FEAT / 4);
     {
         const float* w = L.get(dec + ".14.weight", FEAT / 4);

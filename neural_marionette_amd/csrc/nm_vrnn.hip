@@ -348,6 +348,7 @@ struct StepTape { float *hid_p, *hid_q, *pmu, *psig, *praw, *qmu, *qsig, *qraw, 
 
 struct VrnnTape {
     int B = 0, T = 0, S = 0;
+    bool valid = false;          // set by a completed training forward, cleared by nm_ctx_set_weights and by the backward
     float* base = nullptr; size_t cap = 0;
     // [T][B][...] planes
     float *hid_p, *hid_q, *pmu, *psig, *praw, *qmu, *qsig, *qraw, *hr, *hj, *raw, *rot6, *Rl, *Rg, *eps, *gates;
@@ -361,7 +362,11 @@ struct VrnnTape {
         return s;
     }
 };
-VrnnTape g_tape;
+// the tape belongs to the context (nm_ctx::vtape): two contexts in one process never see each other's forward
+VrnnTape& ctx_tape(nm_ctx* c) {
+    if (!c->vtape) c->vtape = new VrnnTape();
+    return *static_cast<VrnnTape*>(c->vtape);
+}
 
 int tape_reserve(VrnnTape& tp, int B, int T, int S, int K, int Z, int H, hipStream_t s) {
     const size_t per_tb = 128 * 4 + 6 * Z + (3 + K) + 6 * K + 18 * K + Z + 4 * H;
@@ -716,6 +721,15 @@ int max_fk_lds(nm_ctx* c, int S) {
 
 }  // namespace
 
+void nm_vrnn_free_tape(nm_ctx* c) {
+    VrnnTape* tp = static_cast<VrnnTape*>(c->vtape);
+    if (!tp) return;
+    if (tp->base) (void)hipFree(tp->base);
+    delete tp;
+    c->vtape = nullptr;
+}
+void nm_vrnn_invalidate_tape(nm_ctx* c) { if (c->vtape) static_cast<VrnnTape*>(c->vtape)->valid = false; }
+
 extern "C" {
 
 int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) {
@@ -770,7 +784,8 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
     float* offset = c->ws.f((size_t)B * K * 3);
     float* kl = c->ws.f((size_t)B * T); float* rec = c->ws.f((size_t)B * T);
     if (c->ws.overflow) { nm_set_error("vrnn_encode: workspace overflow"); return NM_ERR_STATE; }
-    if (train && (rc = tape_reserve(g_tape, B, T, S, K, Z, H, c->stream))) return rc;
+    VrnnTape* tpp = train ? &ctx_tape(c) : nullptr;
+    if (train) { tpp->valid = false; if ((rc = tape_reserve(*tpp, B, T, S, K, Z, H, c->stream))) return rc; }
     if ((rc = nm_vrnn_offsets(c, keypoints, B, T, offset))) return rc;
     hipLaunchKernelGGL(broadcast_rows_kernel, dim3((H * B + 255) / 256), dim3(256), 0, c->stream, c->vrnn.h0, H, h, (T + 1) * H, B);
     for (int t = 0; t < T; ++t) {
@@ -787,21 +802,23 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
         io.want_prior = true;
         StepTape st; StepBufs sbt = sb;
         if (train) {   // this step's hidden layers / distribution parameters land in the tape instead of the scratch
-            st = g_tape.at(t, K, Z, H); io.tape = &st;
+            st = tpp->at(t, K, Z, H); io.tape = &st;
             sbt.hid_prior = st.hid_p; sbt.hid_post = st.hid_q; sbt.pmu = st.pmu; sbt.psig = st.psig; sbt.qmu = st.qmu; sbt.qsig = st.qsig;
         }
         if ((rc = vrnn_step(c, sbt, io, B, S))) return rc;
     }
     if (train) {
         hipStream_t s = c->stream;
-        (void)hipMemcpyAsync(g_tape.kp_obs, keypoints, (size_t)B * T * S4 * sizeof(float), hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(g_tape.kp_rec, kypt_recon, (size_t)B * T * S4 * sizeof(float), hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(g_tape.z, z, (size_t)B * T * Z * sizeof(float), hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(g_tape.h, h, (size_t)B * (T + 1) * H * sizeof(float), hipMemcpyDeviceToDevice, s);
-        (void)hipMemcpyAsync(g_tape.offset, offset, (size_t)B * K * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        const struct { float* dst; const float* src; size_t n; } cp[5] = {
+            {tpp->kp_obs, keypoints, (size_t)B * T * S4}, {tpp->kp_rec, kypt_recon, (size_t)B * T * S4}, {tpp->z, z, (size_t)B * T * Z},
+            {tpp->h, h, (size_t)B * (T + 1) * H}, {tpp->offset, offset, (size_t)B * K * 3}};
+        for (const auto& e : cp)
+            if ((rc = nm_check_hip(hipMemcpyAsync(e.dst, e.src, e.n * sizeof(float), hipMemcpyDeviceToDevice, s), "vrnn_encode_train: tape copy"))) return rc;
     }
     hipLaunchKernelGGL(vrnn_stats_kernel, dim3(1), dim3(256), 0, c->stream, kl, rec, B * T, Z, scalars2);
-    return nm_check_hip(hipGetLastError(), "vrnn_encode");
+    rc = nm_check_hip(hipGetLastError(), "vrnn_encode");
+    if (train) tpp->valid = rc == NM_OK;
+    return rc;
 }
 
 int nm_vrnn_encode(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
@@ -822,8 +839,13 @@ static int launch_wgrad(const float* dA, int ldA, int rows, WgSeg xa, WgSeg xb, 
 int nm_vrnn_encode_backward(nm_ctx* c, const float* dscal2, const nm_named_grad* grads, int32_t count) {
     int rc = ready(c, "vrnn_encode_backward", true);
     if (rc) return rc;
-    const VrnnTape& tp = g_tape;
-    if (!tp.base || tp.B <= 0) { nm_set_error("vrnn_encode_backward: no recorded forward (call nm_vrnn_encode_train first)"); return NM_ERR_STATE; }
+    VrnnTape& tp = ctx_tape(c);
+    if (!tp.base || tp.B <= 0 || !tp.valid) {
+        nm_set_error("vrnn_encode_backward: no recorded forward on this context (call nm_vrnn_encode_train first; a tape is consumed "
+                     "by one backward and dropped by nm_ctx_set_weights)");
+        return NM_ERR_STATE;
+    }
+    tp.valid = false;            // one backward per forward
     if (!dscal2 || !grads || count <= 0) { nm_set_error("vrnn_encode_backward: bad argument"); return NM_ERR_ARG; }
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4, B = tp.B, T = tp.T, R0 = 3 + K, J6 = 6 * K;
     const VrnnW& w = c->vrnn;

@@ -156,6 +156,61 @@ def test_conv3d_fused_upsample(ctx, Cin, Cout, size, prologue, N, mode):
     assert e < REL, f"fused GroupNorm rel err {e:.3e}"
 
 
+@pytest.mark.parametrize("dims,prologue,N", [((8, 8, 8), True, 3), ((2, 8, 16), False, 2), ((16, 16, 16), True, 2), ((6, 24, 8), True, 1),
+                                              ((32, 32, 32), True, 2), ((4, 40, 8), False, 5)])
+def test_conv3d_fused_upsample_composite(ctx, dims, prologue, N):
+    """The 64 -> 32 resolution-doubling decoder layer (kypt_detector.py:441-447) on the coarse grid with composite weights
+    (nm_up2c.hip): eight parity-class 3x3x3 convolutions + the signed shell corrections that restore the fine conv's zero
+    padding.  Checked against ATen's Upsample -> Conv3d -> GroupNorm, separately on the outer shell (where the corrections
+    act: faces, edges and corners of every side) and on the interior."""
+    from neural_marionette_amd import _lib
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, 1), "set_conv_mode")
+    Cin, Cout = 64, 32
+    D, H, W = dims
+    g = torch.Generator().manual_seed(D * 100 + H * 10 + W)
+    x = torch.randn(N, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    if prologue:
+        sc = torch.rand(N, Cin, generator=g) + 0.5
+        sh = torch.randn(N, Cin, generator=g) * 0.3
+        xin = F.leaky_relu(x * sc[:, :, None, None, None] + sh[:, :, None, None, None], 0.01)
+    else:
+        sc = sh = None
+        xin = F.leaky_relu(x, 0.01)
+    ref = F.conv3d(F.interpolate(xin, scale_factor=2.0, mode="trilinear", align_corners=False), w, b, padding=1)
+    groups = 2
+    gam = torch.rand(Cout, generator=g) + 0.5
+    bet = torch.randn(Cout, generator=g) * 0.2
+    out = torch.full((N, 2 * D, 2 * H, 2 * W, Cout), float("nan")).cuda()
+    gsc = torch.zeros(N, Cout).cuda(); gsh = torch.zeros(N, Cout).cuda()
+    xd, wd, bd, scd, shd, gd, btd = to_cl(x), dev(w), dev(b), dev(sc), dev(sh), dev(gam), dev(bet)
+    _lib.check(ctx.lib.nm_op_conv3d(ctx.handle, _lib.ptr(xd), N, D, H, W, Cin, _lib.ptr(scd), _lib.ptr(shd), 0.01,
+                                    _lib.ptr(wd), _lib.ptr(bd), Cout, 3, 1, 1, _lib.ptr(out), groups, _lib.ptr(gd),
+                                    _lib.ptr(btd), _lib.ptr(gsc), _lib.ptr(gsh), 1), "op_conv3d(up2)")
+    torch.cuda.synchronize()
+    got = from_cl(out, Cout)
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs()
+    inner = err[:, :, 1:-1, 1:-1, 1:-1].max().item() / scale
+    shell = err.clone(); shell[:, :, 1:-1, 1:-1, 1:-1] = 0
+    corners = err[:, :, ::2 * D - 1, ::2 * H - 1, ::2 * W - 1].max().item() / scale
+    print("composite up2 conv: interior %.2e shell %.2e corners %.2e" % (inner, shell.max().item() / scale, corners))
+    assert inner < REL, f"interior rel err {inner:.3e}"
+    assert shell.max().item() / scale < REL, f"shell rel err {shell.max().item() / scale:.3e}"
+    refn = F.group_norm(ref, groups, gam, bet, 1e-5)
+    e = relerr(got * gsc.cpu()[:, :, None, None, None] + gsh.cpu()[:, :, None, None, None], refn)
+    assert e < REL, f"fused GroupNorm rel err {e:.3e}"
+    # the same launch twice: bit-identical (fixed-order partial sums, no atomics)
+    out2 = torch.full_like(out, float("nan")); gsc2 = torch.zeros_like(gsc); gsh2 = torch.zeros_like(gsh)
+    _lib.check(ctx.lib.nm_op_conv3d(ctx.handle, _lib.ptr(xd), N, D, H, W, Cin, _lib.ptr(scd), _lib.ptr(shd), 0.01,
+                                    _lib.ptr(wd), _lib.ptr(bd), Cout, 3, 1, 1, _lib.ptr(out2), groups, _lib.ptr(gd),
+                                    _lib.ptr(btd), _lib.ptr(gsc2), _lib.ptr(gsh2), 1), "op_conv3d(up2)")
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(gsc, gsc2) and torch.equal(gsh, gsh2)
+
+
 @pytest.mark.parametrize("G,Cout,N", [(16, 32, 3), (24, 64, 2), (32, 32, 1)])
 @pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "split16"])
 def test_conv5_occupancy_first_layer(ctx, G, Cout, N, mode):
