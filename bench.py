@@ -34,18 +34,18 @@ F16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense f16/bf16 matri
 
 
 def cpu_baseline(sd, opts, net, dev):
-    """Oracle (kind 'port') on a bounded sample of the same workload: one clip of 64^3 x T=16,
-    full forward (detector + losses + VRNN encode).  The thread count is calibrated first (the
-    path issues thousands of tiny ATen ops per VRNN step, so 'all hardware threads' is far from
-    the fastest setting on a many-core host); `cores` reports the count actually used."""
+    """Oracle (kind 'port') on the bench's own shape (BASELINE config 2: B = 4 clips of 64^3 x T=16, full forward =
+    detector + losses + VRNN encode), bounded to ~30 s of CPU work: as many timed runs as fit (at least one).  The thread
+    count is calibrated first on a 2-frame clip (the path issues thousands of tiny ATen ops per VRNN step, so 'all
+    hardware threads' is far from the fastest setting on a many-core host); `cores` reports the count actually used."""
     from neural_marionette_amd import synth
     from oracle import nm_oracle as O
     ncpu = os.cpu_count() or 1
     default = torch.get_num_threads()
-    nb = 1
+    nb = B_PER_GPU
     vox = synth.figure_clip(nb, T, G, seed=1001)
     eps = synth.make_eps((T, S, nb, opts.nlatent_kypt), seed=1002)
-    small_v, small_e = vox[:, :2].contiguous(), eps[:2].contiguous()
+    small_v, small_e = vox[:1, :2].contiguous(), eps[:2, :, :1].contiguous()
     best_thr, best_t = default, float("inf")
     with torch.no_grad():
         for thr in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)} | {default}):
@@ -60,7 +60,7 @@ def cpu_baseline(sd, opts, net, dev):
         times = []
         t_all = time.perf_counter()
         ref = None
-        while len(times) < 3 and (time.perf_counter() - t_all) < 20.0:
+        while len(times) < 3 and (not times or (time.perf_counter() - t_all) + times[-1] < 32.0):
             t0 = time.perf_counter()
             ref = O.nm_forward(sd, opts, vox, eps)
             times.append(time.perf_counter() - t0)
@@ -73,9 +73,65 @@ def cpu_baseline(sd, opts, net, dev):
     d = (out["keypoints"][..., :3].cpu() - ref["keypoints"][..., :3]).double()
     l2 = d.pow(2).sum(-1).sqrt().max().item()
     return dict(value=nb * T / med, unit="voxel-frames/s", cores=best_thr, kind="port",
-                sample=f"median of {len(times)} x oracle.nm_forward on {nb} clip of 64^3 x T=16 "
+                sample=f"median of {len(times)} x oracle.nm_forward on {nb} clips of 64^3 x T=16 (the bench shape) "
                        f"(detector + losses + VRNN encode), torch {torch.__version__} CPU ops, "
                        f"{best_thr} threads (calibrated; host has {ncpu} hardware threads)"), l2
+
+
+STEP_TFLOP = 99.15e-3 * B_PER_GPU * T          # algorithmic TFLOP of one forward step on one GPU
+
+
+def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
+    """Secondary numbers in the same JSON line, measured AFTER the timed region (the headline is untouched):
+    `fp32_exact` - the same forward with every conv on the exact fp32 MFMA path (the reference's literal arithmetic);
+    `train` - BASELINE configs[2]'s per-GPU shape (64^3, T = 16, B = 4 clips per GPU): detector-mode training step = training
+    forward + backward of the 11 weighted losses + bucketed gradient all-reduce (RCCL when N > 1) + fused Adam, fp32-equivalent."""
+    from neural_marionette_amd.train import DetectorTrainer
+    out = {}
+
+    def timed(fn, warm, steps):
+        for _ in range(warm):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt / steps
+
+    def fwd():
+        with torch.no_grad():
+            return net(vox, acts, eps=eps)
+    net.set_conv_mode("fp32")
+    ms = timed(fwd, 1, 4) * 1e3
+    out["fp32_exact"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=4,
+                             dtype="f32 (v_mfma_f32_32x32x2_f32 for every conv: bit-exact fp32 fma chains)",
+                             frac_of_fp32_mfma_peak=STEP_TFLOP / (ms * 1e-3) / FP32_MFMA_PEAK_TFLOPS)
+    net.set_conv_mode("split16")
+    saved = {k: v.detach().clone() for k, v in net.state_dict().items()}      # the training steps below move the weights
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    net.train()
+    tr = DetectorTrainer(net, lr=4e-4)
+    step = lambda: tr.step(vox, sync=False)
+    ms = timed(step, 2, 5) * 1e3
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    out["train"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=5, warmup=2,
+                        workload="detector-mode training step (train.py:376-412): forward with retained activations + backward of the 11 "
+                                 "AIST-weighted losses + gradient all-reduce (2 bucket chunks) + fused Adam; 64^3, T=16, B=4 clips per GPU",
+                        dtype="f32 storage, conv products as 3x f16-split MFMA (fp32-equivalent)", n_gpus=world,
+                        hbm_gb_taken_by_training=(free0 - free1) / 2 ** 30,
+                        algorithmic_tflop_per_step=3.0 * STEP_TFLOP,
+                        frac_of_f16_mfma_peak=3.0 * STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS)
+    with torch.no_grad():
+        net.load_state_dict(saved)
+    net.eval()
+    return out
 
 
 def main():
@@ -84,6 +140,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (exact-fp32 forward, training step)")
     ap.add_argument("--workload", choices=["forward", "train"], default="forward",
                     help="forward (default, BASELINE configs[1]): full NeuralMarionette.forward; train (configs[2] shape, fp32): one "
                          "detector-mode training step = forward + backward + gradient all-reduce + Adam")
@@ -150,6 +207,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # what each rank saw (the driver can check that RCCL really spanned N devices)
+    ranks_seen = world
+    if dist_on:
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.item())
+
+    extra = {}
+    if args.workload == "forward" and not args.no_extras:
+        extra = extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world)
+
     if rank == 0:
         frames = world * B_PER_GPU * T * args.steps
         # dominant kernel = the conv variant with the largest event-timed total
@@ -165,8 +233,8 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             # HBM bytes per launch of that kernel from the committed PMC passes (separate rocprofv3 --pmc runs)
             traffic = None
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            try:        # (a PMC pass cannot run inside this process: the committed per-kernel figures of this round's passes)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
                 traffic = pm["traffic_bytes_per_launch"].get(name)
             except Exception:
                 pass
@@ -199,6 +267,15 @@ def main():
                         grid=G, T=T, clips_per_gpu=B_PER_GPU, global_clips=world * B_PER_GPU, conv_mode=args.conv_mode,
                         parallelism=f"clip-sharded x{world} (no data-path collective)"),
             roofline=roof, cpu_baseline=cpu, kypt_l2_vs_cpu=l2,
+            step_roofline=dict(algorithmic_tflop_per_step=STEP_TFLOP, achieved=STEP_TFLOP * world / (dt / args.steps),
+                               unit="TFLOP/s", peak=F16_MFMA_PEAK_TFLOPS * world if eng.conv_mode == 1 else FP32_MFMA_PEAK_TFLOPS * world,
+                               frac=STEP_TFLOP / (dt / args.steps) / (F16_MFMA_PEAK_TFLOPS if eng.conv_mode == 1 else FP32_MFMA_PEAK_TFLOPS),
+                               note="whole forward step: 99.15 GFLOP per voxel-frame (BASELINE.md, the reference's dense fp32 conv "
+                                    "arithmetic) x 64 frames; the split-fp16 kernels issue 3 f16 MFMA products per algorithmic product"
+                               ) if args.workload == "forward" else None,
+            distributed=dict(world_size=world, ranks_seen_by_allreduce=ranks_seen, backend=(dist.get_backend() if dist_on else None),
+                             device_count=torch.cuda.device_count(), device=torch.cuda.get_device_name(dev)),
+            **extra,
         )
         print(json.dumps(line), flush=True)
     if dist_on:

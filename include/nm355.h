@@ -34,6 +34,7 @@ extern "C" {
 #define NM_ERR_HIP (-2)
 #define NM_ERR_STATE (-3)
 #define NM_ERR_UNSUPPORTED (-4)
+#define NM_ERR_RANGE (-5)       /* non-finite conv results (operand beyond the split-fp16 range, or non-finite input) */
 
 typedef struct nm_ctx nm_ctx;
 
@@ -67,6 +68,15 @@ int nm_ctx_destroy(nm_ctx* ctx);
  * at a time; when the handle changes, the new stream is made to wait (event) for everything the ctx queued on the old one
  * and on its own side stream, so ctx-owned weights / workspaces are never overwritten under a running kernel. */
 int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream);
+/* Range / finiteness status.  The default conv arithmetic splits every fp32 operand into two fp16 halves (fp32-equivalent
+ * products); an activation of magnitude >= 65520 has no fp16 representation and turns the product into inf / NaN where the
+ * reference's fp32 arithmetic (torch CPU ops under kypt_detector.py:81-169) stays finite.  The reference's networks never come
+ * near that range (every conv input is a GroupNorm output, an occupancy or a Gaussian map), so the guard is a status word, not a
+ * per-launch test: the GroupNorm finalisation of every conv ORs 1 into a ctx-owned device word when the conv's statistics are not
+ * finite.  nm_ctx_check_nonfinite synchronises the ctx stream, returns NM_ERR_RANGE (and clears the word) if that happened since
+ * the last check, 0 otherwise; the remedy is nm_set_conv_mode(ctx, 0) (exact fp32 MFMA, no range limit).  The op-level entry
+ * point nm_op_conv3d is synchronous about it: it scans its result and re-runs the launch on the fp32 path by itself. */
+int nm_ctx_check_nonfinite(nm_ctx* ctx);
 /* Replaces NeuralMarionette.load_state_dict / .cuda() for the HIP path: copies every
  * tensor and re-packs conv weights into the MFMA layout.  Must be called again after an
  * optimizer step.  All 337 keys of the reference state_dict are required.  Asynchronous on the ctx
@@ -181,6 +191,11 @@ int nm_detector_forward_train(nm_ctx* ctx, const float* vox, int32_t B, int32_t 
                               float* keypoints, float* heatmaps, float* first_feature, float* recon,
                               float* affinity, float* losses11);
 int nm_detector_backward(nm_ctx* ctx, const float* dlosses11, const nm_named_grad* grads, int32_t count);
+/* Optional hook for overlapping the gradient all-reduce (train.py:404 `loss.backward()` followed by the optimizer step; here one
+ * collective per bucket chunk): a caller-owned hipEvent_t that the next nm_detector_backward calls record on the ctx stream once
+ * every kypt_detector.kypt_to_vox.* gradient has been written - the decoder's parameters come first in the backward order, the
+ * heads and both feature nets follow.  NULL removes the hook. */
+int nm_ctx_set_backward_event(nm_ctx* ctx, void* hip_event);
 
 /* HSVRNNBVH.generate — model/hsvrnn_bvh.py:158-234.
  *  keypoints_cond (B,Tcond,K,4); eps_post (Tcond,S,B,Z); eps_prior (Ttot-Tcond,B,Z);

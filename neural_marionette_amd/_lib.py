@@ -43,6 +43,7 @@ SIGNATURES = {
     "nm_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NmConfig)]),
     "nm_ctx_destroy": (C.c_int, [C.c_void_p]),
     "nm_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nm_ctx_check_nonfinite": (C.c_int, [C.c_void_p]),
     "nm_ctx_set_weights": (C.c_int, [C.c_void_p, C.POINTER(NmNamedTensor), _I]),
     "nm_workspace_bytes": (C.c_size_t, [C.c_void_p, _I, _I]),
     "nm_detector_forward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "nm_ctx_set_training": (C.c_int, [C.c_void_p, _I]),
     "nm_detector_forward_train": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "nm_detector_backward": (C.c_int, [C.c_void_p, _P, C.POINTER(NmNamedTensor), _I]),
+    "nm_ctx_set_backward_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nm_adam_step_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_int64), _I, _I, _F, _F, _F, _F]),
     "nm_vrnn_generate": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),

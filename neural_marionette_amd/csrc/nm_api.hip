@@ -76,6 +76,11 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
     }
     nm_ctx* c = new nm_ctx();
     c->cfg = *cfg;
+    if (hipMalloc(reinterpret_cast<void**>(&c->nf_flag), sizeof(unsigned)) != hipSuccess || hipMemset(c->nf_flag, 0, sizeof(unsigned)) != hipSuccess) {
+        nm_set_error("ctx_create: could not allocate the status word");
+        delete c;
+        return NM_ERR_HIP;
+    }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_clip, hipEventDisableTiming) != hipSuccess ||
@@ -98,6 +103,7 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     if (ctx->ws2.base) (void)hipFree(ctx->ws2.base);
     if (ctx->ws_t.base) (void)hipFree(ctx->ws_t.base);
     if (ctx->copy_table) (void)hipFree(ctx->copy_table);
+    if (ctx->nf_flag) (void)hipFree(ctx->nf_flag);
     nm_net_free_tape(ctx);
     nm_vrnn_free_tape(ctx);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -122,6 +128,22 @@ int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) {
     ctx->stream = ns;
     ctx->stream_bound = true;
     return NM_OK;
+}
+
+int nm_ctx_check_nonfinite(nm_ctx* ctx) {
+    if (!ctx) { nm_set_error("check_nonfinite: null ctx"); return NM_ERR_ARG; }
+    (void)hipSetDevice(ctx->cfg.device);
+    unsigned v = 0;
+    int rc = nm_check_hip(hipStreamSynchronize(ctx->stream), "check_nonfinite: sync");
+    if (!rc) rc = nm_check_hip(hipMemcpy(&v, ctx->nf_flag, sizeof(v), hipMemcpyDeviceToHost), "check_nonfinite: read");
+    if (rc) return rc;
+    if (!v) return NM_OK;
+    (void)hipMemset(ctx->nf_flag, 0, sizeof(unsigned));
+    nm_set_error("a convolution produced non-finite values since the last check: %s", nm_conv_get_mode() != 0
+                 ? "in the split-fp16 conv mode an activation beyond the fp16 range (|x| >= 65520) or a non-finite input does that - "
+                   "set conv mode 'fp32' (exact fp32 MFMA, no range limit) and run again"
+                 : "the input or the weights hold inf / NaN (exact fp32 mode has no range limit of its own)");
+    return NM_ERR_RANGE;
 }
 
 int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count) {
@@ -188,6 +210,7 @@ static TensorRef make_ref(const float* p, const float* sc, const float* sh, floa
 
 static int finish_gn(nm_ctx* ctx, const float* part, int N, int nblk, int C, int groups, double count,
                      const float* gamma, const float* beta, float* scale, float* shift) {
+    nm_elem_set_nonfinite_flag(nullptr);           // (op-level entry points check their results themselves)
     return nm_launch_gn_finalize(part, N, nblk, C, groups, count, gamma, beta, 1e-5f, scale, shift, ctx->stream);
 }
 
@@ -225,8 +248,27 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     TensorRef t = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad);
     rc = nm_launch_conv(t, wp, bias, out, g, part, ctx->stream, Cin, wp16);
     if (rc) return rc;
+    int nblk_used = nblk;
+    if (nm_conv_get_mode() != 0) {
+        // op-level calls are synchronous about the fp16 range: operands beyond it make the split product inf / NaN where fp32 is
+        // finite - scan the result and, if that happened, run the launch again on the exact fp32 MFMA path
+        const int mode = nm_conv_get_mode();
+        unsigned v = 0;
+        if ((rc = nm_launch_nonfinite_scan(out, (size_t)N * g.OD * g.OH * g.OW * Cout, ctx->nf_flag, ctx->stream))) return rc;
+        if ((rc = nm_check_hip(hipStreamSynchronize(ctx->stream), "op_conv3d: sync"))) return rc;
+        if ((rc = nm_check_hip(hipMemcpy(&v, ctx->nf_flag, sizeof(v), hipMemcpyDeviceToHost), "op_conv3d: status"))) return rc;
+        if (v) {
+            (void)hipMemset(ctx->nf_flag, 0, sizeof(unsigned));
+            nm_conv_set_mode(0);
+            ConvGeom g32 = g; g32.up2c = nullptr;
+            nblk_used = nm_conv_blocks_per_frame(g32, Cin_pad);      // (the fp32 kernel's own partial-block layout; never more blocks than sized for)
+            rc = nm_launch_conv(t, wp, bias, out, g32, part, ctx->stream, Cin, nullptr);
+            nm_conv_set_mode(mode);
+            if (rc) return rc;
+        }
+    }
     if (gn_groups > 0)
-        rc = finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)g.OD * g.OH * g.OW * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
+        rc = finish_gn(ctx, part, N, nblk_used, Cout, gn_groups, (double)g.OD * g.OH * g.OW * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
     return rc;
 }
 

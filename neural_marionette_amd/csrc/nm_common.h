@@ -17,6 +17,7 @@
 #define NM_ERR_HIP (-2)
 #define NM_ERR_STATE (-3)
 #define NM_ERR_UNSUPPORTED (-4)
+#define NM_ERR_RANGE (-5)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -70,6 +71,9 @@ void nm_conv_prof_reset();
 int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count,
                           const float* gamma, const float* beta, float eps, float* scale,
                           float* shift, hipStream_t s);
+// sticky device word (ctx-owned) that gn_finalize ORs a 1 into when a conv's statistics are not finite; null: no reporting
+void nm_elem_set_nonfinite_flag(unsigned* flag);
+int nm_launch_nonfinite_scan(const float* x, size_t n, unsigned* flag, hipStream_t s);
 // partial sums of an already materialised raw tensor (producers without a stats epilogue)
 int nm_stats_blocks_per_frame(int voxels);
 int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part, hipStream_t s);

@@ -82,6 +82,8 @@ struct nm_ctx {
     bool stream_bound = false;             // nm_ctx_set_stream has been called (nullptr = the legacy default stream is a valid choice)
     hipStream_t stream2 = nullptr;         // ctx-owned side stream: clip-mean net / VRNN run beside the frame stack
     hipEvent_t ev_fork = nullptr, ev_clip = nullptr, ev_kp = nullptr, ev_side = nullptr;
+    hipEvent_t ev_user_decoder = nullptr;  // caller's event, recorded by nm_detector_backward once the decoder's gradients are complete
+    unsigned* nf_flag = nullptr;           // sticky: 1 = a conv produced non-finite values (nm_ctx_check_nonfinite reads and clears it)
     Arena ws;                              // activations / scratch, reset per call
     Arena ws2;                             // scratch of work issued on stream2 (VRNN beside the decoder)
     std::vector<void*> owned;              // weight allocations

@@ -28,32 +28,44 @@ __device__ __forceinline__ f32x4 load_t(const TensorRef& t, size_t n, size_t vox
     return v;
 }
 
-// one block per (frame, group)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups,
-                                                          double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double sh_s[256], sh_ss[256];
+// one block per (frame, group): 1024 threads walk the (block, channel) partials (float2 loads, four independent chains per
+// thread), fp64 sums combined in a fixed order (run-to-run identical)
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups,
+                                                           double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           unsigned* __restrict__ nonfinite) {
+    __shared__ double sh_s[1024], sh_ss[1024];
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
-    double s = 0.0, ss = 0.0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
     const int total = nblk * cpg;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        int blk = i / cpg, c = g * cpg + i % cpg;
-        const float* q = part + (((size_t)n * nblk + blk) * C + c) * 2;
-        s += (double)q[0]; ss += (double)q[1];
+    const float* base = part + (size_t)n * nblk * C * 2;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4096) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024;
+            if (i < total) {
+                const int blk = i / cpg, c = g * cpg + i % cpg;
+                const float2 q = *reinterpret_cast<const float2*>(base + ((size_t)blk * C + c) * 2);
+                s[u] += (double)q.x; ss[u] += (double)q.y;
+            }
+        }
     }
-    sh_s[threadIdx.x] = s; sh_ss[threadIdx.x] = ss;
+    sh_s[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]); sh_ss[threadIdx.x] = (ss[0] + ss[1]) + (ss[2] + ss[3]);
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) { sh_s[threadIdx.x] += sh_s[threadIdx.x + st]; sh_ss[threadIdx.x] += sh_ss[threadIdx.x + st]; }
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { sh_s[threadIdx.x] += sh_s[threadIdx.x + st]; sh_ss[threadIdx.x] += sh_ss[threadIdx.x + st]; }
         __syncthreads();
     }
     const double mean = sh_s[0] / count;
     double var = sh_ss[0] / count - mean * mean;
+    // a non-finite sum means the conv produced inf / NaN: in the split-fp16 mode that is what an operand beyond the fp16 range
+    // (|x| >= 65520) turns into, where the reference's fp32 arithmetic stays finite - reported through the ctx's sticky flag
+    if (nonfinite && threadIdx.x == 0 && !(isfinite(sh_s[0]) && isfinite(sh_ss[0]))) atomicOr(nonfinite, 1u);
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    if (threadIdx.x < cpg) {
+    if ((int)threadIdx.x < cpg) {
         int c = g * cpg + threadIdx.x;
         float sc = (float)rstd * gamma[c];
         scale[(size_t)n * C + c] = sc;
@@ -365,10 +377,23 @@ int grid_for(size_t work_items) { return (int)min((work_items + 255) / 256, (siz
 
 }  // namespace
 
+static unsigned* g_nonfinite_flag = nullptr;
+void nm_elem_set_nonfinite_flag(unsigned* flag) { g_nonfinite_flag = flag; }
+
+__global__ __launch_bounds__(256) void nonfinite_scan_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ flag) {
+    bool bad = false;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) bad |= !isfinite(x[i]);
+    if (bad) atomicOr(flag, 1u);
+}
+int nm_launch_nonfinite_scan(const float* x, size_t n, unsigned* flag, hipStream_t s) {
+    hipLaunchKernelGGL(nonfinite_scan_kernel, dim3((unsigned)min((n + 255) / 256, (size_t)4096)), dim3(256), 0, s, x, n, flag);
+    return nm_check_hip(hipGetLastError(), "nonfinite_scan launch");
+}
+
 int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count, const float* gamma,
                           const float* beta, float eps, float* scale, float* shift, hipStream_t s) {
     if (groups <= 0 || C % groups != 0 || C / groups > 256) { nm_set_error("gn_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(1024), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag);
     return nm_check_hip(hipGetLastError(), "gn_finalize launch");
 }
 

@@ -791,6 +791,8 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         if (b.live()) {
             b.run(nm_check_hip(hipMemsetAsync(dfeat, 0, (size_t)F * g3 * FEAT * sizeof(float), b.s), "backward: memset"));
             b.run(nm_launch_combined_bwd(dcomb, d.adjust.csel, t.table, t.keypoints, B, T, K, FEAT, g, (float)width_d, gws, dfeat, dkp, b.s));
+            // every kypt_to_vox.* gradient is complete: the caller's collective for that bucket chunk may start behind this event
+            if (c->ev_user_decoder) b.run(nm_check_hip(hipEventRecord(c->ev_user_decoder, b.s), "backward: decoder-done event"));
         }
         b.ws.release(m);
     }
@@ -868,6 +870,7 @@ int with_workspace(nm_ctx* c, Fn&& graph) {
 int check_ready(nm_ctx* c, const char* who) {
     if (!c) { nm_set_error("%s: null ctx", who); return NM_ERR_ARG; }
     if (!c->has_weights) { nm_set_error("%s: nm_ctx_set_weights has not been called", who); return NM_ERR_STATE; }
+    nm_elem_set_nonfinite_flag(c->nf_flag);        // GroupNorm finalisation reports non-finite conv statistics into this ctx's status word
     return nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
 }
 
@@ -1042,6 +1045,12 @@ int nm_detector_backward(nm_ctx* c, const float* dlosses11, const nm_named_grad*
     std::swap(c->ws, c->ws_t);
     t.valid = false;
     return rc;
+}
+
+int nm_ctx_set_backward_event(nm_ctx* c, void* hip_event) {
+    if (!c) { nm_set_error("set_backward_event: null ctx"); return NM_ERR_ARG; }
+    c->ev_user_decoder = static_cast<hipEvent_t>(hip_event);
+    return NM_OK;
 }
 
 int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, double scale, float* vox, int32_t* idx_out) {

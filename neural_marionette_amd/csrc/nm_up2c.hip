@@ -15,8 +15,8 @@
 // Machine mapping: one 512-thread workgroup per CU, wave w = parity class (pz,py,px) = bits of w, 4 MFMA row tiles per wave
 // (2z x 8y x 8x coarse cells = 128 rows x 32 output channels), v_mfma_f32_32x32x16_f16 with the 3-product hi/lo split of
 // nm_conv.hip (fp32-equivalent products, fp32 accumulate).  Each wave streams ITS parity's weights from L2 (2 KB per k-step for
-// 12 MFMAs, prefetched two k-steps ahead); a row tile is 8(x) x 2(z) x 2(y) cells so that the 16-lane groups of a ds_read_b128 hit
-// 16 distinct 16-byte slots (z-plane pitch = 8 mod 16 slots).
+// 12 MFMAs, prefetched two k-steps ahead); a row tile is 8(x) x 2(z) x 2(y) cells, dealt to the lanes so that each lane group of a
+// ds_read_b128 hits 16 distinct 16-byte slots (z-plane pitch = 8 mod 16 slots).
 //
 // Volume border.  The coarse tile is staged with clamped indices, which reproduces torch's clamped interpolation for every fine
 // position INSIDE the volume.  The fine convolution, however, zero-pads: taps that leave the fine volume must contribute nothing,
@@ -30,6 +30,14 @@
 
 namespace {
 
+#ifndef UP2C_SCHED
+#define UP2C_SCHED 1
+#endif
+#if UP2C_SCHED
+#define UP2C_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define UP2C_SB() do {} while (0)
+#endif
 #define UP2C_SPLIT_SCALE 2048.0f          // same hi/lo split as nm_conv.hip: v = hi + lo * 2^-11
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -41,7 +49,7 @@ constexpr int ZP = 104;                               // z-plane pitch in 16-byt
 constexpr int HVP = HZ * ZP + 1;                      // slots per (chunk, hi|lo, lane half) plane; odd: staging writes spread over the banks
 constexpr int CG = 32;                                // input channels per LDS buffer (two buffers: one read by the MFMAs, one being staged)
 constexpr int NPLANES = CG / 16 * 4;
-constexpr size_t LDS_BYTES = (size_t)2 * NPLANES * HVP * 16;
+constexpr size_t LDS_BYTES = (size_t)2 * NPLANES * HVP * 16 + 2 * CG * sizeof(float);      // + the next tile's GroupNorm scale / shift
 
 struct Up2cParams {
     const float* in; const float* in_scale; const float* in_shift; float in_slope;
@@ -51,7 +59,7 @@ struct Up2cParams {
     int Cout, Co_pad;
     int nbz, nby, nbx;           // bricks per frame
     int nblk;                    // partial blocks per frame (bricks + shell items)
-    int diag;                    // NM355_UP2C_DIAG (timing experiments only): 1 no output stores, 2 no staging, 4 no shell launch, 8 no MFMA loop
+    int diag;                    // NM355_UP2C_DIAG (timing experiments only): 1 (unused), 2 no staging, 4 no shell launch, 8 no MFMA loop, 16 weights from one address, 32 no barriers
 };
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -165,6 +173,7 @@ struct StepPos { int n, br, nh, cg, cz0, cy0, cx0; };
 __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
     extern __shared__ f32x4 lds_raw[];
     half8* tile = reinterpret_cast<half8*>(lds_raw);               // [buffer][chunk*4 + hl*2 + h][HVP] x 16 B, slot = hz*ZP + hy*HX + hx
+    float* aff = reinterpret_cast<float*>(tile + 2 * NPLANES * HVP); // scale[CG], shift[CG] of the tile being staged (kept out of the registers)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
@@ -175,10 +184,14 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
     const unsigned wlane = (unsigned)(h * (int)plane + l31) * 16u;                  // per-lane byte offset of every weight load
     const size_t kbytes = kstride * 16, lobytes = 2 * plane * 16;
     const int OD = 2 * p.ID, OH = 2 * p.IH, OW = 2 * p.IW;
-    // A rows of this lane: tile j covers y in {2j, 2j+1}; row l31 = x + 8 * zbit + 16 * ybit  (16-byte slots, lane half's plane included)
+    // A rows of this lane (16-byte slots, lane half's plane included): tile j covers y in {2j, 2j+1}.  A ds_read_b128 is served in
+    // the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (quads {0,3,5,6} / {1,2,4,7} of a lane half): a group's four quads are
+    // the four (x half, z) combinations of ONE y, i.e. slot bases 0, 4, 8, 12 (+10 for the other y) mod 16 - conflict-free.
+    //   row l31:  x = 4 * bit3 + (l31 & 3),  z = bit4,  y = 2j + ((0x96 >> (l31 >> 2)) & 1)
     int arow[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) arow[j] = h * HVP + ((l31 >> 3) & 1) * ZP + (2 * j + (l31 >> 4)) * HX + (l31 & 7);
+    for (int j = 0; j < 4; ++j)
+        arow[j] = h * HVP + ((l31 >> 4) & 1) * ZP + (2 * j + ((0x96 >> (l31 >> 2)) & 1)) * HX + 4 * ((l31 >> 3) & 1) + (l31 & 3);
     // staging role: channel octet tid & 3 of the 32-channel group, tile voxels tid/4 + 128 k
     const int s_oct = tid & 3;
     const int s_plane = (s_oct >> 1) * 4 + (s_oct & 1);
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
                 const int ks = c * 27 + t, s = ks % 3, s2 = (ks + 2) % 3;
                 if (ks + 2 < KS) { bh[s2] = ldw(wk, 2 * kbytes); bl[s2] = ldw(wk, 2 * kbytes + lobytes); }
                 else { bh[s2] = ldw(wnext, (size_t)(ks + 2 - KS) * kbytes); bl[s2] = ldw(wnext, (size_t)(ks + 2 - KS) * kbytes + lobytes); }
-                wk += kbytes;
+                if (!(p.diag & 16)) wk += kbytes;
                 // staging pieces of the next tile: item i loaded at k-step 1 + 13 i, written at 11 + 13 i
                 if (stage) {
 #pragma unroll
@@ -285,11 +298,11 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
                         if (ks == 11 + 13 * i) commit(nb, i);
                     }
                 }
-                if (have_next && (ks == 10 || ks == 51)) lds_barrier();
-                __builtin_amdgcn_sched_barrier(0);
+                if (have_next && (ks == 10 || ks == 51) && !(p.diag & 32)) lds_barrier();
+                UP2C_SB();
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh[s], acc[j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                UP2C_SB();
                 // A operands of the next k-step (after the last one: tap 0 of the other buffer)
                 const half8* xb = (ks == KS - 1) ? nb : tb;
                 const int nof = (ks == KS - 1) ? 0 : ((t < 26) ? c * 4 * HVP + tap_off((t + 1) % 27) : (c + 1) * 4 * HVP);
@@ -297,20 +310,21 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
                 for (int j = 0; j < 4; ++j) {
                     accl[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl[s], accl[j], 0, 0, 0);
                     ah[j] = xb[arow[j] + nof];
-                    __builtin_amdgcn_sched_barrier(0);
+                    UP2C_SB();
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     accl[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh[s], accl[j], 0, 0, 0);
                     al[j] = xb[arow[j] + 2 * HVP + nof];
-                    __builtin_amdgcn_sched_barrier(0);
+                    UP2C_SB();
                 }
             }
         }
         }
         wk = wnext;
         if (cs.cg == NCG - 1) {
-            // ---- epilogue of this 32-channel group: bias, store, GroupNorm partials without the shell (one slot per wave) ----
+            // ---- epilogue of this 32-channel group: bias, store, GroupNorm partials
+            // without the shell (one slot per wave)
             const int co = cs.nh * 32 + l31;
             const float bv = p.bias ? p.bias[co] : 0.f;
             float s = 0.f, ss = 0.f;
@@ -319,17 +333,28 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float* base = p.out + ((((size_t)cs.n * OD + 2 * cs.cz0 + pz) * OH + 2 * (cs.cy0 + 2 * j) + py) * OW + 2 * cs.cx0 + px) * sX + co;
+                if (!border_brick) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int x = (r & 3) + 4 * h, zb = (r >> 2) & 1, yb = (r >> 3) & 1;
-                    const float v = (acc[j][r] + accl[j][r] * (1.0f / UP2C_SPLIT_SCALE)) + bv;
-                    if (!(p.diag & 1)) base[(size_t)(2 * zb) * sZ + (size_t)(2 * yb) * sY + (size_t)(2 * x) * sX] = v;
-                    bool shell = false;
-                    if (border_brick) {
-                        const int oz = 2 * (cs.cz0 + zb) + pz, oy = 2 * (cs.cy0 + 2 * j + yb) + py, ox = 2 * (cs.cx0 + x) + px;
-                        shell = oz == 0 || oz == OD - 1 || oy == 0 || oy == OH - 1 || ox == 0 || ox == OW - 1;
+                    for (int r = 0; r < 16; ++r) {
+                        // register r of lane half h is row (r & 3) + 4 h + 8 (r >> 2) of the tile (see arow)
+                        const int x = 4 * ((r >> 2) & 1) + (r & 3), zb = (r >> 3) & 1, yb = (0x96 >> (h + 2 * (r >> 2))) & 1;
+                        const float v = __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r]) + bv;
+                        base[(size_t)(2 * zb) * sZ + (size_t)(2 * yb) * sY + (size_t)(2 * x) * sX] = v;
+                        s += v; ss = __builtin_fmaf(v, v, ss);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (!shell) { s += v; ss += v * v; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int x = 4 * ((r >> 2) & 1) + (r & 3), zb = (r >> 3) & 1, yb = (0x96 >> (h + 2 * (r >> 2))) & 1;
+                        const float v = __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r]) + bv;
+                        base[(size_t)(2 * zb) * sZ + (size_t)(2 * yb) * sY + (size_t)(2 * x) * sX] = v;
+                        const int oz = 2 * (cs.cz0 + zb) + pz, oy = 2 * (cs.cy0 + 2 * j + yb) + py, ox = 2 * (cs.cx0 + x) + px;
+                        const bool shell = oz == 0 || oz == OD - 1 || oy == 0 || oy == OH - 1 || ox == 0 || ox == OW - 1;
+                        const float mv = shell ? 0.f : v;
+                        s += mv; ss = __builtin_fmaf(mv, mv, ss);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             if (p.part) {
@@ -376,19 +401,20 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_face_kernel(Up2cParams p, in
     const int C16 = p.Cin >> 4, NH = p.Cout >> 5;
     const bool affine = p.in_scale != nullptr;
     // ---- stage 3 lines x 34 voxels x Cin channels ----
-    const int noct = p.Cin >> 3, nitems = 3 * 34 * noct;
+    const int noct = p.Cin >> 3, nitems = 3 * 34 * noct;             // (noct divides 256: a thread's channel octet is fixed)
+    f32x4 sca = {0.f, 0.f, 0.f, 0.f}, sha = sca, scb = sca, shb = sca;
+    if (affine) {
+        const int oct = tid % noct;
+        const float* ps = p.in_scale + (size_t)n * p.Cin + oct * 8; const float* ph = p.in_shift + (size_t)n * p.Cin + oct * 8;
+        sca = *reinterpret_cast<const f32x4*>(ps); scb = *reinterpret_cast<const f32x4*>(ps + 4);
+        sha = *reinterpret_cast<const f32x4*>(ph); shb = *reinterpret_cast<const f32x4*>(ph + 4);
+    }
     for (int i = tid; i < nitems; i += 256) {
         const int oct = i % noct, v = i / noct, s = v % 34, a = v / 34;
         const int ca = min(max(f + a - 1, 0), AC - 1), cl = min(max(tl * 32 - 1 + s, 0), LA - 1);
         const int gz = type == 2 ? fb : ca, gy = type == 0 ? cl : (type == 1 ? fb : ca), gx = type == 0 ? fb : cl;
         const float* src = p.in + ((((size_t)n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + oct * 8;
         f32x4 va = *reinterpret_cast<const f32x4*>(src), vb = *reinterpret_cast<const f32x4*>(src + 4);
-        f32x4 sca = {0.f, 0.f, 0.f, 0.f}, sha = sca, scb = sca, shb = sca;
-        if (affine) {
-            const float* ps = p.in_scale + (size_t)n * p.Cin + oct * 8; const float* ph = p.in_shift + (size_t)n * p.Cin + oct * 8;
-            sca = *reinterpret_cast<const f32x4*>(ps); scb = *reinterpret_cast<const f32x4*>(ps + 4);
-            sha = *reinterpret_cast<const f32x4*>(ph); shb = *reinterpret_cast<const f32x4*>(ph + 4);
-        }
         half8 hi, lo;
         split8(act4(va, sca, sha, affine, p.in_slope), act4(vb, scb, shb, affine, p.in_slope), hi, lo);
         const int pl = (oct >> 1) * 4 + (oct & 1);

@@ -536,6 +536,14 @@ class NeuralMarionette(nn.Module):
             raise ValueError("conv mode must be 'split16' or 'fp32'")
         self._engine.conv_mode = 1 if mode == "split16" else 0
 
+    def check_finite(self) -> None:
+        """Synchronises and raises NmError if a convolution has produced non-finite values since the last check - in the default
+        'split16' conv mode that is what an activation beyond the fp16 range (|x| >= 65520) turns into, where the reference's
+        fp32 arithmetic stays finite; ``set_conv_mode('fp32')`` has no such limit (nm_ctx_check_nonfinite)."""
+        eng = self._engine
+        eng.ready()
+        eng.call("nm_ctx_check_nonfinite")
+
     def voxelize(self, points, scale: float = 1.0, return_indices: bool = False):
         """Device version of the reference's input path (utils/dataset_utils.py:9-31 as used by
         dataset/dataset.py:70-86 and vis_generation.py:14-25): per-episode bbox normalisation + occupancy
@@ -588,11 +596,12 @@ class NeuralMarionette(nn.Module):
         return dict(keypoints_cond=cond_k, keypoints_gen=gen_k, voxels=(vox >= 0.5).float(), voxels_raw=vox)
 
     @torch.no_grad()
-    def sample_interpolation(self, target_voxel, sample_rate=10, sample_num=10000, eps_a=None, eps_b=None):
+    def sample_interpolation(self, target_voxel, sample_rate=10, sample_num=10000, eps_a=None, eps_b=None, force_picks=None):
         """vis_interpolation.py:80-143: key frames every ``sample_rate`` steps (and the last one) are matched with a
         posterior sample, the frames in between come from the prior trajectory (out of ``sample_num``) that lands
         nearest the next key frame.  eps_a (T,sample_num,Z): the step's first draw (posterior at key frames, prior
         otherwise); eps_b (T,sample_num,Z): the second (prior, 'for choosing') draw at key frames.
+        ``force_picks`` (list of (i1, i2) per key frame) replaces the two nearest-row selections (teacher forcing in tests).
         Returns keypoints (1,T,K,4), voxels (T,1,G,G,G) binarised at 0.5, and the selected row per key frame."""
         d = self.dyna_module
         S, K, Z = int(sample_num), d.nkeypoints, d.nlatent_kypt
@@ -612,8 +621,11 @@ class NeuralMarionette(nn.Module):
                 obs_rows = obs.expand(S, -1).contiguous()
                 kp_post, z_post, _ = d.step(h, off, ea[t][None], keypoints_obs=obs_rows, SAMPLE_NUM=1, update_state=False)
                 kp_pri, _, _ = d.step(h, off, eb[t], update_state=False)
-                i1 = d.nearest_row(kp_post, obs)
-                i2 = d.nearest_row(kp_pri, kp_post[i1])
+                if force_picks is None:
+                    i1 = d.nearest_row(kp_post, obs)
+                    i2 = d.nearest_row(kp_pri, kp_post[i1])
+                else:
+                    i1, i2 = (int(v) for v in force_picks[len(picks)])
                 pending.append(obs_rows)
                 selected += [s[i2].view(K, 4) for s in pending]
                 pending = []

@@ -33,7 +33,8 @@ LEARNER_LOSS_WEIGHTS = {"kypt_recon_loss": 1.0, "kl_kypt": 0.003}
 
 
 def allreduce_mean_(tensors, world: Optional[int] = None) -> None:
-    """Average a list of gradient tensors across ranks through one flat bucket (in place)."""
+    """Average a list of gradient tensors across ranks through one flat bucket (in place).  Generic helper (copies in and out);
+    the trainers below keep their gradients IN a persistent bucket (GradBucket) and skip both copies."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     world = world or dist.get_world_size()
@@ -45,6 +46,63 @@ def allreduce_mean_(tensors, world: Optional[int] = None) -> None:
         n = t.numel()
         t.copy_(flat[off:off + n].view_as(t))
         off += n
+
+
+class GradBucket:
+    """One pre-allocated flat gradient buffer; every parameter's gradient is a view into it, so the backward kernels write
+    straight into the buffer the collective reduces (no torch.cat, no copy back).  ``chunks`` are contiguous element ranges
+    in the order the backward pass completes them: a chunk's all-reduce (RCCL over xGMI: ``torch.distributed`` backend
+    'nccl'; gloo in the CPU tests) is issued on a side stream as soon as its gradients exist and overlaps the rest of the
+    backward pass.  One process per GPU, sum then 1/world."""
+
+    def __init__(self, named_params, chunk_of, nchunks: int):
+        """named_params: [(name, parameter)]; chunk_of(name) -> chunk index in completion order."""
+        order = sorted(range(len(named_params)), key=lambda i: (chunk_of(named_params[i][0]), i))
+        dev, total = named_params[0][1].device, sum(p.numel() for _, p in named_params)
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.views, self.chunks = {}, []
+        off, cur, start = 0, 0, 0
+        for i in order:
+            name, p = named_params[i]
+            ch = chunk_of(name)
+            while cur < ch:
+                self.chunks.append((start, off)); start = off; cur += 1
+            self.views[name] = self.flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        while cur < nchunks:
+            self.chunks.append((start, off)); start = off; cur += 1
+        self.comm_stream = torch.cuda.Stream(dev) if self.flat.is_cuda else None
+        self._pending = []
+
+    def chunk(self, i) -> torch.Tensor:
+        a, b = self.chunks[i]
+        return self.flat[a:b]
+
+    def reduce_chunk(self, i, after_event=None) -> None:
+        """Start the all-reduce of chunk i (asynchronous; on the GPU: on the bucket's side stream, behind ``after_event`` or
+        behind everything queued on the current stream so far)."""
+        if not dist.is_initialized() or dist.get_world_size() == 1 or self.chunks[i][0] == self.chunks[i][1]:
+            return
+        if self.comm_stream is None:
+            self._pending.append(dist.all_reduce(self.chunk(i), op=dist.ReduceOp.SUM, async_op=True))
+            return
+        if after_event is not None:
+            self.comm_stream.wait_event(after_event)
+        else:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self.comm_stream):
+            self._pending.append(dist.all_reduce(self.chunk(i), op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> None:
+        """Wait for the started collectives (stream-ordered on the GPU) and turn the sums into means."""
+        if not self._pending:
+            return
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
+        self.flat.mul_(1.0 / dist.get_world_size())
 
 
 def adam_step_(eng, params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps) -> None:
@@ -103,45 +161,101 @@ DETECTOR_LOSS_WEIGHTS = {"recon_loss": 100.0, "sparsity_loss": 5.0, "separation_
 
 class DetectorTrainer:
     """One step of train.py:376-412 in detector mode: log = network(voxel, {'detector': True, 'learner': False});
-    loss = sum_k weight[k] * log[k]; loss.backward(); Adam(lr 4e-4).  `nepoch` drives KyptDetector.anneal (affinity start)."""
+    loss = sum_k weight[k] * log[k]; loss.backward(); Adam(lr 4e-4).  `nepoch` drives KyptDetector.anneal (affinity start).
+
+    The step calls the library's training forward / backward directly (same kernels as the autograd bridge of
+    KyptDetector.forward) with the gradients landing in a GradBucket: chunk 0 = the decoder's parameters
+    (kypt_detector.kypt_to_vox.*, complete when the decoder's backward is - the library records an event there), chunk 1 = the
+    rest; chunk 0's all-reduce runs beside the backward of the heads and both feature nets."""
 
     def __init__(self, net, lr: float = 4e-4, weights: Optional[Dict[str, float]] = None, betas=(0.9, 0.999), eps: float = 1e-8):
+        from .spec import DETECTOR_LOSS_KEYS
         self.net = net
         self.lr, self.betas, self.eps = lr, betas, eps
         self.weights = dict(DETECTOR_LOSS_WEIGHTS if weights is None else weights)
+        self.loss_keys = DETECTOR_LOSS_KEYS
         self.acts = {"detector": True, "learner": False}
         net.control_active(self.acts)
+        self.bucket: Optional[GradBucket] = None
+        self._bucket_key = None
+        self._wvec = None
+        self._ev = None
         self.reset_optimizer()
 
-    def _params(self):
-        return [p for p in self.net.kypt_detector.parameters() if p.requires_grad]
+    def _named(self):
+        return [("kypt_detector." + n, p) for n, p in self.net.kypt_detector.named_parameters() if p.requires_grad]
 
     def reset_optimizer(self) -> None:
         """The reference re-instantiates Adam at every epoch (train.py:366-374): state starts from zero."""
         self.t = 0
         self.state = {}
 
+    # -- the three device operations (replaced by CPU stand-ins in tests/test_sharding_cpu.py) ---------------------------
+    def _forward_backward(self, vox, named, bucket: GradBucket):
+        """Training forward + backward of L = sum_k w_k loss_k; gradients into bucket.views; returns the 11 losses (device).
+        Starts chunk 0's all-reduce as soon as the decoder's gradients are complete."""
+        import ctypes as C
+        from .spec import FEAT_DIM
+        det = self.net.kypt_detector
+        eng = self.net._engine
+        eng.set_training(True)
+        c = eng.ready()
+        dev = c.device
+        vox = vox.detach().to(device=dev, dtype=torch.float32).contiguous()
+        B, T = int(vox.shape[0]), int(vox.shape[1])
+        G, K, g = det.grid_size, det.nkeypoints, det.grid_size // 4
+        kp = torch.empty(B, T, K, 4, device=dev); hm = torch.empty(B, T, K, g, g, g, device=dev)
+        ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev); recon = torch.empty(B, T, 1, G, G, G, device=dev)
+        aff = torch.empty(det.nneighbor, K, K, 1, device=dev) if det.affinity_start else None
+        losses = torch.empty(len(self.loss_keys), device=dev)
+        eng.call("nm_detector_forward_train", _lib.ptr(vox), B, T, int(det.affinity_start), _lib.ptr(kp), _lib.ptr(hm), _lib.ptr(ff),
+                 _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses))
+        if self._wvec is None or self._wvec.device != dev:
+            self._wvec = torch.tensor([float(self.weights.get(k, 0.0)) for k in self.loss_keys], device=dev)
+            self._ev = torch.cuda.Event()
+            self._ev.record()                       # (creates the HIP event; the library re-records it)
+        eng.call("nm_ctx_set_backward_event", C.c_void_p(self._ev.cuda_event))
+        arr = (_lib.NmNamedTensor * len(named))()
+        keep = []
+        for i, (n, _) in enumerate(named):
+            v = bucket.views[n]
+            keep.append(n.encode())
+            arr[i].name, arr[i].data, arr[i].numel = keep[-1], v.data_ptr(), v.numel()
+        eng.call("nm_detector_backward", _lib.ptr(self._wvec), arr, len(named))
+        eng.call("nm_ctx_set_backward_event", None)
+        bucket.reduce_chunk(0, after_event=self._ev)
+        self._keep = (vox, kp, recon, aff)          # read by the backward kernels (stream-ordered: freed no earlier than the next step)
+        return losses
+
+    def _adam(self, params, grads, m, v):
+        eng = self.net._engine
+        eng.ready()
+        adam_step_(eng, params, grads, m, v, self.t, self.lr, self.betas, self.eps)
+
     def step(self, vox, sync: bool = True):
         """One training step.  sync=True returns python floats (waits for the device); sync=False returns 0-dim device tensors and
         lets the host run ahead into the next step."""
-        net = self.net
-        params = self._params()
-        for p in net.kypt_detector.parameters():
-            p.grad = None
-        log = net(vox, self.acts)
-        loss = sum(w * log[k] for k, w in self.weights.items())
-        loss.backward()
-        params = [p for p in params if p.grad is not None]
-        grads = [p.grad for p in params]
-        allreduce_mean_(grads)
-        eng = net._engine
-        eng.ready()
+        named = self._named()
+        key = tuple((n, p.data_ptr()) for n, p in named)
+        if self.bucket is None or key != self._bucket_key:
+            self.bucket = GradBucket(named, lambda n: 0 if n.startswith("kypt_detector.kypt_to_vox.") else 1, 2)
+            self._bucket_key = key
+        bucket = self.bucket
+        losses = self._forward_backward(vox, named, bucket)
+        bucket.reduce_chunk(1)
+        bucket.finish()
+        params = [p for _, p in named]
+        grads = [bucket.views[n] for n, _ in named]
+        for p, g in zip(params, grads):
+            p.grad = g                                # (a view of the bucket: what a caller inspecting .grad expects to find)
         self.t += 1
         for p in params:
             if id(p) not in self.state:
                 self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
-        adam_step_(eng, params, grads, [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params], self.t,
-                   self.lr, self.betas, self.eps)
+        self._adam(params, grads, [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params])
+        wv = self._wvec if self._wvec is not None else torch.tensor([float(self.weights.get(k, 0.0)) for k in self.loss_keys])
+        loss = (losses * wv.to(losses.device)).sum()
+        log = {k: losses[i] for i, k in enumerate(self.loss_keys) if k in self.weights}
         if not sync:
-            return {"loss": loss.detach(), **{k: log[k].detach() for k in self.weights}}
-        return {"loss": float(loss.detach()), **{k: float(log[k].detach()) for k in self.weights}}
+            return {"loss": loss, **log}
+        return {"loss": float(loss), **{k: float(v) for k, v in log.items()}}

@@ -712,8 +712,10 @@ def sample_generation(sd: SD, opts, cond_voxel: Tensor, Tgen: int, sample_num: i
 
 
 def sample_interpolation(sd: SD, opts, target_voxel: Tensor, sample_rate: int, sample_num: int, eps_a: Tensor, eps_b: Tensor,
-                         order=None, parents=None):
-    """vis_interpolation.py:80-143.  eps_a / eps_b (T,S,Z): first / second normal draw of each step."""
+                         order=None, parents=None, force_picks=None):
+    """vis_interpolation.py:80-143.  eps_a / eps_b (T,S,Z): first / second normal draw of each step.
+    Test aids (not in the reference): ``force_picks`` replaces the two argmin selections of every key frame (teacher forcing);
+    ``margins`` reports, per key frame, the relative gap between the smallest and second smallest distance of both selections."""
     S, K = sample_num, opts.nkeypoints
     det = detector_forward(sd, opts, target_voxel[None])
     kp = det["keypoints"]
@@ -722,7 +724,11 @@ def sample_interpolation(sd: SD, opts, target_voxel: Tensor, sample_rate: int, s
     T = kp.shape[1]
     h = sd[DYN + ".init_kypt_rnn_state"].expand(S, -1)
     off = bone_offsets(sd, kp, parents).expand(S, -1, -1, -1)
-    selected, pending, picks = [], [], []
+    selected, pending, picks, margins = [], [], [], []
+
+    def _gap(d):
+        two = torch.topk(d, 2, largest=False).values
+        return float((two[1] - two[0]) / two[1].clamp_min(1e-30))
     for t in range(T):
         flat = kp[:, t].reshape(1, -1).expand(S, -1)
         if t % sample_rate == 0 or t == T - 1:                            # :99-122
@@ -730,9 +736,12 @@ def sample_interpolation(sd: SD, opts, target_voxel: Tensor, sample_rate: int, s
             z = mu + eps_a[t] * sig
             f, _ = fk_decode(sd, torch.cat([h, z], dim=-1), off, order, parents)
             fc, _ = _prior_rows(sd, h, eps_b[t], off, order, parents)
-            i1 = int((f - flat).pow(2).sum(dim=-1).argmin())
+            d1 = (f - flat).pow(2).sum(dim=-1)
+            i1 = int(d1.argmin()) if force_picks is None else int(force_picks[len(picks)][0])
             f, z, h = f[i1][None].expand(S, -1), z[i1][None].expand(S, -1), h[i1][None].expand(S, -1)
-            i2 = int((fc - f).pow(2).sum(dim=-1).argmin())
+            d2 = (fc - f).pow(2).sum(dim=-1)
+            i2 = int(d2.argmin()) if force_picks is None else int(force_picks[len(picks)][1])
+            margins.append((_gap(d1), _gap(d2)))
             pending.append(flat)
             selected += [s[i2].view(K, 4) for s in pending]
             pending = []
@@ -744,7 +753,7 @@ def sample_interpolation(sd: SD, opts, target_voxel: Tensor, sample_rate: int, s
     sel = torch.stack(selected, 0)[None].clone()
     sel[0, :, :, -1] = sel[0, 0, :, -1]                                   # :133
     vox = decode_from_keypoints(sd, opts, sel, det["first_feature"], target_voxel[None, 0])[0]
-    return dict(keypoints=sel, voxels=(vox >= 0.5).float(), voxels_raw=vox, picks=picks)
+    return dict(keypoints=sel, voxels=(vox >= 0.5).float(), voxels_raw=vox, picks=picks, margins=margins)
 
 
 # ---- evaluation metrics --------------------------------------------------------------------

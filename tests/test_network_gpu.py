@@ -367,29 +367,136 @@ def test_generation_driver_vs_oracle():
     assert mism == 0, f"{mism} binarised voxels differ away from the 0.5 threshold"
 
 
+def _check_interpolation(net, sd, o, vox, rate, S, ea, eb, tol):
+    """Free run: every selection the oracle makes with a clear margin must be reproduced as long as the trajectories
+    have not diverged earlier.  Teacher-forced run (the oracle's selections imposed): keypoints compared unconditionally."""
+    with torch.no_grad():
+        ref = O.sample_interpolation(sd, o, vox, rate, S, ea, eb)
+    out = net.sample_interpolation(vox.cuda(), sample_rate=rate, sample_num=S, eps_a=ea.cuda(), eps_b=eb.cuda())
+    torch.cuda.synchronize()
+    print("interpolation picks", out["picks"], ref["picks"], "margins", ["%.1e/%.1e" % m for m in ref["margins"]])
+    assert len(out["picks"]) == len(ref["picks"])
+    for j, (got, want, (m1, m2)) in enumerate(zip(out["picks"], ref["picks"], ref["margins"])):
+        if m1 > 1e-4:
+            assert got[0] == want[0], f"key frame {j}: posterior selection {got[0]} != {want[0]} (oracle margin {m1:.2e})"
+        if got[0] != want[0]:
+            break
+        if m2 > 1e-4:
+            assert got[1] == want[1], f"key frame {j}: prior selection {got[1]} != {want[1]} (oracle margin {m2:.2e})"
+        if got[1] != want[1]:
+            break
+    forced = net.sample_interpolation(vox.cuda(), sample_rate=rate, sample_num=S, eps_a=ea.cuda(), eps_b=eb.cuda(), force_picks=ref["picks"])
+    torch.cuda.synchronize()
+    assert forced["picks"] == ref["picks"]
+    e = _err(forced["keypoints"], ref["keypoints"])
+    print("interpolation driver (S=%d): teacher-forced keypoints err %.3e" % (S, e))
+    assert e < tol
+    margin = (ref["voxels_raw"] - 0.5).abs()
+    mism = ((forced["voxels"].cpu() != ref["voxels"]) & (margin > 1e-3)).sum().item()
+    assert mism == 0, f"{mism} binarised voxels differ away from the 0.5 threshold"
+    return out
+
+
 def test_interpolation_driver_vs_oracle():
-    """NeuralMarionette.sample_interpolation (vis_interpolation.py:80-143), selection indices exact."""
+    """NeuralMarionette.sample_interpolation (vis_interpolation.py:80-143) at S = 256 and at the demo's
+    S = 10 000 rows (the shape that turns the VRNN MLPs into real GEMMs), both against the oracle."""
     o = HotPathOptions(grid_size=32)
     sd = synth.make_state_dict(o, seed=29, variant="peaky")
     net = _net(o, sd)
     T, S, rate = 11, 256, 5
     vox = synth.figure_clip(1, T, 32, seed=8)[0]
     ea, eb = synth.make_eps((T, S, 128), 9), synth.make_eps((T, S, 128), 10)
-    out = net.sample_interpolation(vox.cuda(), sample_rate=rate, sample_num=S, eps_a=ea.cuda(), eps_b=eb.cuda())
+    out = _check_interpolation(net, sd, o, vox, rate, S, ea, eb, tol=1e-3)
+    assert out["keypoints"].shape == (1, T, 24, 4) and out["voxels"].shape == (T, 1, 32, 32, 32)
+    # the demo's sample count
+    T2, S2 = 5, 10000
+    ea2, eb2 = synth.make_eps((T2, S2, 128), 11), synth.make_eps((T2, S2, 128), 12)
+    import time
+    t0 = time.perf_counter()
+    _check_interpolation(net, sd, o, vox[:T2], 2, S2, ea2, eb2, tol=1e-3)
+    print("S=10000 interpolation incl. oracle: %.2f s" % (time.perf_counter() - t0))
+
+
+def test_range_guard_reports_overflow():
+    """Split-fp16 range guard at the network level: a GroupNorm gain of 1e6 pushes a decoder activation beyond the fp16 range.
+    The default conv mode must REPORT it (NeuralMarionette.check_finite raises, naming the remedy) instead of handing back silent
+    NaNs; the exact-fp32 mode runs the same weights cleanly and matches the oracle."""
+    from neural_marionette_amd import _lib
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=61, variant="default")
+    key = "kypt_detector.kypt_to_vox.decode_voxel_from_combined_representation.2.weight"
+    sd[key] = sd[key] * 1e6
+    vox = synth.figure_clip(1, 2, 32, seed=16)
+    acts = {"detector": True, "learner": False}
+    net = _net(o, sd, "split16")
+    net.check_finite()                                  # clean before
+    out = net(vox.cuda(), acts)
+    with pytest.raises(_lib.NmError, match="fp32"):
+        net.check_finite()
+    net.check_finite()                                  # the status is consumed by the report
+    net.set_conv_mode("fp32")
+    out = net(vox.cuda(), acts)
+    net.check_finite()
+    with torch.no_grad():
+        ref = O.detector_forward(sd, o, vox)
+    assert torch.isfinite(out["recon"]).all()
+    assert _err(out["keypoints"], ref["keypoints"]) < KP_TOL
+    assert _err(out["recon"], ref["recon"]) < 1e-3
+
+
+def test_decode_from_dyna_unit_vs_oracle():
+    """KyptDetector.decode_from_dyna (kypt_detector.py:213-241) in isolation: the ORACLE's keypoints, first feature and first
+    frame in -> reconstruction out (recon 1e-3, occupancy exact away from the 0.5 threshold)."""
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=37, variant="peaky")
+    net = _net(o, sd)
+    B, T, Tg = 2, 3, 4
+    vox = synth.figure_clip(B, T, 32, seed=12)
+    with torch.no_grad():
+        det = O.detector_forward(sd, o, vox)
+        gen = torch.Generator().manual_seed(5)
+        kp = det["keypoints"][:, :1].expand(-1, Tg, -1, -1).clone()
+        kp[..., :3] += 0.05 * torch.randn(B, Tg, o.nkeypoints, 3, generator=gen)          # keypoints the detector never produced
+        kp[..., 3] = (kp[..., 3] * (1 + 0.2 * torch.randn(B, Tg, o.nkeypoints, generator=gen))).clamp(0, 1)
+        ref = O.decode_from_keypoints(sd, o, kp, det["first_feature"], vox[:, 0])
+    got = net.kypt_detector.decode_from_dyna(kp.cuda(), det["first_feature"].cuda(), vox[:, 0].cuda())["gen"]
+    torch.cuda.synchronize()
+    assert got.shape == (B, Tg, 1, 32, 32, 32)
+    e = _err(got, ref)
+    margin = (ref - 0.5).abs()
+    mism = (((got.cpu() >= 0.5) != (ref >= 0.5)) & (margin > 1e-4)).sum().item()
+    print("decode_from_dyna unit: recon err %.3e, occupancy mismatches away from threshold %d" % (e, mism))
+    assert e < 1e-3 and mism == 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_weights_init_variant_end_to_end(mode):
+    """The weights a from-scratch run starts from (train.py:262 -> utils/train_utils.py:248-264: Block convs N(0, 0.001), other
+    convs N(0, 0.02), biases 0, GroupNorm 1/0): conv outputs are O(1e-2) and every GroupNorm divides by a variance near its
+    eps - the full forward, both conv modes, against the oracle."""
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=51, variant="winit")
+    net = _net(o, sd, mode)
+    B, T = 2, 4
+    vox = synth.figure_clip(B, T, 32, seed=14)
+    eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=15)
+    out = net(vox.cuda(), ACTS, eps=eps.cuda())
     torch.cuda.synchronize()
     with torch.no_grad():
-        ref = O.sample_interpolation(sd, o, vox, rate, S, ea, eb)
-    print("interpolation picks", out["picks"], ref["picks"])
-    assert out["picks"][0] == ref["picks"][0], "first key frame's sample selection must match exactly"
-    if out["picks"] == ref["picks"]:
-        e = _err(out["keypoints"], ref["keypoints"])
-        print("interpolation driver: keypoints err %.3e" % e)
-        assert e < 1e-3
-    assert out["keypoints"].shape == (1, T, 24, 4) and out["voxels"].shape == (T, 1, 32, 32, 32)
-    # large sample count of the demo (10 000 rows) runs through the same kernels
-    big = net.sample_interpolation(vox[:3].cuda(), sample_rate=2, sample_num=10000)
-    torch.cuda.synchronize()
-    assert torch.isfinite(big["keypoints"]).all()
+        ref = O.nm_forward(sd, o, vox, eps)
+    e_kp = _err(out["keypoints"], ref["keypoints"])
+    e_hm = _err(out["heatmaps"], ref["heatmaps"]) / max(float(ref["heatmaps"].abs().max()), 1e-30)
+    e_ff = _err(out["first_feature"], ref["first_feature"]) / max(float(ref["first_feature"].abs().max()), 1e-30)
+    print("winit variant (%s): keypoints %.3e heatmaps(rel) %.3e first_feature(rel) %.3e" % (mode, e_kp, e_hm, e_ff))
+    assert e_kp < KP_TOL and e_hm < 1e-3 and e_ff < 1e-3
+    assert _err(out["recon"], ref["recon"]) < 1e-3
+    for k in DETECTOR_LOSS_KEYS:
+        r = float(ref[k])
+        assert abs(float(out[k]) - r) <= 1e-4 * max(1.0, abs(r)), k
+    assert np.array_equal(net.dyna_module.parents.cpu().numpy(), ref["parents"])
+    enc = net.dyna_module.encode(ref["keypoints"].cuda(), ref["affinity"].cuda(), eps=eps.cuda())
+    for k in ("kypt_recon", "z_kypts", "h_kypts"):
+        assert _err(enc[k], ref[k]) < KP_TOL, k
 
 
 def _oracle_learner_grads(sd, o, kp, order, parents, eps, w_rec=1.0, w_kl=0.003):

@@ -211,6 +211,41 @@ def test_conv3d_fused_upsample_composite(ctx, dims, prologue, N):
     assert torch.equal(out, out2) and torch.equal(gsc, gsc2) and torch.equal(gsh, gsh2)
 
 
+@pytest.mark.parametrize("case", [(32, 32, 3, 1, 1, (16, 16, 16), 0), (64, 64, 3, 1, 1, (16, 16, 16), 0), (64, 128, 1, 1, 0, (8, 8, 8), 0),
+                                  (32, 32, 2, 2, 0, (16, 16, 16), 0), (64, 32, 3, 1, 1, (8, 8, 8), 1), (48, 72, 3, 1, 1, (4, 4, 4), 0)],
+                         ids=lambda c: "ci%d_co%d_k%d_up%d" % (c[0], c[1], c[2], c[6]))
+def test_conv3d_beyond_fp16_range_falls_back_to_fp32(ctx, case):
+    """Split-fp16 mode with activations beyond the fp16 range (|x| up to ~3e5 > 65504): hi = fp16(x) would be inf and the
+    product NaN.  The op-level entry point scans its result and re-runs the launch on the exact fp32 MFMA path: the result
+    matches ATen's fp32 conv, never NaN.  (Network level: test_network_gpu.py::test_range_guard_reports_overflow.)"""
+    from neural_marionette_amd import _lib
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, 1), "set_conv_mode")
+    Cin, Cout, ks, stride, pad, dims, up2 = case
+    g = torch.Generator().manual_seed(Cin + Cout)
+    N = 2
+    x = torch.randn(N, Cin, *dims, generator=g)
+    x[0] *= 1e5                                        # frame 0 far outside the fp16 range, frame 1 ordinary
+    w = torch.randn(Cout, Cin, ks, ks, ks, generator=g) / (Cin * ks ** 3) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    xin = F.interpolate(x, scale_factor=2.0, mode="trilinear", align_corners=False) if up2 else x
+    ref = F.conv3d(xin, w, b, stride=stride, padding=pad)
+    out = torch.full((N, *ref.shape[2:], Cout), float("nan")).cuda()
+    groups = Cout // 16
+    gam = torch.ones(Cout); bet = torch.zeros(Cout)
+    gsc = torch.zeros(N, Cout).cuda(); gsh = torch.zeros(N, Cout).cuda()
+    xd, wd, bd, gd, btd = to_cl(x), dev(w), dev(b), dev(gam), dev(bet)
+    _lib.check(ctx.lib.nm_op_conv3d(ctx.handle, _lib.ptr(xd), N, *dims, Cin, None, None, 1.0, _lib.ptr(wd), _lib.ptr(bd), Cout, ks,
+                                    stride, pad, _lib.ptr(out), groups, _lib.ptr(gd), _lib.ptr(btd), _lib.ptr(gsc), _lib.ptr(gsh), up2),
+               "op_conv3d")
+    torch.cuda.synchronize()
+    got = from_cl(out, Cout)
+    assert torch.isfinite(got).all() and torch.isfinite(gsc).all() and torch.isfinite(gsh).all()
+    for n in range(N):                                 # per frame: frame 1's magnitudes are 1e5 times smaller
+        e = (got[n] - ref[n]).abs().max().item() / ref[n].abs().max().item()
+        assert e < REL, f"frame {n}: rel err {e:.3e}"
+    assert ctx.lib.nm_ctx_check_nonfinite(ctx.handle) == 0      # the op cleared the status it consumed
+
+
 @pytest.mark.parametrize("G,Cout,N", [(16, 32, 3), (24, 64, 2), (32, 32, 1)])
 @pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "split16"])
 def test_conv5_occupancy_first_layer(ctx, G, Cout, N, mode):

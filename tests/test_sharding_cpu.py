@@ -88,3 +88,70 @@ def test_gradient_bucket_allreduce_world2():
     g1 = [torch.randn(7, 5, generator=gen), torch.randn(11, generator=gen), torch.randn(3, 2, 2, generator=gen)]
     for a, b, c in zip(g0, g1, avg):
         assert torch.allclose(c, (a + b) / 2, atol=1e-7)
+
+
+# ---- the real DetectorTrainer.step control flow (bucket views, chunked all-reduce, averaging, Adam) with the three device
+# ---- operations replaced by CPU stand-ins: world size 2 over gloo ------------------------------------------------------------
+def _stub_grad(name, shape, rank):
+    g = torch.Generator().manual_seed((sum(name.encode()) * 7919 + 13 * rank) % (2 ** 31))
+    return torch.randn(*shape, generator=g)
+
+
+def _trainer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_marionette_amd import NeuralMarionette, HotPathOptions
+    from neural_marionette_amd.train import DetectorTrainer
+
+    class CpuStandIn(DetectorTrainer):
+        def _forward_backward(self, vox, named, bucket):
+            for n, p in named:
+                bucket.views[n].copy_(_stub_grad(n, p.shape, rank))
+            bucket.reduce_chunk(0)                   # as the HIP step does once the decoder's gradients exist
+            return torch.arange(11, dtype=torch.float32) * (rank + 1)
+
+        def _adam(self, params, grads, m, v):        # torch.optim.Adam's update, written out
+            b1, b2 = self.betas
+            for p, g, mm, vv in zip(params, grads, m, v):
+                mm.mul_(b1).add_(g, alpha=1 - b1); vv.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (vv / (1 - b2 ** self.t)).sqrt_().add_(self.eps)
+                p.data.addcdiv_(mm / (1 - b1 ** self.t), denom, value=-self.lr)
+
+    torch.manual_seed(3)
+    net = NeuralMarionette(HotPathOptions(grid_size=32))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    tr = CpuStandIn(net, lr=1e-2)
+    out = tr.step(torch.zeros(1, 2, 1, 32, 32, 32))
+    assert len(tr.bucket.chunks) == 2 and tr.bucket.chunks[0][1] == tr.bucket.chunks[1][0] > 0
+    assert tr.bucket.chunks[1][1] == tr.bucket.flat.numel() == sum(p.numel() for p in net.kypt_detector.parameters())
+    dec = [n for n in tr.bucket.views if n.startswith("kypt_detector.kypt_to_vox.")]
+    assert sum(tr.bucket.views[n].numel() for n in dec) == tr.bucket.chunks[0][1]
+    worst = 0.0
+    for n, p in net.kypt_detector.named_parameters():
+        name = "kypt_detector." + n
+        g = (_stub_grad(name, p.shape, 0) + _stub_grad(name, p.shape, 1)) / 2
+        assert torch.allclose(p.grad, g, atol=1e-7), name                      # .grad = the bucket view holding the mean gradient
+        assert p.grad.data_ptr() == tr.bucket.views[name].data_ptr()
+        want = before[name] - 1e-2 * g / (g.abs() + 1e-8)                        # first Adam step: m_hat / (sqrt(v_hat) + eps)
+        worst = max(worst, float((p.detach() - want).abs().max()))
+    if rank == 0:
+        q.put((worst, float(out["loss"]), sorted(out)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_detector_trainer_step_world2_with_cpu_stand_ins():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    worst, loss, keys = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert worst < 1e-6
+    from neural_marionette_amd.train import DETECTOR_LOSS_WEIGHTS
+    from neural_marionette_amd.spec import DETECTOR_LOSS_KEYS
+    assert abs(loss - sum(DETECTOR_LOSS_WEIGHTS[k] * i for i, k in enumerate(DETECTOR_LOSS_KEYS))) < 1e-3
+    assert "loss" in keys and "recon_loss" in keys

@@ -159,11 +159,16 @@ def test_detector_gradients_odd_hourglass_40():
 
 
 @pytest.mark.parametrize("K", [16, 32])
-def test_detector_gradients_other_keypoint_counts(K):
-    """K = 16 / 32 keypoints (the combined representation has 2K + 131 channels, the heads K)."""
-    o, sd, vox = _setup(G=32, B=1, T=3, seed=71 + K, K=K)
+@pytest.mark.parametrize("mode", ["split16", "fp32"])
+def test_detector_gradients_other_keypoint_counts(K, mode):
+    """K = 16 / 32 keypoints (the combined representation has 2K + 131 channels, the heads K), both conv modes.
+    Seeds: the losses contain selections (nearest keypoint of the chamfer term, strongest neighbour of the graph terms); a seed on
+    which one of them is a near-tie makes the gradient a coin flip of the last fp32 bit - on K = 32, seed 103 the exact-fp32 path
+    and the split-fp16 paths land 3e-3 away from the fp64 oracle with IDENTICAL deviations (tools/diag_seed_scan.py), on the
+    neighbouring seeds every path is within 1e-4.  Such a seed measures the tie, not the kernels."""
+    o, sd, vox = _setup(G=32, B=1, T=3, seed={16: 87, 32: 104}[K], K=K)
     ref_loss, ref, _ = _oracle_grads(o, sd, vox, AIST, double=True)
-    loss, got, _ = _hip_grads(o, sd, vox, AIST)
+    loss, got, _ = _hip_grads(o, sd, vox, AIST, mode=mode)
     assert abs(loss - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss))
     _compare(ref, got, tol=TOL)
 
