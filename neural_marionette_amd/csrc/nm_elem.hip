@@ -28,23 +28,25 @@ __device__ __forceinline__ f32x4 load_t(const TensorRef& t, size_t n, size_t vox
     return v;
 }
 
-// one block per (frame, group): 1024 threads walk the (block, channel) partials (float2 loads, four independent chains per
-// thread), fp64 sums combined in a fixed order (run-to-run identical)
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups,
+// one block per (frame, group): NT threads walk the (block, channel) partials (float2 loads, four independent chains per
+// thread), fp64 sums combined in a fixed order (run-to-run identical).  NT = 256 for the usual few thousand partials, 1024 for the
+// layers whose kernels leave several thousand blocks per frame (a 256-thread block took 96 us there).
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int groups,
                                                            double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
                                                            float* __restrict__ scale, float* __restrict__ shift,
                                                            unsigned* __restrict__ nonfinite) {
-    __shared__ double sh_s[1024], sh_ss[1024];
+    __shared__ double sh_s[NT], sh_ss[NT];
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
     double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
     const int total = nblk * cpg;
     const float* base = part + (size_t)n * nblk * C * 2;
-    for (int i0 = threadIdx.x; i0 < total; i0 += 4096) {
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4 * NT) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 1024;
+            const int i = i0 + u * NT;
             if (i < total) {
                 const int blk = i / cpg, c = g * cpg + i % cpg;
                 const float2 q = *reinterpret_cast<const float2*>(base + ((size_t)blk * C + c) * 2);
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restri
     }
     sh_s[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]); sh_ss[threadIdx.x] = (ss[0] + ss[1]) + (ss[2] + ss[3]);
     __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
+    for (int st = NT / 2; st > 0; st >>= 1) {
         if ((int)threadIdx.x < st) { sh_s[threadIdx.x] += sh_s[threadIdx.x + st]; sh_ss[threadIdx.x] += sh_ss[threadIdx.x + st]; }
         __syncthreads();
     }
@@ -393,7 +395,10 @@ int nm_launch_nonfinite_scan(const float* x, size_t n, unsigned* flag, hipStream
 int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count, const float* gamma,
                           const float* beta, float eps, float* scale, float* shift, hipStream_t s) {
     if (groups <= 0 || C % groups != 0 || C / groups > 256) { nm_set_error("gn_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(1024), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag);
+    if ((long long)nblk * (C / groups) > 8192)
+        hipLaunchKernelGGL(gn_finalize_kernel<1024>, dim3(N * groups), dim3(1024), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag);
+    else
+        hipLaunchKernelGGL(gn_finalize_kernel<256>, dim3(N * groups), dim3(256), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag);
     return nm_check_hip(hipGetLastError(), "gn_finalize launch");
 }
 

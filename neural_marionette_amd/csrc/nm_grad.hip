@@ -431,8 +431,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         else { tile = (m >> 5) * n_tiles + (c >> 5); grp = tap; col = c & 31; }
         const float* src = part + ((size_t)tile * groups + grp) * 1024 + (m & 31) * 32 + col;
         const size_t stride = (size_t)tiles * groups * 1024;
-        float s = 0.f;
-        for (int k = 0; k < slots; ++k) s += src[(size_t)k * stride];
+        // eight independent chains (the slot loop is a chain of dependent L2 round trips otherwise), combined in a fixed order
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= slots; k += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(k + u) * stride];
+        }
+        for (int u = 0; k < slots; ++k, ++u) a[u] += src[(size_t)k * stride];
+        const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         dW[((size_t)m * Cin + c) * taps + tap] = s * mm;
     }
 }
@@ -468,15 +475,16 @@ __global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restri
     }
 }
 
-// one block per (frame, group); cpg <= 64 channels per group
-__global__ __launch_bounds__(256) void gnb_finalize_kernel(const float* __restrict__ bpart, int nblk_b, const float* __restrict__ fpart,
+// one block per (frame, group); cpg <= 64 channels per group; 1024 threads: 1024 / cpg lanes walk each channel's partial blocks
+#define NM_GNBF_T 1024
+__global__ __launch_bounds__(NM_GNBF_T) void gnb_finalize_kernel(const float* __restrict__ bpart, int nblk_b, const float* __restrict__ fpart,
                                                            int nblk_f, int C, int groups, int voxels, const float* __restrict__ gamma,
                                                            float eps, float* __restrict__ coef, float* __restrict__ dgn) {
-    __shared__ double red[256 * 4];
+    __shared__ double red[NM_GNBF_T * 4];
     __shared__ double chan[64 * 4];      // per channel: sum y, sum y^2, S1, S2
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
-    const int L = 256 / cpg;             // partial lanes per channel
+    const int L = NM_GNBF_T / cpg;       // partial lanes per channel
     const int cl = threadIdx.x % cpg, ln = threadIdx.x / cpg, c = g * cpg + cl;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if (ln < L) {
@@ -531,9 +539,18 @@ __global__ void sum_frames_kernel(const float* __restrict__ src, int N, int C, i
 __global__ void sum_frames3_kernel(const float* __restrict__ dgn, int N, int C, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int n = 0; n < N; ++n) { const float* d = dgn + ((size_t)n * C + c) * 4; s0 += d[0]; s1 += d[1]; s2 += d[2]; }
-    o0[c] = s0; o1[c] = s1; o2[c] = s2;
+    // four independent chains over the frames (16-byte loads), combined in a fixed order
+    f32x4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int n = 0;
+    for (; n + 4 <= N; n += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += *reinterpret_cast<const f32x4*>(dgn + ((size_t)(n + u) * C + c) * 4);
+    }
+    for (int u = 0; n < N; ++n, ++u) a[u] += *reinterpret_cast<const f32x4*>(dgn + ((size_t)n * C + c) * 4);
+    const f32x4 t = (a[0] + a[1]) + (a[2] + a[3]);
+    o0[c] = t[0]; o1[c] = t[1]; o2[c] = t[2];
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out) {
@@ -827,7 +844,7 @@ int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hip
 int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, int nblk_f, int N, int C, int groups, int voxels,
                            const float* gamma, float eps, float* coef, float* dgn, hipStream_t s) {
     if (groups <= 0 || C % groups || C / groups > 64) { nm_set_error("gnb_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
-    hipLaunchKernelGGL(gnb_finalize_kernel, dim3(N * groups), dim3(256), 0, s, bpart, nblk_b, fpart, nblk_f, C, groups, voxels, gamma,
+    hipLaunchKernelGGL(gnb_finalize_kernel, dim3(N * groups), dim3(NM_GNBF_T), 0, s, bpart, nblk_b, fpart, nblk_f, C, groups, voxels, gamma,
                        eps, coef, dgn);
     return nm_check_hip(hipGetLastError(), "gnb_finalize launch");
 }
