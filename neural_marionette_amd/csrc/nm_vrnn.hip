@@ -112,6 +112,101 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinJobs jobs) {
     }
 }
 
+// ---- the same jobs as a tiled GEMM on the fp32 matrix cores, for large batches ------------------------------------------------
+// The reference's interpolation demo pushes S = 10 000 sample rows through every MLP / GRU matrix of the VRNN
+// (vis_interpolation.py:91-143): 10 000 x 640 . 640 x 128, 10 000 x 512 . 512 x 1536 ... - real GEMMs, where one wavefront per
+// output row re-streams the whole batch per row.  Here: workgroup tile 128 samples x 64 outputs, 4 waves x (32 samples x 64
+// outputs), v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate), K in LDS chunks of 32 with the permuted-K operand
+// trick of conv_mfma_kernel (lane half h owns k = 8q + 4h .. +3: one ds_read_b128 feeds four MFMAs; row pitch 36 floats keeps the
+// 16-lane groups on distinct banks).  Same LinJob semantics (two input segments, column offset, bias, broadcast add, activation).
+#define GM_BM 128
+#define GM_BN 64
+#define GM_KC 32
+#define GM_PITCH 36
+struct GemmJobs { LinJob j[5]; int n; int tile0[6]; int mt[5]; };       // tile0: first workgroup of job i; mt: its sample tiles
+
+__global__ __launch_bounds__(256) void gemm_rows_mfma_kernel(GemmJobs jobs) {
+    __shared__ float xs[GM_BM * GM_PITCH];
+    __shared__ float wsm[GM_BN * GM_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < 5; ++i) if (i < jobs.n && (int)blockIdx.x >= jobs.tile0[i]) ji = i;
+    ji = __builtin_amdgcn_readfirstlane(ji);
+    const LinJob& J = jobs.j[ji];
+    const int t = (int)blockIdx.x - jobs.tile0[ji];
+    const int b0 = (t % jobs.mt[ji]) * GM_BM, r0 = (t / jobs.mt[ji]) * GM_BN;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const int K = J.na + J.nb;
+    for (int k0 = 0; k0 < K; k0 += GM_KC) {
+        // stage x[b0 .. +128][k0 .. +32] and W[r0 .. +64][col0 + k0 .. +32]  (a chunk lies inside one input segment)
+        const bool in_a = k0 < J.na;
+        const float* xsrc = in_a ? J.xa : J.xb;
+        const int ld = in_a ? J.lda : J.ldb, kk = in_a ? k0 : k0 - J.na;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (GM_BM * GM_KC / 4) / 256; ++i) {
+            const int e = tid + 256 * i, row = e >> 3, c4 = (e & 7) * 4;
+            const int b = min(b0 + row, J.batch - 1);
+            *reinterpret_cast<f32x4*>(xs + row * GM_PITCH + c4) = *reinterpret_cast<const f32x4*>(xsrc + (size_t)b * ld + kk + c4);
+        }
+#pragma unroll
+        for (int i = 0; i < (GM_BN * GM_KC / 4) / 256; ++i) {
+            const int e = tid + 256 * i, row = e >> 3, c4 = (e & 7) * 4;
+            const int r = min(r0 + row, J.rows - 1);
+            *reinterpret_cast<f32x4*>(wsm + row * GM_PITCH + c4) = *reinterpret_cast<const f32x4*>(J.W + (size_t)r * J.ldw + J.col0 + k0 + c4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < GM_KC / 8; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xs + (wave * 32 + l31) * GM_PITCH + 8 * q + 4 * h);
+            f32x4 bq[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bq[nt] = *reinterpret_cast<const f32x4*>(wsm + (nt * 32 + l31) * GM_PITCH + 8 * q + 4 * h);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx], bq[nt][sidx], acc[nt], 0, 0, 0);
+        }
+    }
+    // epilogue: lane = output row r0 + nt*32 + l31; register r = sample (r & 3) + 8 (r >> 2) + 4 h of the wave's 32
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int r = r0 + nt * 32 + l31;
+        if (r >= J.rows) continue;
+        const float bv = J.bias ? J.bias[r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int b = b0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (b >= J.batch) continue;
+            float v = acc[nt][i] + bv;
+            if (J.add) v += J.add[(size_t)(b % J.add_mod) * J.ldadd + r];
+            if (J.act == 1) v = lrelu(v, 0.01f);
+            else if (J.act == 2) v = tanhf(v);
+            if (J.gate) v *= (J.gate[(size_t)b * J.ldgate + r] > 0.f ? 1.0f : 0.01f);
+            J.out[(size_t)b * J.ldo + r] = v;
+        }
+    }
+}
+
+// GRU cell from precomputed input / hidden projections (large batches: gi from the GEMM above): torch.nn.GRUCell's gates r, z, n
+__global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h,
+                                                        int ldh, float* __restrict__ hout, int ldo, int H, int B) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i >= (size_t)B * H) return;
+    const int b = (int)(i / H), j = (int)(i % H);
+    const float* a = gi + (size_t)b * 3 * H; const float* g = gh + (size_t)b * 3 * H;
+    const float rg = sigmoidf(a[j] + g[j]);
+    const float zg = sigmoidf(a[H + j] + g[H + j]);
+    const float ng = tanhf(a[2 * H + j] + rg * g[2 * H + j]);
+    const float hp = h[(size_t)b * ldh + j];
+    hout[(size_t)b * ldo + j] = (hp - ng) * zg + ng;
+}
+
 // second layer of a prior / posterior MLP: rows (r, r+Z) -> mu, std = softplus(.)+1e-4 and, when eps is given,
 // z[i][b][r] = mu + eps[i][b][r] * std   (hsvrnn_bvh.py:93-107)
 struct DistJob { const float* W; const float* bias; const float* x; float* mu; float* sig; const float* eps; float* z; int S; float* raw_s; };
@@ -583,6 +678,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restr
 
 struct StepBufs {
     float *hid_prior, *hid_post, *rh, *jh, *gh, *pmu, *psig, *qmu, *qsig, *z, *hr, *hj, *rootout, *rot;
+    float* gi;        // [B][3H] input projection of the GRU (large batches only, else null)
 };
 
 void add_job(LinJobs& J, const LinearW& L, int col0, const float* xa, int na, int lda, const float* xb, int nb, int ldb,
@@ -597,7 +693,30 @@ void add_job(LinJobs& J, const LinearW& L, int col0, const float* xa, int na, in
 
 int pick_nb(int batch) { return batch >= 8 ? 8 : (batch >= 4 ? 4 : (batch >= 2 ? 2 : 1)); }
 
+#define NM_GEMM_MIN_BATCH 128
+int g_vrnn_gemm = [] { const char* e = getenv("NM355_VRNN_GEMM"); return e ? atoi(e) : 1; }();     // 0: one wavefront per output row at every batch size (A/B)
+
+// batches of >= 128 rows take the MFMA GEMM (every input segment of this model is a multiple of 32 columns wide)
+bool gemm_eligible(const LinJobs& J) {
+    if (!g_vrnn_gemm) return false;
+    for (int i = 0; i < J.n; ++i) {
+        const LinJob& j = J.j[i];
+        if (j.batch < NM_GEMM_MIN_BATCH || j.na % GM_KC || j.nb % GM_KC || (j.col0 & 3) || (j.ldw & 3) || (j.lda & 3) || (j.nb && (j.ldb & 3))) return false;
+    }
+    return J.n > 0;
+}
+
 int launch_jobs(const LinJobs& J, hipStream_t s) {
+    if (gemm_eligible(J)) {
+        GemmJobs G; G.n = J.n; G.tile0[0] = 0;
+        for (int i = 0; i < J.n; ++i) {
+            G.j[i] = J.j[i];
+            G.mt[i] = (J.j[i].batch + GM_BM - 1) / GM_BM;
+            G.tile0[i + 1] = G.tile0[i] + G.mt[i] * ((J.j[i].rows + GM_BN - 1) / GM_BN);
+        }
+        hipLaunchKernelGGL(gemm_rows_mfma_kernel, dim3(G.tile0[J.n]), dim3(256), 0, s, G);
+        return nm_check_hip(hipGetLastError(), "gemm_rows_mfma launch");
+    }
     int maxb = 0;
     for (int i = 0; i < J.n; ++i) maxb = J.j[i].batch > maxb ? J.j[i].batch : maxb;
     const int nb = pick_nb(maxb);
@@ -610,7 +729,19 @@ int launch_jobs(const LinJobs& J, hipStream_t s) {
 }
 
 int launch_gru(const float* W_ih, const float* b_ih, const float* xa, int na, int lda, const float* xb, int nb_, int ldb,
-               const float* gh, const float* h, int ldh, float* hout, int ldo, int H, int B, hipStream_t s, float* tg = nullptr) {
+               const float* gh, const float* h, int ldh, float* hout, int ldo, int H, int B, hipStream_t s, float* tg = nullptr,
+               float* gi_scratch = nullptr) {
+    if (gi_scratch && !tg && g_vrnn_gemm && B >= NM_GEMM_MIN_BATCH && na % GM_KC == 0 && nb_ % GM_KC == 0) {
+        // large batch: input projection as a GEMM, then the element-wise gates
+        LinJobs J; J.n = 0; J.start[0] = 0;
+        LinearW ih; ih.in = na + nb_; ih.out = 3 * H; ih.w = const_cast<float*>(W_ih); ih.b = const_cast<float*>(b_ih);
+        add_job(J, ih, 0, xa, na, lda, xb, nb_, ldb, true, nullptr, 0, 1, gi_scratch, 3 * H, 0, B);
+        int rc = launch_jobs(J, s);
+        if (rc) return rc;
+        const size_t total = (size_t)B * H;
+        hipLaunchKernelGGL(gru_gates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gi_scratch, gh, h, ldh, hout, ldo, H, B);
+        return nm_check_hip(hipGetLastError(), "gru_gates launch");
+    }
     const int nb = pick_nb(B);
     dim3 grid((H + 3) / 4, (B + nb - 1) / nb);
     if (nb == 1) hipLaunchKernelGGL((gru_rows_kernel<1>), grid, dim3(256), 0, s, W_ih, b_ih, xa, na, lda, xb, nb_, ldb, gh, h, ldh, hout, ldo, H, B, tg);
@@ -627,6 +758,7 @@ StepBufs alloc_step(Arena& ws, int B, int S, int K, int Z, int H) {
     b.pmu = ws.f((size_t)B * Z); b.psig = ws.f((size_t)B * Z); b.qmu = ws.f((size_t)B * Z); b.qsig = ws.f((size_t)B * Z);
     b.z = ws.f((size_t)S * B * Z); b.hr = ws.f((size_t)S * B * 128); b.hj = ws.f((size_t)S * B * 128);
     b.rootout = ws.f((size_t)S * B * (3 + K)); b.rot = ws.f((size_t)S * B * 6 * K);
+    b.gi = B >= NM_GEMM_MIN_BATCH ? ws.f((size_t)B * 3 * H) : nullptr;
     return b;
 }
 
@@ -701,7 +833,7 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         if ((rc = nm_check_hip(hipGetLastError(), "fk launch"))) return rc;
     }
     if (io.hout) {   // 5. GRU
-        if ((rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s, io.tape ? io.tape->gates : nullptr))) return rc;
+        if ((rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s, io.tape ? io.tape->gates : nullptr, sb.gi))) return rc;
     }
     return NM_OK;
 }
@@ -777,7 +909,7 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
     }
     if ((rc = max_fk_lds(c, S))) return rc;
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4;
-    size_t need = ((size_t)B * (4 * 128 + 3 * H + 4 * Z + K * 3 + 2 * T) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
+    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z + K * 3 + 2 * T) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
     if ((rc = nm_ctx_reserve(c, need))) return rc;
     c->ws.release(0);
     StepBufs sb = alloc_step(c->ws, B, S, K, Z, H);
@@ -1007,7 +1139,7 @@ int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_po
     }
     if ((rc = max_fk_lds(c, S))) return rc;
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4, Tg = Ttot - Tcond;
-    size_t need = ((size_t)B * (4 * 128 + 3 * H + 4 * Z + K * 3 + 2 * H + Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
+    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z + K * 3 + 2 * H + Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
     if ((rc = nm_ctx_reserve(c, need))) return rc;
     c->ws.release(0);
     StepBufs sb = alloc_step(c->ws, B, S, K, Z, H);
@@ -1046,7 +1178,7 @@ int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* k
     if (!posterior) S = 1;
     if ((rc = max_fk_lds(c, S))) return rc;
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4;
-    size_t need = ((size_t)B * (4 * 128 + 3 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
+    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
     if ((rc = nm_ctx_reserve(c, need))) return rc;
     c->ws.release(0);
     StepBufs sb = alloc_step(c->ws, B, S, K, Z, H);
