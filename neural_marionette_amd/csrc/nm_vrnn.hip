@@ -389,6 +389,133 @@ __global__ __launch_bounds__(256) void fk_kernel(FkArgs a) {
     }
 }
 
+// ---- prior step, middle phases in ONE workgroup (rollout latency, vis_generation.py:97-127 / hsvrnn_bvh.py:208-225) ----------
+// A prior step is a chain of dependent phases: h-phase -> distribution + sample -> decoder hidden layers -> heads -> forward
+// kinematics -> GRU.  The first and the last stream megabytes of weights and want the whole chip; the four in between touch
+// 128 + 128 + 87 KB of weights and a few hundred floats of state per sample: as separate launches each of them is a dispatch
+// round trip (~6 us) around ~2 us of work.  Here one 512-thread workgroup runs the four back to back with workgroup barriers,
+// state in LDS: a step is 3 dependent launches instead of 6.  Arithmetic identical to dist_rows / linear_rows / fk_kernel
+// (same dot-product order through dot_seg / wave_reduce): the fused step is bit-identical to the six-launch step.
+struct MidArgs {
+    const float *hid_prior, *rh, *jh, *eps, *offset;            // [B][128] x3, [B][Z], [B][K][3]
+    const float *w_p2, *b_p2, *w_root0, *w_joint0, *w_root2, *b_root2, *w_joint2, *b_joint2;
+    const int32_t *order, *parents;
+    float *out_kp, *out_z; int ldkp, ldz;
+    int B, K, Z, H;
+};
+
+// RW rows of one wave at a time: all their weight loads are issued before the first is consumed (a single workgroup has no other
+// parallelism to hide the L2 round trips behind).  Per row the arithmetic is dot_seg's for n = 128 (lanes 0..31 own 4 columns
+// each, ((w0 x0 + w1 x1) + w2 x2) + w3 x3, then the xor-shuffle tree): bit-identical to linear_rows / dist_rows.
+template <int NB, int RW, class RowW, class RowX, class Store>
+__device__ __forceinline__ void mid_rows(int rows, int wave, int lane, int B, RowW roww, RowX rowx, Store store) {
+    for (int r0 = wave * RW; r0 < rows; r0 += 8 * RW) {
+        f32x4 wv[RW];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            const int r = min(r0 + u, rows - 1);
+            wv[u] = lane < 32 ? *reinterpret_cast<const f32x4*>(roww(r) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            const int r = r0 + u;
+            float acc[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                acc[i] = 0.f;
+                if (lane < 32) {
+                    const int bb = i < B ? i : B - 1;
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(rowx(r < rows ? r : rows - 1, bb) + lane * 4);
+                    acc[i] += ((wv[u][0] * xv[0] + wv[u][1] * xv[1]) + wv[u][2] * xv[2]) + wv[u][3] * xv[3];
+                }
+            }
+            wave_reduce(acc);
+            if (r < rows && lane < NB && lane < B) store(r, lane, pick(acc, lane));
+        }
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void vrnn_prior_mid_kernel(MidArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_mu[NB * 128], s_sr[NB * 128], s_z[NB * 128], s_hr[NB * 128], s_hj[NB * 128], s_root[NB * 36], s_rot[NB * 192];
+    __shared__ float s_Rl[NB * 32 * 9], s_Rg[NB * 32 * 9], s_pos[NB * 32 * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, K = a.K, Z = a.Z, H = a.H;
+    // A. prior distribution parameters and the sample (Z = 128 latent dims: rows r -> mu, r + Z -> raw std)
+    mid_rows<NB, 8>(2 * Z, wave, lane, B,
+        [&](int r) { return a.w_p2 + (size_t)r * 128; },
+        [&](int, int b) { return a.hid_prior + (size_t)b * 128; },
+        [&](int r, int b, float v) { (r < Z ? s_mu : s_sr)[b * 128 + (r < Z ? r : r - Z)] = v + a.b_p2[r]; });
+    __syncthreads();
+    for (int t = tid; t < B * Z; t += 512) {
+        const int b = t / Z, j = t % Z;
+        const float sg = softplus(s_sr[b * 128 + j]) + 1e-4f;
+        const float z = s_mu[b * 128 + j] + a.eps[(size_t)b * Z + j] * sg;
+        s_z[b * 128 + j] = z;
+        a.out_z[(size_t)b * a.ldz + j] = z;
+    }
+    __syncthreads();
+    // B. decoder hidden layers: z-half of the first layers + the h-half (and bias) the h-phase left in rh / jh
+    mid_rows<NB, 8>(256, wave, lane, B,
+        [&](int r) { return (r < 128 ? a.w_root0 : a.w_joint0) + (size_t)(r & 127) * (H + Z) + H; },
+        [&](int, int b) { return s_z + b * 128; },
+        [&](int r, int b, float v) {
+            const int rr = r & 127;
+            (r < 128 ? s_hr : s_hj)[b * 128 + rr] = lrelu(v + (r < 128 ? a.rh : a.jh)[(size_t)b * 128 + rr], 0.01f);
+        });
+    __syncthreads();
+    // C. heads: root / intensity (tanh) and 6-D rotations
+    const int R0 = 3 + K, J6 = 6 * K;
+    mid_rows<NB, 8>(R0 + J6, wave, lane, B,
+        [&](int r) { return r < R0 ? a.w_root2 + (size_t)r * 128 : a.w_joint2 + (size_t)(r - R0) * 128; },
+        [&](int r, int b) { return (r < R0 ? s_hr : s_hj) + b * 128; },
+        [&](int r, int b, float v) {
+            if (r < R0) s_root[b * 36 + r] = tanhf(v + a.b_root2[r]); else s_rot[b * 192 + r - R0] = v + a.b_joint2[r - R0];
+        });
+    __syncthreads();
+    // D. forward kinematics (fk_kernel with S = 1, no observation)
+    for (int t = tid; t < B * K; t += 512) {
+        const int b = t / K, k = t % K;
+        const float* p = s_rot + b * 192 + k * 6;
+        float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
+        float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
+        x0 /= nx; x1 /= nx; x2 /= nx;
+        float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+        float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
+        z0 /= nz; z1 /= nz; z2 /= nz;
+        float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
+        float* R = s_Rl + (b * 32 + k) * 9;
+        R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
+    }
+    __syncthreads();
+    if (tid < B) {
+        const int b = tid;
+        const float* rt = s_root + b * 36;
+        float* Rl = s_Rl + b * 32 * 9; float* Rg = s_Rg + b * 32 * 9; float* pos = s_pos + b * 32 * 3;
+        const int root = a.order[0];
+        for (int e = 0; e < 9; ++e) Rg[root * 9 + e] = Rl[root * 9 + e];
+        pos[root * 3 + 0] = rt[0]; pos[root * 3 + 1] = rt[1]; pos[root * 3 + 2] = rt[2];
+        for (int o = 1; o < K; ++o) {
+            const int idx = a.order[o], par = a.parents[idx];
+            const float* P = Rg + par * 9; const float* L = Rl + idx * 9;
+            float* G = Rg + idx * 9;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) G[r * 3 + c] = (P[r * 3] * L[c] + P[r * 3 + 1] * L[3 + c]) + P[r * 3 + 2] * L[6 + c];
+        }
+        for (int o = 1; o < K; ++o) {
+            const int idx = a.order[o], par = a.parents[idx];
+            const float* G = Rg + idx * 9; const float* of = a.offset + ((size_t)b * K + idx) * 3;
+            for (int r = 0; r < 3; ++r)
+                pos[idx * 3 + r] = ((G[r * 3] * of[0] + G[r * 3 + 1] * of[1]) + G[r * 3 + 2] * of[2]) + pos[par * 3 + r];
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < B * K * 4; t += 512) {
+        const int b = t / (K * 4), u = t % (K * 4), k = u >> 2, c = u & 3;
+        a.out_kp[(size_t)b * a.ldkp + u] = c < 3 ? s_pos[(b * 32 + k) * 3 + c] : (s_root[b * 36 + 3 + k] + 1.0f) * 0.5f;
+    }
+}
+
 // get_offset (hsvrnn_bvh.py:236-253): lower median over T of |p_k - p_parent(k)| times unit(offset_param[k])
 __global__ __launch_bounds__(64) void offsets_kernel(const float* __restrict__ kp, const float* __restrict__ offset_param,
                                                      const int32_t* __restrict__ parents, int T, int K, float* __restrict__ out) {
@@ -693,6 +820,10 @@ void add_job(LinJobs& J, const LinearW& L, int col0, const float* xa, int na, in
 
 int pick_nb(int batch) { return batch >= 8 ? 8 : (batch >= 4 ? 4 : (batch >= 2 ? 2 : 1)); }
 
+// prior steps of a rollout: 0 (default) six dependent launches, 1 three (vrnn_prior_mid_kernel).  Measured A/B (tools/time_rollout.py,
+// bit-identical outputs): 39.4 vs 60.6 us/step at B = 1, 43.2 vs 103.1 at B = 3 - one workgroup walking 680 weight rows and the serial
+// kinematic chain is slower than three wide launches, so the fused form stays off.
+int g_vrnn_mid = [] { const char* e = getenv("NM355_VRNN_MID"); return e ? atoi(e) : 0; }();
 #define NM_GEMM_MIN_BATCH 128
 int g_vrnn_gemm = [] { const char* e = getenv("NM355_VRNN_GEMM"); return e ? atoi(e) : 1; }();     // 0: one wavefront per output row at every batch size (A/B)
 
@@ -792,6 +923,21 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         LinearW hh; hh.in = H; hh.out = 3 * H; hh.w = w.w_hh; hh.b = w.b_hh;
         add_job(J, hh, 0, io.h, H, io.ldh, nullptr, 0, 0, true, nullptr, 0, 1, sb.gh, 3 * H, 0, B);
         if ((rc = launch_jobs(J, s))) return rc;
+    }
+    if (!post && B <= 4 && !io.tape && !io.out_R && !io.best && !io.kl && !io.rec && g_vrnn_mid && K <= 32 && Z == 128) {
+        // 2-4 in one workgroup (prior steps of a rollout): see vrnn_prior_mid_kernel
+        MidArgs a;
+        a.hid_prior = sb.hid_prior; a.rh = sb.rh; a.jh = sb.jh; a.eps = io.eps; a.offset = io.offset;
+        a.w_p2 = w.prior2.w; a.b_p2 = w.prior2.b; a.w_root0 = w.root0.w; a.w_joint0 = w.joint0.w;
+        a.w_root2 = w.root2.w; a.b_root2 = w.root2.b; a.w_joint2 = w.joint2.w; a.b_joint2 = w.joint2.b;
+        a.order = w.order; a.parents = w.parents;
+        a.out_kp = io.out_kp; a.ldkp = io.ldkp; a.out_z = io.out_z; a.ldz = io.ldz;
+        a.B = B; a.K = K; a.Z = Z; a.H = H;
+        if (B == 1) hipLaunchKernelGGL((vrnn_prior_mid_kernel<1>), dim3(1), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((vrnn_prior_mid_kernel<4>), dim3(1), dim3(512), 0, s, a);
+        if ((rc = nm_check_hip(hipGetLastError(), "vrnn_prior_mid launch"))) return rc;
+        if (io.hout && (rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s, nullptr, sb.gi))) return rc;
+        return NM_OK;
     }
     {   // 2. distribution parameters + samples
         DistJob jp{w.prior2.w, w.prior2.b, sb.hid_prior, sb.pmu, sb.psig, post ? nullptr : io.eps, sb.z, 1, io.tape ? io.tape->praw : nullptr};
