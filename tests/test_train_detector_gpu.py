@@ -293,3 +293,52 @@ def test_detector_gradients_batch_additivity_at_64cubed():
     _, g_ab2, _ = _hip_grads(o, sd, vox, AIST)
     for k, v in g_ab.items():
         assert torch.equal(v, g_ab2[k]), f"{k}: gradients differ between two runs"
+
+
+def test_config3_per_gpu_shape_training_step():
+    """BASELINE config 3's per-GPU shape (64^3, T = 16, B = 4 clips per GPU, detector-mode training step, train.py:376-412), no oracle
+    needed: (1) the loss of the training forward equals the inference forward's, (2) the gradient of the 4-clip batch is the average
+    of the four single-clip gradients (every loss is a mean over clips, GroupNorm is per frame), (3) two runs are bit-identical,
+    (4) DetectorTrainer.step - direct library calls into the all-reduce bucket - produces exactly the autograd path's gradients
+    and its Adam step moves every parameter."""
+    from neural_marionette_amd.train import DetectorTrainer, DETECTOR_LOSS_WEIGHTS
+    o, sd, vox = _setup(G=64, B=4, T=16, seed=91)
+    loss, g_all, out = _hip_grads(o, sd, vox, AIST)
+    # (1) inference forward on the same weights / clips
+    net = NeuralMarionette(o); net.load_state_dict(sd); net = net.cuda().eval(); net.anneal(1)
+    with torch.no_grad():
+        inf = net(vox.cuda(), {"detector": True, "learner": False})
+    loss_inf = float(sum(w * inf[k] for k, w in AIST.items()))
+    assert abs(loss - loss_inf) <= 1e-6 * max(1.0, abs(loss_inf)), (loss, loss_inf)
+    assert torch.equal(out["keypoints"].cpu(), inf["keypoints"].cpu())
+    # (2) batch additivity
+    acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in g_all.items()}
+    for b in range(4):
+        _, g_b, _ = _hip_grads(o, sd, vox[b:b + 1].contiguous(), AIST)
+        for k in acc:
+            acc[k] += g_b[k].double() / 4
+    gmax = max(v.abs().max().item() for v in g_all.values())
+    worst = 0.0
+    for k, v in g_all.items():
+        scale = max(acc[k].abs().max().item(), 1e-6 * gmax)
+        e = (v.double() - acc[k]).abs().max().item() / scale
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    print("config-3 shape: batch additivity worst relative deviation %.2e, loss %.6f" % (worst, loss))
+    # (3) run-to-run identity
+    _, g_again, _ = _hip_grads(o, sd, vox, AIST)
+    for k, v in g_all.items():
+        assert torch.equal(v, g_again[k]), f"{k}: gradients differ between two runs"
+    # (4) the trainer's direct path
+    net2 = NeuralMarionette(o); net2.load_state_dict(sd); net2 = net2.cuda().train(); net2.anneal(1)
+    before = {k: v.detach().clone() for k, v in net2.state_dict().items()}
+    tr = DetectorTrainer(net2, lr=4e-4)
+    log = tr.step(vox.cuda())
+    assert abs(log["loss"] - loss) <= 1e-6 * max(1.0, abs(loss))
+    for n, p in net2.kypt_detector.named_parameters():
+        k = "kypt_detector." + n
+        assert p.grad.data_ptr() == tr.bucket.views[k].data_ptr()
+        assert torch.equal(p.grad.cpu(), g_all[k]), f"{k}: trainer gradient differs from the autograd path"
+        if g_all[k].abs().max() > 0:
+            assert not torch.equal(p.detach(), before[k]), f"{k}: not updated"
+    assert set(log) >= {"loss", *[k for k in DETECTOR_LOSS_WEIGHTS]}
