@@ -342,3 +342,19 @@ def test_config3_per_gpu_shape_training_step():
         if g_all[k].abs().max() > 0:
             assert not torch.equal(p.detach(), before[k]), f"{k}: not updated"
     assert set(log) >= {"loss", *[k for k in DETECTOR_LOSS_WEIGHTS]}
+
+
+def test_vanishing_loss_weights_give_finite_proportional_gradients():
+    """Power-of-two operand scaling of the data-gradient convs (nm_grad.hip make_scale): with loss weights of 1e-30 every dy is
+    ~1e-30 and the scale 2^k must stay finite in both directions (the exponent is clamped to +-100): gradients finite and
+    proportional to the unscaled ones."""
+    o, sd, vox = _setup(G=32, B=1, T=3, seed=95)
+    _, g1, _ = _hip_grads(o, sd, vox, AIST)
+    tiny = {k: w * 1e-30 for k, w in AIST.items()}
+    _, g2, _ = _hip_grads(o, sd, vox, tiny)
+    gmax = max(v.abs().max().item() for v in g1.values())
+    for k, v in g1.items():
+        assert torch.isfinite(g2[k]).all(), k
+        scale = max(v.abs().max().item(), 1e-6 * gmax)
+        e = (g2[k].double() * 1e30 - v.double()).abs().max().item() / scale
+        assert e < 1e-3, (k, e)
