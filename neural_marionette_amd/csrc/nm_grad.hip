@@ -345,6 +345,227 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(WgradParams p) {
     }
 }
 
+// ---- wgrad16t: the same weight gradient through transposing LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------
+// wgrad16_kernel spends ~35-45 % of its time turning the channels-last tiles into [channel][voxel] planes with VALU before the first
+// MFMA, because v_mfma_f32_32x32x16_f16 wants 8 consecutive K (= voxels) of one channel per lane.  ds_read_b64_tr_b16 delivers a
+// 4 (rows = voxels) x 16 (columns = channels) block of 16-bit elements column-major: lane i of a 16-lane group receives column i of
+// the 4 rows.  So LDS keeps the natural channels-last fp16 tiles - [voxel][32 channels], 64 B per voxel, filled by plain 16-byte
+// stores - and an operand is two transposed reads (x = 0..3, 4..7 of a brick row).  A tap is just a row offset into the halo tile
+// (no register shifting for dx), the four reads of a 32-lane half cover 256 contiguous bytes (conflict-free), the staging is the
+// forward convs' activate + split, and a buffer is 66 KB: two of them, so the next brick is loaded (registers) and written (other
+// buffer) while the MFMAs of the current one run.  512 threads: the 27 taps are dealt to 8 waves (4, 4, 4, 3, 3, 3, 3, 3 - two
+// waves per SIMD), each holding its taps' accumulator pairs; per k-step of 16 voxels a wave reads the dY operand (4 transposed
+// reads) and its taps' X operands (4 each) and issues 3 MFMAs per tap.  Partials and the reduce are wgrad16_kernel's.
+#define WT_HV 400
+#define WT_BV 128
+#define WT_XB (WT_HV * 64)
+#define WT_DB (WT_BV * 64)
+#define WT_BUF (2 * WT_XB + 2 * WT_DB)
+#define WT_LDS (2 * WT_BUF)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 tr_read(const char* lds_ptr) {
+    // (take the 64-bit result as a whole: element-wise extraction of the builtin's vector is miscompiled by this hipcc)
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)lds_ptr));
+}
+__device__ __forceinline__ half8 tr_operand(const char* p) {
+    const u32x2 a = tr_read(p), b = tr_read(p + 4 * 64);
+    return __builtin_bit_cast(half8, u32x4{a[0], a[1], b[0], b[1]});
+}
+
+template <int DBG>      // 0: product; 1: no MFMA loop, 2: no staging after the first brick (timing experiments, NM355_W16_DBG)
+__global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
+    extern __shared__ char lds8[];
+    // per-frame GroupNorm scale / shift of this column tile's 32 input channels: [N][2][32] floats behind the two tile buffers, loaded
+    // once (a commit inside the k-loop must not wait for global memory)
+    float* xtab = reinterpret_cast<float*>(lds8 + WT_LDS);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tp = blockIdx.y, mt = tp / p.n_tiles, nt = tp % p.n_tiles, m0 = mt * 32, n0 = nt * 32;
+    const int ntaps = w < 3 ? 4 : 3;                      // taps w, w + 8, w + 16 (, w + 24)
+    f32x16 acc[4], accl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accl[j][r] = 0.f; }
+    // transposed-read addresses: lane 4q + pp of a 16-lane group supplies row q, columns 4pp .. 4pp + 3 of the group's block;
+    // group = (column block cb = (lane >> 4) & 1, lane half lh)
+    const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, cb = (lane >> 4) & 1;
+    const int a_lane = ((lh * 8 + q) * 32 + 16 * cb + 4 * pp) * 2;          // dY tile: brick row 2s + lh, voxel x0 + q
+    const int b_lane = ((lh * 10 + q) * 32 + 16 * cb + 4 * pp) * 2;         // X tile: halo row (z + tz, 2(s & 3) + lh + ty), voxel x0 + q + tx
+    int tapoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int t = min(w + 8 * j, 26); tapoff[j] = (((t / 9) * 10 + (t / 3) % 3) * 10 + t % 3) * 64; }
+
+    const int per_frame = p.nbz * p.nby * p.nbx, total = p.in.N * per_frame;
+    // staging roles: three (four for 64 threads) X items (halo voxel, channel octet) and one dY item per thread; octet = tid & 3
+    const int oct = tid & 3;
+    for (int i = tid; i < p.in.N * 64; i += 512) {        // (identity when the input carries no pending GroupNorm: the commit is branch-free)
+        const int n = i >> 6, which = (i >> 5) & 1, c = n0 + (i & 31);
+        xtab[i] = p.in.scale ? (c < p.Nc ? (which ? p.in.shift : p.in.scale)[(size_t)n * p.in.C + c] : 0.f) : (which ? 0.f : 1.f);
+    }
+    char* dummy = lds8 + WT_LDS + (size_t)p.in.N * 256;   // 32 B written by the threads without a fourth X item
+    f32x4 xa[4], xb[4], da, db, dsa, dsb, dha, dhb;
+    dsa = dsb = f32x4{1.f, 1.f, 1.f, 1.f}; dha = dhb = f32x4{0.f, 0.f, 0.f, 0.f};
+    int xn = 0, xoz = 0, xoy = 0, xox = 0;                // brick being fetched
+    // the next brick arrives in two instalments (registers): dY item + X items 0, 1 at the start of a brick, X items 2, 3 mid-brick
+    auto locate = [&](int b) __attribute__((always_inline)) {
+        xn = b / per_frame; int r = b % per_frame;
+        const int bx = r % p.nbx; r /= p.nbx;
+        xoz = (r / p.nby) * 2; xoy = (r % p.nby) * 8; xox = bx * 8;
+    };
+    // per X item: the thread's halo voxel as packed (hx, hy, hz) and as an element offset from the brick's first halo voxel; the
+    // brick part of every address is wave-uniform (scalar registers)
+    int hpack[4], hoffs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int hv = min((tid >> 2) + 128 * k, WT_HV - 1), hx = hv % 10, hy = (hv / 10) % 10, hz = hv / 100;
+        hpack[k] = hx | (hy << 8) | (hz << 16);
+        hoffs[k] = ((hz * p.in.H + hy) * p.in.W + hx) * p.in.C + n0 + 8 * oct;
+    }
+    unsigned inmask = 0;                                  // bit k: X item k of the brick being fetched lies inside the tensor
+    auto fetch = [&](int k0, int k1, bool with_dy) __attribute__((always_inline)) {
+        const int c = n0 + 8 * oct;
+        const long long base = ((((long long)xn * p.in.D + (xoz - 1)) * p.in.H + (xoy - 1)) * p.in.W + (xox - 1)) * (long long)p.in.C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < k0 || k >= k1) continue;
+            xa[k] = xb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int gx = xox - 1 + (hpack[k] & 255), gy = xoy - 1 + ((hpack[k] >> 8) & 255), gz = xoz - 1 + (hpack[k] >> 16);
+            const bool in = (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W &&
+                            (tid >> 2) + 128 * k < WT_HV;
+            inmask = (inmask & ~(1u << k)) | ((in ? 1u : 0u) << k);
+            if (in) {
+                const float* src = p.in.p + base + hoffs[k];
+                if (c < p.Nc) xa[k] = *reinterpret_cast<const f32x4*>(src);
+                if (c + 4 < p.Nc) xb[k] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+        }
+        if (with_dy) {
+            const int bv = tid >> 2, z = bv >> 6, y = (bv >> 3) & 7, x = bv & 7, m = m0 + 8 * oct;
+            const float* src = p.dy.p + ((((size_t)xn * p.dy.D + xoz + z) * p.dy.H + xoy + y) * p.dy.W + xox + x) * p.dy.C + m;
+            da = db = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < p.M) da = *reinterpret_cast<const f32x4*>(src);
+            if (m + 4 < p.M) db = *reinterpret_cast<const f32x4*>(src + 4);
+            if (p.dy.scale) {                             // (else they stay 1 / 0)
+                const float* ps = p.dy.scale + (size_t)xn * p.dy.C + m; const float* ph = p.dy.shift + (size_t)xn * p.dy.C + m;
+                if (m < p.M) { dsa = *reinterpret_cast<const f32x4*>(ps); dha = *reinterpret_cast<const f32x4*>(ph); }
+                if (m + 4 < p.M) { dsb = *reinterpret_cast<const f32x4*>(ps + 4); dhb = *reinterpret_cast<const f32x4*>(ph + 4); }
+            }
+        }
+    };
+    // (no branches from here to the store: the conversion of an item has to sit in the same basic block as the k-step's MFMAs for
+    //  the scheduler to interleave the two; slope 1 makes the leaky ReLU an identity, the tables hold 1 / 0 without a GroupNorm)
+    auto act_x = [&](int n, f32x4& a, f32x4& b) __attribute__((always_inline)) {
+        const float* t = xtab + n * 64 + 8 * oct;
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(t), sb = *reinterpret_cast<const f32x4*>(t + 4);
+        const f32x4 ha = *reinterpret_cast<const f32x4*>(t + 32), hb = *reinterpret_cast<const f32x4*>(t + 36);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = fmaf(a[j], sa[j], ha[j]); b[j] = fmaf(b[j], sb[j], hb[j]);
+            a[j] = fmaxf(a[j], a[j] * p.in.slope); b[j] = fmaxf(b[j], b[j] * p.in.slope);
+        }
+    };
+    auto act_d = [&](f32x4& a, f32x4& b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = fmaf(a[j], dsa[j], dha[j]); b[j] = fmaf(b[j], dsb[j], dhb[j]);
+            a[j] = fmaxf(a[j], a[j] * p.dy.slope); b[j] = fmaxf(b[j], b[j] * p.dy.slope);
+        }
+    };
+    auto split_store = [&](const f32x4& a, const f32x4& b, char* hi, char* lo) __attribute__((always_inline)) {
+        unsigned h[4], l[4];
+        h[0] = pack_split(a[0], a[1], l[0]); h[1] = pack_split(a[2], a[3], l[1]);
+        h[2] = pack_split(b[0], b[1], l[2]); h[3] = pack_split(b[2], b[3], l[3]);
+        *reinterpret_cast<u32x4*>(hi) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(lo) = u32x4{l[0], l[1], l[2], l[3]};
+    };
+    // slot 0..3: X items, slot 4: the dY item.  Unconditional: without a next brick the stale registers go to the idle buffer.
+    const float xa_on = n0 + 8 * oct < p.Nc ? 1.f : 0.f, xb_on = n0 + 8 * oct + 4 < p.Nc ? 1.f : 0.f;
+    const float da_on = m0 + 8 * oct < p.M ? 1.f : 0.f, db_on = m0 + 8 * oct + 4 < p.M ? 1.f : 0.f;
+    auto commit = [&](char* buf, int slot) __attribute__((always_inline)) {
+        if (slot < 4) {
+            const int hv = (tid >> 2) + 128 * slot;
+            f32x4 a = xa[slot], b = xb[slot];
+            act_x(xn, a, b);
+            // zero padding, not act(0); as a multiplication (the item's registers are zero, act(0) is finite): a select would be
+            // turned into a branch around the conversion
+            const float in = (float)((inmask >> slot) & 1), ka = in * xa_on, kb = in * xb_on;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] *= ka; b[j] *= kb; }
+            char* hi = buf + hv * 64 + oct * 16; char* lo = hi + WT_XB;
+            if (slot == 3) { const bool item = hv < WT_HV; hi = item ? hi : dummy; lo = item ? lo : dummy + 16; }
+            split_store(a, b, hi, lo);
+        } else {
+            const int bv = tid >> 2;
+            f32x4 a = da, b = db;
+            act_d(a, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] *= da_on; b[j] *= db_on; }
+            split_store(a, b, buf + 2 * WT_XB + bv * 64 + oct * 16, buf + 2 * WT_XB + WT_DB + bv * 64 + oct * 16);
+        }
+    };
+
+    int b = blockIdx.x, cur = 0;
+    if (b < total) {
+        locate(b); fetch(0, 4, true);
+#pragma unroll
+        for (int sl = 0; sl < 5; ++sl) commit(lds8, sl);
+    }
+    __syncthreads();
+    for (; b < total; b += p.S) {
+        const bool has_next = b + p.S < total && DBG != 2;
+        const char* buf = lds8 + cur * WT_BUF;
+        char* nbuf = lds8 + (cur ^ 1) * WT_BUF;
+        // the next brick comes through registers one item at a time (dY item, then the four X items), each written to the other
+        // buffer two or three k-steps (5000+ cycles) after its loads were issued: at most two items are live at once - with all
+        // five in flight the kernel spills, and a scratch reload queues behind the outstanding global loads (vmcnt is in order)
+        if (has_next) { locate(b + p.S); fetch(0, 1, true); }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            if (has_next) {
+                if (s8 == 2) fetch(1, 2, false);
+                if (s8 == 3) fetch(2, 3, false);
+                if (s8 == 4) fetch(3, 4, false);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the item conversion (branch-free) ahead of the k-step's operand reads
+            constexpr int slot_of[8] = {-1, -1, 4, 0, 1, -1, 2, 3};
+            if (DBG != 2 && slot_of[s8] >= 0) commit(nbuf, slot_of[s8]);
+            if (DBG == 1) continue;
+            const char* ap = buf + 2 * WT_XB + a_lane + s8 * 1024;
+            const half8 ah = tr_operand(ap), al = tr_operand(ap + WT_DB);
+            const char* xp = buf + b_lane + (((s8 >> 2) * 10 + 2 * (s8 & 3)) * 10) * 64;
+            {
+                half8 bh[3], bl[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { bh[u] = tr_operand(xp + tapoff[u]); bl[u] = tr_operand(xp + WT_XB + tapoff[u]); }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) accl[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], accl[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) accl[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], accl[u], 0, 0, 0);
+            }
+            if (ntaps == 4) {                             // waves 0..2
+                const half8 bh = tr_operand(xp + tapoff[3]), bl = tr_operand(xp + WT_XB + tapoff[3]);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[3], 0, 0, 0);
+                accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accl[3], 0, 0, 0);
+                accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accl[3], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= ntaps) continue;
+        const int t = w + 8 * j;
+        float* dst = p.part + (((size_t)blockIdx.x * gridDim.y + tp) * 27 + t) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][r] + accl[j][r] * (1.0f / W16_SPLIT);
+    }
+}
+
 // ---- first layer, sparse form ----------------------------------------------------------------------------------------------------
 // dW[co][c][tap] of conv5(cat[occ, x1, x2, x3]): the three coordinate channels do not depend on the frame, so their gradient is
 // the dense kernel (MODE 2) on ONE frame holding sum_n dy[n]; the occupancy channel is 1-3 % dense, so its gradient is a gather:
@@ -747,7 +968,26 @@ int launch_wgrad_t(const WgradPlan& q, hipStream_t s) {
     return nm_check_hip(hipGetLastError(), "wgrad launch");
 }
 
+int g_wgrad_tr = [] { const char* e = getenv("NM355_WGRAD_TR"); return e ? atoi(e) : 1; }();   // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel (transposing LDS reads); A/B in profiles/r02_wgrad16t_ab.txt
+
 int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
+    if (g_wgrad_tr && q.p.in.N <= 96) {                       // (the per-frame scale / shift table of wgrad16t_kernel lives in LDS: 256 B per frame)
+        static bool attr_t = false;
+        if (!attr_t) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                nm_set_error("wgrad16t: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
+            }
+            attr_t = true;
+        }
+        const size_t ldsb = WT_LDS + (size_t)q.p.in.N * 64 * sizeof(float) + 64;
+        const dim3 grid(q.p.S, q.m_tiles * q.p.n_tiles);
+        if (q.p.dbg == 1) hipLaunchKernelGGL(wgrad16t_kernel<1>, grid, dim3(512), ldsb, s, q.p);
+        else if (q.p.dbg == 2) hipLaunchKernelGGL(wgrad16t_kernel<2>, grid, dim3(512), ldsb, s, q.p);
+        else hipLaunchKernelGGL(wgrad16t_kernel<0>, grid, dim3(512), ldsb, s, q.p);
+        return nm_check_hip(hipGetLastError(), "wgrad16t launch");
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {

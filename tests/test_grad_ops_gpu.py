@@ -174,3 +174,16 @@ def test_gn_backward(ctx, C, groups, size, N, slope):
     assert relerr(db.cpu(), bet.grad) < REL
     ref_bias = y.grad.sum(dim=(0, 2, 3, 4))
     assert (dbias.cpu() - ref_bias).abs().max().item() < REL * max(y.grad.abs().sum(dim=(0, 2, 3, 4)).max().item(), 1e-30)
+
+
+def test_conv3d_backward_valu_transposition_wgrad_variant():
+    """The older weight-gradient kernel (wgrad16_kernel, VALU transposition; A/B partner of the default wgrad16t_kernel,
+    profiles/r02_wgrad16t_ab.txt, and the path for more than 96 frames) is selected when the library loads, so its parity run is a
+    child process with NM355_WGRAD_TR=0."""
+    import os, subprocess, sys
+    env = dict(os.environ, NM355_WGRAD_TR="0")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-k", "test_conv3d_backward and split16 and k3 and not variant"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
