@@ -128,9 +128,29 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
                         hbm_gb_taken_by_training=(free0 - free1) / 2 ** 30,
                         algorithmic_tflop_per_step=3.0 * STEP_TFLOP,
                         frac_of_f16_mfma_peak=3.0 * STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS)
+    # the same step in the reduced-precision conv mode (BASELINE configs[2] names bf16): products of fp16-rounded operands, fp32
+    # accumulation / storage / master weights - see include/nm355.h nm_set_conv_mode 3
+    with torch.no_grad():
+        net.load_state_dict(saved)
+    net.set_conv_mode("f16")
+    tr = DetectorTrainer(net, lr=4e-4)
+    step = lambda: tr.step(vox, sync=False)
+    ms = timed(step, 2, 5) * 1e3
+    out["train_f16"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=5, warmup=2,
+                            workload="the `train` step in conv mode 'f16'",
+                            dtype="f32 storage and accumulation, conv products of fp16-rounded operands (1 f16 MFMA per product; gradients "
+                                  "within 1e-2 global L2 of fp64, tests/test_train_detector_gpu.py::test_detector_gradients_f16_mode)",
+                            n_gpus=world, algorithmic_tflop_per_step=3.0 * STEP_TFLOP,
+                            frac_of_f16_mfma_peak=3.0 * STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS)
     with torch.no_grad():
         net.load_state_dict(saved)
     net.eval()
+    ms = timed(fwd, 1, 4) * 1e3
+    out["f16_forward"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=4,
+                              dtype="conv products of fp16-rounded operands, f32 elsewhere (outside the 1e-4 parity contract: keypoints "
+                                    "within 2e-3 of the CPU reference)",
+                              frac_of_f16_mfma_peak=STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS)
+    net.set_conv_mode("split16")
     return out
 
 
@@ -144,7 +164,7 @@ def main():
     ap.add_argument("--workload", choices=["forward", "train"], default="forward",
                     help="forward (default, BASELINE configs[1]): full NeuralMarionette.forward; train (configs[2] shape, fp32): one "
                          "detector-mode training step = forward + backward + gradient all-reduce + Adam")
-    ap.add_argument("--conv-mode", choices=["split16", "fp32"], default="split16",
+    ap.add_argument("--conv-mode", choices=["split16", "fp32", "f16"], default="split16",
                     help="split16: fp32-equivalent 3x f16 MFMA products (default); fp32: exact fp32 MFMA everywhere")
     args = ap.parse_args()
 
@@ -258,7 +278,8 @@ def main():
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
             higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype=("f32 (conv products as 3x f16-split MFMA with f32 accumulate, fp32-equivalent; everything else f32)"
-                   if eng.conv_mode == 1 else "f32"),
+                   if eng.conv_mode == 1 else ("f16 conv products (operands rounded to fp16, 1 MFMA per product), f32 accumulation and storage"
+                                               if eng.conv_mode == 3 else "f32")),
             data="synthetic",
             config=dict(workload=("AIST++-shaped synthetic clips 64^3 T=16 B=4/GPU, full NeuralMarionette.forward "
                                   "(detector + 11 losses + HSVRNNBVH.encode, best-of-10), fp32, random-init weights") if args.workload == "forward" else
@@ -268,8 +289,8 @@ def main():
                         parallelism=f"clip-sharded x{world} (no data-path collective)"),
             roofline=roof, cpu_baseline=cpu, kypt_l2_vs_cpu=l2,
             step_roofline=dict(algorithmic_tflop_per_step=STEP_TFLOP, achieved=STEP_TFLOP * world / (dt / args.steps),
-                               unit="TFLOP/s", peak=F16_MFMA_PEAK_TFLOPS * world if eng.conv_mode == 1 else FP32_MFMA_PEAK_TFLOPS * world,
-                               frac=STEP_TFLOP / (dt / args.steps) / (F16_MFMA_PEAK_TFLOPS if eng.conv_mode == 1 else FP32_MFMA_PEAK_TFLOPS),
+                               unit="TFLOP/s", peak=F16_MFMA_PEAK_TFLOPS * world if eng.conv_mode else FP32_MFMA_PEAK_TFLOPS * world,
+                               frac=STEP_TFLOP / (dt / args.steps) / (F16_MFMA_PEAK_TFLOPS if eng.conv_mode else FP32_MFMA_PEAK_TFLOPS),
                                note="whole forward step: 99.15 GFLOP per voxel-frame (BASELINE.md, the reference's dense fp32 conv "
                                     "arithmetic) x 64 frames; the split-fp16 kernels issue 3 f16 MFMA products per algorithmic product"
                                ) if args.workload == "forward" else None,

@@ -283,7 +283,12 @@ int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, in
  * fp32 — error within one fp32 rounding of the exact product, same tolerance class as the fp32 fma
  * chain, 16x/3 the MFMA rate.  mode 2 = mode 1 with the producer/consumer kernel (conv_f16p) on every layer it
  * supports instead of the Cout == 32 layers only (same arithmetic; a test / measurement switch).  Parity tests run in
- * all modes. */
+ * all modes.  mode 3 = reduced precision for training at autocast-class accuracy (BASELINE.json config 3 names bf16): the
+ * kernels of mode 1 with only the x_hi*w_hi product, i.e. operands rounded to fp16 (11 significant bits - three more than
+ * bf16, same MFMA rate), fp32 accumulation, fp32 tensors, statistics, losses, master weights and optimiser; the layers mode 1
+ * leaves on the fp32 cores (k = 1 / 2 weight gradients, volumes under 16^3, heads, VRNN) stay fp32.  Forward, data and weight
+ * gradients all follow the mode.  Outputs differ from the reference's fp32 path by ~1e-3 relative (tests state the bound);
+ * the 1e-4 parity contract holds in modes 0-2 only. */
 int nm_set_conv_mode(nm_ctx* ctx, int32_t mode);
 int nm_get_conv_mode(nm_ctx* ctx);
 

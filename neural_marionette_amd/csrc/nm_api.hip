@@ -164,7 +164,7 @@ int nm_ctx_set_training(nm_ctx* ctx, int32_t on) {
 }
 
 int nm_set_conv_mode(nm_ctx* ctx, int32_t mode) {
-    if (!ctx || mode < 0 || mode > 2) { nm_set_error("set_conv_mode: mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA) or 2 (split-fp16, conv_f16p wherever eligible)"); return NM_ERR_ARG; }
+    if (!ctx || mode < 0 || mode > 3) { nm_set_error("set_conv_mode: mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA), 2 (split-fp16, conv_f16p wherever eligible) or 3 (fp16 products, fp32 accumulation)"); return NM_ERR_ARG; }
     nm_conv_set_mode(mode);
     return NM_OK;
 }

@@ -21,6 +21,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Second and third product of the split-fp16 scheme (hi*lo, lo*hi).  SINGLE = the reduced-precision mode (nm_set_conv_mode 3): products
+// of the fp16-rounded operands only, fp32 accumulation - what a bf16 / fp16 autocast training step computes; the operand loads that
+// only feed these calls disappear with them.
+typedef _Float16 nm_half8 __attribute__((ext_vector_type(8)));
+template <bool SINGLE>
+__device__ __forceinline__ f32x16 nm_mfma_lo(nm_half8 a, nm_half8 b, f32x16 c) {
+    if constexpr (SINGLE) return c;
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 
 // A tensor reference with an optional pending per-(n,c) affine + leaky-relu.
 struct TensorRef {
@@ -57,6 +67,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
 // conv arithmetic: 0 = exact fp32 MFMA, 1 = split-fp16 MFMA (3 products, fp32 accumulate) where Cin % 16 == 0
 void nm_conv_set_mode(int mode);
 int nm_conv_get_mode();
+int nm_conv_single();            // 1 in conv mode 3 (hi x hi products only)
 int nm_launch_pack_conv_weight16(const float* w_oidhw, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s);
 // first layer: occupancy channel as a taps-as-K GEMM + weight-only constant field (see nm_conv.hip)
 int nm_occ_blocks_per_frame(int G);

@@ -128,7 +128,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, half8& hi
 // fewer voxels per frame a launch is one short wave of workgroups, each a serial chain of K/2 fp32 MFMAs of 64 cycles; the
 // split product (3 MFMAs of 32 cycles per 16 channels) cuts the chain ~4x.  The fp32 tile in LDS is split per tap (2 LDS
 // reads + 20 VALU per 3 NT MFMAs: the chain, not the throughput, is what these launches wait for).
-template <int NT>
+template <int NT, bool SINGLE = false>
 __device__ __forceinline__ void mfma_chunk16(const ConvParams& p, const f32x4* lds, const half8* __restrict__ wq, size_t tap_stride,
                                              int taps, int h, int arow, f32x16 (&acc)[1][NT], f32x16 (&accl)[NT], int tap0 = 0, int tstep = 1) {
     const size_t plane = (size_t)p.Co_pad;
@@ -146,8 +146,8 @@ __device__ __forceinline__ void mfma_chunk16(const ConvParams& p, const f32x4* l
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bh[nt], acc[0][nt], 0, 0, 0);
-            accl[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bl[nt], accl[nt], 0, 0, 0);
-            accl[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bh[nt], accl[nt], 0, 0, 0);
+            accl[nt] = nm_mfma_lo<SINGLE>(hi, bl[nt], accl[nt]);
+            accl[nt] = nm_mfma_lo<SINGLE>(lo, bh[nt], accl[nt]);
         }
     }
 }
@@ -416,7 +416,7 @@ __device__ __forceinline__ float dpp_sum32(float x) {
 // workgroup while staging), so the result is fp32-equivalent for any input.  K = taps: k-step ks, lane half h, element j
 // is tap 16 ks + 8 h + j (taps >= 125 carry zero weights).
 typedef _Float16 occ_half8 __attribute__((ext_vector_type(8)));
-template <int NT>
+template <int NT, bool SINGLE = false>
 __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     __shared__ _Float16 tile_h[8 * 12 * 12], tile_l[8 * 12 * 12];
     __shared__ float red[512];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah, acc[mt][nt], 0, 0, 0);
-                accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah, accl[mt][nt], 0, 0, 0);
+                accl[mt][nt] = nm_mfma_lo<SINGLE>(bl[nt], ah, accl[mt][nt]);
             }
             if (need_lo) {
 #pragma unroll
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
                     al[j] = tile_l[arow[mt] + off];
                 }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al, accl[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = nm_mfma_lo<SINGLE>(bh[nt], al, accl[mt][nt]);
             }
         }
     }
@@ -781,7 +781,7 @@ __device__ __forceinline__ BrickPos super_tile_item(const ConvParams& p, int b, 
 // then hit 16 distinct 16-B slots (conflict-free; the natural (y,x) tile order is a 3-way conflict and makes the
 // Cout = 32 layers LDS-bound).  Staging: thread -> one (halo row position, lane half), loops over the halo planes, so
 // all index arithmetic and the y/x interpolation weights are computed once per kernel.
-template <int MT, int NT, int KS, bool UP2>
+template <int MT, int NT, int KS, bool UP2, bool SINGLE = false>
 __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     constexpr int HZ = KS + 3;                                     // halo planes of a 4-deep brick, stride 1
     constexpr int HB = HZ / 2;                                     // planes per load batch
@@ -1087,18 +1087,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bhv[c], acc[0][0], 0, 0, 0);
                     if (t < 8) { bhv[c ^ 1] = bb[(t + 1) * 128]; blv[c ^ 1] = bb[(t + 1) * 128 + 64]; }
                     __builtin_amdgcn_sched_barrier(0);
-                    accl[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, blv[c], accl[0][0], 0, 0, 0);
+                    accl[0][0] = nm_mfma_lo<SINGLE>(ah0, blv[c], accl[0][0]);
                     ah0 = a_h[arow[0] + nxt];
                     __builtin_amdgcn_sched_barrier(0);
                     acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bhv[c], acc[MT - 1][0], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    accl[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, blv[c], accl[MT - 1][0], 0, 0, 0);
+                    accl[MT - 1][0] = nm_mfma_lo<SINGLE>(ah1, blv[c], accl[MT - 1][0]);
                     ah1 = a_h[arow[MT - 1] + nxt];
                     __builtin_amdgcn_sched_barrier(0);
-                    accl[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bhv[c], accl[0][0], 0, 0, 0);
+                    accl[0][0] = nm_mfma_lo<SINGLE>(al0, bhv[c], accl[0][0]);
                     al0 = a_l[arow[0] + nxt];
                     __builtin_amdgcn_sched_barrier(0);
-                    accl[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bhv[c], accl[MT - 1][0], 0, 0, 0);
+                    accl[MT - 1][0] = nm_mfma_lo<SINGLE>(al1, bhv[c], accl[MT - 1][0]);
                     al1 = a_l[arow[MT - 1] + nxt];
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1143,11 +1143,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[0][nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[0][nt], accl[mt][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = nm_mfma_lo<SINGLE>(ah[mt], bl[0][nt], accl[mt][nt]);
                         ah[mt] = a_h[arow[mt] + nxt];
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[0][nt], accl[mt][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt) accl[mt][nt] = nm_mfma_lo<SINGLE>(al[mt], bh[0][nt], accl[mt][nt]);
                         al[mt] = a_l[arow[mt] + nxt];
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
 // channel chunks of one wave read each 128-byte line completely, back to back.  The generic fp32 kernel staged these layers
 // 8-16 channels per pass with 512 workgroups in flight and fetched the 64^3 x 32 input 2.7x from HBM (PMC FETCH_SIZE).
 // The kernel is bound by that one read of the input; weights (8 taps, a few KB per chunk) come from L2.
-template <int NT>
+template <int NT, bool SINGLE = false>
 __global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
     __shared__ float red[4 * NT * 32 * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1239,8 +1239,8 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
-                    accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], accl[mt][nt], 0, 0, 0);
-                    accl[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], accl[mt][nt], 0, 0, 0);
+                    accl[mt][nt] = nm_mfma_lo<SINGLE>(ah, bl[nt], accl[mt][nt]);
+                    accl[mt][nt] = nm_mfma_lo<SINGLE>(al, bh[nt], accl[mt][nt]);
                 }
             }
         }
@@ -1302,7 +1302,7 @@ template <int V> using ic = std::integral_constant<int, V>;
 //   LDS: halo [2 buffers][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [3][9 taps][4 planes][32] x 16 B, GroupNorm scratch.
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-template <bool UP2>
+template <bool UP2, bool SINGLE = false>
 __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
     constexpr int HV = 600, ZP = 100, HX = 10;
     constexpr int GB = 9 * 4 * 32;                                  // half8 slots of one weight group
@@ -1659,8 +1659,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             gap(ic<0>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(ah0[i], blv[i]);
-            if constexpr (tt == 0 && with_epi) accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blv[i], ah0[i], zero16, 0, 0, 0);
-            else accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blv[i], ah0[i], accl[0], 0, 0, 0);
+            if constexpr (tt == 0 && with_epi) accl[0] = nm_mfma_lo<SINGLE>(blv[i], ah0[i], zero16);
+            else accl[0] = nm_mfma_lo<SINGLE>(blv[i], ah0[i], accl[0]);
             ah0[j] = lds_read16_untracked<AO>(vau);
             gap(ic<1>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -1671,18 +1671,18 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             gap(ic<2>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(ah1[i], blv[i]);
-            if constexpr (tt == 0 && with_epi) accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blv[i], ah1[i], zero16, 0, 0, 0);
-            else accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blv[i], ah1[i], accl[1], 0, 0, 0);
+            if constexpr (tt == 0 && with_epi) accl[1] = nm_mfma_lo<SINGLE>(blv[i], ah1[i], zero16);
+            else accl[1] = nm_mfma_lo<SINGLE>(blv[i], ah1[i], accl[1]);
             ah1[j] = lds_read16_untracked<AO + YO>(vau);
             gap(ic<3>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(al0[i], bhv[i]);
-            accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], al0[i], accl[0], 0, 0, 0);
+            accl[0] = nm_mfma_lo<SINGLE>(bhv[i], al0[i], accl[0]);
             al0[j] = lds_read16_untracked<AO + LO>(vau);
             gap(ic<4>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(al1[i], bhv[i]);
-            accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], al1[i], accl[1], 0, 0, 0);
+            accl[1] = nm_mfma_lo<SINGLE>(bhv[i], al1[i], accl[1]);
             al1[j] = lds_read16_untracked<AO + LO + YO>(vau);
             gap(ic<5>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
 //   * LDS: two weight buffers (2 x 36 KB) instead of three, so the B operands of a tap group's first tap are read after
 //     the barrier that publishes them; operands one tap (12 MFMAs) ahead, double buffered.
 //   LDS: halo [2][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [2][9 taps][4 planes][64] x 16 B, GroupNorm scratch, bias.
-template <bool UP2>
+template <bool UP2, bool SINGLE = false>
 __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
     constexpr int HV = 600, ZP = 100, HX = 10;
     constexpr int GB = 9 * 4 * 64;                                  // half8 slots of one weight group
@@ -1973,18 +1973,19 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             constexpr bool bnext = t < 8;                           // the next tap's weights are in this group's buffer
             constexpr int BN = (t + 1) * 256 * 16;
 #define NM_MFMA2(ACC, B, A) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(B, A, ACC, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+#define NM_MFMA2L(ACC, B, A) ACC = nm_mfma_lo<SINGLE>(B, A, ACC); __builtin_amdgcn_sched_barrier(0)
             NM_MFMA2(acc[0][0], bh0[i], ah0[i]);  ah0[j] = lds_read16_untracked<AO>(vau);
             NM_MFMA2(acc[0][1], bh1[i], ah0[i]);  al0[j] = lds_read16_untracked<AO + LO>(vau);
-            NM_MFMA2(accl[0][0], bl0[i], ah0[i]); ah1[j] = lds_read16_untracked<AO + YO>(vau);
-            NM_MFMA2(accl[0][1], bl1[i], ah0[i]); al1[j] = lds_read16_untracked<AO + LO + YO>(vau);
-            NM_MFMA2(accl[0][0], bh0[i], al0[i]); if constexpr (bnext) bh0[j] = lds_read16_untracked<BN>(vb);
-            NM_MFMA2(accl[0][1], bh1[i], al0[i]); if constexpr (bnext) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb);
+            NM_MFMA2L(accl[0][0], bl0[i], ah0[i]); ah1[j] = lds_read16_untracked<AO + YO>(vau);
+            NM_MFMA2L(accl[0][1], bl1[i], ah0[i]); al1[j] = lds_read16_untracked<AO + LO + YO>(vau);
+            NM_MFMA2L(accl[0][0], bh0[i], al0[i]); if constexpr (bnext) bh0[j] = lds_read16_untracked<BN>(vb);
+            NM_MFMA2L(accl[0][1], bh1[i], al0[i]); if constexpr (bnext) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb);
             NM_MFMA2(acc[1][0], bh0[i], ah1[i]);  if constexpr (bnext) bl0[j] = lds_read16_untracked<BN + 128 * 16>(vb);
             NM_MFMA2(acc[1][1], bh1[i], ah1[i]);  if constexpr (bnext) bl1[j] = lds_read16_untracked<BN + 160 * 16>(vb);
-            NM_MFMA2(accl[1][0], bl0[i], ah1[i]);
-            NM_MFMA2(accl[1][1], bl1[i], ah1[i]);
-            NM_MFMA2(accl[1][0], bh0[i], al1[i]);
-            NM_MFMA2(accl[1][1], bh1[i], al1[i]);
+            NM_MFMA2L(accl[1][0], bl0[i], ah1[i]);
+            NM_MFMA2L(accl[1][1], bl1[i], ah1[i]);
+            NM_MFMA2L(accl[1][0], bh0[i], al1[i]);
+            NM_MFMA2L(accl[1][1], bh1[i], al1[i]);
             if constexpr (t == 8) {
                 // tap-group end: the producers publish the next group's weights (and, at the second barrier, the next tile)
                 asm volatile("s_barrier" ::: "memory");
@@ -2153,12 +2154,15 @@ void choose_super_tile(ConvParams& p, int nblocks, int nbz, int nby, int nbx) {
     p.st_z = sz; p.st_y = 4; p.st_x = 4;
 }
 
-template <int MT, int NT, int KS, bool UP2>
-int launch_f16s(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t s) {
+// conv mode 3: the split-fp16 kernels keep only the hi x hi product (SINGLE instantiations)
+int g_single = 0;
+
+template <int MT, int NT, int KS, bool UP2, bool SINGLE>
+int launch_f16s_impl(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t s) {
     ConvParams p = p_in;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT, KS, UP2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT, KS, UP2, SINGLE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16s)");
         attr_set = true;
@@ -2171,32 +2175,40 @@ int launch_f16s(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t 
     }
     dim3 pgrid(min(grid.x, 512u), grid.y);                          // persistent: ~2 resident workgroups per CU
     choose_super_tile(p, (int)pgrid.x, p.nbz, p.nby, p.nbx);
-    hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2>), pgrid, dim3(256), t.lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2, SINGLE>), pgrid, dim3(256), t.lds_bytes, s, p);
     if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
 }
+template <int MT, int NT, int KS, bool UP2>
+int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
+    return g_single ? launch_f16s_impl<MT, NT, KS, UP2, true>(p, t, grid, s) : launch_f16s_impl<MT, NT, KS, UP2, false>(p, t, grid, s);
+}
 
-template <int NT>
-int launch_pool_f16s(const ConvParams& p, dim3 grid, hipStream_t s) {
+template <int NT, bool SINGLE>
+int launch_pool_f16s_impl(const ConvParams& p, dim3 grid, hipStream_t s) {
     ProfRec rec;
     if (NM_PROF_ON(s)) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 8;
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 8.0;
         (void)hipEventRecord(rec.a, s);
     }
-    hipLaunchKernelGGL((conv_pool_f16s_kernel<NT>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_pool_f16s_kernel<NT, SINGLE>), grid, dim3(256), 0, s, p);
     if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_pool_f16s launch");
+}
+template <int NT>
+int launch_pool_f16s(const ConvParams& p, dim3 grid, hipStream_t s) {
+    return g_single ? launch_pool_f16s_impl<NT, true>(p, grid, s) : launch_pool_f16s_impl<NT, false>(p, grid, s);
 }
 
 int g_num_cus = 0;
 
-template <bool UP2>
-int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
+template <bool UP2, bool SINGLE>
+int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
     ConvParams p = p_in;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2, SINGLE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p)");
         attr_set = true;
@@ -2214,17 +2226,21 @@ int launch_f16p(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStr
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 32) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
-    hipLaunchKernelGGL((conv_f16p_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16p_kernel<UP2, SINGLE>), grid, dim3(512), lds_bytes, s, p);
     if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
-
 template <bool UP2>
-int launch_f16p2(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
+int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
+    return g_single ? launch_f16p_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p_impl<UP2, false>(p, lds_bytes, work_items, s);
+}
+
+template <bool UP2, bool SINGLE>
+int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
     ConvParams p = p_in;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p2_kernel<UP2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p2_kernel<UP2, SINGLE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p2)");
         attr_set = true;
@@ -2242,9 +2258,13 @@ int launch_f16p2(const ConvParams& p_in, size_t lds_bytes, int work_items, hipSt
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
-    hipLaunchKernelGGL((conv_f16p2_kernel<UP2>), grid, dim3(512), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16p2_kernel<UP2, SINGLE>), grid, dim3(512), lds_bytes, s, p);
     if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p2 launch");
+}
+template <bool UP2>
+int launch_f16p2(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
+    return g_single ? launch_f16p2_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p2_impl<UP2, false>(p, lds_bytes, work_items, s);
 }
 
 #ifdef NM_DIAG
@@ -2266,8 +2286,9 @@ bool g_f16p_all = false;  // mode 2: split-fp16 with conv_f16p on every eligible
 #ifdef NM_DIAG
 extern "C" void nm_diag_set_stamps(void* p) { g_stamps = static_cast<unsigned long long*>(p); }
 #endif
-void nm_conv_set_mode(int mode) { g_conv_mode = mode ? 1 : 0; g_f16p_all = mode == 2; }
-int nm_conv_get_mode() { return g_conv_mode && g_f16p_all ? 2 : g_conv_mode; }
+void nm_conv_set_mode(int mode) { g_conv_mode = mode ? 1 : 0; g_f16p_all = mode == 2; g_single = mode == 3; }
+int nm_conv_get_mode() { return g_conv_mode && g_single ? 3 : (g_conv_mode && g_f16p_all ? 2 : g_conv_mode); }
+int nm_conv_single() { return g_conv_mode && g_single; }
 
 int nm_launch_pack_conv_weight16(const float* w, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s) {
     if (Co_pad % 32 || Cout > Co_pad) { nm_set_error("pack_conv_weight16: bad padding Cout=%d/%d", Cout, Co_pad); return NM_ERR_ARG; }   // (channels beyond Cin: zero)
@@ -2449,8 +2470,8 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
         (void)hipEventRecord(rec.a, s);
     }
     if (g_conv_mode == 1 && g_occ16) {
-        if (NT == 2) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1>), grid, dim3(256), 0, s, p);
+        if (NT == 2) { if (g_single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<2>), grid, dim3(256), 0, s, p); }
+        else { if (g_single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1>), grid, dim3(256), 0, s, p); }
     } else if (NT == 2) hipLaunchKernelGGL((conv_k5occ_kernel<2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_k5occ_kernel<1>), grid, dim3(256), 0, s, p);
     if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }

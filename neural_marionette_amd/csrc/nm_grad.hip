@@ -227,12 +227,13 @@ __device__ __forceinline__ half8 w16_shift(const u32x4& q, unsigned e) {
 }
 #define W16_MMA(ACC, ACCL, AH, AL, BH, BL)                                   \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);      \
-    ACCL = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, ACCL, 0, 0, 0);    \
-    ACCL = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, ACCL, 0, 0, 0);
+    ACCL = nm_mfma_lo<SINGLE>(AH, BL, ACCL);                                 \
+    ACCL = nm_mfma_lo<SINGLE>(AL, BH, ACCL);
 
 // Taps per wave: two full (dz, dy) row groups {w, w + 4} (3 dx taps each, one LDS read pair per group) and, for waves 1..3, the tap
 // dx = w - 1 of the ninth group: 6, 7, 7, 7 taps.  The global loads of the next brick are issued before the MFMA phase of the
 // current one (the only wave on its SIMD has nothing else to hide them behind) and converted / written to LDS after it.
+template <bool SINGLE>
 __global__ __launch_bounds__(256) void wgrad16_kernel(WgradParams p) {
     extern __shared__ char lds8[];
     char* A_hi = lds8; char* A_lo = A_hi + 32 * W16_PA; char* D_hi = A_lo + 32 * W16_PA; char* D_lo = D_hi + 32 * W16_PD;
@@ -373,7 +374,7 @@ __device__ __forceinline__ half8 tr_operand(const char* p) {
     return __builtin_bit_cast(half8, u32x4{a[0], a[1], b[0], b[1]});
 }
 
-template <int DBG>      // 0: product; 1: no MFMA loop, 2: no staging after the first brick (timing experiments, NM355_W16_DBG)
+template <int DBG, bool SINGLE = false>      // DBG 0: product; 1: no MFMA loop, 2: no staging after the first brick (timing experiments, NM355_W16_DBG)
 __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
     extern __shared__ char lds8[];
     // per-frame GroupNorm scale / shift of this column tile's 32 input channels: [N][2][32] floats behind the two tile buffers, loaded
@@ -542,15 +543,15 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
 #pragma unroll
                 for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) accl[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], accl[u], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) accl[u] = nm_mfma_lo<SINGLE>(ah, bl[u], accl[u]);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) accl[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], accl[u], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) accl[u] = nm_mfma_lo<SINGLE>(al, bh[u], accl[u]);
             }
             if (ntaps == 4) {                             // waves 0..2
                 const half8 bh = tr_operand(xp + tapoff[3]), bl = tr_operand(xp + WT_XB + tapoff[3]);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[3], 0, 0, 0);
-                accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accl[3], 0, 0, 0);
-                accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accl[3], 0, 0, 0);
+                accl[3] = nm_mfma_lo<SINGLE>(ah, bl, accl[3]);
+                accl[3] = nm_mfma_lo<SINGLE>(al, bh, accl[3]);
             }
         }
         __syncthreads();
@@ -976,7 +977,8 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
         if (!attr_t) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 nm_set_error("wgrad16t: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
             }
             attr_t = true;
@@ -985,17 +987,20 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
         const dim3 grid(q.p.S, q.m_tiles * q.p.n_tiles);
         if (q.p.dbg == 1) hipLaunchKernelGGL(wgrad16t_kernel<1>, grid, dim3(512), ldsb, s, q.p);
         else if (q.p.dbg == 2) hipLaunchKernelGGL(wgrad16t_kernel<2>, grid, dim3(512), ldsb, s, q.p);
+        else if (nm_conv_single()) hipLaunchKernelGGL((wgrad16t_kernel<0, true>), grid, dim3(512), ldsb, s, q.p);
         else hipLaunchKernelGGL(wgrad16t_kernel<0>, grid, dim3(512), ldsb, s, q.p);
         return nm_check_hip(hipGetLastError(), "wgrad16t launch");
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             nm_set_error("wgrad16: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad16_kernel, dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
+    if (nm_conv_single()) hipLaunchKernelGGL(wgrad16_kernel<true>, dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
+    else hipLaunchKernelGGL(wgrad16_kernel<false>, dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
     return nm_check_hip(hipGetLastError(), "wgrad16 launch");
 }
 

@@ -170,10 +170,11 @@ __device__ __forceinline__ constexpr int tap_off(int t) { return (t / 9) * ZP + 
 // one workgroup per CU has nothing else to run meanwhile).  One workgroup barrier per step.
 struct StepPos { int n, br, nh, cg, cz0, cy0, cx0; };
 
+template <bool SINGLE>
 __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
     extern __shared__ f32x4 lds_raw[];
     half8* tile = reinterpret_cast<half8*>(lds_raw);               // [buffer][chunk*4 + hl*2 + h][HVP] x 16 B, slot = hz*ZP + hy*HX + hx
-    float* aff = reinterpret_cast<float*>(tile + 2 * NPLANES * HVP); // scale[CG], shift[CG] of the tile being staged (kept out of the registers)
+
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int pz = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
@@ -308,13 +309,13 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
                 const int nof = (ks == KS - 1) ? 0 : ((t < 26) ? c * 4 * HVP + tap_off((t + 1) % 27) : (c + 1) * 4 * HVP);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    accl[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl[s], accl[j], 0, 0, 0);
+                    accl[j] = nm_mfma_lo<SINGLE>(ah[j], bl[s], accl[j]);
                     ah[j] = xb[arow[j] + nof];
                     UP2C_SB();
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    accl[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh[s], accl[j], 0, 0, 0);
+                    accl[j] = nm_mfma_lo<SINGLE>(al[j], bh[s], accl[j]);
                     al[j] = xb[arow[j] + 2 * HVP + nof];
                     UP2C_SB();
                 }
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
 constexpr int FP = 36;                                // slots per staged line (34 used)
 constexpr int FPV = 3 * FP + 1;                       // slots per plane
 
+template <bool SINGLE>
 __global__ __launch_bounds__(256, 4) void conv_up2c_face_kernel(Up2cParams p, int TY, int TX) {
     extern __shared__ f32x4 lds_raw[];
     half8* tile = reinterpret_cast<half8*>(lds_raw);               // [chunk*4 + hl*2 + h][FPV], slot = across * FP + along
@@ -454,8 +456,8 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_face_kernel(Up2cParams p, in
                     const int kn = min(k + 3, nk - 1);
                     bh[s] = wq[(size_t)kn * kstride]; bl[s] = wq[(size_t)kn * kstride + 2 * plane];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
-                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, accl, 0, 0, 0);
-                    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, accl, 0, 0, 0);
+                    accl = nm_mfma_lo<SINGLE>(ah, wl, accl);
+                    accl = nm_mfma_lo<SINGLE>(al, wh, accl);
                 }
             }
         }
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_face_kernel(Up2cParams p, in
 // conv_up2c_edge_kernel: one wave per item = 32 cells of one parity class on one of the twelve edges (the eight corners belong to
 // the edges along z).  For every non-empty subset S of a row's border axes the signed set (S, parity) is applied with the rows
 // outside the subset's cells zeroed; operands straight from global memory (a few thousand items in all).
+template <bool SINGLE>
 __global__ __launch_bounds__(256, 4) void conv_up2c_edge_kernel(Up2cParams p, int TZ, int TY, int TX, int slot0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
@@ -554,8 +557,8 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_edge_kernel(Up2cParams p, in
                             half8 hi, lo;
                             split8(xa, xb2, hi, lo);
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, wh[u], acc, 0, 0, 0);
-                            accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, wl[u], accl, 0, 0, 0);
-                            accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, wh[u], accl, 0, 0, 0);
+                            accl = nm_mfma_lo<SINGLE>(hi, wl[u], accl);
+                            accl = nm_mfma_lo<SINGLE>(lo, wh[u], accl);
                         }
                     }
                 }
@@ -618,10 +621,12 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     if ((in.scale == nullptr) != (in.shift == nullptr)) { nm_set_error("conv_up2c: scale/shift must come together"); return NM_ERR_ARG; }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_up2c)");
         attr_set = true;
     }
+    const bool single = nm_conv_single() != 0;
     if (g_cus == 0) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nm_check_hip(hipErrorUnknown, "device query");
@@ -636,17 +641,20 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     p.nblk = nm_up2c_blocks_per_frame(in.D, in.H, in.W);
     p.diag = g_diag;
     const int bricks = p.nbz * p.nby * p.nbx, total = p.N * bricks;
-    hipLaunchKernelGGL(conv_up2c_kernel, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    if (single) hipLaunchKernelGGL(conv_up2c_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(conv_up2c_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     int rc = nm_check_hip(hipGetLastError(), "conv_up2c launch");
     if (rc) return rc;
     if (g_diag & 4) return NM_OK;
     int TZ, TY, TX; shell_tiles(in.D, in.H, in.W, TZ, TY, TX);
     const int fg = face_groups(in.D, in.H, in.W), ei = edge_items(in.D, in.H, in.W);
     const size_t face_lds = (size_t)(in.C / 16 * 4) * FPV * 16;
-    hipLaunchKernelGGL(conv_up2c_face_kernel, dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
+    if (single) hipLaunchKernelGGL(conv_up2c_face_kernel<true>, dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
+    else hipLaunchKernelGGL(conv_up2c_face_kernel<false>, dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
     rc = nm_check_hip(hipGetLastError(), "conv_up2c_face launch");
     if (rc) return rc;
     const long long items = (long long)p.N * ei;
-    hipLaunchKernelGGL(conv_up2c_edge_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
+    if (single) hipLaunchKernelGGL(conv_up2c_edge_kernel<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
+    else hipLaunchKernelGGL(conv_up2c_edge_kernel<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
     return nm_check_hip(hipGetLastError(), "conv_up2c_edge launch");
 }

@@ -38,6 +38,9 @@ from .spec import DETECTOR_LOSS_KEYS, FEAT_DIM, HotPathOptions, param_spec
 Priority = namedtuple("Priority", ["values", "indices"])   # what torch.topk returns in the reference
 
 
+CONV_MODES = {"fp32": 0, "0": 0, "exact": 0, "split16": 1, "1": 1, "f16": 3, "3": 3}
+
+
 class Engine:
     """One nm_ctx + weight synchronisation for a NeuralMarionette instance."""
 
@@ -51,8 +54,9 @@ class Engine:
         self.ctx: Optional[_lib.Context] = None
         self._stamp = None
         self._named = None
-        # conv arithmetic: 1 = split-fp16 MFMA with fp32-equivalent accuracy (default), 0 = exact fp32 MFMA
-        self.conv_mode = 0 if os.environ.get("NM355_CONV_MODE", "split16").lower() in ("fp32", "0", "exact") else 1
+        # conv arithmetic: 1 = split-fp16 MFMA with fp32-equivalent accuracy (default), 0 = exact fp32 MFMA, 3 = fp16 products
+        # with fp32 accumulation (reduced precision, for training)
+        self.conv_mode = CONV_MODES.get(os.environ.get("NM355_CONV_MODE", "split16").lower(), 1)
         self.training_packs = False     # detector-mode training: set_weights also packs the data-gradient weights
 
     # -- plumbing ---------------------------------------------------------------------------
@@ -531,10 +535,12 @@ class NeuralMarionette(nn.Module):
 
     def set_conv_mode(self, mode: str) -> None:
         """'split16' (default): convs with Cin % 16 == 0 on the fp16 matrix cores, operands split hi/lo, fp32
-        accumulate (fp32-equivalent accuracy); 'fp32': exact fp32 MFMA everywhere."""
-        if mode not in ("split16", "fp32"):
-            raise ValueError("conv mode must be 'split16' or 'fp32'")
-        self._engine.conv_mode = 1 if mode == "split16" else 0
+        accumulate (fp32-equivalent accuracy); 'fp32': exact fp32 MFMA everywhere; 'f16': the split16 kernels with the
+        hi x hi product only - operands rounded to fp16, fp32 accumulation and storage (autocast-class accuracy, the
+        reduced-precision training mode; outside the 1e-4 parity contract)."""
+        if mode not in ("split16", "fp32", "f16"):
+            raise ValueError("conv mode must be 'split16', 'fp32' or 'f16'")
+        self._engine.conv_mode = CONV_MODES[mode]
 
     def check_finite(self) -> None:
         """Synchronises and raises NmError if a convolution has produced non-finite values since the last check - in the default

@@ -127,6 +127,32 @@ def test_detector_gradients_vs_reference_fixture(golden_dir):
     print("worst relative difference to the reference's gradients %.2e" % worst)
 
 
+@pytest.mark.parametrize("seed", [11, 104])
+def test_detector_gradients_f16_mode(seed):
+    """Reduced-precision conv mode 'f16' (nm_set_conv_mode 3: conv products of fp16-rounded operands, fp32 accumulation and storage -
+    the training arithmetic BASELINE.json's config 3 asks for under the name bf16, with three more operand bits) against the fp64
+    oracle, training weighting.  Stated tolerance of the mode (measured: tools/diag_f16.py - loss 5e-5, keypoints 4e-4, global
+    gradient L2 7e-3, worst tensor L2 0.10 / cosine 0.995 on the deep hourglass convs in front of a GroupNorm, whose backward
+    removes the common mode): loss 5e-4 relative, keypoints 2e-3, whole-gradient L2 distance 2e-2, every parameter tensor's
+    gradient within 0.25 L2-relative and 0.98 cosine of the fp64 gradient.  The fp32-equivalent modes are held to 2e-3 per entry."""
+    o, sd, vox = _setup(seed=seed)
+    ref_loss, ref, ref_out = _oracle_grads(o, sd, vox, AIST, double=True)
+    loss, got, out = _hip_grads(o, sd, vox, AIST, mode="f16")
+    assert abs(loss - ref_loss) <= 5e-4 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    assert (out["keypoints"].detach().cpu().double() - ref_out["keypoints"].double()).abs().max().item() < 2e-3
+    gmax = max(r.abs().max().item() for r in ref.values())
+    num = den = 0.0
+    for k, r in ref.items():
+        g, r = got[k].double(), r.double()
+        assert torch.isfinite(g).all(), k
+        num += ((g - r) ** 2).sum().item(); den += (r ** 2).sum().item()
+        if r.abs().max().item() > 1e-6 * gmax:
+            rel = ((g - r).norm() / r.norm()).item()
+            cos = (g.flatten() @ r.flatten()).item() / (g.norm().item() * r.norm().item())
+            assert rel < 0.25 and cos > 0.98, (k, rel, cos)
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
 def test_detector_gradients_exact_fp32_mode():
     """Exact fp32-MFMA convolutions everywhere (conv mode 'fp32'): under the training weighting the HIP gradients sit closer to the
     fp64 gradients than the fp32 oracle does.  (The single-loss weightings are not run in this mode: a keypoint-only loss sends
