@@ -697,6 +697,55 @@ __global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restri
     }
 }
 
+// The same partial sums with 16-byte loads, four channels per thread and four voxels in flight (C % 4 == 0, C <= 256 with 1024 / C
+// a whole number: every layer of the network).  The one-float-per-thread form above keeps two dependent 4-byte loads in flight per
+// thread and reached 0.54 of the HBM rate on the 64^3 layers (2 reads of 2.1 GB in 1.6 ms).
+__global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restrict__ dA, TensorRef y, int voxels, float* __restrict__ part,
+                                                            const float* __restrict__ dmul) {
+    __shared__ f32x4 sh[256 * 2];
+    const float mm = dmul ? *dmul : 1.0f;
+    const int n = blockIdx.y, blk = blockIdx.x, C = y.C, C4 = C >> 2;
+    const int lanes = 256 / C4;
+    const int c = (threadIdx.x % C4) * 4, vl = threadIdx.x / C4;
+    f32x4 s1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, s2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (vl < lanes) {
+        f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, shf = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (y.scale) { sc = *reinterpret_cast<const f32x4*>(y.scale + (size_t)n * C + c); shf = *reinterpret_cast<const f32x4*>(y.shift + (size_t)n * C + c); }
+        const int v0 = blk * NM_GNB_VB, v1 = min(voxels, v0 + NM_GNB_VB);
+        const float* yp = y.p + (size_t)n * voxels * C + c;
+        const float* dp = dA + (size_t)n * voxels * C + c;
+        auto add = [&](const f32x4& yy, const f32x4& dd, int u) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = fmaf(yy[j], sc[j], shf[j]);
+                const float dz = (dd[j] * mm) * (z > 0.f ? 1.0f : y.slope);
+                s1[u][j] += dz; s2[u][j] += dz * yy[j];
+            }
+        };
+        int v = v0 + vl;
+        for (; v + 3 * lanes < v1; v += 4 * lanes) {
+            f32x4 yy[4], dd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                yy[u] = *reinterpret_cast<const f32x4*>(yp + (size_t)(v + u * lanes) * C);
+                dd[u] = *reinterpret_cast<const f32x4*>(dp + (size_t)(v + u * lanes) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(yy[u], dd[u], u & 1);
+        }
+        for (; v < v1; v += lanes) add(*reinterpret_cast<const f32x4*>(yp + (size_t)v * C), *reinterpret_cast<const f32x4*>(dp + (size_t)v * C), 0);
+    }
+    sh[threadIdx.x * 2] = s1[0] + s1[1]; sh[threadIdx.x * 2 + 1] = s2[0] + s2[1];
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+        for (int l = 0; l < lanes; ++l) { a += sh[(l * C4 + threadIdx.x) * 2]; b += sh[(l * C4 + threadIdx.x) * 2 + 1]; }
+        float* dst = part + (((size_t)n * gridDim.x + blk) * C + c) * 2;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{a[0], b[0], a[1], b[1]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{a[2], b[2], a[3], b[3]};
+    }
+}
+
 // one block per (frame, group); cpg <= 64 channels per group; 1024 threads: 1024 / cpg lanes walk each channel's partial blocks
 #define NM_GNBF_T 1024
 __global__ __launch_bounds__(NM_GNBF_T) void gnb_finalize_kernel(const float* __restrict__ bpart, int nblk_b, const float* __restrict__ fpart,
@@ -1082,7 +1131,10 @@ int nm_gnb_blocks_per_frame(int voxels) { return (voxels + NM_GNB_VB - 1) / NM_G
 int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul) {
     if (y.C > 256 || y.C <= 0) { nm_set_error("gnb_partials: C=%d unsupported", y.C); return NM_ERR_ARG; }
     const int voxels = y.D * y.H * y.W;
-    hipLaunchKernelGGL(gnb_partials_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul);
+    if (y.C % 4 == 0 && 1024 % y.C == 0)
+        hipLaunchKernelGGL(gnb_partials4_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul);
+    else
+        hipLaunchKernelGGL(gnb_partials_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul);
     return nm_check_hip(hipGetLastError(), "gnb_partials launch");
 }
 
