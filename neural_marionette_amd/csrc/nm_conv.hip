@@ -420,6 +420,7 @@ template <int NT, bool SINGLE = false>
 __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     __shared__ _Float16 tile_h[8 * 12 * 12], tile_l[8 * 12 * 12];
     __shared__ float red[512];
+    __shared__ __attribute__((aligned(16))) float stage[4 * 32 * 36];      // epilogue transposition, one 32-voxel x 32-channel tile per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int nb = p.G >> 3, nbz = p.G >> 2;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     const int oz0 = (br / (nb * nb)) << 2, oy0 = ((br / nb) % nb) << 3, ox0 = (br % nb) << 3;
     const int co_base = blockIdx.y * (NT * 32);
     const float* src = p.occ + (size_t)n * p.G * p.G * p.G;
-    int inexact = 0;
+    int inexact = 0, occupied = 0;
     for (int i = tid; i < 8 * 12 * 12; i += 256) {
         int hx = i % 12, hy = (i / 12) % 12, hz = i / 144;
         int gz = oz0 - 2 + hz, gy = oy0 - 2 + hy, gx = ox0 - 2 + hx;
@@ -439,8 +440,12 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
         const _Float16 lo = (_Float16)((v - (float)hi) * NM_SPLIT_SCALE);
         tile_h[i] = hi; tile_l[i] = lo;
         inexact |= (lo != (_Float16)0.f);
+        occupied |= (v != 0.f);
     }
     const bool need_lo = __syncthreads_or(inexact) != 0;            // (also the barrier after staging)
+    // a brick whose 8x12x12 neighbourhood holds no occupied voxel (most of a 64^3 grid around one figure) is the field alone: the
+    // gather + MFMA loop below would add exact zeros
+    const bool any_occ = __syncthreads_or(occupied) != 0;
     int arow[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -455,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accl[mt][nt][r] = 0.f; }
     const occ_half8* __restrict__ wq = reinterpret_cast<const occ_half8*>(p.w + (size_t)128 * p.Co_pad) + (size_t)h * p.Co_pad + co_base + l31;
+    if (any_occ)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
         occ_half8 bh[NT], bl[NT];
@@ -492,6 +498,51 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     // this layer spends its time issuing 64 dword loads / stores per lane (the fp32 and the f16 MFMA variant took the same
     // 1.58 ms); GroupNorm partials by DPP row reductions (rows 1 and 3 of the wave end up with the totals).
     const bool chan_ok = (p.Cout & 3) == 0;
+    if (chan_ok && co_base + NT * 32 <= p.Cout) {
+        // Whole 128-byte lines per store: the accumulator layout gives a lane 16 bytes of one voxel, so a store instruction touches
+        // 32 lines, 32 bytes each.  The tile goes through LDS (per wave, no workgroup barrier) and comes back with 8 lanes per
+        // voxel: one instruction writes 8 x-consecutive voxels = 1 KB contiguous, and reads the field the same way.  This layer is
+        // its 2.1 GB output write: 1.25 ms with the strided stores.
+        float* stg = stage + wave * (32 * 36);
+        const int chunk = lane & 7;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 t1 = f32x4{0.f, 0.f, 0.f, 0.f}, t2 = t1;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * k4 + e] + accl[mt][nt][4 * k4 + e] * (1.0f / NM_SPLIT_SCALE);
+                    *reinterpret_cast<f32x4*>(stg + l31 * 36 + 8 * k4 + 4 * h) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int vv = it * 8 + (lane >> 3);
+                    const int m = (wave * 2 + mt) * 32 + vv;
+                    const int oz = oz0 + (m >> 6), oy = oy0 + ((m >> 3) & 7), ox = ox0 + (m & 7);
+                    const size_t vo = (((size_t)oz * p.G + oy) * p.G + ox) * p.Cout + co_base + nt * 32 + chunk * 4;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + vv * 36 + chunk * 4);
+                    v += *reinterpret_cast<const f32x4*>(p.field + vo);
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)n * p.G * p.G * p.G * p.Cout + vo) = v;
+                    t1 += v; t2 += v * v;
+                }
+            }
+            if (p.part) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = t1[e], b = t2[e];
+                    a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
+                    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                    if (lane < 8) { const int c = nt * 32 + chunk * 4 + e; red[(wave * NT * 32 + c) * 2] = a; red[(wave * NT * 32 + c) * 2 + 1] = b; }
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         float s1[16], s2[16];
