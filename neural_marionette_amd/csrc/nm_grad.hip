@@ -436,7 +436,9 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
     float* xtab = reinterpret_cast<float*>(lds8 + WT_LDS);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tp = blockIdx.y, mt = tp / p.n_tiles, nt = tp % p.n_tiles, m0 = mt * 32, n0 = nt * 32;
-    const int ntaps = w < 3 ? 4 : 3;                      // taps w, w + 8, w + 16 (, w + 24)
+    // taps: wave w owns the tap line (dz, dy) = (w / 3, w % 3) - taps 3 w + dx, whose three X operands come out of ONE halo row read
+    // (10 voxels, shifted in registers) - and waves 0..2 also tap 24 + w of the ninth line
+    const int ntaps = w < 3 ? 4 : 3;
     f32x16 acc[4], accl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -447,9 +449,8 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
     const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, cb = (lane >> 4) & 1;
     const int a_lane = ((lh * 8 + q) * 32 + 16 * cb + 4 * pp) * 2;          // dY tile: brick row 2s + lh, voxel x0 + q
     const int b_lane = ((lh * 10 + q) * 32 + 16 * cb + 4 * pp) * 2;         // X tile: halo row (z + tz, 2(s & 3) + lh + ty), voxel x0 + q + tx
-    int tapoff[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int t = min(w + 8 * j, 26); tapoff[j] = (((t / 9) * 10 + (t / 3) % 3) * 10 + t % 3) * 64; }
+    const int lineoff = (((w / 3) * 10 + w % 3) * 10) * 64;                 // halo row (dz, dy) of the wave's line, x = -1
+    const int extraoff = ((2 * 10 + 2) * 10 + min(w, 2)) * 64;              // tap 24 + w = (2, 2, w)
 
     const int per_frame = p.nbz * p.nby * p.nbx, total = p.in.N * per_frame;
     // staging roles: three (four for 64 threads) X items (halo voxel, channel octet) and one dY item per thread; octet = tid & 3
@@ -591,9 +592,20 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
             const half8 ah = tr_operand(ap), al = tr_operand(ap + WT_DB);
             const char* xp = buf + b_lane + (((s8 >> 2) * 10 + 2 * (s8 & 3)) * 10) * 64;
             {
+                // halo row of the line: voxels x = -1 .. 10 as three transposed reads (x = 9, 10 of the third are never used), hi and lo;
+                // dx = 0 is registers 0..3, dx = 2 registers 1..4, dx = 1 four v_alignbit - 6 LDS reads for three taps instead of 12
+                const char* lp = xp + lineoff;
+                const u32x2 h0 = tr_read(lp), h1 = tr_read(lp + 4 * 64), h2 = tr_read(lp + 8 * 64);
+                const u32x2 l0 = tr_read(lp + WT_XB), l1 = tr_read(lp + WT_XB + 4 * 64), l2 = tr_read(lp + WT_XB + 8 * 64);
                 half8 bh[3], bl[3];
-#pragma unroll
-                for (int u = 0; u < 3; ++u) { bh[u] = tr_operand(xp + tapoff[u]); bl[u] = tr_operand(xp + WT_XB + tapoff[u]); }
+                bh[0] = __builtin_bit_cast(half8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+                bh[2] = __builtin_bit_cast(half8, u32x4{h0[1], h1[0], h1[1], h2[0]});
+                bh[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(h0[1], h0[0], 16), __builtin_amdgcn_alignbit(h1[0], h0[1], 16),
+                                                        __builtin_amdgcn_alignbit(h1[1], h1[0], 16), __builtin_amdgcn_alignbit(h2[0], h1[1], 16)});
+                bl[0] = __builtin_bit_cast(half8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+                bl[2] = __builtin_bit_cast(half8, u32x4{l0[1], l1[0], l1[1], l2[0]});
+                bl[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(l0[1], l0[0], 16), __builtin_amdgcn_alignbit(l1[0], l0[1], 16),
+                                                        __builtin_amdgcn_alignbit(l1[1], l1[0], 16), __builtin_amdgcn_alignbit(l2[0], l1[1], 16)});
 #pragma unroll
                 for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc[u], 0, 0, 0);
 #pragma unroll
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
                 for (int u = 0; u < 3; ++u) accl[u] = nm_mfma_lo<SINGLE>(al, bh[u], accl[u]);
             }
             if (ntaps == 4) {                             // waves 0..2
-                const half8 bh = tr_operand(xp + tapoff[3]), bl = tr_operand(xp + WT_XB + tapoff[3]);
+                const half8 bh = tr_operand(xp + extraoff), bl = tr_operand(xp + WT_XB + extraoff);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[3], 0, 0, 0);
                 accl[3] = nm_mfma_lo<SINGLE>(ah, bl, accl[3]);
                 accl[3] = nm_mfma_lo<SINGLE>(al, bh, accl[3]);
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j >= ntaps) continue;
-        const int t = w + 8 * j;
+        const int t = j < 3 ? 3 * w + j : 24 + w;
         float* dst = p.part + (((size_t)blockIdx.x * gridDim.y + tp) * 27 + t) * 1024;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][r] + accl[j][r] * (1.0f / W16_SPLIT);
