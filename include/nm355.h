@@ -271,7 +271,7 @@ int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
                           int32_t ks, int32_t stride, int32_t pad, int32_t up2, const float* dy, float* d_in,
                           int32_t dgrad_channels, float* d_weight, float* d_bias);
 int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, int32_t Cout, const float* dy,
-                             float* d_weight, float* d_bias, int32_t sparse_occ /* gather over the occupied voxels (per-frame grids) */);
+                             float* d_weight, float* d_bias, int32_t sparse_occ /* occupancy channel: 1 = matrix cores over the non-empty 4x8x8 bricks (the gather when G % 8 != 0), 2 = gather over the occupied voxels, 0 = generic dense kernel */);
 int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                           const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
                           int32_t outpad, const float* dy, float* d_in, float* d_weight, float* d_bias);

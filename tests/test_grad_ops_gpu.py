@@ -95,7 +95,7 @@ def test_conv3d_backward(ctx, case, mode):
     _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, 1), "set_conv_mode")
 
 
-@pytest.mark.parametrize("sparse", [1, 0], ids=["gather", "dense"])
+@pytest.mark.parametrize("sparse", [1, 2, 0], ids=["mfma-bricks", "gather", "dense"])
 @pytest.mark.parametrize("Cout,G,N,frac", [(32, 16, 2, False), (64, 12, 3, False), (32, 32, 1, False), (64, 24, 5, True), (32, 40, 3, True),
                                              (48, 16, 2, False)])
 def test_conv5_occ_backward(ctx, Cout, G, N, frac, sparse):
@@ -104,6 +104,9 @@ def test_conv5_occ_backward(ctx, Cout, G, N, frac, sparse):
     occ = (torch.rand(N, 1, G, G, G, generator=g) < 0.05).float()
     if frac:        # the clip-mean net sees fractional occupancy (kypt_detector.py:312)
         occ = occ * torch.rand(N, 1, G, G, G, generator=g)
+    if G >= 24:     # one figure in the grid: most 4x8x8 bricks (and their halos) are empty - the brick-skipping path
+        box = torch.zeros_like(occ); box[:, :, G // 3:G // 3 + 9, 5:G // 2, G // 2 - 3:G - 6] = 1.0
+        occ = occ * box
     lin = torch.linspace(-1.0, 1.0, G)
     zz, yy, xx = torch.meshgrid(lin, lin, lin, indexing="ij")
     coords = torch.stack([zz, yy, xx])[None].expand(N, -1, -1, -1, -1)
