@@ -1472,13 +1472,15 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
                 asm volatile("" : "+v"(hv));
                 const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
                 hi4[e] = hv[0]; hi4[e + 1] = hv[1];
-                lo4[e] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
-                lo4[e + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+                if constexpr (!SINGLE) {                            // (conv mode 3 has no use for the lo halves)
+                    lo4[e] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
+                    lo4[e + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+                }
             }
             if (pc_pos[k] >= 0) {
                 half4v* dst = reinterpret_cast<half4v*>(ldh + buf * 4 * HV + pc_slot[k]) + (quad & 1);
                 dst[0] = hi4;
-                dst[4 * HV] = lo4;                                  // + 2 HV half8 slots
+                if constexpr (!SINGLE) dst[4 * HV] = lo4;           // + 2 HV half8 slots
             }
         };
         // direct-to-LDS copy of tap group g of (cout group cg, chunk cb) into weight buffer g: 18 one-KiB wave loads; every
@@ -1655,12 +1657,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
     half8 ah0[3], al0[3], ah1[3], al1[3], bhv[3], blv[3];
     {
         const unsigned va = (unsigned)(size_t)(ldh + h * HV + arow0);
-        ah0[0] = lds_read16_untracked<0>(va); al0[0] = lds_read16_untracked<LO>(va);
-        ah1[0] = lds_read16_untracked<YO>(va); al1[0] = lds_read16_untracked<LO + YO>(va);
-        ah0[1] = lds_read16_untracked<16>(va); al0[1] = lds_read16_untracked<LO + 16>(va);
-        ah1[1] = lds_read16_untracked<YO + 16>(va); al1[1] = lds_read16_untracked<LO + YO + 16>(va);
-        bhv[0] = lds_read16_untracked<0>(vb); blv[0] = lds_read16_untracked<64 * 16>(vb);
-        bhv[1] = lds_read16_untracked<128 * 16>(vb); blv[1] = lds_read16_untracked<192 * 16>(vb);
+        ah0[0] = lds_read16_untracked<0>(va); al0[0] = SINGLE ? half8{} : lds_read16_untracked<LO>(va);
+        ah1[0] = lds_read16_untracked<YO>(va); al1[0] = SINGLE ? half8{} : lds_read16_untracked<LO + YO>(va);
+        ah0[1] = lds_read16_untracked<16>(va); al0[1] = SINGLE ? half8{} : lds_read16_untracked<LO + 16>(va);
+        ah1[1] = lds_read16_untracked<YO + 16>(va); al1[1] = SINGLE ? half8{} : lds_read16_untracked<LO + YO + 16>(va);
+        bhv[0] = lds_read16_untracked<0>(vb); blv[0] = SINGLE ? half8{} : lds_read16_untracked<64 * 16>(vb);
+        bhv[1] = lds_read16_untracked<128 * 16>(vb); blv[1] = SINGLE ? half8{} : lds_read16_untracked<192 * 16>(vb);
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(ah0[0]), "+v"(al0[0]), "+v"(ah1[0]), "+v"(al1[0]), "+v"(ah0[1]), "+v"(al0[1]), "+v"(ah1[1]), "+v"(al1[1]),
                        "+v"(bhv[0]), "+v"(blv[0]), "+v"(bhv[1]), "+v"(blv[1]) :: "memory");
@@ -1718,7 +1720,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             NM_WAIT_OPERANDS(ah1[i], bhv[i]);
             if constexpr (tt == 0 && with_epi) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], ah1[i], zero16, 0, 0, 0);
             else acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhv[i], ah1[i], acc[1], 0, 0, 0);
-            blv[j] = lds_read16_untracked<BO + 64 * 16>(vb);
+            blv[j] = SINGLE ? half8{} : lds_read16_untracked<BO + 64 * 16>(vb);
             gap(ic<2>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(ah1[i], blv[i]);
@@ -1729,12 +1731,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(al0[i], bhv[i]);
             accl[0] = nm_mfma_lo<SINGLE>(bhv[i], al0[i], accl[0]);
-            al0[j] = lds_read16_untracked<AO + LO>(vau);
+            al0[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO>(vau);
             gap(ic<4>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(al1[i], bhv[i]);
             accl[1] = nm_mfma_lo<SINGLE>(bhv[i], al1[i], accl[1]);
-            al1[j] = lds_read16_untracked<AO + LO + YO>(vau);
+            al1[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO + YO>(vau);
             gap(ic<5>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (t == 8) {
@@ -1892,13 +1894,15 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
                 asm volatile("" : "+v"(hv));
                 const float t0 = v0 * NM_SPLIT_SCALE, t1 = v1 * NM_SPLIT_SCALE;
                 hi4[e] = hv[0]; hi4[e + 1] = hv[1];
-                lo4[e] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
-                lo4[e + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+                if constexpr (!SINGLE) {                            // (conv mode 3 has no use for the lo halves)
+                    lo4[e] = (_Float16)__builtin_fmaf((float)hv[0], -NM_SPLIT_SCALE, t0);
+                    lo4[e + 1] = (_Float16)__builtin_fmaf((float)hv[1], -NM_SPLIT_SCALE, t1);
+                }
             }
             if (pc_pos[k] >= 0) {
                 half4v* dst = reinterpret_cast<half4v*>(ldh + buf * 4 * HV + pc_slot[k]) + (quad & 1);
                 dst[0] = hi4;
-                dst[4 * HV] = lo4;
+                if constexpr (!SINGLE) dst[4 * HV] = lo4;
             }
         };
         // tap group g of (cout group cg, chunk cb): 36 one-KiB wave pieces (tap t, plane r, 64 channels), nine per producer wave
@@ -1997,8 +2001,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
     half8 ah0[2], al0[2], ah1[2], al1[2], bh0[2], bh1[2], bl0[2], bl1[2];      // operands, double buffered (index = tap & 1)
     {
         const unsigned va = (unsigned)(size_t)(ldh + h * HV + arow0);
-        ah0[0] = lds_read16_untracked<0>(va); al0[0] = lds_read16_untracked<LO>(va);
-        ah1[0] = lds_read16_untracked<YO>(va); al1[0] = lds_read16_untracked<LO + YO>(va);
+        ah0[0] = lds_read16_untracked<0>(va); al0[0] = SINGLE ? half8{} : lds_read16_untracked<LO>(va);
+        ah1[0] = lds_read16_untracked<YO>(va); al1[0] = SINGLE ? half8{} : lds_read16_untracked<LO + YO>(va);
     }
     for (;;) {
         Step nxt = cur;
@@ -2012,7 +2016,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             constexpr int BT = t * 256 * 16;                        // byte offset of this tap in its weight buffer
             if constexpr (t == 0) {                                 // first tap of a group: its weights were published by the barrier
                 bh0[i] = lds_read16_untracked<BT>(vb); bh1[i] = lds_read16_untracked<BT + 32 * 16>(vb);
-                bl0[i] = lds_read16_untracked<BT + 128 * 16>(vb); bl1[i] = lds_read16_untracked<BT + 160 * 16>(vb);
+                bl0[i] = SINGLE ? half8{} : lds_read16_untracked<BT + 128 * 16>(vb); bl1[i] = SINGLE ? half8{} : lds_read16_untracked<BT + 160 * 16>(vb);
             }
             // every operand of this tap has been requested (previous tap / just above): wait for all of them
             asm volatile("s_waitcnt lgkmcnt(0)"
@@ -2026,13 +2030,13 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
 #define NM_MFMA2(ACC, B, A) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(B, A, ACC, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
 #define NM_MFMA2L(ACC, B, A) ACC = nm_mfma_lo<SINGLE>(B, A, ACC); __builtin_amdgcn_sched_barrier(0)
             NM_MFMA2(acc[0][0], bh0[i], ah0[i]);  ah0[j] = lds_read16_untracked<AO>(vau);
-            NM_MFMA2(acc[0][1], bh1[i], ah0[i]);  al0[j] = lds_read16_untracked<AO + LO>(vau);
+            NM_MFMA2(acc[0][1], bh1[i], ah0[i]);  al0[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO>(vau);
             NM_MFMA2L(accl[0][0], bl0[i], ah0[i]); ah1[j] = lds_read16_untracked<AO + YO>(vau);
-            NM_MFMA2L(accl[0][1], bl1[i], ah0[i]); al1[j] = lds_read16_untracked<AO + LO + YO>(vau);
+            NM_MFMA2L(accl[0][1], bl1[i], ah0[i]); al1[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO + YO>(vau);
             NM_MFMA2L(accl[0][0], bh0[i], al0[i]); if constexpr (bnext) bh0[j] = lds_read16_untracked<BN>(vb);
             NM_MFMA2L(accl[0][1], bh1[i], al0[i]); if constexpr (bnext) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb);
-            NM_MFMA2(acc[1][0], bh0[i], ah1[i]);  if constexpr (bnext) bl0[j] = lds_read16_untracked<BN + 128 * 16>(vb);
-            NM_MFMA2(acc[1][1], bh1[i], ah1[i]);  if constexpr (bnext) bl1[j] = lds_read16_untracked<BN + 160 * 16>(vb);
+            NM_MFMA2(acc[1][0], bh0[i], ah1[i]);  if constexpr (bnext) bl0[j] = SINGLE ? half8{} : lds_read16_untracked<BN + 128 * 16>(vb);
+            NM_MFMA2(acc[1][1], bh1[i], ah1[i]);  if constexpr (bnext) bl1[j] = SINGLE ? half8{} : lds_read16_untracked<BN + 160 * 16>(vb);
             NM_MFMA2L(accl[1][0], bl0[i], ah1[i]);
             NM_MFMA2L(accl[1][1], bl1[i], ah1[i]);
             NM_MFMA2L(accl[1][0], bh0[i], al1[i]);

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
         h[0] = pack_split(a[0], a[1], l[0]); h[1] = pack_split(a[2], a[3], l[1]);
         h[2] = pack_split(b[0], b[1], l[2]); h[3] = pack_split(b[2], b[3], l[3]);
         *reinterpret_cast<u32x4*>(hi) = u32x4{h[0], h[1], h[2], h[3]};
-        *reinterpret_cast<u32x4*>(lo) = u32x4{l[0], l[1], l[2], l[3]};
+        if constexpr (!SINGLE) *reinterpret_cast<u32x4*>(lo) = u32x4{l[0], l[1], l[2], l[3]};      // (conv mode 3 never reads the lo tiles)
     };
     // slot 0..3: X items, slot 4: the dY item.  Unconditional: without a next brick the stale registers go to the idle buffer.
     const float xa_on = n0 + 8 * oct < p.Nc ? 1.f : 0.f, xb_on = n0 + 8 * oct + 4 < p.Nc ? 1.f : 0.f;
