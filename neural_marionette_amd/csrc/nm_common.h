@@ -81,7 +81,9 @@ void nm_conv_prof_reset();
 // ---- nm_elem.hip -------------------------------------------------------------------
 int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count,
                           const float* gamma, const float* beta, float eps, float* scale,
-                          float* shift, hipStream_t s);
+                          float* shift, hipStream_t s, double* chsum = nullptr);
+// chsum (training): [N][C][2] doubles (sum y, sum y^2 per channel) for nm_launch_gnb_finalize; available when 256 % (C / groups) == 0
+bool nm_gn_finalize_has_chsum(int C, int groups);
 // sticky device word (ctx-owned) that gn_finalize ORs a 1 into when a conv's statistics are not finite; null: no reporting
 void nm_elem_set_nonfinite_flag(unsigned* flag);
 int nm_launch_nonfinite_scan(const float* x, size_t n, unsigned* flag, hipStream_t s);

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const float* __restrict
                                                            double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps,
                                                            float* __restrict__ scale, float* __restrict__ shift,
-                                                           unsigned* __restrict__ nonfinite) {
+                                                           unsigned* __restrict__ nonfinite, double* __restrict__ chsum) {
     __shared__ double sh_s[NT], sh_ss[NT];
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
@@ -56,6 +56,17 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const float* __restrict
     }
     sh_s[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]); sh_ss[threadIdx.x] = (ss[0] + ss[1]) + (ss[2] + ss[3]);
     __syncthreads();
+    // training: the per-channel (sum y, sum y^2) for the GroupNorm backward, which otherwise walks these partials a second time
+    // (with NT a multiple of cpg every item of a thread belongs to channel tid % cpg)
+    if (chsum) {
+        if ((int)threadIdx.x < cpg) {
+            double a = 0.0, b = 0.0;
+            for (int l = 0; l < NT / cpg; ++l) { a += sh_s[l * cpg + threadIdx.x]; b += sh_ss[l * cpg + threadIdx.x]; }
+            double* d = chsum + ((size_t)n * C + g * cpg + threadIdx.x) * 2;
+            d[0] = a; d[1] = b;
+        }
+        __syncthreads();
+    }
     for (int st = NT / 2; st > 0; st >>= 1) {
         if ((int)threadIdx.x < st) { sh_s[threadIdx.x] += sh_s[threadIdx.x + st]; sh_ss[threadIdx.x] += sh_ss[threadIdx.x + st]; }
         __syncthreads();
@@ -392,13 +403,16 @@ int nm_launch_nonfinite_scan(const float* x, size_t n, unsigned* flag, hipStream
     return nm_check_hip(hipGetLastError(), "nonfinite_scan launch");
 }
 
+bool nm_gn_finalize_has_chsum(int C, int groups) { return groups > 0 && C % groups == 0 && 256 % (C / groups) == 0; }
+
 int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count, const float* gamma,
-                          const float* beta, float eps, float* scale, float* shift, hipStream_t s) {
+                          const float* beta, float eps, float* scale, float* shift, hipStream_t s, double* chsum) {
     if (groups <= 0 || C % groups != 0 || C / groups > 256) { nm_set_error("gn_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
+    if (chsum && !nm_gn_finalize_has_chsum(C, groups)) { nm_set_error("gn_finalize: no per-channel sums for %d channels per group", C / groups); return NM_ERR_ARG; }
     if ((long long)nblk * (C / groups) > 8192)
-        hipLaunchKernelGGL(gn_finalize_kernel<1024>, dim3(N * groups), dim3(1024), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag);
+        hipLaunchKernelGGL(gn_finalize_kernel<1024>, dim3(N * groups), dim3(1024), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag, chsum);
     else
-        hipLaunchKernelGGL(gn_finalize_kernel<256>, dim3(N * groups), dim3(256), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag);
+        hipLaunchKernelGGL(gn_finalize_kernel<256>, dim3(N * groups), dim3(256), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag, chsum);
     return nm_check_hip(hipGetLastError(), "gn_finalize launch");
 }
 

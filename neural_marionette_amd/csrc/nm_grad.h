@@ -26,9 +26,10 @@ int nm_gnb_blocks_per_frame(int voxels);
 // dA_mul (optional, here and in gnb_apply / absmax): device scalar dA is multiplied by on read (the producer left it scaled by 2^k)
 int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul = nullptr);
 // coef[n][c] = (c1, c2, c3, 0) with dy = c1*dz + c2*y + c3;  dgn[n][c] = (dgamma_n, dbeta_n, dbias_n, 0)
-// fpart: the forward partial sums (sum y, sum y^2) the conv epilogue left, [N][nblk_f][C][2]
+// fpart: the forward partial sums (sum y, sum y^2) the conv epilogue left, [N][nblk_f][C][2]; chsum (optional): the per-channel totals
+// of them that the forward finalisation left ([N][C][2] doubles, nm_launch_gn_finalize) - then fpart is not read
 int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, int nblk_f, int N, int C, int groups, int voxels,
-                           const float* gamma, float eps, float* coef, float* dgn, hipStream_t s);
+                           const float* gamma, float eps, float* coef, float* dgn, hipStream_t s, const double* chsum = nullptr);
 // out[c] = sum_n src[(n*C + c)*stride + off]
 int nm_launch_sum_frames(const float* src, int N, int C, int stride, int off, float* out, hipStream_t s);
 int nm_launch_sum_frames3(const float* dgn, int N, int C, float* dgamma, float* dbeta, float* dbias, hipStream_t s);

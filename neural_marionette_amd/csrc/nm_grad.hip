@@ -894,7 +894,8 @@ __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restr
 #define NM_GNBF_T 1024
 __global__ __launch_bounds__(NM_GNBF_T) void gnb_finalize_kernel(const float* __restrict__ bpart, int nblk_b, const float* __restrict__ fpart,
                                                            int nblk_f, int C, int groups, int voxels, const float* __restrict__ gamma,
-                                                           float eps, float* __restrict__ coef, float* __restrict__ dgn) {
+                                                           float eps, float* __restrict__ coef, float* __restrict__ dgn,
+                                                           const double* __restrict__ chsum) {
     __shared__ double red[NM_GNBF_T * 4];
     __shared__ double chan[64 * 4];      // per channel: sum y, sum y^2, S1, S2
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -903,7 +904,8 @@ __global__ __launch_bounds__(NM_GNBF_T) void gnb_finalize_kernel(const float* __
     const int cl = threadIdx.x % cpg, ln = threadIdx.x / cpg, c = g * cpg + cl;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if (ln < L) {
-        for (int b = ln; b < nblk_f; b += L) { const float* q = fpart + (((size_t)n * nblk_f + b) * C + c) * 2; a0 += q[0]; a1 += q[1]; }
+        // (the forward sums: from the forward finalisation when it left them, else a second walk over the conv's partials)
+        if (!chsum) for (int b = ln; b < nblk_f; b += L) { const float* q = fpart + (((size_t)n * nblk_f + b) * C + c) * 2; a0 += q[0]; a1 += q[1]; }
         for (int b = ln; b < nblk_b; b += L) { const float* q = bpart + (((size_t)n * nblk_b + b) * C + c) * 2; a2 += q[0]; a3 += q[1]; }
     }
     red[threadIdx.x * 4] = a0; red[threadIdx.x * 4 + 1] = a1; red[threadIdx.x * 4 + 2] = a2; red[threadIdx.x * 4 + 3] = a3;
@@ -912,6 +914,7 @@ __global__ __launch_bounds__(NM_GNBF_T) void gnb_finalize_kernel(const float* __
         double s[4] = {0, 0, 0, 0};
         for (int l = 0; l < L; ++l)
             for (int j = 0; j < 4; ++j) s[j] += red[(l * cpg + threadIdx.x) * 4 + j];
+        if (chsum) { s[0] = chsum[((size_t)n * C + c) * 2]; s[1] = chsum[((size_t)n * C + c) * 2 + 1]; }
         for (int j = 0; j < 4; ++j) chan[threadIdx.x * 4 + j] = s[j];
     }
     __syncthreads();
@@ -1297,10 +1300,10 @@ int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hip
 }
 
 int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, int nblk_f, int N, int C, int groups, int voxels,
-                           const float* gamma, float eps, float* coef, float* dgn, hipStream_t s) {
+                           const float* gamma, float eps, float* coef, float* dgn, hipStream_t s, const double* chsum) {
     if (groups <= 0 || C % groups || C / groups > 64) { nm_set_error("gnb_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
     hipLaunchKernelGGL(gnb_finalize_kernel, dim3(N * groups), dim3(NM_GNBF_T), 0, s, bpart, nblk_b, fpart, nblk_f, C, groups, voxels, gamma,
-                       eps, coef, dgn);
+                       eps, coef, dgn, chsum);
     return nm_check_hip(hipGetLastError(), "gnb_finalize launch");
 }
 

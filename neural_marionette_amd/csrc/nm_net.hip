@@ -23,14 +23,15 @@ struct ConvRec {
     const ConvW* w = nullptr; const NormW* gn = nullptr;
     TensorRef in{}, out{};                       // lazy input / lazy output (raw conv result + pending GN affine + slope)
     const float* fpart = nullptr; int nblk = 0;  // forward GroupNorm partial sums of the conv epilogue
+    const double* chsum = nullptr;               // their per-channel totals (left by the forward finalisation when it can)
     int stride = 1, pad = 0; bool up2 = false;
 };
 struct ResRec { ConvRec c1, c2, cs; bool has_skip = false; };
-struct UpRec { const UpW* w = nullptr; TensorRef in{}, out{}; const float* fpart = nullptr; int nblk = 0; };
+struct UpRec { const UpW* w = nullptr; TensorRef in{}, out{}; const float* fpart = nullptr; int nblk = 0; const double* chsum = nullptr; };
 struct HgRec { ResRec s1, e1, s2, e2, s3, e3, d3, d2, d1; ConvRec p1, p2, p3; UpRec u3, u2, u1; };
 struct FeatRec {
     const FeatNetW* w = nullptr; const float* occ = nullptr; int N = 0, G = 0;
-    TensorRef first{}; const float* fpart0 = nullptr; int nblk0 = 0;
+    TensorRef first{}; const float* fpart0 = nullptr; int nblk0 = 0; const double* chsum0 = nullptr;
     ConvRec p1, p3; ResRec r2, r5; HgRec hg;
 };
 struct TrainTape {
@@ -282,20 +283,22 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
     float* out = out_buf ? out_buf : n.alloc((size_t)in.N * ov * w.Cout);
     float *part = nullptr, *scale = nullptr, *shift = nullptr;
     const int nblk = nm_conv_blocks_per_frame(g, in.C);
+    double* chsum = nullptr;
     if (gn) {
         part = n.alloc((size_t)in.N * nblk * w.Cout * 2);
         scale = n.alloc((size_t)in.N * w.Cout); shift = n.alloc((size_t)in.N * w.Cout);
+        if (rec && nm_gn_finalize_has_chsum(w.Cout, gn->groups)) chsum = reinterpret_cast<double*>(n.alloc((size_t)in.N * w.Cout * 4));
     }
     if (n.live()) {
         if (in.C != w.Cin_pad) { nm_set_error("conv_gn: input has %d channels, layer expects %d", in.C, w.Cin_pad); n.rc = NM_ERR_STATE; }
         else {
             n.run(nm_launch_conv(in, w.wp, w.bias, out, g, part, n.s, w.Cin, w.wp16));
             if (gn) n.run(nm_launch_gn_finalize(part, in.N, nblk, w.Cout, gn->groups, (double)ov * (w.Cout / gn->groups),
-                                                gn->gamma, gn->beta, 1e-5f, scale, shift, n.s));
+                                                gn->gamma, gn->beta, 1e-5f, scale, shift, n.s, chsum));
         }
     }
     TensorRef o = mk(out, in.N, g.OD, g.OH, g.OW, w.Cout, scale, shift, slope_after);
-    if (rec) { rec->w = &w; rec->gn = gn; rec->in = in; rec->out = o; rec->fpart = part; rec->nblk = nblk; rec->stride = stride; rec->pad = pad; rec->up2 = up2; }
+    if (rec) { rec->w = &w; rec->gn = gn; rec->in = in; rec->out = o; rec->fpart = part; rec->nblk = nblk; rec->chsum = chsum; rec->stride = stride; rec->pad = pad; rec->up2 = up2; }
     return o;
 }
 
@@ -331,14 +334,15 @@ TensorRef up(Net& n, const TensorRef& x, const UpW& w, int outpad, UpRec* rec = 
     const int nblk = nm_stats_blocks_per_frame((int)ov);
     float* part = n.alloc((size_t)x.N * nblk * w.Cout * 2);
     float* scale = n.alloc((size_t)x.N * w.Cout); float* shift = n.alloc((size_t)x.N * w.Cout);
+    double* chsum = (rec && nm_gn_finalize_has_chsum(w.Cout, w.n.groups)) ? reinterpret_cast<double*>(n.alloc((size_t)x.N * w.Cout * 4)) : nullptr;
     if (n.live()) {
         n.run(nm_launch_convT2(x, w.w, w.bias, out, w.Cout, OD, OH, OW, n.s));
         n.run(nm_launch_gn_partials(out, x.N, (int)ov, w.Cout, part, n.s));
         n.run(nm_launch_gn_finalize(part, x.N, nblk, w.Cout, w.n.groups, (double)ov * (w.Cout / w.n.groups), w.n.gamma,
-                                    w.n.beta, 1e-5f, scale, shift, n.s));
+                                    w.n.beta, 1e-5f, scale, shift, n.s, chsum));
     }
     TensorRef o = mk(out, x.N, OD, OH, OW, w.Cout, scale, shift, LRELU);
-    if (rec) { rec->w = &w; rec->in = x; rec->out = o; rec->fpart = part; rec->nblk = nblk; }
+    if (rec) { rec->w = &w; rec->in = x; rec->out = o; rec->fpart = part; rec->nblk = nblk; rec->chsum = chsum; }
     return o;
 }
 
@@ -369,13 +373,14 @@ TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w,
     const int nblk = nm_occ_blocks_per_frame(G);
     float* part = n.alloc((size_t)N * nblk * Cout * 2);
     float* scale = n.alloc((size_t)N * Cout); float* shift = n.alloc((size_t)N * Cout);
+    double* chsum = (rec && nm_gn_finalize_has_chsum(Cout, w.n0.groups)) ? reinterpret_cast<double*>(n.alloc((size_t)N * Cout * 4)) : nullptr;
     if (n.live()) {
         n.run(nm_launch_conv_k5occ(occ, N, G, w.occ_w, w.field, out, Cout, w.c0.Co_pad, part, n.s));
         n.run(nm_launch_gn_finalize(part, N, nblk, Cout, w.n0.groups, (double)G3 * (Cout / w.n0.groups), w.n0.gamma, w.n0.beta,
-                                    1e-5f, scale, shift, n.s));
+                                    1e-5f, scale, shift, n.s, chsum));
     }
     TensorRef o = mk(out, N, G, G, G, Cout, scale, shift, LRELU);
-    if (rec) { rec->w = &w; rec->occ = occ; rec->N = N; rec->G = G; rec->first = o; rec->fpart0 = part; rec->nblk0 = nblk; }
+    if (rec) { rec->w = &w; rec->occ = occ; rec->N = N; rec->G = G; rec->first = o; rec->fpart0 = part; rec->nblk0 = nblk; rec->chsum0 = chsum; }
     return o;
 }
 
@@ -565,8 +570,8 @@ TensorRef plain(const float* p, const TensorRef& like) { return mk(p, like.N, li
 // GroupNorm(+LeakyReLU) backward of a lazy tensor: returns dy (gradient of the raw conv output) and writes the gradients of
 // gamma / beta and of the bias of the producing conv
 // (amax, optional: device word that ends up holding max |dy|, for the operand scaling of the data-gradient conv)
-const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float* fpart, int nblk_f, const std::string& bias_key,
-                      const float* dA, unsigned* amax = nullptr, const float* dA_mul = nullptr) {
+const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float* fpart, int nblk_f, const double* chsum,
+                      const std::string& bias_key, const float* dA, unsigned* amax = nullptr, const float* dA_mul = nullptr) {
     const int N = out.N, C = out.C, V = out.D * out.H * out.W;
     const int nbb = nm_gnb_blocks_per_frame(V);
     float* dy = nullptr;
@@ -578,7 +583,7 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
         float* gg = b.grad(gn->key + ".weight", C); float* gb = b.grad(gn->key + ".bias", C); float* gbias = b.grad(bias_key, C);
         if (b.live()) {
             b.run(nm_launch_gnb_partials(dA, out, bpart, b.s, dA_mul));
-            b.run(nm_launch_gnb_finalize(bpart, nbb, fpart, nblk_f, N, C, gn->groups, V, gn->gamma, 1e-5f, coef, dgn, b.s));
+            b.run(nm_launch_gnb_finalize(bpart, nbb, fpart, nblk_f, N, C, gn->groups, V, gn->gamma, 1e-5f, coef, dgn, b.s, chsum));
             b.run(nm_launch_sum_frames3(dgn, N, C, gg, gb, gbias, b.s));
             b.run(nm_launch_gnb_apply(dA, out, coef, dy, b.s, amax, dA_mul));
         }
@@ -637,7 +642,7 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
     const bool split = nm_conv_get_mode() != 0;          // split-fp16 kernels: dy is read pre-scaled by a power of two
     DyScale ds;
     ds.prepare(b, split && r.stride == 1 && (w.ks == 3 || (need_din && w.wd16)), r.out.N * r.out.C, sc2_keep);
-    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, w.key + ".bias", dA, ds.amax, dA_mul);
+    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, r.chsum, w.key + ".bias", dA, ds.amax, dA_mul);
     const TensorRef dyT = plain(dy, r.out);
     const TensorRef dyS = ds.apply(b, dyT);
     {   // weight gradient
@@ -698,7 +703,7 @@ float* up_bwd(Bwd& b, const UpRec& r, const float* dA) {
     const size_t m = b.ws.mark();
     DyScale ds;
     ds.prepare(b, w.wd16 && nm_conv_get_mode() != 0, r.out.N * r.out.C);
-    const float* dy = norm_bwd(b, r.out, &w.n, r.fpart, r.nblk, w.key + ".bias", dA, ds.amax);
+    const float* dy = norm_bwd(b, r.out, &w.n, r.fpart, r.nblk, r.chsum, w.key + ".bias", dA, ds.amax);
     const TensorRef dyT = plain(dy, r.out);
     float* wsb = b.alloc(nm_wgrad_ws_floats(in.N, in.D, in.H, in.W, w.Cin, w.Cout, 2, 2));
     float* gw = b.grad(w.key + ".weight", (int64_t)w.Cin * w.Cout * 8);
@@ -744,7 +749,7 @@ void feature_net_bwd(Bwd& b, const FeatRec& r, const float* dFeat, bool sparse_o
     float* d_first = conv_bwd(b, r.p1, d_p1, true);
     // first layer: GroupNorm backward, then the weight gradient against cat[occ, coords] rebuilt from the occupancy
     const FeatNetW& w = *r.w;
-    const float* dy = norm_bwd(b, r.first, &w.n0, r.fpart0, r.nblk0, w.c0.key + ".bias", d_first);
+    const float* dy = norm_bwd(b, r.first, &w.n0, r.fpart0, r.nblk0, r.chsum0, w.c0.key + ".bias", d_first);
     float* wsb = b.alloc(nm_wgrad_k5occ_ws_floats(r.N, r.G, w.c0.Cout));
     float* gw = b.grad(w.c0.key + ".weight", (int64_t)w.c0.Cout * 4 * 125);
     if (b.live()) b.run(nm_launch_wgrad_k5occ(r.occ, r.N, r.G, plain(dy, r.first), wsb, gw, b.s, sparse_occ ? 1 : 0));
