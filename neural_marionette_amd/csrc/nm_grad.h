@@ -43,7 +43,7 @@ int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, 
 // below the fp16 normal range (6e-5), where the hi/lo split loses its low bits; dy is read as dy * 2^k through the lazy
 // affine of the conv kernels and the result is multiplied by 2^-k (exact).
 int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s, const float* mul = nullptr);
-int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* sc2 /*[2^k, 2^-k]*/, hipStream_t s);
+int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* sc2 /*[2^k, 2^-k]*/, hipStream_t s, float* zero_shift = nullptr);
 int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s);
 
 // ---- misc --------------------------------------------------------------------------------------------------------------

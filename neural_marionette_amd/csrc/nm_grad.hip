@@ -1038,12 +1038,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 
 // scale[i] = 2^k with max * 2^k in (128, 256] (so that the fp16 hi/lo split of the data-gradient conv sees O(100) operands,
 // far from the fp16 denormal range); sc2[0] = 2^k, sc2[1] = 2^-k
-__global__ void make_scale_kernel(const unsigned* __restrict__ amax, int count, float* __restrict__ scale, float* __restrict__ sc2) {
+__global__ void make_scale_kernel(const unsigned* __restrict__ amax, int count, float* __restrict__ scale, float* __restrict__ sc2,
+                                  float* __restrict__ shift) {
     const float mx = __uint_as_float(*amax);
     float sc = 1.0f;
     // exponent clamped to +-100: for a vanishing (denormal-sized) or huge gradient the scale and its reciprocal must both stay finite
     if (mx > 0.f && mx < INFINITY) { int e; frexpf(mx, &e); sc = ldexpf(1.0f, min(max(8 - e, -100), 100)); }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) scale[i] = sc;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) { scale[i] = sc; if (shift) shift[i] = 0.f; }
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc2[0] = sc; sc2[1] = 1.0f / sc; }
 }
 
@@ -1335,8 +1336,8 @@ int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s, co
     return nm_check_hip(hipGetLastError(), "absmax launch");
 }
 
-int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* sc2, hipStream_t s) {
-    hipLaunchKernelGGL(make_scale_kernel, dim3((count + 255) / 256), dim3(256), 0, s, amax, count, scale, sc2);
+int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* sc2, hipStream_t s, float* zero_shift) {
+    hipLaunchKernelGGL(make_scale_kernel, dim3((count + 255) / 256), dim3(256), 0, s, amax, count, scale, sc2, zero_shift);
     return nm_check_hip(hipGetLastError(), "make_scale launch");
 }
 

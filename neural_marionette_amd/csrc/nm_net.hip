@@ -543,6 +543,7 @@ struct Bwd {
     nm_ctx* c; hipStream_t s; Arena& ws; int rc = NM_OK;
     const std::map<std::string, std::pair<float*, int64_t>>* grads;     // nullptr in the sizing pass
     float* zb = nullptr;                                                  // 512 zeros: bias of the data-gradient convolutions
+    unsigned* amax_pool = nullptr; int amax_next = 0, amax_cap = 0;       // zeroed words behind zb: one max|dy| cell per scaled layer
     Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g) : c(ctx), s(ctx->stream), ws(ctx->ws), grads(g) {}
     Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g, hipStream_t stream) : c(ctx), s(stream), ws(ctx->ws), grads(g) {}
     bool live() const { return rc == NM_OK && !ws.dry; }
@@ -614,15 +615,16 @@ struct DyScale {
     unsigned* amax = nullptr; float* scale = nullptr; float* shift = nullptr; float* sc2 = nullptr;
     void prepare(Bwd& b, bool on, int count, float* sc2_keep = nullptr) {
         if (!on) return;
-        amax = reinterpret_cast<unsigned*>(b.alloc(64)); scale = b.alloc(count); shift = b.alloc(count); sc2 = sc2_keep ? sc2_keep : b.alloc(64);
-        if (b.live()) {
-            b.run(nm_check_hip(hipMemsetAsync(amax, 0, sizeof(unsigned), b.s), "backward: memset"));
-            b.run(nm_check_hip(hipMemsetAsync(shift, 0, (size_t)count * sizeof(float), b.s), "backward: memset"));
-        }
+        // (the max cell from the pool zeroed once per backward; the shift vector is zeroed by make_scale: two memsets per layer
+        //  were 126 dependent stream operations per step)
+        const bool pooled = b.amax_pool && b.amax_next < b.amax_cap;
+        amax = pooled ? b.amax_pool + b.amax_next++ : reinterpret_cast<unsigned*>(b.alloc(64));
+        scale = b.alloc(count); shift = b.alloc(count); sc2 = sc2_keep ? sc2_keep : b.alloc(64);
+        if (!pooled && b.live()) b.run(nm_check_hip(hipMemsetAsync(amax, 0, sizeof(unsigned), b.s), "backward: memset"));
     }
     TensorRef apply(Bwd& b, const TensorRef& dyT) {
         if (!amax) return dyT;
-        if (b.live()) b.run(nm_launch_make_scale(amax, dyT.N * dyT.C, scale, sc2, b.s));
+        if (b.live()) b.run(nm_launch_make_scale(amax, dyT.N * dyT.C, scale, sc2, b.s, shift));
         TensorRef t = dyT; t.scale = scale; t.shift = shift;
         return t;
     }
@@ -765,10 +767,11 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
     const std::string k2v = "kypt_detector.kypt_to_vox", v2k = "kypt_detector.vox_to_kypt";
     float* dkp = b.alloc((size_t)F * K * 4);
     float* dfeat = b.alloc((size_t)F * g3 * FEAT);
-    b.zb = b.alloc(512);
+    b.zb = b.alloc(1024);
+    b.amax_pool = reinterpret_cast<unsigned*>(b.zb + 512); b.amax_cap = 256;      // (the second stream's walk takes cells 256..511)
     if (b.live()) {
         b.run(nm_check_hip(hipMemsetAsync(dkp, 0, (size_t)F * K * 4 * sizeof(float), b.s), "backward: memset"));
-        b.run(nm_check_hip(hipMemsetAsync(b.zb, 0, 512 * sizeof(float), b.s), "backward: memset"));
+        b.run(nm_check_hip(hipMemsetAsync(b.zb, 0, 1024 * sizeof(float), b.s), "backward: memset"));
     }
 
     {   // decoder: tail -> d11 -> d8 -> d4 -> d1 -> adjust -> combined representation
@@ -839,7 +842,7 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         // run beside the per-frame net's backward.  Their scratch stays out of reach of the main stream (the arena top is left at
         // this block's high-water mark), exactly as in the forward.
         Bwd b2(c, grads, c->stream2);
-        b2.zb = b.zb;
+        b2.zb = b.zb; b2.amax_pool = b.amax_pool + 256; b2.amax_cap = 256;
         if (b.live()) {
             b.run(nm_check_hip(hipEventRecord(c->ev_fork, b.s), "backward: fork event"));
             b.run(nm_check_hip(hipStreamWaitEvent(c->stream2, c->ev_fork, 0), "backward: side stream wait"));
