@@ -103,6 +103,7 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     if (ctx->ws2.base) (void)hipFree(ctx->ws2.base);
     if (ctx->ws_t.base) (void)hipFree(ctx->ws_t.base);
     if (ctx->copy_table) (void)hipFree(ctx->copy_table);
+    if (ctx->pack_table) (void)hipFree(ctx->pack_table);
     if (ctx->nf_flag) (void)hipFree(ctx->nf_flag);
     nm_net_free_tape(ctx);
     nm_vrnn_free_tape(ctx);

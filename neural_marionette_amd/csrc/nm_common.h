@@ -69,6 +69,17 @@ void nm_conv_set_mode(int mode);
 int nm_conv_get_mode();
 int nm_conv_single();            // 1 in conv mode 3 (hi x hi products only)
 int nm_launch_pack_conv_weight16(const float* w_oidhw, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s);
+// All the per-layer weight packs of one nm_ctx_set_weights as ONE launch (a training step re-packs every conv after Adam: ~330 tiny
+// dependent launches otherwise).  A job packs the logical weight W(co, ci, tap), co < Cout, ci < Cin, into the fp32 layout of
+// nm_launch_pack_conv_weight (wp) and, when wp16 is set, the split-fp16 layout of nm_launch_pack_conv_weight16.  The source is an
+// OIDHW tensor with src_cin input channels per row: W = src[(co * src_cin + ci) * taps + tap], or with flip the data-gradient
+// weight (flipped taps, transposed channels): W = src[(ci * src_cin + co) * taps + (taps - 1 - tap)].
+struct NmPackJob {
+    const float* src; float* wp; void* wp16;
+    int Cout, Cin, ks, Cin_pad, Co_pad, src_cin, flip, blk0, nblk;
+};
+int nm_pack_job_blocks(const NmPackJob& j);       // blocks the job takes in the launch (fills nothing)
+int nm_launch_pack_jobs(const NmPackJob* device_jobs, int njobs, int total_blocks, hipStream_t s);
 // first layer: occupancy channel as a taps-as-K GEMM + weight-only constant field (see nm_conv.hip)
 int nm_occ_blocks_per_frame(int G);
 int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s);

@@ -2353,6 +2353,52 @@ int nm_launch_pack_conv_weight16(const float* w, int Cout, int Cin, int ks, void
     return nm_check_hip(hipGetLastError(), "pack_conv_weight16 launch");
 }
 
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const NmPackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                           // the job whose block range holds blockIdx.x
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const NmPackJob j = jobs[lo];
+    const int lb = blockIdx.x - j.blk0, taps = j.ks * j.ks * j.ks;
+    auto W = [&](int co, int ci, int tap) -> float {
+        if (co >= j.Cout || ci >= j.Cin) return 0.f;
+        return j.flip ? j.src[((size_t)ci * j.src_cin + co) * taps + (taps - 1 - tap)] : j.src[((size_t)co * j.src_cin + ci) * taps + tap];
+    };
+    const size_t total32 = (size_t)taps * j.Cin_pad * j.Co_pad;
+    for (size_t i = (size_t)lb * 256 + threadIdx.x; i < total32; i += (size_t)j.nblk * 256) {         // pack_conv_weight_kernel's layout
+        const int e = i & 3; size_t r = i >> 2;
+        const int co = r % j.Co_pad; r /= j.Co_pad;
+        const int q = r % (j.Cin_pad / 4), tap = r / (j.Cin_pad / 4);
+        j.wp[i] = W(co, q * 4 + e, tap);
+    }
+    if (j.wp16) {                                                                                      // pack_conv_weight16_kernel's layout
+        _Float16* packed = reinterpret_cast<_Float16*>(j.wp16);
+        const int C16 = (j.Cin + 15) >> 4;
+        const size_t total16 = (size_t)taps * C16 * 2 * j.Co_pad * 8;
+        for (size_t i = (size_t)lb * 256 + threadIdx.x; i < total16; i += (size_t)j.nblk * 256) {
+            const int e = i & 7; size_t r = i >> 3;
+            const int co = r % j.Co_pad; r /= j.Co_pad;
+            const int hh = r & 1; r >>= 1;
+            const int cb = r % C16, tap = r / C16;
+            const float v = W(co, cb * 16 + hh * 8 + e, tap);
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)((v - (float)h) * NM_SPLIT_SCALE);
+            const size_t base = ((((size_t)tap * C16 + cb) * 4) * j.Co_pad) * 8;
+            packed[base + ((size_t)hh * j.Co_pad + co) * 8 + e] = h;
+            packed[base + ((size_t)(2 + hh) * j.Co_pad + co) * 8 + e] = l;
+        }
+    }
+}
+
+int nm_pack_job_blocks(const NmPackJob& j) {
+    const size_t total = (size_t)j.ks * j.ks * j.ks * j.Cin_pad * j.Co_pad;
+    return (int)min((total + 255) / 256, (size_t)64);
+}
+
+int nm_launch_pack_jobs(const NmPackJob* device_jobs, int njobs, int total_blocks, hipStream_t s) {
+    if (njobs <= 0) return NM_OK;
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3(total_blocks), dim3(256), 0, s, device_jobs, njobs);
+    return nm_check_hip(hipGetLastError(), "pack_jobs launch");
+}
+
 size_t nm_packed_weight_floats(int ks, int Cin_pad, int Co_pad) {
     return (size_t)ks * ks * ks * Cin_pad * Co_pad;
 }

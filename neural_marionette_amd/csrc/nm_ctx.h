@@ -94,6 +94,8 @@ struct nm_ctx {
     Arena ws_t;                            // activations retained between nm_detector_forward_train and nm_detector_backward
     std::vector<char> host_table2;         // host staging of set_weights' copy table
     void* copy_table = nullptr; size_t copy_table_cap = 0;      // its device copy
+    std::vector<char> host_table3;         // the same for the weight-pack job table (nm_launch_pack_jobs)
+    void* pack_table = nullptr; size_t pack_table_cap = 0;
     std::vector<char> host_table;          // host staging of nm_adam_step_multi's pointer table (kept alive across the async copy)
     struct TrainTape* tape = nullptr;      // what the backward pass needs of the last training forward (nm_net.hip)
     void* vtape = nullptr;                 // VrnnTape of the last nm_vrnn_encode_train (nm_vrnn.hip)

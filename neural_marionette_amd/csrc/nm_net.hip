@@ -70,6 +70,30 @@ struct Loader {
     int rc = NM_OK;
     std::vector<CopyItem> copies;
 
+    // one launch for all the conv weight packs (forward layouts and, in training, the data-gradient layouts)
+    std::vector<NmPackJob> packs;
+    void pack(const float* src, float* wp, void* wp16, int Cout, int Cin, int ks, int Cin_pad, int Co_pad, int src_cin, int flip) {
+        NmPackJob j; j.src = src; j.wp = wp; j.wp16 = wp16; j.Cout = Cout; j.Cin = Cin; j.ks = ks; j.Cin_pad = Cin_pad; j.Co_pad = Co_pad;
+        j.src_cin = src_cin; j.flip = flip; j.blk0 = 0; j.nblk = 0;
+        packs.push_back(j);
+    }
+    int flush_packs() {
+        if (packs.empty()) return NM_OK;
+        int blocks = 0;
+        for (NmPackJob& j : packs) { j.blk0 = blocks; j.nblk = nm_pack_job_blocks(j); blocks += j.nblk; }
+        const size_t bytes = packs.size() * sizeof(NmPackJob);
+        c->host_table3.assign(reinterpret_cast<const char*>(packs.data()), reinterpret_cast<const char*>(packs.data()) + bytes);
+        if (c->pack_table_cap < bytes) {
+            if (c->pack_table) { (void)hipDeviceSynchronize(); (void)hipFree(c->pack_table); }
+            c->pack_table = nullptr; c->pack_table_cap = 0;
+            if (hipMalloc(&c->pack_table, bytes) != hipSuccess) { nm_set_error("set_weights: hipMalloc(pack table) failed"); return NM_ERR_HIP; }
+            c->pack_table_cap = bytes;
+        }
+        int r = nm_check_hip(hipMemcpyAsync(c->pack_table, c->host_table3.data(), bytes, hipMemcpyHostToDevice, c->stream), "set_weights: pack table");
+        if (r) return r;
+        return nm_launch_pack_jobs(static_cast<const NmPackJob*>(c->pack_table), (int)packs.size(), blocks, c->stream);
+    }
+
     // one launch for all the plain copies (biases, GroupNorm affine, VRNN matrices ...)
     int flush_copies() {
         if (copies.empty()) return NM_OK;
@@ -115,12 +139,15 @@ struct Loader {
         if (!src) return w;
         w.wp = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, w.Cin_pad, w.Co_pad));
         if (!w.wp) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
-        int r = nm_launch_pack_conv_weight(src, Cout, Cin, ks, w.wp, w.Cin_pad, w.Co_pad, c->stream);
-        if (!r && (Cin % 8 == 0 || pad16) && Cin >= 16) {          // (Cin % 16 == 8: zero-padded, used by the small-volume core only)
+        int r = NM_OK;
+        if ((Cin % 8 == 0 || pad16) && Cin >= 16) {                // (Cin % 16 == 8: zero-padded, used by the small-volume core only)
             w.wp16 = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, (Cin + 15) & ~15, w.Co_pad));      // same byte count as fp32
             if (!w.wp16) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
-            r = nm_launch_pack_conv_weight16(src, Cout, Cin, ks, w.wp16, w.Co_pad, c->stream);
         }
+        if (ks == 5) {         // the first layers: packed at once - first_layer_tables() runs a conv with these weights inside set_weights
+            r = nm_launch_pack_conv_weight(src, Cout, Cin, ks, w.wp, w.Cin_pad, w.Co_pad, c->stream);
+            if (!r && w.wp16) r = nm_launch_pack_conv_weight16(src, Cout, Cin, ks, w.wp16, w.Co_pad, c->stream);
+        } else pack(src, w.wp, w.wp16, Cout, Cin, ks, w.Cin_pad, w.Co_pad, Cin, 0);
         if (!r && c->training && ks != 5) r = dgrad_packs(src, w);
         if (r && !rc) rc = r;
         return w;
@@ -135,18 +162,17 @@ struct Loader {
             if (!w.wt) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
             return nm_launch_transpose_convT_weight(src, w.Cout, w.Cin, w.wt, c->stream);
         }
-        float* wf = nm_ctx_weight_alloc(c, (size_t)w.csel * w.Cout * taps);
         const size_t fl = nm_packed_weight_floats(w.ks, w.Cout, w.cd_pad);
         w.wd = nm_ctx_weight_alloc(c, fl);
-        if (!wf || !w.wd) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
-        int r = nm_launch_flip_weight(src, w.Cout, w.Cin, w.csel, w.ks, wf, c->stream);
-        if (!r) r = nm_launch_pack_conv_weight(wf, w.csel, w.Cout, w.ks, w.wd, w.Cout, w.cd_pad, c->stream);
-        if (!r && w.Cout % 16 == 0) {
+        if (!w.wd) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
+        if (w.Cout % 16 == 0) {
             w.wd16 = nm_ctx_weight_alloc(c, fl);
             if (!w.wd16) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
-            r = nm_launch_pack_conv_weight16(wf, w.csel, w.Cout, w.ks, w.wd16, w.cd_pad, c->stream);
         }
-        return r;
+        // the flipped / transposed weight (csel "output" channels = the input channels the gradient is wanted for) read in place
+        pack(src, w.wd, w.wd16, w.csel, w.Cout, w.ks, w.Cout, w.cd_pad, w.Cin, 1);
+        (void)taps;
+        return NM_OK;
     }
     // composite weight sets of the fused-upsample layers (nm_up2c.hip); a null wup leaves the layer on conv_f16s<.., UP2>
     void up2_sets(const std::string& p, ConvW& w) {
@@ -182,11 +208,12 @@ struct Loader {
             u.cd_pad = (ci + 31) & ~31;
             const size_t fl = nm_packed_weight_floats(2, co, u.cd_pad);
             u.wd = nm_ctx_weight_alloc(c, fl);
-            int r = u.wd ? nm_launch_pack_conv_weight(src, ci, co, 2, u.wd, co, u.cd_pad, c->stream) : NM_ERR_HIP;
+            int r = u.wd ? NM_OK : NM_ERR_HIP;
             if (!r && co % 16 == 0) {
                 u.wd16 = nm_ctx_weight_alloc(c, fl);
-                r = u.wd16 ? nm_launch_pack_conv_weight16(src, ci, co, 2, u.wd16, u.cd_pad, c->stream) : NM_ERR_HIP;
+                r = u.wd16 ? NM_OK : NM_ERR_HIP;
             }
+            if (!r) pack(src, u.wd, u.wd16, ci, co, 2, co, u.cd_pad, co, 0);
             if (r && !rc) rc = r;
         }
         u.bias = copy(p + ".block.0.bias", co);
@@ -941,6 +968,7 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
     }
     if (L.rc) return L.rc;
     if ((rc = L.flush_copies())) return rc;
+    if ((rc = L.flush_packs())) return rc;
     rc = nm_check_hip(hipGetLastError(), "set_weights: pack kernels");
     if (rc) return rc;
     if (c->owned_cursor < c->owned.size()) {           // fewer buffers than last time (training packs switched off): drop the rest
