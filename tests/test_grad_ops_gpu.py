@@ -37,6 +37,9 @@ BWD_CASES = [
     (128, 64, 3, 1, 1, 8, 5, True, False, 128),
     (48, 72, 3, 1, 1, 8, 3, True, False, 48),
     (64, 32, 3, 1, 1, 8, 2, True, True, 64),
+    # fused-upsample layers big enough for the LDS-tiled upsample adjoint (coarse extents whole 2x4x8 bricks, borders on every side)
+    (64, 32, 3, 1, 1, 16, 2, True, True, 64),
+    (32, 32, 3, 1, 1, 16, 3, False, True, 32),
     # pool data gradient on the LDS-weight transposed-conv kernel (>= 65536 coarse voxels)
     (32, 32, 2, 2, 0, 32, 5, True, False, 32),
     (64, 64, 2, 2, 0, 32, 3, False, False, 64),
