@@ -76,42 +76,64 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         tv[j] = t < p.groups;
         if (MODE == 2) toff[j] = ((t / 5) * p.HY + (t % 5)) * p.HX * CP;
         else { const int dz = t / (p.ks * p.ks), dyy = (t / p.ks) % p.ks, dx = t % p.ks; toff[j] = ((dz * p.HY + dyy) * p.HX + dx) * CP; }
+        if (!tv[j]) toff[j] = 0;             // a tap slot beyond the layer's taps: multiplied like the others (no branch in the k-loop), never stored
     }
     const int coloff = MODE == 2 ? (l31 < 20 ? l31 : 0) : l31;
 
     const int per_frame = p.nbz * p.nby * p.nbx;
     const int total = p.in.N * per_frame;
+    // Staging.  (1) The loads of a batch are all issued before the first of them is activated and written to LDS: one item per
+    // iteration (load -> affine -> LDS store) made every item a full memory round trip.  (2) What does not depend on the brick is
+    // computed once per thread: an item's position in the brick / halo (packed x | y << 8 | z << 16, bit 31 = the item exists) and its
+    // element offset from the brick's first voxel - the div / mod chains of the item index were ~80 VALU instructions per item and
+    // brick, more than the loads themselves (32 -> 32 pool layer: 1.45 -> 0.95 ms).  Batch sizes keep the kernel under 256 registers
+    // (two workgroups per CU: larger batches, or the next brick prefetched into registers, measured 1.4-2x slower at one workgroup).
+    // A thread's channel quad (i & 7) is the same for all its items.
+    constexpr int DU = 8;                                 // dY items per thread: BV * 8 / 256, BV <= 256
+    constexpr int AU = MODE == 2 ? 5 : 20;                // input items per thread: HV * 8 / 256 <= 18.75 (k3 halo of a 4x8x8 brick); MODE 2: HV / 256
+    const int q = tid & 7;
+    int d_pk[DU], d_rel[DU], a_pk[AU], a_rel[AU];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+        const int k = (tid + 256 * u) >> 3;
+        const int x = k % p.BX, y = (k / p.BX) % p.BY, z = k / (p.BX * p.BY);
+        d_pk[u] = k < BV ? (x | (y << 8) | (z << 16) | (1 << 31)) : 0;
+        d_rel[u] = ((z * OH + y) * OW + x) * p.dy.C + m0 + 4 * q;
+    }
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+        const int hv = MODE == 2 ? tid + 256 * u : (tid + 256 * u) >> 3;
+        const int hx = hv % p.HX, hy = (hv / p.HX) % p.HY, hz = hv / (p.HX * p.HY);
+        a_pk[u] = hv < HV ? (hx | (hy << 8) | (hz << 16) | (1 << 31)) : 0;
+        a_rel[u] = MODE == 2 ? (hz * p.in.H + hy) * p.in.W + hx : ((hz * p.in.H + hy) * p.in.W + hx) * p.in.C + n0 + 4 * q;
+    }
     for (int b = blockIdx.x; b < total; b += p.S) {
         const int n = b / per_frame; int r = b % per_frame;
         const int bx = r % p.nbx; r /= p.nbx;
         const int by = r % p.nby, bz = r / p.nby;
         const int oz0 = bz * p.BZ, oy0 = by * p.BY, ox0 = bx * p.BX;
         __syncthreads();
-        // Staging in batches: the loads of a batch are all issued before the first of them is activated and written to LDS.  One
-        // item per iteration (load -> affine -> LDS store, the store ordered before the next load for all the compiler knows) made
-        // every iteration a full memory round trip: 28 us per brick on the pool layers where the brick's bytes take 2 us.
-        // A thread's channel quad (i & 7) is the same for all its items: the frame's scale / shift are loaded once per brick.
-        const int q = tid & 7;
         {
             const int m = m0 + 4 * q;
             f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.dy.scale && m < p.M) { sc = *reinterpret_cast<const f32x4*>(p.dy.scale + (size_t)n * p.dy.C + m); sh = *reinterpret_cast<const f32x4*>(p.dy.shift + (size_t)n * p.dy.C + m); }
+            const float* base = p.dy.p + ((((size_t)n * OD + oz0) * OH + oy0) * OW + ox0) * p.dy.C;
             constexpr int U = 4;
-            for (int i0 = tid; i0 < BV * 8; i0 += 256 * U) {
+#pragma unroll
+            for (int u0 = 0; u0 < DU; u0 += U) {
+                if (u0 * 256 >= BV * 8) break;            // (uniform)
                 f32x4 v[U]; bool ok[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int k = (i0 + 256 * u) >> 3;
-                    const int x = k % p.BX, y = (k / p.BX) % p.BY, z = k / (p.BX * p.BY);
-                    const int oz = oz0 + z, oy = oy0 + y, ox = ox0 + x;
-                    ok[u] = k < BV && oz < OD && oy < OH && ox < OW && m < p.M;
+                    const int pk = d_pk[u0 + u];
+                    ok[u] = pk < 0 && oz0 + ((pk >> 16) & 255) < OD && oy0 + ((pk >> 8) & 255) < OH && ox0 + (pk & 255) < OW && m < p.M;
                     v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok[u]) v[u] = *reinterpret_cast<const f32x4*>(p.dy.p + ((((size_t)n * OD + oz) * OH + oy) * OW + ox) * p.dy.C + m);
+                    if (ok[u]) v[u] = *reinterpret_cast<const f32x4*>(base + d_rel[u0 + u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int k = (i0 + 256 * u) >> 3;
-                    if (k >= BV) continue;
+                    if (d_pk[u0 + u] >= 0) continue;
+                    const int k = (tid + 256 * (u0 + u)) >> 3;
                     f32x4 t = v[u];
                     if (ok[u]) {
 #pragma unroll
@@ -124,46 +146,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         const int iz0 = oz0 * p.stride - p.pad, iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
         if (MODE == 2) {
             const int G = p.in.D;
-            constexpr int U = 4;
-            for (int h0 = tid; h0 < HV; h0 += 256 * U) {
-                float o[U]; int gz[U], gy[U], gx[U]; bool ok[U];
+            // (signed 64-bit: the brick's first halo voxel can lie before the tensor)
+            const float* base = p.in.p + (long long)n * G * G * G + ((long long)iz0 * G + iy0) * G + ix0;
+            float o[AU]; bool ok[AU];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int hv = h0 + 256 * u;
-                    const int hx = hv % p.HX, hy = (hv / p.HX) % p.HY, hz = hv / (p.HX * p.HY);
-                    gz[u] = iz0 + hz; gy[u] = iy0 + hy; gx[u] = ix0 + hx;
-                    ok[u] = hv < HV && (unsigned)gz[u] < (unsigned)G && (unsigned)gy[u] < (unsigned)G && (unsigned)gx[u] < (unsigned)G;
-                    o[u] = ok[u] ? p.in.p[(((size_t)n * G + gz[u]) * G + gy[u]) * G + gx[u]] : 0.f;
-                }
+            for (int u = 0; u < AU; ++u) {
+                const int pk = a_pk[u];
+                const int gz = iz0 + ((pk >> 16) & 255), gy = iy0 + ((pk >> 8) & 255), gx = ix0 + (pk & 255);
+                ok[u] = pk < 0 && (unsigned)gz < (unsigned)G && (unsigned)gy < (unsigned)G && (unsigned)gx < (unsigned)G;
+                o[u] = ok[u] ? base[a_rel[u]] : 0.f;
+            }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int hv = h0 + 256 * u;
-                    if (hv >= HV) continue;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ok[u]) { v[0] = o[u]; v[1] = lin_coord(gz[u], G); v[2] = lin_coord(gy[u], G); v[3] = lin_coord(gx[u], G); }
-                    *reinterpret_cast<f32x4*>(as + hv * 4) = v;
-                }
+            for (int u = 0; u < AU; ++u) {
+                const int pk = a_pk[u];
+                if (pk >= 0) continue;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok[u]) { v[0] = o[u]; v[1] = lin_coord(iz0 + ((pk >> 16) & 255), G); v[2] = lin_coord(iy0 + ((pk >> 8) & 255), G); v[3] = lin_coord(ix0 + (pk & 255), G); }
+                *reinterpret_cast<f32x4*>(as + (tid + 256 * u) * 4) = v;
             }
         } else {
             const int c = n0 + 4 * q;
             f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.in.scale && c < p.Nc) { sc = *reinterpret_cast<const f32x4*>(p.in.scale + (size_t)n * p.in.C + c); sh = *reinterpret_cast<const f32x4*>(p.in.shift + (size_t)n * p.in.C + c); }
-            constexpr int U = 8;
-            for (int i0 = tid; i0 < HV * 8; i0 += 256 * U) {
+            const float* base = p.in.p + ((((long long)n * p.in.D + iz0) * p.in.H + iy0) * p.in.W + ix0) * (long long)p.in.C;
+            constexpr int U = 4;
+#pragma unroll
+            for (int u0 = 0; u0 < AU; u0 += U) {
+                if (u0 * 256 >= HV * 8) break;            // (uniform)
                 f32x4 v[U]; bool ok[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int hv = (i0 + 256 * u) >> 3;
-                    const int hx = hv % p.HX, hy = (hv / p.HX) % p.HY, hz = hv / (p.HX * p.HY);
-                    const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
-                    ok[u] = hv < HV && (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && c < p.Nc;
+                    const int ui = u0 + u < AU ? u0 + u : AU - 1;
+                    const int pk = u0 + u < AU ? a_pk[ui] : 0;
+                    const int gz = iz0 + ((pk >> 16) & 255), gy = iy0 + ((pk >> 8) & 255), gx = ix0 + (pk & 255);
+                    ok[u] = pk < 0 && (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && c < p.Nc;
                     v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok[u]) v[u] = *reinterpret_cast<const f32x4*>(p.in.p + ((((size_t)n * p.in.D + gz) * p.in.H + gy) * p.in.W + gx) * p.in.C + c);
+                    if (ok[u]) v[u] = *reinterpret_cast<const f32x4*>(base + a_rel[ui]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int hv = (i0 + 256 * u) >> 3;
-                    if (hv >= HV) continue;
+                    if (u0 + u >= AU || a_pk[u0 + u < AU ? u0 + u : 0] >= 0) continue;
+                    const int hv = (tid + 256 * (u0 + u)) >> 3;
                     f32x4 t = v[u];
                     if (ok[u]) {                                                     // zero padding, not act(0)
 #pragma unroll
@@ -182,9 +205,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                     const int k = (z * p.BY + y) * p.BX + x0 + lh;
                     const float a = dys[k * 32 + l31];
                     const int hb = (((z * p.stride) * p.HY + y * p.stride) * p.HX + (x0 + lh) * p.stride) * CP + coloff;
+                    // (no test of tv[j] here: a branch around the MFMA made the compiler move the 16 accumulator registers in and out
+                    //  of every iteration)
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j)
-                        if (tv[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, as[hb + toff[j]], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, as[hb + toff[j]], acc[j], 0, 0, 0);
                 }
     }
     const int slot = MODE == 1 ? blockIdx.x * 4 + w : blockIdx.x;
@@ -1217,6 +1241,13 @@ WgradPlan plan_wgrad(int N, int OD, int OH, int OW, int M, int Nc, int ks, int s
 
 template <int MODE, int NTW>
 int launch_wgrad_t(const WgradPlan& q, hipStream_t s) {
+    {   // the kernel's per-thread item tables: 8 dY items, 20 input items (5 in MODE 2)
+        const int BV = q.p.BZ * q.p.BY * q.p.BX, HV = q.p.HZ * q.p.HY * q.p.HX;
+        if (BV > 256 || (MODE == 2 ? HV > 5 * 256 : HV * 8 > 20 * 256) || q.p.HX > 255 || q.p.HY > 255 || q.p.HZ > 255) {
+            nm_set_error("wgrad: brick %dx%dx%d / halo %dx%dx%d beyond the kernel's item tables", q.p.BZ, q.p.BY, q.p.BX, q.p.HZ, q.p.HY, q.p.HX);
+            return NM_ERR_ARG;
+        }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<MODE, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
