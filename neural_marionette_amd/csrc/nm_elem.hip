@@ -112,15 +112,15 @@ __global__ __launch_bounds__(256) void gn_partials_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void apply2_kernel(TensorRef a, TensorRef b, int has_b, float* __restrict__ out) {
-    const size_t per_frame = (size_t)a.D * a.H * a.W * a.C;       // floats
-    const size_t total4 = (size_t)a.N * per_frame / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        size_t e = i * 4;
-        size_t n = e / per_frame, r = e % per_frame;
-        int c = (int)(r % a.C);
+    // grid (blocks, frames): 32-bit index arithmetic inside a frame (the flat 64-bit index cost a 64-bit division and two
+    // remainders per 16-byte item)
+    const unsigned per_frame = (unsigned)a.D * a.H * a.W * a.C;     // floats
+    const size_t n = blockIdx.y;
+    for (unsigned r = (blockIdx.x * blockDim.x + threadIdx.x) * 4u; r < per_frame; r += gridDim.x * blockDim.x * 4u) {
+        const int c = (int)(r % (unsigned)a.C);
         f32x4 v = load_t(a, n, r, c);
         if (has_b) v = v + load_t(b, n, r, c);
-        *reinterpret_cast<f32x4*>(out + e) = v;
+        *reinterpret_cast<f32x4*>(out + n * per_frame + r) = v;
     }
 }
 
@@ -428,9 +428,11 @@ int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part,
 int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s) {
     if (a.C % 4) { nm_set_error("apply2: C %% 4 != 0"); return NM_ERR_ARG; }
     if (b && (b->N != a.N || b->D != a.D || b->H != a.H || b->W != a.W || b->C != a.C)) { nm_set_error("apply2: shape mismatch"); return NM_ERR_ARG; }
-    size_t total4 = (size_t)a.N * a.D * a.H * a.W * a.C / 4;
+    const size_t frame4 = (size_t)a.D * a.H * a.W * a.C / 4;
+    if (frame4 * 4 >= ((size_t)1 << 31)) { nm_set_error("apply2: frame too large"); return NM_ERR_ARG; }
     TensorRef bb = b ? *b : a;
-    hipLaunchKernelGGL(apply2_kernel, dim3(grid_for(total4)), dim3(256), 0, s, a, bb, b ? 1 : 0, out);
+    const unsigned bx = (unsigned)min((frame4 + 255) / 256, (size_t)max(1, 4096 / max(a.N, 1)));
+    hipLaunchKernelGGL(apply2_kernel, dim3(bx, a.N), dim3(256), 0, s, a, bb, b ? 1 : 0, out);
     return nm_check_hip(hipGetLastError(), "apply2 launch");
 }
 

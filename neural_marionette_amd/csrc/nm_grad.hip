@@ -1019,12 +1019,12 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
                                                         float* __restrict__ dy, unsigned* __restrict__ amax, const float* __restrict__ dmul) {
     float mx = 0.f;
     const float mm = dmul ? *dmul : 1.0f;
-    const size_t per_frame = (size_t)y.D * y.H * y.W * y.C;
-    const size_t total4 = (size_t)y.N * per_frame / 4;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const size_t e = i * 4;
-        const size_t n = e / per_frame;
-        const int c = (int)(e % y.C);
+    // grid (blocks, frames): 32-bit index arithmetic inside a frame (no 64-bit division per 16-byte item)
+    const unsigned per_frame = (unsigned)y.D * y.H * y.W * y.C;
+    const size_t n = blockIdx.y;
+    for (unsigned r = (blockIdx.x * 256u + threadIdx.x) * 4u; r < per_frame; r += gridDim.x * 1024u) {
+        const size_t e = n * per_frame + r;
+        const int c = (int)(r % (unsigned)y.C);
         const f32x4 yy = *reinterpret_cast<const f32x4*>(y.p + e);
         f32x4 d = *reinterpret_cast<const f32x4*>(dA + e);
         d[0] *= mm; d[1] *= mm; d[2] *= mm; d[3] *= mm;
@@ -1418,8 +1418,10 @@ int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipSt
 
 int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax, const float* dA_mul) {
     if (y.C % 4) { nm_set_error("gnb_apply: C %% 4 != 0"); return NM_ERR_ARG; }
-    const size_t total4 = (size_t)y.N * y.D * y.H * y.W * y.C / 4;
-    hipLaunchKernelGGL(gnb_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul);
+    const size_t frame4 = (size_t)y.D * y.H * y.W * y.C / 4;
+    if (frame4 * 4 >= ((size_t)1 << 31)) { nm_set_error("gnb_apply: frame too large"); return NM_ERR_ARG; }
+    const unsigned bx = (unsigned)min((frame4 + 255) / 256, (size_t)max(1, 4096 / max(y.N, 1)));
+    hipLaunchKernelGGL(gnb_apply_kernel, dim3(bx, y.N), dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul);
     return nm_check_hip(hipGetLastError(), "gnb_apply launch");
 }
 
