@@ -915,7 +915,10 @@ __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restr
 }
 
 // one block per (frame, group); cpg <= 64 channels per group; 1024 threads: 1024 / cpg lanes walk each channel's partial blocks
-#define NM_GNBF_T 1024
+// NM_GNBF_T threads: 1024 when the forward partial sums have to be walked as well, 256 when the forward finalisation left the
+// per-channel totals (a 256-thread block with 8 KB of LDS finds a CU beside the other stream's persistent convolutions; the
+// 1024-thread block waited for a whole CU: 49 us average in the two-stream step for microseconds of work)
+template <int NM_GNBF_T>
 __global__ __launch_bounds__(NM_GNBF_T) void gnb_finalize_kernel(const float* __restrict__ bpart, int nblk_b, const float* __restrict__ fpart,
                                                            int nblk_f, int C, int groups, int voxels, const float* __restrict__ gamma,
                                                            float eps, float* __restrict__ coef, float* __restrict__ dgn,
@@ -1396,8 +1399,10 @@ int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hip
 int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, int nblk_f, int N, int C, int groups, int voxels,
                            const float* gamma, float eps, float* coef, float* dgn, hipStream_t s, const double* chsum) {
     if (groups <= 0 || C % groups || C / groups > 64) { nm_set_error("gnb_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
-    hipLaunchKernelGGL(gnb_finalize_kernel, dim3(N * groups), dim3(NM_GNBF_T), 0, s, bpart, nblk_b, fpart, nblk_f, C, groups, voxels, gamma,
-                       eps, coef, dgn, chsum);
+    if (chsum) hipLaunchKernelGGL(gnb_finalize_kernel<256>, dim3(N * groups), dim3(256), 0, s, bpart, nblk_b, fpart, nblk_f, C, groups, voxels, gamma,
+                                  eps, coef, dgn, chsum);
+    else hipLaunchKernelGGL(gnb_finalize_kernel<1024>, dim3(N * groups), dim3(1024), 0, s, bpart, nblk_b, fpart, nblk_f, C, groups, voxels, gamma,
+                            eps, coef, dgn, chsum);
     return nm_check_hip(hipGetLastError(), "gnb_finalize launch");
 }
 
