@@ -834,7 +834,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-#define NM_GNB_VB 512
+// voxels per block of the partial-sum pass: 512, or 2048 for the large volumes (a 512-voxel block of a 32-channel layer lives ~4 us:
+// the 64^3 layers ran 32768 such blocks per launch at 3 TB/s; derived from the voxel count alone so that every caller agrees)
+__host__ __device__ inline int nm_gnb_vb(int voxels) { return voxels >= 32768 ? 2048 : 512; }
 // grid (nblk, N)
 __global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restrict__ dA, TensorRef y, int voxels, float* __restrict__ part,
                                                            const float* __restrict__ dmul) {
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restri
     float s1 = 0.f, s2 = 0.f;
     if (vl < lanes) {
         const float sc = y.scale ? y.scale[(size_t)n * C + c] : 1.0f, shf = y.scale ? y.shift[(size_t)n * C + c] : 0.f;
-        const int v0 = blk * NM_GNB_VB, v1 = min(voxels, v0 + NM_GNB_VB);
+        const int VB = nm_gnb_vb(voxels), v0 = blk * VB, v1 = min(voxels, v0 + VB);
         for (int v = v0 + vl; v < v1; v += lanes) {
             const size_t o = ((size_t)n * voxels + v) * C + c;
             const float yy = y.p[o];
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restr
     if (vl < lanes) {
         f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, shf = f32x4{0.f, 0.f, 0.f, 0.f};
         if (y.scale) { sc = *reinterpret_cast<const f32x4*>(y.scale + (size_t)n * C + c); shf = *reinterpret_cast<const f32x4*>(y.shift + (size_t)n * C + c); }
-        const int v0 = blk * NM_GNB_VB, v1 = min(voxels, v0 + NM_GNB_VB);
+        const int VB = nm_gnb_vb(voxels), v0 = blk * VB, v1 = min(voxels, v0 + VB);
         const float* yp = y.p + (size_t)n * voxels * C + c;
         const float* dp = dA + (size_t)n * voxels * C + c;
         auto add = [&](const f32x4& yy, const f32x4& dd, int u) __attribute__((always_inline)) {
@@ -1384,7 +1386,7 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
     return nm_check_hip(hipGetLastError(), "wgrad_k5occ sparse launch");
 }
 
-int nm_gnb_blocks_per_frame(int voxels) { return (voxels + NM_GNB_VB - 1) / NM_GNB_VB; }
+int nm_gnb_blocks_per_frame(int voxels) { const int vb = nm_gnb_vb(voxels); return (voxels + vb - 1) / vb; }
 
 int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul) {
     if (y.C > 256 || y.C <= 0) { nm_set_error("gnb_partials: C=%d unsupported", y.C); return NM_ERR_ARG; }
