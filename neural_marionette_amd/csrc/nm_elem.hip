@@ -201,6 +201,81 @@ __global__ __launch_bounds__(256) void convT2_lds_kernel(TensorRef in, const flo
     }
 }
 
+// The same op on the fp32 matrix cores (exact fp32 products).  Per tap a it is a plain GEMM out[2i + a][co] = sum_ci X[i][ci] W[a][ci][co]:
+// a wave owns 32 consecutive coarse voxels (M), stages their activated input once in its own LDS slice ([32][Cin + 4] floats), and
+// for each tap and each 32-channel output tile runs Cin / 2 v_mfma_f32_32x32x2_f32 with the weight operand straight from L1/L2 (the
+// 8 x Cin x Cout weights are at most 131 KB and hot); a lane ends up with 16 voxels of ONE output channel, so a store instruction
+// writes two complete 128-byte voxel lines when Cout = 32.  convT2_lds_kernel above is VALU-FMA bound (1.06 ms for the 32 -> 32
+// data gradient of the first pool, whose 2.1 GB output takes 0.5 ms to write) and re-reads the input once per tap.
+__global__ __launch_bounds__(256) void convT2_mfma_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int Cout, int tiles_per_frame, int total_tiles) {
+    extern __shared__ float xs_all[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, wv = tid >> 6;
+    const int Cin = in.C, P = Cin + 4;
+    float* xs = xs_all + (size_t)wv * 32 * P;
+    const int OH = 2 * in.H, OW = 2 * in.W;
+    const size_t out_frame = (size_t)8 * in.D * in.H * in.W * Cout, in_frame = (size_t)in.D * in.H * in.W * Cin;
+    for (int t = blockIdx.x * 4 + wv; t < total_tiles; t += gridDim.x * 4) {
+        const int n = t / tiles_per_frame, v0 = (t % tiles_per_frame) * 32;
+        // stage: 32 voxels x Cin, activated (lanes walk the 16-byte items of the tile, contiguous in memory)
+        const float* src = in.p + (size_t)n * in_frame + (size_t)v0 * Cin;
+        const int items = 8 * Cin;                                     // 32 * Cin / 4
+        for (int i0 = lane; i0 < items; i0 += 256) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; v[u] = i < items ? *reinterpret_cast<const f32x4*>(src + (size_t)i * 4) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u;
+                if (i >= items) continue;
+                const int e = i * 4, vox = e / Cin, c = e % Cin;
+                f32x4 x = v[u];
+                if (in.scale) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(in.scale + (size_t)n * Cin + c), sh = *reinterpret_cast<const f32x4*>(in.shift + (size_t)n * Cin + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = fmaf(x[j], sc[j], sh[j]);
+                }
+                if (in.slope != 1.0f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = x[j] > 0.f ? x[j] : x[j] * in.slope;
+                }
+                *reinterpret_cast<f32x4*>(xs + vox * P + c) = x;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // output rows of this lane's accumulator registers: voxel m = (r & 3) + 8 (r >> 2) + 4 lh of the tile -> fine base offset
+        unsigned obase[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = v0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ix = v % in.W, iy = (v / in.W) % in.H, iz = v / (in.W * in.H);
+            obase[r] = (unsigned)((((size_t)2 * iz * OH + 2 * iy) * OW + 2 * ix) * Cout);
+        }
+        float* outn = out + (size_t)n * out_frame;
+        for (int a = 0; a < 8; ++a) {
+            const unsigned toff = (unsigned)(((size_t)(a >> 2) * OH + ((a >> 1) & 1)) * OW + (a & 1)) * Cout;
+            const float* wa = w + (size_t)a * Cin * Cout;
+            for (int co0 = 0; co0 < Cout; co0 += 32) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const float* wp = wa + co0 + l31;
+                for (int k = 0; k < Cin; k += 8) {                 // (Cin % 8 == 0) four weight loads in flight per dependent MFMA chain link
+                    float bb[4], aa[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { bb[u] = wp[(size_t)(k + 2 * u + lh) * Cout]; aa[u] = xs[l31 * P + k + 2 * u + lh]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u], acc, 0, 0, 0);
+                }
+                const float bv = bias[co0 + l31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) outn[(size_t)obase[r] + toff + co0 + l31] = acc[r] + bv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // trilinear x2, align_corners=False: src = (dst + 0.5) / 2 - 0.5 clamped at 0
 __device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1) {
     float src = 0.5f * ((float)o + 0.5f) - 0.5f;
@@ -444,6 +519,20 @@ int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, flo
     }
     size_t total = (size_t)in.N * OD * OH * OW * (Cout / 4);
     const size_t cvox = (size_t)in.N * in.D * in.H * in.W;
+    const size_t fvox = (size_t)in.D * in.H * in.W;
+    if (OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && Cout % 32 == 0 && in.C <= 128 && in.C % 8 == 0 && fvox % 32 == 0 && cvox >= 4096 &&
+        fvox * 8 * Cout < ((size_t)1 << 31)) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(convT2_mfma)");
+            attr_set = true;
+        }
+        const int tpf = (int)(fvox / 32), tiles = (int)(cvox / 32);
+        const size_t ldsb = (size_t)4 * 32 * (in.C + 4) * sizeof(float);
+        hipLaunchKernelGGL(convT2_mfma_kernel, dim3((unsigned)min((tiles + 3) / 4, 2048)), dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
+        return nm_check_hip(hipGetLastError(), "convT2_mfma launch");
+    }
     if (OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && 256 % (Cout / 4) == 0 && (size_t)in.C * Cout * 4 <= 48 * 1024 && cvox >= 65536) {
         const int vpb = 2048;
         hipLaunchKernelGGL(convT2_lds_kernel, dim3((unsigned)((cvox + vpb - 1) / vpb), 8), dim3(256), (size_t)in.C * Cout * sizeof(float), s, in, w, bias,
