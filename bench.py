@@ -151,7 +151,49 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
                                     "within 2e-3 of the CPU reference)",
                               frac_of_f16_mfma_peak=STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS)
     net.set_conv_mode("split16")
+    # BASELINE configs[3] (D-FAUST-shaped 96^3, T = 8, B = 2: the large-grid stress case) and configs[4] (generation rollout latency,
+    # Tcond = 5 posterior + 64 prior steps, B = 1) - secondary, rank 0's GPU only, each with its own context
+    if world == 1:
+        try:
+            out.update(other_configs(dev, timed))
+        except Exception as e:                                  # (never at the expense of the headline line)
+            out["other_configs_error"] = repr(e)
     return out
+
+
+def other_configs(dev, timed):
+    from neural_marionette_amd import NeuralMarionette, HotPathOptions, synth
+    res = {}
+    o4 = HotPathOptions(grid_size=96)
+    n4 = NeuralMarionette(o4); n4.load_state_dict(synth.make_state_dict(o4, seed=7, variant="peaky")); n4 = n4.to(dev).eval(); n4.anneal(1)
+    v4 = synth.figure_clip(2, 8, 96, seed=3).to(dev)
+    e4 = synth.make_eps((8, 10, 2, o4.nlatent_kypt), seed=4).to(dev)
+    acts = {"detector": True, "learner": True}
+
+    def f4():
+        with torch.no_grad():
+            return n4(v4, acts, eps=e4)
+    ms = timed(f4, 2, 5) * 1e3
+    res["config4_96cubed"] = dict(value=16 / (ms * 1e-3), unit="voxel-frames/s (96^3 frames)", ms_per_step=ms, steps=5,
+                                  workload="full NeuralMarionette.forward, 96^3, T=8, B=2 (parity: tests/test_network_gpu.py::test_config4_96cubed_vs_oracle)",
+                                  voxels_per_s=16 * 96 ** 3 / (ms * 1e-3))
+    del n4, v4
+    o5 = HotPathOptions(grid_size=32, Tcond=5)
+    sd5 = synth.make_state_dict(o5, seed=21, variant="default")
+    n5 = NeuralMarionette(o5); n5.load_state_dict(sd5); n5 = n5.to(dev).eval(); n5.anneal(1)
+    K, Z, Tc, Tt = o5.nkeypoints, o5.nlatent_kypt, 5, 69
+    kp = (torch.rand(1, Tc, K, 4, generator=torch.Generator().manual_seed(1)) * 1.6 - 0.8).to(dev)
+    ep = synth.make_eps((Tc, 10, 1, Z), seed=50).to(dev); er = synth.make_eps((Tt - Tc, 1, Z), seed=51).to(dev)
+    with torch.no_grad():
+        aff = n5.kypt_detector.get_affinity()
+
+    def f5():
+        with torch.no_grad():
+            return n5.dyna_module.generate(kp, aff, Ttot=Tt, Tcond=Tc, eps_post=ep, eps_prior=er)
+    ms = timed(f5, 3, 20) * 1e3
+    res["config5_rollout"] = dict(value=ms * 1e3 / Tt, unit="us per generated step", higher_is_better=False, ms_per_rollout=ms, steps_per_rollout=Tt,
+                                  workload="HSVRNNBVH.generate, Tcond=5 posterior + 64 prior steps, B=1, K=24 (vis_generation.py:81-136)")
+    return res
 
 
 def main():
