@@ -53,3 +53,5 @@ int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, 
 // OIDHW weights of the data-gradient convolution: out[ci][co][K-1-tap] = w[co][ci][tap], ci < csel
 int nm_launch_flip_weight(const float* w, int Cout, int Cin, int csel, int ks, float* out, hipStream_t s);
 int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s);      // dst += src
+// dst = dst * *dst_mul + src * *src_mul (device scalars, null = 1); n % 4 == 0
+int nm_launch_axpby(float* dst, const float* dst_mul, const float* src, const float* src_mul, size_t n, hipStream_t s);

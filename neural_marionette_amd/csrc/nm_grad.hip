@@ -1203,6 +1203,19 @@ __global__ void flip_weight_kernel(const float* __restrict__ w, int Cout, int Ci
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
 }
+// dst = dst * (*dmul) + src * (*smul)   (null multiplier = 1): the un-scaling of a data-gradient conv's result folded into the add
+// that joins it with the other branch (one pass instead of scale_by + axpy)
+__global__ __launch_bounds__(256) void axpby4_kernel(float* __restrict__ dst, const float* __restrict__ dmul, const float* __restrict__ src,
+                                                     const float* __restrict__ smul, size_t n4) {
+    const float a = dmul ? *dmul : 1.0f, b = smul ? *smul : 1.0f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 d = *reinterpret_cast<f32x4*>(dst + i * 4);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(src + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = fmaf(d[j], a, x[j] * b);
+        *reinterpret_cast<f32x4*>(dst + i * 4) = d;
+    }
+}
 
 int grid_for(size_t work_items) { return (int)min((work_items + 255) / 256, (size_t)(256 * 16)); }
 
@@ -1465,6 +1478,12 @@ int nm_launch_flip_weight(const float* w, int Cout, int Cin, int csel, int ks, f
     const int taps = ks * ks * ks, total = csel * Cout * taps;
     hipLaunchKernelGGL(flip_weight_kernel, dim3(min((total + 255) / 256, 4096)), dim3(256), 0, s, w, Cout, Cin, csel, taps, out);
     return nm_check_hip(hipGetLastError(), "flip_weight launch");
+}
+
+int nm_launch_axpby(float* dst, const float* dst_mul, const float* src, const float* src_mul, size_t n, hipStream_t s) {
+    if (n % 4) { nm_set_error("axpby: n %% 4 != 0"); return NM_ERR_ARG; }
+    hipLaunchKernelGGL(axpby4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, dst, dst_mul, src, src_mul, n / 4);
+    return nm_check_hip(hipGetLastError(), "axpby launch");
 }
 
 int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s) {

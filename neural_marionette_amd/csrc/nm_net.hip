@@ -717,10 +717,20 @@ void add_into(Bwd& b, float* dst, const float* src, size_t n) { if (b.live()) b.
 float* res_bwd(Bwd& b, const ResRec& r, const float* dOut) {
     const float* m1 = nullptr;
     float* d1 = conv_bwd(b, r.c2, dOut, true, nullptr, &m1);      // its power-of-two scale is undone by c1's GroupNorm backward
-    float* dx = conv_bwd(b, r.c1, d1, true, m1);
+    // (the results of c1 and of the skip conv are left with their power-of-two scales: the add that joins the branches undoes them)
+    const float *mx = nullptr, *ms = nullptr;
+    float* dx = conv_bwd(b, r.c1, d1, true, m1, &mx);
     const size_t n = numel_of(r.c1.in);
-    if (r.has_skip) { float* d2 = conv_bwd(b, r.cs, dOut, true); add_into(b, dx, d2, n); }
-    else add_into(b, dx, dOut, n);
+    const float* other = dOut;
+    if (r.has_skip) other = conv_bwd(b, r.cs, dOut, true, nullptr, &ms);
+    if (b.live()) {
+        if ((mx || ms) && n % 4 == 0) b.run(nm_launch_axpby(dx, mx, other, ms, n, b.s));
+        else {
+            if (mx) b.run(nm_launch_scale_by(dx, n, mx, b.s));
+            if (ms) b.run(nm_launch_scale_by(const_cast<float*>(other), n, ms, b.s));
+            b.run(nm_launch_axpy(dx, other, n, b.s));
+        }
+    }
     return dx;
 }
 
