@@ -222,6 +222,87 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+// ---- 1x1x1 convolutions: every (m, n) tile of the layer in ONE workgroup -------------------------------------------------------
+// dW[co][ci] = sum_v dY[v][co] X[v][ci] is a GEMM with a huge K (all voxels) and a small M x N (at most 128 x 192 here).  wgrad_kernel
+// gives each 32 x 32 tile its own workgroups, every one staging its own 32-channel slices of the same voxels: the 179 -> 128 layer
+// (24 tiles) read its inputs ~5 times through L2 and spent 1.07 ms on 0.32 GB.  Here a workgroup stages ALL channels of a 64-voxel
+// brick once ([64][Cout] + [64][Cin] floats, activated) and its four waves share the tiles (tile t = w + 4 j, NTW accumulators per
+// wave) - v_mfma_f32_32x32x2_f32, both operands single floats from LDS.  Persistent workgroups, partials in wgrad_kernel's MODE 1
+// layout (the same reduce).
+template <int NTW>
+__global__ __launch_bounds__(256) void wgrad_k1_kernel(WgradParams p, int m_tiles, int n_tiles) {
+    extern __shared__ float lds[];
+    const int Mp = m_tiles * 32 + 4, Np = n_tiles * 32 + 4;          // row pitches (+4: the two lane halves on different banks)
+    float* dys = lds;                     // [64][Mp]
+    float* as = lds + 64 * Mp;            // [64][Np]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, w = tid >> 6;
+    const int T = m_tiles * n_tiles;
+    const int V = p.dy.D * p.dy.H * p.dy.W, bpf = V / 64, total = p.in.N * bpf;
+    int aoff[NTW], boff[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { const int t = min(w + 4 * j, T - 1); aoff[j] = 32 * (t / n_tiles) + l31; boff[j] = 32 * (t % n_tiles) + l31; }
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int mq = m_tiles * 8, nq = n_tiles * 8;                      // 16-byte items per voxel row
+    for (int b = blockIdx.x; b < total; b += gridDim.x) {
+        const int n = b / bpf, v0 = (b % bpf) * 64;
+        __syncthreads();                  // the previous brick's operand reads
+        // stage both tiles (batches of four 16-byte loads; a row's items are contiguous in memory up to the real channel count)
+        auto stage = [&](const TensorRef& t, int real_c, int rowq, int pitch, float* dst) {
+            const float* src = t.p + ((size_t)n * V + v0) * t.C;
+            const int items = 64 * rowq;
+            for (int i0 = tid; i0 < items; i0 += 256 * 4) {
+                f32x4 v[4]; int vox[4], c[4]; bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 256 * u;
+                    vox[u] = i / rowq; c[u] = (i % rowq) * 4;
+                    ok[u] = i < items && c[u] < real_c && c[u] < t.C;
+                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok[u]) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)vox[u] * t.C + c[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + 256 * u >= items) continue;
+                    f32x4 x = v[u];
+                    if (ok[u]) {
+                        if (t.scale) {
+                            const f32x4 sc = *reinterpret_cast<const f32x4*>(t.scale + (size_t)n * t.C + c[u]), sh = *reinterpret_cast<const f32x4*>(t.shift + (size_t)n * t.C + c[u]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[e] = fmaf(x[e], sc[e], sh[e]);
+                        }
+                        if (t.slope != 1.0f) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[e] = lrelu(x[e], t.slope);
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(dst + vox[u] * pitch + c[u]) = x;
+                }
+            }
+        };
+        stage(p.dy, p.M, mq, Mp, dys);
+        stage(p.in, p.Nc, nq, Np, as);
+        __syncthreads();
+#pragma unroll 4
+        for (int pr = 0; pr < 32; ++pr) {
+            const int v = 2 * pr + lh;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[v * Mp + aoff[j]], as[v * Np + boff[j]], acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int t = w + 4 * j;
+        if (t >= T) continue;
+        float* dst = p.part + ((size_t)blockIdx.x * T + t) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][r];
+    }
+}
+
 // ---- split-fp16 weight gradient for the 3x3x3 stride-1 convolutions (the bulk of the backward FLOPs) ---------------------------
 // Same implicit GEMM (K = voxels) on v_mfma_f32_32x32x16_f16 with every fp32 operand split into fp16 hi + lo * 2^-11 and three
 // products hi*hi + 2^-11 (hi*lo + lo*hi), fp32 accumulate (the forward's arithmetic, nm_conv.hip).  This MFMA wants 8
@@ -1332,8 +1413,15 @@ int run_wgrad(WgradPlan& q, float* ws, float* dW, int cin_real, int taps, hipStr
 
 }  // namespace
 
+#define K1_WGS 256
+static bool k1_wide_eligible(int OD, int OH, int OW, int M, int Nc, int ks, int stride) {
+    const int m_tiles = (M + 31) / 32, n_tiles = (Nc + 31) / 32;
+    return ks == 1 && stride == 1 && (OD * OH * OW) % 64 == 0 && m_tiles * n_tiles <= 24 && (size_t)64 * (m_tiles * 32 + n_tiles * 32 + 8) * 4 <= 150 * 1024;
+}
+
 size_t nm_wgrad_ws_floats(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride) {
     size_t a = plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false).ws_floats;
+    if (k1_wide_eligible(OD, OH, OW, M, Nc, ks, stride)) a = max(a, (size_t)K1_WGS * ((M + 31) / 32) * ((Nc + 31) / 32) * 1024);
     if (wgrad16_eligible(OD, OH, OW, ks, stride)) a = max(a, plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false, true).ws_floats);
     return a;
 }
@@ -1349,6 +1437,29 @@ int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride
                     hipStream_t s, const float* mul, int allow_f16) {
     if (in.C % 4 || dy.C % 4 || in.N != dy.N) { nm_set_error("wgrad: channel counts must be multiples of 4 and frame counts equal"); return NM_ERR_ARG; }
     const bool f16 = allow_f16 && pad == 1 && wgrad16_eligible(dy.D, dy.H, dy.W, ks, stride) && in.D == dy.D && in.H == dy.H && in.W == dy.W;
+    if (k1_wide_eligible(dy.D, dy.H, dy.W, dy.C, in.C, ks, stride) && pad == 0 && in.D == dy.D && in.H == dy.H && in.W == dy.W) {
+        WgradParams p; p.in = in; p.dy = dy; p.part = ws; p.ks = 1; p.stride = 1; p.pad = 0; p.M = dy.C; p.Nc = in.C;
+        const int m_tiles = (dy.C + 31) / 32, n_tiles = (in.C + 31) / 32, T = m_tiles * n_tiles;
+        const int bricks = in.N * (dy.D * dy.H * dy.W / 64), S = min(bricks, K1_WGS);
+        const size_t ldsb = (size_t)64 * (m_tiles * 32 + 4 + n_tiles * 32 + 4) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                nm_set_error("wgrad_k1: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
+            }
+            attr_set = true;
+        }
+        if (T <= 4) hipLaunchKernelGGL(wgrad_k1_kernel<1>, dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
+        else if (T <= 8) hipLaunchKernelGGL(wgrad_k1_kernel<2>, dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
+        else hipLaunchKernelGGL(wgrad_k1_kernel<6>, dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
+        int rc = nm_check_hip(hipGetLastError(), "wgrad_k1 launch");
+        if (rc) return rc;
+        const int totalw = dy.C * cin_real;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min((totalw + 255) / 256, 4096)), dim3(256), 0, s, ws, S, T, n_tiles, 1, dy.C, cin_real, 1, 0, mul, dW);
+        return nm_check_hip(hipGetLastError(), "wgrad reduce launch");
+    }
     WgradPlan q = plan_wgrad(in.N, dy.D, dy.H, dy.W, dy.C, in.C, ks, stride, false, f16);
     q.p.in = in; q.p.dy = dy; q.p.pad = pad;
     static const int dbg = getenv("NM355_W16_DBG") ? atoi(getenv("NM355_W16_DBG")) : 0;

@@ -37,6 +37,10 @@ BWD_CASES = [
     (128, 64, 3, 1, 1, 8, 5, True, False, 128),
     (48, 72, 3, 1, 1, 8, 3, True, False, 48),
     (64, 32, 3, 1, 1, 8, 2, True, True, 64),
+    # 1x1 convs on the all-tiles-per-workgroup weight-gradient kernel (voxels % 64 == 0): ragged channel counts, pending GroupNorm
+    (179, 128, 1, 1, 0, 8, 2, False, False, 176),
+    (48, 72, 1, 1, 0, 8, 3, True, False, 48),
+    (72, 48, 1, 1, 0, 4, 5, True, False, 72),
     # fused-upsample layers big enough for the LDS-tiled upsample adjoint (coarse extents whole 2x4x8 bricks, borders on every side)
     (64, 32, 3, 1, 1, 16, 2, True, True, 64),
     (32, 32, 3, 1, 1, 16, 3, False, True, 32),
