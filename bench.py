@@ -144,6 +144,20 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
                             frac_of_f16_mfma_peak=3.0 * STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS)
     with torch.no_grad():
         net.load_state_dict(saved)
+    # the second regime of train.py (pretrained_mode 1): detector frozen and run forward only, the VRNN trained through its BPTT kernels
+    net.set_conv_mode("split16")
+    from neural_marionette_amd.train import LearnerTrainer
+    lt = LearnerTrainer(net, lr=4e-4)
+    lstep = lambda: lt.step(vox, eps=eps, sync=False)
+    ms = timed(lstep, 2, 5) * 1e3
+    out["train_learner"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=5, warmup=2,
+                                workload="learner-mode training step (train.py:376-412, pretrained_mode 1): detector forward (frozen) + HSVRNNBVH.encode "
+                                         "forward and backward through time + gradient all-reduce + Adam; 64^3, T=16, B=4 clips per GPU",
+                                dtype="f32 (VRNN), detector forward fp32-equivalent split-fp16", n_gpus=world)
+    with torch.no_grad():
+        net.load_state_dict(saved)
+    net.control_active({"detector": True, "learner": True})
+    net.set_conv_mode("f16")
     net.eval()
     ms = timed(fwd, 1, 4) * 1e3
     out["f16_forward"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=4,
