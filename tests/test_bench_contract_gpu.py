@@ -1,0 +1,41 @@
+"""The driver's contract with bench.py: one JSON line on stdout with the fields the round instructions name (metric / value / unit /
+n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, plus `roofline`
+and - when asked for - `cpu_baseline`), run here as the driver runs it (a child process), with few steps and without the secondary
+measurements."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "bench.py must print exactly one JSON line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_forward_line():
+    d = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline")
+    assert d["metric"].startswith("voxel-frames/sec") and d["unit"] == "voxel-frames/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # 4 clips x 16 frames per step
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
+    assert d["distributed"]["world_size"] == 1
+
+
+def test_training_line_reduced_precision():
+    d = _run("--workload", "train", "--conv-mode", "f16", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline")
+    assert d["value"] > 0 and "f16 conv products" in d["dtype"]
+    assert "training step" in d["config"]["workload"]
