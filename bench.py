@@ -20,13 +20,72 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (exact-fp32 forward, training step)")
+    ap.add_argument("--workload", choices=["forward", "train"], default="forward",
+                    help="forward (default, BASELINE configs[1]): full NeuralMarionette.forward; train (configs[2] shape, fp32): one "
+                         "detector-mode training step = forward + backward + gradient all-reduce + Adam")
+    ap.add_argument("--conv-mode", choices=["split16", "fp32", "f16"], default="split16",
+                    help="split16: fp32-equivalent 3x f16 MFMA products (default); fp32: exact fp32 MFMA everywhere")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="run only the multi-rank plumbing of this file (rendezvous, barrier, all-reduce of ones, MAX-reduce of the elapsed "
+                         "time) and print it as one JSON line; backend gloo when no GPU is visible (tests/test_sharding_cpu.py)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` outside a torch.distributed launcher: start the N ranks as a CHILD
+    `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  This runs
+    before torch is imported, so the parent never initialises the GPU (a process that has must not be replaced or forked).
+    Returns the exit code: the child's, or 3 if the line does not show N ranks in the all-reduce."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in child.stdout:
+        if ln.startswith("{"):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    if rc != 0:
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the ranks printed no JSON line\n")
+        return 3
+    print(line, flush=True)
+    d = json.loads(line).get("distributed", {})
+    if d.get("world_size") != args.gpus or d.get("ranks_seen_by_allreduce") != args.gpus:
+        sys.stderr.write(f"bench.py: asked for {args.gpus} ranks, the all-reduce saw {d.get('ranks_seen_by_allreduce')} "
+                         f"(world_size {d.get('world_size')})\n")
+        return 3
+    return 0
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        sys.exit(launch_ranks(_a, sys.argv[1:]))
+
+import torch  # noqa: E402  (after the launcher: the parent of an N-rank run never loads it)
 
 G, T, B_PER_GPU, S = 64, 16, 4, 10
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -210,23 +269,42 @@ def other_configs(dev, timed):
     return res
 
 
+def dist_selftest(world, rank, local):
+    """The multi-rank plumbing of main() without the GPU work: rendezvous, barrier, all-reduce of ones, MAX-reduce of a time."""
+    import torch.distributed as dist
+    on_gpu = torch.cuda.is_available()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    seen = torch.ones(1, device=dev)
+    dist.all_reduce(seen)
+    tt = torch.tensor([time.perf_counter() - t0 + rank], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps(dict(selftest="distributed", n_gpus=world, max_over_ranks_checks=bool(tt.item() >= world - 1),
+                              distributed=dict(world_size=world, ranks_seen_by_allreduce=int(seen.item()), backend=dist.get_backend(),
+                                               device_count=torch.cuda.device_count()))), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (exact-fp32 forward, training step)")
-    ap.add_argument("--workload", choices=["forward", "train"], default="forward",
-                    help="forward (default, BASELINE configs[1]): full NeuralMarionette.forward; train (configs[2] shape, fp32): one "
-                         "detector-mode training step = forward + backward + gradient all-reduce + Adam")
-    ap.add_argument("--conv-mode", choices=["split16", "fp32", "f16"], default="split16",
-                    help="split16: fp32-equivalent 3x f16 MFMA products (default); fp32: exact fp32 MFMA everywhere")
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dist_selftest:
+        return dist_selftest(world, rank, local)
     dist_on = world > 1
     if dist_on:
         import torch.distributed as dist

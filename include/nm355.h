@@ -277,7 +277,8 @@ int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
                           int32_t outpad, const float* dy, float* d_in, float* d_weight, float* d_bias);
 int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, int32_t C, int32_t groups, const float* gamma,
                       const float* beta, float slope, const float* dA, float* dy, float* dgamma, float* dbeta, float* dbias);
-/* Conv arithmetic (process-wide).  mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for every conv.
+/* Conv arithmetic (per context: two contexts in one process may run in different modes; like every other launch-time
+ * switch it lives in the nm_ctx).  mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for every conv.
  * mode 1 (default): layers with Cin % 16 == 0 run on the fp16 matrix cores with every fp32 operand split
  * into fp16 hi + lo*2^-11 and three products x_hi*w_hi + 2^-11 (x_hi*w_lo + x_lo*w_hi) accumulated in
  * fp32 — error within one fp32 rounding of the exact product, same tolerance class as the fp32 fma
@@ -293,8 +294,10 @@ int nm_set_conv_mode(nm_ctx* ctx, int32_t mode);
 int nm_get_conv_mode(nm_ctx* ctx);
 
 /* ---- live kernel timing for bench.py's roofline leg -------------------------------------------
- * While enabled, every conv launch on the ctx stream is bracketed by a HIP event pair (launches the library puts on its
- * own side stream are not timed: they overlap the main stream, so their event-to-event time is not their own).
+ * While enabled, every conv launch of this context is bracketed by a HIP event pair.  on = 1: launches on the ctx stream only
+ * (launches the library puts on its own side stream overlap the main stream, so their event-to-event time is not their own);
+ * on = 2: side-stream launches are recorded too (for listing every kernel family's share; durations include contention).
+ * Records belong to the context.
  * nm_prof_read sums duration and ALGORITHMIC flops (2*voxels*Cout*Cin*k^3, un-padded) of one
  * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2); 5,6 =
  * conv_f16s_kernel<2,1>/<2,2> (k1 / k3 without upsampling), 10,11 = the same kernel with the fused trilinear upsampling (NT = 1 / 2),

@@ -7,9 +7,32 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 
 static thread_local char g_err[512] = "";
+
+thread_local NmLaunchState* nm_tls_ls = nullptr;
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+NmLaunchState::NmLaunchState()
+    : supertile(env_int("NM355_SUPERTILE", 1)),     // 0: linear brick order (diagnostic)
+      small16(env_int("NM355_SMALL16", 1)),         // 0: small volumes on the fp32 MFMA core (diagnostic)
+      ksplit(env_int("NM355_KSPLIT", 1)),           // 0: no tap split on the tiny volumes (diagnostic)
+      occ16(env_int("NM355_OCC16", 1)),             // 0: first layer on the fp32 MFMA kernel (diagnostic)
+      pool16(env_int("NM355_POOL16", 1)),           // 0: pool convs on the fp32 kernel (diagnostic)
+      f16p2(env_int("NM355_F16P2", 1)),             // 0: Cout % 64 == 0 layers stay on conv_f16s (diagnostic)
+      // conv_f16p use: 0 never (conv_f16s everywhere), 1 every eligible layer, 2 (default) only Cout == 32 layers - with more cout
+      // groups per brick it re-stages the input per group and measures a little slower than conv_f16s (A/B in one gpurun call)
+      f16p(env_int("NM355_F16P", 2)),
+      wgrad_tr(env_int("NM355_WGRAD_TR", 1)),       // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel
+      up2c(env_int("NM355_UP2C", 1)),               // 0: fused-upsample layers stay on conv_f16s (diagnostic / A-B)
+      up2c_diag(env_int("NM355_UP2C_DIAG", 0)),
+      vrnn_mid(env_int("NM355_VRNN_MID", 0)),
+      vrnn_gemm(env_int("NM355_VRNN_GEMM", 1)) {}  // 0: one wavefront per output row at every batch size (A/B)
+NmLaunchState& nm_ls() {
+    static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
+    return nm_tls_ls ? *nm_tls_ls : outside;
+}
 
 void nm_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt);
@@ -109,11 +132,13 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     nm_vrnn_free_tape(ctx);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side}) if (e) (void)hipEventDestroy(e);
+    for (const NmProfRec& r : ctx->ls.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : ctx->ls.event_pool) (void)hipEventDestroy(e);
     delete ctx;
     return NM_OK;
 }
 
-int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) {
+int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("set_stream: null ctx"); return NM_ERR_ARG; }
     hipStream_t ns = static_cast<hipStream_t>(hip_stream);
     if (ns != ctx->stream && ctx->stream_bound) {
@@ -131,7 +156,7 @@ int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) {
     return NM_OK;
 }
 
-int nm_ctx_check_nonfinite(nm_ctx* ctx) {
+int nm_ctx_check_nonfinite(nm_ctx* ctx) { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("check_nonfinite: null ctx"); return NM_ERR_ARG; }
     (void)hipSetDevice(ctx->cfg.device);
     unsigned v = 0;
@@ -147,7 +172,7 @@ int nm_ctx_check_nonfinite(nm_ctx* ctx) {
     return NM_ERR_RANGE;
 }
 
-int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count) {
+int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count) { NmScope nm_scope_(ctx);
     if (!ctx || !tensors || count <= 0) { nm_set_error("set_weights: bad arguments"); return NM_ERR_ARG; }
     std::map<std::string, std::pair<const float*, int64_t>> sd;
     for (int i = 0; i < count; ++i) {
@@ -158,7 +183,7 @@ int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t coun
     return nm_net_set_weights(ctx, sd);
 }
 
-int nm_ctx_set_training(nm_ctx* ctx, int32_t on) {
+int nm_ctx_set_training(nm_ctx* ctx, int32_t on) { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("set_training: null ctx"); return NM_ERR_ARG; }
     if (ctx->training != (on != 0)) { ctx->training = on != 0; ctx->has_weights = false; }     // the next call needs nm_ctx_set_weights again
     return NM_OK;
@@ -166,20 +191,21 @@ int nm_ctx_set_training(nm_ctx* ctx, int32_t on) {
 
 int nm_set_conv_mode(nm_ctx* ctx, int32_t mode) {
     if (!ctx || mode < 0 || mode > 3) { nm_set_error("set_conv_mode: mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA), 2 (split-fp16, conv_f16p wherever eligible) or 3 (fp16 products, fp32 accumulation)"); return NM_ERR_ARG; }
+    NmScope sc(ctx);
     nm_conv_set_mode(mode);
     return NM_OK;
 }
 
-int nm_get_conv_mode(nm_ctx* ctx) { (void)ctx; return nm_conv_get_mode(); }
+int nm_get_conv_mode(nm_ctx* ctx) { NmScope sc(ctx); return nm_conv_get_mode(); }
 
-int nm_prof_enable(nm_ctx* ctx, int32_t on) {
+int nm_prof_enable(nm_ctx* ctx, int32_t on) { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("prof_enable: null ctx"); return NM_ERR_ARG; }
-    nm_conv_prof_enable(on, ctx->stream);
+    nm_conv_prof_enable(on, ctx->stream);         // 1: launches on the context's main stream, 2: side-stream launches too
     if (on) nm_conv_prof_reset();
     return NM_OK;
 }
 
-int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) {
+int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) { NmScope nm_scope_(ctx);
     if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 12) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
     long long n = 0;
     int rc = nm_conv_prof_collect(variant, ms_total, flops_total, &n);
@@ -219,7 +245,7 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
                  const float* in_scale, const float* in_shift, float in_slope, const float* weight,
                  const float* bias, int32_t Cout, int32_t ks, int32_t stride, int32_t pad, float* out,
                  int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift,
-                 int32_t up2) {
+                 int32_t up2) { NmScope nm_scope_(ctx);
     if (!ctx || !in || !weight || !out) { nm_set_error("op_conv3d: null argument"); return NM_ERR_ARG; }
     const int Cin_pad = (Cin + 7) & ~7, Co_pad = (Cout + 31) & ~31;
     const int us = up2 ? 2 : 1;
@@ -274,7 +300,7 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
 }
 
 int nm_op_conv5_occ(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, const float* weight, const float* bias, int32_t Cout,
-                    float* out, int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) {
+                    float* out, int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) { NmScope nm_scope_(ctx);
     if (!ctx || !occ || !weight || !bias || !out) { nm_set_error("op_conv5_occ: null argument"); return NM_ERR_ARG; }
     const int Co_pad = (Cout + 31) & ~31;
     const size_t G3 = (size_t)G * G * G;
@@ -300,7 +326,7 @@ int nm_op_conv5_occ(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, const f
 
 int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                  const float* weight, const float* bias, int32_t Cout, int32_t outpad, float* out,
-                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) {
+                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) { NmScope nm_scope_(ctx);
     if (!ctx || !in || !weight || !out || !bias) { nm_set_error("op_convT2: null argument"); return NM_ERR_ARG; }
     const int OD = 2 * D + outpad, OH = 2 * H + outpad, OW = 2 * W + outpad;
     const int vox = OD * OH * OW, nblk = nm_stats_blocks_per_frame(vox);
@@ -320,24 +346,24 @@ int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
 
 int nm_op_apply2(nm_ctx* ctx, const float* a, const float* a_scale, const float* a_shift, float a_slope,
                  const float* b, const float* b_scale, const float* b_shift, float b_slope, int32_t N,
-                 int32_t voxels, int32_t C, float* out) {
+                 int32_t voxels, int32_t C, float* out) { NmScope nm_scope_(ctx);
     if (!ctx || !a || !out) { nm_set_error("op_apply2: null argument"); return NM_ERR_ARG; }
     TensorRef ta = make_ref(a, a_scale, a_shift, a_slope, N, 1, 1, voxels, C);
     TensorRef tb = make_ref(b, b_scale, b_shift, b_slope, N, 1, 1, voxels, C);
     return nm_launch_apply2(ta, b ? &tb : nullptr, out, ctx->stream);
 }
 
-int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out) {
+int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out) { NmScope nm_scope_(ctx);
     if (!ctx || !in || !out) { nm_set_error("op_upsample2: null argument"); return NM_ERR_ARG; }
     return nm_launch_upsample2(make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, C), out, ctx->stream);
 }
 
-int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out) {
+int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out) { NmScope nm_scope_(ctx);
     if (!ctx || !vox || !out) { nm_set_error("op_pack_input: null argument"); return NM_ERR_ARG; }
     return nm_launch_pack_input(vox, B, T, G, mean_over_t, out, ctx->stream);
 }
 
-int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out) {
+int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out) { NmScope nm_scope_(ctx);
     if (!ctx || !in || !out) { nm_set_error("op_cl_to_ncdhw: null argument"); return NM_ERR_ARG; }
     return nm_launch_cl_to_ncdhw(make_ref(in, nullptr, nullptr, 1.0f, N, 1, 1, voxels, C), out, ctx->stream);
 }
@@ -348,7 +374,7 @@ int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, i
 int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                           const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
                           int32_t ks, int32_t stride, int32_t pad, int32_t up2, const float* dy, float* d_in,
-                          int32_t dgrad_channels, float* d_weight, float* d_bias) {
+                          int32_t dgrad_channels, float* d_weight, float* d_bias) { NmScope nm_scope_(ctx);
     if (!ctx || !in || !weight || !dy || !d_weight || !d_bias) { nm_set_error("op_conv3d_backward: null argument"); return NM_ERR_ARG; }
     if (Cout % 8) { nm_set_error("op_conv3d_backward: Cout %% 8 != 0"); return NM_ERR_ARG; }
     const int Cin_pad = (Cin + 7) & ~7, us = up2 ? 2 : 1, taps = ks * ks * ks;
@@ -405,7 +431,7 @@ int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
 
 // first layer: dW [Cout][4][125] and d_bias of conv5(cat[occ, coords]) given dy
 int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, int32_t Cout, const float* dy,
-                             float* d_weight, float* d_bias, int32_t sparse_occ) {
+                             float* d_weight, float* d_bias, int32_t sparse_occ) { NmScope nm_scope_(ctx);
     if (!ctx || !occ || !dy || !d_weight || !d_bias) { nm_set_error("op_conv5_occ_backward: null argument"); return NM_ERR_ARG; }
     const size_t wsf = nm_wgrad_k5occ_ws_floats(N, G, Cout);
     const int nbb = nm_gnb_blocks_per_frame(G * G * G);
@@ -422,7 +448,7 @@ int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G
 // Gradients of  y = convT3d_k2s2(a, W) + b  (a = lrelu(in*scale+shift)); weight IODHW
 int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                           const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
-                          int32_t outpad, const float* dy, float* d_in, float* d_weight, float* d_bias) {
+                          int32_t outpad, const float* dy, float* d_in, float* d_weight, float* d_bias) { NmScope nm_scope_(ctx);
     if (!ctx || !in || !weight || !dy || !d_in || !d_weight || !d_bias) { nm_set_error("op_convT2_backward: null argument"); return NM_ERR_ARG; }
     if (Cin % 8 || Cout % 8) { nm_set_error("op_convT2_backward: channels must be multiples of 8"); return NM_ERR_ARG; }
     const int OD = 2 * D + outpad, OH = 2 * H + outpad, OW = 2 * W + outpad;
@@ -453,7 +479,7 @@ int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
 
 // GroupNorm(groups) + LeakyReLU(slope) backward on a raw tensor y [N][voxels][C]: dy, dgamma, dbeta, and sum_v dy (the conv bias gradient)
 int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, int32_t C, int32_t groups, const float* gamma,
-                      const float* beta, float slope, const float* dA, float* dy, float* dgamma, float* dbeta, float* dbias) {
+                      const float* beta, float slope, const float* dA, float* dy, float* dgamma, float* dbeta, float* dbias) { NmScope nm_scope_(ctx);
     if (!ctx || !y || !gamma || !beta || !dA || !dy || !dgamma || !dbeta || !dbias) { nm_set_error("op_gn_backward: null argument"); return NM_ERR_ARG; }
     const int nbf = nm_stats_blocks_per_frame(voxels), nbb = nm_gnb_blocks_per_frame(voxels);
     int rc = nm_ctx_reserve(ctx, ((size_t)N * (nbf + nbb) * C * 2 + (size_t)N * C * 10) * sizeof(float) + 16384);

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #define NM_OK 0
 #define NM_ERR_ARG (-1)
@@ -52,6 +53,29 @@ struct ConvGeom {
 
 void nm_set_error(const char* fmt, ...);
 int nm_check_hip(hipError_t e, const char* what);
+
+// ---- per-context launch state ---------------------------------------------------------
+// Everything a kernel launcher consults besides its arguments lives in the nm_ctx ("separate ctxs are
+// independent"): the conv arithmetic mode, the launch profiler's records, the word GroupNorm finalisation reports non-finite
+// statistics into, and the NM355_* A/B switches (read from the environment once, when the context is created).  Every ABI entry
+// point selects its context's state for the calling thread (NmScope, nm_ctx.h); launchers read it through nm_ls().
+struct NmProfRec { hipEvent_t a, b; int variant; double flops; };
+struct NmLaunchState {
+    int conv_mode = 1;         // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
+    bool f16p_all = false;     // mode 2: split-fp16 with conv_f16p on every eligible layer (parity tests of its multi-cout-group path)
+    bool single = false;       // mode 3: the split-fp16 kernels keep only the hi x hi product (SINGLE instantiations)
+    bool prof_on = false;
+    hipStream_t prof_stream = nullptr;     // main stream of the profiled context; prof_all: launches on any stream are recorded
+    bool prof_all = false;
+    std::vector<NmProfRec> prof;           // records of the current window
+    std::vector<hipEvent_t> event_pool;
+    unsigned* nf_flag = nullptr;           // sticky device word gn_finalize ORs a 1 into (null: no reporting)
+    // A/B and diagnostic switches (NM355_SUPERTILE, _SMALL16, _KSPLIT, _OCC16, _POOL16, _F16P2, _F16P, _WGRAD_TR, _UP2C, _UP2C_DIAG,
+    // _VRNN_MID, _VRNN_GEMM)
+    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, wgrad_tr, up2c, up2c_diag, vrnn_mid, vrnn_gemm;
+    NmLaunchState();
+};
+NmLaunchState& nm_ls();        // the state of the context whose ABI call runs on this thread
 
 // ---- nm_conv.hip -------------------------------------------------------------------
 // packed weight layout: [tap][Cin/4][Co_pad][4]

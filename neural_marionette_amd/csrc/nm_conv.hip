@@ -2159,15 +2159,14 @@ Tiling choose_tiling(const ConvGeom& g, int Cin) {
 }
 
 // ---- optional live timing of the conv launches (bench.py roofline leg) ---------------------------
-struct ProfRec { hipEvent_t a, b; int variant; double flops; };
-bool g_prof_on = false;
-hipStream_t g_prof_stream = nullptr;        // only launches on this stream are timed (side-stream launches overlap the main stream: their
-                                            // event-to-event time is not their own)
-#define NM_PROF_ON(s) (g_prof_on && (s) == g_prof_stream)
-std::vector<ProfRec> g_prof;                 // records of the current window
-std::vector<hipEvent_t> g_event_pool;
+// (records live in the context: NmLaunchState, nm_common.h).  By default only launches on the profiled context's main stream are
+// timed - a side-stream launch overlaps the main stream, so its event-to-event time is not its own; prof_all records those too
+// (bench.py lists them separately)
+typedef NmProfRec ProfRec;
+#define NM_PROF_ON(s) (nm_ls().prof_on && (nm_ls().prof_all || (s) == nm_ls().prof_stream))
 
 hipEvent_t prof_event() {
+    std::vector<hipEvent_t>& g_event_pool = nm_ls().event_pool;
     if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
@@ -2191,16 +2190,15 @@ int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
         (void)hipEventRecord(rec.a, s);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(256), t.lds_bytes, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
-int g_supertile = [] { const char* e = getenv("NM355_SUPERTILE"); return e ? atoi(e) : 1; }();   // 0: linear brick order (diagnostic)
 // XCD super-tile (see super_tile_item): the persistent grid must be 8 x (bricks per super-tile) workgroups, the brick grid
 // a multiple of the super-tile, and the super-tiles split evenly over the eight XCDs
 void choose_super_tile(ConvParams& p, int nblocks, int nbz, int nby, int nbx) {
     p.st_z = p.st_y = p.st_x = 0;
-    if (!g_supertile || nblocks % 8) return;
+    if (!nm_ls().supertile || nblocks % 8) return;
     const int gs = nblocks / 8;
     const int sz = gs == 64 ? 4 : gs == 32 ? 2 : 0;
     if (!sz || nbz % sz || nby % 4 || nbx % 4) return;
@@ -2209,8 +2207,7 @@ void choose_super_tile(ConvParams& p, int nblocks, int nbz, int nby, int nbx) {
     p.st_z = sz; p.st_y = 4; p.st_x = 4;
 }
 
-// conv mode 3: the split-fp16 kernels keep only the hi x hi product (SINGLE instantiations)
-int g_single = 0;
+// conv mode 3 (nm_ls().single): the split-fp16 kernels keep only the hi x hi product (SINGLE instantiations)
 
 template <int MT, int NT, int KS, bool UP2, bool SINGLE>
 int launch_f16s_impl(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t s) {
@@ -2231,12 +2228,12 @@ int launch_f16s_impl(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStre
     dim3 pgrid(min(grid.x, 512u), grid.y);                          // persistent: ~2 resident workgroups per CU
     choose_super_tile(p, (int)pgrid.x, p.nbz, p.nby, p.nbx);
     hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2, SINGLE>), pgrid, dim3(256), t.lds_bytes, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
 }
 template <int MT, int NT, int KS, bool UP2>
 int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
-    return g_single ? launch_f16s_impl<MT, NT, KS, UP2, true>(p, t, grid, s) : launch_f16s_impl<MT, NT, KS, UP2, false>(p, t, grid, s);
+    return nm_ls().single ? launch_f16s_impl<MT, NT, KS, UP2, true>(p, t, grid, s) : launch_f16s_impl<MT, NT, KS, UP2, false>(p, t, grid, s);
 }
 
 template <int NT, bool SINGLE>
@@ -2248,12 +2245,12 @@ int launch_pool_f16s_impl(const ConvParams& p, dim3 grid, hipStream_t s) {
         (void)hipEventRecord(rec.a, s);
     }
     hipLaunchKernelGGL((conv_pool_f16s_kernel<NT, SINGLE>), grid, dim3(256), 0, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_pool_f16s launch");
 }
 template <int NT>
 int launch_pool_f16s(const ConvParams& p, dim3 grid, hipStream_t s) {
-    return g_single ? launch_pool_f16s_impl<NT, true>(p, grid, s) : launch_pool_f16s_impl<NT, false>(p, grid, s);
+    return nm_ls().single ? launch_pool_f16s_impl<NT, true>(p, grid, s) : launch_pool_f16s_impl<NT, false>(p, grid, s);
 }
 
 int g_num_cus = 0;
@@ -2282,12 +2279,12 @@ int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, h
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 32) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p_kernel<UP2, SINGLE>), grid, dim3(512), lds_bytes, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
 template <bool UP2>
 int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
-    return g_single ? launch_f16p_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p_impl<UP2, false>(p, lds_bytes, work_items, s);
+    return nm_ls().single ? launch_f16p_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p_impl<UP2, false>(p, lds_bytes, work_items, s);
 }
 
 template <bool UP2, bool SINGLE>
@@ -2314,36 +2311,26 @@ int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, 
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p2_kernel<UP2, SINGLE>), grid, dim3(512), lds_bytes, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p2 launch");
 }
 template <bool UP2>
 int launch_f16p2(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
-    return g_single ? launch_f16p2_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p2_impl<UP2, false>(p, lds_bytes, work_items, s);
+    return nm_ls().single ? launch_f16p2_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p2_impl<UP2, false>(p, lds_bytes, work_items, s);
 }
 
 #ifdef NM_DIAG
 unsigned long long* g_stamps = nullptr;
 #endif
-int g_small16 = [] { const char* e = getenv("NM355_SMALL16"); return e ? atoi(e) : 1; }();   // 0: small volumes on the fp32 MFMA core (diagnostic)
-int g_ksplit = [] { const char* e = getenv("NM355_KSPLIT"); return e ? atoi(e) : 1; }();     // 0: no tap split on the tiny volumes (diagnostic)
-int g_occ16 = [] { const char* e = getenv("NM355_OCC16"); return e ? atoi(e) : 1; }();     // 0: first layer on the fp32 MFMA kernel (diagnostic)
-int g_pool16 = [] { const char* e = getenv("NM355_POOL16"); return e ? atoi(e) : 1; }();   // 0: pool convs on the fp32 kernel (diagnostic)
-int g_f16p2 = [] { const char* e = getenv("NM355_F16P2"); return e ? atoi(e) : 1; }();   // 0: Cout % 64 == 0 layers stay on conv_f16s (diagnostic)
-// conv_f16p use: 0 never (conv_f16s everywhere), 1 every eligible layer, 2 (default) only Cout == 32 layers - with more cout
-// groups per brick it re-stages the input per group and measures a little slower than conv_f16s (A/B in one gpurun call)
-int g_f16p = [] { const char* e = getenv("NM355_F16P"); return e ? atoi(e) : 2; }();
-int g_conv_mode = 1;      // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
-bool g_f16p_all = false;  // mode 2: split-fp16 with conv_f16p on every eligible layer (parity tests of its multi-cout-group path)
 
 }  // namespace
 
 #ifdef NM_DIAG
 extern "C" void nm_diag_set_stamps(void* p) { g_stamps = static_cast<unsigned long long*>(p); }
 #endif
-void nm_conv_set_mode(int mode) { g_conv_mode = mode ? 1 : 0; g_f16p_all = mode == 2; g_single = mode == 3; }
-int nm_conv_get_mode() { return g_conv_mode && g_single ? 3 : (g_conv_mode && g_f16p_all ? 2 : g_conv_mode); }
-int nm_conv_single() { return g_conv_mode && g_single; }
+void nm_conv_set_mode(int mode) { NmLaunchState& l = nm_ls(); l.conv_mode = mode ? 1 : 0; l.f16p_all = mode == 2; l.single = mode == 3; }
+int nm_conv_get_mode() { const NmLaunchState& l = nm_ls(); return l.conv_mode && l.single ? 3 : (l.conv_mode && l.f16p_all ? 2 : l.conv_mode); }
+int nm_conv_single() { return nm_ls().conv_mode && nm_ls().single; }
 
 int nm_launch_pack_conv_weight16(const float* w, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s) {
     if (Co_pad % 32 || Cout > Co_pad) { nm_set_error("pack_conv_weight16: bad padding Cout=%d/%d", Cout, Co_pad); return NM_ERR_ARG; }   // (channels beyond Cin: zero)
@@ -2416,7 +2403,7 @@ int nm_launch_pack_conv_weight(const float* w, int Cout, int Cin, int ks, float*
 }
 
 static bool use_up2c(const ConvGeom& g, int Cin) {
-    return g.up2 && g.up2c && g_conv_mode == 1 && nm_up2c_eligible(g.OD / 2, g.OH / 2, g.OW / 2, Cin, g.Cout, g.ks, g.stride, g.pad);
+    return g.up2 && g.up2c && nm_ls().conv_mode == 1 && nm_up2c_eligible(g.OD / 2, g.OH / 2, g.OW / 2, Cin, g.Cout, g.ks, g.stride, g.pad);
 }
 
 int nm_conv_blocks_per_frame(const ConvGeom& g, int Cin) {
@@ -2425,13 +2412,13 @@ int nm_conv_blocks_per_frame(const ConvGeom& g, int Cin) {
     return t.nbz * t.nby * t.nbx;
 }
 
-void nm_conv_prof_enable(int on, hipStream_t stream) { g_prof_on = on != 0; g_prof_stream = stream; }
+void nm_conv_prof_enable(int on, hipStream_t stream) { NmLaunchState& l = nm_ls(); l.prof_on = on != 0; l.prof_all = on == 2; l.prof_stream = stream; }
 
 // Sums the event-timed launches of one kernel variant recorded since the last reset.
 // variant: see nm_prof_kernel_name.  Synchronises on the recorded events.
 int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, long long* launches) {
     double ms = 0.0, fl = 0.0; long long n = 0;
-    for (const ProfRec& r : g_prof) {
+    for (const ProfRec& r : nm_ls().prof) {
         if (r.variant != variant) continue;
         if (hipEventSynchronize(r.b) != hipSuccess) return NM_ERR_HIP;
         float t = 0.f;
@@ -2443,8 +2430,9 @@ int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, lon
 }
 
 void nm_conv_prof_reset() {
-    for (const ProfRec& r : g_prof) { g_event_pool.push_back(r.a); g_event_pool.push_back(r.b); }
-    g_prof.clear();
+    NmLaunchState& l = nm_ls();
+    for (const ProfRec& r : l.prof) { l.event_pool.push_back(r.a); l.event_pool.push_back(r.b); }
+    l.prof.clear();
 }
 
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
@@ -2470,7 +2458,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
             (void)hipEventRecord(rec.a, s);
         }
         const int rc = nm_launch_conv_up2c(in, g.up2c, bias, out, g.Cout, g.Co_pad, part, s);
-        if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+        if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
         return rc;
     }
     Tiling t = choose_tiling(g, in.C);
@@ -2485,10 +2473,10 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.up2 = g.up2 ? 1 : 0;
     p.st_z = p.st_y = p.st_x = 0;
-    p.w16 = (g_conv_mode == 1 && g_small16 && w_packed16 && in.C % 8 == 0 && !g.up2 && t.MT == 1 && (t.KC % 16 == 0 || t.KC == in.C)) ? w_packed16 : nullptr;
+    p.w16 = (nm_ls().conv_mode == 1 && nm_ls().small16 && w_packed16 && in.C % 8 == 0 && !g.up2 && t.MT == 1 && (t.KC % 16 == 0 || t.KC == in.C)) ? w_packed16 : nullptr;
     if (p.w16) t.lds_bytes = max(t.lds_bytes, (size_t)(((t.KC + 15) & ~15) / 4) * (t.HVp + t.CVp) * 16);
     p.ksplit = 1;
-    if (p.w16 && g_ksplit) {       // tiny volumes: how many of the 4 row tiles (32 rows each) of the brick hold voxels at all
+    if (p.w16 && nm_ls().ksplit) {       // tiny volumes: how many of the 4 row tiles (32 rows each) of the brick hold voxels at all
         const int top = ((min(g.OD, 1 << t.bz_l2) - 1) << (t.bx_l2 + t.by_l2)) + ((min(g.OH, 1 << t.by_l2) - 1) << t.bx_l2) + min(g.OW, 1 << t.bx_l2) - 1;
         const int rw = top / 32 + 1;
         p.ksplit = rw == 1 ? 4 : (rw == 2 ? 2 : 1);
@@ -2499,26 +2487,26 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
 #endif
     p.KC = t.KC; p.HZ = t.HZ; p.HY = t.HY; p.HX = t.HX; p.HV = t.HV; p.HVp = t.HVp; p.CVp = t.CVp; p.ZP = t.HY * t.HX;
     dim3 grid((unsigned)(in.N * t.nbz * t.nby * t.nbx), (unsigned)(g.Co_pad / (t.NT * 32)));
-    if (g_conv_mode == 1 && g_pool16 && w_packed16 && in.C % 16 == 0 && g.ks == 2 && g.stride == 2 && g.pad == 0 && !g.up2 &&
+    if (nm_ls().conv_mode == 1 && nm_ls().pool16 && w_packed16 && in.C % 16 == 0 && g.ks == 2 && g.stride == 2 && g.pad == 0 && !g.up2 &&
         t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2) {
         p.w = static_cast<const float*>(w_packed16);
         return t.NT == 2 ? launch_pool_f16s<2>(p, grid, s) : launch_pool_f16s<1>(p, grid, s);
     }
-    if (g_conv_mode == 1 && g_f16p2 && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
+    if (nm_ls().conv_mode == 1 && nm_ls().f16p2 && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
         g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 64 == 0) {
         const int work = in.N * (g.OD / 4) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 64);
         p.w = static_cast<const float*>(w_packed16);
         const size_t lds_bytes = (size_t)8 * 600 * 16 + (size_t)2 * 9 * 4 * 64 * 16 + (size_t)(512 + g.Cout) * sizeof(float);
         return launch_f16p2<false>(p, lds_bytes, work, s);
     }
-    if (g_conv_mode == 1 && g_f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
-        g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0 && (g_f16p == 1 || g_f16p_all || g.Cout == 32)) {
+    if (nm_ls().conv_mode == 1 && nm_ls().f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
+        g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0 && (nm_ls().f16p == 1 || nm_ls().f16p_all || g.Cout == 32)) {
         const int work = in.N * (g.OD / 4) * (g.OH / 8) * (g.OW / 8) * (g.Cout / 32);
         p.w = static_cast<const float*>(w_packed16);
         const size_t lds_bytes = (size_t)8 * 600 * 16 + (size_t)3 * 9 * 4 * 32 * 16 + (size_t)(256 + g.Cout) * sizeof(float);
         return launch_f16p<false>(p, lds_bytes, work, s);
     }
-    if (g_conv_mode == 1 && w_packed16 && in.C % 16 == 0 && t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2 &&
+    if (nm_ls().conv_mode == 1 && w_packed16 && in.C % 16 == 0 && t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2 &&
         g.stride == 1 && (g.ks == 1 || g.ks == 3) && t.HZ == g.ks + 3 && t.HY * t.HX * 2 <= 256) {
         // halo planes padded to a pitch of 4 (mod 16) 16-B slots: conflict-free A reads (see conv_f16s_kernel)
         Tiling t16 = t;
@@ -2570,11 +2558,11 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
         rec.flops = 2.0 * N * (double)G * G * G * Cout * 4.0 * 125.0;   // the reference's dense k5 layer over 4 input channels
         (void)hipEventRecord(rec.a, s);
     }
-    if (g_conv_mode == 1 && g_occ16) {
-        if (NT == 2) { if (g_single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<2>), grid, dim3(256), 0, s, p); }
-        else { if (g_single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1>), grid, dim3(256), 0, s, p); }
+    if (nm_ls().conv_mode == 1 && nm_ls().occ16) {
+        if (NT == 2) { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<2>), grid, dim3(256), 0, s, p); }
+        else { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1>), grid, dim3(256), 0, s, p); }
     } else if (NT == 2) hipLaunchKernelGGL((conv_k5occ_kernel<2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_k5occ_kernel<1>), grid, dim3(256), 0, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); g_prof.push_back(rec); }
+    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_k5occ launch");
 }

@@ -78,6 +78,7 @@ struct VrnnW {
 
 struct nm_ctx {
     nm_config cfg;
+    NmLaunchState ls;                      // conv mode, profiler records, status word, A/B switches: nothing of this is process-wide
     hipStream_t stream = nullptr;
     bool stream_bound = false;             // nm_ctx_set_stream has been called (nullptr = the legacy default stream is a valid choice)
     hipStream_t stream2 = nullptr;         // ctx-owned side stream: clip-mean net / VRNN run beside the frame stack
@@ -101,6 +102,16 @@ struct nm_ctx {
     void* vtape = nullptr;                 // VrnnTape of the last nm_vrnn_encode_train (nm_vrnn.hip)
     DetectorW det;
     VrnnW vrnn;
+};
+
+// selects ctx->ls for the calling thread for the duration of one ABI call (nested calls restore the outer selection)
+extern thread_local NmLaunchState* nm_tls_ls;
+struct NmScope {
+    NmLaunchState* prev;
+    explicit NmScope(nm_ctx* c) : prev(nm_tls_ls) { if (c) nm_tls_ls = &c->ls; }
+    ~NmScope() { nm_tls_ls = prev; }
+    NmScope(const NmScope&) = delete;
+    NmScope& operator=(const NmScope&) = delete;
 };
 
 int nm_ctx_reserve(nm_ctx* ctx, size_t bytes);        // grow the workspace (synchronises)

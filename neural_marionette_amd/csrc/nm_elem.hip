@@ -465,8 +465,7 @@ int grid_for(size_t work_items) { return (int)min((work_items + 255) / 256, (siz
 
 }  // namespace
 
-static unsigned* g_nonfinite_flag = nullptr;
-void nm_elem_set_nonfinite_flag(unsigned* flag) { g_nonfinite_flag = flag; }
+void nm_elem_set_nonfinite_flag(unsigned* flag) { nm_ls().nf_flag = flag; }
 
 __global__ __launch_bounds__(256) void nonfinite_scan_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ flag) {
     bool bad = false;
@@ -485,9 +484,9 @@ int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups,
     if (groups <= 0 || C % groups != 0 || C / groups > 256) { nm_set_error("gn_finalize: bad groups %d for C=%d", groups, C); return NM_ERR_ARG; }
     if (chsum && !nm_gn_finalize_has_chsum(C, groups)) { nm_set_error("gn_finalize: no per-channel sums for %d channels per group", C / groups); return NM_ERR_ARG; }
     if ((long long)nblk * (C / groups) > 8192)
-        hipLaunchKernelGGL(gn_finalize_kernel<1024>, dim3(N * groups), dim3(1024), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag, chsum);
+        hipLaunchKernelGGL(gn_finalize_kernel<1024>, dim3(N * groups), dim3(1024), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, nm_ls().nf_flag, chsum);
     else
-        hipLaunchKernelGGL(gn_finalize_kernel<256>, dim3(N * groups), dim3(256), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, g_nonfinite_flag, chsum);
+        hipLaunchKernelGGL(gn_finalize_kernel<256>, dim3(N * groups), dim3(256), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, nm_ls().nf_flag, chsum);
     return nm_check_hip(hipGetLastError(), "gn_finalize launch");
 }
 

@@ -90,7 +90,7 @@ __global__ void semantic_kernel(const float* __restrict__ kypt, const float* __r
 
 extern "C" {
 
-int nm_eval_voxel_chamfer(nm_ctx* c, const float* gt_vox, const float* recon, int32_t B, int32_t T, int32_t G, double* per_frame) {
+int nm_eval_voxel_chamfer(nm_ctx* c, const float* gt_vox, const float* recon, int32_t B, int32_t T, int32_t G, double* per_frame) { NmScope nm_scope_(c);
     if (!c || !gt_vox || !recon || !per_frame || B <= 0 || T <= 0 || G < 2 || G > 1024) { nm_set_error("eval_voxel_chamfer: bad argument"); return NM_ERR_ARG; }
     int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
     if (rc) return rc;
@@ -127,7 +127,7 @@ int nm_eval_voxel_chamfer(nm_ctx* c, const float* gt_vox, const float* recon, in
 }
 
 int nm_eval_semantic(nm_ctx* c, const float* keypoints, const float* gt_keypoints, int32_t BT, int32_t K, int32_t Kg,
-                     int32_t* closest, int64_t* counts) {
+                     int32_t* closest, int64_t* counts) { NmScope nm_scope_(c);
     if (!c || !keypoints || !gt_keypoints || !closest || !counts || BT <= 0 || K <= 0 || Kg <= 0) { nm_set_error("eval_semantic: bad argument"); return NM_ERR_ARG; }
     int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
     if (rc) return rc;

@@ -1358,10 +1358,9 @@ int launch_wgrad_t(const WgradPlan& q, hipStream_t s) {
     return nm_check_hip(hipGetLastError(), "wgrad launch");
 }
 
-int g_wgrad_tr = [] { const char* e = getenv("NM355_WGRAD_TR"); return e ? atoi(e) : 1; }();   // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel (transposing LDS reads); A/B in profiles/r02_wgrad16t_ab.txt
 
 int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
-    if (g_wgrad_tr && q.p.in.N <= 96) {                       // (the per-frame scale / shift table of wgrad16t_kernel lives in LDS: 256 B per frame)
+    if (nm_ls().wgrad_tr && q.p.in.N <= 96) {                       // (the per-frame scale / shift table of wgrad16t_kernel lives in LDS: 256 B per frame)
         static bool attr_t = false;
         if (!attr_t) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

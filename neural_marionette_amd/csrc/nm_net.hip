@@ -175,9 +175,13 @@ struct Loader {
         return NM_OK;
     }
     // composite weight sets of the fused-upsample layers (nm_up2c.hip); a null wup leaves the layer on conv_f16s<.., UP2>
-    void up2_sets(const std::string& p, ConvW& w) {
+    void up2_sets(const std::string& p, ConvW& w, int coarse) {
+        w.wup = nullptr;
+        // only for the layer shapes conv_up2c takes (the composition is a 27-tap fp64 kernel over 8 x 27 x Cin x Cout items and
+        // runs after every optimizer step)
+        if (w.ks != 3 || !nm_up2c_eligible(coarse, coarse, coarse, w.Cin, w.Cout, 3, 1, 1)) return;
         const float* src = get(p + ".weight", (int64_t)w.Cout * w.Cin * 27);
-        if (!src || w.ks != 3 || w.Cin % 16) return;
+        if (!src) return;
         w.wup = nm_ctx_weight_alloc(c, nm_up2c_weight_floats(w.Cin, w.Co_pad));
         if (!w.wup) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return; }
         const int r = nm_launch_up2c_compose(src, w.Cout, w.Cin, w.Co_pad, w.wup, c->stream);
@@ -923,7 +927,7 @@ int check_ready(nm_ctx* c, const char* who) {
 
 void nm_net_free_tape(nm_ctx* c) { delete c->tape; c->tape = nullptr; }
 
-int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const float*, int64_t>>& sd) {
+int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const float*, int64_t>>& sd) { NmScope nm_scope_(c);
     if (c->tape) c->tape->valid = false;
     nm_vrnn_invalidate_tape(c);
     int rc = NM_OK;
@@ -948,9 +952,9 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
         if (pw && pb && d.prop) hipLaunchKernelGGL(pack_small_kernel, dim3(1), dim3(64), 0, c->stream, pw, 2, pb, 1, d.prop);
     }
     d.adjust = L.conv(k2v + ".adjust_combined_representation.0", FEAT, FEAT + 2 * K + 3, 1);       // (pad16 = true puts it on conv_f16s: measured 648 us vs 319 us on the fp32 kernel, which stages all 184 channels per pass; a 1-tap layer has 6 MFMAs per staged 16-channel chunk)
-    d.d1 = L.conv(dec + ".1", FEAT / 2, FEAT, 3); L.up2_sets(dec + ".1", d.d1); d.dn2 = L.norm(dec + ".2", FEAT / 2);
+    d.d1 = L.conv(dec + ".1", FEAT / 2, FEAT, 3); L.up2_sets(dec + ".1", d.d1, c->cfg.grid_size / 4); d.dn2 = L.norm(dec + ".2", FEAT / 2);
     d.d4 = L.conv(dec + ".4", FEAT / 2, FEAT / 2, 3); d.dn5 = L.norm(dec + ".5", FEAT / 2);
-    d.d8 = L.conv(dec + ".8", FEAT / 4, FEAT / 2, 3); L.up2_sets(dec + ".8", d.d8); d.dn9 = L.norm(dec + ".9", FEAT / 4);
+    d.d8 = L.conv(dec + ".8", FEAT / 4, FEAT / 2, 3); L.up2_sets(dec + ".8", d.d8, c->cfg.grid_size / 2); d.dn9 = L.norm(dec + ".9", FEAT / 4);
     d.d11 = L.conv(dec + ".11", FEAT / 4, FEAT / 4, 3); d.dn12 = L.norm(dec + ".12", FEAT / 4);
     {
         const float* w = L.get(dec + ".14.weight", FEAT / 4);
@@ -993,7 +997,7 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
 
 extern "C" {
 
-size_t nm_workspace_bytes(nm_ctx* c, int32_t B, int32_t T) {
+size_t nm_workspace_bytes(nm_ctx* c, int32_t B, int32_t T) { NmScope nm_scope_(c);
     if (!c || !c->has_weights || B <= 0 || T <= 0) return 0;
     c->ws.dry = true; c->ws.peak = 0;
     float dummy = 0.f; float* dp = &dummy;
@@ -1003,7 +1007,7 @@ size_t nm_workspace_bytes(nm_ctx* c, int32_t B, int32_t T) {
 }
 
 int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints,
-                        float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) {
+                        float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_forward");
     if (rc) return rc;
     if (!vox || !keypoints || !heatmaps || !first_feature || !recon || !losses11 || B <= 0 || T <= 0) {
@@ -1014,7 +1018,7 @@ int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32
 
 int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, const float* eps, int32_t S,
                      float* keypoints, float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11,
-                     float* kypt_recon, float* R, float* z, float* h, float* scalars2, int32_t* best_idx) {
+                     float* kypt_recon, float* R, float* z, float* h, float* scalars2, int32_t* best_idx) { NmScope nm_scope_(c);
     int rc = check_ready(c, "forward_fused");
     if (rc) return rc;
     if (!vox || !eps || !keypoints || !heatmaps || !first_feature || !recon || !losses11 || !kypt_recon || !R || !z || !h ||
@@ -1040,7 +1044,7 @@ int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t 
 }
 
 int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* first_feature, const float* first_frame,
-                             int32_t B, int32_t Tg, float* gen) {
+                             int32_t B, int32_t Tg, float* gen) { NmScope nm_scope_(c);
     int rc = check_ready(c, "decode_from_keypoints");
     if (rc) return rc;
     if (!keypoints || !first_feature || !first_frame || !gen || B <= 0 || Tg <= 0) {
@@ -1050,7 +1054,7 @@ int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* fir
 }
 
 int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints,
-                              float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) {
+                              float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_forward_train");
     if (rc) return rc;
     if (!c->training) { nm_set_error("detector_forward_train: call nm_ctx_set_training(ctx, 1) and nm_ctx_set_weights first"); return NM_ERR_STATE; }
@@ -1074,7 +1078,7 @@ int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T,
     return rc;
 }
 
-int nm_detector_backward(nm_ctx* c, const float* dlosses11, const nm_named_grad* grads, int32_t count) {
+int nm_detector_backward(nm_ctx* c, const float* dlosses11, const nm_named_grad* grads, int32_t count) { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_backward");
     if (rc) return rc;
     if (!c->tape || !c->tape->valid) { nm_set_error("detector_backward: no training forward to back-propagate (or the weights changed since)"); return NM_ERR_STATE; }
@@ -1093,13 +1097,13 @@ int nm_detector_backward(nm_ctx* c, const float* dlosses11, const nm_named_grad*
     return rc;
 }
 
-int nm_ctx_set_backward_event(nm_ctx* c, void* hip_event) {
+int nm_ctx_set_backward_event(nm_ctx* c, void* hip_event) { NmScope nm_scope_(c);
     if (!c) { nm_set_error("set_backward_event: null ctx"); return NM_ERR_ARG; }
     c->ev_user_decoder = static_cast<hipEvent_t>(hip_event);
     return NM_OK;
 }
 
-int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, double scale, float* vox, int32_t* idx_out) {
+int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, double scale, float* vox, int32_t* idx_out) { NmScope nm_scope_(c);
     if (!c || !points || !vox || T <= 0 || N <= 0) { nm_set_error("voxelize_clip: bad argument"); return NM_ERR_ARG; }
     int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
     if (rc) return rc;
@@ -1109,7 +1113,7 @@ int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, doub
     return nm_launch_voxelize(points, T, (size_t)N, c->cfg.grid_size, scale, part, vox, idx_out, c->stream);
 }
 
-int nm_get_affinity(nm_ctx* c, float* affinity) {
+int nm_get_affinity(nm_ctx* c, float* affinity) { NmScope nm_scope_(c);
     int rc = check_ready(c, "get_affinity");
     if (rc) return rc;
     if (!affinity) { nm_set_error("get_affinity: null output"); return NM_ERR_ARG; }

@@ -586,14 +586,12 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_edge_kernel(Up2cParams p, in
     }
 }
 
-int g_up2c = [] { const char* e = getenv("NM355_UP2C"); return e ? atoi(e) : 1; }();   // 0: fused-upsample layers stay on conv_f16s (diagnostic / A-B)
 int g_cus = 0;
-int g_diag = [] { const char* e = getenv("NM355_UP2C_DIAG"); return e ? atoi(e) : 0; }();
 
 }  // namespace
 
 bool nm_up2c_eligible(int ID, int IH, int IW, int Cin, int Cout, int ks, int stride, int pad) {
-    return g_up2c && ks == 3 && stride == 1 && pad == 1 && ID % BZ == 0 && IH % BY == 0 && IW % BX == 0 && Cin % CG == 0 && Cout % 32 == 0 &&
+    return nm_ls().up2c && ks == 3 && stride == 1 && pad == 1 && ID % BZ == 0 && IH % BY == 0 && IW % BX == 0 && Cin % CG == 0 && Cout % 32 == 0 &&
            Cin == 64 && Cout == 32;
 }
 
@@ -639,13 +637,13 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     p.Cout = Cout; p.Co_pad = Co_pad;
     p.nbz = in.D / BZ; p.nby = in.H / BY; p.nbx = in.W / BX;
     p.nblk = nm_up2c_blocks_per_frame(in.D, in.H, in.W);
-    p.diag = g_diag;
+    p.diag = nm_ls().up2c_diag;
     const int bricks = p.nbz * p.nby * p.nbx, total = p.N * bricks;
     if (single) hipLaunchKernelGGL(conv_up2c_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else hipLaunchKernelGGL(conv_up2c_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     int rc = nm_check_hip(hipGetLastError(), "conv_up2c launch");
     if (rc) return rc;
-    if (g_diag & 4) return NM_OK;
+    if (nm_ls().up2c_diag & 4) return NM_OK;
     int TZ, TY, TX; shell_tiles(in.D, in.H, in.W, TZ, TY, TX);
     const int fg = face_groups(in.D, in.H, in.W), ei = edge_items(in.D, in.H, in.W);
     const size_t face_lds = (size_t)(in.C / 16 * 4) * FPV * 16;

@@ -823,13 +823,11 @@ int pick_nb(int batch) { return batch >= 8 ? 8 : (batch >= 4 ? 4 : (batch >= 2 ?
 // prior steps of a rollout: 0 (default) six dependent launches, 1 three (vrnn_prior_mid_kernel).  Measured A/B (tools/time_rollout.py,
 // bit-identical outputs): 39.4 vs 60.6 us/step at B = 1, 43.2 vs 103.1 at B = 3 - one workgroup walking 680 weight rows and the serial
 // kinematic chain is slower than three wide launches, so the fused form stays off.
-int g_vrnn_mid = [] { const char* e = getenv("NM355_VRNN_MID"); return e ? atoi(e) : 0; }();
 #define NM_GEMM_MIN_BATCH 128
-int g_vrnn_gemm = [] { const char* e = getenv("NM355_VRNN_GEMM"); return e ? atoi(e) : 1; }();     // 0: one wavefront per output row at every batch size (A/B)
 
 // batches of >= 128 rows take the MFMA GEMM (every input segment of this model is a multiple of 32 columns wide)
 bool gemm_eligible(const LinJobs& J) {
-    if (!g_vrnn_gemm) return false;
+    if (!nm_ls().vrnn_gemm) return false;
     for (int i = 0; i < J.n; ++i) {
         const LinJob& j = J.j[i];
         if (j.batch < NM_GEMM_MIN_BATCH || j.na % GM_KC || j.nb % GM_KC || (j.col0 & 3) || (j.ldw & 3) || (j.lda & 3) || (j.nb && (j.ldb & 3))) return false;
@@ -862,7 +860,7 @@ int launch_jobs(const LinJobs& J, hipStream_t s) {
 int launch_gru(const float* W_ih, const float* b_ih, const float* xa, int na, int lda, const float* xb, int nb_, int ldb,
                const float* gh, const float* h, int ldh, float* hout, int ldo, int H, int B, hipStream_t s, float* tg = nullptr,
                float* gi_scratch = nullptr) {
-    if (gi_scratch && !tg && g_vrnn_gemm && B >= NM_GEMM_MIN_BATCH && na % GM_KC == 0 && nb_ % GM_KC == 0) {
+    if (gi_scratch && !tg && nm_ls().vrnn_gemm && B >= NM_GEMM_MIN_BATCH && na % GM_KC == 0 && nb_ % GM_KC == 0) {
         // large batch: input projection as a GEMM, then the element-wise gates
         LinJobs J; J.n = 0; J.start[0] = 0;
         LinearW ih; ih.in = na + nb_; ih.out = 3 * H; ih.w = const_cast<float*>(W_ih); ih.b = const_cast<float*>(b_ih);
@@ -924,7 +922,7 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         add_job(J, hh, 0, io.h, H, io.ldh, nullptr, 0, 0, true, nullptr, 0, 1, sb.gh, 3 * H, 0, B);
         if ((rc = launch_jobs(J, s))) return rc;
     }
-    if (!post && B <= 4 && !io.tape && !io.out_R && !io.best && !io.kl && !io.rec && g_vrnn_mid && K <= 32 && Z == 128) {
+    if (!post && B <= 4 && !io.tape && !io.out_R && !io.best && !io.kl && !io.rec && nm_ls().vrnn_mid && K <= 32 && Z == 128) {
         // 2-4 in one workgroup (prior steps of a rollout): see vrnn_prior_mid_kernel
         MidArgs a;
         a.hid_prior = sb.hid_prior; a.rh = sb.rh; a.jh = sb.jh; a.eps = io.eps; a.offset = io.offset;
@@ -1010,7 +1008,7 @@ void nm_vrnn_invalidate_tape(nm_ctx* c) { if (c->vtape) static_cast<VrnnTape*>(c
 
 extern "C" {
 
-int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) {
+int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_set_tree", false);
     if (rc) return rc;
     const int K = c->cfg.nkeypoints;
@@ -1035,7 +1033,7 @@ int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) {
     return NM_OK;
 }
 
-int nm_vrnn_offsets(nm_ctx* c, const float* keypoints, int32_t B, int32_t T, float* offset) {
+int nm_vrnn_offsets(nm_ctx* c, const float* keypoints, int32_t B, int32_t T, float* offset) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_offsets", true);
     if (rc) return rc;
     if (!keypoints || !offset || B <= 0 || T <= 0) { nm_set_error("vrnn_offsets: bad argument"); return NM_ERR_ARG; }
@@ -1100,12 +1098,12 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
 }
 
 int nm_vrnn_encode(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
-                   float* R, float* z, float* h, float* scalars2, int32_t* best_idx) {
+                   float* R, float* z, float* h, float* scalars2, int32_t* best_idx) { NmScope nm_scope_(c);
     return encode_impl(c, keypoints, eps, B, T, S, kypt_recon, R, z, h, scalars2, best_idx, false);
 }
 
 int nm_vrnn_encode_train(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
-                         float* R, float* z, float* h, float* scalars2, int32_t* best_idx) {
+                         float* R, float* z, float* h, float* scalars2, int32_t* best_idx) { NmScope nm_scope_(c);
     return encode_impl(c, keypoints, eps, B, T, S, kypt_recon, R, z, h, scalars2, best_idx, true);
 }
 
@@ -1114,7 +1112,7 @@ static int launch_wgrad(const float* dA, int ldA, int rows, WgSeg xa, WgSeg xb, 
     return nm_check_hip(hipGetLastError(), "wgrad launch");
 }
 
-int nm_vrnn_encode_backward(nm_ctx* c, const float* dscal2, const nm_named_grad* grads, int32_t count) {
+int nm_vrnn_encode_backward(nm_ctx* c, const float* dscal2, const nm_named_grad* grads, int32_t count) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_encode_backward", true);
     if (rc) return rc;
     VrnnTape& tp = ctx_tape(c);
@@ -1245,7 +1243,7 @@ int nm_vrnn_encode_backward(nm_ctx* c, const float* dscal2, const nm_named_grad*
 }
 
 int nm_adam_step(nm_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, int32_t step, float lr,
-                 float beta1, float beta2, float eps) {
+                 float beta1, float beta2, float eps) { NmScope nm_scope_(c);
     if (!c || !param || !grad || !exp_avg || !exp_avg_sq || numel <= 0 || step <= 0) { nm_set_error("adam_step: bad argument"); return NM_ERR_ARG; }
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     int blocks = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
@@ -1254,7 +1252,7 @@ int nm_adam_step(nm_ctx* c, float* param, const float* grad, float* exp_avg, flo
 }
 
 int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                       const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps) {
+                       const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps) { NmScope nm_scope_(c);
     if (!c || !params || !grads || !exp_avg || !exp_avg_sq || !numels || count <= 0 || step <= 0) { nm_set_error("adam_step_multi: bad argument"); return NM_ERR_ARG; }
     c->host_table.resize((size_t)count * sizeof(AdamItem));
     AdamItem* items = reinterpret_cast<AdamItem*>(c->host_table.data());
@@ -1277,7 +1275,7 @@ int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grad
 }
 
 int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_post, const float* eps_prior, int32_t B,
-                     int32_t Tcond, int32_t Ttot, int32_t S, float* out_cond, float* out_gen, float* h_last) {
+                     int32_t Tcond, int32_t Ttot, int32_t S, float* out_cond, float* out_gen, float* h_last) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_generate", true);
     if (rc) return rc;
     if (!keypoints_cond || !eps_post || !out_cond || B <= 0 || Tcond <= 0 || Ttot < Tcond || S <= 0 || (Ttot > Tcond && (!eps_prior || !out_gen))) {
@@ -1315,7 +1313,7 @@ int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_po
 }
 
 int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* kp_obs, const float* offset, const float* eps,
-                 int32_t B, int32_t S, float* kp_out, float* z_out, float* h_out) {
+                 int32_t B, int32_t S, float* kp_out, float* z_out, float* h_out) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_step", true);
     if (rc) return rc;
     if (!h_in || !offset || !eps || !kp_out || !z_out || B <= 0 || (posterior && (!kp_obs || S <= 0))) {
@@ -1360,13 +1358,13 @@ __global__ __launch_bounds__(256) void rows_argmin_kernel(const float* __restric
 }
 
 int nm_rows_argmin_dist(nm_ctx* c, const float* rows, const float* target, int32_t target_row_stride, int32_t B, int32_t D,
-                        int32_t* idx_out, float* dist_out) {
+                        int32_t* idx_out, float* dist_out) { NmScope nm_scope_(c);
     if (!c || !rows || !target || !idx_out || B <= 0 || D <= 0) { nm_set_error("rows_argmin_dist: bad argument"); return NM_ERR_ARG; }
     hipLaunchKernelGGL(rows_argmin_kernel, dim3(1), dim3(256), 0, c->stream, rows, target, target_row_stride, B, D, idx_out, dist_out);
     return nm_check_hip(hipGetLastError(), "rows_argmin launch");
 }
 
-int nm_vrnn_mlp(nm_ctx* c, int32_t which, const float* x, int32_t B, float* y) {
+int nm_vrnn_mlp(nm_ctx* c, int32_t which, const float* x, int32_t B, float* y) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_mlp", false);
     if (rc) return rc;
     if (!x || !y || B <= 0 || which < 0 || which > 3) { nm_set_error("vrnn_mlp: bad argument"); return NM_ERR_ARG; }
@@ -1384,7 +1382,7 @@ int nm_vrnn_mlp(nm_ctx* c, int32_t which, const float* x, int32_t B, float* y) {
     return launch_jobs(J2, c->stream);
 }
 
-int nm_vrnn_gru(nm_ctx* c, const float* x, const float* h, int32_t B, float* h_out) {
+int nm_vrnn_gru(nm_ctx* c, const float* x, const float* h, int32_t B, float* h_out) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_gru", false);
     if (rc) return rc;
     if (!x || !h || !h_out || B <= 0) { nm_set_error("vrnn_gru: bad argument"); return NM_ERR_ARG; }
@@ -1400,7 +1398,7 @@ int nm_vrnn_gru(nm_ctx* c, const float* x, const float* h, int32_t B, float* h_o
     return launch_gru(w.w_ih, w.b_ih, x, in, in, nullptr, 0, 0, gh, h, H, h_out, H, H, B, c->stream);
 }
 
-int nm_vrnn_fk(nm_ctx* c, const float* dec_in, const float* offset, int32_t B, float* kp, float* R) {
+int nm_vrnn_fk(nm_ctx* c, const float* dec_in, const float* offset, int32_t B, float* kp, float* R) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_fk", true);
     if (rc) return rc;
     if (!dec_in || !offset || !kp || !R || B <= 0) { nm_set_error("vrnn_fk: bad argument"); return NM_ERR_ARG; }

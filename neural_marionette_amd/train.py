@@ -55,6 +55,8 @@ class GradBucket:
     'nccl'; gloo in the CPU tests) is issued on a side stream as soon as its gradients exist and overlaps the rest of the
     backward pass.  One process per GPU, sum then 1/world."""
 
+    always_reduce = False      # True: issue the collectives in a 1-rank group too (the GPU test of the RCCL path on one device)
+
     def __init__(self, named_params, chunk_of, nchunks: int):
         """named_params: [(name, parameter)]; chunk_of(name) -> chunk index in completion order."""
         order = sorted(range(len(named_params)), key=lambda i: (chunk_of(named_params[i][0]), i))
@@ -81,7 +83,7 @@ class GradBucket:
     def reduce_chunk(self, i, after_event=None) -> None:
         """Start the all-reduce of chunk i (asynchronous; on the GPU: on the bucket's side stream, behind ``after_event`` or
         behind everything queued on the current stream so far)."""
-        if not dist.is_initialized() or dist.get_world_size() == 1 or self.chunks[i][0] == self.chunks[i][1]:
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not self.always_reduce) or self.chunks[i][0] == self.chunks[i][1]:
             return
         if self.comm_stream is None:
             self._pending.append(dist.all_reduce(self.chunk(i), op=dist.ReduceOp.SUM, async_op=True))
@@ -174,16 +176,34 @@ class DetectorTrainer:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.weights = dict(DETECTOR_LOSS_WEIGHTS if weights is None else weights)
         self.loss_keys = DETECTOR_LOSS_KEYS
+        unknown = sorted(set(self.weights) - set(DETECTOR_LOSS_KEYS))
+        if unknown:
+            raise KeyError(f"DetectorTrainer: not detector losses: {unknown} (known: {list(DETECTOR_LOSS_KEYS)})")
         self.acts = {"detector": True, "learner": False}
         net.control_active(self.acts)
         self.bucket: Optional[GradBucket] = None
         self._bucket_key = None
         self._wvec = None
+        self._wvec_key = None
         self._ev = None
         self.reset_optimizer()
 
     def _named(self):
-        return [("kypt_detector." + n, p) for n, p in self.net.kypt_detector.named_parameters() if p.requires_grad]
+        """Every kypt_detector parameter: nm_detector_backward writes a gradient for each of them (frozen ones included - e.g.
+        affinity_params while KyptDetector.anneal keeps it frozen, kypt_detector.py:71-78); `requires_grad` only decides which
+        ones Adam updates and which get a `.grad`."""
+        return [("kypt_detector." + n, p) for n, p in self.net.kypt_detector.named_parameters()]
+
+    def _weight_vector(self, dev):
+        """dL/dloss_k as a device vector, rebuilt whenever `self.weights` is edited (e.g. a per-epoch schedule)."""
+        key = (str(dev), tuple(sorted(self.weights.items())))
+        if key != self._wvec_key:
+            unknown = sorted(set(self.weights) - set(self.loss_keys))
+            if unknown:
+                raise KeyError(f"DetectorTrainer: not detector losses: {unknown}")
+            self._wvec = torch.tensor([float(self.weights.get(k, 0.0)) for k in self.loss_keys], device=dev)
+            self._wvec_key = key
+        return self._wvec
 
     def reset_optimizer(self) -> None:
         """The reference re-instantiates Adam at every epoch (train.py:366-374): state starts from zero."""
@@ -201,28 +221,32 @@ class DetectorTrainer:
         eng.set_training(True)
         c = eng.ready()
         dev = c.device
+        G, K, g = det.grid_size, det.nkeypoints, det.grid_size // 4
+        if vox.dim() != 6 or tuple(vox.shape[2:]) != (1, G, G, G):
+            raise ValueError(f"expected seq of shape (B,T,1,{G},{G},{G}), got {tuple(vox.shape)}")
         vox = vox.detach().to(device=dev, dtype=torch.float32).contiguous()
         B, T = int(vox.shape[0]), int(vox.shape[1])
-        G, K, g = det.grid_size, det.nkeypoints, det.grid_size // 4
         kp = torch.empty(B, T, K, 4, device=dev); hm = torch.empty(B, T, K, g, g, g, device=dev)
         ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev); recon = torch.empty(B, T, 1, G, G, G, device=dev)
         aff = torch.empty(det.nneighbor, K, K, 1, device=dev) if det.affinity_start else None
         losses = torch.empty(len(self.loss_keys), device=dev)
         eng.call("nm_detector_forward_train", _lib.ptr(vox), B, T, int(det.affinity_start), _lib.ptr(kp), _lib.ptr(hm), _lib.ptr(ff),
                  _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses))
-        if self._wvec is None or self._wvec.device != dev:
-            self._wvec = torch.tensor([float(self.weights.get(k, 0.0)) for k in self.loss_keys], device=dev)
+        wvec = self._weight_vector(dev)
+        if self._ev is None:
             self._ev = torch.cuda.Event()
             self._ev.record()                       # (creates the HIP event; the library re-records it)
-        eng.call("nm_ctx_set_backward_event", C.c_void_p(self._ev.cuda_event))
         arr = (_lib.NmNamedTensor * len(named))()
         keep = []
         for i, (n, _) in enumerate(named):
             v = bucket.views[n]
             keep.append(n.encode())
             arr[i].name, arr[i].data, arr[i].numel = keep[-1], v.data_ptr(), v.numel()
-        eng.call("nm_detector_backward", _lib.ptr(self._wvec), arr, len(named))
-        eng.call("nm_ctx_set_backward_event", None)
+        eng.call("nm_ctx_set_backward_event", C.c_void_p(self._ev.cuda_event))
+        try:
+            eng.call("nm_detector_backward", _lib.ptr(wvec), arr, len(named))
+        finally:                                    # never leave the raw event handle in the context (a failed backward included)
+            eng.call("nm_ctx_set_backward_event", None)
         bucket.reduce_chunk(0, after_event=self._ev)
         self._keep = (vox, kp, recon, aff)          # read by the backward kernels (stream-ordered: freed no earlier than the next step)
         return losses
@@ -244,8 +268,9 @@ class DetectorTrainer:
         losses = self._forward_backward(vox, named, bucket)
         bucket.reduce_chunk(1)
         bucket.finish()
-        params = [p for _, p in named]
-        grads = [bucket.views[n] for n, _ in named]
+        live = [(n, p) for n, p in named if p.requires_grad]          # frozen parameters: gradient computed, not applied
+        params = [p for _, p in live]
+        grads = [bucket.views[n] for n, _ in live]
         for p, g in zip(params, grads):
             p.grad = g                                # (a view of the bucket: what a caller inspecting .grad expects to find)
         self.t += 1
@@ -253,8 +278,7 @@ class DetectorTrainer:
             if id(p) not in self.state:
                 self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
         self._adam(params, grads, [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params])
-        wv = self._wvec if self._wvec is not None else torch.tensor([float(self.weights.get(k, 0.0)) for k in self.loss_keys])
-        loss = (losses * wv.to(losses.device)).sum()
+        loss = (losses * self._weight_vector(losses.device)).sum()
         log = {k: losses[i] for i, k in enumerate(self.loss_keys) if k in self.weights}
         if not sync:
             return {"loss": loss, **log}

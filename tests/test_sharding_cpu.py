@@ -155,3 +155,52 @@ def test_detector_trainer_step_world2_with_cpu_stand_ins():
     from neural_marionette_amd.spec import DETECTOR_LOSS_KEYS
     assert abs(loss - sum(DETECTOR_LOSS_WEIGHTS[k] * i for i, k in enumerate(DETECTOR_LOSS_KEYS))) < 1e-3
     assert "loss" in keys and "recon_loss" in keys
+
+
+# ---- bench.py --gpus N outside a launcher: the file starts its own N ranks (child torch.distributed.run, before torch is imported)
+def _bench(*args, env=None):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=root, env=e)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus2_starts_two_ranks_gloo():
+    """`python bench.py --gpus 2 ...` (the form the driver uses for N = 1) must yield n_gpus 2 / world_size 2: here with the
+    plumbing-only --dist-selftest on gloo (no GPU in this container), the same launcher / rendezvous / collectives the bench uses."""
+    r, lines = _bench("--gpus", "2", "--dist-selftest")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["distributed"]["world_size"] == 2 and d["distributed"]["ranks_seen_by_allreduce"] == 2
+    assert d["distributed"]["backend"] == "gloo" and d["max_over_ranks_checks"] is True
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    """Under an external launcher WORLD_SIZE must equal --gpus (a run that silently degenerated to another rank count)."""
+    r, lines = _bench("--gpus", "4", "--dist-selftest", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not lines
+    assert "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_detector_trainer_rejects_unknown_loss_names_and_tracks_weight_edits():
+    from neural_marionette_amd import NeuralMarionette, HotPathOptions
+    from neural_marionette_amd.train import DetectorTrainer
+    import pytest
+    net = NeuralMarionette(HotPathOptions(grid_size=32))
+    with pytest.raises(KeyError):
+        DetectorTrainer(net, weights={"recon_loss": 1.0, "no_such_loss": 2.0})
+    tr = DetectorTrainer(net)
+    w0 = tr._weight_vector(torch.device("cpu")).clone()
+    tr.weights["recon_loss"] = 7.0                        # a per-epoch schedule edits the dict in place
+    w1 = tr._weight_vector(torch.device("cpu"))
+    assert w0[tr.loss_keys.index("recon_loss")] == 100.0 and w1[tr.loss_keys.index("recon_loss")] == 7.0
+    # frozen parameters stay in the gradient bucket (the library writes every detector gradient), only Adam skips them
+    net.kypt_detector.affinity_params.requires_grad = False
+    names = [n for n, _ in tr._named()]
+    assert "kypt_detector.affinity_params" in names and len(names) == len(list(net.kypt_detector.parameters()))
