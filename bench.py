@@ -119,25 +119,66 @@ def cpu_baseline(sd, opts, net, dev):
         times = []
         t_all = time.perf_counter()
         ref = None
-        while len(times) < 3 and (not times or (time.perf_counter() - t_all) + times[-1] < 32.0):
+        # one untimed warm run at the final thread count is the calibration above; then THREE timed runs (median = the middle one)
+        # unless a single run exceeds 40 s on this host (then the runs that fit 120 s; the count is stated in `sample`)
+        while len(times) < 3 and (not times or (time.perf_counter() - t_all) + times[-1] < 120.0):
             t0 = time.perf_counter()
             ref = O.nm_forward(sd, opts, vox, eps)
             times.append(time.perf_counter() - t0)
     times.sort()
-    med = times[len(times) // 2]
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     # parity of the GPU path on exactly this sample (keypoint L2 vs the CPU reference port)
     with torch.no_grad():
         out = net(vox.to(dev), {"detector": True, "learner": True}, eps=eps.to(dev))
     torch.cuda.synchronize(dev)
     d = (out["keypoints"][..., :3].cpu() - ref["keypoints"][..., :3]).double()
     l2 = d.pow(2).sum(-1).sqrt().max().item()
-    return dict(value=nb * T / med, unit="voxel-frames/s", cores=best_thr, kind="port",
-                sample=f"median of {len(times)} x oracle.nm_forward on {nb} clips of 64^3 x T=16 (the bench shape) "
+    lat = max((out[k].cpu().double() - ref[k].double()).abs().max().item() for k in ("z_kypts", "h_kypts"))
+    parity = dict(kypt_l2=l2, latent_linf=lat, kypt_recon_linf=(out["kypt_recon"].cpu().double() - ref["kypt_recon"].double()).abs().max().item(),
+                  best_idx_equal=bool((out["best_idx"].cpu().long() == ref["best_idx"].long()).all()))
+    return dict(value=nb * T / med, unit="voxel-frames/s", cores=best_thr, kind="port", runs_s=[round(t, 3) for t in times],
+                sample=f"{'median' if len(times) >= 3 else 'mean'} of {len(times)} x oracle.nm_forward on {nb} clips of 64^3 x T=16 (the bench shape) "
                        f"(detector + losses + VRNN encode), torch {torch.__version__} CPU ops, "
-                       f"{best_thr} threads (calibrated; host has {ncpu} hardware threads)"), l2
+                       f"{best_thr} threads (calibrated; host has {ncpu} hardware threads)"), parity
 
 
 STEP_TFLOP = 99.15e-3 * B_PER_GPU * T          # algorithmic TFLOP of one forward step on one GPU
+ROUND = "r03"                                   # PMC summaries are only read from this round's files under profiles/
+
+
+def prof_families(lib, h, _lib):
+    """{kernel family: (event-timed ms total, algorithmic flops total, launches)} of the context's current profiler window."""
+    fam = {}
+    for v in range(13):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(lib.nm_prof_read(h, v, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
+        if n.value:
+            fam[lib.nm_prof_kernel_name(v).decode()] = (ms.value, fl.value, n.value)
+    return fam
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from THIS round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in
+    separate runs, reduced by tools/pmc_traffic_all.py; a PMC pass cannot run inside this process).  `traffic` follows
+    MI355X_MICROARCH.md (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE); the raw figure and this access pattern's calibration are beside
+    it.  A file written in another round is refused: stale counters are worse than none."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic.json")
+    try:
+        pm = json.load(open(path))
+    except Exception:
+        return None, dict(file=None, note=f"no profiles/{ROUND}_pmc_traffic.json yet (tools/pmc_traffic_all.py writes it)")
+    if pm.get("round") != ROUND:
+        return None, dict(file=os.path.basename(path), note=f"refused: written in round {pm.get('round')!r}, not {ROUND}")
+    base = kernel.split("<")[0]
+    rec = next((r for r in pm.get("kernels", []) if r["kernel"] == kernel), None) or \
+        next((r for r in pm.get("kernels", []) if r["kernel"].split("<")[0] == base), None)
+    if rec is None:
+        return None, dict(file=os.path.basename(path), note=f"no record for {kernel}")
+    det = dict(file=os.path.basename(path), kernel=rec["kernel"], launches=rec["launches"], fetch_bytes_raw=rec["fetch_bytes_raw"],
+               fetch_bytes_x2=rec["fetch_bytes_x2"], write_bytes=rec["write_bytes"],
+               traffic_raw=rec["fetch_bytes_raw"] + rec["write_bytes"], traffic_x2=rec["fetch_bytes_x2"] + rec["write_bytes"],
+               calibration=pm.get("calibration"))
+    return det["traffic_x2"], det
 
 
 def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
@@ -360,6 +401,17 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    fam_main = prof_families(lib, h, _lib) if rank == 0 else {}        # timed region, launches on the ctx stream (clean durations)
+    # the same families including the launches the library puts on its side stream (clip-mean net / VRNN beside the frame stack):
+    # three more steps after the timed region, every conv launch on either stream bracketed by events (durations include contention)
+    fam_all = {}
+    if rank == 0:
+        _lib.check(lib.nm_prof_enable(h, 2), "prof_enable")
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.nm_prof_enable(h, 0), "prof_enable")
+        fam_all = prof_families(lib, h, _lib)
 
     # what each rank saw (the driver can check that RCCL really spanned N devices)
     ranks_seen = world
@@ -374,27 +426,28 @@ def main():
 
     if rank == 0:
         frames = world * B_PER_GPU * T * args.steps
-        # dominant kernel = the conv variant with the largest event-timed total
-        best = None
-        for v in range(13):
-            ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-            _lib.check(lib.nm_prof_read(h, v, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
-            if n.value and (best is None or ms.value > best[1]):
-                best = (lib.nm_prof_kernel_name(v).decode(), ms.value, fl.value, n.value)
+        # dominant kernel = the conv family with the largest event-timed total per step over BOTH streams (what a rocprof summary
+        # ranks by); its `achieved` comes from its launches on the ctx stream inside the timed region (clean durations)
+        is_split = lambda nm: nm.startswith("conv_f16") or nm.startswith("conv_pool_f16") or nm.startswith("conv_up2c")
+        ranked = sorted(fam_all.items(), key=lambda kv: -kv[1][0])
+        top3 = []
+        for nm, (ms_a, fl_a, n_a) in ranked[:3]:
+            ms_m, fl_m, n_m = fam_main.get(nm, (0.0, 0.0, 0))
+            pk = F16_MFMA_PEAK_TFLOPS if is_split(nm) else FP32_MFMA_PEAK_TFLOPS
+            top3.append(dict(kernel=nm, ms_per_step_all_streams=ms_a / 3.0, launches_per_step_all_streams=n_a / 3.0,
+                             ms_per_step_ctx_stream=ms_m / args.steps, launches_per_step_ctx_stream=n_m / args.steps,
+                             achieved_tflops_ctx_stream=(fl_m / (ms_m * 1e-3) / 1e12 if ms_m else None),
+                             frac_of_peak=(fl_m / (ms_m * 1e-3) / 1e12 / pk if ms_m else None), peak_tflops=pk))
+        best = next(((nm, *fam_main[nm]) for nm, _ in ranked if nm in fam_main), None)
         roof = None
         if best:
             name, ms, fl, n = best
             ach = fl / (ms * 1e-3) / 1e12
-            # HBM bytes per launch of that kernel from the committed PMC passes (separate rocprofv3 --pmc runs)
-            traffic = None
-            try:        # (a PMC pass cannot run inside this process: the committed per-kernel figures of this round's passes)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                traffic = pm["traffic_bytes_per_launch"].get(name)
-            except Exception:
-                pass
-            split = name.startswith("conv_f16") or name.startswith("conv_pool_f16") or name.startswith("conv_up2c")
+            traffic, traffic_detail = pmc_traffic(name)
+            split = is_split(name)
             peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
             roof = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=traffic,
+                        traffic_detail=traffic_detail, top3=top3,
                         kernel=name, launches=n, avg_launch_ms=ms / n, kernel_time_share=ms * 1e-3 / dt,
                         note=("achieved = algorithmic fp32 conv FLOPs (2*voxels*Cout*Cin*k^3) / event-timed launch time; "
                               + ("this kernel issues 3 f16 MFMA products per algorithmic product (hi/lo operand split, "
@@ -404,9 +457,9 @@ def main():
                 roof["issued"] = 3.0 * ach
                 roof["frac_issued"] = 3.0 * ach / peak
                 roof["algorithmic_vs_fp32_mfma_peak"] = ach / FP32_MFMA_PEAK_TFLOPS
-        cpu, l2 = (None, None)
+        cpu, parity = (None, {})
         if world == 1 and not args.no_cpu_baseline and args.workload == "forward":
-            cpu, l2 = cpu_baseline(sd, opts, net, dev)
+            cpu, parity = cpu_baseline(sd, opts, net, dev)
         line = dict(
             metric="voxel-frames/sec (64^3, T=16)", value=frames / dt, unit="voxel-frames/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
@@ -421,7 +474,8 @@ def main():
                                   "11 weighted losses + flat-bucket gradient all-reduce + Adam), fp32, random-init weights"),
                         grid=G, T=T, clips_per_gpu=B_PER_GPU, global_clips=world * B_PER_GPU, conv_mode=args.conv_mode,
                         parallelism=f"clip-sharded x{world} (no data-path collective)"),
-            roofline=roof, cpu_baseline=cpu, kypt_l2_vs_cpu=l2,
+            roofline=roof, cpu_baseline=cpu, kypt_l2_vs_cpu=parity.get("kypt_l2"), latent_linf_vs_cpu=parity.get("latent_linf"),
+            parity_vs_cpu=parity or None,
             step_roofline=dict(algorithmic_tflop_per_step=STEP_TFLOP, achieved=STEP_TFLOP * world / (dt / args.steps),
                                unit="TFLOP/s", peak=F16_MFMA_PEAK_TFLOPS * world if eng.conv_mode else FP32_MFMA_PEAK_TFLOPS * world,
                                frac=STEP_TFLOP / (dt / args.steps) / (F16_MFMA_PEAK_TFLOPS if eng.conv_mode else FP32_MFMA_PEAK_TFLOPS),
