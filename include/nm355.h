@@ -204,6 +204,14 @@ int nm_vrnn_generate(nm_ctx* ctx, const float* keypoints_cond, const float* eps_
                      const float* eps_prior, int32_t B, int32_t Tcond, int32_t Ttot, int32_t S,
                      float* out_cond, float* out_gen, float* h_last);
 
+/* Prior rollout from a given state — the generation loop of vis_generation.py:117-127 (per step: extract_prior_dist, rsample,
+ * extract_kypt_from_latent_and_state, kypt_rnn_cell) for T steps in one call:
+ *  h_in (B,H), offset (B,K,3) [get_offset], eps (T,B,Z); kp_out (B,T,K,4); h_out (B,H) or NULL.
+ * For batches <= 64 rows this and nm_vrnn_generate replay a HIP graph of their launch sequence, captured on first use per
+ * (B, Tcond, T) and kept in the context (three dependent launches per prior step; NM355_VRNN_GRAPH=0 enqueues them one by one). */
+int nm_vrnn_rollout(nm_ctx* ctx, const float* h_in, const float* offset, const float* eps, int32_t B, int32_t T,
+                    float* kp_out, float* h_out);
+
 /* One VRNN step for hand-rolled rollouts (vis_generation.py:97-127 of the reference):
  *  posterior != 0: best-of-S posterior step against kp_obs (B,K*4), eps (S,B,Z);
  *  posterior == 0: prior step, eps (B,Z), S ignored.

@@ -66,6 +66,7 @@ SIGNATURES = {
     "nm_adam_step_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_int64), _I, _I, _F, _F, _F, _F]),
     "nm_vrnn_generate": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "nm_vrnn_rollout": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _P, _P]),
     "nm_vrnn_step": (C.c_int, [C.c_void_p, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "nm_rows_argmin_dist": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P]),
     "nm_vrnn_mlp": (C.c_int, [C.c_void_p, _I, _P, _I, _P]),

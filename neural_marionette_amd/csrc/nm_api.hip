@@ -27,8 +27,9 @@ NmLaunchState::NmLaunchState()
       wgrad_tr(env_int("NM355_WGRAD_TR", 1)),       // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel
       up2c(env_int("NM355_UP2C", 1)),               // 0: fused-upsample layers stay on conv_f16s (diagnostic / A-B)
       up2c_diag(env_int("NM355_UP2C_DIAG", 0)),
-      vrnn_mid(env_int("NM355_VRNN_MID", 0)),
-      vrnn_gemm(env_int("NM355_VRNN_GEMM", 1)) {}  // 0: one wavefront per output row at every batch size (A/B)
+      vrnn_mid(env_int("NM355_VRNN_MID", 1)),          // 0: prior steps as six launches instead of three (A/B)
+      vrnn_gemm(env_int("NM355_VRNN_GEMM", 1)),    // 0: one wavefront per output row at every batch size (A/B)
+      vrnn_graph(env_int("NM355_VRNN_GRAPH", 1)) {} // 0: rollouts enqueue their launches one by one instead of replaying a captured graph (A/B)
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
     return nm_tls_ls ? *nm_tls_ls : outside;
@@ -71,6 +72,7 @@ float* nm_ctx_weight_alloc(nm_ctx* ctx, size_t floats) {
     }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    ctx->weights_epoch++;
     ctx->owned.push_back(p); ctx->owned_bytes.push_back(bytes); ctx->owned_cursor = ctx->owned.size();
     return static_cast<float*>(p);
 }
@@ -128,6 +130,8 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     if (ctx->copy_table) (void)hipFree(ctx->copy_table);
     if (ctx->pack_table) (void)hipFree(ctx->pack_table);
     if (ctx->nf_flag) (void)hipFree(ctx->nf_flag);
+    if (ctx->vrnn.parents) (void)hipFree(ctx->vrnn.parents);
+    nm_vrnn_free_graphs(ctx);
     nm_net_free_tape(ctx);
     nm_vrnn_free_tape(ctx);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);

@@ -72,8 +72,12 @@ struct VrnnW {
     float* offset_param = nullptr;         // (K,3)
     int32_t* parents = nullptr;            // device (K)
     int32_t* order = nullptr;              // device (K)
+    int32_t* lvl_joint = nullptr;          // device (K): joints grouped by tree depth, level 0 (the root) first
+    int32_t* lvl_start = nullptr;          // device (nlevels + 1): first entry of each level in lvl_joint
+    int nlevels = 0;
     std::vector<int32_t> parents_h, order_h;
     bool has_tree = false;
+    uint64_t tree_epoch = 0;               // bumped by nm_vrnn_set_tree (captured rollout graphs bake the level count in)
 };
 
 struct nm_ctx {
@@ -90,6 +94,7 @@ struct nm_ctx {
     std::vector<void*> owned;              // weight allocations
     std::vector<size_t> owned_bytes;       // their sizes: a repeated nm_ctx_set_weights walks the same sequence and reuses them (no sync)
     size_t owned_cursor = 0;
+    uint64_t weights_epoch = 0;            // bumped whenever a weight buffer is (re)allocated: captured graphs hold the old pointers
     bool has_weights = false;
     bool training = false;                 // nm_ctx_set_training: set_weights also packs the data-gradient weights
     Arena ws_t;                            // activations retained between nm_detector_forward_train and nm_detector_backward
@@ -100,6 +105,7 @@ struct nm_ctx {
     std::vector<char> host_table;          // host staging of nm_adam_step_multi's pointer table (kept alive across the async copy)
     struct TrainTape* tape = nullptr;      // what the backward pass needs of the last training forward (nm_net.hip)
     void* vtape = nullptr;                 // VrnnTape of the last nm_vrnn_encode_train (nm_vrnn.hip)
+    void* vgraphs = nullptr;               // cache of captured rollout graphs (nm_vrnn.hip)
     DetectorW det;
     VrnnW vrnn;
 };
@@ -120,6 +126,7 @@ float* nm_ctx_weight_alloc(nm_ctx* ctx, size_t floats);
 // nm_vrnn.hip
 void nm_vrnn_free_tape(nm_ctx* ctx);
 void nm_vrnn_invalidate_tape(nm_ctx* ctx);
+void nm_vrnn_free_graphs(nm_ctx* ctx);          // captured rollout graphs (nm_vrnn_generate / nm_vrnn_rollout)
 // nm_net.hip
 void nm_net_free_tape(nm_ctx* ctx);
 int nm_net_set_weights(nm_ctx* ctx, const std::map<std::string, std::pair<const float*, int64_t>>& sd);

@@ -974,11 +974,11 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
     r.w_hh = L.copy(m + ".kypt_rnn_cell.weight_hh", (int64_t)3 * H * H);
     r.b_ih = L.copy(m + ".kypt_rnn_cell.bias_ih", 3 * H);
     r.b_hh = L.copy(m + ".kypt_rnn_cell.bias_hh", 3 * H);
-    if (!r.parents) {
-        if (hipMalloc(reinterpret_cast<void**>(&r.parents), K * sizeof(int32_t)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&r.order), K * sizeof(int32_t)) != hipSuccess) {
+    if (!r.parents) {                   // one block: parents[K], order[K], lvl_joint[K], lvl_start[K + 2] (nm_vrnn_set_tree fills them)
+        if (hipMalloc(reinterpret_cast<void**>(&r.parents), (4 * K + 2) * sizeof(int32_t)) != hipSuccess) {
             nm_set_error("set_weights: hipMalloc(tree) failed"); return NM_ERR_HIP;
         }
+        r.order = r.parents + K; r.lvl_joint = r.parents + 2 * K; r.lvl_start = r.parents + 3 * K;
     }
     if (L.rc) return L.rc;
     if ((rc = L.flush_copies())) return rc;

@@ -15,6 +15,8 @@
 // phases are separate launches rather than one persistent kernel.
 #include "nm_ctx.h"
 #include <cmath>
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -97,17 +99,23 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(LinJobs jobs) {
 #pragma unroll
     for (int s = 0; s < NB; ++s) acc[s] = 0.f;
     const float* wr = J.W + (size_t)r * J.ldw + J.col0;
+    // epilogue operands requested BEFORE the dot products, unconditionally, from addresses that are valid either way (a load under
+    // a condition is waited for at the join, and one issued after the reduction is a second dependent L2 round trip per launch)
+    const int bl = min(b0 + (lane < NB ? lane : 0), J.batch - 1);
+    const float bias_v = *(J.bias ? J.bias + r : wr);
+    const float add_v = *(J.add ? J.add + (size_t)(bl % J.add_mod) * J.ldadd + r : wr);
+    const float gate_v = *(J.gate ? J.gate + (size_t)bl * J.ldgate + r : wr);
     dot_seg(wr, J.xa, J.na, J.lda, b0, J.batch, lane, acc);
     dot_seg(wr + J.na, J.xb, J.nb, J.ldb, b0, J.batch, lane, acc);
     wave_reduce(acc);
     if (lane < NB && b0 + lane < J.batch) {
         const int b = b0 + lane;
         float v = pick(acc, lane);
-        if (J.bias) v += J.bias[r];
-        if (J.add) v += J.add[(size_t)(b % J.add_mod) * J.ldadd + r];
+        if (J.bias) v += bias_v;
+        if (J.add) v += add_v;
         if (J.act == 1) v = lrelu(v, 0.01f);
         else if (J.act == 2) v = tanhf(v);
-        if (J.gate) v *= (J.gate[(size_t)b * J.ldgate + r] > 0.f ? 1.0f : 0.01f);
+        if (J.gate) v *= (gate_v > 0.f ? 1.0f : 0.01f);
         J.out[(size_t)b * J.ldo + r] = v;
     }
 }
@@ -221,13 +229,14 @@ __global__ __launch_bounds__(256) void dist_rows_kernel(DistJob a, DistJob b, in
     float am[NB], as[NB];
 #pragma unroll
     for (int s = 0; s < NB; ++s) { am[s] = 0.f; as[s] = 0.f; }
+    const float bias_mu = J.bias[r], bias_s = J.bias[r + Z];       // (before the dot products: one L2 round trip, not two)
     dot_seg(J.W + (size_t)r * hid, J.x, hid, hid, b0, B, lane, am);
     dot_seg(J.W + (size_t)(r + Z) * hid, J.x, hid, hid, b0, B, lane, as);
     wave_reduce(am); wave_reduce(as);
     if (lane < NB && b0 + lane < B) {
         const int bb = b0 + lane;
-        const float mu = pick(am, lane) + J.bias[r];
-        const float sraw = pick(as, lane) + J.bias[r + Z];
+        const float mu = pick(am, lane) + bias_mu;
+        const float sraw = pick(as, lane) + bias_s;
         const float sg = softplus(sraw) + 1e-4f;
         J.mu[(size_t)bb * Z + r] = mu; J.sig[(size_t)bb * Z + r] = sg;
         if (J.raw_s) J.raw_s[(size_t)bb * Z + r] = sraw;
@@ -255,21 +264,24 @@ __global__ __launch_bounds__(256) void gru_rows_kernel(const float* __restrict__
 #pragma unroll
     for (int s = 0; s < NB; ++s) { ar[s] = 0.f; az[s] = 0.f; an[s] = 0.f; }
     const float* w0 = W_ih + (size_t)j * in; const float* w1 = W_ih + (size_t)(H + j) * in; const float* w2 = W_ih + (size_t)(2 * H + j) * in;
+    // gate operands requested before the dot products (one L2 round trip instead of two dependent ones)
+    const int bl = min(b0 + (lane < NB ? lane : 0), B - 1);
+    const float* gl = gh + (size_t)bl * 3 * H;
+    const float g_r = gl[j], g_z = gl[H + j], g_n = gl[2 * H + j], hp = h[(size_t)bl * ldh + j];
+    const float bi_r = b_ih[j], bi_z = b_ih[H + j], bi_n = b_ih[2 * H + j];
     dot_seg(w0, xa, na, lda, b0, B, lane, ar); dot_seg(w0 + na, xb, nb, ldb, b0, B, lane, ar);
     dot_seg(w1, xa, na, lda, b0, B, lane, az); dot_seg(w1 + na, xb, nb, ldb, b0, B, lane, az);
     dot_seg(w2, xa, na, lda, b0, B, lane, an); dot_seg(w2 + na, xb, nb, ldb, b0, B, lane, an);
     wave_reduce(ar); wave_reduce(az); wave_reduce(an);
     if (lane < NB && b0 + lane < B) {
         const int b = b0 + lane;
-        const float* g = gh + (size_t)b * 3 * H;
-        const float rg = sigmoidf((pick(ar, lane) + b_ih[j]) + g[j]);
-        const float zg = sigmoidf((pick(az, lane) + b_ih[H + j]) + g[H + j]);
-        const float ng = tanhf((pick(an, lane) + b_ih[2 * H + j]) + rg * g[2 * H + j]);
-        const float hp = h[(size_t)b * ldh + j];
+        const float rg = sigmoidf((pick(ar, lane) + bi_r) + g_r);
+        const float zg = sigmoidf((pick(az, lane) + bi_z) + g_z);
+        const float ng = tanhf((pick(an, lane) + bi_n) + rg * g_n);
         hout[(size_t)b * ldo + j] = (hp - ng) * zg + ng;
         if (tape_gates) {
             const size_t o = (size_t)b * H + j, pl = (size_t)B * H;
-            tape_gates[o] = rg; tape_gates[pl + o] = zg; tape_gates[2 * pl + o] = ng; tape_gates[3 * pl + o] = g[2 * H + j];
+            tape_gates[o] = rg; tape_gates[pl + o] = zg; tape_gates[2 * pl + o] = ng; tape_gates[3 * pl + o] = g_n;
         }
     }
 }
@@ -282,6 +294,7 @@ struct FkArgs {
     const float* obs; int ldobs;       // [B][..] detected keypoints (K*4) or null (prior step)
     const float* z;                    // [S*B][Z]
     const int32_t* order; const int32_t* parents;
+    const int32_t* lvl_joint; const int32_t* lvl_start; int nlevels;   // joints grouped by tree depth (level 0 = the root): nm_vrnn_set_tree
     const float *qmu, *qsig, *pmu, *psig;   // posterior / prior params [B][Z] (KL) or null
     float* out_kp; int ldkp;           // best keypoints (K*4)
     float* out_z; int ldz;
@@ -294,15 +307,66 @@ struct FkArgs {
     float *t_hr, *t_hj, *t_raw, *t_rot6, *t_Rl, *t_Rg, *t_eps;       // [B][128], [B][128], [B][3+K], [B][6K], [B][9K], [B][9K], [B][Z]
 };
 
+// Forward kinematics over S samples of one batch element, level by level (called by all threads of the workgroup; ends with a barrier).
+// Rl: local rotations [S][K][9] (in LDS, complete), Rg / pos: outputs [S][K][9] / [S][K][3].  root: tanh-MLP rows [S*B][ldr].
+// The tree tables and this batch element's bone offsets come from LDS (FkTables, filled at kernel start): read from global memory
+// inside the level loop every level is a chain of three dependent L2 round trips (level bounds -> joint -> parent), ~2 us per level.
+// A thread works for ONE sample: sample `smp` (or -1), as lane `lt` of the `per` threads of that sample.
+struct FkTables { int32_t lvl_joint[32], lvl_start[34], parents[32]; float offset[96]; };
+__device__ __forceinline__ void fk_tables_load(FkTables& tb, const int32_t* __restrict__ lvl_joint, const int32_t* __restrict__ lvl_start,
+                                               const int32_t* __restrict__ parents, const float* __restrict__ offset_b, int K, int nlevels, int tid) {
+    // one batch of independent, UNCONDITIONAL loads from clamped addresses (a load under a branch makes hipcc drain all outstanding
+    // loads at the join: three branches were three serial L2 round trips); the caller's next barrier publishes the table
+    const int32_t lj = lvl_joint[min(tid, K - 1)], pa = parents[min(tid, K - 1)], ls = lvl_start[min(tid, nlevels)];
+    const float of = offset_b[min(tid, K * 3 - 1)];
+    if (tid < K) { tb.lvl_joint[tid] = lj; tb.parents[tid] = pa; }
+    if (tid <= nlevels) tb.lvl_start[tid] = ls;
+    if (tid < K * 3) tb.offset[tid] = of;
+}
+__device__ __forceinline__ void fk_levels(const FkTables& tb, int nlevels, const float* Rl, float* Rg, float* pos,
+                                          const float* __restrict__ root, int ldr, int K, int B, int b, int smp, int lt, int per) {
+    const int rootj = tb.lvl_joint[0];
+    if (smp >= 0 && lt < 12) {
+        const int i = smp;
+        if (lt < 9) Rg[(i * K + rootj) * 9 + lt] = Rl[(i * K + rootj) * 9 + lt];
+        else pos[(i * K + rootj) * 3 + (lt - 9)] = root[((size_t)(i * B + b)) * ldr + (lt - 9)];
+    }
+    __syncthreads();
+    for (int l = 1; l <= nlevels; ++l) {
+        if (smp >= 0) {
+            const int i = smp;
+            if (l < nlevels) {             // global rotations of level l: G = P(parent) . L
+                const int j0 = tb.lvl_start[l], nj = tb.lvl_start[l + 1] - j0;
+                for (int u = lt; u < nj * 9; u += per) {
+                    const int idx = tb.lvl_joint[j0 + u / 9], e = u % 9, r = e / 3, c = e % 3;
+                    const float* P = Rg + (i * K + tb.parents[idx]) * 9; const float* L = Rl + (i * K + idx) * 9;
+                    Rg[(i * K + idx) * 9 + e] = (P[r * 3] * L[c] + P[r * 3 + 1] * L[3 + c]) + P[r * 3 + 2] * L[6 + c];
+                }
+            }
+            if (l >= 2) {                  // positions of level l - 1: p = G . offset + p(parent)
+                const int j0 = tb.lvl_start[l - 1], nj = tb.lvl_start[l] - j0;
+                for (int u = lt; u < nj * 3; u += per) {
+                    const int idx = tb.lvl_joint[j0 + u / 3], r = u % 3;
+                    const float* G = Rg + (i * K + idx) * 9; const float* of = tb.offset + idx * 3;
+                    pos[(i * K + idx) * 3 + r] = ((G[r * 3] * of[0] + G[r * 3 + 1] * of[1]) + G[r * 3 + 2] * of[2]) + pos[(i * K + tb.parents[idx]) * 3 + r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void fk_kernel(FkArgs a) {
     extern __shared__ float sm[];
     const int K = a.K, S = a.S, b = blockIdx.x;
     float* Rl = sm;                    // [S][K][9]
     float* Rg = Rl + S * K * 9;        // [S][K][9]
     float* pos = Rg + S * K * 9;       // [S][K][3]
-    float* dist = pos + S * K * 3;     // [S]
+    float* dist = pos + S * K * 3;     // [S] + [S][K]
     __shared__ float red[256];
     __shared__ int best_s;
+    __shared__ FkTables tb;
+    fk_tables_load(tb, a.lvl_joint, a.lvl_start, a.parents, a.offset + (size_t)b * K * 3, K, a.nlevels, threadIdx.x);
     // 6-D -> rotation (geo_utils.py:56-78)
     for (int t = threadIdx.x; t < S * K; t += 256) {
         const int i = t / K, k = t % K;
@@ -318,35 +382,31 @@ __global__ __launch_bounds__(256) void fk_kernel(FkArgs a) {
         R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
     }
     __syncthreads();
-    // chain along the tree in priority order (geo_utils.py:16-25, hsvrnn_bvh.py:272-277): one thread per sample
+    // chain along the tree (geo_utils.py:16-25, hsvrnn_bvh.py:272-277), LEVEL-PARALLEL: a joint only needs its parent, so all joints of
+    // one tree depth (of all S samples) are computed together - depth ~4-6 dependent steps instead of K - 1 = 23 on one thread per
+    // sample.  Step l computes the global rotations of level l and the positions of level l - 1 (which need that level's rotation,
+    // finished one barrier ago).  Per element the arithmetic is the serial chain's.
+    {
+        const int per = S <= 256 ? 256 / S : 1, smp = (int)threadIdx.x / per;
+        fk_levels(tb, a.nlevels, Rl, Rg, pos, a.root, a.ldr, K, a.B, b, smp < S ? smp : -1, (int)threadIdx.x % per, per);
+    }
+    // squared distance to the observed keypoints: per (sample, joint) term, then thread i adds its sample's K terms in joint order
+    float* dk = dist + S;              // [S][K]
+    if (a.obs) {
+        const float* ob = a.obs + (size_t)b * a.ldobs;
+        for (int t = threadIdx.x; t < S * K; t += 256) {
+            const int i = t / K, k = t % K;
+            const float* rt = a.root + ((size_t)(i * a.B + b)) * a.ldr;
+            const float u0 = ob[k * 4] - pos[(i * K + k) * 3], u1 = ob[k * 4 + 1] - pos[(i * K + k) * 3 + 1], u2 = ob[k * 4 + 2] - pos[(i * K + k) * 3 + 2];
+            const float u3 = ob[k * 4 + 3] - (rt[3 + k] + 1.0f) * 0.5f;
+            dk[t] = ((u0 * u0 + u1 * u1) + u2 * u2) + u3 * u3;
+        }
+    }
+    __syncthreads();
     if ((int)threadIdx.x < S) {
-        const int i = threadIdx.x;
-        const float* rt = a.root + ((size_t)(i * a.B + b)) * a.ldr;
-        const int root = a.order[0];
-        for (int e = 0; e < 9; ++e) Rg[(i * K + root) * 9 + e] = Rl[(i * K + root) * 9 + e];
-        pos[(i * K + root) * 3 + 0] = rt[0]; pos[(i * K + root) * 3 + 1] = rt[1]; pos[(i * K + root) * 3 + 2] = rt[2];
-        for (int o = 1; o < K; ++o) {
-            const int idx = a.order[o], par = a.parents[idx];
-            const float* P = Rg + (i * K + par) * 9; const float* L = Rl + (i * K + idx) * 9;
-            float* G = Rg + (i * K + idx) * 9;
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) G[r * 3 + c] = (P[r * 3] * L[c] + P[r * 3 + 1] * L[3 + c]) + P[r * 3 + 2] * L[6 + c];
-        }
-        for (int o = 1; o < K; ++o) {
-            const int idx = a.order[o], par = a.parents[idx];
-            const float* G = Rg + (i * K + idx) * 9; const float* of = a.offset + ((size_t)b * K + idx) * 3;
-            for (int r = 0; r < 3; ++r)
-                pos[(i * K + idx) * 3 + r] = ((G[r * 3] * of[0] + G[r * 3 + 1] * of[1]) + G[r * 3 + 2] * of[2]) + pos[(i * K + par) * 3 + r];
-        }
         float d = 0.f;
-        if (a.obs) {
-            const float* ob = a.obs + (size_t)b * a.ldobs;
-            for (int k = 0; k < K; ++k) {
-                for (int c = 0; c < 3; ++c) { float u = ob[k * 4 + c] - pos[(i * K + k) * 3 + c]; d += u * u; }
-                float u = ob[k * 4 + 3] - (rt[3 + k] + 1.0f) * 0.5f; d += u * u;
-            }
-        }
-        dist[i] = d;
+        if (a.obs) for (int k = 0; k < K; ++k) d += dk[threadIdx.x * K + k];
+        dist[threadIdx.x] = d;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -389,94 +449,116 @@ __global__ __launch_bounds__(256) void fk_kernel(FkArgs a) {
     }
 }
 
-// ---- prior step, middle phases in ONE workgroup (rollout latency, vis_generation.py:97-127 / hsvrnn_bvh.py:208-225) ----------
+// ---- prior step, middle phases in ONE workgroup per sample (rollout latency, vis_generation.py:97-127 / hsvrnn_bvh.py:208-225) ---
 // A prior step is a chain of dependent phases: h-phase -> distribution + sample -> decoder hidden layers -> heads -> forward
 // kinematics -> GRU.  The first and the last stream megabytes of weights and want the whole chip; the four in between touch
 // 128 + 128 + 87 KB of weights and a few hundred floats of state per sample: as separate launches each of them is a dispatch
-// round trip (~6 us) around ~2 us of work.  Here one 512-thread workgroup runs the four back to back with workgroup barriers,
-// state in LDS: a step is 3 dependent launches instead of 6.  Arithmetic identical to dist_rows / linear_rows / fk_kernel
-// (same dot-product order through dot_seg / wave_reduce): the fused step is bit-identical to the six-launch step.
+// round trip (~6 us) around ~2 us of work.  Here ONE 1024-thread workgroup per batch element runs the four back to back with
+// workgroup barriers, state in LDS: a step is 3 dependent launches instead of 6.
+// What makes one workgroup fast enough (round 2's version, 8 waves x 85 rows fetched a few at a time, took ~45 us: every batch of
+// rows was a dependent L2 round trip): the weights do not depend on the data, so EVERY weight row the workgroup will need in the
+// three matrix phases is requested in the first instructions of the kernel - 22 16-byte loads per lane, 88 registers - and the
+// phases then run from registers; a wavefront holds TWO rows per load (a 128-column row is 32 lanes x 4 floats: lanes 0-31 one row,
+// lanes 32-63 the other) and the per-row bias / noise / h-half values are preloaded the same way.  Arithmetic per row is
+// dot_seg's / wave_reduce's for n = 128 (((w0 x0 + w1 x1) + w2 x2) + w3 x3 per lane, xor-shuffle tree 16..1 - the tree's first step,
+// offset 32, adds the zeros of the idle half there): the fused step is bit-identical to the six-launch step.
 struct MidArgs {
     const float *hid_prior, *rh, *jh, *eps, *offset;            // [B][128] x3, [B][Z], [B][K][3]
     const float *w_p2, *b_p2, *w_root0, *w_joint0, *w_root2, *b_root2, *w_joint2, *b_joint2;
-    const int32_t *order, *parents;
+    const int32_t *order, *parents, *lvl_joint, *lvl_start; int nlevels;
     float *out_kp, *out_z; int ldkp, ldz;
     int B, K, Z, H;
 };
 
-// RW rows of one wave at a time: all their weight loads are issued before the first is consumed (a single workgroup has no other
-// parallelism to hide the L2 round trips behind).  Per row the arithmetic is dot_seg's for n = 128 (lanes 0..31 own 4 columns
-// each, ((w0 x0 + w1 x1) + w2 x2) + w3 x3, then the xor-shuffle tree): bit-identical to linear_rows / dist_rows.
-template <int NB, int RW, class RowW, class RowX, class Store>
-__device__ __forceinline__ void mid_rows(int rows, int wave, int lane, int B, RowW roww, RowX rowx, Store store) {
-    for (int r0 = wave * RW; r0 < rows; r0 += 8 * RW) {
-        f32x4 wv[RW];
+__device__ __forceinline__ float half_reduce(float v) {          // sum over the 32 lanes of this lane's half; every lane gets it
 #pragma unroll
-        for (int u = 0; u < RW; ++u) {
-            const int r = min(r0 + u, rows - 1);
-            wv[u] = lane < 32 ? *reinterpret_cast<const f32x4*>(roww(r) + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < RW; ++u) {
-            const int r = r0 + u;
-            float acc[NB];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                acc[i] = 0.f;
-                if (lane < 32) {
-                    const int bb = i < B ? i : B - 1;
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(rowx(r < rows ? r : rows - 1, bb) + lane * 4);
-                    acc[i] += ((wv[u][0] * xv[0] + wv[u][1] * xv[1]) + wv[u][2] * xv[2]) + wv[u][3] * xv[3];
-                }
-            }
-            wave_reduce(acc);
-            if (r < rows && lane < NB && lane < B) store(r, lane, pick(acc, lane));
-        }
-    }
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
 }
+__device__ __forceinline__ float dot4(const f32x4& w, const f32x4& x) { return ((w[0] * x[0] + w[1] * x[1]) + w[2] * x[2]) + w[3] * x[3]; }
 
-template <int NB>
-__global__ __launch_bounds__(512) void vrnn_prior_mid_kernel(MidArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_mu[NB * 128], s_sr[NB * 128], s_z[NB * 128], s_hr[NB * 128], s_hj[NB * 128], s_root[NB * 36], s_rot[NB * 192];
-    __shared__ float s_Rl[NB * 32 * 9], s_Rg[NB * 32 * 9], s_pos[NB * 32 * 3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int B = a.B, K = a.K, Z = a.Z, H = a.H;
-    // A. prior distribution parameters and the sample (Z = 128 latent dims: rows r -> mu, r + Z -> raw std)
-    mid_rows<NB, 8>(2 * Z, wave, lane, B,
-        [&](int r) { return a.w_p2 + (size_t)r * 128; },
-        [&](int, int b) { return a.hid_prior + (size_t)b * 128; },
-        [&](int r, int b, float v) { (r < Z ? s_mu : s_sr)[b * 128 + (r < Z ? r : r - Z)] = v + a.b_p2[r]; });
-    __syncthreads();
-    for (int t = tid; t < B * Z; t += 512) {
-        const int b = t / Z, j = t % Z;
-        const float sg = softplus(s_sr[b * 128 + j]) + 1e-4f;
-        const float z = s_mu[b * 128 + j] + a.eps[(size_t)b * Z + j] * sg;
-        s_z[b * 128 + j] = z;
-        a.out_z[(size_t)b * a.ldz + j] = z;
+#define MID_PAIRS 8        // row pairs per wavefront and phase: 16 waves x 8 pairs x 2 rows = 256 rows
+__global__ __launch_bounds__(1024) void vrnn_prior_mid_kernel(MidArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_z[128], s_hr[128], s_hj[128], s_root[36], s_rot[192];
+    __shared__ float s_Rl[32 * 9], s_Rg[32 * 9], s_pos[32 * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31, b = blockIdx.x;
+    const int K = a.K, Z = a.Z, H = a.H, R0 = 3 + K, J6 = 6 * K, rows_c = R0 + J6;
+    // ---- every weight row of the three matrix phases, requested up front ----------------------------------------------
+    f32x4 wa[MID_PAIRS], wb[MID_PAIRS], wc[MID_PAIRS];
+#pragma unroll
+    for (int u = 0; u < MID_PAIRS; ++u) {
+        const int p = wave * MID_PAIRS + u;                      // A: lower half row p (mu), upper half row p + Z (raw std)
+        wa[u] = *reinterpret_cast<const f32x4*>(a.w_p2 + (size_t)(p + half * Z) * 128 + l32 * 4);
+        // B: lower half root0 row p, upper half joint0 row p (the z-columns H .. H+Z of the first decoder layers)
+        wb[u] = *reinterpret_cast<const f32x4*>((half ? a.w_joint0 : a.w_root0) + (size_t)p * (H + Z) + H + l32 * 4);
+        // C: rows [0, R0) root / intensity head, [R0, R0 + J6) 6-D rotations (rows beyond: clamped, never stored).  The ADDRESS is
+        // selected, the load is unconditional: a conditional load is a branch, and hipcc drains every outstanding load at its join
+        const int r = min(p * 2 + half, rows_c - 1);
+        const float* pc = r < R0 ? a.w_root2 + (size_t)r * 128 : a.w_joint2 + (size_t)(r - R0) * 128;
+        wc[u] = *reinterpret_cast<const f32x4*>(pc + l32 * 4);
+    }
+    const f32x4 xh = *reinterpret_cast<const f32x4*>(a.hid_prior + (size_t)b * 128 + l32 * 4);
+    // per-row scalars: lane u (< MID_PAIRS) of each half finishes pair u of its wave (unconditional loads from clamped / selected
+    // addresses for the same reason; lanes >= MID_PAIRS read pair 0's values and never use them)
+    const int pl = wave * MID_PAIRS + (l32 < MID_PAIRS ? l32 : 0);
+    const float bias_a = a.b_p2[pl], bias_a2 = a.b_p2[pl + Z], epsv = a.eps[(size_t)b * Z + pl];
+    const float add_b = (half ? a.jh : a.rh)[(size_t)b * 128 + pl];
+    const int rl = min(pl * 2 + half, rows_c - 1);
+    const float bias_c = *(rl < R0 ? a.b_root2 + rl : a.b_joint2 + (rl - R0));
+    __shared__ FkTables tb;
+    fk_tables_load(tb, a.lvl_joint, a.lvl_start, a.parents, a.offset + (size_t)b * K * 3, K, a.nlevels, tid);
+    // ---- A. prior distribution parameters and the sample --------------------------------------------------------------
+    {
+        float mine = 0.f, other = 0.f;
+#pragma unroll
+        for (int u = 0; u < MID_PAIRS; ++u) {
+            const float v = half_reduce(dot4(wa[u], xh));
+            const float o = __shfl_xor(v, 32);
+            if (l32 == u) { mine = v; other = o; }
+        }
+        if (!half && l32 < MID_PAIRS) {
+            const int p = wave * MID_PAIRS + l32;
+            const float mu = mine + bias_a, sraw = other + bias_a2;
+            const float sg = softplus(sraw) + 1e-4f;
+            const float z = mu + epsv * sg;
+            s_z[p] = z;
+            a.out_z[(size_t)b * a.ldz + p] = z;
+        }
     }
     __syncthreads();
-    // B. decoder hidden layers: z-half of the first layers + the h-half (and bias) the h-phase left in rh / jh
-    mid_rows<NB, 8>(256, wave, lane, B,
-        [&](int r) { return (r < 128 ? a.w_root0 : a.w_joint0) + (size_t)(r & 127) * (H + Z) + H; },
-        [&](int, int b) { return s_z + b * 128; },
-        [&](int r, int b, float v) {
-            const int rr = r & 127;
-            (r < 128 ? s_hr : s_hj)[b * 128 + rr] = lrelu(v + (r < 128 ? a.rh : a.jh)[(size_t)b * 128 + rr], 0.01f);
-        });
+    // ---- B. decoder hidden layers: z-half of the first layers + the h-half (and bias) the h-phase left in rh / jh -------
+    {
+        const f32x4 xz = *reinterpret_cast<const f32x4*>(s_z + l32 * 4);
+        float mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < MID_PAIRS; ++u) {
+            const float v = half_reduce(dot4(wb[u], xz));
+            if (l32 == u) mine = v;
+        }
+        if (l32 < MID_PAIRS) (half ? s_hj : s_hr)[wave * MID_PAIRS + l32] = lrelu(mine + add_b, 0.01f);
+    }
     __syncthreads();
-    // C. heads: root / intensity (tanh) and 6-D rotations
-    const int R0 = 3 + K, J6 = 6 * K;
-    mid_rows<NB, 8>(R0 + J6, wave, lane, B,
-        [&](int r) { return r < R0 ? a.w_root2 + (size_t)r * 128 : a.w_joint2 + (size_t)(r - R0) * 128; },
-        [&](int r, int b) { return (r < R0 ? s_hr : s_hj) + b * 128; },
-        [&](int r, int b, float v) {
-            if (r < R0) s_root[b * 36 + r] = tanhf(v + a.b_root2[r]); else s_rot[b * 192 + r - R0] = v + a.b_joint2[r - R0];
-        });
+    // ---- C. heads: root / intensity (tanh) and 6-D rotations ---------------------------------------------------------------
+    {
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(s_hr + l32 * 4);
+        const f32x4 xj = *reinterpret_cast<const f32x4*>(s_hj + l32 * 4);
+        float mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < MID_PAIRS; ++u) {
+            const int r = (wave * MID_PAIRS + u) * 2 + half;
+            const float v = half_reduce(dot4(wc[u], r < R0 ? xr : xj));
+            if (l32 == u) mine = v;
+        }
+        if (l32 < MID_PAIRS) {
+            const int r = (wave * MID_PAIRS + l32) * 2 + half;
+            if (r < R0) s_root[r] = tanhf(mine + bias_c);
+            else if (r < rows_c) s_rot[r - R0] = mine + bias_c;
+        }
+    }
     __syncthreads();
-    // D. forward kinematics (fk_kernel with S = 1, no observation)
-    for (int t = tid; t < B * K; t += 512) {
-        const int b = t / K, k = t % K;
-        const float* p = s_rot + b * 192 + k * 6;
+    // ---- D. forward kinematics (fk_kernel with S = 1, no observation) ----------------------------------------------------
+    if (tid < K) {
+        const float* p = s_rot + tid * 6;
         float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
         float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
         x0 /= nx; x1 /= nx; x2 /= nx;
@@ -484,35 +566,15 @@ __global__ __launch_bounds__(512) void vrnn_prior_mid_kernel(MidArgs a) {
         float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
         z0 /= nz; z1 /= nz; z2 /= nz;
         float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
-        float* R = s_Rl + (b * 32 + k) * 9;
+        float* R = s_Rl + tid * 9;
         R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
     }
     __syncthreads();
-    if (tid < B) {
-        const int b = tid;
-        const float* rt = s_root + b * 36;
-        float* Rl = s_Rl + b * 32 * 9; float* Rg = s_Rg + b * 32 * 9; float* pos = s_pos + b * 32 * 3;
-        const int root = a.order[0];
-        for (int e = 0; e < 9; ++e) Rg[root * 9 + e] = Rl[root * 9 + e];
-        pos[root * 3 + 0] = rt[0]; pos[root * 3 + 1] = rt[1]; pos[root * 3 + 2] = rt[2];
-        for (int o = 1; o < K; ++o) {
-            const int idx = a.order[o], par = a.parents[idx];
-            const float* P = Rg + par * 9; const float* L = Rl + idx * 9;
-            float* G = Rg + idx * 9;
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) G[r * 3 + c] = (P[r * 3] * L[c] + P[r * 3 + 1] * L[3 + c]) + P[r * 3 + 2] * L[6 + c];
-        }
-        for (int o = 1; o < K; ++o) {
-            const int idx = a.order[o], par = a.parents[idx];
-            const float* G = Rg + idx * 9; const float* of = a.offset + ((size_t)b * K + idx) * 3;
-            for (int r = 0; r < 3; ++r)
-                pos[idx * 3 + r] = ((G[r * 3] * of[0] + G[r * 3 + 1] * of[1]) + G[r * 3 + 2] * of[2]) + pos[par * 3 + r];
-        }
-    }
-    __syncthreads();
-    for (int t = tid; t < B * K * 4; t += 512) {
-        const int b = t / (K * 4), u = t % (K * 4), k = u >> 2, c = u & 3;
-        a.out_kp[(size_t)b * a.ldkp + u] = c < 3 ? s_pos[(b * 32 + k) * 3 + c] : (s_root[b * 36 + 3 + k] + 1.0f) * 0.5f;
+    // (root row read from LDS: B = 1, b = 0 in fk_levels' indexing of `root`)
+    fk_levels(tb, a.nlevels, s_Rl, s_Rg, s_pos, s_root, 36, K, 1, 0, 0, tid, 1024);
+    if (tid < K * 4) {
+        const int k = tid >> 2, c = tid & 3;
+        a.out_kp[(size_t)b * a.ldkp + tid] = c < 3 ? s_pos[k * 3 + c] : (s_root[3 + k] + 1.0f) * 0.5f;
     }
 }
 
@@ -820,9 +882,8 @@ void add_job(LinJobs& J, const LinearW& L, int col0, const float* xa, int na, in
 
 int pick_nb(int batch) { return batch >= 8 ? 8 : (batch >= 4 ? 4 : (batch >= 2 ? 2 : 1)); }
 
-// prior steps of a rollout: 0 (default) six dependent launches, 1 three (vrnn_prior_mid_kernel).  Measured A/B (tools/time_rollout.py,
-// bit-identical outputs): 39.4 vs 60.6 us/step at B = 1, 43.2 vs 103.1 at B = 3 - one workgroup walking 680 weight rows and the serial
-// kinematic chain is slower than three wide launches, so the fused form stays off.
+// prior steps of a rollout (nm_ls().vrnn_mid, NM355_VRNN_MID): 1 (default) three dependent launches (h-phase, vrnn_prior_mid_kernel,
+// GRU), 0 six.  A/B: profiles/r03_rollout_ab.txt (tools/time_rollout.py, bit-identical outputs).
 #define NM_GEMM_MIN_BATCH 128
 
 // batches of >= 128 rows take the MFMA GEMM (every input segment of this model is a multiple of 32 columns wide)
@@ -922,17 +983,16 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         add_job(J, hh, 0, io.h, H, io.ldh, nullptr, 0, 0, true, nullptr, 0, 1, sb.gh, 3 * H, 0, B);
         if ((rc = launch_jobs(J, s))) return rc;
     }
-    if (!post && B <= 4 && !io.tape && !io.out_R && !io.best && !io.kl && !io.rec && nm_ls().vrnn_mid && K <= 32 && Z == 128) {
-        // 2-4 in one workgroup (prior steps of a rollout): see vrnn_prior_mid_kernel
+    if (!post && B <= 64 && !io.tape && !io.out_R && !io.best && !io.kl && !io.rec && nm_ls().vrnn_mid && K % 8 == 0 && K <= 32 && Z == 128) {
+        // 2-4 in one workgroup per batch element (prior steps of a rollout): see vrnn_prior_mid_kernel
         MidArgs a;
         a.hid_prior = sb.hid_prior; a.rh = sb.rh; a.jh = sb.jh; a.eps = io.eps; a.offset = io.offset;
         a.w_p2 = w.prior2.w; a.b_p2 = w.prior2.b; a.w_root0 = w.root0.w; a.w_joint0 = w.joint0.w;
         a.w_root2 = w.root2.w; a.b_root2 = w.root2.b; a.w_joint2 = w.joint2.w; a.b_joint2 = w.joint2.b;
-        a.order = w.order; a.parents = w.parents;
+        a.order = w.order; a.parents = w.parents; a.lvl_joint = w.lvl_joint; a.lvl_start = w.lvl_start; a.nlevels = w.nlevels;
         a.out_kp = io.out_kp; a.ldkp = io.ldkp; a.out_z = io.out_z; a.ldz = io.ldz;
         a.B = B; a.K = K; a.Z = Z; a.H = H;
-        if (B == 1) hipLaunchKernelGGL((vrnn_prior_mid_kernel<1>), dim3(1), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((vrnn_prior_mid_kernel<4>), dim3(1), dim3(512), 0, s, a);
+        hipLaunchKernelGGL(vrnn_prior_mid_kernel, dim3(B), dim3(1024), 0, s, a);
         if ((rc = nm_check_hip(hipGetLastError(), "vrnn_prior_mid launch"))) return rc;
         if (io.hout && (rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s, nullptr, sb.gi))) return rc;
         return NM_OK;
@@ -963,7 +1023,7 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
     {   // 4. forward kinematics, best-of-S, KL
         FkArgs a;
         a.root = sb.rootout; a.ldr = 3 + K; a.rot = sb.rot; a.offset = io.offset; a.obs = io.obs; a.ldobs = io.ldobs; a.z = sb.z;
-        a.order = w.order; a.parents = w.parents;
+        a.order = w.order; a.parents = w.parents; a.lvl_joint = w.lvl_joint; a.lvl_start = w.lvl_start; a.nlevels = w.nlevels;
         const bool kl = post && io.want_prior && io.kl;
         a.qmu = kl ? sb.qmu : nullptr; a.qsig = sb.qsig; a.pmu = sb.pmu; a.psig = sb.psig;
         a.out_kp = io.out_kp; a.ldkp = io.ldkp; a.out_z = io.out_z; a.ldz = io.ldz; a.out_R = io.out_R; a.ldR = io.ldR;
@@ -972,7 +1032,7 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         a.hr = sb.hr; a.hj = sb.hj; a.eps = io.eps;
         a.t_hr = a.t_hj = a.t_raw = a.t_rot6 = a.t_Rl = a.t_Rg = a.t_eps = nullptr;
         if (io.tape) { a.t_hr = io.tape->hr; a.t_hj = io.tape->hj; a.t_raw = io.tape->raw; a.t_rot6 = io.tape->rot6; a.t_Rl = io.tape->Rl; a.t_Rg = io.tape->Rg; a.t_eps = io.tape->eps; }
-        size_t lds = ((size_t)S * K * 21 + S) * sizeof(float);
+        size_t lds = ((size_t)S * K * 22 + S) * sizeof(float);
         hipLaunchKernelGGL(fk_kernel, dim3(B), dim3(256), lds, s, a);
         if ((rc = nm_check_hip(hipGetLastError(), "fk launch"))) return rc;
     }
@@ -990,7 +1050,7 @@ int ready(nm_ctx* c, const char* who, bool need_tree) {
 }
 
 int max_fk_lds(nm_ctx* c, int S) {
-    size_t lds = ((size_t)S * c->cfg.nkeypoints * 21 + S) * sizeof(float);
+    size_t lds = ((size_t)S * c->cfg.nkeypoints * 22 + S) * sizeof(float);
     if (lds > 60 * 1024) { nm_set_error("vrnn: S=%d samples exceed the FK kernel's LDS budget", S); return NM_ERR_UNSUPPORTED; }
     return NM_OK;
 }
@@ -1023,9 +1083,20 @@ int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) { 
         seen[k] = 1;
     }
     c->vrnn.parents_h.assign(parents, parents + K); c->vrnn.order_h.assign(order, order + K);
-    rc = nm_check_hip(hipMemcpyAsync(c->vrnn.parents, c->vrnn.parents_h.data(), K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream), "set_tree copy");
-    if (rc) return rc;
-    rc = nm_check_hip(hipMemcpyAsync(c->vrnn.order, c->vrnn.order_h.data(), K * sizeof(int32_t), hipMemcpyHostToDevice, c->stream), "set_tree copy");
+    // joints grouped by depth (level 0 = the root) for the level-parallel kinematic chain: a joint needs only its parent
+    std::vector<int32_t> depth(K, 0), table(4 * K + 2, 0);
+    int nlev = 1;
+    for (int i = 1; i < K; ++i) { const int k = order[i]; depth[k] = depth[parents[k]] + 1; nlev = std::max(nlev, depth[k] + 1); }
+    int32_t* lj = table.data() + 2 * K; int32_t* ls = table.data() + 3 * K;
+    int n = 0;
+    for (int l = 0; l < nlev; ++l) { ls[l] = n; for (int i = 0; i < K; ++i) if (depth[order[i]] == l) lj[n++] = order[i]; }
+    ls[nlev] = n;
+    std::copy(parents, parents + K, table.begin()); std::copy(order, order + K, table.begin() + K);
+    c->vrnn.nlevels = nlev;
+    c->vrnn.tree_epoch++;
+    // (pageable host memory: the copy has left `table` when hipMemcpyAsync returns; the sync orders it before later launches on
+    // other streams)
+    rc = nm_check_hip(hipMemcpyAsync(c->vrnn.parents, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream), "set_tree copy");
     if (rc) return rc;
     rc = nm_check_hip(hipStreamSynchronize(c->stream), "set_tree sync");
     if (rc) return rc;
@@ -1274,6 +1345,175 @@ int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grad
     return nm_check_hip(hipGetLastError(), "adam_multi launch");
 }
 
+// ---- rollouts: nm_vrnn_generate (hsvrnn_bvh.py:158-234) and nm_vrnn_rollout (the prior loop of vis_generation.py:117-127) ------
+// A rollout is hundreds of dependent ~3 us launches; enqueued one by one the host (3-5 us per launch) is the bottleneck.  For the
+// small batches of the latency path the whole step sequence is therefore captured ONCE per (kind, B, Tcond, Ttot, S) into a HIP
+// graph (stream capture of the very same launch code on the ctx-owned side stream) and replayed with one hipGraphLaunch.  The graph
+// works on buffers it owns; a call copies its inputs in and its outputs out (device-to-device, a few KB).  A graph is dropped when
+// the weight buffers were re-allocated or the tree changed (epochs below); weight VALUES may change freely (same buffers).
+struct RolloutBufs {
+    StepBufs sb;
+    float *kp_cond, *eps_post, *eps_prior, *out_cond, *out_gen, *h_in, *offset, *hbuf[2], *zbuf;
+};
+struct RolloutGraph {
+    int kind, B, Tcond, Ttot, S;
+    uint64_t wepoch, tepoch;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    char* base = nullptr;
+    RolloutBufs rb; int cur = 0;
+};
+struct GraphCache { std::vector<RolloutGraph*> items; bool broken = false; };
+
+static void free_rollout_graph(RolloutGraph* g) {
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->base) (void)hipFree(g->base);
+    delete g;
+}
+}  // extern "C"
+void nm_vrnn_free_graphs(nm_ctx* c) {
+    GraphCache* gc = static_cast<GraphCache*>(c->vgraphs);
+    if (!gc) return;
+    for (RolloutGraph* g : gc->items) free_rollout_graph(g);
+    delete gc;
+    c->vgraphs = nullptr;
+}
+extern "C" {
+
+static size_t rollout_floats(int B, int Tcond, int Ttot, int S, int K, int Z, int H) {
+    const size_t S4 = (size_t)K * 4, Tg = Ttot - Tcond;
+    return (size_t)B * (4 * 128 + 3 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K) + (B >= NM_GEMM_MIN_BATCH ? (size_t)B * 3 * H : 0)
+         + (size_t)B * Tcond * S4 * 2 + (size_t)Tcond * S * B * Z + Tg * B * Z + (size_t)B * Tg * S4 + (size_t)B * K * 3 + 3 * (size_t)B * H + (size_t)B * Z
+         + 64 * 32;          // (256-byte alignment of each of the ~28 pieces)
+}
+static RolloutBufs carve_rollout(Arena& ws, int B, int Tcond, int Ttot, int S, int K, int Z, int H) {
+    RolloutBufs r;
+    const size_t S4 = (size_t)K * 4, Tg = Ttot - Tcond;
+    r.sb = alloc_step(ws, B, S, K, Z, H);
+    r.kp_cond = ws.f((size_t)B * Tcond * S4 + 1); r.eps_post = ws.f((size_t)Tcond * S * B * Z + 1); r.eps_prior = ws.f(Tg * B * Z + 1);
+    r.out_cond = ws.f((size_t)B * Tcond * S4 + 1); r.out_gen = ws.f((size_t)B * Tg * S4 + 1);
+    r.h_in = ws.f((size_t)B * H); r.offset = ws.f((size_t)B * K * 3);
+    r.hbuf[0] = ws.f((size_t)B * H); r.hbuf[1] = ws.f((size_t)B * H); r.zbuf = ws.f((size_t)B * Z);
+    return r;
+}
+
+// the step sequence itself, on c->stream.  kind 0: generate (offsets from the conditioning keypoints, h from init_kypt_rnn_state,
+// Tcond posterior steps, then prior steps); kind 1: prior steps only, from the given state r.h_in and offsets r.offset.
+static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, int Ttot, int S, int* cur_out) {
+    const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4, Tg = Ttot - Tcond;
+    int rc;
+    const float* h = r.h_in;
+    int nxt = 0;                        // hbuf the next step writes
+    if (kind == 0) {
+        if ((rc = nm_vrnn_offsets(c, r.kp_cond, B, Tcond, r.offset))) return rc;
+        hipLaunchKernelGGL(broadcast_rows_kernel, dim3((H * B + 255) / 256), dim3(256), 0, c->stream, c->vrnn.h0, H, r.hbuf[0], H, B);
+        h = r.hbuf[0]; nxt = 1;
+    }
+    for (int t = 0; t < Ttot; ++t) {
+        StepIO io;
+        const bool post = t < Tcond;
+        io.h = h; io.ldh = H;
+        io.obs = post ? r.kp_cond + (size_t)t * S4 : nullptr; io.ldobs = Tcond * S4;
+        io.eps = post ? r.eps_post + (size_t)t * S * B * Z : r.eps_prior + (size_t)(t - Tcond) * B * Z;
+        io.offset = r.offset;
+        io.out_kp = post ? r.out_cond + (size_t)t * S4 : r.out_gen + (size_t)(t - Tcond) * S4; io.ldkp = (post ? Tcond : Tg) * S4;
+        io.out_z = r.zbuf; io.ldz = Z; io.out_R = nullptr; io.ldR = 0;
+        io.best = nullptr; io.ldbest = 0; io.kl = nullptr; io.rec = nullptr; io.ldstat = 0;
+        io.hout = r.hbuf[nxt]; io.ldho = H; io.want_prior = false;
+        if ((rc = vrnn_step(c, r.sb, io, B, S))) return rc;
+        h = io.hout; nxt ^= 1;
+    }
+    *cur_out = nxt ^ 1;                 // the hbuf holding the last state
+    return nm_check_hip(hipGetLastError(), "rollout launches");
+}
+
+static int copy_dd(float* dst, const float* src, size_t n, hipStream_t s, const char* what) {
+    if (!n || !dst || !src) return NM_OK;
+    return nm_check_hip(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s), what);
+}
+
+// kind 0 / 1 as above; user pointers may be null where the kind does not use them
+static int rollout_impl(nm_ctx* c, int kind, const float* kp_cond, const float* eps_post, const float* eps_prior, const float* h_in,
+                        const float* offset_in, int B, int Tcond, int Ttot, int S, float* out_cond, float* out_gen, float* h_last) {
+    const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4, Tg = Ttot - Tcond;
+    int rc;
+    const size_t n_kc = (size_t)B * Tcond * S4, n_ep = (size_t)Tcond * S * B * Z, n_er = (size_t)Tg * B * Z, n_og = (size_t)B * Tg * S4;
+    GraphCache* gc = static_cast<GraphCache*>(c->vgraphs);
+    const bool want_graph = nm_ls().vrnn_graph && B <= 64 && !(gc && gc->broken);
+    if (want_graph) {
+        if (!gc) { gc = new GraphCache(); c->vgraphs = gc; }
+        RolloutGraph* g = nullptr;
+        for (size_t i = 0; i < gc->items.size(); ++i) {
+            RolloutGraph* it = gc->items[i];
+            if (it->wepoch != c->weights_epoch || it->tepoch != c->vrnn.tree_epoch) {       // stale: pointers / level count baked in
+                (void)hipStreamSynchronize(c->stream);
+                free_rollout_graph(it); gc->items.erase(gc->items.begin() + i); --i; continue;
+            }
+            if (it->kind == kind && it->B == B && it->Tcond == Tcond && it->Ttot == Ttot && it->S == S) g = it;
+        }
+        if (!g) {
+            if (gc->items.size() >= 16) {                      // bounded cache: drop the oldest entry
+                (void)hipStreamSynchronize(c->stream);
+                free_rollout_graph(gc->items.front()); gc->items.erase(gc->items.begin());
+            }
+            g = new RolloutGraph();
+            g->kind = kind; g->B = B; g->Tcond = Tcond; g->Ttot = Ttot; g->S = S; g->wepoch = c->weights_epoch; g->tepoch = c->vrnn.tree_epoch;
+            const size_t bytes = rollout_floats(B, Tcond, Ttot, S, K, Z, H) * sizeof(float);
+            bool ok = hipMalloc(reinterpret_cast<void**>(&g->base), bytes) == hipSuccess;
+            if (ok) {
+                Arena ar; ar.base = g->base; ar.cap = bytes;
+                g->rb = carve_rollout(ar, B, Tcond, Ttot, S, K, Z, H);
+                ok = !ar.overflow;
+            }
+            if (ok) {
+                // capture the launch sequence on the side stream (a capture cannot run on the legacy default stream, which the caller's
+                // stream may be); relaxed mode: other threads of the process (torch's allocator) stay free to call the runtime
+                hipStream_t main = c->stream;
+                ok = hipStreamSynchronize(c->stream2) == hipSuccess && hipStreamBeginCapture(c->stream2, hipStreamCaptureModeRelaxed) == hipSuccess;
+                if (ok) {
+                    c->stream = c->stream2;
+                    const int r2 = rollout_steps(c, g->rb, kind, B, Tcond, Ttot, S, &g->cur);
+                    c->stream = main;
+                    ok = hipStreamEndCapture(c->stream2, &g->graph) == hipSuccess && r2 == NM_OK && g->graph;
+                }
+                if (ok) ok = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) == hipSuccess;
+            }
+            if (!ok) {                                          // no graph on this runtime: the eager launch sequence below is the same work
+                (void)hipGetLastError();
+                free_rollout_graph(g); g = nullptr; gc->broken = true;
+            } else gc->items.push_back(g);
+        }
+        if (g) {
+            hipStream_t s = c->stream;
+            RolloutBufs& r = g->rb;
+            if ((rc = copy_dd(r.kp_cond, kp_cond, n_kc, s, "rollout: in"))) return rc;
+            if ((rc = copy_dd(r.eps_post, eps_post, n_ep, s, "rollout: in"))) return rc;
+            if ((rc = copy_dd(r.eps_prior, eps_prior, n_er, s, "rollout: in"))) return rc;
+            if (kind == 1) {
+                if ((rc = copy_dd(r.h_in, h_in, (size_t)B * H, s, "rollout: in"))) return rc;
+                if ((rc = copy_dd(r.offset, offset_in, (size_t)B * K * 3, s, "rollout: in"))) return rc;
+            }
+            if ((rc = nm_check_hip(hipGraphLaunch(g->exec, s), "rollout: hipGraphLaunch"))) return rc;
+            if ((rc = copy_dd(out_cond, r.out_cond, n_kc, s, "rollout: out"))) return rc;
+            if ((rc = copy_dd(out_gen, r.out_gen, n_og, s, "rollout: out"))) return rc;
+            return copy_dd(h_last, Ttot > 0 ? r.hbuf[g->cur] : r.h_in, (size_t)B * H, s, "rollout: h_last");
+        }
+    }
+    // eager: the same launch sequence straight onto the ctx stream, working on the caller's buffers
+    if ((rc = nm_ctx_reserve(c, rollout_floats(B, 0, 0, S, K, Z, H) * sizeof(float) + 4096))) return rc;
+    c->ws.release(0);
+    RolloutBufs r;
+    r.sb = alloc_step(c->ws, B, S, K, Z, H);
+    r.hbuf[0] = c->ws.f((size_t)B * H); r.hbuf[1] = c->ws.f((size_t)B * H); r.zbuf = c->ws.f((size_t)B * Z);
+    r.offset = kind == 0 ? c->ws.f((size_t)B * K * 3) : const_cast<float*>(offset_in);
+    if (c->ws.overflow) { nm_set_error("vrnn rollout: workspace overflow"); return NM_ERR_STATE; }
+    r.kp_cond = const_cast<float*>(kp_cond); r.eps_post = const_cast<float*>(eps_post); r.eps_prior = const_cast<float*>(eps_prior);
+    r.out_cond = out_cond; r.out_gen = out_gen; r.h_in = const_cast<float*>(h_in);
+    int cur = 0;
+    if ((rc = rollout_steps(c, r, kind, B, Tcond, Ttot, S, &cur))) return rc;
+    return copy_dd(h_last, Ttot > 0 ? r.hbuf[cur] : h_in, (size_t)B * H, c->stream, "rollout: h_last");
+}
+
 int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_post, const float* eps_prior, int32_t B,
                      int32_t Tcond, int32_t Ttot, int32_t S, float* out_cond, float* out_gen, float* h_last) { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_generate", true);
@@ -1282,34 +1522,15 @@ int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_po
         nm_set_error("vrnn_generate: bad argument"); return NM_ERR_ARG;
     }
     if ((rc = max_fk_lds(c, S))) return rc;
-    const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4, Tg = Ttot - Tcond;
-    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z + K * 3 + 2 * H + Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
-    if ((rc = nm_ctx_reserve(c, need))) return rc;
-    c->ws.release(0);
-    StepBufs sb = alloc_step(c->ws, B, S, K, Z, H);
-    float* offset = c->ws.f((size_t)B * K * 3);
-    float* hbuf[2] = {c->ws.f((size_t)B * H), c->ws.f((size_t)B * H)};
-    float* zbuf = c->ws.f((size_t)B * Z);
-    if (c->ws.overflow) { nm_set_error("vrnn_generate: workspace overflow"); return NM_ERR_STATE; }
-    if ((rc = nm_vrnn_offsets(c, keypoints_cond, B, Tcond, offset))) return rc;
-    hipLaunchKernelGGL(broadcast_rows_kernel, dim3((H * B + 255) / 256), dim3(256), 0, c->stream, c->vrnn.h0, H, hbuf[0], H, B);
-    int cur = 0;
-    for (int t = 0; t < Ttot; ++t) {
-        StepIO io;
-        const bool post = t < Tcond;
-        io.h = hbuf[cur]; io.ldh = H;
-        io.obs = post ? keypoints_cond + (size_t)t * S4 : nullptr; io.ldobs = Tcond * S4;
-        io.eps = post ? eps_post + (size_t)t * S * B * Z : eps_prior + (size_t)(t - Tcond) * B * Z;
-        io.offset = offset;
-        io.out_kp = post ? out_cond + (size_t)t * S4 : out_gen + (size_t)(t - Tcond) * S4; io.ldkp = (post ? Tcond : Tg) * S4;
-        io.out_z = zbuf; io.ldz = Z; io.out_R = nullptr; io.ldR = 0;
-        io.best = nullptr; io.ldbest = 0; io.kl = nullptr; io.rec = nullptr; io.ldstat = 0;
-        io.hout = hbuf[cur ^ 1]; io.ldho = H; io.want_prior = false;
-        if ((rc = vrnn_step(c, sb, io, B, S))) return rc;
-        cur ^= 1;
-    }
-    if (h_last) rc = nm_check_hip(hipMemcpyAsync(h_last, hbuf[cur], (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "generate: h_last");
-    return rc;
+    return rollout_impl(c, 0, keypoints_cond, eps_post, eps_prior, nullptr, nullptr, B, Tcond, Ttot, S, out_cond, out_gen, h_last);
+}
+
+int nm_vrnn_rollout(nm_ctx* c, const float* h_in, const float* offset, const float* eps, int32_t B, int32_t T, float* kp_out, float* h_out) { NmScope nm_scope_(c);
+    int rc = ready(c, "vrnn_rollout", true);
+    if (rc) return rc;
+    if (!h_in || !offset || !eps || !kp_out || B <= 0 || T <= 0) { nm_set_error("vrnn_rollout: bad argument"); return NM_ERR_ARG; }
+    if ((rc = max_fk_lds(c, 1))) return rc;
+    return rollout_impl(c, 1, nullptr, nullptr, eps, h_in, offset, B, 0, T, 1, nullptr, kp_out, h_out);
 }
 
 int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* kp_obs, const float* offset, const float* eps,
@@ -1418,11 +1639,11 @@ int nm_vrnn_fk(nm_ctx* c, const float* dec_in, const float* offset, int32_t B, f
     if ((rc = launch_jobs(J2, c->stream))) return rc;
     FkArgs a;
     a.root = rootout; a.ldr = 3 + K; a.rot = rot; a.offset = offset; a.obs = nullptr; a.ldobs = 0; a.z = nullptr;
-    a.order = w.order; a.parents = w.parents; a.qmu = a.qsig = a.pmu = a.psig = nullptr;
+    a.order = w.order; a.parents = w.parents; a.lvl_joint = w.lvl_joint; a.lvl_start = w.lvl_start; a.nlevels = w.nlevels; a.qmu = a.qsig = a.pmu = a.psig = nullptr;
     a.out_kp = kp; a.ldkp = K * 4; a.out_z = nullptr; a.ldz = 0; a.out_R = R; a.ldR = K * 9;
     a.best = nullptr; a.ldbest = 0; a.kl = nullptr; a.rec = nullptr; a.ldstat = 0; a.K = K; a.S = 1; a.B = B; a.Z = Z;
     a.hr = a.hj = a.eps = nullptr; a.t_hr = a.t_hj = a.t_raw = a.t_rot6 = a.t_Rl = a.t_Rg = a.t_eps = nullptr;
-    size_t lds = ((size_t)K * 21 + 1) * sizeof(float);
+    size_t lds = ((size_t)K * 22 + 1) * sizeof(float);
     hipLaunchKernelGGL(fk_kernel, dim3(B), dim3(256), lds, c->stream, a);
     return nm_check_hip(hipGetLastError(), "fk launch");
 }

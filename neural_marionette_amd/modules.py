@@ -497,6 +497,25 @@ class HSVRNNBVH(nn.Module):
                  int(SAMPLE_NUM), _lib.ptr(kp), _lib.ptr(z), _lib.ptr(hn))
         return kp, z, hn
 
+    def rollout(self, h, offset, eps):
+        """The prior loop of vis_generation.py:117-127 in one library call (nm_vrnn_rollout: a captured HIP graph of three
+        launches per step for small batches): h (B,H), offset (B,K,3,1), eps (T,B,Z) -> keypoints (B,T,K,4), h_T (B,H)."""
+        eng = self._eng()
+        ctx = eng.ready()
+        self._ensure_tree(None, ctx)
+        dev = ctx.device
+        hh = _f32(h, dev)
+        B, K = int(hh.shape[0]), self.nkeypoints
+        off = _f32(offset.reshape(B, K, 3), dev)
+        e = _f32(eps, dev)
+        T = int(e.shape[0])
+        if tuple(e.shape) != (T, B, self.nlatent_kypt):
+            raise ValueError(f"eps must be (T,{B},{self.nlatent_kypt}), got {tuple(e.shape)}")
+        kp = torch.empty(B, T, K, 4, device=dev)
+        hn = torch.empty_like(hh)
+        eng.call("nm_vrnn_rollout", _lib.ptr(hh), _lib.ptr(off), _lib.ptr(e), B, T, _lib.ptr(kp), _lib.ptr(hn))
+        return kp, hn
+
     def nearest_row(self, rows, target):
         """Index (python int) of the row of ``rows`` (B,D) nearest to ``target`` ((D,) or (B,D)) in squared L2 —
         the sample selection of the reference's demo loops (vis_generation.py:109-110)."""
@@ -589,12 +608,8 @@ class NeuralMarionette(nn.Module):
             cond.append(kp[0, t])
         h = h.expand(S, -1).contiguous()
         off = offset.expand(S, -1, -1, -1).contiguous()
-        gen = []
-        for t in range(Tgen):
-            kps, _, h = d.step(h, off, e_prior[t])
-            gen.append(kps.view(S, K, 4))
+        gen_k = d.rollout(h, off, e_prior)[0].transpose(0, 1)[None]          # (1, Tgen, S, K, 4)
         cond_k = torch.stack(cond, 0)[None]
-        gen_k = torch.stack(gen, 0)[None]
         full = torch.cat([cond_k.expand(S, -1, -1, -1), gen_k[0].transpose(0, 1)], dim=1).contiguous()
         ff = det["first_feature"].expand(S, -1, -1, -1, -1).contiguous()
         fr = cond_voxel[None, 0].to(dev).expand(S, -1, -1, -1, -1).contiguous()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 5: prior rollout latency (Tcond = 5 posterior steps + 64 prior steps), B = 1 and 3.
-NM355_VRNN_MID=0 runs a prior step as six dependent launches, 1 (default) as three (vrnn_prior_mid_kernel).
+NM355_VRNN_MID=0 runs a prior step as six dependent launches, 1 (default) as three (vrnn_prior_mid_kernel);
+NM355_VRNN_GRAPH=0 enqueues the launches one by one, 1 (default) replays the captured HIP graph.
 usage: time_rollout.py <out.pt> [compare.pt]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +28,7 @@ for B in (1, 3):
         out = d.generate(kpc, aff, Ttot=Tt, Tcond=Tc, eps_post=e_post, eps_prior=e_prior)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     ts.sort()
-    print("MID=%s B=%d: 69-step generate median %.3f ms = %.1f us/step" % (os.environ.get("NM355_VRNN_MID", "1"), B, ts[10] * 1e3, ts[10] * 1e6 / Tt))
+    print("MID=%s GRAPH=%s B=%d: 69-step generate median %.3f ms = %.1f us/step (min %.1f)" % (os.environ.get("NM355_VRNN_MID", "1"), os.environ.get("NM355_VRNN_GRAPH", "1"), B, ts[10] * 1e3, ts[10] * 1e6 / Tt, ts[0] * 1e6 / Tt))
     res[B] = out["keypoints_gen"].cpu()
 torch.save(res, sys.argv[1])
 if len(sys.argv) > 2:
