@@ -40,6 +40,11 @@ struct TensorRef {
     const float* shift;   // [N][C] or nullptr
     float slope;          // leaky-relu slope applied after the affine; 1.0f => none
     int N, D, H, W, C;
+    // Brick-sparse tensor (the first layer's output in inference, nm_conv.hip "sparse first layer"): brickmap[n][4x8x8 brick] == 0
+    // means the brick was not written to p and equals the frame-independent tensor `alt` ([D][H][W][C], no frame stride) there.
+    // Only the k2 s2 split-fp16 pool kernel reads such tensors; every other launcher rejects them.
+    const float* alt = nullptr;
+    const unsigned char* brickmap = nullptr;
 };
 
 struct ConvGeom {
@@ -71,8 +76,8 @@ struct NmLaunchState {
     std::vector<hipEvent_t> event_pool;
     unsigned* nf_flag = nullptr;           // sticky device word gn_finalize ORs a 1 into (null: no reporting)
     // A/B and diagnostic switches (NM355_SUPERTILE, _SMALL16, _KSPLIT, _OCC16, _POOL16, _F16P2, _F16P, _WGRAD_TR, _UP2C, _UP2C_DIAG,
-    // _VRNN_MID, _VRNN_GEMM, _VRNN_GRAPH)
-    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, wgrad_tr, up2c, up2c_diag, vrnn_mid, vrnn_gemm, vrnn_graph;
+    // _VRNN_MID, _VRNN_GEMM, _VRNN_GRAPH, _SPARSE_FIRST)
+    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, wgrad_tr, up2c, up2c_diag, vrnn_mid, vrnn_gemm, vrnn_graph, sparse_first, gn_diag;
     NmLaunchState();
 };
 NmLaunchState& nm_ls();        // the state of the context whose ABI call runs on this thread
@@ -108,7 +113,9 @@ int nm_launch_pack_jobs(const NmPackJob* device_jobs, int njobs, int total_block
 int nm_occ_blocks_per_frame(int G);
 int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s);
 int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
-                         int Co_pad, float* part, hipStream_t s);
+                         int Co_pad, float* part, hipStream_t s, unsigned char* brickmap = nullptr, const float* field_part = nullptr);
+// true when nm_launch_conv sends a k2 s2 p0 conv of this input to conv_pool_f16s_kernel (the consumer of a brick-sparse tensor)
+bool nm_conv_pool16_eligible(int Cin, int OD, int OH, int OW, bool have_w16);
 void nm_conv_prof_enable(int on, hipStream_t stream);
 int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, long long* launches);
 void nm_conv_prof_reset();
@@ -119,6 +126,9 @@ int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups,
                           float* shift, hipStream_t s, double* chsum = nullptr);
 // chsum (training): [N][C][2] doubles (sum y, sum y^2 per channel) for nm_launch_gnb_finalize; available when 256 % (C / groups) == 0
 bool nm_gn_finalize_has_chsum(int C, int groups);
+// diagnostic reference (NM355_GN_DIAG=1): statistics straight from the stored tensor, two passes in fp64
+int nm_launch_gn_direct(const float* x, int N, int voxels, int C, int groups, const float* gamma, const float* beta, float eps,
+                        float* scale, float* shift, hipStream_t s, double* chsum);
 // sticky device word (ctx-owned) that gn_finalize ORs a 1 into when a conv's statistics are not finite; null: no reporting
 void nm_elem_set_nonfinite_flag(unsigned* flag);
 int nm_launch_nonfinite_scan(const float* x, size_t n, unsigned* flag, hipStream_t s);

@@ -48,6 +48,7 @@ struct ConvParams {
     const void* w16;              // conv_mfma_kernel<1,NT>: split-fp16 weights (null: fp32 MFMA core)
     int ksplit;                   // conv_mfma_kernel<1,NT> + w16: the taps are dealt to 2 / 4 waves that share a row tile (tiny volumes)
     int st_z, st_y, st_x;         // f16s / f16p: XCD super-tile in bricks (0: bricks in linear order), see super_tile_item()
+    const float* in_alt; const unsigned char* in_map;   // brick-sparse input (TensorRef::alt / brickmap), conv_pool_f16s only
 #ifdef NM_DIAG
     unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
 #endif
@@ -324,6 +325,10 @@ struct OccParams {
     const float* field;    // [G][G][G][Cout]
     float* out; float* part;
     int N, G, Cout, Co_pad;
+    // sparse first layer (inference): a brick whose 8x12x12 occupancy halo is empty equals the constant field - it is not written,
+    // brickmap[n][brick] = 0 tells the consumer (the pool conv) to read the field there, and its GroupNorm partial sums are the
+    // field's own (field_part [brick][Cout][2], computed once per weight update by this very kernel on an empty frame).  Null: dense.
+    unsigned char* brickmap; const float* field_part;
 };
 
 __host__ __device__ constexpr int occ_tap_off(int t) { return t < 125 ? ((t / 25) * 12 + (t / 5) % 5) * 12 + t % 5 : 0; }
@@ -446,6 +451,16 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     // a brick whose 8x12x12 neighbourhood holds no occupied voxel (most of a 64^3 grid around one figure) is the field alone: the
     // gather + MFMA loop below would add exact zeros
     const bool any_occ = __syncthreads_or(occupied) != 0;
+    if (p.brickmap) {
+        if (tid == 0 && blockIdx.y == 0) p.brickmap[(size_t)n * nblk + br] = any_occ ? 1 : 0;
+        if (!any_occ) {                 // the brick is the field: nothing to compute, nothing to write but its (precomputed) partial sums
+            if (p.part && tid < NT * 32 && co_base + tid < p.Cout) {
+                const float2 v = *reinterpret_cast<const float2*>(p.field_part + ((size_t)br * p.Cout + co_base + tid) * 2);
+                *reinterpret_cast<float2*>(p.part + (((size_t)n * nblk + br) * p.Cout + co_base + tid) * 2) = v;
+            }
+            return;
+        }
+    }
     int arow[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -1252,7 +1267,14 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
     for (int mt = 0; mt < 2; ++mt) {
         const int y = 2 * wave + mt;
         ok[mt] = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
-        src[mt] = p.in + ((((size_t)n * p.ID + 2 * (oz0 + z)) * p.IH + 2 * (oy0 + y)) * p.IW + 2 * (ox0 + x)) * p.Cin + 8 * h;
+        const size_t voff = (((size_t)(2 * (oz0 + z)) * p.IH + 2 * (oy0 + y)) * p.IW + 2 * (ox0 + x)) * p.Cin + 8 * h;
+        src[mt] = p.in + (size_t)n * p.ID * p.IH * p.IW * p.Cin + voff;
+        if (p.in_map && ok[mt]) {
+            // brick-sparse input: the 2x2x2 fine voxels of an output voxel lie in one 4x8x8 input brick; an unwritten brick is the
+            // frame-independent tensor in_alt there
+            const int fb = (((oz0 + z) >> 1) * (p.IH >> 3) + ((oy0 + y) >> 2)) * (p.IW >> 3) + ((ox0 + x) >> 2);
+            if (!p.in_map[(size_t)n * (p.ID >> 2) * (p.IH >> 3) * (p.IW >> 3) + fb]) src[mt] = p.in_alt + voff;
+        }
     }
     f32x16 acc[2][NT], accl[2][NT];
 #pragma unroll
@@ -2406,6 +2428,13 @@ static bool use_up2c(const ConvGeom& g, int Cin) {
     return g.up2 && g.up2c && nm_ls().conv_mode == 1 && nm_up2c_eligible(g.OD / 2, g.OH / 2, g.OW / 2, Cin, g.Cout, g.ks, g.stride, g.pad);
 }
 
+bool nm_conv_pool16_eligible(int Cin, int OD, int OH, int OW, bool have_w16) {
+    if (!(nm_ls().conv_mode == 1 && nm_ls().pool16 && have_w16 && Cin % 16 == 0)) return false;
+    ConvGeom g; g.ks = 2; g.stride = 2; g.pad = 0; g.OD = OD; g.OH = OH; g.OW = OW; g.Cout = Cin; g.Co_pad = (Cin + 31) & ~31;
+    const Tiling t = choose_tiling(g, Cin);
+    return t.MT == 2 && t.bx_l2 == 3 && t.by_l2 == 3 && t.bz_l2 == 2;
+}
+
 int nm_conv_blocks_per_frame(const ConvGeom& g, int Cin) {
     if (use_up2c(g, Cin)) return nm_up2c_blocks_per_frame(g.OD / 2, g.OH / 2, g.OW / 2);
     Tiling t = choose_tiling(g, 16);
@@ -2449,6 +2478,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
         return NM_ERR_ARG;
     }
     if ((in.scale == nullptr) != (in.shift == nullptr)) { nm_set_error("conv: scale/shift must come together"); return NM_ERR_ARG; }
+    if (in.brickmap && g.up2) { nm_set_error("conv: a brick-sparse input tensor can only feed the k2 s2 split-fp16 pool kernel"); return NM_ERR_ARG; }
     if (use_up2c(g, in.C)) {
         // the fused-upsample layers on the coarse grid with composite weights (nm_up2c.hip): main + shell launch, timed together
         ProfRec rec;
@@ -2473,6 +2503,11 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.up2 = g.up2 ? 1 : 0;
     p.st_z = p.st_y = p.st_x = 0;
+    p.in_alt = in.alt; p.in_map = in.brickmap;
+    if (in.brickmap && !(nm_conv_pool16_eligible(in.C, g.OD, g.OH, g.OW, w_packed16 != nullptr) && g.ks == 2 && g.stride == 2 && g.pad == 0 && !g.up2 &&
+                         in.alt && in.D % 4 == 0 && in.H % 8 == 0 && in.W % 8 == 0)) {
+        nm_set_error("conv: a brick-sparse input tensor can only feed the k2 s2 split-fp16 pool kernel"); return NM_ERR_ARG;
+    }
     p.w16 = (nm_ls().conv_mode == 1 && nm_ls().small16 && w_packed16 && in.C % 8 == 0 && !g.up2 && t.MT == 1 && (t.KC % 16 == 0 || t.KC == in.C)) ? w_packed16 : nullptr;
     if (p.w16) t.lds_bytes = max(t.lds_bytes, (size_t)(((t.KC + 15) & ~15) / 4) * (t.HVp + t.CVp) * 16);
     p.ksplit = 1;
@@ -2547,9 +2582,13 @@ int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float*
 }
 
 int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
-                         int Co_pad, float* part, hipStream_t s) {
+                         int Co_pad, float* part, hipStream_t s, unsigned char* brickmap, const float* field_part) {
     if (G % 8 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("conv_k5occ: unsupported G=%d Cout=%d", G, Cout); return NM_ERR_ARG; }
     OccParams p; p.occ = occ; p.w = w_packed; p.field = field; p.out = out; p.part = part; p.N = N; p.G = G; p.Cout = Cout; p.Co_pad = Co_pad;
+    p.brickmap = brickmap; p.field_part = field_part;
+    if (brickmap && (!(nm_ls().conv_mode == 1 && nm_ls().occ16) || (part && !field_part))) {
+        nm_set_error("conv_k5occ: the brick-sparse output exists on the split-fp16 kernel only and needs the field's partial sums"); return NM_ERR_ARG;
+    }
     const int NT = (Co_pad % 64 == 0) ? 2 : 1;
     dim3 grid((unsigned)(N * nm_occ_blocks_per_frame(G)), (unsigned)(Co_pad / (NT * 32)));
     ProfRec rec;

@@ -52,6 +52,7 @@ struct FeatNetW {
     ConvW c0; NormW n0; PoolW p1, p3; ResW r2, r5; HourglassW hg;
     float* occ_w = nullptr;    // occupancy-channel taps of c0: fp32 [32 tap-quads][Co_pad][4], then split fp16 [8 k-steps][4][Co_pad][8]
     float* field = nullptr;    // conv5(cat[0, coords]) + bias for one frame: [G^3][Cout]
+    float* field_part = nullptr;  // GroupNorm partial sums of the field per 4x8x8 brick [bricks][Cout][2] (sparse first layer)
 };
 struct LinearW { int in = 0, out = 0; float* w = nullptr; float* b = nullptr; };
 

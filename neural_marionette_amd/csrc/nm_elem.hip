@@ -86,6 +86,54 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// DIAGNOSTIC (NM355_GN_DIAG=1): GroupNorm statistics straight from the stored raw tensor, two passes in fp64 - the reference point for
+// the accuracy of the single-pass (sum x, sum x^2) block partials the conv epilogues produce.  One block per (frame, group).
+__global__ __launch_bounds__(1024) void gn_direct_kernel(const float* __restrict__ x, int voxels, int C, int groups, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                        double* __restrict__ chsum, int flags) {
+    __shared__ double sh[1024];
+    __shared__ double mean_s;
+    const int n = blockIdx.x / groups, g = blockIdx.x % groups, cpg = C / groups;
+    const int c = g * cpg + threadIdx.x % cpg, lanes = 1024 / cpg;
+    const int vl = (int)threadIdx.x / cpg < lanes ? (int)threadIdx.x / cpg : voxels;     // (threads beyond lanes * cpg idle)
+    const float* base = x + (size_t)n * voxels * C;
+    double s = 0.0;
+    for (int v = vl; v < voxels; v += lanes) s += (double)base[(size_t)v * C + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    double chs = 0.0;
+    if ((int)threadIdx.x < cpg) for (int l = 0; l < lanes; ++l) chs += sh[l * cpg + threadIdx.x];
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) sh[threadIdx.x] = chs;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < cpg; ++i) t += sh[i]; mean_s = t / ((double)voxels * cpg); }
+    __syncthreads();
+    const double mean = mean_s;
+    double q = 0.0, q2 = 0.0;
+    for (int v = vl; v < voxels; v += lanes) { const double d = (double)base[(size_t)v * C + c] - mean; q += d * d; q2 += (double)base[(size_t)v * C + c] * (double)base[(size_t)v * C + c]; }
+    __syncthreads();
+    sh[threadIdx.x] = q;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) { if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st]; __syncthreads(); }
+    const double var = sh[0] / ((double)voxels * cpg);
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    __syncthreads();
+    if (chsum && (flags & 2)) {
+        sh[threadIdx.x] = q2;
+        __syncthreads();
+        if ((int)threadIdx.x < cpg) {
+            double b = 0.0;
+            for (int l = 0; l < lanes; ++l) b += sh[l * cpg + threadIdx.x];
+            chsum[((size_t)n * C + c) * 2] = chs; chsum[((size_t)n * C + c) * 2 + 1] = b;
+        }
+    }
+    if ((int)threadIdx.x < cpg && (flags & 1)) {
+        const float sc = (float)rstd * gamma[c];
+        scale[(size_t)n * C + c] = sc;
+        shift[(size_t)n * C + c] = -sc * (float)mean + beta[c];
+    }
+}
+
 #define NM_STATS_VB 512
 __global__ __launch_bounds__(256) void gn_partials_kernel(const float* __restrict__ x, int voxels, int C, int nblk,
                                                           float* __restrict__ part) {
@@ -488,6 +536,13 @@ int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups,
     else
         hipLaunchKernelGGL(gn_finalize_kernel<256>, dim3(N * groups), dim3(256), 0, s, part, nblk, C, groups, count, gamma, beta, eps, scale, shift, nm_ls().nf_flag, chsum);
     return nm_check_hip(hipGetLastError(), "gn_finalize launch");
+}
+
+int nm_launch_gn_direct(const float* x, int N, int voxels, int C, int groups, const float* gamma, const float* beta, float eps,
+                        float* scale, float* shift, hipStream_t s, double* chsum) {
+    if (groups <= 0 || C % groups || C / groups > 1024) { nm_set_error("gn_direct: unsupported channels"); return NM_ERR_ARG; }
+    hipLaunchKernelGGL(gn_direct_kernel, dim3(N * groups), dim3(1024), 0, s, x, voxels, C, groups, gamma, beta, eps, scale, shift, chsum, nm_ls().gn_diag);
+    return nm_check_hip(hipGetLastError(), "gn_direct launch");
 }
 
 int nm_stats_blocks_per_frame(int voxels) { return (voxels + NM_STATS_VB - 1) / NM_STATS_VB; }

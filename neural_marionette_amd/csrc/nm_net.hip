@@ -16,6 +16,9 @@
 #include "nm_heads_bwd.h"
 #include "nm_up2c.h"
 #include <cmath>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
 #include <functional>
 
 // ---- what a training forward leaves behind for nm_detector_backward (all pointers into ctx->ws_t or caller buffers) --------
@@ -265,6 +268,16 @@ struct Loader {
             // (the caller's bias tensor: the ctx-owned copy is filled by the batched copy at the end of set_weights)
             r = nm_launch_conv(t, f.c0.wp, get(p + ".bias", Cout), f.field, g, nullptr, c->stream, 4);
         }
+        // the field's own GroupNorm partial sums per brick, by the first-layer kernel itself on the empty frame (bit-identical to what
+        // it computes for an empty brick of any frame): what the sparse first layer reports for the bricks it skips
+        f.field_part = nullptr;
+        if (!r && !c->training && nm_conv_get_mode() == 1 && nm_ls().occ16 && nm_ls().sparse_first) {
+            const int nblk = nm_occ_blocks_per_frame(G);
+            f.field_part = nm_ctx_weight_alloc(c, (size_t)nblk * Cout * 2);
+            float* scratch = nm_ctx_weight_alloc(c, G3 * Cout);           // (dense output of that one launch; reused at the next update)
+            if (!f.field_part || !scratch) r = NM_ERR_HIP;
+            else r = nm_launch_conv_k5occ(zero, 1, G, f.occ_w, f.field, scratch, Cout, f.c0.Co_pad, f.field_part, c->stream);
+        }
         if (r && !rc) rc = r;
     }
     LinearW linear(const std::string& p, int out, int in) {
@@ -326,6 +339,7 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
             n.run(nm_launch_conv(in, w.wp, w.bias, out, g, part, n.s, w.Cin, w.wp16));
             if (gn) n.run(nm_launch_gn_finalize(part, in.N, nblk, w.Cout, gn->groups, (double)ov * (w.Cout / gn->groups),
                                                 gn->gamma, gn->beta, 1e-5f, scale, shift, n.s, chsum));
+            if (gn && nm_ls().gn_diag) n.run(nm_launch_gn_direct(out, in.N, (int)ov, w.Cout, gn->groups, gn->gamma, gn->beta, 1e-5f, scale, shift, n.s, chsum));
         }
     }
     TensorRef o = mk(out, in.N, g.OD, g.OH, g.OW, w.Cout, scale, shift, slope_after);
@@ -371,6 +385,7 @@ TensorRef up(Net& n, const TensorRef& x, const UpW& w, int outpad, UpRec* rec = 
         n.run(nm_launch_gn_partials(out, x.N, (int)ov, w.Cout, part, n.s));
         n.run(nm_launch_gn_finalize(part, x.N, nblk, w.Cout, w.n.groups, (double)ov * (w.Cout / w.n.groups), w.n.gamma,
                                     w.n.beta, 1e-5f, scale, shift, n.s, chsum));
+        if (nm_ls().gn_diag) n.run(nm_launch_gn_direct(out, x.N, (int)ov, w.Cout, w.n.groups, w.n.gamma, w.n.beta, 1e-5f, scale, shift, n.s, chsum));
     }
     TensorRef o = mk(out, x.N, OD, OH, OW, w.Cout, scale, shift, LRELU);
     if (rec) { rec->w = &w; rec->in = x; rec->out = o; rec->fpart = part; rec->nblk = nblk; rec->chsum = chsum; }
@@ -403,14 +418,22 @@ TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w,
     float* out = n.alloc((size_t)N * G3 * Cout);
     const int nblk = nm_occ_blocks_per_frame(G);
     float* part = n.alloc((size_t)N * nblk * Cout * 2);
+    // inference: bricks with an empty occupancy halo (most of the grid around one figure) are neither computed nor written; the pool
+    // conv - this tensor's only consumer - reads the constant field there (TensorRef::alt / brickmap).  Training keeps the dense
+    // tensor (the backward pass reads it).
+    const bool sparse = !rec && w.field_part && nm_conv_get_mode() == 1 && nm_ls().occ16 && nm_ls().sparse_first &&
+                        nm_conv_pool16_eligible(Cout, G / 2, G / 2, G / 2, w.p1.c.wp16 != nullptr);
+    unsigned char* bmap = sparse ? reinterpret_cast<unsigned char*>(n.alloc(((size_t)N * nblk + 3) / 4)) : nullptr;
     float* scale = n.alloc((size_t)N * Cout); float* shift = n.alloc((size_t)N * Cout);
     double* chsum = (rec && nm_gn_finalize_has_chsum(Cout, w.n0.groups)) ? reinterpret_cast<double*>(n.alloc((size_t)N * Cout * 4)) : nullptr;
     if (n.live()) {
-        n.run(nm_launch_conv_k5occ(occ, N, G, w.occ_w, w.field, out, Cout, w.c0.Co_pad, part, n.s));
+        n.run(nm_launch_conv_k5occ(occ, N, G, w.occ_w, w.field, out, Cout, w.c0.Co_pad, part, n.s, bmap, sparse ? w.field_part : nullptr));
         n.run(nm_launch_gn_finalize(part, N, nblk, Cout, w.n0.groups, (double)G3 * (Cout / w.n0.groups), w.n0.gamma, w.n0.beta,
                                     1e-5f, scale, shift, n.s, chsum));
+        if (nm_ls().gn_diag && !sparse) n.run(nm_launch_gn_direct(out, N, (int)G3, Cout, w.n0.groups, w.n0.gamma, w.n0.beta, 1e-5f, scale, shift, n.s, chsum));
     }
     TensorRef o = mk(out, N, G, G, G, Cout, scale, shift, LRELU);
+    if (sparse) { o.alt = w.field; o.brickmap = bmap; }
     if (rec) { rec->w = &w; rec->occ = occ; rec->N = N; rec->G = G; rec->first = o; rec->fpart0 = part; rec->nblk0 = nblk; rec->chsum0 = chsum; }
     return o;
 }

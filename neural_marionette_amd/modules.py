@@ -100,7 +100,8 @@ class Engine:
             dev = self.ctx.device
             self._named = own + [(k, torch.zeros(*shape, device=dev)) for k, shape in param_spec(self.opts) if k not in have]
         sd = self._named
-        stamp = tuple((t.data_ptr(), t._version) for _, t in sd)
+        # (the conv mode and the training switch decide which derived tables set_weights builds: part of the stamp)
+        stamp = (self.conv_mode, self.training_packs) + tuple((t.data_ptr(), t._version) for _, t in sd)
         if stamp == self._stamp:
             return
         names, keep = [], []

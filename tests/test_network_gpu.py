@@ -691,3 +691,33 @@ def test_parity_at_64cubed_on_trained_weights():
             tol = 3e-4 if k == "graph_traj_loss" else 5e-5
             assert abs(float(out[k]) - r) <= tol * max(1.0, abs(r)), (mode, k, float(out[k]), r)
         net.check_finite()
+
+
+def test_sparse_first_layer_is_bit_identical_to_dense():
+    """Inference skips the first-layer bricks whose occupancy halo is empty (their output is the weight-only constant field; the pool
+    conv reads the field there): every output must equal, bit for bit, the dense evaluation (NM355_SPARSE_FIRST=0, read when a
+    context is created) - on a figure clip (most bricks empty), on Bernoulli noise (no brick empty), on an all-empty clip, and on a
+    clip whose only occupied voxels sit in a corner / on brick boundaries."""
+    G, B, T = 64, 2, 3
+    o = HotPathOptions(grid_size=G)
+    sd = synth.make_state_dict(o, seed=8, variant="peaky")
+    sparse = _net(o, sd)
+    os.environ["NM355_SPARSE_FIRST"] = "0"
+    try:
+        dense = _net(o, sd)
+        eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=9).cuda()
+        corner = torch.zeros(B, T, 1, G, G, G)
+        corner[:, :, 0, 0, 0, 0] = 1; corner[:, 1, 0, 3, 7, 8] = 1; corner[1, 2, 0, 63, 63, 63] = 1; corner[0, 0, 0, 32, 31, 15] = 1
+        clips = {"figure": synth.figure_clip(B, T, G, seed=10), "bernoulli": (torch.rand(B, T, 1, G, G, G, generator=torch.Generator().manual_seed(11)) < 0.03).float(),
+                 "empty": torch.zeros(B, T, 1, G, G, G), "corner": corner}
+        for name, vox in clips.items():
+            with torch.no_grad():
+                for n in (sparse, dense):
+                    n(vox.cuda(), ACTS, eps=eps)                    # (first call: tree; second: the fused forward)
+                a = sparse(vox.cuda(), ACTS, eps=eps); b = dense(vox.cuda(), ACTS, eps=eps)
+            torch.cuda.synchronize()
+            for k in ("keypoints", "heatmaps", "first_feature", "recon", "z_kypts", "h_kypts", *DETECTOR_LOSS_KEYS):
+                # bitwise (the empty clip's chamfer term is 0/0 = NaN in the reference too, and NaN != NaN)
+                assert torch.equal(a[k].contiguous().view(torch.int32), b[k].contiguous().view(torch.int32)), (name, k, float((a[k] - b[k]).abs().max()))
+    finally:
+        del os.environ["NM355_SPARSE_FIRST"]
