@@ -31,7 +31,8 @@ NmLaunchState::NmLaunchState()
       vrnn_gemm(env_int("NM355_VRNN_GEMM", 1)),    // 0: one wavefront per output row at every batch size (A/B)
       vrnn_graph(env_int("NM355_VRNN_GRAPH", 1)),       // 0: rollouts enqueue their launches one by one instead of replaying a captured graph (A/B)
       sparse_first(env_int("NM355_SPARSE_FIRST", 1)), // 0: the first layer writes its dense output in inference too (A/B)
-      gn_diag(env_int("NM355_GN_DIAG", 0)) {}         // 1: GroupNorm statistics recomputed from the stored tensor in fp64 (diagnostic)
+      gn_diag(env_int("NM355_GN_DIAG", 0)),                 // 1: GroupNorm statistics recomputed from the stored tensor in fp64 (diagnostic)
+      lazy_res(env_int("NM355_LAZY_RES", 1)) {}       // 0: every residual sum is materialised by apply2 (A/B)
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
     return nm_tls_ls ? *nm_tls_ls : outside;

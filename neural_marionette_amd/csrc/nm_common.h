@@ -45,6 +45,10 @@ struct TensorRef {
     // Only the k2 s2 split-fp16 pool kernel reads such tensors; every other launcher rejects them.
     const float* alt = nullptr;
     const unsigned char* brickmap = nullptr;
+    // Un-materialised residual sum (Res3DBlock output = GN(conv) + skip, vox_modules.py:44-47): the tensor's value is
+    // T(p; scale, shift, slope) + T(p2; scale2, shift2, slope2), evaluated exactly as apply2 would have stored it.  Only the k2 s2
+    // split-fp16 pool kernel reads such tensors (the block's only consumer in the inference encoder); others reject them.
+    const float* p2 = nullptr; const float* scale2 = nullptr; const float* shift2 = nullptr; float slope2 = 1.0f;
 };
 
 struct ConvGeom {
@@ -77,7 +81,7 @@ struct NmLaunchState {
     unsigned* nf_flag = nullptr;           // sticky device word gn_finalize ORs a 1 into (null: no reporting)
     // A/B and diagnostic switches (NM355_SUPERTILE, _SMALL16, _KSPLIT, _OCC16, _POOL16, _F16P2, _F16P, _WGRAD_TR, _UP2C, _UP2C_DIAG,
     // _VRNN_MID, _VRNN_GEMM, _VRNN_GRAPH, _SPARSE_FIRST)
-    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, wgrad_tr, up2c, up2c_diag, vrnn_mid, vrnn_gemm, vrnn_graph, sparse_first, gn_diag;
+    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, wgrad_tr, up2c, up2c_diag, vrnn_mid, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res;
     NmLaunchState();
 };
 NmLaunchState& nm_ls();        // the state of the context whose ABI call runs on this thread

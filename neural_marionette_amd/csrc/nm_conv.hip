@@ -49,6 +49,7 @@ struct ConvParams {
     int ksplit;                   // conv_mfma_kernel<1,NT> + w16: the taps are dealt to 2 / 4 waves that share a row tile (tiny volumes)
     int st_z, st_y, st_x;         // f16s / f16p: XCD super-tile in bricks (0: bricks in linear order), see super_tile_item()
     const float* in_alt; const unsigned char* in_map;   // brick-sparse input (TensorRef::alt / brickmap), conv_pool_f16s only
+    const float* in2; const float* in2_scale; const float* in2_shift; float in2_slope;   // un-materialised residual sum (TensorRef::p2 ...), conv_pool_f16s only
 #ifdef NM_DIAG
     unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
 #endif
@@ -78,6 +79,21 @@ __device__ __forceinline__ f32x4 apply_act(const ConvParams& p, f32x4 v, const f
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], v[j] * p.in_slope);
     }
     return v;
+}
+
+// value of an un-materialised residual sum, bit for bit what apply2_kernel (nm_elem.hip load_t) would have stored: each addend
+// x * scale + shift as a multiply and an add (not fused), LeakyReLU as v > 0 ? v : v * slope, then the sum
+__device__ __forceinline__ f32x4 sum_act2(const ConvParams& p, f32x4 a, const f32x4& sca, const f32x4& sha, f32x4 b, const f32x4& scb, const f32x4& shb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float u = a[j], v = b[j];
+        if (p.in_scale) { u = u * sca[j]; u = u + sha[j]; }
+        if (p.in_slope != 1.0f) u = u > 0.f ? u : u * p.in_slope;
+        if (p.in2_scale) { v = v * scb[j]; v = v + shb[j]; }
+        if (p.in2_slope != 1.0f) v = v > 0.f ? v : v * p.in2_slope;
+        a[j] = u + v;
+    }
+    return a;
 }
 
 // activated input sample: x * scale + shift, LeakyReLU (the producer's pending GroupNorm)
@@ -1262,6 +1278,7 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
     const int c = l31 >> 2;
     const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
     const float* src[2];
+    const float* src2[2];
     bool ok[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -1269,6 +1286,7 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
         ok[mt] = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
         const size_t voff = (((size_t)(2 * (oz0 + z)) * p.IH + 2 * (oy0 + y)) * p.IW + 2 * (ox0 + x)) * p.Cin + 8 * h;
         src[mt] = p.in + (size_t)n * p.ID * p.IH * p.IW * p.Cin + voff;
+        src2[mt] = p.in2 ? p.in2 + (size_t)n * p.ID * p.IH * p.IW * p.Cin + voff : src[mt];
         if (p.in_map && ok[mt]) {
             // brick-sparse input: the 2x2x2 fine voxels of an output voxel lie in one 4x8x8 input brick; an unwritten brick is the
             // frame-independent tensor in_alt there
@@ -1291,6 +1309,13 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
             sca = *reinterpret_cast<const f32x4*>(ps); scb = *reinterpret_cast<const f32x4*>(ps + 4);
             sha = *reinterpret_cast<const f32x4*>(ph); shb = *reinterpret_cast<const f32x4*>(ph + 4);
         }
+        // second addend of an un-materialised residual sum: its own affine (and slope), apply2's arithmetic (mul, add - not fused)
+        f32x4 s2a = zero4, s2b = zero4, h2a = zero4, h2b = zero4;
+        if (p.in2 && p.in2_scale) {
+            const float* ps = p.in2_scale + (size_t)n * p.Cin + cb * 16 + 8 * h; const float* ph = p.in2_shift + (size_t)n * p.Cin + cb * 16 + 8 * h;
+            s2a = *reinterpret_cast<const f32x4*>(ps); s2b = *reinterpret_cast<const f32x4*>(ps + 4);
+            h2a = *reinterpret_cast<const f32x4*>(ph); h2b = *reinterpret_cast<const f32x4*>(ph + 4);
+        }
         const half8* wq = w8 + (size_t)cb * 4 * plane + co_base;
 #pragma unroll
         for (int tap = 0; tap < 8; ++tap) {
@@ -1301,6 +1326,15 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
                 ra[mt] = ok[mt] ? *reinterpret_cast<const f32x4*>(src[mt] + toff) : zero4;
                 rb[mt] = ok[mt] ? *reinterpret_cast<const f32x4*>(src[mt] + toff + 4) : zero4;
             }
+            if (p.in2) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f32x4 qa = ok[mt] ? *reinterpret_cast<const f32x4*>(src2[mt] + toff) : zero4;
+                    const f32x4 qb = ok[mt] ? *reinterpret_cast<const f32x4*>(src2[mt] + toff + 4) : zero4;
+                    ra[mt] = ok[mt] ? sum_act2(p, ra[mt], sca, sha, qa, s2a, h2a) : zero4;
+                    rb[mt] = ok[mt] ? sum_act2(p, rb[mt], scb, shb, qb, s2b, h2b) : zero4;
+                }
+            }
             const half8* wt = wq + (size_t)tap * C16 * 4 * plane;
             half8 bh[NT], bl[NT];
 #pragma unroll
@@ -1308,7 +1342,8 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16s_kernel(ConvParams p) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 half8 ah, al;
-                split8(apply_act(p, ra[mt], sca, sha), apply_act(p, rb[mt], scb, shb), ah, al);
+                if (p.in2) split8(ra[mt], rb[mt], ah, al);
+                else split8(apply_act(p, ra[mt], sca, sha), apply_act(p, rb[mt], scb, shb), ah, al);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
@@ -2478,7 +2513,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
         return NM_ERR_ARG;
     }
     if ((in.scale == nullptr) != (in.shift == nullptr)) { nm_set_error("conv: scale/shift must come together"); return NM_ERR_ARG; }
-    if (in.brickmap && g.up2) { nm_set_error("conv: a brick-sparse input tensor can only feed the k2 s2 split-fp16 pool kernel"); return NM_ERR_ARG; }
+    if ((in.brickmap || in.p2) && g.up2) { nm_set_error("conv: a brick-sparse input tensor can only feed the k2 s2 split-fp16 pool kernel"); return NM_ERR_ARG; }
     if (use_up2c(g, in.C)) {
         // the fused-upsample layers on the coarse grid with composite weights (nm_up2c.hip): main + shell launch, timed together
         ProfRec rec;
@@ -2504,6 +2539,10 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.up2 = g.up2 ? 1 : 0;
     p.st_z = p.st_y = p.st_x = 0;
     p.in_alt = in.alt; p.in_map = in.brickmap;
+    p.in2 = in.p2; p.in2_scale = in.scale2; p.in2_shift = in.shift2; p.in2_slope = in.slope2;
+    if (in.p2 && !(nm_conv_pool16_eligible(in.C, g.OD, g.OH, g.OW, w_packed16 != nullptr) && g.ks == 2 && g.stride == 2 && g.pad == 0 && !g.up2 && !in.brickmap)) {
+        nm_set_error("conv: an un-materialised residual sum can only feed the k2 s2 split-fp16 pool kernel"); return NM_ERR_ARG;
+    }
     if (in.brickmap && !(nm_conv_pool16_eligible(in.C, g.OD, g.OH, g.OW, w_packed16 != nullptr) && g.ks == 2 && g.stride == 2 && g.pad == 0 && !g.up2 &&
                          in.alt && in.D % 4 == 0 && in.H % 8 == 0 && in.W % 8 == 0)) {
         nm_set_error("conv: a brick-sparse input tensor can only feed the k2 s2 split-fp16 pool kernel"); return NM_ERR_ARG;

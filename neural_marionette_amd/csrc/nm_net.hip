@@ -355,7 +355,18 @@ TensorRef add2(Net& n, const TensorRef& a, const TensorRef* b, float* out_buf = 
 
 // Res3DBlock (vox_modules.py:22-47): GN(conv3(lrelu(GN(conv3 x)))) + skip(x); the trailing
 // F.leaky_relu(., True) is the identity.
-TensorRef res(Net& n, const TensorRef& x, const ResW& w, float* out_buf = nullptr, ResRec* rec = nullptr) {
+// lazy_sum (inference encoder, the block in front of a pool conv): the sum is not materialised - the result is the un-materialised
+// pair (TensorRef::p2), which the split-fp16 pool kernel evaluates while staging (one write and one read of the tensor less); the
+// caller's mark / release then owns the two branches' buffers.
+TensorRef res(Net& n, const TensorRef& x, const ResW& w, float* out_buf = nullptr, ResRec* rec = nullptr, bool lazy_sum = false) {
+    if (lazy_sum && !rec && !out_buf) {
+        TensorRef r1 = conv_gn(n, x, w.c1, &w.n1, 1, 1, LRELU);
+        TensorRef r2 = conv_gn(n, r1, w.c2, &w.n2, 1, 1, 1.0f);
+        TensorRef sk = w.has_skip ? conv_gn(n, x, w.cs, &w.ns, 1, 0, 1.0f) : x;
+        TensorRef o = r2;
+        o.p2 = sk.p; o.scale2 = sk.scale; o.shift2 = sk.shift; o.slope2 = sk.slope;
+        return o;
+    }
     float* out = out_buf ? out_buf : n.alloc((size_t)x.N * vox(x) * w.c2.Cout);
     const size_t m = n.ws.mark();
     TensorRef r1 = conv_gn(n, x, w.c1, &w.n1, 1, 1, LRELU, nullptr, false, rec ? &rec->c1 : nullptr);
@@ -443,7 +454,10 @@ void feature_net(Net& n, const float* occ, int N, int G, const FeatNetW& w, int 
     const size_t m = n.ws.mark();
     TensorRef x = first_layer(n, occ, N, G, w, r);
     x = pool(n, x, w.p1, r ? &r->p1 : nullptr);
-    x = res(n, x, w.r2, nullptr, r ? &r->r2 : nullptr);
+    // (inference: r2's residual sum is evaluated by the pool conv that consumes it)
+    const bool lazy = !r && nm_ls().lazy_res && nm_conv_pool16_eligible(w.r2.c2.Cout, x.D / 2, x.H / 2, x.W / 2, w.p3.c.wp16 != nullptr) &&
+                      x.D % 2 == 0 && x.H % 2 == 0 && x.W % 2 == 0;
+    x = res(n, x, w.r2, nullptr, r ? &r->r2 : nullptr, lazy);
     x = pool(n, x, w.p3, r ? &r->p3 : nullptr);
     x = hourglass(n, x, w.hg, g, r ? &r->hg : nullptr);
     res(n, x, w.r5, out_buf, r ? &r->r5 : nullptr);

@@ -693,31 +693,36 @@ def test_parity_at_64cubed_on_trained_weights():
         net.check_finite()
 
 
-def test_sparse_first_layer_is_bit_identical_to_dense():
-    """Inference skips the first-layer bricks whose occupancy halo is empty (their output is the weight-only constant field; the pool
-    conv reads the field there): every output must equal, bit for bit, the dense evaluation (NM355_SPARSE_FIRST=0, read when a
-    context is created) - on a figure clip (most bricks empty), on Bernoulli noise (no brick empty), on an all-empty clip, and on a
-    clip whose only occupied voxels sit in a corner / on brick boundaries."""
-    G, B, T = 64, 2, 3
+@pytest.mark.parametrize("G", [64, 96, 40])
+def test_inference_shortcuts_are_bit_identical_to_the_plain_evaluation(G):
+    """Two inference-only shortcuts of the encoder must not change a single bit of any output:
+    (1) sparse first layer - bricks whose occupancy halo is empty are neither computed nor written (their output is the weight-only
+        constant field; the pool conv reads the field there);
+    (2) the residual sum of the Res3DBlock in front of the second pool conv is evaluated by that pool conv while staging instead of
+        being materialised by apply2.
+    Reference: a context created with NM355_SPARSE_FIRST=0 NM355_LAZY_RES=0 (the switches are read when a context is created).  Clips:
+    a figure (most bricks empty), Bernoulli noise (no brick empty), an all-empty clip, single voxels in corners / on brick boundaries.
+    G = 40 has odd hourglass sizes and is not eligible for either shortcut (the test then checks the fall-back changes nothing)."""
+    B, T = (2, 3) if G == 64 else (1, 2)
     o = HotPathOptions(grid_size=G)
     sd = synth.make_state_dict(o, seed=8, variant="peaky")
-    sparse = _net(o, sd)
-    os.environ["NM355_SPARSE_FIRST"] = "0"
+    fast = _net(o, sd)
+    os.environ["NM355_SPARSE_FIRST"] = "0"; os.environ["NM355_LAZY_RES"] = "0"
     try:
-        dense = _net(o, sd)
+        plain = _net(o, sd)
         eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=9).cuda()
         corner = torch.zeros(B, T, 1, G, G, G)
-        corner[:, :, 0, 0, 0, 0] = 1; corner[:, 1, 0, 3, 7, 8] = 1; corner[1, 2, 0, 63, 63, 63] = 1; corner[0, 0, 0, 32, 31, 15] = 1
+        corner[:, :, 0, 0, 0, 0] = 1; corner[:, 1, 0, 3, 7, 8] = 1; corner[B - 1, T - 1, 0, G - 1, G - 1, G - 1] = 1; corner[0, 0, 0, G // 2, G // 2 - 1, 15] = 1
         clips = {"figure": synth.figure_clip(B, T, G, seed=10), "bernoulli": (torch.rand(B, T, 1, G, G, G, generator=torch.Generator().manual_seed(11)) < 0.03).float(),
                  "empty": torch.zeros(B, T, 1, G, G, G), "corner": corner}
         for name, vox in clips.items():
             with torch.no_grad():
-                for n in (sparse, dense):
+                for n in (fast, plain):
                     n(vox.cuda(), ACTS, eps=eps)                    # (first call: tree; second: the fused forward)
-                a = sparse(vox.cuda(), ACTS, eps=eps); b = dense(vox.cuda(), ACTS, eps=eps)
+                a = fast(vox.cuda(), ACTS, eps=eps); b = plain(vox.cuda(), ACTS, eps=eps)
             torch.cuda.synchronize()
             for k in ("keypoints", "heatmaps", "first_feature", "recon", "z_kypts", "h_kypts", *DETECTOR_LOSS_KEYS):
                 # bitwise (the empty clip's chamfer term is 0/0 = NaN in the reference too, and NaN != NaN)
-                assert torch.equal(a[k].contiguous().view(torch.int32), b[k].contiguous().view(torch.int32)), (name, k, float((a[k] - b[k]).abs().max()))
+                assert torch.equal(a[k].contiguous().view(torch.int32), b[k].contiguous().view(torch.int32)), (G, name, k, float((a[k] - b[k]).abs().max()))
     finally:
-        del os.environ["NM355_SPARSE_FIRST"]
+        del os.environ["NM355_SPARSE_FIRST"]; del os.environ["NM355_LAZY_RES"]
