@@ -59,6 +59,8 @@ struct LinearW { int in = 0, out = 0; float* w = nullptr; float* b = nullptr; };
 struct DetectorW {
     FeatNetW frame, clip;
     ConvW head, clip_head, adjust;
+    ConvW adjust_rest;                     // inference: columns K.. of `adjust` (first_feature, gauss_0, coords) as a conv of its own
+    float* adjust_wg = nullptr;            //            columns 0..K-1 transposed to [K][Cout] (the per-frame gaussian part)
     float* prop = nullptr;                 // [w0, w1, b] of propagate_heatmaps (device)
     float* zeros = nullptr;                // 512 zeros (bias of the data-gradient convolutions)
     ConvW d1, d4, d8, d11; NormW dn2, dn5, dn9, dn12;

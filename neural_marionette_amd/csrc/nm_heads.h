@@ -8,6 +8,12 @@ int nm_launch_keypoints(const float* part, int F, int K, int g, float* keypoints
 int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s);
 int nm_launch_combined(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int F,
                        int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s);
+// the 1x1 conv of the combined representation split by linearity (inference): per-clip part / per-frame part, see nm_heads.hip
+int nm_launch_combined_rest(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int nb, int T,
+                            int K, int Fd, int g, int Cr, float* out, hipStream_t s);
+int nm_launch_adjust_gauss(const float* table, const float* keypoints, const float* base, const float* wg, int F, int T, int K, int g,
+                           int Cout, float* out, hipStream_t s);
+int nm_launch_adjust_wg(const float* w, int Cout, int Cin_total, int K, float* wg, hipStream_t s);
 int nm_tail_blocks(int G);
 int nm_launch_decoder_tail(const TensorRef& x, const float* w14, const float* first_frames, int ff_stride_frames, int T,
                            const float* target, const float* keypoints, int K, int G, float* recon, float* part,

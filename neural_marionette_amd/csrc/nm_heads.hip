@@ -462,6 +462,95 @@ int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, fl
     return nm_check_hip(hipGetLastError(), "gauss_table launch");
 }
 
+// ---- the combined representation's 1x1 conv split by linearity (inference; kypt_detector.py:380-383,406) -----------------------------
+// cat[gauss_t (K), first_feature (Fd), gauss_0 (K), coords (3)] -> conv1x1 -> 128: only the first K channels change from frame to
+// frame of a clip.  out[f] = W[:, :K] gauss_t[f]  +  ( W[:, K:] cat[first_feature, gauss_0, coords] + bias )[clip of f]: the bracket
+// is one small conv per CLIP (combined_rest -> the generic conv), the per-frame part a 24-term dot per output that never
+// materialises the 184-channel tensor (193 MB per 64 frames written and read back by a fp32-MFMA conv before).
+__global__ __launch_bounds__(256) void combined_rest_kernel(const float* __restrict__ table, const float* __restrict__ keypoints,
+                                                            const float* __restrict__ first_feature, int ff_stride, int nb, int T,
+                                                            int K, int Fd, int g, int Cr, float* __restrict__ out) {
+    const int g2 = g * g, g3 = g2 * g, cq = Cr / 4;
+    const size_t total = (size_t)nb * g3 * cq;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int q = (int)(i % cq); size_t r = i / cq;
+        int v = (int)(r % g3); int b = (int)(r / g3);
+        int f0 = b * T;
+        int x = v % g, y = (v / g) % g, z = v / g2;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = q * 4 + j;
+            float val = 0.f;
+            if (c < Fd) val = first_feature[(((size_t)b * ff_stride) * g3 + v) * Fd + c];
+            else if (c < K + Fd) {
+                int k = c - Fd;
+                const float* e = table + ((size_t)f0 * K + k) * 3 * g;
+                val = ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f0 * K + k) * 4 + 3];
+            } else if (c < K + Fd + 3) {
+                int d = c - K - Fd;
+                val = lin_coord(d == 0 ? z : (d == 1 ? y : x), g);
+            }
+            o[j] = val;
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    }
+}
+int nm_launch_combined_rest(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int nb, int T,
+                            int K, int Fd, int g, int Cr, float* out, hipStream_t s) {
+    size_t total = (size_t)nb * g * g * g * (Cr / 4);
+    int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(combined_rest_kernel, dim3(blocks), dim3(256), 0, s, table, keypoints, first_feature, ff_stride, nb, T, K, Fd, g, Cr, out);
+    return nm_check_hip(hipGetLastError(), "combined_rest launch");
+}
+
+// out[f][v][co] = base[f / T][v][co] + sum_k wg[k][co] * gauss(f, k, v); one workgroup = 8 voxels x (Cout / 4) channel quads
+// (Cout = 128: 32 threads per voxel), the 8 x K gaussian values of the block through LDS
+__global__ __launch_bounds__(256) void adjust_gauss_kernel(const float* __restrict__ table, const float* __restrict__ keypoints,
+                                                           const float* __restrict__ base, const float* __restrict__ wg, int T, int K, int g,
+                                                           int Cout, float* __restrict__ out) {
+    __shared__ float gs[8 * 32];
+    const int g2 = g * g, g3 = g2 * g;
+    const int f = blockIdx.y, v0 = blockIdx.x * 8, tid = threadIdx.x;
+    if (tid < 8 * K) {
+        const int vl = tid / K, k = tid % K, v = v0 + vl;
+        float val = 0.f;
+        if (v < g3) {
+            const int x = v % g, y = (v / g) % g, z = v / g2;
+            const float* e = table + ((size_t)f * K + k) * 3 * g;
+            val = ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f * K + k) * 4 + 3];
+        }
+        gs[vl * 32 + k] = val;
+    }
+    __syncthreads();
+    const int cq = Cout / 4, vl = tid / cq, q = tid % cq, v = v0 + vl;
+    if (vl >= 8 || v >= g3) return;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(base + (((size_t)(f / T)) * g3 + v) * Cout + q * 4);
+    for (int k = 0; k < K; ++k) {
+        const float gk = gs[vl * 32 + k];
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wg + (size_t)k * Cout + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(w[j], gk, acc[j]);
+    }
+    *reinterpret_cast<f32x4*>(out + ((size_t)f * g3 + v) * Cout + q * 4) = acc;
+}
+int nm_launch_adjust_gauss(const float* table, const float* keypoints, const float* base, const float* wg, int F, int T, int K, int g,
+                           int Cout, float* out, hipStream_t s) {
+    if (K > 32 || Cout % 4 || 8 * (Cout / 4) != 256) { nm_set_error("adjust_gauss: unsupported K=%d Cout=%d", K, Cout); return NM_ERR_ARG; }
+    const int g3 = g * g * g;
+    hipLaunchKernelGGL(adjust_gauss_kernel, dim3((g3 + 7) / 8, F), dim3(256), 0, s, table, keypoints, base, wg, T, K, g, Cout, out);
+    return nm_check_hip(hipGetLastError(), "adjust_gauss launch");
+}
+// wg[k][co] = W[co][k] for k < K (W: (Cout, Cin_total) row-major)
+__global__ void adjust_wg_kernel(const float* __restrict__ w, int Cout, int Cin_total, int K, float* __restrict__ wg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K * Cout) wg[i] = w[(size_t)(i % Cout) * Cin_total + i / Cout];
+}
+int nm_launch_adjust_wg(const float* w, int Cout, int Cin_total, int K, float* wg, hipStream_t s) {
+    hipLaunchKernelGGL(adjust_wg_kernel, dim3((K * Cout + 255) / 256), dim3(256), 0, s, w, Cout, Cin_total, K, wg);
+    return nm_check_hip(hipGetLastError(), "adjust_wg launch");
+}
+
 int nm_launch_combined(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int F,
                        int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s) {
     size_t total = (size_t)F * g * g * g * (Cc / 4);

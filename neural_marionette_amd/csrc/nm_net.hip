@@ -488,13 +488,29 @@ void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int fea
         const int nb = (B - b0) < clips_per_pass ? (B - b0) : clips_per_pass;
         const int f0 = b0 * T, nf = nb * T;
         const size_t m1 = n.ws.mark();
-        float* comb = n.alloc((size_t)nf * g3 * Cc);
-        if (n.live())
-            n.run(nm_launch_combined(table + (size_t)f0 * K * 3 * g, keypoints + (size_t)f0 * K * 4,
-                                     feat_cl + (size_t)b0 * feat_frame_stride * g3 * FEAT, feat_frame_stride, nf, T, K, FEAT, g,
-                                     Cc, comb, n.s));
-        TensorRef x = mk(comb, nf, g, g, g, Cc);
-        x = conv_gn(n, x, d.adjust, nullptr, 1, 0, LRELU, nullptr, false, tape ? &tape->adjust : nullptr);
+        TensorRef x;
+        if (!tape && d.adjust_wg && d.adjust_rest.wp) {
+            // inference: per-clip conv over [first_feature, gauss_0, coords] (+ bias), then the per-frame gaussian part on top of it
+            const int Cr = d.adjust_rest.Cin_pad;
+            float* rest = n.alloc((size_t)nb * g3 * Cr);
+            if (n.live())
+                n.run(nm_launch_combined_rest(table + (size_t)f0 * K * 3 * g, keypoints + (size_t)f0 * K * 4,
+                                              feat_cl + (size_t)b0 * feat_frame_stride * g3 * FEAT, feat_frame_stride, nb, T, K, FEAT, g, Cr, rest, n.s));
+            ConvW wr = d.adjust_rest; wr.bias = d.adjust.bias;
+            TensorRef base = conv_gn(n, mk(rest, nb, g, g, g, Cr), wr, nullptr, 1, 0, 1.0f);
+            float* adj = n.alloc((size_t)nf * g3 * FEAT);
+            if (n.live())
+                n.run(nm_launch_adjust_gauss(table + (size_t)f0 * K * 3 * g, keypoints + (size_t)f0 * K * 4, base.p, d.adjust_wg, nf, T, K, g, FEAT, adj, n.s));
+            x = mk(adj, nf, g, g, g, FEAT, nullptr, nullptr, LRELU);
+        } else {
+            float* comb = n.alloc((size_t)nf * g3 * Cc);
+            if (n.live())
+                n.run(nm_launch_combined(table + (size_t)f0 * K * 3 * g, keypoints + (size_t)f0 * K * 4,
+                                         feat_cl + (size_t)b0 * feat_frame_stride * g3 * FEAT, feat_frame_stride, nf, T, K, FEAT, g,
+                                         Cc, comb, n.s));
+            x = mk(comb, nf, g, g, g, Cc);
+            x = conv_gn(n, x, d.adjust, nullptr, 1, 0, LRELU, nullptr, false, tape ? &tape->adjust : nullptr);
+        }
         x = conv_gn(n, x, d.d1, &d.dn2, 1, 1, LRELU, nullptr, true, tape ? &tape->d1 : nullptr);    // Upsample(x2, trilinear) fused into the staging
         x = conv_gn(n, x, d.d4, &d.dn5, 1, 1, LRELU, nullptr, false, tape ? &tape->d4 : nullptr);
         x = conv_gn(n, x, d.d8, &d.dn9, 1, 1, LRELU, nullptr, true, tape ? &tape->d8 : nullptr);    // second Upsample(x2) likewise
@@ -987,6 +1003,24 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
         const float* pb = L.get(v + ".propagate_heatmaps.0.bias", 1);
         d.prop = nm_ctx_weight_alloc(c, 3);
         if (pw && pb && d.prop) hipLaunchKernelGGL(pack_small_kernel, dim3(1), dim3(64), 0, c->stream, pw, 2, pb, 1, d.prop);
+    }
+    {   // inference: the same layer split by linearity (nm_heads.hip): per-clip conv over the frame-independent channels + per-frame gaussians
+        const std::string key = k2v + ".adjust_combined_representation.0";
+        const int Cin = FEAT + 2 * K + 3, Cr = Cin - K;
+        ConvW& w = d.adjust_rest;
+        w = ConvW(); w.Cin = Cr; w.Cout = FEAT; w.ks = 1; w.Cin_pad = (Cr + 7) & ~7; w.Co_pad = (FEAT + 31) & ~31; w.key = key;
+        d.adjust_wg = nullptr;
+        const float* src = L.get(key + ".weight", (int64_t)FEAT * Cin);
+        if (src && !c->training && nm_ls().adjust_split) {
+            w.wp = nm_ctx_weight_alloc(c, nm_packed_weight_floats(1, w.Cin_pad, w.Co_pad));
+            d.adjust_wg = nm_ctx_weight_alloc(c, (size_t)K * FEAT);
+            if (!w.wp || !d.adjust_wg) { if (!L.rc) { nm_set_error("set_weights: hipMalloc failed"); L.rc = NM_ERR_HIP; } }
+            else {
+                L.pack(src + K, w.wp, nullptr, FEAT, Cr, 1, w.Cin_pad, w.Co_pad, Cin, 0);      // columns K.. of every row (row stride Cin)
+                int r = nm_launch_adjust_wg(src, FEAT, Cin, K, d.adjust_wg, c->stream);
+                if (r && !L.rc) L.rc = r;
+            }
+        }
     }
     d.adjust = L.conv(k2v + ".adjust_combined_representation.0", FEAT, FEAT + 2 * K + 3, 1);       // (pad16 = true puts it on conv_f16s: measured 648 us vs 319 us on the fp32 kernel, which stages all 184 channels per pass; a 1-tap layer has 6 MFMAs per staged 16-channel chunk)
     d.d1 = L.conv(dec + ".1", FEAT / 2, FEAT, 3); L.up2_sets(dec + ".1", d.d1, c->cfg.grid_size / 4); d.dn2 = L.norm(dec + ".2", FEAT / 2);
