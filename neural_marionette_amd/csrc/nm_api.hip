@@ -33,7 +33,8 @@ NmLaunchState::NmLaunchState()
       sparse_first(env_int("NM355_SPARSE_FIRST", 1)), // 0: the first layer writes its dense output in inference too (A/B)
       gn_diag(env_int("NM355_GN_DIAG", 0)),                 // 1: GroupNorm statistics recomputed from the stored tensor in fp64 (diagnostic)
       lazy_res(env_int("NM355_LAZY_RES", 1)),         // 0: every residual sum is materialised by apply2 (A/B)
-      adjust_split(env_int("NM355_ADJUST_SPLIT", 1)) {} // 0: the decoder's first 1x1 conv runs over the materialised 184-channel tensor in inference too (A/B)
+      adjust_split(env_int("NM355_ADJUST_SPLIT", 1)), // 0: the decoder's first 1x1 conv runs over the materialised 184-channel tensor in inference too (A/B)
+      hg_core(env_int("NM355_HG_CORE", 1)) {}           // 0: the two lowest hourglass levels as separate launches in inference too (A/B)
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
     return nm_tls_ls ? *nm_tls_ls : outside;

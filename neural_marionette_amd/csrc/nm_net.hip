@@ -15,6 +15,7 @@
 #include "nm_grad.h"
 #include "nm_heads_bwd.h"
 #include "nm_up2c.h"
+#include "nm_hgcore.h"
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -404,20 +405,57 @@ TensorRef up(Net& n, const TensorRef& x, const UpW& w, int outpad, UpRec* rec = 
 }
 
 // HG (vox_modules.py:78-120)
+// the two lowest levels as one launch (nm_hgcore.hip): parameters from the packed weights; false when a layer has no split-fp16 pack
+static bool hg_core_params(const HourglassW& w, const TensorRef& a2, float* out, NmHgCoreParams& p) {
+    auto cv = [](const ConvW& c, NmHgConv& o) { o.w16 = c.wp16; o.bias = c.bias; o.Cin = c.Cin; o.Cout = c.Cout; o.Co_pad = c.Co_pad; o.ks = c.ks; return c.wp16 != nullptr && c.Cin % 8 == 0; };
+    auto nv = [](const NormW& g, NmHgNorm& o) { o.gamma = g.gamma; o.beta = g.beta; o.groups = g.groups; };
+    auto rv = [&](const ResW& r, NmHgRes& o) {
+        bool ok = cv(r.c1, o.c1) && cv(r.c2, o.c2);
+        nv(r.n1, o.n1); nv(r.n2, o.n2);
+        o.has_skip = r.has_skip ? 1 : 0;
+        if (r.has_skip) { ok = ok && cv(r.cs, o.cs); nv(r.ns, o.ns); } else { o.cs = o.c1; o.ns = o.n1; }
+        return ok;
+    };
+    bool ok = rv(w.e2, p.e2) && rv(w.s3, p.s3) && rv(w.e3, p.e3) && rv(w.d3, p.d3) && rv(w.d2, p.d2) && cv(w.p3.c, p.p3);
+    nv(w.p3.n, p.np3); nv(w.u3.n, p.nu3);
+    p.u3_w = w.u3.w; p.u3_bias = w.u3.bias; p.u3_Cin = w.u3.Cin; p.u3_Cout = w.u3.Cout;
+    p.in = a2.p; p.in_scale = a2.scale; p.in_shift = a2.shift; p.in_slope = a2.slope; p.out = out;
+    p.N = a2.N; p.D2 = a2.D; p.D3 = a2.D / 2; p.Cin0 = a2.C;
+    int c2 = std::max(a2.C, std::max(w.e2.c2.Cout, std::max(w.s3.c2.Cout, std::max(w.u3.Cout, w.d2.c2.Cout))));
+    int c3 = std::max(w.p3.c.Cout, std::max(w.e3.c2.Cout, w.d3.c2.Cout));
+    p.pitch2 = (c2 + 15) & ~15; p.pitch3 = (c3 + 15) & ~15;
+    ok = ok && a2.D == a2.H && a2.H == a2.W && a2.D >= 2 && a2.D <= 6 && p.u3_w && w.u3.Cout == w.s3.c2.Cout && a2.C == w.e2.c1.Cin &&
+         w.e2.c2.Cout == w.s3.c1.Cin && w.e2.c2.Cout == w.p3.c.Cin && w.p3.c.Cout == w.e3.c1.Cin && w.d3.c2.Cout == w.u3.Cin &&
+         w.u3.Cout == w.d2.c1.Cin && nm_hg_core_lds_bytes(p) <= 150 * 1024;
+    return ok;
+}
+
 TensorRef hourglass(Net& n, const TensorRef& x0, const HourglassW& w, int Ng, HgRec* r = nullptr) {
     const int op3 = (Ng / 4) % 2, op2 = (Ng / 2) % 2, op1 = Ng % 2;
     TensorRef s1 = res(n, x0, w.s1, nullptr, r ? &r->s1 : nullptr);
     TensorRef x = res(n, pool(n, x0, w.p1, r ? &r->p1 : nullptr), w.e1, nullptr, r ? &r->e1 : nullptr);
     TensorRef s2 = res(n, x, w.s2, nullptr, r ? &r->s2 : nullptr);
-    x = res(n, pool(n, x, w.p2, r ? &r->p2 : nullptr), w.e2, nullptr, r ? &r->e2 : nullptr);
-    TensorRef s3 = res(n, x, w.s3, nullptr, r ? &r->s3 : nullptr);
-    x = res(n, pool(n, x, w.p3, r ? &r->p3 : nullptr), w.e3, nullptr, r ? &r->e3 : nullptr);
-    x = res(n, x, w.d3, nullptr, r ? &r->d3 : nullptr);
-    TensorRef u = up(n, x, w.u3, op3, r ? &r->u3 : nullptr); x = add2(n, u, &s3);
-    x = res(n, x, w.d2, nullptr, r ? &r->d2 : nullptr);
+    TensorRef a2 = pool(n, x, w.p2, r ? &r->p2 : nullptr);
+    NmHgCoreParams hp;
+    TensorRef u;
+    if (!r && nm_conv_get_mode() == 1 && nm_ls().hg_core && hg_core_params(w, a2, nullptr, hp)) {
+        // inference: encoder_res2 ... decoder_res2 (13 convs, 14 GroupNorms, the transposed conv and the adds) in one launch
+        float* d2out = n.alloc((size_t)a2.N * vox(a2) * w.d2.c2.Cout);
+        hp.out = d2out;
+        if (n.live()) n.run(nm_launch_hg_core(hp, n.s));
+        x = mk(d2out, a2.N, a2.D, a2.H, a2.W, w.d2.c2.Cout);
+    } else {
+        x = res(n, a2, w.e2, nullptr, r ? &r->e2 : nullptr);
+        TensorRef s3 = res(n, x, w.s3, nullptr, r ? &r->s3 : nullptr);
+        x = res(n, pool(n, x, w.p3, r ? &r->p3 : nullptr), w.e3, nullptr, r ? &r->e3 : nullptr);
+        x = res(n, x, w.d3, nullptr, r ? &r->d3 : nullptr);
+        u = up(n, x, w.u3, op3, r ? &r->u3 : nullptr); x = add2(n, u, &s3);
+        x = res(n, x, w.d2, nullptr, r ? &r->d2 : nullptr);
+    }
     u = up(n, x, w.u2, op2, r ? &r->u2 : nullptr); x = add2(n, u, &s2);
     x = res(n, x, w.d1, nullptr, r ? &r->d1 : nullptr);
     u = up(n, x, w.u1, op1, r ? &r->u1 : nullptr); x = add2(n, u, &s1);
+    (void)op3;
     return x;
 }
 
