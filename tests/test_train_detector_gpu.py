@@ -336,7 +336,9 @@ def test_config3_per_gpu_shape_training_step():
         inf = net(vox.cuda(), {"detector": True, "learner": False})
     loss_inf = float(sum(w * inf[k] for k, w in AIST.items()))
     assert abs(loss - loss_inf) <= 1e-6 * max(1.0, abs(loss_inf)), (loss, loss_inf)
-    assert torch.equal(out["keypoints"].cpu(), inf["keypoints"].cpu())
+    # (the inference forward takes shortcuts the training forward cannot - two hourglass levels in one launch, the split 1x1 conv -
+    # whose summation orders differ: same values to fp32 rounding, not the same bits)
+    assert (out["keypoints"].cpu() - inf["keypoints"].cpu()).abs().max().item() < 2e-6
     # (2) batch additivity
     acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in g_all.items()}
     for b in range(4):
