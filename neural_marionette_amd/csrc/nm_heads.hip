@@ -504,41 +504,53 @@ int nm_launch_combined_rest(const float* table, const float* keypoints, const fl
     return nm_check_hip(hipGetLastError(), "combined_rest launch");
 }
 
-// out[f][v][co] = base[f / T][v][co] + sum_k wg[k][co] * gauss(f, k, v); one workgroup = 8 voxels x (Cout / 4) channel quads
-// (Cout = 128: 32 threads per voxel), the 8 x K gaussian values of the block through LDS
+// out[f][v][co] = base[f / T][v][co] + sum_k wg[k][co] * gauss(f, k, v); one workgroup = 64 voxels x (Cout / 4) channel quads
+// (Cout = 128: thread = (voxel lane 0..7, quad 0..31), 8 voxels per thread with the thread's K weight quads held in registers), the
+// 64 x K gaussian values of the block through LDS
+template <int KMAX>
 __global__ __launch_bounds__(256) void adjust_gauss_kernel(const float* __restrict__ table, const float* __restrict__ keypoints,
                                                            const float* __restrict__ base, const float* __restrict__ wg, int T, int K, int g,
                                                            int Cout, float* __restrict__ out) {
-    __shared__ float gs[8 * 32];
+    __shared__ float gs[64 * KMAX];
     const int g2 = g * g, g3 = g2 * g;
-    const int f = blockIdx.y, v0 = blockIdx.x * 8, tid = threadIdx.x;
-    if (tid < 8 * K) {
-        const int vl = tid / K, k = tid % K, v = v0 + vl;
+    const int f = blockIdx.y, v0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int cq = Cout / 4, vl = tid / cq, q = tid % cq;
+    f32x4 w[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) w[k] = *reinterpret_cast<const f32x4*>(wg + (size_t)(k < K ? k : K - 1) * Cout + q * 4);
+    for (int i = tid; i < 64 * KMAX; i += 256) {
+        const int vv = i / KMAX, k = i % KMAX, v = v0 + vv;
         float val = 0.f;
-        if (v < g3) {
+        if (v < g3 && k < K) {
             const int x = v % g, y = (v / g) % g, z = v / g2;
             const float* e = table + ((size_t)f * K + k) * 3 * g;
             val = ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f * K + k) * 4 + 3];
         }
-        gs[vl * 32 + k] = val;
+        gs[i] = val;
     }
     __syncthreads();
-    const int cq = Cout / 4, vl = tid / cq, q = tid % cq, v = v0 + vl;
-    if (vl >= 8 || v >= g3) return;
-    f32x4 acc = *reinterpret_cast<const f32x4*>(base + (((size_t)(f / T)) * g3 + v) * Cout + q * 4);
-    for (int k = 0; k < K; ++k) {
-        const float gk = gs[vl * 32 + k];
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wg + (size_t)k * Cout + q * 4);
+    for (int vv = vl; vv < 64; vv += 8) {
+        const int v = v0 + vv;
+        if (v >= g3) break;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(base + (((size_t)(f / T)) * g3 + v) * Cout + q * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(w[j], gk, acc[j]);
+        for (int k = 0; k < KMAX; ++k) {
+            const float gk = gs[vv * KMAX + k];          // (k >= K: zero)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(w[k][j], gk, acc[j]);
+        }
+        *reinterpret_cast<f32x4*>(out + ((size_t)f * g3 + v) * Cout + q * 4) = acc;
     }
-    *reinterpret_cast<f32x4*>(out + ((size_t)f * g3 + v) * Cout + q * 4) = acc;
 }
 int nm_launch_adjust_gauss(const float* table, const float* keypoints, const float* base, const float* wg, int F, int T, int K, int g,
                            int Cout, float* out, hipStream_t s) {
-    if (K > 32 || Cout % 4 || 8 * (Cout / 4) != 256) { nm_set_error("adjust_gauss: unsupported K=%d Cout=%d", K, Cout); return NM_ERR_ARG; }
+    if (K > 32 || K % 8 || Cout % 4 || 8 * (Cout / 4) != 256) { nm_set_error("adjust_gauss: unsupported K=%d Cout=%d", K, Cout); return NM_ERR_ARG; }
     const int g3 = g * g * g;
-    hipLaunchKernelGGL(adjust_gauss_kernel, dim3((g3 + 7) / 8, F), dim3(256), 0, s, table, keypoints, base, wg, T, K, g, Cout, out);
+    const dim3 grid((g3 + 63) / 64, F);
+    if (K <= 8) hipLaunchKernelGGL(adjust_gauss_kernel<8>, grid, dim3(256), 0, s, table, keypoints, base, wg, T, K, g, Cout, out);
+    else if (K <= 16) hipLaunchKernelGGL(adjust_gauss_kernel<16>, grid, dim3(256), 0, s, table, keypoints, base, wg, T, K, g, Cout, out);
+    else if (K <= 24) hipLaunchKernelGGL(adjust_gauss_kernel<24>, grid, dim3(256), 0, s, table, keypoints, base, wg, T, K, g, Cout, out);
+    else hipLaunchKernelGGL(adjust_gauss_kernel<32>, grid, dim3(256), 0, s, table, keypoints, base, wg, T, K, g, Cout, out);
     return nm_check_hip(hipGetLastError(), "adjust_gauss launch");
 }
 // wg[k][co] = W[co][k] for k < K (W: (Cout, Cin_total) row-major)

@@ -20,6 +20,7 @@
 // training forward keeps every layer's output for the backward pass).
 #include "nm_ctx.h"
 #include "nm_hgcore.h"
+#include <cstdlib>
 
 namespace {
 
@@ -27,6 +28,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define HG_SPLIT 2048.0f
+__device__ int g_hg_diag = 0;          // NM355_HG_DIAG: phase ablations (wrong results, timing only); set by nm_launch_hg_core
 // Address spaces, explicitly: behind a (non-inlined) function boundary a pointer is generic, every access a FLAT instruction that
 // counts on both the LDS and the vector-memory counter - the LDS operand reads of a k-step then wait for the weight prefetches of
 // the following ones (measured: one L2 round trip per k-step, ~1 ms per launch).
@@ -65,7 +67,7 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
     const int ks = __builtin_amdgcn_readfirstlane(L.ks), Cin = __builtin_amdgcn_readfirstlane(L.Cin), Cout = __builtin_amdgcn_readfirstlane(L.Cout);
     const int Co_pad = __builtin_amdgcn_readfirstlane(L.Co_pad);
     const int Vout = Dout * Dout * Dout, mtiles = (Vout + 31) >> 5, ntiles = Co_pad >> 5;
-    const int nchunk = (Cin + 15) >> 4, nk = ks * ks * ks * nchunk;
+    const int nchunk = (Cin + 15) >> 4, nk = (g_hg_diag & 2) ? 1 : ks * ks * ks * nchunk;          // (diagnostic bit 2: one k-step per conv - timing only)
     glb_half8* w8 = (glb_half8*)L.w16;
     const lds_float* srcl = (const lds_float*)src;
     lds_float* dstl = (lds_float*)dst;
@@ -142,6 +144,7 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
 __device__ void gn_lds(float* buf, int pitch_, int V_, int C_, const NmHgNorm& g, float slope, const float* add, int addp_, double* red_generic) {
     const int pitch = __builtin_amdgcn_readfirstlane(pitch_), V = __builtin_amdgcn_readfirstlane(V_), C = __builtin_amdgcn_readfirstlane(C_);
     const int addp = __builtin_amdgcn_readfirstlane(addp_), groups = __builtin_amdgcn_readfirstlane(g.groups);
+    if (g_hg_diag & 1) return;                                      // (diagnostic bit 1: no GroupNorm - timing only)
     const int cpg = C / groups, tid = threadIdx.x, vlanes = 256 / pitch;
     const int c = tid % pitch, vl = tid / pitch;
     const bool active = vl < vlanes && c < C;
@@ -272,6 +275,10 @@ int nm_launch_hg_core(const NmHgCoreParams& p, hipStream_t s) {
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(hg_core)");
         attr_set = true;
     }
+    static int diag_set = -1;
+    const char* e = getenv("NM355_HG_DIAG");
+    const int diag = e ? atoi(e) : 0;
+    if (diag != diag_set) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hg_diag), &diag, sizeof(int)); diag_set = diag; }
     hipLaunchKernelGGL(hg_core_kernel, dim3(p.N), dim3(256), lds, s, p);
     return nm_check_hip(hipGetLastError(), "hg_core launch");
 }
