@@ -103,14 +103,27 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
         // (tz, ty, tx, cb) advance as scalar counters - no division per k-step.
         const int nkp = (nk + HG_PF - 1) / HG_PF * HG_PF;
         int tz = 0, ty = 0, tx = 0, cb = 0;
+        // the LDS operand of k-step k + 1 is requested before k-step k is split and multiplied (one wave per SIMD: nothing else hides
+        // the LDS latency in front of ~25 dependent VALU instructions)
+        auto a_addr = [&](int k) -> const lds_float* {
+            const int toff = ((tz * Din + ty) * Din + tx) * sp + cb * 16;                     // scalar
+            const bool ok = k < nk && (((mz >> tz) & (my >> ty) & (mx >> tx)) & 1);
+            return ok ? srcl + (off0 + toff) : zl;                                            // (taps outside the volume / padding steps read zeros)
+        };
+        auto advance = [&]() {
+            if (++cb == nchunk) { cb = 0; if (++tx == ks) { tx = 0; if (++ty == ks) { ty = 0; ++tz; } } }
+            if (tz >= ks) { tz = ks - 1; ty = ks - 1; tx = ks - 1; cb = nchunk - 1; }          // (padding steps stay on the last tap)
+        };
+        const lds_float* q0 = a_addr(0);
+        f32x4 a = *(const lds_f32x4*)q0, b = *(const lds_f32x4*)(q0 + 4);
+        advance();
         for (int k0 = 0; k0 < nkp; k0 += HG_PF) {
 #pragma unroll
             for (int u = 0; u < HG_PF; ++u) {
                 const int k = k0 + u;
-                const int toff = ((tz * Din + ty) * Din + tx) * sp + cb * 16;                 // scalar
-                const bool ok = k < nk && (((mz >> tz) & (my >> ty) & (mx >> tx)) & 1);
-                const lds_float* q = ok ? srcl + (off0 + toff) : zl;       // (taps outside the volume / padding steps read 8 zeros)
-                const f32x4 a = *(const lds_f32x4*)q, b = *(const lds_f32x4*)(q + 4);
+                const lds_float* qn = a_addr(k + 1);
+                const f32x4 an = *(const lds_f32x4*)qn, bn = *(const lds_f32x4*)(qn + 4);
+                advance();
                 half8 ah, al;
                 hg_split8(a, b, ah, al);
                 const half8 wh = bh[u], wlo = bl[u];
@@ -119,8 +132,7 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
                 accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wlo, accl, 0, 0, 0);
                 accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, accm, 0, 0, 0);
-                if (++cb == nchunk) { cb = 0; if (++tx == ks) { tx = 0; if (++ty == ks) { ty = 0; ++tz; } } }
-                if (tz >= ks) { tz = ks - 1; ty = ks - 1; tx = ks - 1; cb = nchunk - 1; }      // (padding steps stay on the last tap)
+                a = an; b = bn;
             }
         }
         // accumulator layout (activations first): lane holds column n = nt*32 + l31, rows (r & 3) + 8 (r >> 2) + 4 h
@@ -242,8 +254,14 @@ __global__ __launch_bounds__(256) void hg_core_kernel(NmHgCoreParams p) {
                 const float* w = p.u3_w + (size_t)tap * Ci * Co + co;
                 float a0 = 0.f, a1 = 0.f;
                 int ci = 0;
-                for (; ci + 1 < Ci; ci += 2) { a0 = fmaf(x[ci], w[(size_t)ci * Co], a0); a1 = fmaf(x[ci + 1], w[(size_t)(ci + 1) * Co], a1); }
-                if (ci < Ci) a0 = fmaf(x[ci], w[(size_t)ci * Co], a0);
+                for (; ci + 7 < Ci; ci += 8) {                    // 8 weight loads in flight (each was a dependent L2 round trip)
+                    float wv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wv[j] = w[(size_t)(ci + j) * Co];
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) { a0 = fmaf(x[ci + j], wv[j], a0); a1 = fmaf(x[ci + j + 1], wv[j + 1], a1); }
+                }
+                for (; ci < Ci; ++ci) a0 = fmaf(x[ci], w[(size_t)ci * Co], a0);
                 acc += a0 + a1;
             }
             B0[(size_t)v * P2 + co] = acc;
