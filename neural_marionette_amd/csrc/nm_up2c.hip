@@ -220,8 +220,11 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
         }
     };
     auto issue = [&](const StepPos& s, int k) {
-        int v = (tid >> 2) + 128 * k;
-        asm volatile("" : "+v"(v));                                  // (keeps the per-item coordinates out of long-lived registers)
+        // the item's voxel index (tid >> 2) + 128 k, computed HERE by an opaque instruction pair: as a plain expression it is
+        // loop-invariant, hipcc hoists it, keeps the four of them (k = 0..3) alive across the k-loop and - at 256 registers - spills
+        // them; every reload was followed by s_waitcnt vmcnt(0), i.e. drained the weight loads in flight (8 drains per step)
+        int v;
+        asm volatile("v_lshrrev_b32 %0, 2, %1\n\tv_add_u32 %0, %2, %0" : "=v"(v) : "v"(tid), "s"(128 * k));
         if (v < NV) {
             const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
             const int gz = min(max(s.cz0 - 1 + hz, 0), p.ID - 1), gy = min(max(s.cy0 - 1 + hy, 0), p.IH - 1), gx = min(max(s.cx0 - 1 + hx, 0), p.IW - 1);
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
         }
     };
     auto commit = [&](half8* buf, int k) {
-        int v = (tid >> 2) + 128 * k;
-        asm volatile("" : "+v"(v));
+        int v;
+        asm volatile("v_lshrrev_b32 %0, 2, %1\n\tv_add_u32 %0, %2, %0" : "=v"(v) : "v"(tid), "s"(128 * k));
         if (v < NV) {
             const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
             half8 hi, lo;
