@@ -750,3 +750,37 @@ def test_inference_shortcuts_are_bit_identical_to_the_plain_evaluation(G):
                 assert torch.equal(a[k].contiguous().view(torch.int32), b[k].contiguous().view(torch.int32)), (G, name, k, float((a[k] - b[k]).abs().max()))
     finally:
         del os.environ["NM355_SPARSE_FIRST"]; del os.environ["NM355_LAZY_RES"]
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("G", [48, 56])
+def test_odd_hourglass_levels_with_output_padding_vs_oracle(G, path):
+    """Grids whose hourglass levels are odd below the top (G = 48: 12 -> 6 -> 3 -> 1, G = 56: 14 -> 7 -> 3 -> 1): the transposed convs
+    take output_padding = 1 (vox_modules.py:81), the pool convs drop the last plane; in the inference forward the 3^3 / 1^3 levels run
+    inside hg_core_kernel (its padding planes hold the bias only).  Detector + VRNN against the CPU oracle."""
+    o = HotPathOptions(grid_size=G)
+    sd = synth.make_state_dict(o, seed=60 + G, variant="peaky")
+    net = _net(o, sd)
+    B, T = 1, 3                                   # (T >= 3: the trajectory loss averages accelerations)
+    vox = synth.figure_clip(B, T, G, seed=61)
+    eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=62)
+    _call(path, net, vox.cuda(), ACTS, eps=eps.cuda())                 # (first call builds the tree; the second takes the fused forward)
+    out = _call(path, net, vox.cuda(), ACTS, eps=eps.cuda())
+    torch.cuda.synchronize()
+    key = "odd%d" % G
+    if key not in _ORACLE_CACHE:
+        with torch.no_grad():
+            _ORACLE_CACHE[key] = O.nm_forward(sd, o, vox, eps)
+    ref = _ORACLE_CACHE[key]
+    e_kp = _err(out["keypoints"], ref["keypoints"])
+    print("G=%d %s: keypoints %.3e heatmaps %.3e first_feature %.3e z %.3e" % (G, path, e_kp, _err(out["heatmaps"], ref["heatmaps"]),
+                                                                          _err(out["first_feature"], ref["first_feature"]), _err(out["z_kypts"], ref["z_kypts"])))
+    assert e_kp < KP_TOL
+    assert _err(out["heatmaps"], ref["heatmaps"]) < 1e-4 * max(1.0, float(ref["heatmaps"].abs().max()))
+    assert _err(out["first_feature"], ref["first_feature"]) < 1e-4 * max(1.0, float(ref["first_feature"].abs().max()))
+    assert np.array_equal(out["best_idx"].cpu().numpy(), ref["best_idx"].numpy().astype(np.int32))
+    for k in ("z_kypts", "h_kypts", "kypt_recon"):
+        assert _err(out[k], ref[k]) < KP_TOL, k
+    for k in DETECTOR_LOSS_KEYS:
+        r = float(ref[k])
+        assert abs(float(out[k]) - r) <= 5e-5 * max(1.0, abs(r)), k
