@@ -2002,23 +2002,29 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             if (s2.w.n != s1.w.n || s2.w.oz0 != s1.w.oz0 || s2.w.oy0 != s1.w.oy0 || s2.w.ox0 != s1.w.ox0) m_ld = inside_mask(s2.w);
             else m_ld = m_cvt;
             const float* b2 = tile_base(s2.w, s2.cb);
-            // tap group 0: weights of this step's group 1 (into the buffer group 2 of the last step was read from); pieces 0-3.
+            // The ten pieces are dealt 3 / 5 / 2 to the three tap groups (round 3; they were 4 / 6 / 0).  In-kernel stamps
+            // (tools/diag_f16p2_steps.py) showed the producers, not the MFMA waves, arriving last at the first two barriers of a step
+            // (MFMA waves waiting 734 + 1011 of a 15 272-cycle step) with 1 100 cycles to spare at the third: a step's 39 global loads
+            // and 47 LDS stores cost these waves ~100 cycles of issue each beside the MFMA waves' streams.  The tile of step s + 1 is
+            // therefore complete at the step's LAST barrier, and the MFMA waves fetch a step's first operands after that barrier.
+            // tap group 0: weights of this step's group 1 (into the buffer group 2 of the last step was read from); pieces 0-2.
             // Everything older than the 9 weight loads has landed after the first wait.
             load_b_group(cur.w.cg, cur.cb, 1);
             NM_PRODUCER2_WAIT(9);
-            static_for<4>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
-            NM_PRODUCER2_WAIT(4);                                   // the weight loads (older than the 4 new piece loads)
+            static_for<3>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
+            NM_PRODUCER2_WAIT(3);                                   // the weight loads (older than the 3 new piece loads)
             store_b_group(gpar ^ 1);
             lds_barrier(); gpar ^= 1;
-            // tap group 1: weights of this step's group 2; pieces 4-9; the halo tile is complete at this barrier
+            // tap group 1: weights of this step's group 2; pieces 3-7
             load_b_group(cur.w.cg, cur.cb, 2);
-            static_for<6>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 4>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 4>{}); });
-            load_affine(s2.w, s2.cb);
-            NM_PRODUCER2_WAIT(8);                                   // the weight loads: 6 piece + 2 affine loads are younger
+            static_for<5>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 3>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 3>{}); });
+            NM_PRODUCER2_WAIT(5);                                   // the weight loads: 5 piece loads are younger
             store_b_group(gpar ^ 1);
             lds_barrier(); gpar ^= 1;
-            // tap group 2: weights of the next step's group 0
+            // tap group 2: weights of the next step's group 0; pieces 8-9; the halo tile is complete at this barrier
             load_b_group(s1.w.cg, s1.cb, 0);
+            static_for<2>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 8>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 8>{}); });
+            load_affine(s2.w, s2.cb);                               // (sc / sh are free: piece 9 was their last user)
             NM_PRODUCER2_WAIT(0);
             store_b_group(gpar ^ 1);
             lds_barrier(); gpar ^= 1;
@@ -2080,16 +2086,17 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
                          : "+v"(ah0[i]), "+v"(al0[i]), "+v"(ah1[i]), "+v"(al1[i]), "+v"(bh0[i]), "+v"(bh1[i]), "+v"(bl0[i]), "+v"(bl1[i]) :: "memory");
             __builtin_amdgcn_sched_barrier(0);
             constexpr int u = tt + 1, ug = (u < 27) ? u / 9 : 0, ut = (u < 27) ? u % 9 : 0;
-            constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;           // A byte offset of tap tt + 1 (tap 26: next step's tap 0)
-            const unsigned vau = (u < 27) ? va : van;
+            constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;           // A byte offset of tap tt + 1
+            constexpr bool anext = u < 27;                          // (tap 26 requests nothing: the next tile is complete only at the step's last barrier)
+            const unsigned vau = va;
             constexpr bool bnext = t < 8;                           // the next tap's weights are in this group's buffer
             constexpr int BN = (t + 1) * 256 * 16;
 #define NM_MFMA2(ACC, B, A) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(B, A, ACC, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
 #define NM_MFMA2L(ACC, B, A) ACC = nm_mfma_lo<SINGLE>(B, A, ACC); __builtin_amdgcn_sched_barrier(0)
-            NM_MFMA2(acc[0][0], bh0[i], ah0[i]);  ah0[j] = lds_read16_untracked<AO>(vau);
-            NM_MFMA2(acc[0][1], bh1[i], ah0[i]);  al0[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO>(vau);
-            NM_MFMA2L(accl[0][0], bl0[i], ah0[i]); ah1[j] = lds_read16_untracked<AO + YO>(vau);
-            NM_MFMA2L(accl[0][1], bl1[i], ah0[i]); al1[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO + YO>(vau);
+            NM_MFMA2(acc[0][0], bh0[i], ah0[i]);  if constexpr (anext) ah0[j] = lds_read16_untracked<AO>(vau);
+            NM_MFMA2(acc[0][1], bh1[i], ah0[i]);  if constexpr (anext) al0[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO>(vau);
+            NM_MFMA2L(accl[0][0], bl0[i], ah0[i]); if constexpr (anext) ah1[j] = lds_read16_untracked<AO + YO>(vau);
+            NM_MFMA2L(accl[0][1], bl1[i], ah0[i]); if constexpr (anext) al1[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO + YO>(vau);
             NM_MFMA2L(accl[0][0], bh0[i], al0[i]); if constexpr (bnext) bh0[j] = lds_read16_untracked<BN>(vb);
             NM_MFMA2L(accl[0][1], bh1[i], al0[i]); if constexpr (bnext) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb);
             NM_MFMA2(acc[1][0], bh0[i], ah1[i]);  if constexpr (bnext) bl0[j] = SINGLE ? half8{} : lds_read16_untracked<BN + 128 * 16>(vb);
@@ -2105,10 +2112,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             }
         });
         gpar ^= 1;                                                  // three groups per step
-        // 27 taps are an odd count: the A operands prefetched for the next step's first tap sit in slot 1; wait for them (the
-        // reads are untracked) and move them to slot 0
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah0[1]), "+v"(al0[1]), "+v"(ah1[1]), "+v"(al1[1]) :: "memory");
-        ah0[0] = ah0[1]; al0[0] = al0[1]; ah1[0] = ah1[1]; al1[0] = al1[1];
+        // the next step's tile is complete since the barrier that ended tap group 2: request its first tap's A operands now (slot 0;
+        // the step's first wait covers them)
+        if (has_next) {
+            ah0[0] = lds_read16_untracked<0>(van); al0[0] = SINGLE ? half8{} : lds_read16_untracked<LO>(van);
+            ah1[0] = lds_read16_untracked<YO>(van); al1[0] = SINGLE ? half8{} : lds_read16_untracked<LO + YO>(van);
+        }
         if (cur.cb == C16 - 1) {
             // ---- epilogue of the finished brick (exposed): transposed accumulators -> 16-byte stores, DPP partial sums
             const Work& w = cur.w;
