@@ -50,6 +50,7 @@ struct ConvParams {
     int st_z, st_y, st_x;         // f16s / f16p: XCD super-tile in bricks (0: bricks in linear order), see super_tile_item()
     const float* in_alt; const unsigned char* in_map;   // brick-sparse input (TensorRef::alt / brickmap), conv_pool_f16s only
     const float* in2; const float* in2_scale; const float* in2_shift; float in2_slope;   // un-materialised residual sum (TensorRef::p2 ...), conv_pool_f16s only
+    int wdma;                     // conv_f16p2: the producers copy the weights global -> LDS by LDS-DMA instead of through registers (A/B switch)
 #ifdef NM_DIAG
     unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
 #endif
@@ -1970,12 +1971,26 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             w_src[i] = (unsigned)(((size_t)t * C16 * 4 + r) * plane + lane) * 16u;
             w_dst[i] = (unsigned)(t * 256 + r * 64 + lane) * 16u;
         }
-        auto load_b_group = [&](int cg, int cb, int g) {
+        // (wdma: the same nine 1-KiB pieces by LDS-DMA straight into weight buffer `buf` - no registers, no ds_write; the counted waits
+        // are the same, a DMA instruction counts on vmcnt like the load it replaces.  The target buffer is free at issue time: it was
+        // read during the previous tap group, which ended at the barrier just passed.)
+        const bool wdma = p.wdma != 0;
+        auto load_b_group = [&](int cg, int cb, int g, int buf) {
             const float* base = reinterpret_cast<const float*>(w8 + ((size_t)(9 * g) * C16 * 4 + (size_t)cb * 4) * plane + cg * 64);
+            if (wdma) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) wreg[i] = load16_untracked(base, w_src[i]);
+                for (int i = 0; i < 9; ++i) {
+                    const int j = pw + 4 * i;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + w_src[i]),
+                                                     (__attribute__((address_space(3))) void*)(ldb + buf * GB + (j >> 2) * 256 + (j & 3) * 64), 16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) wreg[i] = load16_untracked(base, w_src[i]);
+            }
         };
         auto store_b_group = [&](int buf) {
+            if (wdma) return;
             char* lbase = reinterpret_cast<char*>(ldb + buf * GB);
 #pragma unroll
             for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(lbase + w_dst[i]) = wreg[i];
@@ -1988,7 +2003,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
         unsigned m_cvt = inside_mask(cur.w), m_ld = m_cvt;
         for (int c = pt; c < p.Cout; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
         // prologue: first tile + first weight group in the open, loads of the second tile in flight
-        load_b_group(cur.w.cg, 0, 0);
+        load_b_group(cur.w.cg, 0, 0, 0);
         load_affine(cur.w, 0);
         { const float* b = tile_base(cur.w, 0); static_for<NP>([&](auto K) { load_piece(b, m_cvt, K); }); }
         NM_PRODUCER2_WAIT(0);
@@ -2009,20 +2024,20 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             // therefore complete at the step's LAST barrier, and the MFMA waves fetch a step's first operands after that barrier.
             // tap group 0: weights of this step's group 1 (into the buffer group 2 of the last step was read from); pieces 0-2.
             // Everything older than the 9 weight loads has landed after the first wait.
-            load_b_group(cur.w.cg, cur.cb, 1);
+            load_b_group(cur.w.cg, cur.cb, 1, gpar ^ 1);
             NM_PRODUCER2_WAIT(9);
             static_for<3>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
             NM_PRODUCER2_WAIT(3);                                   // the weight loads (older than the 3 new piece loads)
             store_b_group(gpar ^ 1);
             lds_barrier(); gpar ^= 1;
             // tap group 1: weights of this step's group 2; pieces 3-7
-            load_b_group(cur.w.cg, cur.cb, 2);
+            load_b_group(cur.w.cg, cur.cb, 2, gpar ^ 1);
             static_for<5>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 3>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 3>{}); });
             NM_PRODUCER2_WAIT(5);                                   // the weight loads: 5 piece loads are younger
             store_b_group(gpar ^ 1);
             lds_barrier(); gpar ^= 1;
             // tap group 2: weights of the next step's group 0; pieces 8-9; the halo tile is complete at this barrier
-            load_b_group(s1.w.cg, s1.cb, 0);
+            load_b_group(s1.w.cg, s1.cb, 0, gpar ^ 1);
             static_for<2>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 8>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 8>{}); });
             load_affine(s2.w, s2.cb);                               // (sc / sh are free: piece 9 was their last user)
             NM_PRODUCER2_WAIT(0);
@@ -2549,6 +2564,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.st_z = p.st_y = p.st_x = 0;
     p.in_alt = in.alt; p.in_map = in.brickmap;
     p.in2 = in.p2; p.in2_scale = in.scale2; p.in2_shift = in.shift2; p.in2_slope = in.slope2;
+    p.wdma = nm_ls().f16p_dma;
     if (in.p2 && !(nm_conv_pool16_eligible(in.C, g.OD, g.OH, g.OW, w_packed16 != nullptr) && g.ks == 2 && g.stride == 2 && g.pad == 0 && !g.up2 && !in.brickmap)) {
         nm_set_error("conv: an un-materialised residual sum can only feed the k2 s2 split-fp16 pool kernel"); return NM_ERR_ARG;
     }
