@@ -25,6 +25,8 @@ NmLaunchState::NmLaunchState()
       // groups per brick it re-stages the input per group and measures a little slower than conv_f16s (A/B in one gpurun call)
       f16p(env_int("NM355_F16P", 2)),
       wgrad_tr(env_int("NM355_WGRAD_TR", 1)),       // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel
+      wgrad_u(env_int("NM355_WGRAD_U", 1)),         // 0: wgrad16t_kernel (conditional staging loads) instead of wgrad16u_kernel
+      wgrad_z(env_int("NM355_WGRAD_Z", 1)),         // 0: bricks in any order with their full halo (wgrad16u_kernel) instead of z-columns with a plane ring
       up2c(env_int("NM355_UP2C", 1)),               // 0: fused-upsample layers stay on conv_f16s (diagnostic / A-B)
       up2c_diag(env_int("NM355_UP2C_DIAG", 0)),
       vrnn_mid(env_int("NM355_VRNN_MID", 1)),          // 0: prior steps as six launches instead of three (A/B)

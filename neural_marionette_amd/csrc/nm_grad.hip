@@ -15,6 +15,7 @@
 //   upsample2_adjoint    adjoint of the trilinear x2 upsampling (gather form, deterministic).  HBM-bound.
 #include "nm_grad.h"
 #include <cstdlib>
+#include <utility>
 
 namespace {
 
@@ -738,6 +739,611 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
     }
 }
 
+// ---- wgrad16u: wgrad16t_kernel with a statically countable memory pipeline (round 3) -------------------------------------------
+// What held wgrad16t_kernel at 2.5-3x its MFMA time (6.8-8.2 us per 128-voxel brick against 2.7 us of matrix work) shows in its
+// ISA: (1) every staging load sat under a condition (halo voxel inside the volume, channel tail, "is there a next brick"), so the
+// compiler could not count the loads in flight and drained them - s_waitcnt vmcnt(0) - in front of every item's conversion,
+// i.e. right behind the loads it had just issued for the NEXT item: five exposed memory round trips per brick; (2) a k-step's
+// transposing LDS reads were issued in front of the MFMAs that consume them (their latency exposed once per k-step and wave),
+// and the fourth tap of waves 0..2 sat in a branch of its own (four reads, a full wait, three MFMAs).  Here: every load is
+// unconditional - the address of an item that does not exist is replaced by the tensor's first element and its value multiplied
+// by zero - and "no next brick" fetches the current one again; the dY tensor's affine comes from an identity table when it has
+// none; the body is instantiated for 4 and 3 taps and the wave picks its copy once, outside the brick loop; a k-step requests the
+// NEXT k-step's operands before its own MFMAs.  Nothing inside the brick loop branches, so every wait is a counted one.
+__device__ float w16u_ident[16] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+struct W16uHi { u32x2 a[2]; u32x2 x[3]; };       // hi halves of a k-step's operands: dY (2 transposing reads), halo row (3) - requested one k-step ahead
+struct W16uLo { u32x2 a[2]; u32x2 x[3]; };       // lo halves, requested at the top of their own k-step (first used behind the hi x hi MFMAs)
+struct W16uExt { u32x2 h[2], l[2]; };            // the fourth tap's X operand
+
+#define W16U_PIN4(v) asm volatile("" : "+v"(v))
+template <typename F, int... I>
+__device__ __forceinline__ void w16u_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void w16u_static_for(F&& f) { w16u_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+template <int V> using ic_ = std::integral_constant<int, V>;
+template <int NT, int DBG, bool SINGLE>
+__device__ __forceinline__ void wgrad16u_run(const WgradParams& p, const int w) {
+    extern __shared__ char lds8[];
+    float* xtab = reinterpret_cast<float*>(lds8 + WT_LDS);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int tp = blockIdx.y, mt = tp / p.n_tiles, nt = tp % p.n_tiles, m0 = mt * 32, n0 = nt * 32;
+    f32x16 acc[NT], accl[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accl[j][r] = 0.f; }
+    const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, cb = (lane >> 4) & 1;
+    // per-lane LDS byte offsets of the three operand streams (buffer base and the k-step's row are added per use: immediates)
+    const int a_off = 2 * WT_XB + ((lh * 8 + q) * 32 + 16 * cb + 4 * pp) * 2;
+    const int b_lane = ((lh * 10 + q) * 32 + 16 * cb + 4 * pp) * 2;
+    const int x_off = b_lane + (((w / 3) * 10 + w % 3) * 10) * 64;
+    const int e_off = b_lane + ((2 * 10 + 2) * 10 + min(w, 2)) * 64;
+    const int per_frame = p.nbz * p.nby * p.nbx, total = p.in.N * per_frame;
+    const int oct = tid & 3;
+    for (int i = tid; i < p.in.N * 64; i += 512) {
+        const int n = i >> 6, which = (i >> 5) & 1, c = n0 + (i & 31);
+        xtab[i] = p.in.scale ? (c < p.Nc ? (which ? p.in.shift : p.in.scale)[(size_t)n * p.in.C + c] : 0.f) : (which ? 0.f : 1.f);
+    }
+    const int dummy_off = WT_LDS + p.in.N * 256;      // 32 B written by the threads without a fourth X item
+    int xn = 0, xoz = 0, xoy = 0, xox = 0;
+    auto locate = [&](int b) __attribute__((always_inline)) {
+        xn = b / per_frame; int r = b % per_frame;
+        const int bx = r % p.nbx; r /= p.nbx;
+        xoz = (r / p.nby) * 2; xoy = (r % p.nby) * 8; xox = bx * 8;
+    };
+    const bool ca_ok = n0 + 8 * oct < p.Nc, cb_ok = n0 + 8 * oct + 4 < p.Nc;
+    const bool ma_ok = m0 + 8 * oct < p.M, mb_ok = m0 + 8 * oct + 4 < p.M;
+    // X item k: halo voxel (tid >> 2) + 128 k as packed (hx, hy, hz, exists), channel octet oct
+    int hpack[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int hv0 = (tid >> 2) + 128 * k, hv = min(hv0, WT_HV - 1), hx = hv % 10, hy = (hv / 10) % 10, hz = hv / 100;
+        hpack[k] = hx | (hy << 8) | (hz << 16) | ((hv0 < WT_HV ? 1 : 0) << 24);
+    }
+    // two unconditional 16-byte loads; an item outside the volume (or the tile's channels) reads the tensor's first element and is
+    // multiplied by zero at its conversion.  (The unpacking goes through an opaque copy: as a loop invariant the compiler keeps the
+    // twelve coordinates in registers of their own, spills them, and a scratch reload queues behind the loads in flight.)
+    auto x_inside = [&](int hp, int& gx, int& gy, int& gz) __attribute__((always_inline)) {
+        gx = xox - 1 + (hp & 255); gy = xoy - 1 + ((hp >> 8) & 255); gz = xoz - 1 + ((hp >> 16) & 255);
+        return (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && (hp >> 24) != 0;
+    };
+    auto x_issue = [&](int k, f32x4& a, f32x4& b) __attribute__((always_inline)) {
+        int hp = hpack[k], gx, gy, gz;
+        asm volatile("" : "+v"(hp));
+        const bool in = x_inside(hp, gx, gy, gz);
+        const long long off = ((((long long)xn * p.in.D + gz) * p.in.H + gy) * p.in.W + gx) * (long long)p.in.C + n0 + 8 * oct;
+        const float* src = p.in.p + off;
+        const float* sa = in && ca_ok ? src : p.in.p;
+        const float* sb = in && cb_ok ? src + 4 : p.in.p;
+        a = *reinterpret_cast<const f32x4*>(sa); b = *reinterpret_cast<const f32x4*>(sb);
+    };
+    // the dY item: brick voxel tid >> 2, channel octet; values now, the tensor's pending affine (identity table without one) one
+    // k-step ahead of the conversion
+    auto d_issue = [&](f32x4& a, f32x4& b) __attribute__((always_inline)) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int bv = t >> 2, z = bv >> 6, y = (bv >> 3) & 7, x = bv & 7, m = m0 + 8 * (t & 3);
+        const float* src = p.dy.p + ((((size_t)xn * p.dy.D + xoz + z) * p.dy.H + xoy + y) * p.dy.W + xox + x) * p.dy.C + m;
+        a = *reinterpret_cast<const f32x4*>(ma_ok ? src : p.dy.p); b = *reinterpret_cast<const f32x4*>(mb_ok ? src + 4 : p.dy.p);
+    };
+    auto d_affine = [&](f32x4& sa, f32x4& sb, f32x4& ha, f32x4& hb) __attribute__((always_inline)) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const bool has = p.dy.scale != nullptr;
+        const size_t so = (size_t)xn * p.dy.C + m0 + 8 * (t & 3);
+        const float* ps = has ? p.dy.scale + so : w16u_ident; const float* ph = has ? p.dy.shift + so : w16u_ident + 8;
+        sa = *reinterpret_cast<const f32x4*>(ma_ok ? ps : w16u_ident); ha = *reinterpret_cast<const f32x4*>(ma_ok ? ph : w16u_ident + 8);
+        sb = *reinterpret_cast<const f32x4*>(mb_ok ? ps + 4 : w16u_ident); hb = *reinterpret_cast<const f32x4*>(mb_ok ? ph + 4 : w16u_ident + 8);
+    };
+    auto split_store = [&](const f32x4& a, const f32x4& b, char* hi, char* lo) __attribute__((always_inline)) {
+        unsigned h[4], l[4];
+        h[0] = pack_split(a[0], a[1], l[0]); h[1] = pack_split(a[2], a[3], l[1]);
+        h[2] = pack_split(b[0], b[1], l[2]); h[3] = pack_split(b[2], b[3], l[3]);
+        *reinterpret_cast<u32x4*>(hi) = u32x4{h[0], h[1], h[2], h[3]};
+        if constexpr (!SINGLE) *reinterpret_cast<u32x4*>(lo) = u32x4{l[0], l[1], l[2], l[3]};
+    };
+    // conversions: the item's registers pass through an opaque statement first - otherwise the compiler starts the arithmetic right
+    // behind the loads (it frees registers) and waits for them there
+    auto x_commit = [&](char* cbase, int k, int n, f32x4 a, f32x4 b) __attribute__((always_inline)) {
+        W16U_PIN4(a); W16U_PIN4(b);
+        int hp = hpack[k], gx, gy, gz;
+        asm volatile("" : "+v"(hp));
+        const bool in = x_inside(hp, gx, gy, gz);        // (recomputed: cheaper than a register carried from the request)
+        const float* t = xtab + n * 64 + 8 * oct;
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(t), sb = *reinterpret_cast<const f32x4*>(t + 4);
+        const f32x4 ha = *reinterpret_cast<const f32x4*>(t + 32), hb = *reinterpret_cast<const f32x4*>(t + 36);
+        const float ka = in && ca_ok ? 1.f : 0.f, kb = in && cb_ok ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = fmaf(a[j], sa[j], ha[j]); b[j] = fmaf(b[j], sb[j], hb[j]);
+            a[j] = fmaxf(a[j], a[j] * p.in.slope) * ka; b[j] = fmaxf(b[j], b[j] * p.in.slope) * kb;
+        }
+        char* hi = cbase + 8192 * k; char* lo = hi + WT_XB;                 // (voxel (tid >> 2) + 128 k, octet) = byte 16 tid + 8192 k
+        if (k == 3) { const bool item = tid < 64; hi = item ? hi : lds8 + dummy_off; lo = item ? lo : lds8 + dummy_off + 16; }
+        split_store(a, b, hi, lo);
+    };
+    auto d_commit = [&](char* cbase, f32x4 a, f32x4 b, f32x4 sa, f32x4 sb, f32x4 ha, f32x4 hb) __attribute__((always_inline)) {
+        W16U_PIN4(a); W16U_PIN4(b); W16U_PIN4(sa); W16U_PIN4(sb); W16U_PIN4(ha); W16U_PIN4(hb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = fmaf(a[j], sa[j], ha[j]); b[j] = fmaf(b[j], sb[j], hb[j]);
+            a[j] = fmaxf(a[j], a[j] * p.dy.slope) * (ma_ok ? 1.f : 0.f); b[j] = fmaxf(b[j], b[j] * p.dy.slope) * (mb_ok ? 1.f : 0.f);
+        }
+        split_store(a, b, cbase + 2 * WT_XB, cbase + 2 * WT_XB + WT_DB);
+    };
+    auto read_hi = [&](const char* buf, int s8, W16uHi& o) __attribute__((always_inline)) {
+        const char* ap = buf + a_off + s8 * 1024;
+        const char* lp = buf + x_off + (((s8 >> 2) * 10 + 2 * (s8 & 3)) * 10) * 64;
+        o.a[0] = tr_read(ap); o.a[1] = tr_read(ap + 4 * 64);
+        o.x[0] = tr_read(lp); o.x[1] = tr_read(lp + 4 * 64); o.x[2] = tr_read(lp + 8 * 64);
+    };
+    auto read_lo = [&](const char* buf, int s8, W16uLo& o) __attribute__((always_inline)) {
+        const char* ap = buf + a_off + s8 * 1024 + WT_DB;
+        const char* lp = buf + x_off + (((s8 >> 2) * 10 + 2 * (s8 & 3)) * 10) * 64 + WT_XB;
+        o.x[0] = tr_read(lp); o.x[1] = tr_read(lp + 4 * 64); o.x[2] = tr_read(lp + 8 * 64);
+        o.a[0] = tr_read(ap); o.a[1] = tr_read(ap + 4 * 64);
+    };
+    auto read_ext = [&](const char* buf, int s8, W16uExt& e) __attribute__((always_inline)) {
+        const char* xp = buf + e_off + (((s8 >> 2) * 10 + 2 * (s8 & 3)) * 10) * 64;
+        e.h[0] = tr_read(xp); e.h[1] = tr_read(xp + 4 * 64);
+        if constexpr (!SINGLE) { e.l[0] = tr_read(xp + WT_XB); e.l[1] = tr_read(xp + WT_XB + 4 * 64); }
+    };
+    auto shifted = [&](const u32x2& r0, const u32x2& r1, const u32x2& r2, half8 (&o)[3]) __attribute__((always_inline)) {
+        o[0] = __builtin_bit_cast(half8, u32x4{r0[0], r0[1], r1[0], r1[1]});
+        o[2] = __builtin_bit_cast(half8, u32x4{r0[1], r1[0], r1[1], r2[0]});
+        o[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(r0[1], r0[0], 16), __builtin_amdgcn_alignbit(r1[0], r0[1], 16),
+                                               __builtin_amdgcn_alignbit(r1[1], r1[0], 16), __builtin_amdgcn_alignbit(r2[0], r1[1], 16)});
+    };
+    auto mma = [&](const W16uHi& o, const W16uLo& ol, const W16uExt& e) __attribute__((always_inline)) {
+        const half8 ah = __builtin_bit_cast(half8, u32x4{o.a[0][0], o.a[0][1], o.a[1][0], o.a[1][1]});
+        half8 bh[3];
+        shifted(o.x[0], o.x[1], o.x[2], bh);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc[u], 0, 0, 0);
+        half8 eh;
+        if constexpr (NT == 4) {
+            eh = __builtin_bit_cast(half8, u32x4{e.h[0][0], e.h[0][1], e.h[1][0], e.h[1][1]});
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, eh, acc[3], 0, 0, 0);
+        }
+        if constexpr (!SINGLE) {
+            half8 bl[3];
+            shifted(ol.x[0], ol.x[1], ol.x[2], bl);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) accl[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], accl[u], 0, 0, 0);
+            const half8 al = __builtin_bit_cast(half8, u32x4{ol.a[0][0], ol.a[0][1], ol.a[1][0], ol.a[1][1]});
+            if constexpr (NT == 4)
+                accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, u32x4{e.l[0][0], e.l[0][1], e.l[1][0], e.l[1][1]}), accl[3], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) accl[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], accl[u], 0, 0, 0);
+            if constexpr (NT == 4) accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, eh, accl[3], 0, 0, 0);
+        }
+    };
+
+    int b = blockIdx.x, cur = 0;
+    if (b < total) {                                  // the first brick: plain fetch + convert (once per workgroup)
+        locate(b);
+        f32x4 a, c, sa, sb, ha, hb;
+        char* cbase = lds8 + tid * 16;
+        d_issue(a, c); d_affine(sa, sb, ha, hb); d_commit(cbase, a, c, sa, sb, ha, hb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x_issue(k, a, c); x_commit(cbase, k, xn, a, c); }
+    }
+    __syncthreads();
+    for (; b < total; b += p.S) {
+        const bool has_next = b + p.S < total;
+        const char* buf = lds8 + cur * WT_BUF;
+        char* cbase = lds8 + (cur ^ 1) * WT_BUF + tid * 16;
+        locate(has_next ? b + p.S : b);               // (no next brick: this one again, into the idle buffer)
+        // staging of the next brick, two items in flight: requested at the end of a k-step, converted at the end of the second (dY,
+        // X0, X1) or third (X2, X3) k-step after it
+        f32x4 da, db, dsa, dsb, dha, dhb, xa[4], xb[4];
+        constexpr bool STAGE = DBG != 2 && DBG != 3 && DBG != 4;
+        if (STAGE) d_issue(da, db);
+        W16uHi h0, h1;
+        W16uLo lo;
+        W16uExt e0;
+        if (DBG != 1) read_hi(buf, 0, h0);
+        // An item's conversion as six pieces (+ the request of a later item, + the dY affine's loads), placed by hand between the
+        // k-step's MFMAs: left to itself the scheduler issues the MFMAs back to back and the ~130 vector instructions as one block
+        // behind them, through which the matrix pipe idles (sched_group_barrier spreads some k-steps and not others).
+        f32x4 ca, cb, csa, csb, cha, chb;
+        float cka = 0.f, ckb = 0.f, cslope = 1.f;
+        unsigned ch[4], cl[4];
+        w16u_static_for<8>([&](auto S8) __attribute__((always_inline)) {
+            constexpr int s8 = decltype(S8)::value;
+            constexpr int CI = s8 >= 2 && s8 <= 6 ? s8 - 2 : -1;          // item converted in this k-step: 0 = dY, 1..4 = X item CI - 1
+            constexpr int RI = s8 <= 3 ? s8 : -1;                          // X item requested in this k-step
+            auto piece = [&](auto P) __attribute__((always_inline)) {
+                constexpr int pc = decltype(P)::value;
+                if constexpr (!STAGE) return;
+                if constexpr (CI >= 0 && pc == 0) {
+                    if constexpr (CI == 0) {
+                        ca = da; cb = db; csa = dsa; csb = dsb; cha = dha; chb = dhb;
+                        W16U_PIN4(ca); W16U_PIN4(cb); W16U_PIN4(csa); W16U_PIN4(csb); W16U_PIN4(cha); W16U_PIN4(chb);
+                        cka = ma_ok ? 1.f : 0.f; ckb = mb_ok ? 1.f : 0.f; cslope = p.dy.slope;
+                    } else {
+                        ca = xa[CI - 1]; cb = xb[CI - 1];
+                        W16U_PIN4(ca); W16U_PIN4(cb);
+                        int hp = hpack[CI - 1], gx, gy, gz;
+                        asm volatile("" : "+v"(hp));
+                        const bool in = x_inside(hp, gx, gy, gz);
+                        cka = in && ca_ok ? 1.f : 0.f; ckb = in && cb_ok ? 1.f : 0.f; cslope = p.in.slope;
+                        const float* t = xtab + xn * 64 + 8 * oct;
+                        csa = *reinterpret_cast<const f32x4*>(t); csb = *reinterpret_cast<const f32x4*>(t + 4);
+                        cha = *reinterpret_cast<const f32x4*>(t + 32); chb = *reinterpret_cast<const f32x4*>(t + 36);
+                    }
+                }
+                if constexpr (CI >= 0 && pc >= 1 && pc <= 4) {
+                    constexpr int j = (pc - 1) & 1;
+                    float v0, v1;
+                    if constexpr (pc <= 2) {
+                        v0 = fmaf(ca[2 * j], csa[2 * j], cha[2 * j]); v1 = fmaf(ca[2 * j + 1], csa[2 * j + 1], cha[2 * j + 1]);
+                        v0 = fmaxf(v0, v0 * cslope) * cka; v1 = fmaxf(v1, v1 * cslope) * cka;
+                    } else {
+                        v0 = fmaf(cb[2 * j], csb[2 * j], chb[2 * j]); v1 = fmaf(cb[2 * j + 1], csb[2 * j + 1], chb[2 * j + 1]);
+                        v0 = fmaxf(v0, v0 * cslope) * ckb; v1 = fmaxf(v1, v1 * cslope) * ckb;
+                    }
+                    ch[pc - 1] = pack_split(v0, v1, cl[pc - 1]);
+                }
+                if constexpr (CI >= 0 && pc == 5) {
+                    char* hi; char* lo_;
+                    if constexpr (CI == 0) { hi = cbase + 2 * WT_XB; lo_ = hi + WT_DB; }
+                    else {
+                        hi = cbase + 8192 * (CI - 1); lo_ = hi + WT_XB;
+                        if constexpr (CI == 4) { const bool item = tid < 64; hi = item ? hi : lds8 + dummy_off; lo_ = item ? lo_ : lds8 + dummy_off + 16; }
+                    }
+                    *reinterpret_cast<u32x4*>(hi) = u32x4{ch[0], ch[1], ch[2], ch[3]};
+                    if constexpr (!SINGLE) *reinterpret_cast<u32x4*>(lo_) = u32x4{cl[0], cl[1], cl[2], cl[3]};
+                }
+                if constexpr (RI >= 0 && pc == 6) x_issue(RI, xa[RI], xb[RI]);
+                if constexpr (s8 == 1 && pc == 7) d_affine(dsa, dsb, dha, dhb);
+            };
+            if constexpr (DBG == 1) {
+                w16u_static_for<8>([&](auto P) __attribute__((always_inline)) { piece(P); });
+            } else {
+                W16uHi& hc = (s8 & 1) ? h1 : h0;
+                W16uHi& hn = (s8 & 1) ? h0 : h1;
+                if (DBG == 3) { if (s8 == 0) { if (NT == 4) read_ext(buf, 0, e0); read_lo(buf, 0, lo); h1 = h0; } }
+                else {
+                    if (NT == 4) read_ext(buf, s8, e0);
+                    if (!SINGLE) read_lo(buf, s8, lo);
+                    if (s8 < 7) read_hi(buf, s8 + 1, hn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const W16uHi& o = DBG == 3 ? h0 : hc;
+                // the MFMAs in order, each followed by the piece of its position (DBG 5: all pieces behind the last MFMA instead)
+                auto slot = [&](auto P) __attribute__((always_inline)) {
+                    if constexpr (DBG != 5) { __builtin_amdgcn_sched_barrier(0); piece(P); __builtin_amdgcn_sched_barrier(0); }
+                };
+                const half8 ah = __builtin_bit_cast(half8, u32x4{o.a[0][0], o.a[0][1], o.a[1][0], o.a[1][1]});
+                half8 bh[3], eh;
+                shifted(o.x[0], o.x[1], o.x[2], bh);
+                if constexpr (NT == 4) eh = __builtin_bit_cast(half8, u32x4{e0.h[0][0], e0.h[0][1], e0.h[1][0], e0.h[1][1]});
+                constexpr int Q = NT == 4 ? 1 : 0;        // position shift behind each group's fourth MFMA
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc[0], 0, 0, 0); slot(ic_<0>{});
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc[1], 0, 0, 0); slot(ic_<1>{});
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[2], acc[2], 0, 0, 0); slot(ic_<2>{});
+                if constexpr (NT == 4) { acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, eh, acc[3], 0, 0, 0); slot(ic_<3>{}); }
+                if constexpr (!SINGLE) {
+                    half8 bl[3];
+                    shifted(lo.x[0], lo.x[1], lo.x[2], bl);
+                    accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], accl[0], 0, 0, 0); slot(ic_<3 + Q>{});
+                    accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], accl[1], 0, 0, 0); slot(ic_<4 + Q>{});
+                    accl[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], accl[2], 0, 0, 0); slot(ic_<5 + Q>{});
+                    if constexpr (NT == 4) {
+                        accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, u32x4{e0.l[0][0], e0.l[0][1], e0.l[1][0], e0.l[1][1]}), accl[3], 0, 0, 0);
+                        slot(ic_<7>{});
+                    }
+                    const half8 al = __builtin_bit_cast(half8, u32x4{lo.a[0][0], lo.a[0][1], lo.a[1][0], lo.a[1][1]});
+                    accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], accl[0], 0, 0, 0); slot(ic_<6 + 2 * Q>{});
+                    accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], accl[1], 0, 0, 0); slot(ic_<7 + 2 * Q>{});
+                    accl[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], accl[2], 0, 0, 0);
+                    if constexpr (NT == 4) accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, eh, accl[3], 0, 0, 0);
+                    if constexpr (DBG == 5) w16u_static_for<8>([&](auto P) __attribute__((always_inline)) { piece(P); });
+                    // (positions 8 .. 10 of the four-tap waves carry no piece: 8 pieces in all)
+                } else {
+                    // one product: the pieces beyond the three / four MFMAs follow the last one
+                    w16u_static_for<8 - 3 - Q>([&](auto P) __attribute__((always_inline)) { piece(ic_<decltype(P)::value + 3 + Q>{}); });
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (DBG != 4) __syncthreads();                    // (4: timing experiment without the brick barrier, no staging)
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = j < 3 ? 3 * w + j : 24 + w;
+        float* dst = p.part + (((size_t)blockIdx.x * gridDim.y + tp) * 27 + t) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][r] + accl[j][r] * (1.0f / W16_SPLIT);
+    }
+}
+
+template <int DBG, bool SINGLE = false>
+__global__ __launch_bounds__(512, 1) void wgrad16u_kernel(WgradParams p) {
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w < 3) wgrad16u_run<4, DBG, SINGLE>(p, w);
+    else wgrad16u_run<3, DBG, SINGLE>(p, w);
+}
+
+// ---- wgrad16z: wgrad16u walking its bricks along z with the shared halo planes kept in LDS -------------------------------------
+// A 2 x 8 x 8 brick needs the 4 x 10 x 10 halo of its input: 3.1 staged voxels per brick voxel, and the staging (activate, split,
+// 9-10 vector instructions per element at 4 issue cycles each) costs the SIMDs about as many cycles as the MFMAs - the kernel is
+// bound by vector issue, not by the matrix pipe.  Consecutive bricks of one (frame, y, x) column share two of their four halo
+// planes, so here a workgroup walks whole columns: the X tile is a ring of six z-planes (four being read, the next brick's two new
+// ones being written), and a brick stages 200 halo voxels instead of 400 - 1312 items instead of 2112 with the dY tile.  The first
+// brick of a column stages its four planes in the open (once per 16-32 bricks).  Plane z of the column lives in slot (z + 1) mod 6.
+#define WZ_PL (100 * 64)                  // one plane of one ring: 100 halo voxels x 32 fp16 channels
+#define WZ_XR (6 * WZ_PL)                 // hi ring; the lo ring follows
+#define WZ_D0 (2 * WZ_XR)                 // two dY buffers (hi 8 KB + lo 8 KB each)
+#define WZ_DBUF (2 * WT_DB)
+#define WZ_LDS (WZ_D0 + 2 * WZ_DBUF)
+
+template <int NT, int DBG, bool SINGLE>
+__device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) {
+    extern __shared__ char lds8[];
+    float* xtab = reinterpret_cast<float*>(lds8 + WZ_LDS);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int tp = blockIdx.y, mt = tp / p.n_tiles, nt = tp % p.n_tiles, m0 = mt * 32, n0 = nt * 32;
+    f32x16 acc[NT], accl[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accl[j][r] = 0.f; }
+    const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, cb = (lane >> 4) & 1;
+    const int dz = w / 3, dy = w % 3;
+    const int a_off = WZ_D0 + ((lh * 8 + q) * 32 + 16 * cb + 4 * pp) * 2;                        // dY tile: brick row 2 s + lh, voxel q
+    const int x_off = (((lh + dy) * 10 + q) * 32 + 16 * cb + 4 * pp) * 2;                        // within a plane: row 2 (s & 3) + lh + dy, x = q - 1
+    const int e_off = (((lh + 2) * 10 + q + min(w, 2)) * 32 + 16 * cb + 4 * pp) * 2;             // tap (2, 2, w)
+    const int ncols = p.in.N * p.nby * p.nbx;
+    const int oct = tid & 3;
+    for (int i = tid; i < p.in.N * 64; i += 512) {
+        const int n = i >> 6, which = (i >> 5) & 1, c = n0 + (i & 31);
+        xtab[i] = p.in.scale ? (c < p.Nc ? (which ? p.in.shift : p.in.scale)[(size_t)n * p.in.C + c] : 0.f) : (which ? 0.f : 1.f);
+    }
+    const int dummy_off = WZ_LDS + p.in.N * 256;
+    const bool ca_ok = n0 + 8 * oct < p.Nc, cb_ok = n0 + 8 * oct + 4 < p.Nc;
+    const bool ma_ok = m0 + 8 * oct < p.M, mb_ok = m0 + 8 * oct + 4 < p.M;
+    int xn = 0, xoy = 0, xox = 0;
+    // one 16-byte-pair item of the input: halo voxel (gz, xoy - 1 + hy, xox - 1 + hx); unconditional loads (wgrad16u)
+    auto x_load = [&](int gz, int hy, int hx, bool exists, f32x4& a, f32x4& b, bool& in) __attribute__((always_inline)) {
+        const int gy = xoy - 1 + hy, gx = xox - 1 + hx;
+        in = (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && exists;
+        const long long off = ((((long long)xn * p.in.D + gz) * p.in.H + gy) * p.in.W + gx) * (long long)p.in.C + n0 + 8 * oct;
+        const float* src = p.in.p + off;
+        a = *reinterpret_cast<const f32x4*>(in && ca_ok ? src : p.in.p); b = *reinterpret_cast<const f32x4*>(in && cb_ok ? src + 4 : p.in.p);
+    };
+    auto d_issue = [&](int bz, f32x4& a, f32x4& b) __attribute__((always_inline)) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int bv = t >> 2, z = bv >> 6, y = (bv >> 3) & 7, x = bv & 7, m = m0 + 8 * (t & 3);
+        const float* src = p.dy.p + ((((size_t)xn * p.dy.D + 2 * bz + z) * p.dy.H + xoy + y) * p.dy.W + xox + x) * p.dy.C + m;
+        a = *reinterpret_cast<const f32x4*>(ma_ok ? src : p.dy.p); b = *reinterpret_cast<const f32x4*>(mb_ok ? src + 4 : p.dy.p);
+    };
+    auto d_affine = [&](f32x4& sa, f32x4& sb, f32x4& ha, f32x4& hb) __attribute__((always_inline)) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const bool has = p.dy.scale != nullptr;
+        const size_t so = (size_t)xn * p.dy.C + m0 + 8 * (t & 3);
+        const float* ps = has ? p.dy.scale + so : w16u_ident; const float* ph = has ? p.dy.shift + so : w16u_ident + 8;
+        sa = *reinterpret_cast<const f32x4*>(ma_ok ? ps : w16u_ident); ha = *reinterpret_cast<const f32x4*>(ma_ok ? ph : w16u_ident + 8);
+        sb = *reinterpret_cast<const f32x4*>(mb_ok ? ps + 4 : w16u_ident); hb = *reinterpret_cast<const f32x4*>(mb_ok ? ph + 4 : w16u_ident + 8);
+    };
+    // conversion of one item in the open (column starts): affine, leaky ReLU, zero mask, split, two 16-byte stores
+    auto convert_store = [&](f32x4 a, f32x4 b, const f32x4& sa, const f32x4& sb, const f32x4& ha, const f32x4& hb, float slope, float ka, float kb,
+                             char* hi, char* lo) __attribute__((always_inline)) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = fmaf(a[j], sa[j], ha[j]); b[j] = fmaf(b[j], sb[j], hb[j]);
+            a[j] = fmaxf(a[j], a[j] * slope) * ka; b[j] = fmaxf(b[j], b[j] * slope) * kb;
+        }
+        h[0] = pack_split(a[0], a[1], l[0]); h[1] = pack_split(a[2], a[3], l[1]);
+        h[2] = pack_split(b[0], b[1], l[2]); h[3] = pack_split(b[2], b[3], l[3]);
+        *reinterpret_cast<u32x4*>(hi) = u32x4{h[0], h[1], h[2], h[3]};
+        if constexpr (!SINGLE) *reinterpret_cast<u32x4*>(lo) = u32x4{l[0], l[1], l[2], l[3]};
+    };
+    // the in-loop X items of a thread: voxel (tid >> 2) + 128 k of the 200 of the two new planes, as packed (hx, hy, plane, exists)
+    int npack[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int v0 = (tid >> 2) + 128 * k, v = min(v0, 199), pl = v / 100, pv = v % 100;
+        npack[k] = (pv % 10) | ((pv / 10) << 8) | (pl << 16) | ((v0 < 200 ? 1 : 0) << 24);
+    }
+    // (xb / db / eb: the lane's byte address of the stream in this brick's ring slot / dY buffer, one opaque register each - as an
+    //  expression of bz the compiler forms one address register per read)
+    auto read_hi = [&](int xb, int db, int s8, W16uHi& o) __attribute__((always_inline)) {
+        const char* ap = lds8 + db + s8 * 1024;
+        const char* lp = lds8 + xb + (2 * (s8 & 3) * 10) * 64;
+        o.a[0] = tr_read(ap); o.a[1] = tr_read(ap + 4 * 64);
+        o.x[0] = tr_read(lp); o.x[1] = tr_read(lp + 4 * 64); o.x[2] = tr_read(lp + 8 * 64);
+    };
+    auto read_lo = [&](int xb, int db, int s8, W16uLo& o) __attribute__((always_inline)) {
+        const char* ap = lds8 + db + s8 * 1024 + WT_DB;
+        const char* lp = lds8 + xb + (2 * (s8 & 3) * 10) * 64 + WZ_XR;
+        o.x[0] = tr_read(lp); o.x[1] = tr_read(lp + 4 * 64); o.x[2] = tr_read(lp + 8 * 64);
+        o.a[0] = tr_read(ap); o.a[1] = tr_read(ap + 4 * 64);
+    };
+    auto read_ext = [&](int eb, int s8, W16uExt& e) __attribute__((always_inline)) {
+        const char* xp = lds8 + eb + (2 * (s8 & 3) * 10) * 64;
+        e.h[0] = tr_read(xp); e.h[1] = tr_read(xp + 4 * 64);
+        if constexpr (!SINGLE) { e.l[0] = tr_read(xp + WZ_XR); e.l[1] = tr_read(xp + WZ_XR + 4 * 64); }
+    };
+    auto shifted = [&](const u32x2& r0, const u32x2& r1, const u32x2& r2, half8 (&o)[3]) __attribute__((always_inline)) {
+        o[0] = __builtin_bit_cast(half8, u32x4{r0[0], r0[1], r1[0], r1[1]});
+        o[2] = __builtin_bit_cast(half8, u32x4{r0[1], r1[0], r1[1], r2[0]});
+        o[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(r0[1], r0[0], 16), __builtin_amdgcn_alignbit(r1[0], r0[1], 16),
+                                               __builtin_amdgcn_alignbit(r1[1], r1[0], 16), __builtin_amdgcn_alignbit(r2[0], r1[1], 16)});
+    };
+    constexpr bool STAGE = DBG != 2;
+
+    int cur = 0;
+    for (int col = blockIdx.x; col < ncols; col += p.S) {
+        xn = col / (p.nby * p.nbx);
+        { const int r = col % (p.nby * p.nbx); xoy = (r / p.nbx) * 8; xox = (r % p.nbx) * 8; }
+        {   // column start: the four planes z = -1 .. 2 (slots 0 .. 3, contiguous) and the first dY tile, in the open, one item at a
+            // time (the accumulators are live: no registers for a batch)
+            {
+                f32x4 da, db, dsa, dsb, dha, dhb;
+                d_issue(0, da, db); d_affine(dsa, dsb, dha, dhb);
+                convert_store(da, db, dsa, dsb, dha, dhb, p.dy.slope, ma_ok ? 1.f : 0.f, mb_ok ? 1.f : 0.f,
+                              lds8 + WZ_D0 + cur * WZ_DBUF + tid * 16, lds8 + WZ_D0 + cur * WZ_DBUF + WT_DB + tid * 16);
+            }
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const int hv0 = (tid >> 2) + 128 * k, hv = min(hv0, 399);
+                f32x4 a, b; bool in;
+                x_load(hv / 100 - 1, (hv / 10) % 10, hv % 10, hv0 < 400, a, b, in);
+                const float* t = xtab + xn * 64 + 8 * oct;
+                const f32x4 sa = *reinterpret_cast<const f32x4*>(t), sb = *reinterpret_cast<const f32x4*>(t + 4);
+                const f32x4 ha = *reinterpret_cast<const f32x4*>(t + 32), hb = *reinterpret_cast<const f32x4*>(t + 36);
+                const bool item = hv0 < 400;
+                char* hi = item ? lds8 + tid * 16 + 8192 * k : lds8 + dummy_off; char* lo = item ? lds8 + tid * 16 + 8192 * k + WZ_XR : lds8 + dummy_off + 16;
+                convert_store(a, b, sa, sb, ha, hb, p.in.slope, in && ca_ok ? 1.f : 0.f, in && cb_ok ? 1.f : 0.f, hi, lo);
+            }
+        }
+        __syncthreads();
+        for (int bz = 0; bz < p.nbz; ++bz) {
+            // ring slots of this brick's operands: main line plane zb + dz, fourth tap plane zb + 2 (zb = k-step >> 2)
+            const int sl = __builtin_amdgcn_readfirstlane((2 * bz) % 6);       // slot of plane 2 bz - 1 (even: 0, 2, 4)
+            auto slot_off = [&](int k) __attribute__((always_inline)) { const int v = sl + k; return (v >= 6 ? v - 6 : v) * WZ_PL; };
+            int xb0 = x_off + slot_off(dz), xb1 = x_off + slot_off(dz + 1), eb0 = e_off + slot_off(2), eb1 = e_off + slot_off(3);
+            int dbs = a_off + cur * WZ_DBUF;
+            asm volatile("" : "+v"(xb0), "+v"(xb1), "+v"(eb0), "+v"(eb1), "+v"(dbs));
+            const int ndbuf = (cur ^ 1) * WZ_DBUF;
+            const int ns0 = slot_off(4), ns1 = slot_off(5);                    // slots of the next brick's two new planes
+            const int bzn = min(bz + 1, p.nbz - 1);        // (behind the column's last brick: its dY tile again, into the idle buffer)
+            f32x4 da, db, dsa, dsb, dha, dhb, xa[2], xb[2];
+            if (STAGE) d_issue(bzn, da, db);
+            W16uHi h0, h1;
+            W16uLo lo;
+            W16uExt e0;
+            if (DBG != 1) read_hi(xb0, dbs, 0, h0);
+            f32x4 ca, cb_, csa, csb, cha, chb;
+            float cka = 0.f, ckb = 0.f, cslope = 1.f;
+            unsigned ch[4], cl[4];
+            w16u_static_for<8>([&](auto S8) __attribute__((always_inline)) {
+                constexpr int s8 = decltype(S8)::value;
+                constexpr int CI = s8 == 2 ? 0 : (s8 == 4 ? 1 : (s8 == 5 ? 2 : -1));      // converted here: 0 = dY, 1 / 2 = X item 0 / 1
+                constexpr int RI = s8 <= 1 ? s8 : -1;                                      // X item requested here
+                auto piece = [&](auto P) __attribute__((always_inline)) {
+                    constexpr int pc = decltype(P)::value;
+                    if constexpr (!STAGE) return;
+                    if constexpr (CI >= 0 && pc == 0) {
+                        if constexpr (CI == 0) {
+                            ca = da; cb_ = db; csa = dsa; csb = dsb; cha = dha; chb = dhb;
+                            W16U_PIN4(ca); W16U_PIN4(cb_); W16U_PIN4(csa); W16U_PIN4(csb); W16U_PIN4(cha); W16U_PIN4(chb);
+                            cka = ma_ok ? 1.f : 0.f; ckb = mb_ok ? 1.f : 0.f; cslope = p.dy.slope;
+                        } else {
+                            ca = xa[CI - 1]; cb_ = xb[CI - 1];
+                            W16U_PIN4(ca); W16U_PIN4(cb_);
+                            int np = npack[CI - 1];
+                            asm volatile("" : "+v"(np));
+                            const int gz = 2 * bz + 3 + ((np >> 16) & 1), gy = xoy - 1 + ((np >> 8) & 255), gx = xox - 1 + (np & 255);
+                            const bool in = (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && (np >> 24) != 0;
+                            cka = in && ca_ok ? 1.f : 0.f; ckb = in && cb_ok ? 1.f : 0.f; cslope = p.in.slope;
+                            const float* t = xtab + xn * 64 + 8 * oct;
+                            csa = *reinterpret_cast<const f32x4*>(t); csb = *reinterpret_cast<const f32x4*>(t + 4);
+                            cha = *reinterpret_cast<const f32x4*>(t + 32); chb = *reinterpret_cast<const f32x4*>(t + 36);
+                        }
+                    }
+                    if constexpr (CI >= 0 && pc >= 1 && pc <= 4) {
+                        constexpr int j = (pc - 1) & 1;
+                        float v0, v1;
+                        if constexpr (pc <= 2) {
+                            v0 = fmaf(ca[2 * j], csa[2 * j], cha[2 * j]); v1 = fmaf(ca[2 * j + 1], csa[2 * j + 1], cha[2 * j + 1]);
+                            v0 = fmaxf(v0, v0 * cslope) * cka; v1 = fmaxf(v1, v1 * cslope) * cka;
+                        } else {
+                            v0 = fmaf(cb_[2 * j], csb[2 * j], chb[2 * j]); v1 = fmaf(cb_[2 * j + 1], csb[2 * j + 1], chb[2 * j + 1]);
+                            v0 = fmaxf(v0, v0 * cslope) * ckb; v1 = fmaxf(v1, v1 * cslope) * ckb;
+                        }
+                        ch[pc - 1] = pack_split(v0, v1, cl[pc - 1]);
+                    }
+                    if constexpr (CI >= 0 && pc == 5) {
+                        char* hi; char* lo_;
+                        if constexpr (CI == 0) { hi = lds8 + WZ_D0 + ndbuf + tid * 16; lo_ = hi + WT_DB; }
+                        else {
+                            int np = npack[CI - 1];
+                            asm volatile("" : "+v"(np));
+                            const int pl = (np >> 16) & 1, pv = ((np >> 8) & 255) * 10 + (np & 255);
+                            hi = lds8 + (pl ? ns1 : ns0) + pv * 64 + oct * 16; lo_ = hi + WZ_XR;
+                            if constexpr (CI == 2) { const bool item = (np >> 24) != 0; hi = item ? hi : lds8 + dummy_off; lo_ = item ? lo_ : lds8 + dummy_off + 16; }
+                        }
+                        *reinterpret_cast<u32x4*>(hi) = u32x4{ch[0], ch[1], ch[2], ch[3]};
+                        if constexpr (!SINGLE) *reinterpret_cast<u32x4*>(lo_) = u32x4{cl[0], cl[1], cl[2], cl[3]};
+                    }
+                    if constexpr (RI >= 0 && pc == 6) {
+                        int np = npack[RI];
+                        asm volatile("" : "+v"(np));
+                        bool in;
+                        x_load(2 * bz + 3 + ((np >> 16) & 1), (np >> 8) & 255, np & 255, (np >> 24) != 0, xa[RI], xb[RI], in);
+                    }
+                    if constexpr (s8 == 0 && pc == 7) d_affine(dsa, dsb, dha, dhb);
+                };
+                if constexpr (DBG == 1) {
+                    w16u_static_for<8>([&](auto P) __attribute__((always_inline)) { piece(P); });
+                } else {
+                    W16uHi& hc = (s8 & 1) ? h1 : h0;
+                    W16uHi& hn = (s8 & 1) ? h0 : h1;
+                    if (NT == 4) read_ext(s8 < 4 ? eb0 : eb1, s8, e0);
+                    if (!SINGLE) read_lo(s8 < 4 ? xb0 : xb1, dbs, s8, lo);
+                    if (s8 < 7) read_hi(s8 + 1 < 4 ? xb0 : xb1, dbs, s8 + 1, hn);
+                    __builtin_amdgcn_sched_barrier(0);
+                    auto slot = [&](auto P) __attribute__((always_inline)) {
+                        __builtin_amdgcn_sched_barrier(0); piece(P); __builtin_amdgcn_sched_barrier(0);
+                    };
+                    const half8 ah = __builtin_bit_cast(half8, u32x4{hc.a[0][0], hc.a[0][1], hc.a[1][0], hc.a[1][1]});
+                    half8 bh[3], eh;
+                    shifted(hc.x[0], hc.x[1], hc.x[2], bh);
+                    if constexpr (NT == 4) eh = __builtin_bit_cast(half8, u32x4{e0.h[0][0], e0.h[0][1], e0.h[1][0], e0.h[1][1]});
+                    constexpr int Q = NT == 4 ? 1 : 0;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc[0], 0, 0, 0); slot(ic_<0>{});
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc[1], 0, 0, 0); slot(ic_<1>{});
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[2], acc[2], 0, 0, 0); slot(ic_<2>{});
+                    if constexpr (NT == 4) { acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, eh, acc[3], 0, 0, 0); slot(ic_<3>{}); }
+                    if constexpr (!SINGLE) {
+                        half8 bl[3];
+                        shifted(lo.x[0], lo.x[1], lo.x[2], bl);
+                        accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], accl[0], 0, 0, 0); slot(ic_<3 + Q>{});
+                        accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], accl[1], 0, 0, 0); slot(ic_<4 + Q>{});
+                        accl[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], accl[2], 0, 0, 0); slot(ic_<5 + Q>{});
+                        if constexpr (NT == 4) {
+                            accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, u32x4{e0.l[0][0], e0.l[0][1], e0.l[1][0], e0.l[1][1]}), accl[3], 0, 0, 0);
+                            slot(ic_<7>{});
+                        }
+                        const half8 al = __builtin_bit_cast(half8, u32x4{lo.a[0][0], lo.a[0][1], lo.a[1][0], lo.a[1][1]});
+                        accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], accl[0], 0, 0, 0); slot(ic_<6 + 2 * Q>{});
+                        accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], accl[1], 0, 0, 0); slot(ic_<7 + 2 * Q>{});
+                        accl[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], accl[2], 0, 0, 0);
+                        if constexpr (NT == 4) accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, eh, accl[3], 0, 0, 0);
+                    } else {
+                        w16u_static_for<8 - 3 - Q>([&](auto P) __attribute__((always_inline)) { piece(ic_<decltype(P)::value + 3 + Q>{}); });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = j < 3 ? 3 * w + j : 24 + w;
+        float* dst = p.part + (((size_t)blockIdx.x * gridDim.y + tp) * 27 + t) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[j][r] + accl[j][r] * (1.0f / W16_SPLIT);
+    }
+}
+
+template <int DBG, bool SINGLE = false>
+__global__ __launch_bounds__(512, 1) void wgrad16z_kernel(WgradParams p) {
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w < 3) wgrad16z_run<4, DBG, SINGLE>(p, w);
+    else wgrad16z_run<3, DBG, SINGLE>(p, w);
+}
+
 // ---- first layer, sparse form ----------------------------------------------------------------------------------------------------
 // dW[co][c][tap] of conv5(cat[occ, x1, x2, x3]): the three coordinate channels do not depend on the frame, so their gradient is
 // the dense kernel (MODE 2) on ONE frame holding sum_n dy[n]; the occupancy channel is 1-3 % dense, so its gradient is a gather:
@@ -1319,6 +1925,8 @@ WgradPlan plan_wgrad(int N, int OD, int OH, int OW, int M, int Nc, int ks, int s
         q.m_tiles = (M + 31) / 32; p.n_tiles = (Nc + 31) / 32; p.groups = 27;
         const int tiles = q.m_tiles * p.n_tiles, total = N * p.nbz * p.nby * p.nbx;
         p.S = max(1, min(total, 256 / tiles));
+        // wgrad16z_kernel hands out whole (frame, y, x) columns: no more workgroups per tile pair than columns
+        if (nm_ls().wgrad_tr && nm_ls().wgrad_z && p.nbz >= 2 && N <= 96) p.S = max(1, min(p.S, N * p.nby * p.nbx));
         q.slots = p.S; q.lds = W16_LDS; q.ws_floats = (size_t)q.slots * tiles * 27 * 1024;
         return q;
     }
@@ -1366,13 +1974,50 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16u_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16u_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16u_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16u_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16u_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16u_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16u_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 nm_set_error("wgrad16t: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
             }
             attr_t = true;
         }
         const size_t ldsb = WT_LDS + (size_t)q.p.in.N * 64 * sizeof(float) + 64;
         const dim3 grid(q.p.S, q.m_tiles * q.p.n_tiles);
+        if (nm_ls().wgrad_z && q.p.nbz >= 2) {
+            static bool attr_z = false;
+            if (!attr_z) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    nm_set_error("wgrad16z: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
+                }
+                attr_z = true;
+            }
+            const WgradParams& pz = q.p;                  // (plan_wgrad bounded S by the column count)
+            const size_t ldsz = WZ_LDS + (size_t)q.p.in.N * 64 * sizeof(float) + 64;
+            const dim3 gz(pz.S, q.m_tiles * q.p.n_tiles);
+            if (q.p.dbg == 1) hipLaunchKernelGGL(wgrad16z_kernel<1>, gz, dim3(512), ldsz, s, pz);
+            else if (q.p.dbg == 2) hipLaunchKernelGGL(wgrad16z_kernel<2>, gz, dim3(512), ldsz, s, pz);
+            else if (nm_conv_single()) hipLaunchKernelGGL((wgrad16z_kernel<0, true>), gz, dim3(512), ldsz, s, pz);
+            else hipLaunchKernelGGL(wgrad16z_kernel<0>, gz, dim3(512), ldsz, s, pz);
+            return nm_check_hip(hipGetLastError(), "wgrad16z launch");
+        }
+        if (nm_ls().wgrad_u) {
+            if (q.p.dbg == 1) hipLaunchKernelGGL(wgrad16u_kernel<1>, grid, dim3(512), ldsb, s, q.p);
+            else if (q.p.dbg == 2) hipLaunchKernelGGL(wgrad16u_kernel<2>, grid, dim3(512), ldsb, s, q.p);
+            else if (q.p.dbg == 3) hipLaunchKernelGGL(wgrad16u_kernel<3>, grid, dim3(512), ldsb, s, q.p);
+            else if (q.p.dbg == 4) hipLaunchKernelGGL(wgrad16u_kernel<4>, grid, dim3(512), ldsb, s, q.p);
+            else if (q.p.dbg == 5) hipLaunchKernelGGL(wgrad16u_kernel<5>, grid, dim3(512), ldsb, s, q.p);
+            else if (nm_conv_single()) hipLaunchKernelGGL((wgrad16u_kernel<0, true>), grid, dim3(512), ldsb, s, q.p);
+            else hipLaunchKernelGGL(wgrad16u_kernel<0>, grid, dim3(512), ldsb, s, q.p);
+            return nm_check_hip(hipGetLastError(), "wgrad16u launch");
+        }
         if (q.p.dbg == 1) hipLaunchKernelGGL(wgrad16t_kernel<1>, grid, dim3(512), ldsb, s, q.p);
         else if (q.p.dbg == 2) hipLaunchKernelGGL(wgrad16t_kernel<2>, grid, dim3(512), ldsb, s, q.p);
         else if (nm_conv_single()) hipLaunchKernelGGL((wgrad16t_kernel<0, true>), grid, dim3(512), ldsb, s, q.p);
