@@ -1178,11 +1178,27 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
                                                __builtin_amdgcn_alignbit(r1[1], r1[0], 16), __builtin_amdgcn_alignbit(r2[0], r1[1], 16)});
     };
     constexpr bool STAGE = DBG != 2;
+    float* dtab = reinterpret_cast<float*>(lds8 + WZ_LDS + p.in.N * 256 + 64);      // the dY tensor's pending affine of the column's frame: [scale 32][shift 32]
+    const long long xstep = 2LL * p.in.H * p.in.W * p.in.C, dstep = 2LL * p.dy.H * p.dy.W * p.dy.C;    // one brick further along z
 
     int cur = 0;
     for (int col = blockIdx.x; col < ncols; col += p.S) {
         xn = col / (p.nby * p.nbx);
         { const int r = col % (p.nby * p.nbx); xoy = (r / p.nbx) * 8; xox = (r % p.nbx) * 8; }
+        // per-thread constants of the column: element offsets of its in-loop items for the brick behind brick 0, (y, x) validity
+        long long xoff[2], doff;
+        int inyx = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int np = npack[k], gy = xoy - 1 + ((np >> 8) & 255), gx = xox - 1 + (np & 255);
+            if ((unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && (np >> 24) != 0) inyx |= 1 << k;
+            xoff[k] = ((((long long)xn * p.in.D + 3 + ((np >> 16) & 1)) * p.in.H + gy) * p.in.W + gx) * (long long)p.in.C + n0 + 8 * oct;
+        }
+        { const int bv = tid >> 2; doff = ((((long long)xn * p.dy.D + (bv >> 6)) * p.dy.H + xoy + ((bv >> 3) & 7)) * p.dy.W + xox + (bv & 7)) * (long long)p.dy.C + m0 + 8 * oct; }
+        if (tid < 64) {
+            const int which = tid >> 5, c = m0 + (tid & 31);
+            dtab[tid] = p.dy.scale && c < p.M ? (which ? p.dy.shift : p.dy.scale)[(size_t)xn * p.dy.C + c] : (which ? 0.f : 1.f);
+        }
         {   // column start: the four planes z = -1 .. 2 (slots 0 .. 3, contiguous) and the first dY tile, in the open, one item at a
             // time (the accumulators are live: no registers for a batch)
             {
@@ -1215,111 +1231,150 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
             const int ndbuf = (cur ^ 1) * WZ_DBUF;
             const int ns0 = slot_off(4), ns1 = slot_off(5);                    // slots of the next brick's two new planes
             const int bzn = min(bz + 1, p.nbz - 1);        // (behind the column's last brick: its dY tile again, into the idle buffer)
-            f32x4 da, db, dsa, dsb, dha, dhb, xa[2], xb[2];
-            if (STAGE) d_issue(bzn, da, db);
+            f32x4 da, db, xa[2], xb[2];
             W16uHi h0, h1;
             W16uLo lo;
             W16uExt e0;
             if (DBG != 1) read_hi(xb0, dbs, 0, h0);
-            f32x4 ca, cb_, csa, csb, cha, chb;
-            float cka = 0.f, ckb = 0.f, cslope = 1.f;
+            // The next brick's staging as 60 pieces of 4-6 vector instructions, one behind each MFMA (position g = 9 k-step + MFMA;
+            // the one-product instantiation runs three per MFMA): a wave hides about five single-issue instructions in the 32 cycles
+            // of a 32x32x16 MFMA, and blocks of 20+ (a whole element pair per gap) measured no better than the conversion as one
+            // block behind the k-step's MFMAs.  g 0 dY request, 10-11 / 16-17 the two X requests, 18-31 / 32-45 / 46-59 the conversions of
+            // dY / X0 / X1 (14 pieces each: table reads, 4 x (affine + slope, max + mask, split), stores).
+            f32x4 ca, cb_, csa, cha;
+            float cka = 0.f, ckb = 0.f, cslope = 1.f, t0 = 0.f, t1 = 0.f, u0 = 0.f, u1 = 0.f;
             unsigned ch[4], cl[4];
-            w16u_static_for<8>([&](auto S8) __attribute__((always_inline)) {
-                constexpr int s8 = decltype(S8)::value;
-                constexpr int CI = s8 == 2 ? 0 : (s8 == 4 ? 1 : (s8 == 5 ? 2 : -1));      // converted here: 0 = dY, 1 / 2 = X item 0 / 1
-                constexpr int RI = s8 <= 1 ? s8 : -1;                                      // X item requested here
-                auto piece = [&](auto P) __attribute__((always_inline)) {
-                    constexpr int pc = decltype(P)::value;
-                    if constexpr (!STAGE) return;
-                    if constexpr (CI >= 0 && pc == 0) {
-                        if constexpr (CI == 0) {
-                            ca = da; cb_ = db; csa = dsa; csb = dsb; cha = dha; chb = dhb;
-                            W16U_PIN4(ca); W16U_PIN4(cb_); W16U_PIN4(csa); W16U_PIN4(csb); W16U_PIN4(cha); W16U_PIN4(chb);
+            const float* xsrc = nullptr; bool xin = false;
+            auto piece = [&](auto GG) __attribute__((always_inline)) {
+                constexpr int g = decltype(GG)::value;
+                if constexpr (!STAGE || g < 0 || g >= 60) return;
+                if constexpr (g == 0) {
+                    const float* src = p.dy.p + (doff + bzn * dstep);
+                    da = *reinterpret_cast<const f32x4*>(ma_ok ? src : p.dy.p); db = *reinterpret_cast<const f32x4*>(mb_ok ? src + 4 : p.dy.p);
+                }
+                if constexpr (g == 10 || g == 16) {
+                    constexpr int k = g == 10 ? 0 : 1;
+                    int np = npack[k];
+                    asm volatile("" : "+v"(np));
+                    xin = ((inyx >> k) & 1) != 0 && 2 * bz + 3 + ((np >> 16) & 1) < p.in.D;
+                    xsrc = p.in.p + (xoff[k] + bz * xstep);
+                }
+                if constexpr (g == 11 || g == 17) {
+                    constexpr int k = g == 11 ? 0 : 1;
+                    xa[k] = *reinterpret_cast<const f32x4*>(xin && ca_ok ? xsrc : p.in.p); xb[k] = *reinterpret_cast<const f32x4*>(xin && cb_ok ? xsrc + 4 : p.in.p);
+                }
+                if constexpr (g >= 18) {
+                    constexpr int item = (g - 18) / 14, c = (g - 18) % 14;          // item 0 = dY, 1 / 2 = X item 0 / 1
+                    if constexpr (c == 0) {
+                        const float* t;
+                        if constexpr (item == 0) {
+                            ca = da; cb_ = db;
                             cka = ma_ok ? 1.f : 0.f; ckb = mb_ok ? 1.f : 0.f; cslope = p.dy.slope;
+                            t = dtab + 8 * oct;
                         } else {
-                            ca = xa[CI - 1]; cb_ = xb[CI - 1];
-                            W16U_PIN4(ca); W16U_PIN4(cb_);
-                            int np = npack[CI - 1];
+                            ca = xa[item - 1]; cb_ = xb[item - 1];
+                            int np = npack[item - 1];
                             asm volatile("" : "+v"(np));
-                            const int gz = 2 * bz + 3 + ((np >> 16) & 1), gy = xoy - 1 + ((np >> 8) & 255), gx = xox - 1 + (np & 255);
-                            const bool in = (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && (np >> 24) != 0;
+                            const bool in = ((inyx >> (item - 1)) & 1) != 0 && 2 * bz + 3 + ((np >> 16) & 1) < p.in.D;
                             cka = in && ca_ok ? 1.f : 0.f; ckb = in && cb_ok ? 1.f : 0.f; cslope = p.in.slope;
-                            const float* t = xtab + xn * 64 + 8 * oct;
-                            csa = *reinterpret_cast<const f32x4*>(t); csb = *reinterpret_cast<const f32x4*>(t + 4);
-                            cha = *reinterpret_cast<const f32x4*>(t + 32); chb = *reinterpret_cast<const f32x4*>(t + 36);
+                            t = xtab + xn * 64 + 8 * oct;
                         }
-                    }
-                    if constexpr (CI >= 0 && pc >= 1 && pc <= 4) {
-                        constexpr int j = (pc - 1) & 1;
-                        float v0, v1;
-                        if constexpr (pc <= 2) {
-                            v0 = fmaf(ca[2 * j], csa[2 * j], cha[2 * j]); v1 = fmaf(ca[2 * j + 1], csa[2 * j + 1], cha[2 * j + 1]);
-                            v0 = fmaxf(v0, v0 * cslope) * cka; v1 = fmaxf(v1, v1 * cslope) * cka;
-                        } else {
-                            v0 = fmaf(cb_[2 * j], csb[2 * j], chb[2 * j]); v1 = fmaf(cb_[2 * j + 1], csb[2 * j + 1], chb[2 * j + 1]);
-                            v0 = fmaxf(v0, v0 * cslope) * ckb; v1 = fmaxf(v1, v1 * cslope) * ckb;
-                        }
-                        ch[pc - 1] = pack_split(v0, v1, cl[pc - 1]);
-                    }
-                    if constexpr (CI >= 0 && pc == 5) {
+                        W16U_PIN4(ca); W16U_PIN4(cb_);
+                        csa = *reinterpret_cast<const f32x4*>(t); cha = *reinterpret_cast<const f32x4*>(t + 32);
+                    } else if constexpr (c <= 12) {
+                        constexpr int j = (c - 1) / 3, part = (c - 1) % 3, e = 2 * (j & 1);
+                        if constexpr (part == 0) {
+                            // (one table pair of registers: the second channel quad's scale / shift replace the first's once it is through)
+                            if constexpr (j == 2) {
+                                const float* t = item == 0 ? dtab + 8 * oct : xtab + xn * 64 + 8 * oct;
+                                csa = *reinterpret_cast<const f32x4*>(t + 4); cha = *reinterpret_cast<const f32x4*>(t + 36);
+                            }
+                            if constexpr (j < 2) { t0 = fmaf(ca[e], csa[e], cha[e]); t1 = fmaf(ca[e + 1], csa[e + 1], cha[e + 1]); }
+                            else { t0 = fmaf(cb_[e], csa[e], cha[e]); t1 = fmaf(cb_[e + 1], csa[e + 1], cha[e + 1]); }
+                            u0 = t0 * cslope; u1 = t1 * cslope;
+                        } else if constexpr (part == 1) {
+                            const float k = j < 2 ? cka : ckb;
+                            t0 = fmaxf(t0, u0) * k; t1 = fmaxf(t1, u1) * k;
+                        } else ch[j] = pack_split(t0, t1, cl[j]);
+                    } else {
                         char* hi; char* lo_;
-                        if constexpr (CI == 0) { hi = lds8 + WZ_D0 + ndbuf + tid * 16; lo_ = hi + WT_DB; }
+                        if constexpr (item == 0) { hi = lds8 + WZ_D0 + ndbuf + tid * 16; lo_ = hi + WT_DB; }
                         else {
-                            int np = npack[CI - 1];
+                            int np = npack[item - 1];
                             asm volatile("" : "+v"(np));
-                            const int pl = (np >> 16) & 1, pv = ((np >> 8) & 255) * 10 + (np & 255);
-                            hi = lds8 + (pl ? ns1 : ns0) + pv * 64 + oct * 16; lo_ = hi + WZ_XR;
-                            if constexpr (CI == 2) { const bool item = (np >> 24) != 0; hi = item ? hi : lds8 + dummy_off; lo_ = item ? lo_ : lds8 + dummy_off + 16; }
+                            const int pv = ((np >> 8) & 255) * 10 + (np & 255);
+                            hi = lds8 + ((np >> 16) & 1 ? ns1 : ns0) + pv * 64 + oct * 16; lo_ = hi + WZ_XR;
+                            if constexpr (item == 2) { const bool it = (np >> 24) != 0; hi = it ? hi : lds8 + dummy_off; lo_ = it ? lo_ : lds8 + dummy_off + 16; }
                         }
                         *reinterpret_cast<u32x4*>(hi) = u32x4{ch[0], ch[1], ch[2], ch[3]};
                         if constexpr (!SINGLE) *reinterpret_cast<u32x4*>(lo_) = u32x4{cl[0], cl[1], cl[2], cl[3]};
                     }
-                    if constexpr (RI >= 0 && pc == 6) {
-                        int np = npack[RI];
-                        asm volatile("" : "+v"(np));
-                        bool in;
-                        x_load(2 * bz + 3 + ((np >> 16) & 1), (np >> 8) & 255, np & 255, (np >> 24) != 0, xa[RI], xb[RI], in);
-                    }
-                    if constexpr (s8 == 0 && pc == 7) d_affine(dsa, dsb, dha, dhb);
-                };
+                }
+            };
+            w16u_static_for<8>([&](auto S8) __attribute__((always_inline)) {
+                constexpr int s8 = decltype(S8)::value;
                 if constexpr (DBG == 1) {
-                    w16u_static_for<8>([&](auto P) __attribute__((always_inline)) { piece(P); });
+                    w16u_static_for<9>([&](auto P) __attribute__((always_inline)) { piece(ic_<9 * s8 + decltype(P)::value>{}); });
                 } else {
                     W16uHi& hc = (s8 & 1) ? h1 : h0;
                     W16uHi& hn = (s8 & 1) ? h0 : h1;
-                    if (NT == 4) read_ext(s8 < 4 ? eb0 : eb1, s8, e0);
-                    if (!SINGLE) read_lo(s8 < 4 ? xb0 : xb1, dbs, s8, lo);
-                    if (s8 < 7) read_hi(s8 + 1 < 4 ? xb0 : xb1, dbs, s8 + 1, hn);
-                    __builtin_amdgcn_sched_barrier(0);
+                    const int xbc = s8 < 4 ? xb0 : xb1, xbn = s8 + 1 < 4 ? xb0 : xb1, ebc = s8 < 4 ? eb0 : eb1;
+                    const char* lpc = lds8 + xbc + (2 * (s8 & 3) * 10) * 64 + WZ_XR;                 // this k-step's lo halo row
+                    const char* apc = lds8 + dbs + s8 * 1024 + WT_DB;                               //              lo dY operand
+                    const char* lpn = lds8 + xbn + (2 * ((s8 + 1) & 3) * 10) * 64;                   // the next k-step's hi halo row
+                    const char* apn = lds8 + dbs + (s8 + 1) * 1024;
+                    const char* epc = lds8 + ebc + (2 * (s8 & 3) * 10) * 64;
+                    // behind MFMA number `pos`: this k-step's lo operands (first used by MFMA 3 / 6), the fourth tap's operand (its
+                    // MFMAs close the k-step), the next k-step's hi operands one read per gap - no block of 10-14 LDS reads in front of a
+                    // k-step's first MFMA - and the staging piece of the position
                     auto slot = [&](auto P) __attribute__((always_inline)) {
-                        __builtin_amdgcn_sched_barrier(0); piece(P); __builtin_amdgcn_sched_barrier(0);
+                        constexpr int pos = decltype(P)::value;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!SINGLE) {
+                            if constexpr (pos == 0) { lo.a[0] = tr_read(apc); lo.a[1] = tr_read(apc + 4 * 64); }
+                            if constexpr (pos == 1) { lo.x[0] = tr_read(lpc); lo.x[1] = tr_read(lpc + 4 * 64); lo.x[2] = tr_read(lpc + 8 * 64); }
+                            if constexpr (NT == 4 && pos == 2) { e0.h[0] = tr_read(epc); e0.h[1] = tr_read(epc + 4 * 64); }
+                            if constexpr (NT == 4 && pos == 3) { e0.l[0] = tr_read(epc + WZ_XR); e0.l[1] = tr_read(epc + WZ_XR + 4 * 64); }
+                            if constexpr (s8 < 7) {
+                                if constexpr (pos == 4) hn.a[0] = tr_read(apn);
+                                if constexpr (pos == 5) hn.a[1] = tr_read(apn + 4 * 64);
+                                if constexpr (pos == 6) hn.x[0] = tr_read(lpn);
+                                if constexpr (pos == 7) hn.x[1] = tr_read(lpn + 4 * 64);
+                                if constexpr (pos == 8) hn.x[2] = tr_read(lpn + 8 * 64);
+                            }
+                            if constexpr (pos < 9) piece(ic_<9 * s8 + pos>{});
+                        } else {
+                            if constexpr (NT == 4 && pos == 0) { e0.h[0] = tr_read(epc); e0.h[1] = tr_read(epc + 4 * 64); }
+                            if constexpr (s8 < 7 && pos == 1) { hn.a[0] = tr_read(apn); hn.a[1] = tr_read(apn + 4 * 64); }
+                            if constexpr (s8 < 7 && pos == 2) { hn.x[0] = tr_read(lpn); hn.x[1] = tr_read(lpn + 4 * 64); hn.x[2] = tr_read(lpn + 8 * 64); }
+                            piece(ic_<9 * s8 + 3 * pos>{}); piece(ic_<9 * s8 + 3 * pos + 1>{}); piece(ic_<9 * s8 + 3 * pos + 2>{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     };
                     const half8 ah = __builtin_bit_cast(half8, u32x4{hc.a[0][0], hc.a[0][1], hc.a[1][0], hc.a[1][1]});
-                    half8 bh[3], eh;
+                    half8 bh[3];
                     shifted(hc.x[0], hc.x[1], hc.x[2], bh);
-                    if constexpr (NT == 4) eh = __builtin_bit_cast(half8, u32x4{e0.h[0][0], e0.h[0][1], e0.h[1][0], e0.h[1][1]});
-                    constexpr int Q = NT == 4 ? 1 : 0;
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc[0], 0, 0, 0); slot(ic_<0>{});
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc[1], 0, 0, 0); slot(ic_<1>{});
                     acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[2], acc[2], 0, 0, 0); slot(ic_<2>{});
-                    if constexpr (NT == 4) { acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, eh, acc[3], 0, 0, 0); slot(ic_<3>{}); }
                     if constexpr (!SINGLE) {
+                        const half8 al = __builtin_bit_cast(half8, u32x4{lo.a[0][0], lo.a[0][1], lo.a[1][0], lo.a[1][1]});
+                        accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], accl[0], 0, 0, 0); slot(ic_<3>{});
+                        accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], accl[1], 0, 0, 0); slot(ic_<4>{});
+                        accl[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], accl[2], 0, 0, 0); slot(ic_<5>{});
                         half8 bl[3];
                         shifted(lo.x[0], lo.x[1], lo.x[2], bl);
-                        accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], accl[0], 0, 0, 0); slot(ic_<3 + Q>{});
-                        accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], accl[1], 0, 0, 0); slot(ic_<4 + Q>{});
-                        accl[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], accl[2], 0, 0, 0); slot(ic_<5 + Q>{});
+                        accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], accl[0], 0, 0, 0); slot(ic_<6>{});
+                        accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], accl[1], 0, 0, 0); slot(ic_<7>{});
+                        accl[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], accl[2], 0, 0, 0); slot(ic_<8>{});
                         if constexpr (NT == 4) {
+                            const half8 eh = __builtin_bit_cast(half8, u32x4{e0.h[0][0], e0.h[0][1], e0.h[1][0], e0.h[1][1]});
+                            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, eh, acc[3], 0, 0, 0);
+                            accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, eh, accl[3], 0, 0, 0);
                             accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, u32x4{e0.l[0][0], e0.l[0][1], e0.l[1][0], e0.l[1][1]}), accl[3], 0, 0, 0);
-                            slot(ic_<7>{});
                         }
-                        const half8 al = __builtin_bit_cast(half8, u32x4{lo.a[0][0], lo.a[0][1], lo.a[1][0], lo.a[1][1]});
-                        accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], accl[0], 0, 0, 0); slot(ic_<6 + 2 * Q>{});
-                        accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], accl[1], 0, 0, 0); slot(ic_<7 + 2 * Q>{});
-                        accl[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], accl[2], 0, 0, 0);
-                        if constexpr (NT == 4) accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, eh, accl[3], 0, 0, 0);
-                    } else {
-                        w16u_static_for<8 - 3 - Q>([&](auto P) __attribute__((always_inline)) { piece(ic_<decltype(P)::value + 3 + Q>{}); });
+                    } else if constexpr (NT == 4) {
+                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, u32x4{e0.h[0][0], e0.h[0][1], e0.h[1][0], e0.h[1][1]}), acc[3], 0, 0, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -2000,7 +2055,7 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
                 attr_z = true;
             }
             const WgradParams& pz = q.p;                  // (plan_wgrad bounded S by the column count)
-            const size_t ldsz = WZ_LDS + (size_t)q.p.in.N * 64 * sizeof(float) + 64;
+            const size_t ldsz = WZ_LDS + (size_t)q.p.in.N * 64 * sizeof(float) + 64 + 256;   // tiles, X affine table, dummy item, dY affine table
             const dim3 gz(pz.S, q.m_tiles * q.p.n_tiles);
             if (q.p.dbg == 1) hipLaunchKernelGGL(wgrad16z_kernel<1>, gz, dim3(512), ldsz, s, pz);
             else if (q.p.dbg == 2) hipLaunchKernelGGL(wgrad16z_kernel<2>, gz, dim3(512), ldsz, s, pz);
