@@ -26,6 +26,7 @@ NmLaunchState::NmLaunchState()
       f16p(env_int("NM355_F16P", 2)),
       wgrad_tr(env_int("NM355_WGRAD_TR", 1)),       // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel
       wgrad_u(env_int("NM355_WGRAD_U", 1)),         // 0: wgrad16t_kernel (conditional staging loads) instead of wgrad16u_kernel
+      tail_rank1(env_int("NM355_TAIL_RANK1", 1)),   // 0: the decoder tail's backward materialises its [F][G^3][32] gradient (A/B)
       wgrad_z(env_int("NM355_WGRAD_Z", 1)),         // 0: bricks in any order with their full halo (wgrad16u_kernel) instead of z-columns with a plane ring
       up2c(env_int("NM355_UP2C", 1)),               // 0: fused-upsample layers stay on conv_f16s (diagnostic / A-B)
       up2c_diag(env_int("NM355_UP2C_DIAG", 0)),

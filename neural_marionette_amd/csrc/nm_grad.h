@@ -24,7 +24,9 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
 //   dz = dA * lrelu'(scale*y + shift);   partials: per (frame, block, channel) (sum dz, sum dz*y)
 int nm_gnb_blocks_per_frame(int voxels);
 // dA_mul (optional, here and in gnb_apply / absmax): device scalar dA is multiplied by on read (the producer left it scaled by 2^k)
-int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul = nullptr);
+// dv, wv (optional, here and in gnb_apply): dA is the outer product dv[n][voxel] * wv[channel] and the dA pointer is not read
+int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul = nullptr,
+                           const float* dv = nullptr, const float* wv = nullptr);
 // coef[n][c] = (c1, c2, c3, 0) with dy = c1*dz + c2*y + c3;  dgn[n][c] = (dgamma_n, dbeta_n, dbias_n, 0)
 // fpart: the forward partial sums (sum y, sum y^2) the conv epilogue left, [N][nblk_f][C][2]; chsum (optional): the per-channel totals
 // of them that the forward finalisation left ([N][C][2] doubles, nm_launch_gn_finalize) - then fpart is not read
@@ -38,7 +40,7 @@ int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipSt
 // dy = c1*dz + c2*y + c3 (coef) or dy = dz (coef == nullptr)
 // amax (optional): device word that receives max |dy| as float bits (integer atomicMax; zero it first)
 int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax = nullptr,
-                        const float* dA_mul = nullptr);
+                        const float* dA_mul = nullptr, const float* dv = nullptr, const float* wv = nullptr);
 // Power-of-two operand scaling of the data-gradient convolutions in the split-fp16 conv mode: gradients are often
 // below the fp16 normal range (6e-5), where the hi/lo split loses its low bits; dy is read as dy * 2^k through the lazy
 // affine of the conv kernels and the result is multiplied by 2^-k (exact).

@@ -895,31 +895,6 @@ __device__ __forceinline__ void wgrad16u_run(const WgradParams& p, const int w) 
         o[1] = __builtin_bit_cast(half8, u32x4{__builtin_amdgcn_alignbit(r0[1], r0[0], 16), __builtin_amdgcn_alignbit(r1[0], r0[1], 16),
                                                __builtin_amdgcn_alignbit(r1[1], r1[0], 16), __builtin_amdgcn_alignbit(r2[0], r1[1], 16)});
     };
-    auto mma = [&](const W16uHi& o, const W16uLo& ol, const W16uExt& e) __attribute__((always_inline)) {
-        const half8 ah = __builtin_bit_cast(half8, u32x4{o.a[0][0], o.a[0][1], o.a[1][0], o.a[1][1]});
-        half8 bh[3];
-        shifted(o.x[0], o.x[1], o.x[2], bh);
-#pragma unroll
-        for (int u = 0; u < 3; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc[u], 0, 0, 0);
-        half8 eh;
-        if constexpr (NT == 4) {
-            eh = __builtin_bit_cast(half8, u32x4{e.h[0][0], e.h[0][1], e.h[1][0], e.h[1][1]});
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, eh, acc[3], 0, 0, 0);
-        }
-        if constexpr (!SINGLE) {
-            half8 bl[3];
-            shifted(ol.x[0], ol.x[1], ol.x[2], bl);
-#pragma unroll
-            for (int u = 0; u < 3; ++u) accl[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], accl[u], 0, 0, 0);
-            const half8 al = __builtin_bit_cast(half8, u32x4{ol.a[0][0], ol.a[0][1], ol.a[1][0], ol.a[1][1]});
-            if constexpr (NT == 4)
-                accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, u32x4{e.l[0][0], e.l[0][1], e.l[1][0], e.l[1][1]}), accl[3], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 3; ++u) accl[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], accl[u], 0, 0, 0);
-            if constexpr (NT == 4) accl[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, eh, accl[3], 0, 0, 0);
-        }
-    };
-
     int b = blockIdx.x, cur = 0;
     if (b < total) {                                  // the first brick: plain fetch + convert (once per workgroup)
         locate(b);
@@ -1612,8 +1587,10 @@ __global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restri
 // The same partial sums with 16-byte loads, four channels per thread and four voxels in flight (C % 4 == 0, C <= 256 with 1024 / C
 // a whole number: every layer of the network).  The one-float-per-thread form above keeps two dependent 4-byte loads in flight per
 // thread and reached 0.54 of the HBM rate on the 64^3 layers (2 reads of 2.1 GB in 1.6 ms).
+// (dv, wv: dA given as the outer product dv[n][voxel] * wv[channel] instead of a tensor - the decoder's last conv layer, whose
+//  incoming gradient is the 1x1 tail conv's weight row times one scalar per voxel: 67 MB instead of 2.1 GB, read twice)
 __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restrict__ dA, TensorRef y, int voxels, float* __restrict__ part,
-                                                            const float* __restrict__ dmul) {
+                                                            const float* __restrict__ dmul, const float* __restrict__ dv, const float* __restrict__ wv) {
     __shared__ f32x4 sh[256 * 2];
     const float mm = dmul ? *dmul : 1.0f;
     const int n = blockIdx.y, blk = blockIdx.x, C = y.C, C4 = C >> 2;
@@ -1626,6 +1603,13 @@ __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restr
         const int VB = nm_gnb_vb(voxels), v0 = blk * VB, v1 = min(voxels, v0 + VB);
         const float* yp = y.p + (size_t)n * voxels * C + c;
         const float* dp = dA + (size_t)n * voxels * C + c;
+        const float* dvp = dv + (size_t)n * voxels;
+        f32x4 w4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (dv) w4 = *reinterpret_cast<const f32x4*>(wv + c);
+        auto grad = [&](int vv) __attribute__((always_inline)) {
+            if (dv) { const float d = dvp[vv]; return f32x4{d * w4[0], d * w4[1], d * w4[2], d * w4[3]}; }
+            return *reinterpret_cast<const f32x4*>(dp + (size_t)vv * C);
+        };
         auto add = [&](const f32x4& yy, const f32x4& dd, int u) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1640,12 +1624,12 @@ __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 yy[u] = *reinterpret_cast<const f32x4*>(yp + (size_t)(v + u * lanes) * C);
-                dd[u] = *reinterpret_cast<const f32x4*>(dp + (size_t)(v + u * lanes) * C);
+                dd[u] = grad(v + u * lanes);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) add(yy[u], dd[u], u & 1);
         }
-        for (; v < v1; v += lanes) add(*reinterpret_cast<const f32x4*>(yp + (size_t)v * C), *reinterpret_cast<const f32x4*>(dp + (size_t)v * C), 0);
+        for (; v < v1; v += lanes) add(*reinterpret_cast<const f32x4*>(yp + (size_t)v * C), grad(v), 0);
     }
     sh[threadIdx.x * 2] = s1[0] + s1[1]; sh[threadIdx.x * 2 + 1] = s2[0] + s2[1];
     __syncthreads();
@@ -1763,7 +1747,8 @@ __device__ __forceinline__ void block_absmax(float m, unsigned* amax) {
 }
 
 __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict__ dA, TensorRef y, const float* __restrict__ coef,
-                                                        float* __restrict__ dy, unsigned* __restrict__ amax, const float* __restrict__ dmul) {
+                                                        float* __restrict__ dy, unsigned* __restrict__ amax, const float* __restrict__ dmul,
+                                                        const float* __restrict__ dv, const float* __restrict__ wv) {
     float mx = 0.f;
     const float mm = dmul ? *dmul : 1.0f;
     // grid (blocks, frames): 32-bit index arithmetic inside a frame (no 64-bit division per 16-byte item)
@@ -1773,7 +1758,12 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
         const size_t e = n * per_frame + r;
         const int c = (int)(r % (unsigned)y.C);
         const f32x4 yy = *reinterpret_cast<const f32x4*>(y.p + e);
-        f32x4 d = *reinterpret_cast<const f32x4*>(dA + e);
+        f32x4 d;
+        if (dv) {
+            const float dd = dv[n * (per_frame / (unsigned)y.C) + r / (unsigned)y.C];
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + c);
+            d = f32x4{dd * w4[0], dd * w4[1], dd * w4[2], dd * w4[3]};
+        } else d = *reinterpret_cast<const f32x4*>(dA + e);
         d[0] *= mm; d[1] *= mm; d[2] *= mm; d[3] *= mm;
         if (y.slope != 1.0f) {
             f32x4 z = yy;
@@ -2211,11 +2201,12 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
 
 int nm_gnb_blocks_per_frame(int voxels) { const int vb = nm_gnb_vb(voxels); return (voxels + vb - 1) / vb; }
 
-int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul) {
+int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hipStream_t s, const float* dA_mul, const float* dv, const float* wv) {
     if (y.C > 256 || y.C <= 0) { nm_set_error("gnb_partials: C=%d unsupported", y.C); return NM_ERR_ARG; }
     const int voxels = y.D * y.H * y.W;
+    if (dv && !(y.C % 4 == 0 && 1024 % y.C == 0)) { nm_set_error("gnb_partials: outer-product gradient needs C %% 4 == 0 and 1024 %% C == 0"); return NM_ERR_ARG; }
     if (y.C % 4 == 0 && 1024 % y.C == 0)
-        hipLaunchKernelGGL(gnb_partials4_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul);
+        hipLaunchKernelGGL(gnb_partials4_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul, dv, wv);
     else
         hipLaunchKernelGGL(gnb_partials_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul);
     return nm_check_hip(hipGetLastError(), "gnb_partials launch");
@@ -2246,12 +2237,13 @@ int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipSt
     return nm_check_hip(hipGetLastError(), "sum_partials launch");
 }
 
-int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax, const float* dA_mul) {
+int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, float* dy, hipStream_t s, unsigned* amax, const float* dA_mul,
+                        const float* dv, const float* wv) {
     if (y.C % 4) { nm_set_error("gnb_apply: C %% 4 != 0"); return NM_ERR_ARG; }
     const size_t frame4 = (size_t)y.D * y.H * y.W * y.C / 4;
     if (frame4 * 4 >= ((size_t)1 << 31)) { nm_set_error("gnb_apply: frame too large"); return NM_ERR_ARG; }
     const unsigned bx = (unsigned)min((frame4 + 255) / 256, (size_t)max(1, 4096 / max(y.N, 1)));
-    hipLaunchKernelGGL(gnb_apply_kernel, dim3(bx, y.N), dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul);
+    hipLaunchKernelGGL(gnb_apply_kernel, dim3(bx, y.N), dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
     return nm_check_hip(hipGetLastError(), "gnb_apply launch");
 }
 

@@ -4,8 +4,9 @@
 
 int nm_tail_bwd_blocks(int G);
 // dA [F][G^3][C] = gradient w.r.t. the activated decoder output; part [F][blocks][C+1] -> (d w14, d b14) via nm_launch_sum_rows
+// dvout (optional, C == 32): only the per-voxel factor is written, [F][G^3] - dA = dvout (x) w14[0..C) is never materialised
 int nm_launch_decoder_tail_bwd(const TensorRef& x, const float* w14, const float* target, const float* recon, const float* dloss, int G,
-                               float* dA, float* part, hipStream_t s);
+                               float* dA, float* part, hipStream_t s, float* dvout = nullptr);
 int nm_launch_sum_rows(const float* part, int rows, int cols, float* out, hipStream_t s);
 int nm_chamfer_bwd_blocks(int G);
 // ws: F * blocks * K * 3 floats; dkp [F][K][4] is accumulated into

@@ -80,9 +80,10 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TensorRef x, const float*
 // The network's decoder (C = 32): the voxel's activated channels stay in registers between the dot product and the outer
 // product, and the per-thread partial sums of d w14 live in registers too (the generic kernel above keeps them in LDS: 33
 // read-modify-writes per voxel), reduced once per block.
+// (dvout: the per-voxel factor alone - dA = dvout (x) w14 is then formed by the GroupNorm backward on read, nm_grad.h)
 __global__ __launch_bounds__(256) void tail_bwd32_kernel(TensorRef x, const float* __restrict__ w14, const float* __restrict__ target,
                                                          const float* __restrict__ recon, const float* __restrict__ dloss, float inv_count,
-                                                         size_t G3, float* __restrict__ dA, float* __restrict__ part) {
+                                                         size_t G3, float* __restrict__ dA, float* __restrict__ part, float* __restrict__ dvout) {
     constexpr int C = 32;
     __shared__ float sh[256 * 33];
     const int f = blockIdx.y;
@@ -110,13 +111,19 @@ __global__ __launch_bounds__(256) void tail_bwd32_kernel(TensorRef x, const floa
         const float p = recon[(size_t)f * G3 + v], y = target[(size_t)f * G3 + v];
         const float pq = (1.0f - p) * p;
         const float dv = coef * ((p - y) / fmaxf(pq, 1e-12f)) * pq * 10.0f * (1.0f - th * th);
-        float* pd = dA + ((size_t)f * G3 + v) * C;
+        if (dvout) {
+            dvout[(size_t)f * G3 + v] = dv;
 #pragma unroll
-        for (int c = 0; c < C; c += 4) {
-            f32x4 o;
+            for (int c = 0; c < C; ++c) acc[c] += dv * a[c];
+        } else {
+            float* pd = dA + ((size_t)f * G3 + v) * C;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[c + j] += dv * a[c + j]; o[j] = dv * w[c + j]; }
-            *reinterpret_cast<f32x4*>(pd + c) = o;
+            for (int c = 0; c < C; c += 4) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[c + j] += dv * a[c + j]; o[j] = dv * w[c + j]; }
+                *reinterpret_cast<f32x4*>(pd + c) = o;
+            }
         }
         acc[C] += dv;
     }
@@ -539,12 +546,13 @@ int grid_for(size_t work_items) { return (int)min((work_items + 255) / 256, (siz
 int nm_tail_bwd_blocks(int G) { return (int)(((size_t)G * G * G + NM_TAILB_VPB - 1) / NM_TAILB_VPB); }
 
 int nm_launch_decoder_tail_bwd(const TensorRef& x, const float* w14, const float* target, const float* recon, const float* dloss, int G,
-                               float* dA, float* part, hipStream_t s) {
+                               float* dA, float* part, hipStream_t s, float* dvout) {
+    if (dvout && x.C != 32) { nm_set_error("decoder_tail_bwd: the per-voxel form needs C == 32"); return NM_ERR_ARG; }
     if (x.C % 4 || !x.scale || x.C > 60) { nm_set_error("decoder_tail_bwd: needs a lazy GN input with C %% 4 == 0, C <= 60"); return NM_ERR_ARG; }
     const size_t G3 = (size_t)G * G * G;
     if (x.C == 32) {
         hipLaunchKernelGGL(tail_bwd32_kernel, dim3(nm_tail_bwd_blocks(G), x.N), dim3(256), 0, s, x, w14, target, recon, dloss,
-                           1.0f / ((float)x.N * (float)G3), G3, dA, part);
+                           1.0f / ((float)x.N * (float)G3), G3, dA, part, dvout);
         return nm_check_hip(hipGetLastError(), "decoder_tail_bwd launch");
     }
     const size_t lds = (size_t)256 * (x.C + 1) * sizeof(float);

@@ -693,8 +693,10 @@ TensorRef plain(const float* p, const TensorRef& like) { return mk(p, like.N, li
 // GroupNorm(+LeakyReLU) backward of a lazy tensor: returns dy (gradient of the raw conv output) and writes the gradients of
 // gamma / beta and of the bias of the producing conv
 // (amax, optional: device word that ends up holding max |dy|, for the operand scaling of the data-gradient conv)
+// dv / wv (optional): dA is the outer product dv[frame][voxel] * wv[channel] (the decoder's last conv layer) and is never materialised
 const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float* fpart, int nblk_f, const double* chsum,
-                      const std::string& bias_key, const float* dA, unsigned* amax = nullptr, const float* dA_mul = nullptr) {
+                      const std::string& bias_key, const float* dA, unsigned* amax = nullptr, const float* dA_mul = nullptr,
+                      const float* dv = nullptr, const float* wv = nullptr) {
     const int N = out.N, C = out.C, V = out.D * out.H * out.W;
     const int nbb = nm_gnb_blocks_per_frame(V);
     float* dy = nullptr;
@@ -705,14 +707,15 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
         float* coef = b.alloc((size_t)N * C * 4); float* dgn = b.alloc((size_t)N * C * 4);
         float* gg = b.grad(gn->key + ".weight", C); float* gb = b.grad(gn->key + ".bias", C); float* gbias = b.grad(bias_key, C);
         if (b.live()) {
-            b.run(nm_launch_gnb_partials(dA, out, bpart, b.s, dA_mul));
+            b.run(nm_launch_gnb_partials(dA, out, bpart, b.s, dA_mul, dv, wv));
             b.run(nm_launch_gnb_finalize(bpart, nbb, fpart, nblk_f, N, C, gn->groups, V, gn->gamma, 1e-5f, coef, dgn, b.s, chsum));
             b.run(nm_launch_sum_frames3(dgn, N, C, gg, gb, gbias, b.s));
-            b.run(nm_launch_gnb_apply(dA, out, coef, dy, b.s, amax, dA_mul));
+            b.run(nm_launch_gnb_apply(dA, out, coef, dy, b.s, amax, dA_mul, dv, wv));
         }
         b.ws.release(m);
         return dy;
     }
+    if (dv) { nm_set_error("detector_backward: outer-product gradient into a layer without GroupNorm"); b.rc = NM_ERR_STATE; return nullptr; }
     const float* res = dA;
     if (out.slope != 1.0f || dA_mul) {
         dy = b.alloc(numel_of(out));
@@ -756,7 +759,8 @@ struct DyScale {
 // dA_mul: device scalar the incoming dA still has to be multiplied by (the producing conv_bwd left its power-of-two scale in).
 // out_mul (optional): the caller feeds the result straight into the next conv_bwd as dA + dA_mul; then the un-scaling pass over
 // the returned tensor is skipped and *out_mul is the scalar to hand on (nullptr when the result is already unscaled).
-float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const float* dA_mul = nullptr, const float** out_mul = nullptr) {
+float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const float* dA_mul = nullptr, const float** out_mul = nullptr,
+                const float* dA_dv = nullptr, const float* dA_wv = nullptr) {
     const ConvW& w = *r.w;
     const TensorRef& in = r.in;
     float* din = need_din ? b.alloc((size_t)in.N * in.D * in.H * in.W * w.csel) : nullptr;
@@ -766,7 +770,7 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
     const bool split = nm_conv_get_mode() != 0;          // split-fp16 kernels: dy is read pre-scaled by a power of two
     DyScale ds;
     ds.prepare(b, split && r.stride == 1 && (w.ks == 3 || (need_din && w.wd16)), r.out.N * r.out.C, sc2_keep);
-    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, r.chsum, w.key + ".bias", dA, ds.amax, dA_mul);
+    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, r.chsum, w.key + ".bias", dA, ds.amax, dA_mul, dA_dv, dA_wv);
     const TensorRef dyT = plain(dy, r.out);
     const TensorRef dyS = ds.apply(b, dyT);
     {   // weight gradient
@@ -910,19 +914,23 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         const size_t m = b.ws.mark();
         const TensorRef& x = t.d11.out;
         const int tb = nm_tail_bwd_blocks(G), C = x.C;
-        float* dA = b.alloc((size_t)F * G3 * C);
+        // the gradient of the decoder's last activated tensor is d14's weight row times one factor per voxel: with 32 channels and a
+        // GroupNorm behind the layer only the factors are stored (67 MB for 2.1 GB) and its GroupNorm backward forms the products
+        const bool rank1 = C == 32 && t.d11.gn != nullptr && nm_ls().tail_rank1;
+        float* dA = rank1 ? nullptr : b.alloc((size_t)F * G3 * C);
+        float* dvox = rank1 ? b.alloc((size_t)F * G3) : nullptr;
         float* part = b.alloc((size_t)F * tb * (C + 1));
         float* g14 = b.alloc(C + 1);
         float* gw14 = b.grad(k2v + ".decode_voxel_from_combined_representation.14.weight", C);
         float* gb14 = b.grad(k2v + ".decode_voxel_from_combined_representation.14.bias", 1);
         if (b.live()) {
-            b.run(nm_launch_decoder_tail_bwd(x, d.d14, t.vox, t.recon, dloss, G, dA, part, b.s));
+            b.run(nm_launch_decoder_tail_bwd(x, d.d14, t.vox, t.recon, dloss, G, dA, part, b.s, dvox));
             b.run(nm_launch_sum_rows(part, F * tb, C + 1, g14, b.s));
             b.run(nm_check_hip(hipMemcpyAsync(gw14, g14, C * sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
             b.run(nm_check_hip(hipMemcpyAsync(gb14, g14 + C, sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
         }
         const float *m11 = nullptr, *m4 = nullptr;
-        float* dx = conv_bwd(b, t.d11, dA, true, nullptr, &m11);
+        float* dx = conv_bwd(b, t.d11, dA, true, nullptr, &m11, dvox, rank1 ? d.d14 : nullptr);
         dx = conv_bwd(b, t.d8, dx, true, m11);
         dx = conv_bwd(b, t.d4, dx, true, nullptr, &m4);
         dx = conv_bwd(b, t.d1, dx, true, m4);
