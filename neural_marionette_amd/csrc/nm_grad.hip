@@ -1135,17 +1135,6 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
         o.a[0] = tr_read(ap); o.a[1] = tr_read(ap + 4 * 64);
         o.x[0] = tr_read(lp); o.x[1] = tr_read(lp + 4 * 64); o.x[2] = tr_read(lp + 8 * 64);
     };
-    auto read_lo = [&](int xb, int db, int s8, W16uLo& o) __attribute__((always_inline)) {
-        const char* ap = lds8 + db + s8 * 1024 + WT_DB;
-        const char* lp = lds8 + xb + (2 * (s8 & 3) * 10) * 64 + WZ_XR;
-        o.x[0] = tr_read(lp); o.x[1] = tr_read(lp + 4 * 64); o.x[2] = tr_read(lp + 8 * 64);
-        o.a[0] = tr_read(ap); o.a[1] = tr_read(ap + 4 * 64);
-    };
-    auto read_ext = [&](int eb, int s8, W16uExt& e) __attribute__((always_inline)) {
-        const char* xp = lds8 + eb + (2 * (s8 & 3) * 10) * 64;
-        e.h[0] = tr_read(xp); e.h[1] = tr_read(xp + 4 * 64);
-        if constexpr (!SINGLE) { e.l[0] = tr_read(xp + WZ_XR); e.l[1] = tr_read(xp + WZ_XR + 4 * 64); }
-    };
     auto shifted = [&](const u32x2& r0, const u32x2& r1, const u32x2& r2, half8 (&o)[3]) __attribute__((always_inline)) {
         o[0] = __builtin_bit_cast(half8, u32x4{r0[0], r0[1], r1[0], r1[1]});
         o[2] = __builtin_bit_cast(half8, u32x4{r0[1], r1[0], r1[1], r2[0]});
