@@ -201,3 +201,23 @@ def test_conv3d_backward_valu_transposition_wgrad_variant():
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("env", [{"NM355_WGRAD_Z": "0"}, {"NM355_WGRAD_Z": "0", "NM355_WGRAD_U": "0"}, {"NM355_TAIL_RANK1": "0"}],
+                         ids=["wgrad16u", "wgrad16t", "tail-gradient-tensor"])
+def test_conv3d_backward_older_kernel_variants(env):
+    """The A/B partners of the round-3 defaults stay under parity: wgrad16u_kernel (bricks in any order, full halo per brick) and
+    wgrad16t_kernel (conditional staging loads) against the default wgrad16z_kernel, and the decoder tail's backward with its
+    [F][G^3][32] gradient materialised (NM355_TAIL_RANK1=0; that one re-runs the detector gradient fixtures).  The switches are read
+    when a context is created: child processes."""
+    import os, subprocess, sys
+    here = os.path.abspath(__file__)
+    if "NM355_TAIL_RANK1" in env:
+        target = [os.path.join(os.path.dirname(here), "test_train_detector_gpu.py"), "-k", "test_detector_gradients_vs_oracle_autograd or test_detector_gradients_vs_reference_fixture"]
+    else:
+        target = [here, "-k", "test_conv3d_backward and (split16 or f16) and k3 and not variant"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + target, env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=1500, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
