@@ -31,6 +31,8 @@ NmLaunchState::NmLaunchState()
       up2c(env_int("NM355_UP2C", 1)),               // 0: fused-upsample layers stay on conv_f16s (diagnostic / A-B)
       up2c_diag(env_int("NM355_UP2C_DIAG", 0)),
       vrnn_mid(env_int("NM355_VRNN_MID", 1)),          // 0: prior steps as six launches instead of three (A/B)
+      vrnn_postmid(env_int("NM355_VRNN_POSTMID", 0)),   // 1: posterior steps of encode as three launches (vrnn_post_mid_kernel): measured slower, see there
+      vrnn_nb(env_int("NM355_VRNN_NB", 2)),             // batch rows per wavefront pass of the VRNN row kernels (4 / 8: the slow instantiations, A/B)
       vrnn_gemm(env_int("NM355_VRNN_GEMM", 1)),    // 0: one wavefront per output row at every batch size (A/B)
       vrnn_graph(env_int("NM355_VRNN_GRAPH", 1)),       // 0: rollouts enqueue their launches one by one instead of replaying a captured graph (A/B)
       sparse_first(env_int("NM355_SPARSE_FIRST", 1)), // 0: the first layer writes its dense output in inference too (A/B)
@@ -115,6 +117,11 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
         delete c;
         return NM_ERR_HIP;
     }
+    if (hipMalloc(reinterpret_cast<void**>(&c->vrnn_cnt), 256 * sizeof(int32_t)) != hipSuccess || hipMemset(c->vrnn_cnt, 0, 256 * sizeof(int32_t)) != hipSuccess) {
+        nm_set_error("ctx_create: could not allocate the VRNN arrival counters");
+        delete c;
+        return NM_ERR_HIP;
+    }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_clip, hipEventDisableTiming) != hipSuccess ||
@@ -135,6 +142,7 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     for (void* p : ctx->owned) (void)hipFree(p);
     if (ctx->ws.base) (void)hipFree(ctx->ws.base);
     if (ctx->ws2.base) (void)hipFree(ctx->ws2.base);
+    if (ctx->vrnn_cnt) (void)hipFree(ctx->vrnn_cnt);
     if (ctx->ws_t.base) (void)hipFree(ctx->ws_t.base);
     if (ctx->copy_table) (void)hipFree(ctx->copy_table);
     if (ctx->pack_table) (void)hipFree(ctx->pack_table);

@@ -584,6 +584,197 @@ __global__ __launch_bounds__(1024) void vrnn_prior_mid_kernel(MidArgs a) {
     }
 }
 
+// ---- posterior step of encode (inference), middle phases: one workgroup per (sample, batch element) ---------------------------------
+// NOT the default (NM355_VRNN_POSTMID=1 selects it; parity-tested): measured against the six-launch step once the row kernels had
+// been fixed (pick_nb), it loses - encode alone 52.6 us per timestep against 40.7, and in the forward +0.4 ms: a 1024-thread,
+// 128-register workgroup only starts on a completely free CU, so beside the decoder's persistent convolutions it advances at their
+// kernel boundaries only (8 of 16 steps done when the decoder ends, against 11), and the two device-scope fences of the selection
+// write back / invalidate the L2 (40 us per launch in the forward's tail).  Kept as the measured alternative of BASELINE's "one
+// kernel per timestep".
+// hsvrnn_bvh.py:86-135: S posterior samples per clip and timestep, each decoded to keypoints; the sample nearest to the detected
+// keypoints is kept.  Here the step is three launches like a prior step of the rollout: h-phase, THIS kernel, GRU.  Workgroup (s, b) is vrnn_prior_mid_kernel with
+// the posterior's distribution (post2 on hid_post[b]) and noise eps[s][b], plus the squared distance of its keypoints to the
+// observation; the sample-0 workgroup of a clip also evaluates the prior's parameters and the KL term.  The LAST workgroup of a
+// clip to finish (device-scope counter behind a release fence; acquire fence before it reads the others' results) picks the
+// nearest sample - lowest index on ties, fk_kernel's scan - and copies its keypoints / latent / rotations to the step's outputs.
+// Arithmetic per row, the kinematic chain, the distance sum (joint order) and the KL reduction tree are fk_kernel's and the row
+// kernels': the fused step is bit-identical to the six-launch step (tests/test_network_gpu.py).
+struct PostArgs {
+    const float *hid_post, *hid_prior, *rh, *jh, *eps, *offset, *obs; int ldobs;     // [B][128] x4, (S,B,Z), [B][K][3], [B][ldobs]
+    const float *w_q2, *b_q2, *w_p2, *b_p2, *w_root0, *w_joint0, *w_root2, *b_root2, *w_joint2, *b_joint2;
+    const int32_t *parents, *lvl_joint, *lvl_start; int nlevels;
+    float *zall, *kpall, *rall, *dall;          // per (s, b): [S*B][Z], [S*B][128], [S*B][9K], [S*B]
+    int32_t* counter;                           // [B], zero between launches
+    float* out_kp; int ldkp; float* out_z; int ldz; float* out_R; int ldR; int32_t* best; int ldbest; float* kl; float* rec; int ldstat;
+    int B, S, K, Z, H;
+};
+
+__global__ __launch_bounds__(1024) void vrnn_post_mid_kernel(PostArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_z[128], s_hr[128], s_hj[128], s_root[36], s_rot[192], s_mu[128], s_sg[128];
+    __shared__ float s_Rl[32 * 9], s_Rg[32 * 9], s_pos[32 * 3], s_dk[32], s_red[256];
+    __shared__ int s_last, s_best;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+    const int sb = blockIdx.x, b = sb % a.B, smp = sb / a.B;
+    const int K = a.K, Z = a.Z, H = a.H, R0 = 3 + K, J6 = 6 * K, rows_c = R0 + J6;
+    f32x4 wa[MID_PAIRS], wb[MID_PAIRS], wc[MID_PAIRS];
+#pragma unroll
+    for (int u = 0; u < MID_PAIRS; ++u) {
+        const int p = wave * MID_PAIRS + u;
+        wa[u] = *reinterpret_cast<const f32x4*>(a.w_q2 + (size_t)(p + half * Z) * 128 + l32 * 4);
+        wb[u] = *reinterpret_cast<const f32x4*>((half ? a.w_joint0 : a.w_root0) + (size_t)p * (H + Z) + H + l32 * 4);
+        const int r = min(p * 2 + half, rows_c - 1);
+        const float* pc = r < R0 ? a.w_root2 + (size_t)r * 128 : a.w_joint2 + (size_t)(r - R0) * 128;
+        wc[u] = *reinterpret_cast<const f32x4*>(pc + l32 * 4);
+    }
+    const f32x4 xh = *reinterpret_cast<const f32x4*>(a.hid_post + (size_t)b * 128 + l32 * 4);
+    const int pl = wave * MID_PAIRS + (l32 < MID_PAIRS ? l32 : 0);
+    const float bias_a = a.b_q2[pl], bias_a2 = a.b_q2[pl + Z], epsv = a.eps[(size_t)sb * Z + pl];
+    const float add_b = (half ? a.jh : a.rh)[(size_t)b * 128 + pl];
+    const int rl = min(pl * 2 + half, rows_c - 1);
+    const float bias_c = *(rl < R0 ? a.b_root2 + rl : a.b_joint2 + (rl - R0));
+    const float obsv = a.obs[(size_t)b * a.ldobs + min(tid, K * 4 - 1)];
+    __shared__ FkTables tb;
+    fk_tables_load(tb, a.lvl_joint, a.lvl_start, a.parents, a.offset + (size_t)b * K * 3, K, a.nlevels, tid);
+    // ---- A. posterior distribution parameters and this workgroup's sample
+    {
+        float mine = 0.f, other = 0.f;
+#pragma unroll
+        for (int u = 0; u < MID_PAIRS; ++u) {
+            const float v = half_reduce(dot4(wa[u], xh));
+            const float o = __shfl_xor(v, 32);
+            if (l32 == u) { mine = v; other = o; }
+        }
+        if (!half && l32 < MID_PAIRS) {
+            const int p = wave * MID_PAIRS + l32;
+            const float mu = mine + bias_a, sraw = other + bias_a2;
+            const float sg = softplus(sraw) + 1e-4f;
+            const float z = mu + epsv * sg;
+            s_z[p] = z; s_mu[p] = mu; s_sg[p] = sg;
+            a.zall[(size_t)sb * Z + p] = z;
+        }
+    }
+    __syncthreads();
+    // ---- B. decoder hidden layers
+    {
+        const f32x4 xz = *reinterpret_cast<const f32x4*>(s_z + l32 * 4);
+        float mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < MID_PAIRS; ++u) {
+            const float v = half_reduce(dot4(wb[u], xz));
+            if (l32 == u) mine = v;
+        }
+        if (l32 < MID_PAIRS) (half ? s_hj : s_hr)[wave * MID_PAIRS + l32] = lrelu(mine + add_b, 0.01f);
+    }
+    __syncthreads();
+    // ---- C. heads
+    {
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(s_hr + l32 * 4);
+        const f32x4 xj = *reinterpret_cast<const f32x4*>(s_hj + l32 * 4);
+        float mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < MID_PAIRS; ++u) {
+            const int r = (wave * MID_PAIRS + u) * 2 + half;
+            const float v = half_reduce(dot4(wc[u], r < R0 ? xr : xj));
+            if (l32 == u) mine = v;
+        }
+        if (l32 < MID_PAIRS) {
+            const int r = (wave * MID_PAIRS + l32) * 2 + half;
+            if (r < R0) s_root[r] = tanhf(mine + bias_c);
+            else if (r < rows_c) s_rot[r - R0] = mine + bias_c;
+        }
+    }
+    // (the sample-0 workgroup: the prior's rows into the registers phase A is done with - in flight across D)
+    const bool klwg = smp == 0 && a.kl != nullptr;
+    f32x4 xp = xh;
+    float pb = 0.f, pb2 = 0.f;
+    if (klwg) {
+#pragma unroll
+        for (int u = 0; u < MID_PAIRS; ++u) {
+            const int p = wave * MID_PAIRS + u;
+            wa[u] = *reinterpret_cast<const f32x4*>(a.w_p2 + (size_t)(p + half * Z) * 128 + l32 * 4);
+        }
+        xp = *reinterpret_cast<const f32x4*>(a.hid_prior + (size_t)b * 128 + l32 * 4);
+        pb = a.b_p2[pl]; pb2 = a.b_p2[pl + Z];
+    }
+    __syncthreads();
+    // ---- D. forward kinematics
+    if (tid < K) {
+        const float* p = s_rot + tid * 6;
+        float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
+        float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
+        x0 /= nx; x1 /= nx; x2 /= nx;
+        float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+        float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
+        z0 /= nz; z1 /= nz; z2 /= nz;
+        float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
+        float* R = s_Rl + tid * 9;
+        R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
+    }
+    __syncthreads();
+    fk_levels(tb, a.nlevels, s_Rl, s_Rg, s_pos, s_root, 36, K, 1, 0, 0, tid, 1024);
+    // ---- E. this sample's keypoints, rotations, distance to the observation (fk_kernel: per-joint terms, summed in joint order)
+    float kpv = 0.f;
+    if (tid < K * 4) {
+        const int k = tid >> 2, c = tid & 3;
+        kpv = c < 3 ? s_pos[k * 3 + c] : (s_root[3 + k] + 1.0f) * 0.5f;
+        a.kpall[(size_t)sb * 128 + tid] = kpv;
+    }
+    if (tid < K * 9) a.rall[(size_t)sb * 9 * K + tid] = s_Rg[tid];
+    {
+        // u_c = obs - kp per component; lanes 4k .. 4k+3 hold joint k's four: ((u0^2 + u1^2) + u2^2) + u3^2
+        const float u = obsv - kpv, q = u * u;
+        const float q1 = __shfl_down(q, 1), q2 = __shfl_down(q, 2), q3 = __shfl_down(q, 3);
+        if (tid < K * 4 && (tid & 3) == 0) s_dk[tid >> 2] = ((q + q1) + q2) + q3;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float d = 0.f;
+        for (int k = 0; k < K; ++k) d += s_dk[k];
+        a.dall[sb] = d;
+    }
+    // ---- F. sample 0: prior parameters and the KL term (fk_kernel's 256-entry tree)
+    if (klwg) {
+        float mine = 0.f, other = 0.f;
+#pragma unroll
+        for (int u = 0; u < MID_PAIRS; ++u) {
+            const float v = half_reduce(dot4(wa[u], xp));
+            const float o = __shfl_xor(v, 32);
+            if (l32 == u) { mine = v; other = o; }
+        }
+        if (tid < 256) s_red[tid] = 0.f;
+        __syncthreads();
+        if (!half && l32 < MID_PAIRS) {
+            const int p = wave * MID_PAIRS + l32;
+            const float pmu = mine + pb, psg = softplus(other + pb2) + 1e-4f;
+            const float ratio = s_sg[p] / psg, vr = ratio * ratio, dm = (s_mu[p] - pmu) / psg;
+            s_red[p] = 0.f + 0.5f * (((vr + dm * dm) - 1.0f) - logf(vr));
+        }
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) { if (tid < st) s_red[tid] += s_red[tid + st]; __syncthreads(); }
+        if (tid == 0) a.kl[(size_t)b * a.ldstat] = s_red[0];
+    }
+    // ---- G. the clip's last workgroup selects
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(a.counter + b, 1) == a.S - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) {
+        int bi = 0; float bd = __builtin_nontemporal_load(a.dall + b);
+        for (int i = 1; i < a.S; ++i) { const float d = __builtin_nontemporal_load(a.dall + (size_t)i * a.B + b); if (d < bd) { bd = d; bi = i; } }
+        s_best = bi;
+        if (a.best) a.best[(size_t)b * a.ldbest] = bi;
+        if (a.rec) a.rec[(size_t)b * a.ldstat] = bd;
+        a.counter[b] = 0;
+    }
+    __syncthreads();
+    const size_t src = (size_t)s_best * a.B + b;
+    if (tid < K * 4) a.out_kp[(size_t)b * a.ldkp + tid] = __builtin_nontemporal_load(a.kpall + src * 128 + tid);
+    if (tid < Z) a.out_z[(size_t)b * a.ldz + tid] = __builtin_nontemporal_load(a.zall + src * Z + tid);
+    if (a.out_R && tid < K * 9) a.out_R[(size_t)b * a.ldR + tid] = __builtin_nontemporal_load(a.rall + src * 9 * K + tid);
+}
+
 // get_offset (hsvrnn_bvh.py:236-253): lower median over T of |p_k - p_parent(k)| times unit(offset_param[k])
 __global__ __launch_bounds__(64) void offsets_kernel(const float* __restrict__ kp, const float* __restrict__ offset_param,
                                                      const int32_t* __restrict__ parents, int T, int K, float* __restrict__ out) {
@@ -873,6 +1064,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restr
 
 struct StepBufs {
     float *hid_prior, *hid_post, *rh, *jh, *gh, *pmu, *psig, *qmu, *qsig, *z, *hr, *hj, *rootout, *rot;
+    float *rall, *dall;   // vrnn_post_mid_kernel: every sample's global rotations [S*B][9K] and distance to the observation [S*B]
     float* gi;        // [B][3H] input projection of the GRU (large batches only, else null)
 };
 
@@ -886,7 +1078,15 @@ void add_job(LinJobs& J, const LinearW& L, int col0, const float* xa, int na, in
     J.n++;
 }
 
-int pick_nb(int batch) { return batch >= 8 ? 8 : (batch >= 4 ? 4 : (batch >= 2 ? 2 : 1)); }
+// rows per wavefront pass: at most two.  The 4- and 8-row instantiations of the row kernels - meant to amortise a weight row over
+// more batch rows - measure 30 / 22 us per launch (linear_rows / gru_rows, idle device, tools/time_vrnn_rows.py) where the 1- and
+// 2-row ones take 4.8: with the batch split into more workgroups instead, nm_vrnn_gru at B = 4 / 8 / 16 runs 9.3 / 10.0 / 12.6 us
+// instead of 50 / 53 / 64, and a posterior step of encode (B = 4, S = 10) 41 us instead of 95 (NM355_VRNN_NB = 4 / 8 restores them)
+int pick_nb(int batch) {
+    const int cap = nm_ls().vrnn_nb;
+    const int nb = batch >= 8 ? 8 : (batch >= 4 ? 4 : (batch >= 2 ? 2 : 1));
+    return nb < cap ? nb : cap;
+}
 
 // prior steps of a rollout (nm_ls().vrnn_mid, NM355_VRNN_MID): 1 (default) three dependent launches (h-phase, vrnn_prior_mid_kernel,
 // GRU), 0 six.  A/B: profiles/r03_rollout_ab.txt (tools/time_rollout.py, bit-identical outputs).
@@ -954,6 +1154,7 @@ StepBufs alloc_step(Arena& ws, int B, int S, int K, int Z, int H) {
     b.pmu = ws.f((size_t)B * Z); b.psig = ws.f((size_t)B * Z); b.qmu = ws.f((size_t)B * Z); b.qsig = ws.f((size_t)B * Z);
     b.z = ws.f((size_t)S * B * Z); b.hr = ws.f((size_t)S * B * 128); b.hj = ws.f((size_t)S * B * 128);
     b.rootout = ws.f((size_t)S * B * (3 + K)); b.rot = ws.f((size_t)S * B * 6 * K);
+    b.rall = ws.f((size_t)S * B * 9 * K); b.dall = ws.f((size_t)S * B);
     b.gi = B >= NM_GEMM_MIN_BATCH ? ws.f((size_t)B * 3 * H) : nullptr;
     return b;
 }
@@ -1000,6 +1201,23 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         a.B = B; a.K = K; a.Z = Z; a.H = H;
         hipLaunchKernelGGL(vrnn_prior_mid_kernel, dim3(B), dim3(1024), 0, s, a);
         if ((rc = nm_check_hip(hipGetLastError(), "vrnn_prior_mid launch"))) return rc;
+        if (io.hout && (rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s, nullptr, sb.gi))) return rc;
+        return NM_OK;
+    }
+    if (post && !io.tape && nm_ls().vrnn_postmid && c->vrnn_cnt && B <= 256 && (size_t)S * B <= 4096 && K % 8 == 0 && K <= 32 && Z == 128 && io.out_kp && io.out_z) {
+        // 2-4 of a posterior step in one workgroup per (sample, clip), selection by the clip's last workgroup: vrnn_post_mid_kernel
+        PostArgs a;
+        a.hid_post = sb.hid_post; a.hid_prior = sb.hid_prior; a.rh = sb.rh; a.jh = sb.jh; a.eps = io.eps; a.offset = io.offset;
+        a.obs = io.obs; a.ldobs = io.ldobs;
+        a.w_q2 = w.post2.w; a.b_q2 = w.post2.b; a.w_p2 = w.prior2.w; a.b_p2 = w.prior2.b; a.w_root0 = w.root0.w; a.w_joint0 = w.joint0.w;
+        a.w_root2 = w.root2.w; a.b_root2 = w.root2.b; a.w_joint2 = w.joint2.w; a.b_joint2 = w.joint2.b;
+        a.parents = w.parents; a.lvl_joint = w.lvl_joint; a.lvl_start = w.lvl_start; a.nlevels = w.nlevels;
+        a.zall = sb.z; a.kpall = sb.hr; a.rall = sb.rall; a.dall = sb.dall; a.counter = c->vrnn_cnt;
+        a.out_kp = io.out_kp; a.ldkp = io.ldkp; a.out_z = io.out_z; a.ldz = io.ldz; a.out_R = io.out_R; a.ldR = io.ldR;
+        a.best = io.best; a.ldbest = io.ldbest; a.kl = (io.want_prior && io.kl) ? io.kl : nullptr; a.rec = io.rec; a.ldstat = io.ldstat;
+        a.B = B; a.S = S; a.K = K; a.Z = Z; a.H = H;
+        hipLaunchKernelGGL(vrnn_post_mid_kernel, dim3(S * B), dim3(1024), 0, s, a);
+        if ((rc = nm_check_hip(hipGetLastError(), "vrnn_post_mid launch"))) return rc;
         if (io.hout && (rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s, nullptr, sb.gi))) return rc;
         return NM_OK;
     }
@@ -1130,7 +1348,7 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
     }
     if ((rc = max_fk_lds(c, S))) return rc;
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4;
-    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z + K * 3 + 2 * T) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
+    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z + K * 3 + 2 * T) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K + 9 * K + 1)) * sizeof(float) + 64 * 256;
     if ((rc = nm_ctx_reserve(c, need))) return rc;
     c->ws.release(0);
     StepBufs sb = alloc_step(c->ws, B, S, K, Z, H);
@@ -1388,7 +1606,7 @@ extern "C" {
 
 static size_t rollout_floats(int B, int Tcond, int Ttot, int S, int K, int Z, int H) {
     const size_t S4 = (size_t)K * 4, Tg = Ttot - Tcond;
-    return (size_t)B * (4 * 128 + 3 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K) + (B >= NM_GEMM_MIN_BATCH ? (size_t)B * 3 * H : 0)
+    return (size_t)B * (4 * 128 + 3 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K + 9 * K + 1) + (B >= NM_GEMM_MIN_BATCH ? (size_t)B * 3 * H : 0)
          + (size_t)B * Tcond * S4 * 2 + (size_t)Tcond * S * B * Z + Tg * B * Z + (size_t)B * Tg * S4 + (size_t)B * K * 3 + 3 * (size_t)B * H + (size_t)B * Z
          + 64 * 32;          // (256-byte alignment of each of the ~28 pieces)
 }
@@ -1549,7 +1767,7 @@ int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* k
     if (!posterior) S = 1;
     if ((rc = max_fk_lds(c, S))) return rc;
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4;
-    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K)) * sizeof(float) + 64 * 256;
+    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K + 9 * K + 1)) * sizeof(float) + 64 * 256;
     if ((rc = nm_ctx_reserve(c, need))) return rc;
     c->ws.release(0);
     StepBufs sb = alloc_step(c->ws, B, S, K, Z, H);

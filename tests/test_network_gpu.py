@@ -7,6 +7,7 @@ Tolerances (BASELINE.json north_star): fp32 keypoint coordinates and VRNN latent
 checked on the oracle's keypoints (unit parity), and end-to-end errors are reported per
 stage (SURVEY §7 'Error amplification')."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -784,3 +785,19 @@ def test_odd_hourglass_levels_with_output_padding_vs_oracle(G, path):
     for k in DETECTOR_LOSS_KEYS:
         r = float(ref[k])
         assert abs(float(out[k]) - r) <= 5e-5 * max(1.0, abs(r)), k
+
+
+@pytest.mark.parametrize("env", [{"NM355_VRNN_POSTMID": "1"}, {"NM355_VRNN_NB": "8"}, {"NM355_VRNN_MID": "0"}],
+                         ids=["posterior-mid-kernel", "rows-per-pass-8", "six-launch-prior-step"])
+def test_vrnn_kernel_variants_stay_under_parity(env):
+    """The VRNN's A/B partners: posterior steps as three launches (vrnn_post_mid_kernel: measured slower than the six-launch step and not
+    the default), the 4- / 8-row instantiations of the row kernels (6x slower per launch than the 1- / 2-row ones, the
+    default since round 3) and prior steps as six launches.  Switches are read at context creation: child processes re-run the
+    VRNN parity tests (reference fixture G2 with exact best-of-10 indices, G4 generation, the rollouts, the submodule callables)."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    sel = "test_g2_vrnn_unit_parity_on_reference_keypoints or test_g4_generate32 or test_config5_rollout64 or test_submodule_callables_vs_oracle or test_generation_driver_vs_oracle"
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-k", sel], env=dict(os.environ, **env), capture_output=True,
+                       text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
