@@ -1393,6 +1393,184 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 template <int V> using ic = std::integral_constant<int, V>;
 
+// ---- conv_pool_f16q: conv_pool_f16s with a counted, one-tap-ahead memory pipeline (round 3) --------------------------------------
+// conv_pool_f16s_kernel's loop compiled to 247 branches and 110 s_waitcnt vmcnt(0): every load sat under a condition (row inside the
+// volume, tensor has a pending affine, second addend present), so each tap was load -> full wait -> convert -> MFMAs, a chain of
+// C16 x 8 memory round trips per workgroup (64 -> 128 @32^3 -> 16^3 x 64 frames: 450 us for a 0.54 GB read).  Here: rows outside
+// the volume read the tensor's first voxel (their results are never stored), the frame's pending affines sit in an LDS table (identity
+// where a tensor has none), the second addend is a template parameter, and a tap's input rows and weights are requested while the previous tap is
+// converted and multiplied - no branch inside the loop, every wait a counted one.  Same arithmetic per element.
+template <int NT, bool IN2> struct PoolBuf { f32x4 ra[2], rb[2], qa[IN2 ? 2 : 1], qb[IN2 ? 2 : 1]; half8 bh[NT], bl[NT]; };
+
+template <int NT, bool SINGLE, bool IN2>
+__global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
+    __shared__ float red[4 * NT * 32 * 2];
+    __shared__ __attribute__((aligned(16))) float s_aff[4][128];       // this frame's pending affines: scale, shift, second addend's scale, shift (Cin <= 128)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nblk = p.nbz * p.nby * p.nbx;
+    const int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
+    const int bxi = br % p.nbx, byi = (br / p.nbx) % p.nby, bzi = br / (p.nbx * p.nby);
+    const int oz0 = bzi << 2, oy0 = byi << 3, ox0 = bxi << 3;
+    const int co_base = blockIdx.y * (NT * 32);
+    const int C16 = p.Cin >> 4;
+    for (int i = tid; i < 4 * p.Cin; i += 256) {
+        const int which = i / p.Cin, cc = i % p.Cin;
+        const float* t = which == 0 ? p.in_scale : which == 1 ? p.in_shift : which == 2 ? p.in2_scale : p.in2_shift;
+        s_aff[which][cc] = t && (which < 2 || IN2) ? t[(size_t)n * p.Cin + cc] : ((which & 1) ? 0.f : 1.f);
+    }
+    const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+    const size_t plane = (size_t)p.Co_pad;
+    const int lane_off = h * (int)plane + l31;
+    const int c = l31 >> 2;
+    const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
+    const float* src[2];
+    const float* src2[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int y = 2 * wave + mt;
+        const bool ok = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
+        const size_t voff = ok ? (((size_t)(2 * (oz0 + z)) * p.IH + 2 * (oy0 + y)) * p.IW + 2 * (ox0 + x)) * p.Cin + 8 * h : (size_t)(8 * h);
+        const size_t foff = (size_t)n * p.ID * p.IH * p.IW * p.Cin;
+        src[mt] = p.in + foff + voff;
+        src2[mt] = IN2 ? p.in2 + foff + voff : src[mt];
+        if (p.in_map && ok) {
+            const int fb = (((oz0 + z) >> 1) * (p.IH >> 3) + ((oy0 + y) >> 2)) * (p.IW >> 3) + ((ox0 + x) >> 2);
+            if (!p.in_map[(size_t)n * (p.ID >> 2) * (p.IH >> 3) * (p.IW >> 3) + fb]) src[mt] = p.in_alt + voff;
+        }
+    }
+    f32x16 acc[2][NT], accl[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; accl[mt][nt][r] = 0.f; }
+    // the pending affines of channel chunk cb, from the LDS table (identity where a tensor has none)
+    struct Aff { f32x4 sca, scb, sha, shb, s2a, s2b, h2a, h2b; };
+    auto load_aff = [&](int cb, Aff& a) __attribute__((always_inline)) {
+        const int o = cb * 16 + 8 * h;
+        a.sca = *reinterpret_cast<const f32x4*>(&s_aff[0][o]); a.scb = *reinterpret_cast<const f32x4*>(&s_aff[0][o + 4]);
+        a.sha = *reinterpret_cast<const f32x4*>(&s_aff[1][o]); a.shb = *reinterpret_cast<const f32x4*>(&s_aff[1][o + 4]);
+        if constexpr (IN2) {
+            a.s2a = *reinterpret_cast<const f32x4*>(&s_aff[2][o]); a.s2b = *reinterpret_cast<const f32x4*>(&s_aff[2][o + 4]);
+            a.h2a = *reinterpret_cast<const f32x4*>(&s_aff[3][o]); a.h2b = *reinterpret_cast<const f32x4*>(&s_aff[3][o + 4]);
+        }
+    };
+    // (the chunk index goes through an opaque statement: with it visible, src + tap offset is loop-invariant for every (tap, row, tensor)
+    //  and the compiler keeps all of those addresses in registers - 64 of them - and spills)
+    auto issue = [&](int cb, int tap, PoolBuf<NT, IN2>& b) __attribute__((always_inline)) {
+        asm volatile("" : "+s"(cb));
+        const size_t toff = ((size_t)((tap >> 2) * p.IH + ((tap >> 1) & 1)) * p.IW + (tap & 1)) * p.Cin + cb * 16;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            b.ra[mt] = *reinterpret_cast<const f32x4*>(src[mt] + toff); b.rb[mt] = *reinterpret_cast<const f32x4*>(src[mt] + toff + 4);
+            if constexpr (IN2) { b.qa[mt] = *reinterpret_cast<const f32x4*>(src2[mt] + toff); b.qb[mt] = *reinterpret_cast<const f32x4*>(src2[mt] + toff + 4); }
+        }
+        if constexpr (!IN2) {      // (with a second addend in flight the weights are requested at the tap itself: registers)
+            const half8* wt = w8 + (size_t)cb * 4 * plane + co_base + (size_t)tap * C16 * 4 * plane;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { b.bh[nt] = wt[lane_off + nt * 32]; if constexpr (!SINGLE) b.bl[nt] = (wt + 2 * plane)[lane_off + nt * 32]; }
+        }
+    };
+    // branch-free forms of apply_act / sum_act2 (a uniform branch inside the tap loop ends the basic block, and the waits at its join
+    // are not counted ones): the identity affine (x * 1 + 0) and slope 1 (max(v, v) / v > 0 ? v : v) leave the values as they are
+    const float slope1 = p.in_slope, slope2 = p.in2_slope;
+    auto act1 = [&](f32x4 v, const f32x4& sc, const f32x4& sh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(v[j], sc[j], sh[j]); v[j] = fmaxf(v[j], v[j] * slope1); }
+        return v;
+    };
+    auto act2 = [&](f32x4 a, const f32x4& sca, const f32x4& sha, const f32x4& b, const f32x4& scb, const f32x4& shb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float u = a[j] * sca[j]; u = u + sha[j]; u = u > 0.f ? u : u * slope1;
+            float v = b[j] * scb[j]; v = v + shb[j]; v = v > 0.f ? v : v * slope2;
+            a[j] = u + v;
+        }
+        return a;
+    };
+    auto compute = [&](PoolBuf<NT, IN2>& b, const Aff& a, int cb, int tap) __attribute__((always_inline)) {
+        if constexpr (IN2) {
+            const half8* wt = w8 + (size_t)cb * 4 * plane + co_base + (size_t)tap * C16 * 4 * plane;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { b.bh[nt] = wt[lane_off + nt * 32]; if constexpr (!SINGLE) b.bl[nt] = (wt + 2 * plane)[lane_off + nt * 32]; }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            half8 ah, al;
+            if constexpr (IN2) split8(act2(b.ra[mt], a.sca, a.sha, b.qa[mt], a.s2a, a.h2a), act2(b.rb[mt], a.scb, a.shb, b.qb[mt], a.s2b, a.h2b), ah, al);
+            else split8(act1(b.ra[mt], a.sca, a.sha), act1(b.rb[mt], a.scb, a.shb), ah, al);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.bh[nt], acc[mt][nt], 0, 0, 0);
+                accl[mt][nt] = nm_mfma_lo<SINGLE>(ah, b.bl[nt], accl[mt][nt]);
+                accl[mt][nt] = nm_mfma_lo<SINGLE>(al, b.bh[nt], accl[mt][nt]);
+            }
+        }
+    };
+    if constexpr (IN2) {
+        // two tensors per row: the pipeline's unit is one ROW TILE of a tap (16 registers in flight per buffer instead of 32); the
+        // tap's weights are requested with its first row tile
+        f32x4 xa[2], xb[2], ya[2], yb[2];                     // [buffer]
+        auto issue_row = [&](int cb, int tap, int mt, int bi) __attribute__((always_inline)) {
+            asm volatile("" : "+s"(cb));
+            const size_t toff = ((size_t)((tap >> 2) * p.IH + ((tap >> 1) & 1)) * p.IW + (tap & 1)) * p.Cin + cb * 16;
+            xa[bi] = *reinterpret_cast<const f32x4*>(src[mt] + toff); xb[bi] = *reinterpret_cast<const f32x4*>(src[mt] + toff + 4);
+            ya[bi] = *reinterpret_cast<const f32x4*>(src2[mt] + toff); yb[bi] = *reinterpret_cast<const f32x4*>(src2[mt] + toff + 4);
+        };
+        Aff af;
+        half8 bh[NT], bl[NT];
+        issue_row(0, 0, 0, 0);
+        __syncthreads();                                      // the affine table
+        for (int cb = 0; cb < C16; ++cb) {
+            const int cbn = cb + 1 < C16 ? cb + 1 : cb;
+            load_aff(cb, af);
+            static_for<16>([&](auto U) __attribute__((always_inline)) {
+                constexpr int u = decltype(U)::value, tap = u >> 1, mt = u & 1;
+                if constexpr (u < 15) issue_row(cb, (u + 1) >> 1, (u + 1) & 1, (u + 1) & 1); else issue_row(cbn, 0, 0, 0);
+                if constexpr (mt == 0) {
+                    const half8* wt = w8 + (size_t)cb * 4 * plane + co_base + (size_t)tap * C16 * 4 * plane;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { bh[nt] = wt[lane_off + nt * 32]; if constexpr (!SINGLE) bl[nt] = (wt + 2 * plane)[lane_off + nt * 32]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                half8 ah, al;
+                split8(act2(xa[mt], af.sca, af.sha, ya[mt], af.s2a, af.h2a), act2(xb[mt], af.scb, af.shb, yb[mt], af.s2b, af.h2b), ah, al);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+                    accl[mt][nt] = nm_mfma_lo<SINGLE>(ah, bl[nt], accl[mt][nt]);
+                    accl[mt][nt] = nm_mfma_lo<SINGLE>(al, bh[nt], accl[mt][nt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    } else {
+    PoolBuf<NT, IN2> b0, b1;
+    Aff af;
+    issue(0, 0, b0);
+    __syncthreads();                                          // the affine table
+    for (int cb = 0; cb < C16; ++cb) {
+        const int cbn = cb + 1 < C16 ? cb + 1 : cb;           // (behind the last chunk: its first tap again, never used)
+        load_aff(cb, af);
+        static_for<8>([&](auto T) __attribute__((always_inline)) {
+            constexpr int tap = decltype(T)::value;
+            PoolBuf<NT, IN2>& cur = (tap & 1) ? b1 : b0;
+            PoolBuf<NT, IN2>& nxt = (tap & 1) ? b0 : b1;
+            if constexpr (tap < 7) issue(cb, tap + 1, nxt); else issue(cbn, 0, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur, af, cb, tap);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    }
+    EpiArgs e;
+    e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
+    e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3; e.xz_tiles = 1;
+    epilogue_xz<2, NT>(e, red, acc, accl, n, br, nblk, oz0, oy0, ox0, co_base);
+}
+
 // ---- conv_f16p: k3 s1 p1 split-fp16 conv, one persistent workgroup per CU, MFMA waves + producer waves ---------------
 // conv_f16s runs two independent 4-wave workgroups per CU and leaves the matrix pipe ~50 % idle: staging, the epilogue
 // and the per-brick set-up of one workgroup overlap the other's MFMAs only by chance.  Here ONE workgroup owns the CU and
@@ -2325,6 +2503,10 @@ int launch_pool_f16s_impl(const ConvParams& p, dim3 grid, hipStream_t s) {
         rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 8.0;
         (void)hipEventRecord(rec.a, s);
     }
+    if (nm_ls().pool_q && p.Cin <= 128) {                           // (the affine table holds 128 channels)
+        if (p.in2) hipLaunchKernelGGL((conv_pool_f16q_kernel<NT, SINGLE, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_pool_f16q_kernel<NT, SINGLE, false>), grid, dim3(256), 0, s, p);
+    } else
     hipLaunchKernelGGL((conv_pool_f16s_kernel<NT, SINGLE>), grid, dim3(256), 0, s, p);
     if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_pool_f16s launch");
