@@ -6,7 +6,7 @@ usage: pmc_traffic_all.py <fetch_dir> <write_dir> <round tag, e.g. r03> <out.jso
 
 FETCH_SIZE / WRITE_SIZE are in KB (x1024).  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports exactly half of the
 bytes of a wide coalesced streaming read -> `fetch_bytes_x2`; other access widths are uncalibrated, so the raw figure is kept too and
-the file carries a calibration on a known byte count in this library's own access pattern: conv_pool_f16s_kernel<1> reads its
+the file carries a calibration on a known byte count in this library's own access pattern: conv_pool_f16q_kernel<1, ..> (conv_pool_f16s_kernel<1> before round 3's rewrite) reads its
 64 x 64^3 x 32-channel fp32 input (2.147 GB at the bench shape) exactly once, 32 contiguous bytes per lane."""
 import collections, csv, glob, json, re, sys
 
@@ -36,7 +36,7 @@ for k, d in fa.items():
                      fetch_bytes_raw_max_launch=max(d.values()) * 1024))
 rows.sort(key=lambda r: -(r["fetch_bytes_x2"] + r["write_bytes"]) * r["launches"])
 cal = None
-pool = [r for r in rows if r["kernel"].startswith("conv_pool_f16s_kernel<1")]
+pool = [r for r in rows if r["kernel"].startswith("conv_pool_f16q_kernel<1") or r["kernel"].startswith("conv_pool_f16s_kernel<1")]
 if pool:
     known = 64 * 64 ** 3 * 32 * 4.0
     cal = dict(kernel=pool[0]["kernel"], known_input_bytes=known, fetch_bytes_raw_largest_launch=pool[0]["fetch_bytes_raw_max_launch"],
