@@ -81,7 +81,7 @@ struct NmLaunchState {
     unsigned* nf_flag = nullptr;           // sticky device word gn_finalize ORs a 1 into (null: no reporting)
     // A/B and diagnostic switches (NM355_SUPERTILE, _SMALL16, _KSPLIT, _OCC16, _POOL16, _F16P2, _F16P, _WGRAD_TR, _UP2C, _UP2C_DIAG,
     // _VRNN_MID, _VRNN_GEMM, _VRNN_GRAPH, _SPARSE_FIRST)
-    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, pool_q, wgrad_tr, wgrad_u, tail_rank1, wgrad_z, up2c, up2c_diag, vrnn_mid, vrnn_postmid, vrnn_nb, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res, adjust_split, hg_core, f16p_dma;
+    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, pool_q, occ_flags, wgrad_tr, wgrad_u, tail_rank1, wgrad_z, up2c, up2c_diag, vrnn_mid, vrnn_postmid, vrnn_nb, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res, adjust_split, hg_core, f16p_dma;
     NmLaunchState();
 };
 NmLaunchState& nm_ls();        // the state of the context whose ABI call runs on this thread
@@ -117,7 +117,8 @@ int nm_launch_pack_jobs(const NmPackJob* device_jobs, int njobs, int total_block
 int nm_occ_blocks_per_frame(int G);
 int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s);
 int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
-                         int Co_pad, float* part, hipStream_t s, unsigned char* brickmap = nullptr, const float* field_part = nullptr);
+                         int Co_pad, float* part, hipStream_t s, unsigned char* brickmap = nullptr, const float* field_part = nullptr,
+                         unsigned char* flags = nullptr /* N * bricks bytes of scratch: per-brick occupancy pre-filter of the sparse form */);
 // true when nm_launch_conv sends a k2 s2 p0 conv of this input to conv_pool_f16s_kernel (the consumer of a brick-sparse tensor)
 bool nm_conv_pool16_eligible(int Cin, int OD, int OH, int OW, bool have_w16);
 void nm_conv_prof_enable(int on, hipStream_t stream);

@@ -346,6 +346,8 @@ struct OccParams {
     // brickmap[n][brick] = 0 tells the consumer (the pool conv) to read the field there, and its GroupNorm partial sums are the
     // field's own (field_part [brick][Cout][2], computed once per weight update by this very kernel on an empty frame).  Null: dense.
     unsigned char* brickmap; const float* field_part;
+    const unsigned char* flags;    // [N][bricks]: the brick holds an occupied voxel (occ_brick_flags_kernel) - a one-load pre-filter of the halo test
+    int row_walk;                  // 1: a workgroup walks one x-row of bricks (grid / (G / 8))
 };
 
 __host__ __device__ constexpr int occ_tap_off(int t) { return t < 125 ? ((t / 25) * 12 + (t / 5) % 5) * 12 + t % 5 : 0; }
@@ -432,6 +434,24 @@ __device__ __forceinline__ float dpp_sum32(float x) {
     return dpp_add<0x142, 0xa>(x);
 }
 
+// flags[n][brick] = 1 when the 4 x 8 x 8 brick holds an occupied voxel.  One workgroup per (frame, slab of four z-planes): the slab is
+// read once, coalesced (the first-layer kernel tests a brick's 8 x 12 x 12 halo with five scattered loads per thread - and 85 % of its
+// 65 536 workgroups at the bench shape exist only to find that halo empty; with the flags they find out from 27 bytes).
+__global__ __launch_bounds__(256) void occ_brick_flags_kernel(const float* __restrict__ occ, int G, unsigned char* __restrict__ flags) {
+    __shared__ int f[256];
+    const int nb = G >> 3, n = blockIdx.x / (G >> 2), bz = blockIdx.x % (G >> 2);
+    if ((int)threadIdx.x < nb * nb) f[threadIdx.x] = 0;
+    __syncthreads();
+    const f32x4* src = reinterpret_cast<const f32x4*>(occ + ((size_t)n * G + 4 * bz) * G * G);
+    const int q = G >> 2;                                   // float4 per row
+    for (int i = threadIdx.x; i < G * G; i += 256) {        // [4][G][G / 4]
+        const f32x4 v = src[i];
+        if (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f) f[(((i / q) % G) >> 3) * nb + ((i % q) >> 1)] = 1;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nb * nb) flags[((size_t)n * (G >> 2) + bz) * nb * nb + threadIdx.x] = (unsigned char)f[threadIdx.x];
+}
+
 // The same layer on the fp16 matrix cores.  Voxel occupancy is 0/1 in the reference's data, exact in fp16, so the product
 // needs only occ * w_hi + occ * w_lo / 2^11: two f16 MFMAs at 16x the fp32-MFMA rate (the fp32 kernel above is bound by its
 // 128 fp32 MFMAs per wave).  A volume with other values takes a third MFMA with the lo part of the input (decided per
@@ -443,14 +463,39 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     __shared__ _Float16 tile_h[8 * 12 * 12], tile_l[8 * 12 * 12];
     __shared__ float red[512];
     __shared__ __attribute__((aligned(16))) float stage[4 * 32 * 36];      // epilogue transposition, one 32-voxel x 32-channel tile per wave
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, l31 = lane & 31;
     const int nb = p.G >> 3, nbz = p.G >> 2;
     const int nblk = nbz * nb * nb;
-    const int n = blockIdx.x % p.N, br = blockIdx.x / p.N;          // frame index fastest (see conv_k5occ_kernel)
+    const int n = blockIdx.x % p.N;                                 // frame index fastest (see conv_k5occ_kernel)
+    // with the occupancy flags (sparse inference form) a workgroup walks one x-row of bricks: 8 192 workgroups instead of 65 536 at the
+    // bench shape, most of whose bricks cost 27 flag bytes and one partial-sum copy
+    const int per_wg = p.row_walk ? nb : 1;
+    for (int sub = 0; sub < per_wg; ++sub) {
+    if (sub) __syncthreads();
+    // (the thread index goes through an opaque statement per brick: visible, every lane-derived LDS offset of the body is a loop invariant
+    //  that hipcc keeps in a register of its own across the loop - 256 registers and 1 KB of scratch per lane)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int br = (blockIdx.x / p.N) * per_wg + sub;
     const int oz0 = (br / (nb * nb)) << 2, oy0 = ((br / nb) % nb) << 3, ox0 = (br % nb) << 3;
     const int co_base = blockIdx.y * (NT * 32);
     const float* src = p.occ + (size_t)n * p.G * p.G * p.G;
+    if (p.flags && p.brickmap) {
+        // pre-filter: no occupied voxel in the 27 bricks around -> none in the halo (2 voxels wide) -> the brick is the field
+        int fl = 0;
+        if (tid < 27) {
+            const int bz = (br / (nb * nb)) + tid / 9 - 1, by = ((br / nb) % nb) + (tid / 3) % 3 - 1, bx = (br % nb) + tid % 3 - 1;
+            if ((unsigned)bz < (unsigned)nbz && (unsigned)by < (unsigned)nb && (unsigned)bx < (unsigned)nb) fl = p.flags[(size_t)n * nblk + (bz * nb + by) * nb + bx];
+        }
+        if (!__syncthreads_or(fl)) {
+            if (tid == 0 && blockIdx.y == 0) p.brickmap[(size_t)n * nblk + br] = 0;
+            if (p.part && tid < NT * 32 && co_base + tid < p.Cout) {
+                const float2 v = *reinterpret_cast<const float2*>(p.field_part + ((size_t)br * p.Cout + co_base + tid) * 2);
+                *reinterpret_cast<float2*>(p.part + (((size_t)n * nblk + br) * p.Cout + co_base + tid) * 2) = v;
+            }
+            continue;
+        }
+    }
     int inexact = 0, occupied = 0;
     {
         // the thread's five halo cells requested together, from clamped addresses, and masked afterwards: under `if (inside)` each
@@ -486,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
                 const float2 v = *reinterpret_cast<const float2*>(p.field_part + ((size_t)br * p.Cout + co_base + tid) * 2);
                 *reinterpret_cast<float2*>(p.part + (((size_t)n * nblk + br) * p.Cout + co_base + tid) * 2) = v;
             }
-            return;
+            continue;
         }
     }
     int arow[2];
@@ -641,6 +686,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
             }
         }
     }
+    }   // bricks of this workgroup
 }
 
 // (Cout, 125) occupancy-tap matrix -> split fp16 [k-step 8][hi h0 | hi h1 | lo h0 | lo h1][Co_pad][8]
@@ -2839,15 +2885,20 @@ int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float*
 }
 
 int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
-                         int Co_pad, float* part, hipStream_t s, unsigned char* brickmap, const float* field_part) {
+                         int Co_pad, float* part, hipStream_t s, unsigned char* brickmap, const float* field_part, unsigned char* flags) {
     if (G % 8 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("conv_k5occ: unsupported G=%d Cout=%d", G, Cout); return NM_ERR_ARG; }
     OccParams p; p.occ = occ; p.w = w_packed; p.field = field; p.out = out; p.part = part; p.N = N; p.G = G; p.Cout = Cout; p.Co_pad = Co_pad;
-    p.brickmap = brickmap; p.field_part = field_part;
+    p.brickmap = brickmap; p.field_part = field_part; p.flags = nullptr; p.row_walk = 0;
+    if (brickmap && flags && G <= 128 && G % 8 == 0 && nm_ls().occ_flags) {
+        hipLaunchKernelGGL(occ_brick_flags_kernel, dim3((unsigned)(N * (G >> 2))), dim3(256), 0, s, occ, G, flags);
+        p.flags = flags; p.row_walk = nm_ls().occ_flags >= 2 ? 1 : 0;
+    }
     if (brickmap && (!(nm_ls().conv_mode == 1 && nm_ls().occ16) || (part && !field_part))) {
         nm_set_error("conv_k5occ: the brick-sparse output exists on the split-fp16 kernel only and needs the field's partial sums"); return NM_ERR_ARG;
     }
     const int NT = (Co_pad % 64 == 0) ? 2 : 1;
     dim3 grid((unsigned)(N * nm_occ_blocks_per_frame(G)), (unsigned)(Co_pad / (NT * 32)));
+    if (p.row_walk) grid.x /= (unsigned)(G >> 3);         // one workgroup per x-row of bricks (conv_k5occ_f16_kernel)
     ProfRec rec;
     if (NM_PROF_ON(s)) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 4;

@@ -473,10 +473,11 @@ TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w,
     const bool sparse = !rec && w.field_part && nm_conv_get_mode() == 1 && nm_ls().occ16 && nm_ls().sparse_first &&
                         nm_conv_pool16_eligible(Cout, G / 2, G / 2, G / 2, w.p1.c.wp16 != nullptr);
     unsigned char* bmap = sparse ? reinterpret_cast<unsigned char*>(n.alloc(((size_t)N * nblk + 3) / 4)) : nullptr;
+    unsigned char* bflags = sparse ? reinterpret_cast<unsigned char*>(n.alloc(((size_t)N * nblk + 3) / 4)) : nullptr;
     float* scale = n.alloc((size_t)N * Cout); float* shift = n.alloc((size_t)N * Cout);
     double* chsum = (rec && nm_gn_finalize_has_chsum(Cout, w.n0.groups)) ? reinterpret_cast<double*>(n.alloc((size_t)N * Cout * 4)) : nullptr;
     if (n.live()) {
-        n.run(nm_launch_conv_k5occ(occ, N, G, w.occ_w, w.field, out, Cout, w.c0.Co_pad, part, n.s, bmap, sparse ? w.field_part : nullptr));
+        n.run(nm_launch_conv_k5occ(occ, N, G, w.occ_w, w.field, out, Cout, w.c0.Co_pad, part, n.s, bmap, sparse ? w.field_part : nullptr, bflags));
         n.run(nm_launch_gn_finalize(part, N, nblk, Cout, w.n0.groups, (double)G3 * (Cout / w.n0.groups), w.n0.gamma, w.n0.beta,
                                     1e-5f, scale, shift, n.s, chsum));
         if (nm_ls().gn_diag && !sparse) n.run(nm_launch_gn_direct(out, N, (int)G3, Cout, w.n0.groups, w.n0.gamma, w.n0.beta, 1e-5f, scale, shift, n.s, chsum));
