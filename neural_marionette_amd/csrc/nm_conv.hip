@@ -151,12 +151,20 @@ __device__ __forceinline__ void mfma_chunk16(const ConvParams& p, const f32x4* l
                                              int taps, int h, int arow, f32x16 (&acc)[1][NT], f32x16 (&accl)[NT], int tap0 = 0, int tstep = 1) {
     const size_t plane = (size_t)p.Co_pad;
     const int k2 = p.ks * p.ks;
-    for (int tap = tap0; tap < taps; tap += tstep) {
-        const int tz = tap / k2, ty = (tap / p.ks) % p.ks, tx = tap % p.ks;
-        const half8* wt = wq + (size_t)tap * tap_stride;
-        half8 bh[NT], bl[NT];
+    // the weights of a tap are requested while the previous tap is split and multiplied (loaded at their tap they were one exposed L2
+    // round trip per tap: 27 per 16-channel chunk, most of the time of these small-volume launches)
+    half8 bh[NT], bl[NT];
+    if (tap0 < taps) {
+        const half8* wt = wq + (size_t)tap0 * tap_stride;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { bh[nt] = wt[nt * 32]; bl[nt] = wt[2 * plane + nt * 32]; }
+    }
+    for (int tap = tap0; tap < taps; tap += tstep) {
+        const int tz = tap / k2, ty = (tap / p.ks) % p.ks, tx = tap % p.ks;
+        const half8* wn = wq + (size_t)min(tap + tstep, taps - 1) * tap_stride;        // (behind the last tap: any valid address)
+        half8 nh[NT], nl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { nh[nt] = wn[nt * 32]; nl[nt] = wn[2 * plane + nt * 32]; }
         const int tapoff = (tz * p.HY + ty) * p.HX + tx;
         const f32x4 a = lds[(2 * h) * p.HVp + arow + tapoff], b = lds[(2 * h + 1) * p.HVp + arow + tapoff];
         half8 hi, lo;
@@ -167,6 +175,8 @@ __device__ __forceinline__ void mfma_chunk16(const ConvParams& p, const f32x4* l
             accl[nt] = nm_mfma_lo<SINGLE>(hi, bl[nt], accl[nt]);
             accl[nt] = nm_mfma_lo<SINGLE>(lo, bh[nt], accl[nt]);
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bh[nt] = nh[nt]; bl[nt] = nl[nt]; }
     }
 }
 
