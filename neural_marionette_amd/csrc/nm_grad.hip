@@ -1776,6 +1776,68 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
     if (amax) block_absmax(mx, amax);
 }
 
+// gnb_apply_kernel for the layers whose channel count divides 1024 (every layer of the network): a thread keeps ONE channel quad for the
+// whole launch, so the per-channel operands (forward scale / shift, the three coefficients, the outer-product weights) are loaded
+// once instead of per 16-byte item, and four items' tensor loads are in flight before the first is used.  The generic kernel's loop
+// is one item per iteration behind three dependent waits (tensor loads, scale / shift, coefficients) and runs at 4.9 TB/s on
+// occupancy alone.  Identity operands (scale 1 / shift 0, slope 1) leave the values as they are; same arithmetic per element.
+template <bool RANK1, bool COEF>
+__global__ __launch_bounds__(256) void gnb_apply4_kernel(const float* __restrict__ dA, TensorRef y, const float* __restrict__ coef,
+                                                         float* __restrict__ dy, unsigned* __restrict__ amax, const float* __restrict__ dmul,
+                                                         const float* __restrict__ dv, const float* __restrict__ wv) {
+    float mx = 0.f;
+    const float mm = dmul ? *dmul : 1.0f;
+    const unsigned C = (unsigned)y.C, per_frame = (unsigned)y.D * y.H * y.W * C;
+    const size_t n = blockIdx.y;
+    const unsigned r0 = (blockIdx.x * 256u + threadIdx.x) * 4u, step = gridDim.x * 1024u;      // (step % C == 0: the quad is fixed)
+    const unsigned c = r0 % C;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, w4 = sh, c1 = sc, c2 = sh, c3 = sh;
+    if (y.scale) { sc = *reinterpret_cast<const f32x4*>(y.scale + n * C + c); sh = *reinterpret_cast<const f32x4*>(y.shift + n * C + c); }
+    if (RANK1) w4 = *reinterpret_cast<const f32x4*>(wv + c);
+    if (COEF) {
+        const float* cf = coef + (n * C + c) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c1[j] = cf[j * 4]; c2[j] = cf[j * 4 + 1]; c3[j] = cf[j * 4 + 2]; }
+    }
+    const float slope = y.slope;
+    const float* yp = y.p + n * per_frame;
+    const float* dp = dA + n * per_frame;
+    const float* dvp = dv + n * (per_frame / C);
+    float* op = dy + n * per_frame;
+    auto one = [&](const f32x4& yy, f32x4 d, unsigned r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d[j] *= mm;
+            const float z = fmaf(yy[j], sc[j], sh[j]);
+            d[j] = z > 0.f ? d[j] : d[j] * slope;
+            if (COEF) d[j] = fmaf(c1[j], d[j], fmaf(c2[j], yy[j], c3[j]));
+        }
+        *reinterpret_cast<f32x4*>(op + r) = d;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+    };
+    unsigned r = r0;
+    for (; r + 3u * step < per_frame && r + 3u * step >= r; r += 4u * step) {
+        f32x4 yy[4], dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned ru = r + u * step;
+            yy[u] = *reinterpret_cast<const f32x4*>(yp + ru);
+            if (RANK1) { const float q = dvp[ru / C]; dd[u] = f32x4{q * w4[0], q * w4[1], q * w4[2], q * w4[3]}; }
+            else dd[u] = *reinterpret_cast<const f32x4*>(dp + ru);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(yy[u], dd[u], r + u * step);
+    }
+    for (; r < per_frame; r += step) {
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(yp + r);
+        f32x4 dd;
+        if (RANK1) { const float q = dvp[r / C]; dd = f32x4{q * w4[0], q * w4[1], q * w4[2], q * w4[3]}; }
+        else dd = *reinterpret_cast<const f32x4*>(dp + r);
+        one(yy, dd, r);
+    }
+    if (amax) block_absmax(mx, amax);
+}
+
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ amax, const float* __restrict__ dmul) {
     const float mm = dmul ? fabsf(*dmul) : 1.0f;
     float mx = 0.f;
@@ -2232,6 +2294,14 @@ int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, 
     const size_t frame4 = (size_t)y.D * y.H * y.W * y.C / 4;
     if (frame4 * 4 >= ((size_t)1 << 31)) { nm_set_error("gnb_apply: frame too large"); return NM_ERR_ARG; }
     const unsigned bx = (unsigned)min((frame4 + 255) / 256, (size_t)max(1, 4096 / max(y.N, 1)));
+    if (nm_ls().gnb_apply4 && 1024 % y.C == 0) {
+        const dim3 g(bx, y.N);
+        if (dv) { if (coef) hipLaunchKernelGGL((gnb_apply4_kernel<true, true>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
+                  else hipLaunchKernelGGL((gnb_apply4_kernel<true, false>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv); }
+        else if (coef) hipLaunchKernelGGL((gnb_apply4_kernel<false, true>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
+        else hipLaunchKernelGGL((gnb_apply4_kernel<false, false>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
+        return nm_check_hip(hipGetLastError(), "gnb_apply4 launch");
+    }
     hipLaunchKernelGGL(gnb_apply_kernel, dim3(bx, y.N), dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
     return nm_check_hip(hipGetLastError(), "gnb_apply launch");
 }
