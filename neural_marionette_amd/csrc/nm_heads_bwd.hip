@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float* __restric
     __shared__ float kp[32 * 3];
     __shared__ int sk[256];
     __shared__ float sd[256 * 3];
+    __shared__ unsigned long long smask[4];
     const int f = blockIdx.y;
     const size_t G3 = (size_t)G * G * G;
     if ((int)threadIdx.x < K * 3) kp[threadIdx.x] = keypoints[((size_t)f * K + threadIdx.x / 3) * 4 + threadIdx.x % 3];
@@ -179,11 +180,22 @@ __global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float* __restric
                 }
             }
         }
+        // the occupied voxels of the group (1-3 % of a grid, most groups have none) as one ballot per wave: the owners of the K * 3
+        // components visit only those, in voxel order - the order of the 256-entry scan this replaces (0.5 ms per launch)
+        const unsigned long long occm = __ballot(bk >= 0);
+        if ((threadIdx.x & 63) == 0) smask[threadIdx.x >> 6] = occm;
         sk[threadIdx.x] = bk; sd[threadIdx.x * 3] = d[0]; sd[threadIdx.x * 3 + 1] = d[1]; sd[threadIdx.x * 3 + 2] = d[2];
         __syncthreads();
         if ((int)threadIdx.x < K * 3) {
             const int k = threadIdx.x / 3, dd = threadIdx.x % 3;
-            for (int t = 0; t < 256; ++t) if (sk[t] == k) acc += sd[t * 3 + dd];
+            for (int wv = 0; wv < 4; ++wv) {
+                unsigned long long m = smask[wv];
+                while (m) {
+                    const int t = wv * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (sk[t] == k) acc += sd[t * 3 + dd];
+                }
+            }
         }
         __syncthreads();
     }
@@ -194,10 +206,22 @@ __global__ void chamfer_bwd_finish_kernel(const float* __restrict__ part, int nb
                                           const float* __restrict__ dloss, int F, int K, float* __restrict__ dkp) {
     const int f = blockIdx.x, t = threadIdx.x;
     if (t >= K * 3) return;
-    float cnt = 0.f;
-    for (int j = 0; j < tail_blocks; ++j) cnt += tail_part[((size_t)f * tail_blocks + j) * 3 + 2];
-    float s = 0.f;
-    for (int j = 0; j < nblk; ++j) s += part[((size_t)f * nblk + j) * (K * 3) + t];
+    // (eight loads in flight per step, added in index order: as written one by one the two sums were ~130 dependent L2 round trips)
+    float cnt = 0.f, s = 0.f;
+    for (int j0 = 0; j0 < tail_blocks; j0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = tail_part[((size_t)f * tail_blocks + min(j0 + u, tail_blocks - 1)) * 3 + 2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (j0 + u < tail_blocks) cnt += v[u];
+    }
+    for (int j0 = 0; j0 < nblk; j0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[((size_t)f * nblk + min(j0 + u, nblk - 1)) * (K * 3) + t];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (j0 + u < nblk) s += v[u];
+    }
     dkp[((size_t)f * K + t / 3) * 4 + t % 3] += (dloss[1] / (float)F) * (-2.0f * s) / cnt;
 }
 
