@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void occ_brick_flags_kernel(const float* __res
 // workgroup while staging), so the result is fp32-equivalent for any input.  K = taps: k-step ks, lane half h, element j
 // is tap 16 ks + 8 h + j (taps >= 125 carry zero weights).
 typedef _Float16 occ_half8 __attribute__((ext_vector_type(8)));
-template <int NT, bool SINGLE = false>
+template <int NT, bool SINGLE = false, bool WALK = false>      // WALK: one workgroup per x-row of bricks (sparse inference form)
 __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     __shared__ _Float16 tile_h[8 * 12 * 12], tile_l[8 * 12 * 12];
     __shared__ float red[512];
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     const int n = blockIdx.x % p.N;                                 // frame index fastest (see conv_k5occ_kernel)
     // with the occupancy flags (sparse inference form) a workgroup walks one x-row of bricks: 8 192 workgroups instead of 65 536 at the
     // bench shape, most of whose bricks cost 27 flag bytes and one partial-sum copy
-    const int per_wg = p.row_walk ? nb : 1;
+    const int per_wg = WALK ? nb : 1;                               // (a template parameter: as a run-time loop the dense form lost a wave of occupancy)
     for (int sub = 0; sub < per_wg; ++sub) {
     if (sub) __syncthreads();
     // (the thread index goes through an opaque statement per brick: visible, every lane-derived LDS offset of the body is a loop invariant
@@ -2915,7 +2915,10 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
         rec.flops = 2.0 * N * (double)G * G * G * Cout * 4.0 * 125.0;   // the reference's dense k5 layer over 4 input channels
         (void)hipEventRecord(rec.a, s);
     }
-    if (nm_ls().conv_mode == 1 && nm_ls().occ16) {
+    if (nm_ls().conv_mode == 1 && nm_ls().occ16 && p.row_walk) {
+        if (NT == 2) { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, false, true>), grid, dim3(256), 0, s, p); }
+        else { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, false, true>), grid, dim3(256), 0, s, p); }
+    } else if (nm_ls().conv_mode == 1 && nm_ls().occ16) {
         if (NT == 2) { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<2>), grid, dim3(256), 0, s, p); }
         else { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1>), grid, dim3(256), 0, s, p); }
     } else if (NT == 2) hipLaunchKernelGGL((conv_k5occ_kernel<2>), grid, dim3(256), 0, s, p);
