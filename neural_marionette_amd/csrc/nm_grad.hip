@@ -1448,20 +1448,24 @@ __global__ __launch_bounds__(256) void wgrad_k5occ_mfma_kernel(const float* __re
         const int oz0 = (r / nb) * 4, oy0 = (r % nb) * 8, ox0 = bx * 8;
         __syncthreads();                  // the previous brick's operand reads
         const float* src = occ + (size_t)n * G * G * G;
-        float ov[5]; int nz = 0;
+        // the five halo cells of a thread requested together from clamped addresses and masked afterwards (under `if (inside)` each load
+        // had a full wait behind it: five dependent round trips per brick, and 85 % of the bricks are dropped right after this test)
+        float ov[5]; bool in[5]; int nz = 0;
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
-            const int i = tid + 256 * u;
+            const int i = min(tid + 256 * u, OT - 1);
             const int hx = i % 12, hy = (i / 12) % 12, hz = i / 144;
             const int gz = oz0 - 2 + hz, gy = oy0 - 2 + hy, gx = ox0 - 2 + hx;
-            ov[u] = 0.f;
-            if (i < OT && (unsigned)gz < (unsigned)G && (unsigned)gy < (unsigned)G && (unsigned)gx < (unsigned)G) ov[u] = src[((size_t)gz * G + gy) * G + gx];
+            in[u] = tid + 256 * u < OT && (unsigned)gz < (unsigned)G && (unsigned)gy < (unsigned)G && (unsigned)gx < (unsigned)G;
+            const int cz = min(max(gz, 0), G - 1), cy = min(max(gy, 0), G - 1), cx = min(max(gx, 0), G - 1);
+            ov[u] = src[((size_t)cz * G + cy) * G + cx];
         }
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
             const int i = tid + 256 * u;
-            if (i < OT) tile[i] = ov[u];
-            nz |= (ov[u] != 0.f);
+            const float o = in[u] ? ov[u] : 0.f;
+            if (i < OT) tile[i] = o;
+            nz |= (o != 0.f);
         }
         if (!__syncthreads_or(nz)) continue;                       // (uniform over the workgroup; also the barrier after the tile)
         constexpr int C4 = COUT / 4, ITEMS = 256 * C4 / 256;       // 16-byte items per thread
@@ -1500,8 +1504,15 @@ __global__ __launch_bounds__(256) void wgrad_k5occ_sparse_reduce_kernel(const fl
     const int total = 125 * Cout;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int co = i % Cout, tap = i / Cout;
+        // sixteen partials in flight, added in block order (one by one the sum was a chain of `blocks` L2 round trips: 148 us for 512)
         float s = 0.f;
-        for (int b = 0; b < blocks; ++b) s += part[(size_t)b * total + i];
+        for (int b0 = 0; b0 < blocks; b0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = part[(size_t)min(b0 + u, blocks - 1) * total + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (b0 + u < blocks) s += v[u];
+        }
         dW[((size_t)co * 4) * 125 + tap] = s;
     }
 }
@@ -2237,7 +2248,9 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
             if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(wgrad_k5occ_mfma)");
             attr_set = true;
         }
-        const int blocks = min(512, N * chunks);                   // (the partial buffer is sized for N * chunks blocks)
+        // eight workgroups per CU when the clip allows: a workgroup's bricks are a serial chain (halo test, dY brick through LDS, 128
+        // MFMA steps, no double buffering) - 512 / 1024 / 2048 workgroups: 915 / 794 / 637 us (+ 24 / 46 / 92 us of reduce)
+        const int blocks = min(2048, N * chunks);                  // (the partial buffer is sized for N * chunks blocks)
         const size_t ldsb = (size_t)(8 * 12 * 12 + 8 + 256 * C) * sizeof(float);
         if (C == 32) hipLaunchKernelGGL((wgrad_k5occ_mfma_kernel<32>), dim3(blocks), dim3(256), ldsb, s, occ, dy.p, N, G, part);
         else hipLaunchKernelGGL((wgrad_k5occ_mfma_kernel<64>), dim3(blocks), dim3(256), ldsb, s, occ, dy.p, N, G, part);
