@@ -2164,7 +2164,7 @@ int run_wgrad(WgradPlan& q, float* ws, float* dW, int cin_real, int taps, hipStr
 
 }  // namespace
 
-#define K1_WGS 256
+#define K1_WGS 512            // (256 / 512 / 1024 workgroups: 2.36 / 1.92 / 1.84 ms per step over the three instantiations - one serial brick chain per workgroup; the reduce grows with it)
 static bool k1_wide_eligible(int OD, int OH, int OW, int M, int Nc, int ks, int stride) {
     const int m_tiles = (M + 31) / 32, n_tiles = (Nc + 31) / 32;
     return ks == 1 && stride == 1 && (OD * OH * OW) % 64 == 0 && m_tiles * n_tiles <= 24 && (size_t)64 * (m_tiles * 32 + n_tiles * 32 + 8) * 4 <= 150 * 1024;
