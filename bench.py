@@ -389,7 +389,7 @@ def main():
         step()
     eng = net._engine
     lib, h = eng.ctx.lib, eng.ctx.handle
-    _lib.check(lib.nm_prof_enable(h, 1), "prof_enable")
+    _lib.check(lib.nm_prof_enable(h, 3), "prof_enable")      # conv launches of >= 20 GFLOP on the ctx stream, bracketed by HIP events
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

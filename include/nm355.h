@@ -305,6 +305,8 @@ int nm_get_conv_mode(nm_ctx* ctx);
  * While enabled, every conv launch of this context is bracketed by a HIP event pair.  on = 1: launches on the ctx stream only
  * (launches the library puts on its own side stream overlap the main stream, so their event-to-event time is not their own);
  * on = 2: side-stream launches are recorded too (for listing every kernel family's share; durations include contention).
+ * on = 3: as 1, but only launches of >= 20 GFLOP algorithmic work (what bench.py's timed region uses: the event pairs around the
+ * many small dependent launches of the coarse hourglass levels cost the step ~1 % and no roofline is read from them).
  * Records belong to the context.
  * nm_prof_read sums duration and ALGORITHMIC flops (2*voxels*Cout*Cin*k^3, un-padded) of one
  * kernel variant (0..3 = conv_mfma_kernel<MT,NT> with (MT,NT) = (1,1),(1,2),(2,1),(2,2); 5,6 =

@@ -76,6 +76,7 @@ struct NmLaunchState {
     bool prof_on = false;
     hipStream_t prof_stream = nullptr;     // main stream of the profiled context; prof_all: launches on any stream are recorded
     bool prof_all = false;
+    double prof_min_flops = 0.0;           // launches below this algorithmic work are not bracketed (nm_prof_enable mode 3)
     std::vector<NmProfRec> prof;           // records of the current window
     std::vector<hipEvent_t> event_pool;
     unsigned* nf_flag = nullptr;           // sticky device word gn_finalize ORs a 1 into (null: no reporting)

@@ -2509,14 +2509,15 @@ int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
         attr_set = true;
     }
     ProfRec rec;
-    if (NM_PROF_ON(s)) {
-        rec.a = prof_event(); rec.b = prof_event(); rec.variant = (MT - 1) * 2 + (NT - 1);
+    rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
         // algorithmic work: real channels and taps, no padding
-        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
+    const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+    if (prof_rec) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = (MT - 1) * 2 + (NT - 1);
         (void)hipEventRecord(rec.a, s);
     }
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(256), t.lds_bytes, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+    if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_mfma launch");
 }
 
@@ -2546,15 +2547,16 @@ int launch_f16s_impl(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStre
         attr_set = true;
     }
     ProfRec rec;
-    if (NM_PROF_ON(s)) {
+    rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
+    const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+    if (prof_rec) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = UP2 ? 10 + (NT - 1) : 5 + (NT - 1);      // the fused-upsample layers are families of their own
-        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
         (void)hipEventRecord(rec.a, s);
     }
     dim3 pgrid(min(grid.x, 512u), grid.y);                          // persistent: ~2 resident workgroups per CU
     choose_super_tile(p, (int)pgrid.x, p.nbz, p.nby, p.nbx);
     hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2, SINGLE>), pgrid, dim3(256), t.lds_bytes, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+    if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
 }
 template <int MT, int NT, int KS, bool UP2>
@@ -2565,9 +2567,10 @@ int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) 
 template <int NT, bool SINGLE>
 int launch_pool_f16s_impl(const ConvParams& p, dim3 grid, hipStream_t s) {
     ProfRec rec;
-    if (NM_PROF_ON(s)) {
+    rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 8.0;
+    const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+    if (prof_rec) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 8;
-        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 8.0;
         (void)hipEventRecord(rec.a, s);
     }
     if (nm_ls().pool_q && p.Cin <= 128) {                           // (the affine table holds 128 channels)
@@ -2575,7 +2578,7 @@ int launch_pool_f16s_impl(const ConvParams& p, dim3 grid, hipStream_t s) {
         else hipLaunchKernelGGL((conv_pool_f16q_kernel<NT, SINGLE, false>), grid, dim3(256), 0, s, p);
     } else
     hipLaunchKernelGGL((conv_pool_f16s_kernel<NT, SINGLE>), grid, dim3(256), 0, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+    if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_pool_f16s launch");
 }
 template <int NT>
@@ -2601,15 +2604,16 @@ int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, h
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     ProfRec rec;
-    if (NM_PROF_ON(s)) {
+    rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
+    const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+    if (prof_rec) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 7;
-        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
         (void)hipEventRecord(rec.a, s);
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 32) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p_kernel<UP2, SINGLE>), grid, dim3(512), lds_bytes, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+    if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
 template <bool UP2>
@@ -2633,15 +2637,16 @@ int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, 
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     ProfRec rec;
-    if (NM_PROF_ON(s)) {
+    rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
+    const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+    if (prof_rec) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 9;
-        rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
         (void)hipEventRecord(rec.a, s);
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p2_kernel<UP2, SINGLE>), grid, dim3(512), lds_bytes, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+    if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p2 launch");
 }
 template <bool UP2>
@@ -2749,7 +2754,11 @@ int nm_conv_blocks_per_frame(const ConvGeom& g, int Cin) {
     return t.nbz * t.nby * t.nbx;
 }
 
-void nm_conv_prof_enable(int on, hipStream_t stream) { NmLaunchState& l = nm_ls(); l.prof_on = on != 0; l.prof_all = on == 2; l.prof_stream = stream; }
+void nm_conv_prof_enable(int on, hipStream_t stream) {
+    NmLaunchState& l = nm_ls(); l.prof_on = on != 0; l.prof_all = on == 2; l.prof_stream = stream;
+    l.prof_min_flops = on == 3 ? 2e10 : 0.0;       // 3: only launches that can matter to a roofline (>= 20 GFLOP algorithmic): an event pair costs
+                                                   // the many small dependent launches of the hourglass levels more than it tells about them
+}
 
 // Sums the event-timed launches of one kernel variant recorded since the last reset.
 // variant: see nm_prof_kernel_name.  Synchronises on the recorded events.
@@ -2790,13 +2799,14 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     if (use_up2c(g, in.C)) {
         // the fused-upsample layers on the coarse grid with composite weights (nm_up2c.hip): main + shell launch, timed together
         ProfRec rec;
-        if (NM_PROF_ON(s)) {
+        rec.flops = 2.0 * in.N * (double)g.OD * g.OH * g.OW * g.Cout * (double)(cin_real > 0 ? cin_real : in.C) * 27.0;
+        const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+        if (prof_rec) {
             rec.a = prof_event(); rec.b = prof_event(); rec.variant = 12;
-            rec.flops = 2.0 * in.N * (double)g.OD * g.OH * g.OW * g.Cout * (double)(cin_real > 0 ? cin_real : in.C) * 27.0;
             (void)hipEventRecord(rec.a, s);
         }
         const int rc = nm_launch_conv_up2c(in, g.up2c, bias, out, g.Cout, g.Co_pad, part, s);
-        if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+        if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
         return rc;
     }
     Tiling t = choose_tiling(g, in.C);
@@ -2910,9 +2920,10 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
     dim3 grid((unsigned)(N * nm_occ_blocks_per_frame(G)), (unsigned)(Co_pad / (NT * 32)));
     if (p.row_walk) grid.x /= (unsigned)(G >> 3);         // one workgroup per x-row of bricks (conv_k5occ_f16_kernel)
     ProfRec rec;
-    if (NM_PROF_ON(s)) {
+    rec.flops = 2.0 * N * (double)G * G * G * Cout * 4.0 * 125.0;   // the reference's dense k5 layer over 4 input channels
+    const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+    if (prof_rec) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 4;
-        rec.flops = 2.0 * N * (double)G * G * G * Cout * 4.0 * 125.0;   // the reference's dense k5 layer over 4 input channels
         (void)hipEventRecord(rec.a, s);
     }
     if (nm_ls().conv_mode == 1 && nm_ls().occ16 && p.row_walk) {
@@ -2923,6 +2934,6 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
         else { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1>), grid, dim3(256), 0, s, p); }
     } else if (NT == 2) hipLaunchKernelGGL((conv_k5occ_kernel<2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_k5occ_kernel<1>), grid, dim3(256), 0, s, p);
-    if (NM_PROF_ON(s)) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+    if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_k5occ launch");
 }
