@@ -27,6 +27,7 @@ NmLaunchState::NmLaunchState()
       pool_q(env_int("NM355_POOL_Q", 1)),           // 0: conv_pool_f16s_kernel (conditional loads, one memory round trip per tap) instead of conv_pool_f16q_kernel
       occ_flags(env_int("NM355_OCC_FLAGS", 2)),     // sparse first layer: 0 every brick tests its own halo; 1 per-brick occupancy flags as a pre-filter; 2 (default) also one workgroup per x-row of bricks
       gnb_apply4(env_int("NM355_GNB_APPLY4", 1)),   // 0: gnb_apply_kernel (one 16-byte item per iteration) for every channel count
+      defer_sums(env_int("NM355_DEFER_SUMS", 1)),      // 0: the per-layer gamma / beta / bias gradient sums are launched inside each GroupNorm backward (A/B)
       wgrad_tr(env_int("NM355_WGRAD_TR", 1)),       // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel
       wgrad_u(env_int("NM355_WGRAD_U", 1)),         // 0: wgrad16t_kernel (conditional staging loads) instead of wgrad16u_kernel
       tail_rank1(env_int("NM355_TAIL_RANK1", 1)),   // 0: the decoder tail's backward materialises its [F][G^3][32] gradient (A/B)

@@ -35,6 +35,11 @@ int nm_launch_gnb_finalize(const float* bpart, int nblk_b, const float* fpart, i
 // out[c] = sum_n src[(n*C + c)*stride + off]
 int nm_launch_sum_frames(const float* src, int N, int C, int stride, int off, float* out, hipStream_t s);
 int nm_launch_sum_frames3(const float* dgn, int N, int C, float* dgamma, float* dbeta, float* dbias, hipStream_t s);
+// the same for many layers at once (host array of jobs, NM_SUM3_JOBS per launch); results are bit-identical to the single launches
+#define NM_SUM3_JOBS 24
+struct NmSum3Job { const float* dgn; float* o0; float* o1; float* o2; int N, C; };
+struct NmSum3Jobs { NmSum3Job j[NM_SUM3_JOBS]; };
+int nm_launch_sum_frames3_multi(const NmSum3Job* jobs, int njobs, hipStream_t s);
 // out[c] = sum_{n,blk} part[((n*nblk + blk)*C + c)*2]       (bias gradient of a conv without GroupNorm)
 int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipStream_t s);
 // dy = c1*dz + c2*y + c3 (coef) or dy = dz (coef == nullptr)

@@ -1726,6 +1726,26 @@ __global__ void sum_frames3_kernel(const float* __restrict__ dgn, int N, int C, 
     o0[c] = t[0]; o1[c] = t[1]; o2[c] = t[2];
 }
 
+// the same sums for up to NM_SUM3_JOBS layers in one launch (blockIdx.y = layer): the per-layer results are parameter gradients, which
+// nothing in the backward walk reads - launched one by one they sat in the dependent chain of every GroupNorm layer
+__global__ void sum_frames3_multi_kernel(NmSum3Jobs jobs) {
+    const NmSum3Job& J = jobs.j[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, N = J.N, C = J.C;
+    if (c >= C) return;
+    const float* __restrict__ dgn = J.dgn;
+    f32x4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int n = 0;
+    for (; n + 4 <= N; n += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += *reinterpret_cast<const f32x4*>(dgn + ((size_t)(n + u) * C + c) * 4);
+    }
+    for (int u = 0; n < N; ++n, ++u) a[u] += *reinterpret_cast<const f32x4*>(dgn + ((size_t)n * C + c) * 4);
+    const f32x4 t = (a[0] + a[1]) + (a[2] + a[3]);
+    J.o0[c] = t[0]; J.o1[c] = t[1]; J.o2[c] = t[2];
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out) {
     __shared__ double sh[256];
     const int c = blockIdx.x;
@@ -2294,6 +2314,17 @@ int nm_launch_sum_frames(const float* src, int N, int C, int stride, int off, fl
 int nm_launch_sum_frames3(const float* dgn, int N, int C, float* dgamma, float* dbeta, float* dbias, hipStream_t s) {
     hipLaunchKernelGGL(sum_frames3_kernel, dim3((C + 63) / 64), dim3(64), 0, s, dgn, N, C, dgamma, dbeta, dbias);
     return nm_check_hip(hipGetLastError(), "sum_frames3 launch");
+}
+
+int nm_launch_sum_frames3_multi(const NmSum3Job* jobs, int njobs, hipStream_t s) {
+    for (int j0 = 0; j0 < njobs; j0 += NM_SUM3_JOBS) {
+        NmSum3Jobs a;
+        const int n = njobs - j0 < NM_SUM3_JOBS ? njobs - j0 : NM_SUM3_JOBS;
+        int cmax = 0;
+        for (int i = 0; i < n; ++i) { a.j[i] = jobs[j0 + i]; cmax = a.j[i].C > cmax ? a.j[i].C : cmax; }
+        hipLaunchKernelGGL(sum_frames3_multi_kernel, dim3((cmax + 63) / 64, n), dim3(64), 0, s, a);
+    }
+    return nm_check_hip(hipGetLastError(), "sum_frames3_multi launch");
 }
 
 int nm_launch_sum_partials(const float* part, int rows, int C, float* out, hipStream_t s) {

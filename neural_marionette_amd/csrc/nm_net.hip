@@ -667,6 +667,15 @@ struct Bwd {
     const std::map<std::string, std::pair<float*, int64_t>>* grads;     // nullptr in the sizing pass
     float* zb = nullptr;                                                  // 512 zeros: bias of the data-gradient convolutions
     unsigned* amax_pool = nullptr; int amax_next = 0, amax_cap = 0;       // zeroed words behind zb: one max|dy| cell per scaled layer
+    // per-layer (dgamma_n, dbeta_n, dbias_n) rows of the GroupNorm backward, kept until flush_sums() turns them into the three parameter
+    // gradients of every layer in one launch (they are outputs only: nothing in the walk waits for them)
+    float* dgn_pool = nullptr; size_t dgn_cap = 0, dgn_used = 0;
+    std::vector<NmSum3Job> sums;
+    float* dgn_rows(size_t n) { if (!dgn_pool || dgn_used + n > dgn_cap) return nullptr; float* p = dgn_pool + dgn_used; dgn_used += n; return p; }
+    void flush_sums() {
+        if (live() && !sums.empty()) run(nm_launch_sum_frames3_multi(sums.data(), (int)sums.size(), s));
+        sums.clear();
+    }
     Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g) : c(ctx), s(ctx->stream), ws(ctx->ws), grads(g) {}
     Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g, hipStream_t stream) : c(ctx), s(stream), ws(ctx->ws), grads(g) {}
     bool live() const { return rc == NM_OK && !ws.dry; }
@@ -705,12 +714,16 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
         dy = b.alloc(numel_of(out));
         const size_t m = b.ws.mark();
         float* bpart = b.alloc((size_t)N * nbb * C * 2);
-        float* coef = b.alloc((size_t)N * C * 4); float* dgn = b.alloc((size_t)N * C * 4);
+        float* coef = b.alloc((size_t)N * C * 4);
+        float* dgn = b.dgn_rows((size_t)N * C * 4);
+        const bool deferred = dgn != nullptr;
+        if (!deferred) dgn = b.alloc((size_t)N * C * 4);
         float* gg = b.grad(gn->key + ".weight", C); float* gb = b.grad(gn->key + ".bias", C); float* gbias = b.grad(bias_key, C);
         if (b.live()) {
             b.run(nm_launch_gnb_partials(dA, out, bpart, b.s, dA_mul, dv, wv));
             b.run(nm_launch_gnb_finalize(bpart, nbb, fpart, nblk_f, N, C, gn->groups, V, gn->gamma, 1e-5f, coef, dgn, b.s, chsum));
-            b.run(nm_launch_sum_frames3(dgn, N, C, gg, gb, gbias, b.s));
+            if (deferred) b.sums.push_back(NmSum3Job{dgn, gg, gb, gbias, N, C});
+            else b.run(nm_launch_sum_frames3(dgn, N, C, gg, gb, gbias, b.s));
             b.run(nm_launch_gnb_apply(dA, out, coef, dy, b.s, amax, dA_mul, dv, wv));
         }
         b.ws.release(m);
@@ -906,6 +919,8 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
     float* dfeat = b.alloc((size_t)F * g3 * FEAT);
     b.zb = b.alloc(1024);
     b.amax_pool = reinterpret_cast<unsigned*>(b.zb + 512); b.amax_cap = 256;      // (the second stream's walk takes cells 256..511)
+    const size_t dgn_main = (size_t)2 << 20, dgn_side = (size_t)1 << 18;           // floats: 4 F C per GroupNorm layer (F C <= 8192: 60 layers)
+    b.dgn_pool = nm_ls().defer_sums ? b.alloc(dgn_main + dgn_side) : nullptr; b.dgn_cap = dgn_main;
     if (b.live()) {
         b.run(nm_check_hip(hipMemsetAsync(dkp, 0, (size_t)F * K * 4 * sizeof(float), b.s), "backward: memset"));
         b.run(nm_check_hip(hipMemsetAsync(b.zb, 0, 1024 * sizeof(float), b.s), "backward: memset"));
@@ -940,6 +955,7 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         if (b.live()) {
             b.run(nm_check_hip(hipMemsetAsync(dfeat, 0, (size_t)F * g3 * FEAT * sizeof(float), b.s), "backward: memset"));
             b.run(nm_launch_combined_bwd(dcomb, d.adjust.csel, t.table, t.keypoints, B, T, K, FEAT, g, (float)width_d, gws, dfeat, dkp, b.s));
+            b.flush_sums();
             // every kypt_to_vox.* gradient is complete: the caller's collective for that bucket chunk may start behind this event
             if (c->ev_user_decoder) b.run(nm_check_hip(hipEventRecord(c->ev_user_decoder, b.s), "backward: decoder-done event"));
         }
@@ -984,6 +1000,7 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         // this block's high-water mark), exactly as in the forward.
         Bwd b2(c, grads, c->stream2);
         b2.zb = b.zb; b2.amax_pool = b.amax_pool + 256; b2.amax_cap = 256;
+        if (b.dgn_pool) { b2.dgn_pool = b.dgn_pool + dgn_main; b2.dgn_cap = dgn_side; }
         if (b.live()) {
             b.run(nm_check_hip(hipEventRecord(c->ev_fork, b.s), "backward: fork event"));
             b.run(nm_check_hip(hipStreamWaitEvent(c->stream2, c->ev_fork, 0), "backward: side stream wait"));
@@ -996,10 +1013,12 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         const size_t local_peak = b2.ws.peak;
         b2.ws.peak = saved_peak > local_peak ? saved_peak : local_peak;
         b2.ws.top = local_peak;
+        b2.flush_sums();
         if (b2.live()) b2.run(nm_check_hip(hipEventRecord(c->ev_side, c->stream2), "backward: side event"));
         b.run(b2.rc);
     }
     feature_net_bwd(b, t.frame, dfeat, true);
+    b.flush_sums();
     if (b.live()) b.run(nm_check_hip(hipStreamWaitEvent(b.s, c->ev_side, 0), "backward: join side stream"));
     return b.rc;
 }
