@@ -801,3 +801,19 @@ def test_vrnn_kernel_variants_stay_under_parity(env):
                        text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(here)))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("env", [{"NM355_POOL_Q": "0"}, {"NM355_OCC_FLAGS": "0"}, {"NM355_OCC_FLAGS": "1"}],
+                         ids=["pool-conv-f16s", "first-layer-no-flags", "first-layer-flags-no-row-walk"])
+def test_forward_kernel_variants_stay_under_parity(env):
+    """The forward's late round-3 A/B partners: the k2 s2 pool convs on conv_pool_f16s_kernel (conditional staging loads) instead of
+    conv_pool_f16q_kernel, and the sparse first layer finding its empty bricks without the per-brick occupancy flags / with the flags
+    but one workgroup per brick instead of per x-row of bricks.  Child processes (switches are read at context creation) re-run the
+    reference fixtures G1 / G2 and the bit-identity of the inference shortcuts."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    sel = "test_g1_config1_detector64 or test_g2_forward32_vs_reference_fixture or test_inference_shortcuts_are_bit_identical_to_the_plain_evaluation"
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-k", sel], env=dict(os.environ, **env), capture_output=True,
+                       text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(here)))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
