@@ -28,6 +28,7 @@ NmLaunchState::NmLaunchState()
       occ_flags(env_int("NM355_OCC_FLAGS", 2)),     // sparse first layer: 0 every brick tests its own halo; 1 per-brick occupancy flags as a pre-filter; 2 (default) also one workgroup per x-row of bricks
       gnb_apply4(env_int("NM355_GNB_APPLY4", 1)),   // 0: gnb_apply_kernel (one 16-byte item per iteration) for every channel count
       defer_sums(env_int("NM355_DEFER_SUMS", 1)),      // 0: the per-layer gamma / beta / bias gradient sums are launched inside each GroupNorm backward (A/B)
+      wgrad_async(env_int("NM355_WGRAD_ASYNC", 1)),    // 0: the weight gradients of the training backward stay in the main stream's chain (A/B)
       wgrad_tr(env_int("NM355_WGRAD_TR", 1)),       // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel
       wgrad_u(env_int("NM355_WGRAD_U", 1)),         // 0: wgrad16t_kernel (conditional staging loads) instead of wgrad16u_kernel
       tail_rank1(env_int("NM355_TAIL_RANK1", 1)),   // 0: the decoder tail's backward materialises its [F][G^3][32] gradient (A/B)
@@ -97,6 +98,17 @@ extern "C" {
 int nm_abi_version(void) { return NM_ABI_VERSION; }
 const char* nm_last_error(void) { return g_err; }
 
+// the weight-gradient stream; NM355_WGRAD_PRIO=1: at the lowest priority the device offers (A/B)
+static hipError_t create_wgrad_stream(hipStream_t* s) {
+    const char* e = getenv("NM355_WGRAD_PRIO");
+    if (e && atoi(e) != 0) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
     if (!out || !cfg) { nm_set_error("ctx_create: null argument"); return NM_ERR_ARG; }
     if (cfg->grid_size < 32 || cfg->grid_size % 8) { nm_set_error("ctx_create: grid_size %d unsupported", cfg->grid_size); return NM_ERR_UNSUPPORTED; }
@@ -127,6 +139,12 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
         return NM_ERR_HIP;
     }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        create_wgrad_stream(&c->stream3) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_w[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_w[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_w[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_dy, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_wjoin, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_clip, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_kp, hipEventDisableTiming) != hipSuccess ||
@@ -156,7 +174,9 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     nm_net_free_tape(ctx);
     nm_vrnn_free_tape(ctx);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side}) if (e) (void)hipEventDestroy(e);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->wside) (void)hipFree(ctx->wside);
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side, ctx->ev_w[0], ctx->ev_w[1], ctx->ev_w[2], ctx->ev_dy, ctx->ev_wjoin}) if (e) (void)hipEventDestroy(e);
     for (const NmProfRec& r : ctx->ls.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : ctx->ls.event_pool) (void)hipEventDestroy(e);
     delete ctx;

@@ -90,6 +90,13 @@ struct nm_ctx {
     bool stream_bound = false;             // nm_ctx_set_stream has been called (nullptr = the legacy default stream is a valid choice)
     hipStream_t stream2 = nullptr;         // ctx-owned side stream: clip-mean net / VRNN run beside the frame stack
     hipEvent_t ev_fork = nullptr, ev_clip = nullptr, ev_kp = nullptr, ev_side = nullptr;
+    // weight gradients of the training backward on a stream of their own (nm_net.hip conv_bwd): their inputs that must outlive the main
+    // stream's arena frames (a ring of dY buffers, the re-materialised upsample + slot workspace, the operand-scale vectors) live in one
+    // ctx-owned block sized by the sizing pass of nm_detector_forward_train
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_w[3] = {nullptr, nullptr, nullptr}, ev_dy = nullptr, ev_wjoin = nullptr;
+    float* wside = nullptr; size_t wside_floats = 0;                     // the block and its capacity
+    size_t wside_slot = 0, wside_scratch = 0, wside_sc = 0;              // floats per ring slot / scratch / scale pool (last sizing pass)
     hipEvent_t ev_user_decoder = nullptr;  // caller's event, recorded by nm_detector_backward once the decoder's gradients are complete
     unsigned* nf_flag = nullptr;           // sticky: 1 = a conv produced non-finite values (nm_ctx_check_nonfinite reads and clears it)
     Arena ws;                              // activations / scratch, reset per call

@@ -676,6 +676,36 @@ struct Bwd {
         if (live() && !sums.empty()) run(nm_launch_sum_frames3_multi(sums.data(), (int)sums.size(), s));
         sums.clear();
     }
+    // weight gradients on the context's third stream (async_w; main walk only).  The walk's dependent chain is GroupNorm backward -> data
+    // gradient -> the previous layer's GroupNorm backward ...; a layer's weight gradient hangs off it, and it is matrix-core work while
+    // the GroupNorm passes are HBM work: issued on a stream of its own it runs under the NEXT layers' memory passes instead of between
+    // them.  What it reads must then outlive the main stream's arena frames: dY comes from a ring of three ctx-owned buffers (a slot is
+    // handed out again only behind the event of the weight gradient that read it), the operand-scale vectors from a pool, and the
+    // re-materialised upsample / slot workspace is scratch that only stream3 touches (in order).
+    bool async_w = false;
+    float* ring[3] = {nullptr, nullptr, nullptr}; size_t slot_floats = 0; int ring_i = 0; bool slot_busy[3] = {false, false, false};
+    int last_slot = -1;                                   // ring slot of the dY the last norm_bwd returned (-1: arena)
+    float* sscratch = nullptr; size_t sscratch_floats = 0;
+    float* scpool = nullptr; size_t sc_floats = 0, sc_used = 0;
+    size_t need_slot = 0, need_scratch = 0, need_sc = 0;  // sizing pass: what the walk asked for
+    static size_t r64(size_t n) { return (n + 63) & ~(size_t)63; }
+    float* fake() const { return reinterpret_cast<float*>((uintptr_t)256); }
+    float* dy_alloc(size_t n) {
+        last_slot = -1;
+        if (!async_w) return alloc(n);
+        if (ws.dry) { need_slot = std::max(need_slot, r64(n)); last_slot = 0; return fake(); }
+        if (n > slot_floats) return alloc(n);
+        const int k = ring_i; ring_i = (ring_i + 1) % 3;
+        if (slot_busy[k]) { run(nm_check_hip(hipStreamWaitEvent(s, c->ev_w[k], 0), "backward: dY ring slot")); slot_busy[k] = false; }
+        last_slot = k;
+        return ring[k];
+    }
+    float* sc_alloc(size_t n) {
+        n = r64(n);
+        if (ws.dry) { need_sc += n; return fake(); }
+        if (sc_used + n > sc_floats) return nullptr;
+        float* p = scpool + sc_used; sc_used += n; return p;
+    }
     Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g) : c(ctx), s(ctx->stream), ws(ctx->ws), grads(g) {}
     Bwd(nm_ctx* ctx, const std::map<std::string, std::pair<float*, int64_t>>* g, hipStream_t stream) : c(ctx), s(stream), ws(ctx->ws), grads(g) {}
     bool live() const { return rc == NM_OK && !ws.dry; }
@@ -710,8 +740,9 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
     const int N = out.N, C = out.C, V = out.D * out.H * out.W;
     const int nbb = nm_gnb_blocks_per_frame(V);
     float* dy = nullptr;
+    b.last_slot = -1;
     if (gn) {
-        dy = b.alloc(numel_of(out));
+        dy = b.dy_alloc(numel_of(out));
         const size_t m = b.ws.mark();
         float* bpart = b.alloc((size_t)N * nbb * C * 2);
         float* coef = b.alloc((size_t)N * C * 4);
@@ -752,8 +783,19 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
 // Operand scaling of a data-gradient conv that runs on the split-fp16 kernels (nm_grad.h): dy is read as dy * 2^k.
 struct DyScale {
     unsigned* amax = nullptr; float* scale = nullptr; float* shift = nullptr; float* sc2 = nullptr;
+    bool pool = false;             // vectors from the backward's scale pool (they outlive the caller's arena frame)
     void prepare(Bwd& b, bool on, int count, float* sc2_keep = nullptr) {
         if (!on) return;
+        if (b.async_w) {
+            float* blk = b.sc_alloc((size_t)2 * Bwd::r64(count) + 64);
+            if (blk) {
+                const bool pooled = b.amax_pool && b.amax_next < b.amax_cap;
+                amax = pooled ? b.amax_pool + b.amax_next++ : reinterpret_cast<unsigned*>(b.alloc(64));
+                scale = blk; shift = blk + Bwd::r64(count); sc2 = shift + Bwd::r64(count); pool = true;
+                if (!pooled && b.live()) b.run(nm_check_hip(hipMemsetAsync(amax, 0, sizeof(unsigned), b.s), "backward: memset"));
+                return;
+            }
+        }
         // (the max cell from the pool zeroed once per backward; the shift vector is zeroed by make_scale: two memsets per layer
         //  were 126 dependent stream operations per step)
         const bool pooled = b.amax_pool && b.amax_next < b.amax_cap;
@@ -785,9 +827,36 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
     DyScale ds;
     ds.prepare(b, split && r.stride == 1 && (w.ks == 3 || (need_din && w.wd16)), r.out.N * r.out.C, sc2_keep);
     const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, r.chsum, w.key + ".bias", dA, ds.amax, dA_mul, dA_dv, dA_wv);
+    const int slot = b.last_slot;                        // >= 0: dY sits in the ring (Bwd::dy_alloc)
     const TensorRef dyT = plain(dy, r.out);
     const TensorRef dyS = ds.apply(b, dyT);
-    {   // weight gradient
+    // weight gradient; on the third stream when everything it reads outlives this call (Bwd::async_w)
+    const size_t up_floats = r.up2 ? Bwd::r64(numel_of(in) * 8) : 0;
+    const size_t wg_floats = nm_wgrad_ws_floats(in.N, r.out.D, r.out.H, r.out.W, w.Cout, in.C, w.ks, r.stride);
+    bool side = b.async_w && slot >= 0 && (!ds.amax || ds.pool);
+    if (side && b.ws.dry) b.need_scratch = std::max(b.need_scratch, up_floats + Bwd::r64(wg_floats));
+    if (side && !b.ws.dry && up_floats + wg_floats > b.sscratch_floats) side = false;
+    // (enqueued BEHIND this layer's data gradient: started together with it, the two matrix-core kernels only share the CUs; started
+    //  behind it, the weight gradient runs beside the next layer's GroupNorm passes, which are HBM work)
+    auto side_wgrad = [&]() {
+        float* gw = b.grad(w.key + ".weight", (int64_t)w.Cout * w.Cin * w.ks * w.ks * w.ks);
+        if (b.live()) {
+            hipStream_t s3 = b.c->stream3;
+            b.run(nm_check_hip(hipEventRecord(b.c->ev_dy, b.s), "backward: dY-ready event"));
+            b.run(nm_check_hip(hipStreamWaitEvent(s3, b.c->ev_dy, 0), "backward: weight-gradient stream wait"));
+            TensorRef a = in;
+            if (r.up2) {
+                b.run(nm_launch_upsample2(in, b.sscratch, s3));
+                a = mk(b.sscratch, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C);
+            }
+            b.run(nm_launch_wgrad(a, dyS, w.ks, r.stride, r.pad, w.Cin, b.sscratch + up_floats, gw, s3, ds.inv(), split ? 1 : 0));
+            b.run(nm_check_hip(hipEventRecord(b.c->ev_w[slot], s3), "backward: weight-gradient done event"));
+            b.slot_busy[slot] = true;
+        }
+    };
+    const bool side_first = nm_ls().wgrad_async == 2;          // 2: enqueue it in front of the data gradient (A/B)
+    if (side && side_first) side_wgrad();
+    if (!side) {
         const size_t m2 = b.ws.mark();
         TensorRef a = in;
         if (r.up2) {
@@ -795,7 +864,7 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
             if (b.live()) b.run(nm_launch_upsample2(in, upb, b.s));
             a = mk(upb, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C);
         }
-        float* wsb = b.alloc(nm_wgrad_ws_floats(in.N, r.out.D, r.out.H, r.out.W, w.Cout, in.C, w.ks, r.stride));
+        float* wsb = b.alloc(wg_floats);
         float* gw = b.grad(w.key + ".weight", (int64_t)w.Cout * w.Cin * w.ks * w.ks * w.ks);
         if (b.live()) b.run(nm_launch_wgrad(a, dyS, w.ks, r.stride, r.pad, w.Cin, wsb, gw, b.s, ds.inv(), split ? 1 : 0));
         b.ws.release(m2);
@@ -820,6 +889,7 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
             else b.run(nm_launch_convT2(dyT, w.wt, b.zb, din, w.Cin, in.D, in.H, in.W, b.s));
         }
     }
+    if (side && !side_first) side_wgrad();
     b.ws.release(m);
     return din;
 }
@@ -919,6 +989,17 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
     float* dfeat = b.alloc((size_t)F * g3 * FEAT);
     b.zb = b.alloc(1024);
     b.amax_pool = reinterpret_cast<unsigned*>(b.zb + 512); b.amax_cap = 256;      // (the second stream's walk takes cells 256..511)
+    if (nm_ls().wgrad_async && c->stream3) {
+        b.async_w = true;
+        if (!b.ws.dry) {
+            b.slot_floats = c->wside_slot; b.sscratch_floats = c->wside_scratch; b.sc_floats = c->wside_sc;
+            if (!c->wside || c->wside_floats < 3 * b.slot_floats + b.sscratch_floats + b.sc_floats) {
+                nm_set_error("detector_backward: the weight-gradient side block was not sized (call nm_detector_forward_train first)"); return NM_ERR_STATE;
+            }
+            for (int k = 0; k < 3; ++k) b.ring[k] = c->wside + (size_t)k * b.slot_floats;
+            b.sscratch = c->wside + 3 * b.slot_floats; b.scpool = b.sscratch + b.sscratch_floats;
+        }
+    }
     const size_t dgn_main = (size_t)2 << 20, dgn_side = (size_t)1 << 18;           // floats: 4 F C per GroupNorm layer (F C <= 8192: 60 layers)
     b.dgn_pool = nm_ls().defer_sums ? b.alloc(dgn_main + dgn_side) : nullptr; b.dgn_cap = dgn_main;
     if (b.live()) {
@@ -957,7 +1038,13 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
             b.run(nm_launch_combined_bwd(dcomb, d.adjust.csel, t.table, t.keypoints, B, T, K, FEAT, g, (float)width_d, gws, dfeat, dkp, b.s));
             b.flush_sums();
             // every kypt_to_vox.* gradient is complete: the caller's collective for that bucket chunk may start behind this event
-            if (c->ev_user_decoder) b.run(nm_check_hip(hipEventRecord(c->ev_user_decoder, b.s), "backward: decoder-done event"));
+            if (c->ev_user_decoder) {
+                if (b.async_w) {       // the decoder's weight gradients are on stream3: the caller's event goes behind them AND behind this point of the walk
+                    b.run(nm_check_hip(hipEventRecord(c->ev_dy, b.s), "backward: decoder walk event"));
+                    b.run(nm_check_hip(hipStreamWaitEvent(c->stream3, c->ev_dy, 0), "backward: weight-gradient stream wait"));
+                    b.run(nm_check_hip(hipEventRecord(c->ev_user_decoder, c->stream3), "backward: decoder-done event"));
+                } else b.run(nm_check_hip(hipEventRecord(c->ev_user_decoder, b.s), "backward: decoder-done event"));
+            }
         }
         b.ws.release(m);
     }
@@ -1020,6 +1107,13 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
     feature_net_bwd(b, t.frame, dfeat, true);
     b.flush_sums();
     if (b.live()) b.run(nm_check_hip(hipStreamWaitEvent(b.s, c->ev_side, 0), "backward: join side stream"));
+    if (b.async_w) {
+        if (b.ws.dry) { c->wside_slot = b.need_slot; c->wside_scratch = b.need_scratch; c->wside_sc = b.need_sc; }
+        else if (b.rc == NM_OK) {
+            b.run(nm_check_hip(hipEventRecord(c->ev_wjoin, c->stream3), "backward: weight-gradient stream event"));
+            b.run(nm_check_hip(hipStreamWaitEvent(b.s, c->ev_wjoin, 0), "backward: join weight-gradient stream"));
+        }
+    }
     return b.rc;
 }
 
@@ -1190,6 +1284,20 @@ int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* fir
     return with_workspace(c, [&]() { return decode_graph(c, keypoints, first_feature, first_frame, B, Tg, gen); });
 }
 
+// the ctx-owned block behind the weight-gradient stream (ring of dY buffers + scratch + scale pool), grown to the last sizing pass
+static int reserve_wside(nm_ctx* c) {
+    const size_t want = 3 * c->wside_slot + c->wside_scratch + c->wside_sc;
+    if (want <= c->wside_floats) return NM_OK;
+    int rc = nm_check_hip(hipDeviceSynchronize(), "reserve: device sync");
+    if (rc) return rc;
+    if (c->wside) { (void)hipFree(c->wside); c->wside = nullptr; c->wside_floats = 0; }
+    const size_t got = want + want / 16 + 4096;
+    rc = nm_check_hip(hipMalloc(reinterpret_cast<void**>(&c->wside), got * sizeof(float)), "reserve: hipMalloc weight-gradient side block");
+    if (rc) return rc;
+    c->wside_floats = got;
+    return NM_OK;
+}
+
 int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints,
                               float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_forward_train");
@@ -1205,9 +1313,11 @@ int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T,
     // sizing pass over forward + backward (the arena must not move between the two calls), then the forward proper
     c->ws.dry = true; c->ws.peak = 0; c->ws.overflow = false;
     rc = detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11, nullptr, &t);
+    c->wside_slot = c->wside_scratch = c->wside_sc = 0;
     if (!rc) rc = backward_graph(c, t, nullptr, nullptr);
     c->ws.dry = false;
     if (!rc) rc = nm_ctx_reserve(c, c->ws.peak + 4096);
+    if (!rc) rc = reserve_wside(c);
     if (!rc) rc = detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11, nullptr, &t);
     t.fwd_top = c->ws.top;
     std::swap(c->ws, c->ws_t);

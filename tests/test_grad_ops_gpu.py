@@ -204,17 +204,19 @@ def test_conv3d_backward_valu_transposition_wgrad_variant():
 
 
 @pytest.mark.parametrize("env", [{"NM355_WGRAD_Z": "0"}, {"NM355_WGRAD_Z": "0", "NM355_WGRAD_U": "0"}, {"NM355_TAIL_RANK1": "0"},
-                                 {"NM355_GNB_APPLY4": "0", "NM355_DEFER_SUMS": "0"}],
-                         ids=["wgrad16u", "wgrad16t", "tail-gradient-tensor", "gnb-apply-and-sums-per-layer"])
+                                 {"NM355_GNB_APPLY4": "0", "NM355_DEFER_SUMS": "0"}, {"NM355_WGRAD_ASYNC": "0"}, {"NM355_WGRAD_ASYNC": "2"}],
+                         ids=["wgrad16u", "wgrad16t", "tail-gradient-tensor", "gnb-apply-and-sums-per-layer", "weight-gradients-in-the-main-stream",
+                              "weight-gradients-enqueued-before-the-data-gradient"])
 def test_conv3d_backward_older_kernel_variants(env):
     """The A/B partners of the round-3 defaults stay under parity: wgrad16u_kernel (bricks in any order, full halo per brick) and
     wgrad16t_kernel (conditional staging loads) against the default wgrad16z_kernel, and the decoder tail's backward with its
     [F][G^3][32] gradient materialised (NM355_TAIL_RANK1=0; that one re-runs the detector gradient fixtures), and the GroupNorm
-    backward with the one-voxel-at-a-time apply kernel and its gamma / beta / bias sums launched per layer (same fixtures).  The
+    backward with the one-voxel-at-a-time apply kernel and its gamma / beta / bias sums launched per layer (same fixtures), and the
+    weight gradients inside the main stream's chain / enqueued on their own stream in front of the data gradient (same fixtures).  The
     switches are read when a context is created: child processes."""
     import os, subprocess, sys
     here = os.path.abspath(__file__)
-    if "NM355_TAIL_RANK1" in env or "NM355_GNB_APPLY4" in env:
+    if "NM355_TAIL_RANK1" in env or "NM355_GNB_APPLY4" in env or "NM355_WGRAD_ASYNC" in env:
         target = [os.path.join(os.path.dirname(here), "test_train_detector_gpu.py"), "-k", "test_detector_gradients_vs_oracle_autograd or test_detector_gradients_vs_reference_fixture"]
     else:
         target = [here, "-k", "test_conv3d_backward and (split16 or f16) and k3 and not variant"]
