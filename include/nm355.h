@@ -192,9 +192,12 @@ int nm_detector_forward_train(nm_ctx* ctx, const float* vox, int32_t B, int32_t 
                               float* affinity, float* losses11);
 int nm_detector_backward(nm_ctx* ctx, const float* dlosses11, const nm_named_grad* grads, int32_t count);
 /* Optional hook for overlapping the gradient all-reduce (train.py:404 `loss.backward()` followed by the optimizer step; here one
- * collective per bucket chunk): a caller-owned hipEvent_t that the next nm_detector_backward calls record on the ctx stream once
- * every kypt_detector.kypt_to_vox.* gradient has been written - the decoder's parameters come first in the backward order, the
- * heads and both feature nets follow.  NULL removes the hook. */
+ * collective per bucket chunk): a caller-owned hipEvent_t that the next nm_detector_backward calls record once every
+ * kypt_detector.kypt_to_vox.* gradient has been written - the decoder's parameters come first in the backward order, the
+ * heads and both feature nets follow.  The event is recorded on a ctx-owned stream (the one the weight gradients run on, behind the
+ * ctx stream's walk through the decoder): wait for it with hipStreamWaitEvent / hipEventSynchronize, do not assume it orders anything
+ * else on the ctx stream.  When nm_detector_backward returns, all of its work is ordered before anything enqueued on the ctx stream
+ * afterwards.  NULL removes the hook. */
 int nm_ctx_set_backward_event(nm_ctx* ctx, void* hip_event);
 
 /* HSVRNNBVH.generate — model/hsvrnn_bvh.py:158-234.
