@@ -187,6 +187,7 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
     `train` - BASELINE configs[2]'s per-GPU shape (64^3, T = 16, B = 4 clips per GPU): detector-mode training step = training
     forward + backward of the 11 weighted losses + bucketed gradient all-reduce (RCCL when N > 1) + fused Adam, fp32-equivalent."""
     from neural_marionette_amd.train import DetectorTrainer
+    from neural_marionette_amd import _lib
     out = {}
 
     def timed(fn, warm, steps):
@@ -221,6 +222,10 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
     step = lambda: tr.step(vox, sync=False)
     ms = timed(step, 2, 5) * 1e3
     free1 = torch.cuda.mem_get_info(dev)[0]
+    mem = (C.c_size_t * 4)()
+    _lib.check(net._engine.ctx.lib.nm_ctx_memory(net._engine.ctx.handle, mem), "ctx_memory")
+    out["train_memory_gb"] = dict(inference_workspace=mem[0] / 1e9, training_arena=mem[1] / 1e9, weight_gradient_side_block=mem[2] / 1e9,
+                                  weights_and_packs=mem[3] / 1e9, note="ctx-owned device memory after the fp32-equivalent training steps (nm_ctx_memory)")
     out["train"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=5, warmup=2,
                         workload="detector-mode training step (train.py:376-412): forward with retained activations + backward of the 11 "
                                  "AIST-weighted losses + gradient all-reduce (2 bucket chunks) + fused Adam; 64^3, T=16, B=4 clips per GPU",

@@ -86,6 +86,10 @@ int nm_ctx_check_nonfinite(nm_ctx* ctx);
 int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count);
 /* Bytes of ctx-owned workspace a (B, T) call needs (allocated lazily, grown on demand). */
 size_t nm_workspace_bytes(nm_ctx* ctx, int32_t B, int32_t T);
+/* Device memory the context owns right now, in bytes: out[0] inference workspace, out[1] training arena (every layer output of the
+ * last nm_detector_forward_train + the backward's transients), out[2] the block behind the weight-gradient stream (dY ring, upsample /
+ * slot scratch, scale pool), out[3] weights and their packs. */
+int nm_ctx_memory(nm_ctx* ctx, size_t out[4]);
 
 /* KyptDetector.forward — model/kypt_detector.py:81-169.
  *  vox        (B,T,1,G,G,G)            in

@@ -1237,6 +1237,13 @@ size_t nm_workspace_bytes(nm_ctx* c, int32_t B, int32_t T) { NmScope nm_scope_(c
     return c->ws.peak + 4096;
 }
 
+int nm_ctx_memory(nm_ctx* c, size_t out[4]) { NmScope nm_scope_(c);
+    if (!c || !out) { nm_set_error("ctx_memory: null argument"); return NM_ERR_ARG; }
+    out[0] = c->ws.cap + c->ws2.cap; out[1] = c->ws_t.cap; out[2] = c->wside_floats * sizeof(float); out[3] = 0;
+    for (size_t b : c->owned_bytes) out[3] += b;
+    return NM_OK;
+}
+
 int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints,
                         float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_forward");
