@@ -216,8 +216,11 @@ def test_conv3d_backward_older_kernel_variants(env):
     switches are read when a context is created: child processes."""
     import os, subprocess, sys
     here = os.path.abspath(__file__)
-    if "NM355_TAIL_RANK1" in env or "NM355_GNB_APPLY4" in env or "NM355_WGRAD_ASYNC" in env:
+    if "NM355_TAIL_RANK1" in env:
         target = [os.path.join(os.path.dirname(here), "test_train_detector_gpu.py"), "-k", "test_detector_gradients_vs_oracle_autograd or test_detector_gradients_vs_reference_fixture"]
+    elif "NM355_GNB_APPLY4" in env or "NM355_WGRAD_ASYNC" in env:       # (the all-losses case + the reference's own gradients: every backward path once)
+        target = [os.path.join(os.path.dirname(here), "test_train_detector_gpu.py"), "-k",
+                  "(test_detector_gradients_vs_oracle_autograd and aist) or test_detector_gradients_vs_reference_fixture"]
     else:
         target = [here, "-k", "test_conv3d_backward and (split16 or f16) and k3 and not variant"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + target, env=dict(os.environ, **env), capture_output=True, text=True,
