@@ -29,6 +29,7 @@ NmLaunchState::NmLaunchState()
       gnb_apply4(env_int("NM355_GNB_APPLY4", 1)),   // 0: gnb_apply_kernel (one 16-byte item per iteration) for every channel count
       defer_sums(env_int("NM355_DEFER_SUMS", 1)),      // 0: the per-layer gamma / beta / bias gradient sums are launched inside each GroupNorm backward (A/B)
       wgrad_async(env_int("NM355_WGRAD_ASYNC", 1)),    // 0: the weight gradients of the training backward stay in the main stream's chain (A/B)
+      wgrad_wgs(env_int("NM355_WGRAD_WGS", 0)),       // workgroups of a split-fp16 weight-gradient launch (0: 224 beside the main stream's walk, else 256; plan_wgrad)
       wgrad_tr(env_int("NM355_WGRAD_TR", 1)),       // 0: wgrad16_kernel (VALU transposition) instead of wgrad16t_kernel
       wgrad_u(env_int("NM355_WGRAD_U", 1)),         // 0: wgrad16t_kernel (conditional staging loads) instead of wgrad16u_kernel
       tail_rank1(env_int("NM355_TAIL_RANK1", 1)),   // 0: the decoder tail's backward materialises its [F][G^3][32] gradient (A/B)

@@ -2051,7 +2051,12 @@ WgradPlan plan_wgrad(int N, int OD, int OH, int OW, int M, int Nc, int ks, int s
         p.BZ = 2; p.BY = 8; p.BX = 8; p.nbz = OD / 2; p.nby = OH / 8; p.nbx = OW / 8; p.HZ = 4; p.HY = 10; p.HX = 10;
         q.m_tiles = (M + 31) / 32; p.n_tiles = (Nc + 31) / 32; p.groups = 27;
         const int tiles = q.m_tiles * p.n_tiles, total = N * p.nbz * p.nby * p.nbx;
-        p.S = max(1, min(total, 256 / tiles));
+        // workgroups of a launch: one per CU, or - when the weight gradients run on their own stream beside the main stream's walk
+        // (nm_net.hip conv_bwd) - 224, which leaves 32 CUs to the GroupNorm passes and small kernels of the walk: a whole-CU kernel on
+        // every CU admits nothing beside it until it ends (73.0 -> 71.3 ms per training step; 208: 71.7, 240: 72.9, 192: 72.7; in the
+        // reduced-precision mode 256 stays better: 53.4 vs 53.9).  NM355_WGRAD_WGS overrides.
+        const int wgs = nm_ls().wgrad_wgs > 0 ? nm_ls().wgrad_wgs : (nm_ls().wgrad_async == 1 && !nm_ls().single ? 224 : 256);
+        p.S = max(1, min(total, max(tiles, wgs) / tiles));
         // wgrad16z_kernel hands out whole (frame, y, x) columns: no more workgroups per tile pair than columns
         if (nm_ls().wgrad_tr && nm_ls().wgrad_z && p.nbz >= 2 && N <= 96) p.S = max(1, min(p.S, N * p.nby * p.nbx));
         q.slots = p.S; q.lds = W16_LDS; q.ws_floats = (size_t)q.slots * tiles * 27 * 1024;
