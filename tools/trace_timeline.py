@@ -2,7 +2,7 @@
 """Timeline of one step from a rocprofv3 --kernel-trace CSV: per-queue busy time, the union of the busy intervals, idle gaps, and the
 launches in start order with the other queue's occupancy beside them.  What the per-kernel statistics cannot show: which launches
 overlap, where the device idles, and which durations are inflated by waiting for CUs another stream's persistent kernels hold.
-usage: trace_timeline.py <rocprof output dir> <marker kernel substring> [step index from the end, default 1] [--list]"""
+usage: trace_timeline.py <rocprof output dir> <marker kernel substring> [step index from the end, default 1] [--list] [--starved]"""
 import csv, glob, os, re, sys
 
 
@@ -14,7 +14,8 @@ def load(d):
     out = []
     for r in rows:
         q = r.get("Stream_Id") or r.get("Queue_Id") or "0"
-        out.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), q, r["Kernel_Name"]))
+        grid = (r.get("Grid_Size_X") or r.get("Grid_Size") or "", r.get("Grid_Size_Y") or "", r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or "")
+        out.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), q, r["Kernel_Name"], grid))
     out.sort()
     return out
 
@@ -74,8 +75,29 @@ def main():
     if len(qs) > 1:
         per = [union([(e[0], e[1]) for e in step if e[2] == q]) for q in qs]
         print("  overlap (sum of per-queue busy - union): %.3f ms" % ((sum(per) - union(allv)) / 1e6))
+    if "--starved" in sys.argv:
+        # launches that took far longer than the same kernel's fastest launch of the same grid in this trace while another queue was busy:
+        # a whole-CU persistent kernel on another stream admits nothing beside it, so a small kernel launched behind it "runs" until it ends.
+        # CANDIDATES only: a persistent kernel launches the same grid for every layer size, so its rows compare different problems - read
+        # them against the layer; for the small per-layer kernels (finalisations, scale vectors, sums) the comparison is like for like.
+        best = {}
+        for s, e, q, n, g in ((x[0], x[1], x[2], x[3], x[4] if len(x) > 4 else None) for x in ev):
+            k = (n, g)
+            best[k] = min(best.get(k, 1 << 62), e - s)
+        rows = []
+        for x in step:
+            s, e, q, n = x[:4]
+            g = x[4] if len(x) > 4 else None
+            d, b = e - s, best[(n, g)]
+            if d > 3 * b and d - b > 50000:
+                other = sorted(set(short(y[3])[:28] for y in step if y[2] != q and y[0] < e and y[1] > s))
+                rows.append((d - b, s, d, b, q, n, other))
+        rows.sort(reverse=True)
+        print("  starved launches (> 3x the kernel's fastest launch of that grid, > 50 us lost): %d, %.3f ms lost" % (len(rows), sum(r[0] for r in rows) / 1e6))
+        for lost, s, d, b, q, n, other in rows[:25]:
+            print("%9.3f %8.1f us (fastest %7.1f)  q%-4s %-40s | %s" % ((s - t0) / 1e6, d / 1e3, b / 1e3, q, short(n)[:40], ", ".join(other)[:70]))
     if "--list" in sys.argv:
-        for s, e, q, n in step:
+        for s, e, q, n, _g in step:
             other = [x for x in step if x[2] != q and x[0] < e and x[1] > s]
             print("%9.3f %8.1f us  q%-4s %-44s %s" % ((s - t0) / 1e6, (e - s) / 1e3, q, short(n), ("| " + ", ".join(sorted(set(short(x[3])[:24] for x in other)))[:70]) if other else ""))
 
