@@ -134,6 +134,13 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
         delete c;
         return NM_ERR_HIP;
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->nf_host), 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+        nm_set_error("ctx_create: could not allocate the pinned status slots");
+        delete c;
+        return NM_ERR_HIP;
+    }
+    for (int i = 0; i < 4; ++i) c->nf_host[i] = 0;
+    { const char* e = getenv("NM355_RANGE_CHECK"); c->range_check = e ? atoi(e) : 1; }
     if (hipMalloc(reinterpret_cast<void**>(&c->vrnn_cnt), 256 * sizeof(int32_t)) != hipSuccess || hipMemset(c->vrnn_cnt, 0, 256 * sizeof(int32_t)) != hipSuccess) {
         nm_set_error("ctx_create: could not allocate the VRNN arrival counters");
         delete c;
@@ -149,7 +156,11 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_clip, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_kp, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_nf[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_nf[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_nf[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_nf[3], hipEventDisableTiming) != hipSuccess) {
         nm_set_error("ctx_create: could not create the side stream / events");
         delete c;
         return NM_ERR_HIP;
@@ -170,6 +181,8 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     if (ctx->copy_table) (void)hipFree(ctx->copy_table);
     if (ctx->pack_table) (void)hipFree(ctx->pack_table);
     if (ctx->nf_flag) (void)hipFree(ctx->nf_flag);
+    if (ctx->nf_host) (void)hipHostFree(ctx->nf_host);
+    for (hipEvent_t e : ctx->ev_nf) if (e) (void)hipEventDestroy(e);
     if (ctx->vrnn.parents) (void)hipFree(ctx->vrnn.parents);
     nm_vrnn_free_graphs(ctx);
     nm_net_free_tape(ctx);
@@ -209,6 +222,10 @@ int nm_ctx_check_nonfinite(nm_ctx* ctx) { NmScope nm_scope_(ctx);
     int rc = nm_check_hip(hipStreamSynchronize(ctx->stream), "check_nonfinite: sync");
     if (!rc) rc = nm_check_hip(hipMemcpy(&v, ctx->nf_flag, sizeof(v), hipMemcpyDeviceToHost), "check_nonfinite: read");
     if (rc) return rc;
+    for (int i = 0; i < 4; ++i) {          // the stream is drained: every pending status copy has landed; this report consumes them
+        if (ctx->nf_busy[i] && ctx->nf_host[i]) v = 1;
+        ctx->nf_busy[i] = false; ctx->nf_host[i] = 0;
+    }
     if (!v) return NM_OK;
     (void)hipMemset(ctx->nf_flag, 0, sizeof(unsigned));
     nm_set_error("a convolution produced non-finite values since the last check: %s", nm_conv_get_mode() != 0

@@ -61,6 +61,14 @@ struct ConvGeom {
 };
 
 void nm_set_error(const char* fmt, ...);
+// "done once" flags of per-DEVICE state (hipFuncSetAttribute, hipMemcpyToSymbol): one bit per device id, so that a second context on
+// another device of the same process sets its own attributes (a process-wide bool left it launching with the default LDS limit)
+struct NmDeviceOnce {
+    unsigned long long mask = 0;
+    static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    bool done() const { return (mask & bit()) != 0; }
+    void mark() { mask |= bit(); }
+};
 int nm_check_hip(hipError_t e, const char* what);
 
 // ---- per-context launch state ---------------------------------------------------------

@@ -2501,12 +2501,12 @@ hipEvent_t prof_event() {
 
 template <int MT, int NT>
 int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MT, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv)");
-        attr_set = true;
+        attr_set.mark();
     }
     ProfRec rec;
     rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
@@ -2539,12 +2539,12 @@ void choose_super_tile(ConvParams& p, int nblocks, int nbz, int nby, int nbx) {
 template <int MT, int NT, int KS, bool UP2, bool SINGLE>
 int launch_f16s_impl(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t s) {
     ConvParams p = p_in;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT, KS, UP2, SINGLE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16s)");
-        attr_set = true;
+        attr_set.mark();
     }
     ProfRec rec;
     rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * p.ks * p.ks * p.ks;
@@ -2591,12 +2591,12 @@ int g_num_cus = 0;
 template <bool UP2, bool SINGLE>
 int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
     ConvParams p = p_in;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2, SINGLE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p)");
-        attr_set = true;
+        attr_set.mark();
     }
     if (g_num_cus == 0) {
         int dev = 0; hipDeviceProp_t prop;
@@ -2624,12 +2624,12 @@ int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream
 template <bool UP2, bool SINGLE>
 int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
     ConvParams p = p_in;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p2_kernel<UP2, SINGLE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p2)");
-        attr_set = true;
+        attr_set.mark();
     }
     if (g_num_cus == 0) {
         int dev = 0; hipDeviceProp_t prop;

@@ -99,6 +99,16 @@ struct nm_ctx {
     size_t wside_slot = 0, wside_scratch = 0, wside_sc = 0;              // floats per ring slot / scratch / scale pool (last sizing pass)
     hipEvent_t ev_user_decoder = nullptr;  // caller's event, recorded by nm_detector_backward once the decoder's gradients are complete
     unsigned* nf_flag = nullptr;           // sticky: 1 = a conv produced non-finite values (nm_ctx_check_nonfinite reads and clears it)
+    // Deferred range guard (nm_net.hip nf_post / nf_poll): every forward-type call ends with an asynchronous copy of the status word
+    // into one of four pinned host slots + an event; the next calls' entry reads the slots whose event has completed (and waits for
+    // the ones two or more calls old, which never stalls the pipeline) - no host synchronisation per call.
+    unsigned* nf_host = nullptr;           // pinned [4]
+    hipEvent_t ev_nf[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool nf_busy[4] = {false, false, false, false};
+    uint64_t nf_seq[4] = {0, 0, 0, 0};     // call number of the slot's copy
+    const char* nf_who[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t nf_calls = 0;                 // forward-type calls so far
+    int range_check = 1;                   // NM355_RANGE_CHECK=0 switches the deferred guard off (A/B)
     Arena ws;                              // activations / scratch, reset per call
     Arena ws2;                             // scratch of work issued on stream2 (VRNN beside the decoder)
     std::vector<void*> owned;              // weight allocations

@@ -576,11 +576,11 @@ int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, flo
     const size_t fvox = (size_t)in.D * in.H * in.W;
     if (OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && Cout % 32 == 0 && in.C <= 128 && in.C % 8 == 0 && fvox % 32 == 0 && cvox >= 4096 &&
         fvox * 8 * Cout < ((size_t)1 << 31)) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static NmDeviceOnce attr_set;
+        if (!attr_set.done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(convT2_mfma)");
-            attr_set = true;
+            attr_set.mark();
         }
         const int tpf = (int)(fvox / 32), tiles = (int)(cvox / 32);
         const size_t ldsb = (size_t)4 * 32 * (in.C + 4) * sizeof(float);

@@ -2087,12 +2087,12 @@ int launch_wgrad_t(const WgradPlan& q, hipStream_t s) {
             return NM_ERR_ARG;
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<MODE, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             nm_set_error("wgrad: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL((wgrad_kernel<MODE, NTW>), dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
     return nm_check_hip(hipGetLastError(), "wgrad launch");
@@ -2156,13 +2156,13 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
         else hipLaunchKernelGGL(wgrad16t_kernel<0>, grid, dim3(512), ldsb, s, q.p);
         return nm_check_hip(hipGetLastError(), "wgrad16t launch");
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             nm_set_error("wgrad16: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     if (nm_conv_single()) hipLaunchKernelGGL(wgrad16_kernel<true>, dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
     else hipLaunchKernelGGL(wgrad16_kernel<false>, dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
@@ -2218,14 +2218,14 @@ int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride
         const int m_tiles = (dy.C + 31) / 32, n_tiles = (in.C + 31) / 32, T = m_tiles * n_tiles;
         const int bricks = in.N * (dy.D * dy.H * dy.W / 64), S = min(bricks, K1_WGS);
         const size_t ldsb = (size_t)64 * (m_tiles * 32 + 4 + n_tiles * 32 + 4) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static NmDeviceOnce attr_set;
+        if (!attr_set.done()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 nm_set_error("wgrad_k1: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
             }
-            attr_set = true;
+            attr_set.mark();
         }
         if (T <= 4) hipLaunchKernelGGL(wgrad_k1_kernel<1>, dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
         else if (T <= 8) hipLaunchKernelGGL(wgrad_k1_kernel<2>, dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
@@ -2267,11 +2267,11 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
     if ((rc = run_wgrad(q, dense_ws, dW, 4, 125, s))) return rc;
     // occupancy channel: matrix cores over the non-empty bricks (sparse_occ 1, grids that are whole 4x8x8 bricks), else the gather
     if (sparse_occ == 1 && G % 8 == 0) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static NmDeviceOnce attr_set;
+        if (!attr_set.done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k5occ_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(wgrad_k5occ_mfma)");
-            attr_set = true;
+            attr_set.mark();
         }
         // eight workgroups per CU when the clip allows: a workgroup's bricks are a serial chain (halo test, dY brick through LDS, 128
         // MFMA steps, no double buffering) - 512 / 1024 / 2048 workgroups: 915 / 794 / 637 us (+ 24 / 46 / 92 us of reduce)

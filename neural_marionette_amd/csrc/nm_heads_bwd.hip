@@ -628,12 +628,12 @@ int nm_launch_clip_loss_bwd(const float* keypoints, const float* affinity, const
                             int use_traj, float* dkp, float* dinfl, hipStream_t s) {
     const size_t lds = ((size_t)4 * T * K * 3 + K * 3 + 4 * K * K) * sizeof(float);
     if (lds > 150 * 1024) { nm_set_error("clip_loss_bwd: T*K too large (%d x %d)", T, K); return NM_ERR_UNSUPPORTED; }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(clip_loss_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
             nm_set_error("clip_loss_bwd: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(clip_loss_bwd_kernel, dim3(B), dim3(256), lds, s, keypoints, affinity, dloss, B, T, K, N, sep_sigma, use_traj, dkp,
                        affinity ? dinfl : nullptr);

@@ -287,16 +287,17 @@ size_t nm_hg_core_lds_bytes(const NmHgCoreParams& p) {
 int nm_launch_hg_core(const NmHgCoreParams& p, hipStream_t s) {
     const size_t lds = nm_hg_core_lds_bytes(p);
     if (lds > 150 * 1024) { nm_set_error("hg_core: %zu bytes of LDS per frame", lds); return NM_ERR_UNSUPPORTED; }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hg_core_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(hg_core)");
-        attr_set = true;
+        attr_set.mark();
     }
-    static int diag_set = -1;
+    static int diag_set[64];                // per device (the symbol is per-device state), stored + 1 so that 0 = never written
     const char* e = getenv("NM355_HG_DIAG");
     const int diag = e ? atoi(e) : 0;
-    if (diag != diag_set) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hg_diag), &diag, sizeof(int)); diag_set = diag; }
+    int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
+    if (diag + 1 != diag_set[dev]) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hg_diag), &diag, sizeof(int)); diag_set[dev] = diag + 1; }
     hipLaunchKernelGGL(hg_core_kernel, dim3(p.N), dim3(256), lds, s, p);
     return nm_check_hip(hipGetLastError(), "hg_core launch");
 }

@@ -1114,6 +1114,12 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
             b.run(nm_check_hip(hipStreamWaitEvent(b.s, c->ev_wjoin, 0), "backward: join weight-gradient stream"));
         }
     }
+    if (!b.ws.dry && b.rc != NM_OK) {
+        // a failed walk may have queued side-stream work that still writes the caller's gradient buffers and reads the dY ring: the
+        // header promises that nothing of this call is in flight on another stream when it returns an error
+        (void)hipStreamSynchronize(c->stream2);
+        if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+    }
     return b.rc;
 }
 
@@ -1129,11 +1135,58 @@ int with_workspace(nm_ctx* c, Fn&& graph) {
     return graph();
 }
 
+// ---- deferred range guard (include/nm355.h "Range / finiteness status") -----------------------------------------------------------
+// nf_post: behind a forward-type call, on its stream: status word -> pinned host slot, event.  nf_poll: at the entry of every later
+// call: slots whose event has completed are read (hipEventQuery, no wait); a slot two or more calls old is waited for - the device
+// is at least one whole call behind it, so the wait returns at once and the host never runs more than ~2 calls ahead of a report.
+// A set slot clears the device word, drops the younger slots (they saw the same sticky word) and fails the CURRENT call with
+// NM_ERR_RANGE naming the call that overflowed: its outputs, handed out earlier, hold NaN / inf.
+int nf_poll(nm_ctx* c) {
+    if (!c->range_check || !c->nf_host) return NM_OK;
+    int bad = -1;
+    for (int i = 0; i < 4; ++i) {
+        if (!c->nf_busy[i]) continue;
+        const bool old = c->nf_seq[i] + 2 <= c->nf_calls;
+        hipError_t e = old ? hipEventSynchronize(c->ev_nf[i]) : hipEventQuery(c->ev_nf[i]);
+        if (e == hipErrorNotReady) continue;
+        if (e != hipSuccess) return nm_check_hip(e, "range guard: status event");
+        c->nf_busy[i] = false;
+        if (c->nf_host[i] && (bad < 0 || c->nf_seq[i] < c->nf_seq[bad])) bad = i;
+        else c->nf_host[i] = 0;
+    }
+    if (bad < 0) return NM_OK;
+    const uint64_t seq = c->nf_seq[bad]; const char* who = c->nf_who[bad] ? c->nf_who[bad] : "?";
+    for (int i = 0; i < 4; ++i) {          // error path: drain the younger copies (they read the same sticky word), then clear it
+        if (c->nf_busy[i]) (void)hipEventSynchronize(c->ev_nf[i]);
+        c->nf_busy[i] = false; c->nf_host[i] = 0;
+    }
+    (void)hipMemsetAsync(c->nf_flag, 0, sizeof(unsigned), c->stream);
+    nm_set_error("call #%llu (%s) produced non-finite values - its outputs are invalid: %s", (unsigned long long)seq, who,
+                 nm_conv_get_mode() != 0
+                 ? "in the split-fp16 conv mode an activation beyond the fp16 range (|x| >= 65520) or a non-finite input does that where the "
+                   "reference's fp32 arithmetic stays finite - set conv mode 'fp32' (exact fp32 MFMA, no range limit) or 'auto' and run again"
+                 : "the input or the weights hold inf / NaN (exact fp32 mode has no range limit of its own)");
+    return NM_ERR_RANGE;
+}
+void nf_post(nm_ctx* c, const char* who) {
+    ++c->nf_calls;
+    if (!c->range_check || !c->nf_host) return;
+    int k = -1;
+    for (int i = 0; i < 4; ++i) if (!c->nf_busy[i]) { k = i; break; }
+    if (k < 0) return;                     // (cannot happen: nf_poll retires every slot two calls old)
+    c->nf_host[k] = 0;
+    if (hipMemcpyAsync(c->nf_host + k, c->nf_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return;
+    if (hipEventRecord(c->ev_nf[k], c->stream) != hipSuccess) { (void)hipStreamSynchronize(c->stream); return; }
+    c->nf_busy[k] = true; c->nf_seq[k] = c->nf_calls; c->nf_who[k] = who;
+}
+
 int check_ready(nm_ctx* c, const char* who) {
     if (!c) { nm_set_error("%s: null ctx", who); return NM_ERR_ARG; }
     if (!c->has_weights) { nm_set_error("%s: nm_ctx_set_weights has not been called", who); return NM_ERR_STATE; }
     nm_elem_set_nonfinite_flag(c->nf_flag);        // GroupNorm finalisation reports non-finite conv statistics into this ctx's status word
-    return nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
+    int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
+    if (!rc) rc = nf_poll(c);
+    return rc;
 }
 
 }  // namespace
@@ -1251,7 +1304,9 @@ int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32
     if (!vox || !keypoints || !heatmaps || !first_feature || !recon || !losses11 || B <= 0 || T <= 0) {
         nm_set_error("detector_forward: null / non-positive argument"); return NM_ERR_ARG;
     }
-    return with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11); });
+    rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11); });
+    if (!rc) nf_post(c, "nm_detector_forward");
+    return rc;
 }
 
 int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, const float* eps, int32_t S,
@@ -1278,7 +1333,9 @@ int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t 
     };
     rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11, &hook); });
     if (rc) return rc;
-    return nm_check_hip(hipStreamWaitEvent(c->stream, c->ev_side, 0), "join side stream");
+    rc = nm_check_hip(hipStreamWaitEvent(c->stream, c->ev_side, 0), "join side stream");
+    if (!rc) nf_post(c, "nm_forward_fused");
+    return rc;
 }
 
 int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* first_feature, const float* first_frame,
@@ -1288,7 +1345,9 @@ int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* fir
     if (!keypoints || !first_feature || !first_frame || !gen || B <= 0 || Tg <= 0) {
         nm_set_error("decode_from_keypoints: null / non-positive argument"); return NM_ERR_ARG;
     }
-    return with_workspace(c, [&]() { return decode_graph(c, keypoints, first_feature, first_frame, B, Tg, gen); });
+    rc = with_workspace(c, [&]() { return decode_graph(c, keypoints, first_feature, first_frame, B, Tg, gen); });
+    if (!rc) nf_post(c, "nm_decode_from_keypoints");
+    return rc;
 }
 
 // the ctx-owned block behind the weight-gradient stream (ring of dY buffers + scratch + scale pool), grown to the last sizing pass
@@ -1329,6 +1388,7 @@ int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T,
     t.fwd_top = c->ws.top;
     std::swap(c->ws, c->ws_t);
     t.valid = rc == NM_OK;
+    if (!rc) nf_post(c, "nm_detector_forward_train");
     return rc;
 }
 

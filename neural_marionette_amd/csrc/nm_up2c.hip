@@ -620,12 +620,12 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
                         hipStream_t s) {
     if (!nm_up2c_eligible(in.D, in.H, in.W, in.C, Cout, 3, 1, 1) || !packed) { nm_set_error("conv_up2c: shape not eligible"); return NM_ERR_ARG; }
     if ((in.scale == nullptr) != (in.shift == nullptr)) { nm_set_error("conv_up2c: scale/shift must come together"); return NM_ERR_ARG; }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_up2c)");
-        attr_set = true;
+        attr_set.mark();
     }
     const bool single = nm_conv_single() != 0;
     if (g_cus == 0) {

@@ -332,10 +332,12 @@ __device__ __forceinline__ void fk_tables_load(FkTables& tb, const int32_t* __re
 __device__ __forceinline__ void fk_levels(const FkTables& tb, int nlevels, const float* Rl, float* Rg, float* pos,
                                           const float* __restrict__ root, int ldr, int K, int B, int b, int smp, int lt, int per) {
     const int rootj = tb.lvl_joint[0];
-    if (smp >= 0 && lt < 12) {
+    if (smp >= 0) {                        // strided like the level loops: a sample may own fewer than 12 threads (S > 21 at 256 threads)
         const int i = smp;
-        if (lt < 9) Rg[(i * K + rootj) * 9 + lt] = Rl[(i * K + rootj) * 9 + lt];
-        else pos[(i * K + rootj) * 3 + (lt - 9)] = root[((size_t)(i * B + b)) * ldr + (lt - 9)];
+        for (int u = lt; u < 12; u += per) {
+            if (u < 9) Rg[(i * K + rootj) * 9 + u] = Rl[(i * K + rootj) * 9 + u];
+            else pos[(i * K + rootj) * 3 + (u - 9)] = root[((size_t)(i * B + b)) * ldr + (u - 9)];
+        }
     }
     __syncthreads();
     for (int l = 1; l <= nlevels; ++l) {

@@ -38,7 +38,9 @@ from .spec import DETECTOR_LOSS_KEYS, FEAT_DIM, HotPathOptions, param_spec
 Priority = namedtuple("Priority", ["values", "indices"])   # what torch.topk returns in the reference
 
 
-CONV_MODES = {"fp32": 0, "0": 0, "exact": 0, "split16": 1, "1": 1, "f16": 3, "3": 3}
+CONV_MODES = {"fp32": 0, "0": 0, "exact": 0, "split16": 1, "1": 1, "f16": 3, "3": 3, "auto": 1}
+NM_ERR_RANGE = -5
+CONV_MODE_NAMES = ("split16", "fp32", "f16", "auto")
 
 
 class Engine:
@@ -57,6 +59,11 @@ class Engine:
         # conv arithmetic: 1 = split-fp16 MFMA with fp32-equivalent accuracy (default), 0 = exact fp32 MFMA, 3 = fp16 products
         # with fp32 accumulation (reduced precision, for training)
         self.conv_mode = CONV_MODES.get(os.environ.get("NM355_CONV_MODE", "split16").lower(), 1)
+        # 'auto' (set_conv_mode): split16 with a synchronous range probe on the first conv-running call after every weight change;
+        # a call that overflows the fp16 range is re-run on the exact fp32 path, which then stays selected until the weights change
+        self.auto = os.environ.get("NM355_CONV_MODE", "").lower() == "auto"
+        self._probe = True
+        self._auto_fp32 = False
         self.training_packs = False     # detector-mode training: set_weights also packs the data-gradient weights
 
     # -- plumbing ---------------------------------------------------------------------------
@@ -81,7 +88,8 @@ class Engine:
             self._named = None
         _lib.check(self.ctx.lib.nm_ctx_set_training(self.ctx.handle, int(self.training_packs)), "set_training")
         self.ctx.bind_stream()
-        _lib.check(self.ctx.lib.nm_set_conv_mode(self.ctx.handle, self.conv_mode), "set_conv_mode")
+        mode = 0 if (self.auto and self._auto_fp32) else self.conv_mode
+        _lib.check(self.ctx.lib.nm_set_conv_mode(self.ctx.handle, mode), "set_conv_mode")
         self._sync_weights()
         return self.ctx
 
@@ -101,7 +109,13 @@ class Engine:
             self._named = own + [(k, torch.zeros(*shape, device=dev)) for k, shape in param_spec(self.opts) if k not in have]
         sd = self._named
         # (the conv mode and the training switch decide which derived tables set_weights builds: part of the stamp)
-        stamp = (self.conv_mode, self.training_packs) + tuple((t.data_ptr(), t._version) for _, t in sd)
+        wstamp = tuple((t.data_ptr(), t._version) for _, t in sd)
+        if self._stamp is not None and wstamp != self._stamp[2:] and self.auto:
+            self._probe = True                      # new weights: the next conv-running call is range-probed again ...
+            if self._auto_fp32:                     # ... starting over on the split path
+                self._auto_fp32 = False
+                _lib.check(self.ctx.lib.nm_set_conv_mode(self.ctx.handle, self.conv_mode), "set_conv_mode")
+        stamp = (0 if (self.auto and self._auto_fp32) else self.conv_mode, self.training_packs) + wstamp
         if stamp == self._stamp:
             return
         names, keep = [], []
@@ -120,6 +134,25 @@ class Engine:
 
     def call(self, fn: str, *args) -> None:
         _lib.check(getattr(self.ctx.lib, fn)(self.ctx.handle, *args), fn)
+
+    def call_conv(self, fn: str, *args) -> None:
+        """A call that runs the conv stacks.  Every such call is covered by the library's deferred range guard (a call whose
+        split-fp16 arithmetic overflowed makes a LATER call raise NmError, no host synchronisation).  In conv mode 'auto' the first
+        one after a weight change is also probed synchronously: if it overflowed it is re-run here on the exact fp32 path (all of a
+        call's outputs are rewritten), and fp32 stays selected until the weights change."""
+        self.call(fn, *args)
+        if not (self.auto and self._probe):
+            return
+        self._probe = False
+        rc = self.ctx.lib.nm_ctx_check_nonfinite(self.ctx.handle)
+        if rc == 0:
+            return
+        if rc != NM_ERR_RANGE or self._auto_fp32:
+            _lib.check(rc, "check_nonfinite")
+        self._auto_fp32 = True
+        self.ready()                                # exact fp32 MFMA + the weight tables of that mode
+        self.call(fn, *args)
+        _lib.check(self.ctx.lib.nm_ctx_check_nonfinite(self.ctx.handle), fn + " (re-run in fp32)")
 
 
 def _f32(t: torch.Tensor, dev) -> torch.Tensor:
@@ -149,7 +182,7 @@ class _DetectorTrain(torch.autograd.Function):
         recon = torch.empty(B, T, 1, G, G, G, device=dev)
         aff = torch.empty(module.nneighbor, K, K, 1, device=dev) if module.affinity_start else torch.empty(0, device=dev)
         losses = torch.empty(len(DETECTOR_LOSS_KEYS), device=dev)
-        eng.call("nm_detector_forward_train", _lib.ptr(vox), B, T, int(module.affinity_start), _lib.ptr(kp), _lib.ptr(hm),
+        eng.call_conv("nm_detector_forward_train", _lib.ptr(vox), B, T, int(module.affinity_start), _lib.ptr(kp), _lib.ptr(hm),
                  _lib.ptr(ff), _lib.ptr(recon), _lib.ptr(aff) if module.affinity_start else None, _lib.ptr(losses))
         ctx.module, ctx.names = module, names
         ctx.shapes = [p.shape for p in params]
@@ -241,7 +274,7 @@ class KyptDetector(nn.Module):
             recon = torch.empty(B, T, 1, G, G, G, device=dev)
             aff = torch.empty(self.nneighbor, K, K, 1, device=dev) if self.affinity_start else None
             losses = torch.empty(len(DETECTOR_LOSS_KEYS), device=dev)
-            eng.call("nm_detector_forward", _lib.ptr(vox), B, T, int(self.affinity_start), _lib.ptr(kp), _lib.ptr(hm),
+            eng.call_conv("nm_detector_forward", _lib.ptr(vox), B, T, int(self.affinity_start), _lib.ptr(kp), _lib.ptr(hm),
                      _lib.ptr(ff), _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses))
         out = dict(recon=recon, keypoints=kp, heatmaps=hm, affinity=aff)
         for i, name in enumerate(DETECTOR_LOSS_KEYS):
@@ -266,7 +299,7 @@ class KyptDetector(nn.Module):
         G = self.grid_size
         gen = torch.empty(B, Tg, 1, G, G, G, device=dev)
         kp, ff, fr = _f32(keypoints, dev), _f32(first_feature, dev), _f32(first_frame, dev)
-        eng.call("nm_decode_from_keypoints", _lib.ptr(kp), _lib.ptr(ff), _lib.ptr(fr), B, Tg, _lib.ptr(gen))
+        eng.call_conv("nm_decode_from_keypoints", _lib.ptr(kp), _lib.ptr(ff), _lib.ptr(fr), B, Tg, _lib.ptr(gen))
         return dict(gen=gen)
 
 
@@ -557,10 +590,15 @@ class NeuralMarionette(nn.Module):
         """'split16' (default): convs with Cin % 16 == 0 on the fp16 matrix cores, operands split hi/lo, fp32
         accumulate (fp32-equivalent accuracy); 'fp32': exact fp32 MFMA everywhere; 'f16': the split16 kernels with the
         hi x hi product only - operands rounded to fp16, fp32 accumulation and storage (autocast-class accuracy, the
-        reduced-precision training mode; outside the 1e-4 parity contract)."""
-        if mode not in ("split16", "fp32", "f16"):
-            raise ValueError("conv mode must be 'split16', 'fp32' or 'f16'")
-        self._engine.conv_mode = CONV_MODES[mode]
+        reduced-precision training mode; outside the 1e-4 parity contract); 'auto': split16, but the first conv-running call after
+        every weight change is range-checked synchronously and re-run on the exact fp32 path if an activation left the fp16 range
+        (fp32 then stays selected until the weights change).  In every mode the library's deferred range guard makes a LATER call
+        raise NmError when an earlier one produced non-finite values (no per-call host synchronisation)."""
+        if mode not in CONV_MODE_NAMES:
+            raise ValueError("conv mode must be one of " + ", ".join(repr(m) for m in CONV_MODE_NAMES))
+        eng = self._engine
+        eng.conv_mode = CONV_MODES[mode]
+        eng.auto, eng._probe, eng._auto_fp32 = mode == "auto", True, False
 
     def check_finite(self) -> None:
         """Synchronises and raises NmError if a convolution has produced non-finite values since the last check - in the default
@@ -712,7 +750,7 @@ class NeuralMarionette(nn.Module):
         rec = torch.empty(B, T, K, 4, device=dev); R = torch.empty(B, T, K, 3, 3, device=dev)
         z = torch.empty(B, T, Z, device=dev); h = torch.empty(B, T + 1, H, device=dev)
         sc = torch.empty(2, device=dev); best = torch.empty(B, T, device=dev, dtype=torch.int32)
-        eng.call("nm_forward_fused", _lib.ptr(vox), B, T, 1, _lib.ptr(e), S, _lib.ptr(kp), _lib.ptr(hm), _lib.ptr(ff),
+        eng.call_conv("nm_forward_fused", _lib.ptr(vox), B, T, 1, _lib.ptr(e), S, _lib.ptr(kp), _lib.ptr(hm), _lib.ptr(ff),
                  _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses), _lib.ptr(rec), _lib.ptr(R), _lib.ptr(z), _lib.ptr(h),
                  _lib.ptr(sc), _lib.ptr(best))
         log = dict(recon=recon, keypoints=kp, heatmaps=hm, affinity=aff)

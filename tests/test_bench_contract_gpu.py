@@ -39,3 +39,20 @@ def test_training_line_reduced_precision():
     d = _run("--workload", "train", "--conv-mode", "f16", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline")
     assert d["value"] > 0 and "f16 conv products" in d["dtype"]
     assert "training step" in d["config"]["workload"]
+
+
+def test_forward_line_under_torchrun_one_rank():
+    """The N > 1 branch of bench.py on real RCCL as far as one GPU allows: `python -m torch.distributed.run --nproc-per-node 1 bench.py`
+    (no --gpus: the launcher's WORLD_SIZE is adopted) runs init_process_group('nccl'), the barriers around the timed region, the
+    MAX-reduce of the elapsed time and the all-reduce of ones on a 1-rank RCCL communicator."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+                        "--nproc-per-node=1", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["distributed"]["backend"] == "nccl" and d["distributed"]["world_size"] == 1 and d["distributed"]["ranks_seen_by_allreduce"] == 1

@@ -124,6 +124,26 @@ def test_g2_vrnn_unit_parity_on_reference_keypoints(golden_dir):
     assert out["gae_recon_loss"].dtype == torch.int64
 
 
+def test_vrnn_encode_with_more_than_21_samples_vs_oracle():
+    """S = 25 best-of-S samples with K = 24: a sample owns 256 // 25 = 10 threads of the level-parallel FK kernel, fewer than the 12
+    root entries (the root joint was only initialised for S <= 21 before round 4).  Unit parity on given keypoints."""
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=4, variant="default")
+    net = _net(o, sd)
+    B, T, S, K, Z = 2, 3, 25, o.nkeypoints, o.nlatent_kypt
+    gsd = torch.Generator().manual_seed(5)
+    kp = torch.rand(B, T, K, 4, generator=gsd) * 1.6 - 0.8
+    eps = synth.make_eps((T, S, B, Z), seed=9)
+    with torch.no_grad():
+        aff = O.affinity_v3(sd["kypt_detector.affinity_params"])
+        _, order, _, parents = O.build_tree(aff)
+        ref = O.vrnn_encode(sd, o, kp, order, parents, eps)
+        out = net.dyna_module.encode(kp.cuda(), aff.cuda(), SAMPLE_NUM=S, eps=eps.cuda())
+    for k in ("kypt_recon", "R", "z_kypts", "h_kypts"):
+        assert _err(out[k], ref[k]) < KP_TOL, (k, _err(out[k], ref[k]))
+    assert np.array_equal(out["best_idx"].cpu().numpy(), ref["best_idx"].numpy().astype(np.int32))
+
+
 @pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("mode", MODES)
 def test_g1_config1_detector64(golden_dir, mode, path):
@@ -474,6 +494,50 @@ def test_range_guard_reports_overflow():
     assert torch.isfinite(out["recon"]).all()
     assert _err(out["keypoints"], ref["keypoints"]) < KP_TOL
     assert _err(out["recon"], ref["recon"]) < 1e-3
+
+
+def test_range_guard_is_automatic_and_auto_mode_falls_back():
+    """No check_finite() anywhere.  (a) default mode: the library copies its status word to a pinned host slot behind every
+    forward-type call and reads it at the entry of the next ones - the call AFTER an overflowing one raises NmError naming it once the
+    device has finished it (here: after the caller drained the stream to look at the outputs), and at the latest two calls later
+    without any synchronisation.  (b) conv mode 'auto': the first call after a weight change is probed and re-run in exact fp32 -
+    finite outputs that match the oracle, where the reference's fp32 arithmetic (kypt_detector.py:81-169) never returns NaN."""
+    from neural_marionette_amd import _lib
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=61, variant="default")
+    key = "kypt_detector.kypt_to_vox.decode_voxel_from_combined_representation.2.weight"
+    sd[key] = sd[key] * 1e6
+    vox = synth.figure_clip(1, 2, 32, seed=16).cuda()
+    acts = {"detector": True, "learner": False}
+    net = _net(o, sd, "split16")
+    with torch.no_grad():
+        out = net(vox, acts)
+        assert not torch.isfinite(out["recon"]).all()           # (reading the outputs drains the stream)
+        with pytest.raises(_lib.NmError, match=r"call #\d+ \(nm_detector_forward\)"):
+            net(vox, acts)
+        # the report cleared the status word: the next two calls go through, the one after them reports the overflow again
+        raised = 0
+        for _ in range(4):
+            try:
+                net(vox, acts)
+            except _lib.NmError:
+                raised += 1
+        assert raised >= 1, "without any synchronisation the guard must still fire within two calls"
+        torch.cuda.synchronize()
+        net.set_conv_mode("auto")
+        out = net(vox, acts)
+        assert net._engine._auto_fp32, "the probe must have switched this weight set to the exact fp32 path"
+        assert torch.isfinite(out["recon"]).all()
+        ref = O.detector_forward(sd, o, vox.cpu())
+        assert _err(out["keypoints"], ref["keypoints"]) < KP_TOL
+        assert _err(out["recon"], ref["recon"]) < 1e-3
+        out2 = net(vox, acts)                                    # stays on fp32 for these weights, no further probe
+        assert torch.equal(out2["recon"], out["recon"])
+        # healthy weights in 'auto' stay on the split path
+        sd_ok = synth.make_state_dict(o, seed=61, variant="default")
+        net.load_state_dict(sd_ok)
+        out3 = net(vox, acts)
+        assert not net._engine._auto_fp32 and torch.isfinite(out3["recon"]).all()
 
 
 def test_decode_from_dyna_unit_vs_oracle():

@@ -204,3 +204,12 @@ def test_detector_trainer_rejects_unknown_loss_names_and_tracks_weight_edits():
     net.kypt_detector.affinity_params.requires_grad = False
     names = [n for n, _ in tr._named()]
     assert "kypt_detector.affinity_params" in names and len(names) == len(list(net.kypt_detector.parameters()))
+
+
+def test_bench_adopts_world_size_when_gpus_is_not_given():
+    """`torchrun --nproc-per-node N bench.py` without --gpus: the launcher's rank count is the request (only an explicit mismatch fails)."""
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    r, lines = _bench("--dist-selftest", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["distributed"]["world_size"] == 1
