@@ -39,8 +39,9 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=["forward", "train"], default="forward",
                     help="forward (default, BASELINE configs[1]): full NeuralMarionette.forward; train (configs[2] shape, fp32): one "
                          "detector-mode training step = forward + backward + gradient all-reduce + Adam")
-    ap.add_argument("--conv-mode", choices=["split16", "fp32", "f16"], default="split16",
-                    help="split16: fp32-equivalent 3x f16 MFMA products (default); fp32: exact fp32 MFMA everywhere")
+    ap.add_argument("--conv-mode", choices=["split16", "fp32", "f16", "bf16"], default="split16",
+                    help="split16: fp32-equivalent 3x f16 MFMA products (default); fp32: exact fp32 MFMA everywhere; f16: products of fp16-rounded "
+                         "operands, fp32 storage; bf16: f16 arithmetic + bfloat16 storage of the training path (BASELINE config 3 as named)")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run only the multi-rank plumbing of this file (rendezvous, barrier, all-reduce of ones, MAX-reduce of the elapsed "
                          "time) and print it as one JSON line; backend gloo when no GPU is visible (tests/test_sharding_cpu.py)")
@@ -274,6 +275,32 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
                             frac_of_f16_mfma_peak=3.0 * STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS)
     with torch.no_grad():
         net.load_state_dict(saved)
+    # BASELINE configs[2] in its NAMED precision: the 'f16' arithmetic with bfloat16 storage of every activation / activation gradient of
+    # >= 32^3 voxels per frame that the training forward keeps (conv mode 4; fp32 master weights, GroupNorm statistics, accumulators, Adam)
+    # (a context of its own: a context's arenas only grow, and this mode's point is the halved training arena)
+    from neural_marionette_amd import NeuralMarionette as _NM
+    net_b = _NM(net.options)
+    net_b.load_state_dict(saved)
+    net_b = net_b.to(dev).train()
+    net_b.anneal(1)
+    net_b.set_conv_mode("bf16")
+    tr = DetectorTrainer(net_b, lr=4e-4)
+    step = lambda: tr.step(vox, sync=False)
+    ms = timed(step, 2, 5) * 1e3
+    mem2 = (C.c_size_t * 4)()
+    _lib.check(net_b._engine.ctx.lib.nm_ctx_memory(net_b._engine.ctx.handle, mem2), "ctx_memory")
+    del tr, net_b
+    out["train_bf16"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=5, warmup=2,
+                             workload="the `train` step in conv mode 'bf16' (BASELINE configs[2]: 64^3, T=16, B=4 clips per GPU, bf16)",
+                             dtype="bfloat16 storage of the training path's activations and activation gradients (>= 32^3 voxels per frame), conv products of "
+                                   "fp16-rounded operands with fp32 accumulation, fp32 master weights / GroupNorm statistics / Adam "
+                                   "(tests/test_storage16_gpu.py states the gradient bounds)",
+                             n_gpus=world, algorithmic_tflop_per_step=3.0 * STEP_TFLOP,
+                             frac_of_f16_mfma_peak=3.0 * STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS,
+                             training_arena_gb=mem2[1] / 1e9, weight_gradient_side_block_gb=mem2[2] / 1e9,
+                             note="memory: ctx-owned arenas of this mode's own context (nm_ctx_memory); the fp32-storage figures are in train_memory_gb")
+    with torch.no_grad():
+        net.load_state_dict(saved)
     # the second regime of train.py (pretrained_mode 1): detector frozen and run forward only, the VRNN trained through its BPTT kernels
     net.set_conv_mode("split16")
     from neural_marionette_amd.train import LearnerTrainer
@@ -500,7 +527,9 @@ def main():
             higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype=("f32 (conv products as 3x f16-split MFMA with f32 accumulate, fp32-equivalent; everything else f32)"
                    if eng.conv_mode == 1 else ("f16 conv products (operands rounded to fp16, 1 MFMA per product), f32 accumulation and storage"
-                                               if eng.conv_mode == 3 else "f32")),
+                                               if eng.conv_mode == 3 else ("bf16 storage of the training path (activations / activation gradients >= 32^3 voxels per frame), "
+                                                                            "f16 conv products, f32 accumulation, master weights, statistics and optimizer"
+                                                                            if eng.conv_mode == 4 else "f32"))),
             data="synthetic",
             config=dict(workload=("AIST++-shaped synthetic clips 64^3 T=16 B=4/GPU, full NeuralMarionette.forward "
                                   "(detector + 11 losses + HSVRNNBVH.encode, best-of-10), fp32, random-init weights") if args.workload == "forward" else
@@ -520,6 +549,11 @@ def main():
                              device_count=torch.cuda.device_count(), device=torch.cuda.get_device_name(dev)),
             **extra,
         )
+        if args.workload == "train":
+            mem = (C.c_size_t * 4)()
+            _lib.check(lib.nm_ctx_memory(h, mem), "ctx_memory")
+            line["train_memory_gb"] = dict(inference_workspace=mem[0] / 1e9, training_arena=mem[1] / 1e9, weight_gradient_side_block=mem[2] / 1e9,
+                                           weights_and_packs=mem[3] / 1e9, note="ctx-owned device memory after this mode's training steps (nm_ctx_memory)")
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

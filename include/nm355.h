@@ -304,9 +304,22 @@ int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, in
  * bf16, same MFMA rate), fp32 accumulation, fp32 tensors, statistics, losses, master weights and optimiser; the layers mode 1
  * leaves on the fp32 cores (k = 1 / 2 weight gradients, volumes under 16^3, heads, VRNN) stay fp32.  Forward, data and weight
  * gradients all follow the mode.  Outputs differ from the reference's fp32 path by ~1e-3 relative (tests state the bound);
- * the 1e-4 parity contract holds in modes 0-2 only. */
+ * the 1e-4 parity contract holds in modes 0-2 only.
+ * mode 4 = BASELINE config 3 as named ("bf16"): mode 3's arithmetic with 16-BIT STORAGE of the training path - every activation the
+ * training forward keeps for the backward pass and every activation gradient with at least 32^3 voxels per frame is stored as
+ * bfloat16 (8 significant bits, fp32's range: no loss scaling), converted to fp32 on read and rounded to nearest even on write;
+ * master weights, GroupNorm statistics / scale / shift, every partial sum and accumulator, the losses and the Adam state stay fp32,
+ * as do the tensors below 32^3 (the hourglass, heads, keypoints) and the inference forward (which keeps mode 3's fp32 workspace).
+ * Halves the training arena and the bytes of the GroupNorm-backward passes; gradients agree with the fp64 oracle to a few 1e-2 in
+ * whole-gradient L2 (tests state the bound). */
 int nm_set_conv_mode(nm_ctx* ctx, int32_t mode);
 int nm_get_conv_mode(nm_ctx* ctx);
+/* Element type of the tensors the op-level entry points below (nm_op_*) read and write, for unit parity of the 16-bit storage kernels
+ * of conv mode 4: in_h != 0 - the tensors on the input side (in / a / y and every gradient of their shape: d_in, dA, dy of
+ * nm_op_gn_backward) are bfloat16; out_h != 0 - the tensors on the output side (out, the incoming dy of the backward ops) are.
+ * Defaults 0 / 0 (fp32, the element type of every network-level entry point's arguments).  Kernels without an instantiation for the
+ * requested combination fail with NM_ERR_UNSUPPORTED. */
+int nm_op_set_storage16(nm_ctx* ctx, int32_t in_h, int32_t out_h);
 
 /* ---- live kernel timing for bench.py's roofline leg -------------------------------------------
  * While enabled, every conv launch of this context is bracketed by a HIP event pair.  on = 1: launches on the ctx stream only

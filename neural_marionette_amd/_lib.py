@@ -87,6 +87,7 @@ SIGNATURES = {
     "nm_op_gn_backward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "nm_set_conv_mode": (C.c_int, [C.c_void_p, _I]),
     "nm_get_conv_mode": (C.c_int, [C.c_void_p]),
+    "nm_op_set_storage16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "nm_prof_enable": (C.c_int, [C.c_void_p, _I]),
     "nm_prof_read": (C.c_int, [C.c_void_p, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nm_prof_kernel_name": (C.c_char_p, [_I]),
@@ -129,15 +130,16 @@ def check(rc: int, what: str = "") -> None:
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor (None -> NULL)."""
+    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor (None -> NULL); bfloat16 for the op-level entry points under
+    nm_op_set_storage16 (unit parity of the 16-bit storage kernels)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise NmError("nm355 needs device tensors (HIP); got a CPU tensor — there is no CPU fallback")
     if not t.is_contiguous():
         raise NmError("nm355 needs contiguous tensors")
-    if t.dtype not in (torch.float32, torch.int32, torch.float64):
-        raise NmError(f"nm355 needs fp32/int32 (fp64 for point clouds) tensors, got {t.dtype}")
+    if t.dtype not in (torch.float32, torch.int32, torch.float64, torch.bfloat16):
+        raise NmError(f"nm355 needs fp32/int32 (fp64 for point clouds; bfloat16 for the 16-bit storage op tests) tensors, got {t.dtype}")
     return t.data_ptr()
 
 

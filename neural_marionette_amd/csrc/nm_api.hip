@@ -46,7 +46,7 @@ NmLaunchState::NmLaunchState()
       lazy_res(env_int("NM355_LAZY_RES", 1)),         // 0: every residual sum is materialised by apply2 (A/B)
       adjust_split(env_int("NM355_ADJUST_SPLIT", 1)), // 0: the decoder's first 1x1 conv runs over the materialised 184-channel tensor in inference too (A/B)
       hg_core(env_int("NM355_HG_CORE", 1)),           // 0: the two lowest hourglass levels as separate launches in inference too (A/B)
-      f16p_dma(env_int("NM355_F16P_DMA", 0)) {}         // 1: conv_f16p2's producers copy the weights by LDS-DMA instead of through registers (A/B)
+      f16p_dma(env_int("NM355_F16P_DMA", 0)) { store16_min = env_int("NM355_STORE16_MIN", 32768); }         // 1: conv_f16p2's producers copy the weights by LDS-DMA instead of through registers (A/B)
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
     return nm_tls_ls ? *nm_tls_ls : outside;
@@ -253,13 +253,19 @@ int nm_ctx_set_training(nm_ctx* ctx, int32_t on) { NmScope nm_scope_(ctx);
 }
 
 int nm_set_conv_mode(nm_ctx* ctx, int32_t mode) {
-    if (!ctx || mode < 0 || mode > 3) { nm_set_error("set_conv_mode: mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA), 2 (split-fp16, conv_f16p wherever eligible) or 3 (fp16 products, fp32 accumulation)"); return NM_ERR_ARG; }
+    if (!ctx || mode < 0 || mode > 4) { nm_set_error("set_conv_mode: mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA), 2 (split-fp16, conv_f16p wherever eligible), 3 (fp16 products, fp32 accumulation) or 4 (mode 3 + bfloat16 storage of the training path's tensors)"); return NM_ERR_ARG; }
     NmScope sc(ctx);
     nm_conv_set_mode(mode);
     return NM_OK;
 }
 
 int nm_get_conv_mode(nm_ctx* ctx) { NmScope sc(ctx); return nm_conv_get_mode(); }
+
+int nm_op_set_storage16(nm_ctx* ctx, int32_t in_h, int32_t out_h) {
+    if (!ctx) { nm_set_error("op_set_storage16: null ctx"); return NM_ERR_ARG; }
+    ctx->ls.op_in_h = in_h ? 1 : 0; ctx->ls.op_out_h = out_h ? 1 : 0;
+    return NM_OK;
+}
 
 int nm_prof_enable(nm_ctx* ctx, int32_t on) { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("prof_enable: null ctx"); return NM_ERR_ARG; }
@@ -298,6 +304,12 @@ static TensorRef make_ref(const float* p, const float* sc, const float* sh, floa
     return t;
 }
 
+// 16-bit storage at the op level (nm_op_set_storage16): element type of the tensors on the input side (in / a / y, and the gradients of
+// their shape) and on the output side (out, dy and the fine-grid temporaries)
+static int op_ih() { return nm_ls().op_in_h; }
+static int op_oh() { return nm_ls().op_out_h; }
+static TensorRef with_h(TensorRef t, int h) { t.h = h; return t; }
+
 static int finish_gn(nm_ctx* ctx, const float* part, int N, int nblk, int C, int groups, double count,
                      const float* gamma, const float* beta, float* scale, float* shift) {
     nm_elem_set_nonfinite_flag(nullptr);           // (op-level entry points check their results themselves)
@@ -335,11 +347,11 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     if (wp16 && (rc = nm_launch_pack_conv_weight16(weight, Cout, Cin, ks, wp16, Co_pad, ctx->stream))) return rc;
     if (wup && (rc = nm_launch_up2c_compose(weight, Cout, Cin, Co_pad, wup, ctx->stream))) return rc;
     g.up2c = wup;
-    TensorRef t = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad);
-    rc = nm_launch_conv(t, wp, bias, out, g, part, ctx->stream, Cin, wp16);
+    TensorRef t = with_h(make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad), op_ih());
+    rc = nm_launch_conv(t, wp, bias, out, g, part, ctx->stream, Cin, wp16, op_oh());
     if (rc) return rc;
     int nblk_used = nblk;
-    if (nm_conv_get_mode() != 0) {
+    if (nm_conv_get_mode() != 0 && !op_oh() && !op_ih()) {
         // op-level calls are synchronous about the fp16 range: operands beyond it make the split product inf / NaN where fp32 is
         // finite - scan the result and, if that happened, run the launch again on the exact fp32 MFMA path
         const int mode = nm_conv_get_mode();
@@ -382,7 +394,7 @@ int nm_op_conv5_occ(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, const f
     if ((rc = nm_launch_pack_input(zero, 1, 1, G, 0, packed_in, s))) return rc;
     ConvGeom g; g.ks = 5; g.stride = 1; g.pad = 2; g.OD = g.OH = g.OW = G; g.Cout = Cout; g.Co_pad = Co_pad;
     if ((rc = nm_launch_conv(make_ref(packed_in, nullptr, nullptr, 1.0f, 1, G, G, G, 8), wfull, bias, field, g, nullptr, s, 4))) return rc;
-    if ((rc = nm_launch_conv_k5occ(occ, N, G, wocc, field, out, Cout, Co_pad, gn_groups > 0 ? part : nullptr, s))) return rc;
+    if ((rc = nm_launch_conv_k5occ(occ, N, G, wocc, field, out, Cout, Co_pad, gn_groups > 0 ? part : nullptr, s, nullptr, nullptr, nullptr, op_oh()))) return rc;
     if (gn_groups > 0) rc = finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)G3 * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
     return rc;
 }
@@ -399,10 +411,10 @@ int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     float* wt = ctx->ws.f((size_t)Cin * Cout * 8);
     float* part = ctx->ws.f((size_t)N * nblk * Cout * 2);
     if ((rc = nm_launch_transpose_convT_weight(weight, Cin, Cout, wt, ctx->stream))) return rc;
-    TensorRef t = make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, Cin);
-    rc = nm_launch_convT2(t, wt, bias, out, Cout, OD, OH, OW, ctx->stream);
+    TensorRef t = with_h(make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, Cin), op_ih());
+    rc = nm_launch_convT2(t, wt, bias, out, Cout, OD, OH, OW, ctx->stream, op_oh());
     if (rc || gn_groups <= 0) return rc;
-    rc = nm_launch_gn_partials(out, N, vox, Cout, part, ctx->stream);
+    rc = nm_launch_gn_partials(out, N, vox, Cout, part, ctx->stream, op_oh());
     if (rc) return rc;
     return finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)vox * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
 }
@@ -411,14 +423,14 @@ int nm_op_apply2(nm_ctx* ctx, const float* a, const float* a_scale, const float*
                  const float* b, const float* b_scale, const float* b_shift, float b_slope, int32_t N,
                  int32_t voxels, int32_t C, float* out) { NmScope nm_scope_(ctx);
     if (!ctx || !a || !out) { nm_set_error("op_apply2: null argument"); return NM_ERR_ARG; }
-    TensorRef ta = make_ref(a, a_scale, a_shift, a_slope, N, 1, 1, voxels, C);
-    TensorRef tb = make_ref(b, b_scale, b_shift, b_slope, N, 1, 1, voxels, C);
-    return nm_launch_apply2(ta, b ? &tb : nullptr, out, ctx->stream);
+    TensorRef ta = with_h(make_ref(a, a_scale, a_shift, a_slope, N, 1, 1, voxels, C), op_ih());
+    TensorRef tb = with_h(make_ref(b, b_scale, b_shift, b_slope, N, 1, 1, voxels, C), op_ih());
+    return nm_launch_apply2(ta, b ? &tb : nullptr, out, ctx->stream, op_oh());
 }
 
 int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out) { NmScope nm_scope_(ctx);
     if (!ctx || !in || !out) { nm_set_error("op_upsample2: null argument"); return NM_ERR_ARG; }
-    return nm_launch_upsample2(make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, C), out, ctx->stream);
+    return nm_launch_upsample2(with_h(make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, C), op_ih()), out, ctx->stream, op_oh());
 }
 
 int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out) { NmScope nm_scope_(ctx);
@@ -454,12 +466,12 @@ int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
     if (rc) return rc;
     ctx->ws.release(0);
     hipStream_t s = ctx->stream;
-    TensorRef a = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad);
-    TensorRef dyT = make_ref(dy, nullptr, nullptr, 1.0f, N, OD, OH, OW, Cout);
+    TensorRef a = with_h(make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin_pad), op_ih());
+    TensorRef dyT = with_h(make_ref(dy, nullptr, nullptr, 1.0f, N, OD, OH, OW, Cout), op_oh());
     if (up2) {
         float* up = ctx->ws.f(fine * Cin_pad);
-        if ((rc = nm_launch_upsample2(a, up, s))) return rc;
-        a = make_ref(up, nullptr, nullptr, 1.0f, N, FD, FH, FW, Cin_pad);
+        if ((rc = nm_launch_upsample2(a, up, s, op_oh()))) return rc;
+        a = with_h(make_ref(up, nullptr, nullptr, 1.0f, N, FD, FH, FW, Cin_pad), op_oh());
     }
     float* ws = ctx->ws.f(wsf);
     if ((rc = nm_launch_wgrad(a, dyT, ks, stride, pad, Cin, ws, d_weight, s, nullptr, nm_conv_get_mode() != 0))) return rc;
@@ -478,8 +490,8 @@ int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
         if ((rc = nm_check_hip(hipMemsetAsync(zb, 0, co_pad2 * sizeof(float), s), "memset"))) return rc;
         ConvGeom g; g.ks = ks; g.stride = 1; g.pad = ks - 1 - pad; g.OD = FD; g.OH = FH; g.OW = FW; g.Cout = csel; g.Co_pad = co_pad2;
         float* dfine = up2 ? ctx->ws.f(fine * csel) : d_in;
-        if ((rc = nm_launch_conv(dyT, wp, zb, dfine, g, nullptr, s, Cout, h16 ? wp16 : nullptr))) return rc;
-        if (up2) rc = nm_launch_upsample2_adjoint(dfine, N, D, H, W, csel, d_in, s);
+        if ((rc = nm_launch_conv(dyT, wp, zb, dfine, g, nullptr, s, Cout, h16 ? wp16 : nullptr, up2 ? op_oh() : op_ih()))) return rc;
+        if (up2) rc = nm_launch_upsample2_adjoint(dfine, N, D, H, W, csel, d_in, s, nullptr, op_oh(), op_ih());
         return rc;
     }
     if (stride == 2 && ks == 2 && pad == 0 && !up2) {
@@ -487,7 +499,7 @@ int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
         if (csel != Cin) { nm_set_error("op_conv3d_backward: pool dgrad needs all input channels"); return NM_ERR_ARG; }
         if ((rc = nm_launch_transpose_convT_weight(weight, Cout, Cin, wt, s))) return rc;
         if ((rc = nm_check_hip(hipMemsetAsync(zb, 0, co_pad2 * sizeof(float), s), "memset"))) return rc;
-        return nm_launch_convT2(dyT, wt, zb, d_in, Cin, D, H, W, s);
+        return nm_launch_convT2(dyT, wt, zb, d_in, Cin, D, H, W, s, op_ih());
     }
     nm_set_error("op_conv3d_backward: unsupported geometry"); return NM_ERR_UNSUPPORTED;
 }
@@ -501,7 +513,7 @@ int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G
     int rc = nm_ctx_reserve(ctx, (wsf + (size_t)N * nbb * Cout * 2) * sizeof(float) + 8192);
     if (rc) return rc;
     ctx->ws.release(0);
-    TensorRef dyT = make_ref(dy, nullptr, nullptr, 1.0f, N, G, G, G, Cout);
+    TensorRef dyT = with_h(make_ref(dy, nullptr, nullptr, 1.0f, N, G, G, G, Cout), op_oh());
     float* ws = ctx->ws.f(wsf); float* bp = ctx->ws.f((size_t)N * nbb * Cout * 2);
     if ((rc = nm_launch_wgrad_k5occ(occ, N, G, dyT, ws, d_weight, ctx->stream, sparse_occ))) return rc;
     if ((rc = nm_launch_gnb_partials(dy, dyT, bp, ctx->stream))) return rc;
@@ -552,9 +564,9 @@ int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, in
     float* fpart = ctx->ws.f((size_t)N * nbf * C * 2); float* bpart = ctx->ws.f((size_t)N * nbb * C * 2);
     float* scale = ctx->ws.f((size_t)N * C); float* shift = ctx->ws.f((size_t)N * C);
     float* coef = ctx->ws.f((size_t)N * C * 4); float* dgn = ctx->ws.f((size_t)N * C * 4);
-    if ((rc = nm_launch_gn_partials(y, N, voxels, C, fpart, s))) return rc;
+    if ((rc = nm_launch_gn_partials(y, N, voxels, C, fpart, s, op_ih()))) return rc;
     if ((rc = finish_gn(ctx, fpart, N, nbf, C, groups, (double)voxels * (C / groups), gamma, beta, scale, shift))) return rc;
-    TensorRef yT = make_ref(y, scale, shift, slope, N, 1, 1, voxels, C);
+    TensorRef yT = with_h(make_ref(y, scale, shift, slope, N, 1, 1, voxels, C), op_ih());
     if ((rc = nm_launch_gnb_partials(dA, yT, bpart, s))) return rc;
     if ((rc = nm_launch_gnb_finalize(bpart, nbb, fpart, nbf, N, C, groups, voxels, gamma, 1e-5f, coef, dgn, s))) return rc;
     if ((rc = nm_launch_sum_frames(dgn, N, C, 4, 0, dgamma, s))) return rc;

@@ -33,6 +33,48 @@ __device__ __forceinline__ f32x16 nm_mfma_lo(nm_half8 a, nm_half8 b, f32x16 c) {
 }
 
 
+// ---- 16-bit storage (conv mode 4, 'bf16': BASELINE config 3) -----------------------------------------------------------------------
+// In this mode the activations and activation gradients of the training path with >= nm_ls().store16_min voxels per frame are stored
+// as bfloat16 (same channels-last layout, half the bytes); weights, GroupNorm statistics / scale / shift, partial sums, accumulators,
+// the Adam state and every tensor below the threshold stay fp32.  A tensor's element type travels as TensorRef::h (raw gradient
+// pointers: as an explicit flag of the launcher); pointers stay `float*` and element offsets are scaled by the accessors below.
+// Conversions: bf16 -> f32 is a shift / mask (exact), f32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32).
+typedef unsigned nm_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 nm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float nm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned nm_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(nm_f32x2{a, b}, nm_bf16x2));
+}
+__device__ __forceinline__ float nm_bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float nm_bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ f32x4 nm_bf4_to_f32(nm_u32x2 u) { return f32x4{nm_bf_lo(u[0]), nm_bf_hi(u[0]), nm_bf_lo(u[1]), nm_bf_hi(u[1])}; }
+__device__ __forceinline__ nm_u32x2 nm_f32_to_bf4(const f32x4& v) { return nm_u32x2{nm_pk_bf16(v[0], v[1]), nm_pk_bf16(v[2], v[3])}; }
+// four consecutive elements starting at ELEMENT offset e (e % 4 == 0) of a tensor stored as fp32 (H = false) or bf16 (H = true)
+template <bool H> __device__ __forceinline__ f32x4 nm_ld4(const float* base, size_t e) {
+    if constexpr (H) return nm_bf4_to_f32(*reinterpret_cast<const nm_u32x2*>(reinterpret_cast<const unsigned short*>(base) + e));
+    else return *reinterpret_cast<const f32x4*>(base + e);
+}
+template <bool H> __device__ __forceinline__ void nm_st4(float* base, size_t e, const f32x4& v) {
+    if constexpr (H) *reinterpret_cast<nm_u32x2*>(reinterpret_cast<unsigned short*>(base) + e) = nm_f32_to_bf4(v);
+    else *reinterpret_cast<f32x4*>(base + e) = v;
+}
+template <bool H> __device__ __forceinline__ float nm_ld1(const float* base, size_t e) {
+    if constexpr (H) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(base)[e] << 16);
+    else return base[e];
+}
+template <bool H> __device__ __forceinline__ void nm_st1(float* base, size_t e, float v) {
+    if constexpr (H) reinterpret_cast<unsigned short*>(base)[e] = (unsigned short)(nm_pk_bf16(v, 0.f) & 0xffffu);
+    else base[e] = v;
+}
+// the same with a wave-uniform runtime flag (the HBM-bound elementwise kernels: one uniform branch per access costs nothing there)
+__device__ __forceinline__ f32x4 nm_ld4(const float* base, size_t e, int h) { return h ? nm_ld4<true>(base, e) : nm_ld4<false>(base, e); }
+__device__ __forceinline__ void nm_st4(float* base, size_t e, const f32x4& v, int h) { if (h) nm_st4<true>(base, e, v); else nm_st4<false>(base, e, v); }
+__device__ __forceinline__ float nm_ld1(const float* base, size_t e, int h) { return h ? nm_ld1<true>(base, e) : nm_ld1<false>(base, e); }
+__device__ __forceinline__ void nm_st1(float* base, size_t e, float v, int h) { if (h) nm_st1<true>(base, e, v); else nm_st1<false>(base, e, v); }
+// pointer to ELEMENT e of a tensor of either type, as the float* the launchers pass around (host and device)
+__host__ __device__ inline float* nm_eptr(float* base, size_t e, int h) { return h ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(base) + e) : base + e; }
+__host__ __device__ inline const float* nm_eptr(const float* base, size_t e, int h) { return h ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(base) + e) : base + e; }
+
 // A tensor reference with an optional pending per-(n,c) affine + leaky-relu.
 struct TensorRef {
     const float* p;       // [N][D][H][W][C]
@@ -49,6 +91,7 @@ struct TensorRef {
     // T(p; scale, shift, slope) + T(p2; scale2, shift2, slope2), evaluated exactly as apply2 would have stored it.  Only the k2 s2
     // split-fp16 pool kernel reads such tensors (the block's only consumer in the inference encoder); others reject them.
     const float* p2 = nullptr; const float* scale2 = nullptr; const float* shift2 = nullptr; float slope2 = 1.0f;
+    int h = 0;            // element type of p: 0 fp32, 1 bfloat16 (16-bit storage mode; the launchers that cannot read it reject it)
 };
 
 struct ConvGeom {
@@ -80,7 +123,10 @@ struct NmProfRec { hipEvent_t a, b; int variant; double flops; };
 struct NmLaunchState {
     int conv_mode = 1;         // 0: exact fp32 MFMA everywhere, 1: split-fp16 MFMA where the layer shape allows
     bool f16p_all = false;     // mode 2: split-fp16 with conv_f16p on every eligible layer (parity tests of its multi-cout-group path)
-    bool single = false;       // mode 3: the split-fp16 kernels keep only the hi x hi product (SINGLE instantiations)
+    bool single = false;       // mode 3 / 4: the split-fp16 kernels keep only the hi x hi product (SINGLE instantiations)
+    bool store16 = false;      // mode 4 ('bf16'): mode 3's arithmetic + bfloat16 storage of the training path's large tensors
+    int op_in_h = 0, op_out_h = 0;   // op-level entry points (nm_op_*): element type of the input-side / output-side tensors (nm_op_set_storage16)
+    int store16_min = 32768;   // ... those with at least this many voxels per frame (NM355_STORE16_MIN; 32^3: everything above the hourglass)
     bool prof_on = false;
     hipStream_t prof_stream = nullptr;     // main stream of the profiled context; prof_all: launches on any stream are recorded
     bool prof_all = false;
@@ -105,7 +151,8 @@ int nm_conv_blocks_per_frame(const ConvGeom& g, int Cin = 16 /* decides the kern
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
                    const ConvGeom& g, float* part /*[N][nblk][Cout][2] or null*/, hipStream_t s,
                    int cin_real = 0 /* un-padded Cin, for the profiler's FLOP count */,
-                   const void* w_packed16 = nullptr /* split-fp16 weights; enables the fp16-split kernel */);
+                   const void* w_packed16 = nullptr /* split-fp16 weights; enables the fp16-split kernel */,
+                   int out_h = 0 /* 1: `out` is bfloat16 (16-bit storage, conv mode 4); the input's type is in.h */);
 // conv arithmetic: 0 = exact fp32 MFMA, 1 = split-fp16 MFMA (3 products, fp32 accumulate) where Cin % 16 == 0
 void nm_conv_set_mode(int mode);
 int nm_conv_get_mode();
@@ -127,7 +174,8 @@ int nm_occ_blocks_per_frame(int G);
 int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float* packed, int Co_pad, hipStream_t s);
 int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
                          int Co_pad, float* part, hipStream_t s, unsigned char* brickmap = nullptr, const float* field_part = nullptr,
-                         unsigned char* flags = nullptr /* N * bricks bytes of scratch: per-brick occupancy pre-filter of the sparse form */);
+                         unsigned char* flags = nullptr /* N * bricks bytes of scratch: per-brick occupancy pre-filter of the sparse form */,
+                         int out_h = 0 /* 1: `out` is bfloat16 (dense form only) */);
 // true when nm_launch_conv sends a k2 s2 p0 conv of this input to conv_pool_f16s_kernel (the consumer of a brick-sparse tensor)
 bool nm_conv_pool16_eligible(int Cin, int OD, int OH, int OW, bool have_w16);
 void nm_conv_prof_enable(int on, hipStream_t stream);
@@ -148,13 +196,13 @@ void nm_elem_set_nonfinite_flag(unsigned* flag);
 int nm_launch_nonfinite_scan(const float* x, size_t n, unsigned* flag, hipStream_t s);
 // partial sums of an already materialised raw tensor (producers without a stats epilogue)
 int nm_stats_blocks_per_frame(int voxels);
-int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part, hipStream_t s);
-int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s);
+int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part, hipStream_t s, int h = 0 /* x is bfloat16 */);
+int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s, int out_h = 0 /* 1: out is bfloat16 */);
 // w_t: weights transposed to [tap][Cin][Cout] by nm_launch_transpose_convT_weight
 int nm_launch_transpose_convT_weight(const float* w_iodhw, int Cin, int Cout, float* out, hipStream_t s);
 int nm_launch_convT2(const TensorRef& in, const float* w_t, const float* bias, float* out,
-                     int Cout, int OD, int OH, int OW, hipStream_t s);
-int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s);
+                     int Cout, int OD, int OH, int OW, hipStream_t s, int out_h = 0);
+int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s, int out_h = 0);
 int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t, float* out,
                          hipStream_t s);
 int nm_launch_mean_t(const float* vox, int B, int T, size_t G3, float* out, hipStream_t s);

@@ -23,6 +23,7 @@
 //   atomics).
 #include "nm_common.h"
 #include "nm_up2c.h"
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -51,6 +52,7 @@ struct ConvParams {
     const float* in_alt; const unsigned char* in_map;   // brick-sparse input (TensorRef::alt / brickmap), conv_pool_f16s only
     const float* in2; const float* in2_scale; const float* in2_shift; float in2_slope;   // un-materialised residual sum (TensorRef::p2 ...), conv_pool_f16s only
     int wdma;                     // conv_f16p2: the producers copy the weights global -> LDS by LDS-DMA instead of through registers (A/B switch)
+    int in_h, out_h;              // 16-bit storage (conv mode 4): the input / output tensor is bfloat16 (kernels take it as the IO template bits 1 / 2)
 #ifdef NM_DIAG
     unsigned long long* stamps;   // diagnostic build only: per-block phase timestamps
 #endif
@@ -63,8 +65,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 
+template <bool IH = false>
 __device__ __forceinline__ f32x4 load_raw(const ConvParams& p, int n, int z, int y, int x, int c) {
-    return *reinterpret_cast<const f32x4*>(p.in + ((((size_t)n * p.ID + z) * p.IH + y) * p.IW + x) * p.Cin + c);
+    return nm_ld4<IH>(p.in, ((((size_t)n * p.ID + z) * p.IH + y) * p.IW + x) * p.Cin + c);
 }
 
 // pending GroupNorm of the producer: x * scale + shift, LeakyReLU.  Written per component with scalar fma / mul / max:
@@ -98,8 +101,9 @@ __device__ __forceinline__ f32x4 sum_act2(const ConvParams& p, f32x4 a, const f3
 }
 
 // activated input sample: x * scale + shift, LeakyReLU (the producer's pending GroupNorm)
+template <bool IH = false>
 __device__ __forceinline__ f32x4 load_act(const ConvParams& p, int n, int z, int y, int x, int c) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.in + ((((size_t)n * p.ID + z) * p.IH + y) * p.IW + x) * p.Cin + c);
+    f32x4 v = nm_ld4<IH>(p.in, ((((size_t)n * p.ID + z) * p.IH + y) * p.IW + x) * p.Cin + c);
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
     if (p.in_scale) {
         sc = *reinterpret_cast<const f32x4*>(p.in_scale + (size_t)n * p.Cin + c);
@@ -281,7 +285,9 @@ __device__ __forceinline__ void epilogue(const EpiArgs& p, float* red /*[4][NT*3
 // Epilogue of the 8(x) x 4(z) tile mapping.  Register r of a 32x32 accumulator is row (r&3) + 8(r>>2) + 4h, i.e.
 // z = r>>2, x = 4 * (h ^ G[r>>2]) + (r&3) with G = {0,1,1,0}; y is the tile index.  Interior bricks with all 32
 // channels of every N tile valid take the branch-free path: one base pointer per tile, constant row offsets.
-template <int MT, int NT>
+// OH16: bfloat16 output.  A lane holds ONE channel of 16 voxels; the two lanes of neighbouring channels exchange values (one DPP move
+// per register pair) so that each stores one packed dword per two registers: even lanes the channel pair of row r, odd lanes of row r + 1.
+template <int MT, int NT, bool OH16 = false>
 __device__ __forceinline__ void epilogue_xz(const EpiArgs& p, float* red, f32x16 (&acc)[MT][NT], f32x16 (&accl)[MT][NT], int n,
                                             int br, int nblk, int oz0, int oy0, int ox0, int co_base) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,8 +304,26 @@ __device__ __forceinline__ void epilogue_xz(const EpiArgs& p, float* red, f32x16
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int y = wave * MT + mt;
-            float* base = p.out + ((((size_t)n * p.OD + oz0) * p.OH + oy0 + y) * p.OW + ox0) * sX + co;
-            if (interior) {
+            float* base = nm_eptr(p.out, ((((size_t)n * p.OD + oz0) * p.OH + oy0 + y) * p.OW + ox0) * sX + co, OH16);
+            if constexpr (OH16) {
+                const bool odd = (l31 & 1) != 0;
+                unsigned short* bq = reinterpret_cast<unsigned short*>(base) - (odd ? 1 : 0);        // channel pair (co & ~1, co | 1)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int g = r >> 2;
+                    const int x0 = 4 * (h ^ ((g == 1 || g == 2) ? 1 : 0)) + (r & 3);              // voxel x of register r (r + 1: x0 + 1)
+                    const bool ok0 = interior || (cv && oz0 + g < p.OD && oy0 + y < p.OH && ox0 + x0 < p.OW);
+                    const bool ok1 = interior || (cv && oz0 + g < p.OD && oy0 + y < p.OH && ox0 + x0 + 1 < p.OW);
+                    const float v0 = (acc[mt][nt][r] + accl[mt][nt][r] * (1.0f / NM_SPLIT_SCALE)) + bv;
+                    const float v1 = (acc[mt][nt][r + 1] + accl[mt][nt][r + 1] * (1.0f / NM_SPLIT_SCALE)) + bv;
+                    if (ok0) { s += v0; ss += v0 * v0; }
+                    if (ok1) { s += v1; ss += v1 * v1; }
+                    const float send = odd ? v0 : v1;
+                    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                    const unsigned pk = odd ? nm_pk_bf16(recv, v1) : nm_pk_bf16(v0, recv);
+                    if (odd ? ok1 : ok0) *reinterpret_cast<unsigned*>(bq + (size_t)g * sZ + (size_t)(x0 + (odd ? 1 : 0)) * sX) = pk;
+                }
+            } else if (interior) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int g = r >> 2;
@@ -468,7 +492,7 @@ __global__ __launch_bounds__(256) void occ_brick_flags_kernel(const float* __res
 // workgroup while staging), so the result is fp32-equivalent for any input.  K = taps: k-step ks, lane half h, element j
 // is tap 16 ks + 8 h + j (taps >= 125 carry zero weights).
 typedef _Float16 occ_half8 __attribute__((ext_vector_type(8)));
-template <int NT, bool SINGLE = false, bool WALK = false>      // WALK: one workgroup per x-row of bricks (sparse inference form)
+template <int NT, bool SINGLE = false, bool WALK = false, bool OH = false>      // WALK: one workgroup per x-row of bricks (sparse inference form); OH: bfloat16 output
 __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
     __shared__ _Float16 tile_h[8 * 12 * 12], tile_l[8 * 12 * 12];
     __shared__ float red[512];
@@ -625,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
                     const size_t vo = (((size_t)oz * p.G + oy) * p.G + ox) * p.Cout + co_base + nt * 32 + chunk * 4;
                     f32x4 v = *reinterpret_cast<const f32x4*>(stg + vv * 36 + chunk * 4);
                     v += *reinterpret_cast<const f32x4*>(p.field + vo);
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)n * p.G * p.G * p.G * p.Cout + vo) = v;
+                    nm_st4<OH>(p.out, (size_t)n * p.G * p.G * p.G * p.Cout + vo, v);
                     t1 += v; t2 += v * v;
                 }
             }
@@ -659,11 +683,11 @@ __global__ __launch_bounds__(256, 2) void conv_k5occ_f16_kernel(OccParams p) {
                 for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * k4 + e] + accl[mt][nt][4 * k4 + e] * (1.0f / NM_SPLIT_SCALE);
                 if (chan_ok && co + 4 <= p.Cout) {
                     v += *reinterpret_cast<const f32x4*>(p.field + vo + co);
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)n * p.G * p.G * p.G * p.Cout + vo + co) = v;
+                    nm_st4<OH>(p.out, (size_t)n * p.G * p.G * p.G * p.Cout + vo + co, v);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (co + e < p.Cout) { v[e] += p.field[vo + co + e]; p.out[(size_t)n * p.G * p.G * p.G * p.Cout + vo + co + e] = v[e]; }
+                        if (co + e < p.Cout) { v[e] += p.field[vo + co + e]; nm_st1<OH>(p.out, (size_t)n * p.G * p.G * p.G * p.Cout + vo + co + e, v[e]); }
                         else v[e] = 0.f;
                     }
                 }
@@ -931,8 +955,10 @@ __device__ __forceinline__ BrickPos super_tile_item(const ConvParams& p, int b, 
 // then hit 16 distinct 16-B slots (conflict-free; the natural (y,x) tile order is a 3-way conflict and makes the
 // Cout = 32 layers LDS-bound).  Staging: thread -> one (halo row position, lane half), loops over the halo planes, so
 // all index arithmetic and the y/x interpolation weights are computed once per kernel.
-template <int MT, int NT, int KS, bool UP2, bool SINGLE = false>
+// IO: bit 0 = the input tensor is bfloat16, bit 1 = the output tensor is (16-bit storage, conv mode 4)
+template <int MT, int NT, int KS, bool UP2, bool SINGLE = false, int IO = 0>
 __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
+    constexpr bool IH = (IO & 1) != 0, OH = (IO & 2) != 0;
     constexpr int HZ = KS + 3;                                     // halo planes of a 4-deep brick, stride 1
     constexpr int HB = HZ / 2;                                     // planes per load batch
     // Cout = 32 layers: the weights of 9 taps at a time are shared by the block's four waves through LDS (double
@@ -1041,8 +1067,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                 for (int hz = 0; hz < (PFA && !UP2 ? HZ : 1); ++hz) {
                     const int gz = iz0 + hz;
                     const bool in = s_in && (unsigned)gz < (unsigned)p.ID;
-                    pa[hz] = in ? load_raw(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh) : z4;
-                    pb[hz] = in ? load_raw(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh + 4) : z4;
+                    pa[hz] = in ? load_raw<IH>(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh) : z4;
+                    pb[hz] = in ? load_raw<IH>(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh + 4) : z4;
                 }
             }
         } else {
@@ -1056,7 +1082,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                     int x = cv % CX, t2 = cv / CX;
                     int y = t2 % CY, z = t2 / CY;
                     pci[k] = q * p.CVp + cv;
-                    prc[k] = load_raw(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
+                    prc[k] = load_raw<IH>(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
                 }
             }
         }
@@ -1107,8 +1133,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                         for (int j = 0; j < HB; ++j) {
                             const int gz = iz0 + hb + j;
                             const bool in = s_in && (unsigned)gz < (unsigned)p.ID;
-                            ra[j] = in ? load_raw(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh) : zero4;
-                            rb[j] = in ? load_raw(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh + 4) : zero4;
+                            ra[j] = in ? load_raw<IH>(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh) : zero4;
+                            rb[j] = in ? load_raw<IH>(p, n, gz, s_gy, s_gx, c0 + 8 * s_hh + 4) : zero4;
                         }
 #pragma unroll
                         for (int j = 0; j < HB; ++j) {
@@ -1137,7 +1163,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                             int x = cv % CX, t2 = cv / CX;
                             int y = t2 % CY, z = t2 / CY;
                             pci[k] = q * p.CVp + cv;
-                            prc[k] = load_raw(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
+                            prc[k] = load_raw<IH>(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
                         }
                     }
                 }
@@ -1154,7 +1180,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                     int q = i & 3, cv = i >> 2;
                     int x = cv % CX, t2 = cv / CX;
                     int y = t2 % CY, z = t2 / CY;
-                    ldc[q * p.CVp + cv] = load_act(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
+                    ldc[q * p.CVp + cv] = load_act<IH>(p, n, cz0 + z, cy0 + y, cx0 + x, c0 + 4 * q);
                 }
             }
             lds_barrier();
@@ -1316,7 +1342,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
     e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
     e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3; e.xz_tiles = 1;
     lds_barrier();
-    epilogue_xz<MT, NT>(e, reinterpret_cast<float*>(lds), acc, accl, n, br, nblk, oz0, oy0, ox0, co_base);
+    epilogue_xz<MT, NT, OH>(e, reinterpret_cast<float*>(lds), acc, accl, n, br, nblk, oz0, oy0, ox0, co_base);
     NM_STAMP(10);
     }   // persistent item loop
 }
@@ -1447,6 +1473,14 @@ __device__ __forceinline__ half8 lds_read16_untracked(unsigned base) {
     return r;
 }
 
+// 8-byte form (four bfloat16 channels of a 16-bit-storage tensor), same tracking rules
+__device__ __forceinline__ nm_u32x2 load8_untracked(const float* base, unsigned byte_off) {
+    nm_u32x2 r;
+    const char* q = reinterpret_cast<const char*>(base) + byte_off;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(q) : "memory");
+    return r;
+}
+
 // the same from a wave-uniform base and a 32-bit per-lane byte offset (one 64-bit VALU add; the scalar-base addressing form
 // needs the base in SGPRs, which the compiler does not guarantee for an inline-asm operand computed through VALU divisions)
 __device__ __forceinline__ f32x4 load16_untracked(const float* base, unsigned byte_off) {
@@ -1469,8 +1503,11 @@ template <int V> using ic = std::integral_constant<int, V>;
 // converted and multiplied - no branch inside the loop, every wait a counted one.  Same arithmetic per element.
 template <int NT, bool IN2> struct PoolBuf { f32x4 ra[2], rb[2], qa[IN2 ? 2 : 1], qb[IN2 ? 2 : 1]; half8 bh[NT], bl[NT]; };
 
-template <int NT, bool SINGLE, bool IN2>
+// IO (bit 0: bfloat16 input, bit 1: bfloat16 output; IN2 = false only): a row's 16 channels of a tap are ONE 16-byte load per lane half
+template <int NT, bool SINGLE, bool IN2, int IO = 0>
 __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
+    constexpr bool IH = (IO & 1) != 0, OH = (IO & 2) != 0;
+    static_assert(!(IH && IN2), "the un-materialised residual sum exists in the inference forward only (fp32 workspace)");
     __shared__ float red[4 * NT * 32 * 2];
     __shared__ __attribute__((aligned(16))) float s_aff[4][128];       // this frame's pending affines: scale, shift, second addend's scale, shift (Cin <= 128)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1499,7 +1536,7 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
         const bool ok = (oz0 + z < p.OD) && (oy0 + y < p.OH) && (ox0 + x < p.OW);
         const size_t voff = ok ? (((size_t)(2 * (oz0 + z)) * p.IH + 2 * (oy0 + y)) * p.IW + 2 * (ox0 + x)) * p.Cin + 8 * h : (size_t)(8 * h);
         const size_t foff = (size_t)n * p.ID * p.IH * p.IW * p.Cin;
-        src[mt] = p.in + foff + voff;
+        src[mt] = nm_eptr(p.in, foff + voff, IH);
         src2[mt] = IN2 ? p.in2 + foff + voff : src[mt];
         if (p.in_map && ok) {
             const int fb = (((oz0 + z) >> 1) * (p.IH >> 3) + ((oy0 + y) >> 2)) * (p.IW >> 3) + ((ox0 + x) >> 2);
@@ -1531,7 +1568,10 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
         const size_t toff = ((size_t)((tap >> 2) * p.IH + ((tap >> 1) & 1)) * p.IW + (tap & 1)) * p.Cin + cb * 16;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            b.ra[mt] = *reinterpret_cast<const f32x4*>(src[mt] + toff); b.rb[mt] = *reinterpret_cast<const f32x4*>(src[mt] + toff + 4);
+            if constexpr (IH) {          // 8 bf16 channels = 16 bytes: one load, widened at the point of use (compute)
+                const f32x4 q = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(src[mt]) + toff);
+                b.ra[mt] = q;
+            } else { b.ra[mt] = *reinterpret_cast<const f32x4*>(src[mt] + toff); b.rb[mt] = *reinterpret_cast<const f32x4*>(src[mt] + toff + 4); }
             if constexpr (IN2) { b.qa[mt] = *reinterpret_cast<const f32x4*>(src2[mt] + toff); b.qb[mt] = *reinterpret_cast<const f32x4*>(src2[mt] + toff + 4); }
         }
         if constexpr (!IN2) {      // (with a second addend in flight the weights are requested at the tap itself: registers)
@@ -1567,7 +1607,12 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
         for (int mt = 0; mt < 2; ++mt) {
             half8 ah, al;
             if constexpr (IN2) split8(act2(b.ra[mt], a.sca, a.sha, b.qa[mt], a.s2a, a.h2a), act2(b.rb[mt], a.scb, a.shb, b.qb[mt], a.s2b, a.h2b), ah, al);
-            else split8(act1(b.ra[mt], a.sca, a.sha), act1(b.rb[mt], a.scb, a.shb), ah, al);
+            else if constexpr (IH) {
+                const f32x4 q = b.ra[mt];
+                const unsigned u0 = __builtin_bit_cast(unsigned, q[0]), u1 = __builtin_bit_cast(unsigned, q[1]), u2 = __builtin_bit_cast(unsigned, q[2]), u3 = __builtin_bit_cast(unsigned, q[3]);
+                split8(act1(f32x4{nm_bf_lo(u0), nm_bf_hi(u0), nm_bf_lo(u1), nm_bf_hi(u1)}, a.sca, a.sha),
+                       act1(f32x4{nm_bf_lo(u2), nm_bf_hi(u2), nm_bf_lo(u3), nm_bf_hi(u3)}, a.scb, a.shb), ah, al);
+            } else split8(act1(b.ra[mt], a.sca, a.sha), act1(b.rb[mt], a.scb, a.shb), ah, al);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.bh[nt], acc[mt][nt], 0, 0, 0);
@@ -1635,7 +1680,7 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
     EpiArgs e;
     e.out = p.out; e.part = p.part; e.bias = p.bias; e.field = nullptr;
     e.OD = p.OD; e.OH = p.OH; e.OW = p.OW; e.Cout = p.Cout; e.bz_l2 = 2; e.by_l2 = 3; e.bx_l2 = 3; e.xz_tiles = 1;
-    epilogue_xz<2, NT>(e, red, acc, accl, n, br, nblk, oz0, oy0, ox0, co_base);
+    epilogue_xz<2, NT, OH>(e, red, acc, accl, n, br, nblk, oz0, oy0, ox0, co_base);
 }
 
 // ---- conv_f16p: k3 s1 p1 split-fp16 conv, one persistent workgroup per CU, MFMA waves + producer waves ---------------
@@ -1656,8 +1701,11 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
 //   LDS: halo [2 buffers][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [3][9 taps][4 planes][32] x 16 B, GroupNorm scratch.
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-template <bool UP2, bool SINGLE = false>
+// IO: bit 0 = bfloat16 input (a producer piece is then an 8-byte load of the same four channels), bit 1 = bfloat16 output
+template <bool UP2, bool SINGLE = false, int IO = 0>
 __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
+    constexpr bool IH = (IO & 1) != 0, OH = (IO & 2) != 0;
+    constexpr unsigned EB = IH ? 2u : 4u;                           // bytes per input element
     constexpr int HV = 600, ZP = 100, HX = 10;
     constexpr int GB = 9 * 4 * 32;                                  // half8 slots of one weight group
     constexpr int NP = 10;                                          // 16-byte input pieces per producer thread and step (2400 / 256)
@@ -1729,9 +1777,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             pc_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin + 4 * quad;
             pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
         }
-        f32x4 raw[NP], sc, sh, wreg[5];
+        using RawT = std::conditional_t<IH, nm_u32x2, f32x4>;
+        RawT raw[NP]; f32x4 sc, sh, wreg[5];
         const bool has_affine = p.in_scale != nullptr;
-        const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * 4u;   // halo voxel (1,1,1): always inside
+        const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * EB;   // halo voxel (1,1,1): always inside
         // bit k: piece k of a brick's halo tile lies inside the volume
         auto inside_mask = [&](const Work& w) {
             unsigned m = 0;
@@ -1745,11 +1794,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             return m;
         };
         auto tile_base = [&](const Work& w, int cb) {               // wave-uniform: halo voxel (0,0,0), channel 16 cb (may lie
-            return p.in + ((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin + cb * 16;   // outside)
+            return nm_eptr(p.in, (size_t)(((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin + cb * 16), IH);   // outside)
         };
         auto load_piece = [&](const float* base, unsigned mask, auto K) {      // outside pieces fetch an inside voxel (zeroed later)
             constexpr int k = decltype(K)::value;
-            raw[k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * 4u : rel111);
+            if constexpr (IH) raw[k] = load8_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * EB : rel111);
+            else raw[k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * EB : rel111);
         };
         auto load_affine = [&](const Work& w, int cb) {             // always two loads: the waits below count instructions
             const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 : p.in;
@@ -1767,7 +1817,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             const float keep = ((mask >> k) & 1) ? 1.f : 0.f;       // padding is zero AFTER the activation
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-                float v0 = raw[k][e], v1 = raw[k][e + 1];
+                float v0, v1;
+                if constexpr (IH) { const unsigned u = raw[k][e >> 1]; v0 = nm_bf_lo(u); v1 = nm_bf_hi(u); }
+                else { v0 = raw[k][e]; v1 = raw[k][e + 1]; }
                 if (has_affine) { v0 = __builtin_fmaf(v0, sc[e], sh[e]); v1 = __builtin_fmaf(v1, sc[e + 1], sh[e + 1]); }
                 // LeakyReLU (slope in (0, 1]) and the padding mask in two instructions per value: max(v, slope v) * keep
                 v0 = fmaxf(v0 * keep, (v0 * keep) * p.in_slope); v1 = fmaxf(v1 * keep, (v1 * keep) * p.in_slope);
@@ -1902,9 +1954,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
     const int vx = ((((0x96 >> (l31 >> 2)) & 1) << 2) + (l31 & 3)), vz = l31 >> 3;
     auto epi_store = [&](auto E) {                                  // store e = 4 mt + k4 of the 8 per lane
         constexpr int e = decltype(E)::value, mt = e >> 2, k4 = e & 3;
-        float* dst = p.out + ((((size_t)epi.n * p.OD + epi.oz0 + vz) * p.OH + epi.oy0 + 2 * wave + mt) * p.OW + epi.ox0 + vx) * (size_t)p.Cout +
-                     epi.cg * 32 + 8 * k4 + 4 * h;
-        *reinterpret_cast<f32x4*>(dst) = f32x4{outv[mt][4 * k4], outv[mt][4 * k4 + 1], outv[mt][4 * k4 + 2], outv[mt][4 * k4 + 3]};
+        const size_t dst = ((((size_t)epi.n * p.OD + epi.oz0 + vz) * p.OH + epi.oy0 + 2 * wave + mt) * p.OW + epi.ox0 + vx) * (size_t)p.Cout +
+                           epi.cg * 32 + 8 * k4 + 4 * h;
+        nm_st4<OH>(p.out, dst, f32x4{outv[mt][4 * k4], outv[mt][4 * k4 + 1], outv[mt][4 * k4 + 2], outv[mt][4 * k4 + 3]});
     };
     // GroupNorm partial sums, in place: outv[0][r] <- sum over the two tiles, outv[1][r] <- sum of squares; then over the 32
     // voxels (lanes of one half) with DPP adds; rows 1 and 3 of the wave end up holding the totals
@@ -2088,8 +2140,11 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
 //   * LDS: two weight buffers (2 x 36 KB) instead of three, so the B operands of a tap group's first tap are read after
 //     the barrier that publishes them; operands one tap (12 MFMAs) ahead, double buffered.
 //   LDS: halo [2][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [2][9 taps][4 planes][64] x 16 B, GroupNorm scratch, bias.
-template <bool UP2, bool SINGLE = false>
+// IO: bit 0 = bfloat16 input (a producer piece is then an 8-byte load of the same four channels), bit 1 = bfloat16 output
+template <bool UP2, bool SINGLE = false, int IO = 0>
 __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
+    constexpr bool IH = (IO & 1) != 0, OH = (IO & 2) != 0;
+    constexpr unsigned EB = IH ? 2u : 4u;                           // bytes per input element
     constexpr int HV = 600, ZP = 100, HX = 10;
     constexpr int GB = 9 * 4 * 64;                                  // half8 slots of one weight group
     constexpr int NP = 10;                                          // 16-byte input pieces per producer thread and step (2400 / 256)
@@ -2153,9 +2208,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             pc_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin + 4 * quad;
             pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
         }
-        f32x4 raw[NP], sc, sh, wreg[9];
+        using RawT = std::conditional_t<IH, nm_u32x2, f32x4>;
+        RawT raw[NP]; f32x4 sc, sh, wreg[9];
         const bool has_affine = p.in_scale != nullptr;
-        const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * 4u;   // halo voxel (1,1,1): always inside
+        const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * EB;   // halo voxel (1,1,1): always inside
         auto inside_mask = [&](const Work& w) {
             unsigned m = 0;
 #pragma unroll
@@ -2168,11 +2224,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             return m;
         };
         auto tile_base = [&](const Work& w, int cb) {
-            return p.in + ((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin + cb * 16;
+            return nm_eptr(p.in, (size_t)(((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin + cb * 16), IH);
         };
         auto load_piece = [&](const float* base, unsigned mask, auto K) {
             constexpr int k = decltype(K)::value;
-            raw[k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * 4u : rel111);
+            if constexpr (IH) raw[k] = load8_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * EB : rel111);
+            else raw[k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * EB : rel111);
         };
         auto load_affine = [&](const Work& w, int cb) {             // always two loads: the waits below count instructions
             const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 : p.in;
@@ -2190,7 +2247,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             const float keep = ((mask >> k) & 1) ? 1.f : 0.f;       // padding is zero AFTER the activation
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-                float v0 = raw[k][e], v1 = raw[k][e + 1];
+                float v0, v1;
+                if constexpr (IH) { const unsigned u = raw[k][e >> 1]; v0 = nm_bf_lo(u); v1 = nm_bf_hi(u); }
+                else { v0 = raw[k][e]; v1 = raw[k][e + 1]; }
                 if (has_affine) { v0 = __builtin_fmaf(v0, sc[e], sh[e]); v1 = __builtin_fmaf(v1, sc[e + 1], sh[e + 1]); }
                 v0 = fmaxf(v0 * keep, (v0 * keep) * p.in_slope); v1 = fmaxf(v1 * keep, (v1 * keep) * p.in_slope);
                 half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
@@ -2388,8 +2447,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
                 for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    float* dst = p.out + ((((size_t)w.n * p.OD + w.oz0 + vz) * p.OH + w.oy0 + 2 * wave + mt) * p.OW + w.ox0 + vx) * (size_t)p.Cout +
-                                 w.cg * 64 + nt * 32 + 4 * h;
+                    const size_t dst = ((((size_t)w.n * p.OD + w.oz0 + vz) * p.OH + w.oy0 + 2 * wave + mt) * p.OW + w.ox0 + vx) * (size_t)p.Cout +
+                                       w.cg * 64 + nt * 32 + 4 * h;
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + w.cg * 64 + nt * 32 + 8 * k4 + 4 * h);
@@ -2400,7 +2459,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
                             s1[4 * k4 + e] += v[e]; s2[4 * k4 + e] += v[e] * v[e];
                             acc[mt][nt][4 * k4 + e] = 0.f; accl[mt][nt][4 * k4 + e] = 0.f;
                         }
-                        *reinterpret_cast<f32x4*>(dst + 8 * k4) = v;
+                        nm_st4<OH>(p.out, dst + 8 * k4, v);
                     }
                 }
                 if (p.part) {
@@ -2536,12 +2595,12 @@ void choose_super_tile(ConvParams& p, int nblocks, int nbz, int nby, int nbx) {
 
 // conv mode 3 (nm_ls().single): the split-fp16 kernels keep only the hi x hi product (SINGLE instantiations)
 
-template <int MT, int NT, int KS, bool UP2, bool SINGLE>
+template <int MT, int NT, int KS, bool UP2, bool SINGLE, int IO = 0>
 int launch_f16s_impl(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStream_t s) {
     ConvParams p = p_in;
     static NmDeviceOnce attr_set;
     if (!attr_set.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT, KS, UP2, SINGLE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MT, NT, KS, UP2, SINGLE, IO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16s)");
         attr_set.mark();
@@ -2555,12 +2614,25 @@ int launch_f16s_impl(const ConvParams& p_in, const Tiling& t, dim3 grid, hipStre
     }
     dim3 pgrid(min(grid.x, 512u), grid.y);                          // persistent: ~2 resident workgroups per CU
     choose_super_tile(p, (int)pgrid.x, p.nbz, p.nby, p.nbx);
-    hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2, SINGLE>), pgrid, dim3(256), t.lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16s_kernel<MT, NT, KS, UP2, SINGLE, IO>), pgrid, dim3(256), t.lds_bytes, s, p);
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16s launch");
 }
+// 16-bit storage (p.in_h / p.out_h): the instantiations the training path of conv mode 4 needs - k1 layers at >= 32^3 (both tensors
+// bfloat16) and the fused-upsample layer that crosses the storage threshold (fp32 in, bfloat16 out); anything else is rejected
+int io16_unsupported(const char* k, const ConvParams& p) {
+    nm_set_error("%s: no instantiation for bfloat16 input=%d / output=%d in this conv mode / layer shape (16-bit storage needs conv mode 4)", k, p.in_h, p.out_h);
+    return NM_ERR_UNSUPPORTED;
+}
 template <int MT, int NT, int KS, bool UP2>
 int launch_f16s(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
+    const int io = (p.in_h ? 1 : 0) | (p.out_h ? 2 : 0);
+    if (io) {
+        if (!nm_ls().single) return io16_unsupported("conv_f16s", p);
+        if constexpr (KS == 1 && !UP2) { if (io == 3) return launch_f16s_impl<MT, NT, KS, UP2, true, 3>(p, t, grid, s); }
+        if constexpr (KS == 3 && UP2 && NT == 2) { if (io == 2) return launch_f16s_impl<MT, NT, KS, UP2, true, 2>(p, t, grid, s); }
+        return io16_unsupported("conv_f16s", p);
+    }
     return nm_ls().single ? launch_f16s_impl<MT, NT, KS, UP2, true>(p, t, grid, s) : launch_f16s_impl<MT, NT, KS, UP2, false>(p, t, grid, s);
 }
 
@@ -2573,6 +2645,14 @@ int launch_pool_f16s_impl(const ConvParams& p, dim3 grid, hipStream_t s) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 8;
         (void)hipEventRecord(rec.a, s);
     }
+    const int io = (p.in_h ? 1 : 0) | (p.out_h ? 2 : 0);
+    if (io) {                                                       // 16-bit storage: the pool convs of the training path (input always bfloat16)
+        if constexpr (SINGLE) {
+            if (p.Cin > 128 || p.in2 || p.in_map || !(io & 1)) return io16_unsupported("conv_pool_f16q", p);
+            if (io == 3) hipLaunchKernelGGL((conv_pool_f16q_kernel<NT, true, false, 3>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv_pool_f16q_kernel<NT, true, false, 1>), grid, dim3(256), 0, s, p);
+        } else return io16_unsupported("conv_pool_f16q", p);
+    } else
     if (nm_ls().pool_q && p.Cin <= 128) {                           // (the affine table holds 128 channels)
         if (p.in2) hipLaunchKernelGGL((conv_pool_f16q_kernel<NT, SINGLE, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv_pool_f16q_kernel<NT, SINGLE, false>), grid, dim3(256), 0, s, p);
@@ -2588,12 +2668,12 @@ int launch_pool_f16s(const ConvParams& p, dim3 grid, hipStream_t s) {
 
 int g_num_cus = 0;
 
-template <bool UP2, bool SINGLE>
+template <bool UP2, bool SINGLE, int IO = 0>
 int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
     ConvParams p = p_in;
     static NmDeviceOnce attr_set;
     if (!attr_set.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2, SINGLE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2, SINGLE, IO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p)");
         attr_set.mark();
@@ -2612,21 +2692,26 @@ int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, h
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 32) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
-    hipLaunchKernelGGL((conv_f16p_kernel<UP2, SINGLE>), grid, dim3(512), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16p_kernel<UP2, SINGLE, IO>), grid, dim3(512), lds_bytes, s, p);
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
 template <bool UP2>
 int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
+    const int io = (p.in_h ? 1 : 0) | (p.out_h ? 2 : 0);
+    if (io) {                                                       // 16-bit storage: both tensors bfloat16 (layers at >= 32^3 and their data gradients)
+        if (io != 3 || !nm_ls().single) return io16_unsupported("conv_f16p", p);
+        return launch_f16p_impl<UP2, true, 3>(p, lds_bytes, work_items, s);
+    }
     return nm_ls().single ? launch_f16p_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p_impl<UP2, false>(p, lds_bytes, work_items, s);
 }
 
-template <bool UP2, bool SINGLE>
+template <bool UP2, bool SINGLE, int IO = 0>
 int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
     ConvParams p = p_in;
     static NmDeviceOnce attr_set;
     if (!attr_set.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p2_kernel<UP2, SINGLE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p2_kernel<UP2, SINGLE, IO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p2)");
         attr_set.mark();
@@ -2645,12 +2730,17 @@ int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, 
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
     if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
-    hipLaunchKernelGGL((conv_f16p2_kernel<UP2, SINGLE>), grid, dim3(512), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16p2_kernel<UP2, SINGLE, IO>), grid, dim3(512), lds_bytes, s, p);
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p2 launch");
 }
 template <bool UP2>
 int launch_f16p2(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
+    const int io = (p.in_h ? 1 : 0) | (p.out_h ? 2 : 0);
+    if (io) {                                                       // 16-bit storage: both tensors bfloat16 (layers at >= 32^3 and their data gradients)
+        if (io != 3 || !nm_ls().single) return io16_unsupported("conv_f16p2", p);
+        return launch_f16p2_impl<UP2, true, 3>(p, lds_bytes, work_items, s);
+    }
     return nm_ls().single ? launch_f16p2_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p2_impl<UP2, false>(p, lds_bytes, work_items, s);
 }
 
@@ -2663,8 +2753,8 @@ unsigned long long* g_stamps = nullptr;
 #ifdef NM_DIAG
 extern "C" void nm_diag_set_stamps(void* p) { g_stamps = static_cast<unsigned long long*>(p); }
 #endif
-void nm_conv_set_mode(int mode) { NmLaunchState& l = nm_ls(); l.conv_mode = mode ? 1 : 0; l.f16p_all = mode == 2; l.single = mode == 3; }
-int nm_conv_get_mode() { const NmLaunchState& l = nm_ls(); return l.conv_mode && l.single ? 3 : (l.conv_mode && l.f16p_all ? 2 : l.conv_mode); }
+void nm_conv_set_mode(int mode) { NmLaunchState& l = nm_ls(); l.conv_mode = mode ? 1 : 0; l.f16p_all = mode == 2; l.single = mode == 3 || mode == 4; l.store16 = mode == 4; }
+int nm_conv_get_mode() { const NmLaunchState& l = nm_ls(); return l.conv_mode && l.single ? (l.store16 ? 4 : 3) : (l.conv_mode && l.f16p_all ? 2 : l.conv_mode); }
 int nm_conv_single() { return nm_ls().conv_mode && nm_ls().single; }
 
 int nm_launch_pack_conv_weight16(const float* w, int Cout, int Cin, int ks, void* packed, int Co_pad, hipStream_t s) {
@@ -2782,7 +2872,7 @@ void nm_conv_prof_reset() {
 }
 
 int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias, float* out,
-                   const ConvGeom& g, float* part, hipStream_t s, int cin_real, const void* w_packed16) {
+                   const ConvGeom& g, float* part, hipStream_t s, int cin_real, const void* w_packed16, int out_h) {
     if (in.C % 8 != 0 || g.Co_pad % 32 != 0 || g.Cout > g.Co_pad || g.Cout <= 0) {
         nm_set_error("conv: unsupported channels Cin=%d Cout=%d Co_pad=%d", in.C, g.Cout, g.Co_pad);
         return NM_ERR_ARG;
@@ -2805,7 +2895,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
             rec.a = prof_event(); rec.b = prof_event(); rec.variant = 12;
             (void)hipEventRecord(rec.a, s);
         }
-        const int rc = nm_launch_conv_up2c(in, g.up2c, bias, out, g.Cout, g.Co_pad, part, s);
+        const int rc = nm_launch_conv_up2c(in, g.up2c, bias, out, g.Cout, g.Co_pad, part, s, out_h);
         if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
         return rc;
     }
@@ -2824,6 +2914,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.in_alt = in.alt; p.in_map = in.brickmap;
     p.in2 = in.p2; p.in2_scale = in.scale2; p.in2_shift = in.shift2; p.in2_slope = in.slope2;
     p.wdma = nm_ls().f16p_dma;
+    p.in_h = in.h; p.out_h = out_h;
     if (in.p2 && !(nm_conv_pool16_eligible(in.C, g.OD, g.OH, g.OW, w_packed16 != nullptr) && g.ks == 2 && g.stride == 2 && g.pad == 0 && !g.up2 && !in.brickmap)) {
         nm_set_error("conv: an un-materialised residual sum can only feed the k2 s2 split-fp16 pool kernel"); return NM_ERR_ARG;
     }
@@ -2883,6 +2974,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
         }
         p.HVp = t.HVp;
     }
+    if (p.in_h || p.out_h) return io16_unsupported("conv (fp32 MFMA kernel)", p);
     if (t.MT == 2 && t.NT == 2) return launch_t<2, 2>(p, t, grid, s);
     if (t.MT == 2 && t.NT == 1) return launch_t<2, 1>(p, t, grid, s);
     if (t.MT == 1 && t.NT == 2) return launch_t<1, 2>(p, t, grid, s);
@@ -2905,7 +2997,7 @@ int nm_launch_pack_occ_weight(const float* w_oidhw, int Cout, float* tmp, float*
 }
 
 int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, const float* field, float* out, int Cout,
-                         int Co_pad, float* part, hipStream_t s, unsigned char* brickmap, const float* field_part, unsigned char* flags) {
+                         int Co_pad, float* part, hipStream_t s, unsigned char* brickmap, const float* field_part, unsigned char* flags, int out_h) {
     if (G % 8 || Co_pad % 32 || Cout > Co_pad) { nm_set_error("conv_k5occ: unsupported G=%d Cout=%d", G, Cout); return NM_ERR_ARG; }
     OccParams p; p.occ = occ; p.w = w_packed; p.field = field; p.out = out; p.part = part; p.N = N; p.G = G; p.Cout = Cout; p.Co_pad = Co_pad;
     p.brickmap = brickmap; p.field_part = field_part; p.flags = nullptr; p.row_walk = 0;
@@ -2926,6 +3018,13 @@ int nm_launch_conv_k5occ(const float* occ, int N, int G, const float* w_packed, 
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 4;
         (void)hipEventRecord(rec.a, s);
     }
+    if (out_h) {                                                    // 16-bit storage: the dense training form on the f16 MFMA kernel only
+        if (!(nm_ls().conv_mode == 1 && nm_ls().occ16 && nm_ls().single) || brickmap || Cout % 4) {
+            nm_set_error("conv_k5occ: bfloat16 output needs conv mode 4, the dense (training) form and Cout %% 4 == 0"); return NM_ERR_UNSUPPORTED;
+        }
+        if (NT == 2) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, true, false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, true, false, true>), grid, dim3(256), 0, s, p);
+    } else
     if (nm_ls().conv_mode == 1 && nm_ls().occ16 && p.row_walk) {
         if (NT == 2) { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<2, false, true>), grid, dim3(256), 0, s, p); }
         else { if (nm_ls().single) hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, true, true>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((conv_k5occ_f16_kernel<1, false, true>), grid, dim3(256), 0, s, p); }

@@ -15,7 +15,7 @@ namespace {
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 __device__ __forceinline__ f32x4 load_t(const TensorRef& t, size_t n, size_t vox_in_frame_times_C_plus_c, int c) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(t.p + n * ((size_t)t.D * t.H * t.W * t.C) + vox_in_frame_times_C_plus_c);
+    f32x4 v = nm_ld4(t.p, n * ((size_t)t.D * t.H * t.W * t.C) + vox_in_frame_times_C_plus_c, t.h);     // (fp32 or bf16 storage)
     if (t.scale) {
         f32x4 sc = *reinterpret_cast<const f32x4*>(t.scale + n * t.C + c);
         f32x4 sh = *reinterpret_cast<const f32x4*>(t.shift + n * t.C + c);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(1024) void gn_direct_kernel(const float* __restrict
 
 #define NM_STATS_VB 512
 __global__ __launch_bounds__(256) void gn_partials_kernel(const float* __restrict__ x, int voxels, int C, int nblk,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, int h) {
     __shared__ float sh[256 * 2];
     const int n = blockIdx.x / nblk, blk = blockIdx.x % nblk;
     const int lanes = 256 / C;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void gn_partials_kernel(const float* __restric
     if (vl < lanes) {
         const int v0 = blk * NM_STATS_VB, v1 = min(voxels, v0 + NM_STATS_VB);
         for (int v = v0 + vl; v < v1; v += lanes) {
-            float t = x[((size_t)n * voxels + v) * C + c];
+            float t = nm_ld1(x, ((size_t)n * voxels + v) * C + c, h);
             s += t; ss += t * t;
         }
     }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void gn_partials_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void apply2_kernel(TensorRef a, TensorRef b, int has_b, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void apply2_kernel(TensorRef a, TensorRef b, int has_b, float* __restrict__ out, int oh) {
     // grid (blocks, frames): 32-bit index arithmetic inside a frame (the flat 64-bit index cost a 64-bit division and two
     // remainders per 16-byte item)
     const unsigned per_frame = (unsigned)a.D * a.H * a.W * a.C;     // floats
@@ -168,14 +168,14 @@ __global__ __launch_bounds__(256) void apply2_kernel(TensorRef a, TensorRef b, i
         const int c = (int)(r % (unsigned)a.C);
         f32x4 v = load_t(a, n, r, c);
         if (has_b) v = v + load_t(b, n, r, c);
-        *reinterpret_cast<f32x4*>(out + n * per_frame + r) = v;
+        nm_st4(out, n * per_frame + r, v, oh);
     }
 }
 
 // ConvTranspose3d k2 s2: out[2i+a] += x[i] * W[ci][co][a]; one thread per (out voxel, 4 channels);
 // the weights arrive transposed to [tap][ci][co] (nm_launch_transpose_convT_weight)
 __global__ __launch_bounds__(256) void convT2_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
-                                                     float* __restrict__ out, int Cout, int OD, int OH, int OW) {
+                                                     float* __restrict__ out, int Cout, int OD, int OH, int OW, int oh) {
     const int cq = Cout / 4;
     const size_t total = (size_t)in.N * OD * OH * OW * cq;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void convT2_kernel(TensorRef in, const float* 
                 }
             }
         }
-        *reinterpret_cast<f32x4*>(out + ((((size_t)n * OD + oz) * OH + oy) * OW + ox) * Cout + co) = acc;
+        nm_st4(out, ((((size_t)n * OD + oz) * OH + oy) * OW + ox) * Cout + co, acc, oh);
     }
 }
 
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void convT2_kernel(TensorRef in, const float* 
 // taps); the tap's [ci][co] weight slice sits in LDS (the kernel above re-fetches 4 weight vectors per 16 FMAs through the
 // texture path: 2.7 ms for that launch, load-issue bound), a thread owns (coarse voxel, 4 output channels) and walks the chunk.
 __global__ __launch_bounds__(256) void convT2_lds_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         float* __restrict__ out, int Cout, int OD, int OH, int OW, int vox_per_block) {
+                                                         float* __restrict__ out, int Cout, int OD, int OH, int OW, int vox_per_block, int oh) {
     extern __shared__ float wl[];            // [Cin][Cout]
     const int tap = blockIdx.y, cq = Cout / 4, q = threadIdx.x % cq, vl = threadIdx.x / cq, vpi = 256 / cq;
     for (int i = threadIdx.x; i < in.C * Cout / 4; i += 256)
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void convT2_lds_kernel(TensorRef in, const flo
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (ok[u]) *reinterpret_cast<f32x4*>(out + oo[u]) = acc[u];
+        for (int u = 0; u < 4; ++u) if (ok[u]) nm_st4(out, oo[u], acc[u], oh);
     }
 }
 
@@ -255,6 +255,9 @@ __global__ __launch_bounds__(256) void convT2_lds_kernel(TensorRef in, const flo
 // 8 x Cin x Cout weights are at most 131 KB and hot); a lane ends up with 16 voxels of ONE output channel, so a store instruction
 // writes two complete 128-byte voxel lines when Cout = 32.  convT2_lds_kernel above is VALU-FMA bound (1.06 ms for the 32 -> 32
 // data gradient of the first pool, whose 2.1 GB output takes 0.5 ms to write) and re-reads the input once per tap.
+// OH16: bfloat16 output - two lanes that hold neighbouring channels exchange values (one DPP move per register pair) so that every lane
+// stores ONE packed dword per two accumulator registers: even lanes the channel pair of voxel row r, odd lanes that of row r + 1
+template <bool OH16>
 __global__ __launch_bounds__(256) void convT2_mfma_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, int Cout, int tiles_per_frame, int total_tiles) {
     extern __shared__ float xs_all[];
@@ -266,12 +269,12 @@ __global__ __launch_bounds__(256) void convT2_mfma_kernel(TensorRef in, const fl
     for (int t = blockIdx.x * 4 + wv; t < total_tiles; t += gridDim.x * 4) {
         const int n = t / tiles_per_frame, v0 = (t % tiles_per_frame) * 32;
         // stage: 32 voxels x Cin, activated (lanes walk the 16-byte items of the tile, contiguous in memory)
-        const float* src = in.p + (size_t)n * in_frame + (size_t)v0 * Cin;
+        const size_t src = (size_t)n * in_frame + (size_t)v0 * Cin;   // (element offset)
         const int items = 8 * Cin;                                     // 32 * Cin / 4
         for (int i0 = lane; i0 < items; i0 += 256) {
             f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; v[u] = i < items ? *reinterpret_cast<const f32x4*>(src + (size_t)i * 4) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; v[u] = i < items ? nm_ld4(in.p, src + (size_t)i * 4, in.h) : f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + 64 * u;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void convT2_mfma_kernel(TensorRef in, const fl
             const int ix = v % in.W, iy = (v / in.W) % in.H, iz = v / (in.W * in.H);
             obase[r] = (unsigned)((((size_t)2 * iz * OH + 2 * iy) * OW + 2 * ix) * Cout);
         }
-        float* outn = out + (size_t)n * out_frame;
+        float* outn = nm_eptr(out, (size_t)n * out_frame, OH16);
         for (int a = 0; a < 8; ++a) {
             const unsigned toff = (unsigned)(((size_t)(a >> 2) * OH + ((a >> 1) & 1)) * OW + (a & 1)) * Cout;
             const float* wa = w + (size_t)a * Cin * Cout;
@@ -316,8 +319,21 @@ __global__ __launch_bounds__(256) void convT2_mfma_kernel(TensorRef in, const fl
                     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u], acc, 0, 0, 0);
                 }
                 const float bv = bias[co0 + l31];
+                if constexpr (OH16) {
+                    const bool odd = (l31 & 1) != 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) outn[(size_t)obase[r] + toff + co0 + l31] = acc[r] + bv;
+                    for (int r = 0; r < 16; r += 2) {
+                        const float mine0 = acc[r] + bv, mine1 = acc[r + 1] + bv;
+                        const float send = odd ? mine0 : mine1;
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                        const unsigned pk = odd ? nm_pk_bf16(recv, mine1) : nm_pk_bf16(mine0, recv);
+                        const size_t e = (size_t)(odd ? obase[r + 1] : obase[r]) + toff + co0 + (l31 & ~1);
+                        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(outn) + e) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) outn[(size_t)obase[r] + toff + co0 + l31] = acc[r] + bv;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -337,7 +353,7 @@ __device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1
 // loads instead of 8 per fine voxel = 64 per cell), interpolated separably x -> y -> z.  Fine index 2i+a along an axis:
 // a = 0: 0.25 c[i-1] + 0.75 c[i], a = 1: 0.75 c[i] + 0.25 c[i+1], neighbour indices clamped to the volume - exactly the
 // align_corners=False weights (src = (dst + 0.5)/2 - 0.5 clamped at 0; the upper clamp folds c[I] onto c[I-1]).
-__global__ __launch_bounds__(256) void upsample2_kernel(TensorRef in, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void upsample2_kernel(TensorRef in, float* __restrict__ out, int oh) {
     const int D = in.D, H = in.H, W = in.W, cq = in.C / 4;
     const size_t total = (size_t)in.N * D * H * W * cq;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -368,8 +384,8 @@ __global__ __launch_bounds__(256) void upsample2_kernel(TensorRef in, float* __r
             for (int cy = 0; cy < 2; ++cy) {
                 const f32x4 o0 = 0.25f * fy[0][cy] + 0.75f * fy[1][cy], o1 = 0.75f * fy[1][cy] + 0.25f * fy[2][cy];
                 const size_t base = ((((size_t)n * 2 * D + 2 * z) * OH + 2 * y + cy) * OW + 2 * x + cx) * in.C + c;
-                *reinterpret_cast<f32x4*>(out + base) = o0;
-                *reinterpret_cast<f32x4*>(out + base + (size_t)OH * OW * in.C) = o1;
+                nm_st4(out, base, o0, oh);
+                nm_st4(out, base + (size_t)OH * OW * in.C, o1, oh);
             }
         }
     }
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(256) void upsample2_kernel(TensorRef in, float* __r
 // The same with the 3x3x3 neighbourhoods shared through LDS: a block owns 2 x 4 x 4 coarse cells and 32 channels; the clamped
 // 4 x 6 x 6 coarse halo is loaded and activated once (4.5 loads per cell instead of 27), every thread then interpolates its cell's
 // eight children from LDS and writes 128-byte voxel rows.  Used when C % 32 == 0 and the extents are multiples of the tile.
-__global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float* __restrict__ out, int tz, int ty, int tx) {
+__global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float* __restrict__ out, int tz, int ty, int tx, int oh) {
     __shared__ f32x4 tile[4 * 6 * 6 * 8];          // [hz][hy][hx][quad]
     const int D = in.D, H = in.H, W = in.W, chunks = in.C / 32;
     int b = blockIdx.x;
@@ -416,8 +432,8 @@ __global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float
         for (int ky = 0; ky < 2; ++ky) {
             const f32x4 o0 = 0.25f * fy[0][ky] + 0.75f * fy[1][ky], o1 = 0.75f * fy[1][ky] + 0.25f * fy[2][ky];
             const size_t base = ((((size_t)n * 2 * D + 2 * z) * OH + 2 * y + ky) * OW + 2 * x + kx) * in.C + c0 + 4 * q;
-            *reinterpret_cast<f32x4*>(out + base) = o0;
-            *reinterpret_cast<f32x4*>(out + base + (size_t)OH * OW * in.C) = o1;
+            nm_st4(out, base, o0, oh);
+            nm_st4(out, base + (size_t)OH * OW * in.C, o1, oh);
         }
     }
 }
@@ -547,26 +563,26 @@ int nm_launch_gn_direct(const float* x, int N, int voxels, int C, int groups, co
 
 int nm_stats_blocks_per_frame(int voxels) { return (voxels + NM_STATS_VB - 1) / NM_STATS_VB; }
 
-int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part, hipStream_t s) {
+int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part, hipStream_t s, int h) {
     if (C > 256 || C <= 0) { nm_set_error("gn_partials: C=%d unsupported", C); return NM_ERR_ARG; }
     int nblk = nm_stats_blocks_per_frame(voxels);
-    hipLaunchKernelGGL(gn_partials_kernel, dim3(N * nblk), dim3(256), 0, s, x, voxels, C, nblk, part);
+    hipLaunchKernelGGL(gn_partials_kernel, dim3(N * nblk), dim3(256), 0, s, x, voxels, C, nblk, part, h);
     return nm_check_hip(hipGetLastError(), "gn_partials launch");
 }
 
-int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s) {
+int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s, int out_h) {
     if (a.C % 4) { nm_set_error("apply2: C %% 4 != 0"); return NM_ERR_ARG; }
     if (b && (b->N != a.N || b->D != a.D || b->H != a.H || b->W != a.W || b->C != a.C)) { nm_set_error("apply2: shape mismatch"); return NM_ERR_ARG; }
     const size_t frame4 = (size_t)a.D * a.H * a.W * a.C / 4;
     if (frame4 * 4 >= ((size_t)1 << 31)) { nm_set_error("apply2: frame too large"); return NM_ERR_ARG; }
     TensorRef bb = b ? *b : a;
     const unsigned bx = (unsigned)min((frame4 + 255) / 256, (size_t)max(1, 4096 / max(a.N, 1)));
-    hipLaunchKernelGGL(apply2_kernel, dim3(bx, a.N), dim3(256), 0, s, a, bb, b ? 1 : 0, out);
+    hipLaunchKernelGGL(apply2_kernel, dim3(bx, a.N), dim3(256), 0, s, a, bb, b ? 1 : 0, out, out_h);
     return nm_check_hip(hipGetLastError(), "apply2 launch");
 }
 
 int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, float* out, int Cout, int OD, int OH,
-                     int OW, hipStream_t s) {
+                     int OW, hipStream_t s, int out_h) {
     if (Cout % 4 || in.C % 4) { nm_set_error("convT2: channels must be multiples of 4"); return NM_ERR_ARG; }
     if (OD < 2 * in.D || OD > 2 * in.D + 1 || OH < 2 * in.H || OH > 2 * in.H + 1 || OW < 2 * in.W || OW > 2 * in.W + 1) {
         nm_set_error("convT2: bad output size"); return NM_ERR_ARG;
@@ -578,34 +594,36 @@ int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, flo
         fvox * 8 * Cout < ((size_t)1 << 31)) {
         static NmDeviceOnce attr_set;
         if (!attr_set.done()) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(convT2_mfma)");
             attr_set.mark();
         }
         const int tpf = (int)(fvox / 32), tiles = (int)(cvox / 32);
         const size_t ldsb = (size_t)4 * 32 * (in.C + 4) * sizeof(float);
-        hipLaunchKernelGGL(convT2_mfma_kernel, dim3((unsigned)min((tiles + 3) / 4, 2048)), dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
+        if (out_h) hipLaunchKernelGGL(convT2_mfma_kernel<true>, dim3((unsigned)min((tiles + 3) / 4, 2048)), dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
+        else hipLaunchKernelGGL(convT2_mfma_kernel<false>, dim3((unsigned)min((tiles + 3) / 4, 2048)), dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
         return nm_check_hip(hipGetLastError(), "convT2_mfma launch");
     }
     if (OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && 256 % (Cout / 4) == 0 && (size_t)in.C * Cout * 4 <= 48 * 1024 && cvox >= 65536) {
         const int vpb = 2048;
         hipLaunchKernelGGL(convT2_lds_kernel, dim3((unsigned)((cvox + vpb - 1) / vpb), 8), dim3(256), (size_t)in.C * Cout * sizeof(float), s, in, w, bias,
-                           out, Cout, OD, OH, OW, vpb);
+                           out, Cout, OD, OH, OW, vpb, out_h);
         return nm_check_hip(hipGetLastError(), "convT2_lds launch");
     }
-    hipLaunchKernelGGL(convT2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w, bias, out, Cout, OD, OH, OW);
+    hipLaunchKernelGGL(convT2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w, bias, out, Cout, OD, OH, OW, out_h);
     return nm_check_hip(hipGetLastError(), "convT2 launch");
 }
 
-int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s) {
+int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s, int out_h) {
     if (in.C % 4) { nm_set_error("upsample2: C %% 4 != 0"); return NM_ERR_ARG; }
     if (in.C % 32 == 0 && in.D % 2 == 0 && in.H % 4 == 0 && in.W % 4 == 0) {
         const int tz = in.D / 2, ty = in.H / 4, tx = in.W / 4;
-        hipLaunchKernelGGL(upsample2_tile_kernel, dim3((unsigned)((size_t)in.N * tz * ty * tx * (in.C / 32))), dim3(256), 0, s, in, out, tz, ty, tx);
+        hipLaunchKernelGGL(upsample2_tile_kernel, dim3((unsigned)((size_t)in.N * tz * ty * tx * (in.C / 32))), dim3(256), 0, s, in, out, tz, ty, tx, out_h);
         return nm_check_hip(hipGetLastError(), "upsample2 launch");
     }
     size_t total = (size_t)in.N * in.D * in.H * in.W * (in.C / 4);
-    hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out);
+    hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, out_h);
     return nm_check_hip(hipGetLastError(), "upsample2 launch");
 }
 
@@ -616,6 +634,7 @@ int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t,
 }
 
 int nm_launch_cl_to_ncdhw_strided(const TensorRef& in, int frame_stride, float* out, hipStream_t s) {
+    if (in.h) { nm_set_error("cl_to_ncdhw: bfloat16 input is not supported"); return NM_ERR_UNSUPPORTED; }
     int voxels = in.D * in.H * in.W;
     dim3 grid((voxels + 31) / 32, (in.C + 31) / 32, in.N);
     hipLaunchKernelGGL(cl_to_ncdhw_kernel, grid, dim3(256), 0, s, in, frame_stride, out);

@@ -49,16 +49,17 @@ int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, 
 // Power-of-two operand scaling of the data-gradient convolutions in the split-fp16 conv mode: gradients are often
 // below the fp16 normal range (6e-5), where the hi/lo split loses its low bits; dy is read as dy * 2^k through the lazy
 // affine of the conv kernels and the result is multiplied by 2^-k (exact).
-int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s, const float* mul = nullptr);
+// h (here and below): the raw tensors are stored as bfloat16 (16-bit storage mode); for the GroupNorm backward y.h covers y, dA and dy
+int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s, const float* mul = nullptr, int h = 0);
 int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* sc2 /*[2^k, 2^-k]*/, hipStream_t s, float* zero_shift = nullptr);
-int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s);
+int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s, int h = 0);
 
 // ---- misc --------------------------------------------------------------------------------------------------------------
 // adjoint of nn.Upsample(x2, trilinear, align_corners=False): dfine [N][2D][2H][2W][C] -> dcoarse [N][D][H][W][C]
 int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s,
-                                const float* mul = nullptr /* device scalar multiplied into the result */);
+                                const float* mul = nullptr /* device scalar multiplied into the result */, int h_fine = 0, int h_coarse = 0);
 // OIDHW weights of the data-gradient convolution: out[ci][co][K-1-tap] = w[co][ci][tap], ci < csel
 int nm_launch_flip_weight(const float* w, int Cout, int Cin, int csel, int ks, float* out, hipStream_t s);
-int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s);      // dst += src
+int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s, int h = 0);      // dst += src
 // dst = dst * *dst_mul + src * *src_mul (device scalars, null = 1); n % 4 == 0
-int nm_launch_axpby(float* dst, const float* dst_mul, const float* src, const float* src_mul, size_t n, hipStream_t s);
+int nm_launch_axpby(float* dst, const float* dst_mul, const float* src, const float* src_mul, size_t n, hipStream_t s, int h = 0);

@@ -53,7 +53,9 @@ struct WgradParams {
 
 // MODE 0: taps dealt to the waves (NTW per wave);  MODE 1: ks = 1, the waves split the voxels;
 // MODE 2: first layer, columns = (dx, channel) of cat[occ, x1, x2, x3], tap groups = (dz, dy)
-template <int MODE, int NTW>
+// HX / HD: the input / dY tensor is stored as bfloat16 (16-bit storage mode; template parameters, not run-time flags: a load under a
+// uniform branch ends the batch of loads it belongs to)
+template <int MODE, int NTW, bool HX = false, bool HD = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     extern __shared__ float lds[];
     constexpr int CP = MODE == 2 ? 4 : 32;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             const int m = m0 + 4 * q;
             f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.dy.scale && m < p.M) { sc = *reinterpret_cast<const f32x4*>(p.dy.scale + (size_t)n * p.dy.C + m); sh = *reinterpret_cast<const f32x4*>(p.dy.shift + (size_t)n * p.dy.C + m); }
-            const float* base = p.dy.p + ((((size_t)n * OD + oz0) * OH + oy0) * OW + ox0) * p.dy.C;
+            const size_t base = ((((size_t)n * OD + oz0) * OH + oy0) * OW + ox0) * p.dy.C;      // element offset
             constexpr int U = 4;
 #pragma unroll
             for (int u0 = 0; u0 < DU; u0 += U) {
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                     const int pk = d_pk[u0 + u];
                     ok[u] = pk < 0 && oz0 + ((pk >> 16) & 255) < OD && oy0 + ((pk >> 8) & 255) < OH && ox0 + (pk & 255) < OW && m < p.M;
                     v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok[u]) v[u] = *reinterpret_cast<const f32x4*>(base + d_rel[u0 + u]);
+                    if (ok[u]) v[u] = nm_ld4<HD>(p.dy.p, base + d_rel[u0 + u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             const int c = n0 + 4 * q;
             f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.in.scale && c < p.Nc) { sc = *reinterpret_cast<const f32x4*>(p.in.scale + (size_t)n * p.in.C + c); sh = *reinterpret_cast<const f32x4*>(p.in.shift + (size_t)n * p.in.C + c); }
-            const float* base = p.in.p + ((((long long)n * p.in.D + iz0) * p.in.H + iy0) * p.in.W + ix0) * (long long)p.in.C;
+            const long long base = ((((long long)n * p.in.D + iz0) * p.in.H + iy0) * p.in.W + ix0) * (long long)p.in.C;   // element offset (may be negative)
             constexpr int U = 4;
 #pragma unroll
             for (int u0 = 0; u0 < AU; u0 += U) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                     const int gz = iz0 + ((pk >> 16) & 255), gy = iy0 + ((pk >> 8) & 255), gx = ix0 + (pk & 255);
                     ok[u] = pk < 0 && (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && c < p.Nc;
                     v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok[u]) v[u] = *reinterpret_cast<const f32x4*>(base + a_rel[ui]);
+                    if (ok[u]) v[u] = nm_ld4<HX>(p.in.p, (size_t)(base + a_rel[ui]));
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 // brick once ([64][Cout] + [64][Cin] floats, activated) and its four waves share the tiles (tile t = w + 4 j, NTW accumulators per
 // wave) - v_mfma_f32_32x32x2_f32, both operands single floats from LDS.  Persistent workgroups, partials in wgrad_kernel's MODE 1
 // layout (the same reduce).
-template <int NTW>
+template <int NTW, bool H16 = false>       // H16: both tensors bfloat16 (16-bit storage mode)
 __global__ __launch_bounds__(256) void wgrad_k1_kernel(WgradParams p, int m_tiles, int n_tiles) {
     extern __shared__ float lds[];
     const int Mp = m_tiles * 32 + 4, Np = n_tiles * 32 + 4;          // row pitches (+4: the two lane halves on different banks)
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(WgradParams p, int m_tile
         __syncthreads();                  // the previous brick's operand reads
         // stage both tiles (batches of four 16-byte loads; a row's items are contiguous in memory up to the real channel count)
         auto stage = [&](const TensorRef& t, int real_c, int rowq, int pitch, float* dst) {
-            const float* src = t.p + ((size_t)n * V + v0) * t.C;
+            const size_t src = ((size_t)n * V + v0) * t.C;             // element offset
             const int items = 64 * rowq;
             for (int i0 = tid; i0 < items; i0 += 256 * 4) {
                 f32x4 v[4]; int vox[4], c[4]; bool ok[4];
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void wgrad_k1_kernel(WgradParams p, int m_tile
                     vox[u] = i / rowq; c[u] = (i % rowq) * 4;
                     ok[u] = i < items && c[u] < real_c && c[u] < t.C;
                     v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok[u]) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)vox[u] * t.C + c[u]);
+                    if (ok[u]) v[u] = nm_ld4<H16>(t.p, src + (size_t)vox[u] * t.C + c[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -1056,7 +1058,9 @@ __global__ __launch_bounds__(512, 1) void wgrad16u_kernel(WgradParams p) {
 #define WZ_DBUF (2 * WT_DB)
 #define WZ_LDS (WZ_D0 + 2 * WZ_DBUF)
 
-template <int NT, int DBG, bool SINGLE>
+// H16: both operand tensors are stored as bfloat16 (16-bit storage mode): an item's eight channels are ONE 16-byte load, kept raw in
+// the `a` register quad and widened (shift / mask) inside the conversion pieces - two more vector instructions per affine piece
+template <int NT, int DBG, bool SINGLE, bool H16>
 __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) {
     extern __shared__ char lds8[];
     float* xtab = reinterpret_cast<float*>(lds8 + WZ_LDS);
@@ -1087,15 +1091,22 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
         const int gy = xoy - 1 + hy, gx = xox - 1 + hx;
         in = (unsigned)gz < (unsigned)p.in.D && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W && exists;
         const long long off = ((((long long)xn * p.in.D + gz) * p.in.H + gy) * p.in.W + gx) * (long long)p.in.C + n0 + 8 * oct;
-        const float* src = p.in.p + off;
-        a = *reinterpret_cast<const f32x4*>(in && ca_ok ? src : p.in.p); b = *reinterpret_cast<const f32x4*>(in && cb_ok ? src + 4 : p.in.p);
+        if constexpr (H16) a = *reinterpret_cast<const f32x4*>(in && ca_ok ? nm_eptr(p.in.p, (size_t)off, 1) : p.in.p);
+        else {
+            const float* src = p.in.p + off;
+            a = *reinterpret_cast<const f32x4*>(in && ca_ok ? src : p.in.p); b = *reinterpret_cast<const f32x4*>(in && cb_ok ? src + 4 : p.in.p);
+        }
     };
     auto d_issue = [&](int bz, f32x4& a, f32x4& b) __attribute__((always_inline)) {
         int t = tid;
         asm volatile("" : "+v"(t));
         const int bv = t >> 2, z = bv >> 6, y = (bv >> 3) & 7, x = bv & 7, m = m0 + 8 * (t & 3);
-        const float* src = p.dy.p + ((((size_t)xn * p.dy.D + 2 * bz + z) * p.dy.H + xoy + y) * p.dy.W + xox + x) * p.dy.C + m;
-        a = *reinterpret_cast<const f32x4*>(ma_ok ? src : p.dy.p); b = *reinterpret_cast<const f32x4*>(mb_ok ? src + 4 : p.dy.p);
+        const size_t eo = ((((size_t)xn * p.dy.D + 2 * bz + z) * p.dy.H + xoy + y) * p.dy.W + xox + x) * p.dy.C + m;
+        if constexpr (H16) a = *reinterpret_cast<const f32x4*>(ma_ok ? nm_eptr(p.dy.p, eo, 1) : p.dy.p);
+        else {
+            const float* src = p.dy.p + eo;
+            a = *reinterpret_cast<const f32x4*>(ma_ok ? src : p.dy.p); b = *reinterpret_cast<const f32x4*>(mb_ok ? src + 4 : p.dy.p);
+        }
     };
     auto d_affine = [&](f32x4& sa, f32x4& sb, f32x4& ha, f32x4& hb) __attribute__((always_inline)) {
         int t = tid;
@@ -1110,6 +1121,11 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
     auto convert_store = [&](f32x4 a, f32x4 b, const f32x4& sa, const f32x4& sb, const f32x4& ha, const f32x4& hb, float slope, float ka, float kb,
                              char* hi, char* lo) __attribute__((always_inline)) {
         unsigned h[4], l[4];
+        if constexpr (H16) {
+            const unsigned u0 = __builtin_bit_cast(unsigned, a[0]), u1 = __builtin_bit_cast(unsigned, a[1]), u2 = __builtin_bit_cast(unsigned, a[2]), u3 = __builtin_bit_cast(unsigned, a[3]);
+            a = f32x4{nm_bf_lo(u0), nm_bf_hi(u0), nm_bf_lo(u1), nm_bf_hi(u1)};
+            b = f32x4{nm_bf_lo(u2), nm_bf_hi(u2), nm_bf_lo(u3), nm_bf_hi(u3)};
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             a[j] = fmaf(a[j], sa[j], ha[j]); b[j] = fmaf(b[j], sb[j], hb[j]);
@@ -1213,37 +1229,41 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
                 constexpr int g = decltype(GG)::value;
                 if constexpr (!STAGE || g < 0 || g >= 60) return;
                 if constexpr (g == 0) {
-                    const float* src = p.dy.p + (doff + bzn * dstep);
-                    da = *reinterpret_cast<const f32x4*>(ma_ok ? src : p.dy.p); db = *reinterpret_cast<const f32x4*>(mb_ok ? src + 4 : p.dy.p);
+                    if constexpr (H16) da = *reinterpret_cast<const f32x4*>(ma_ok ? nm_eptr(p.dy.p, (size_t)(doff + bzn * dstep), 1) : p.dy.p);
+                    else {
+                        const float* src = p.dy.p + (doff + bzn * dstep);
+                        da = *reinterpret_cast<const f32x4*>(ma_ok ? src : p.dy.p); db = *reinterpret_cast<const f32x4*>(mb_ok ? src + 4 : p.dy.p);
+                    }
                 }
                 if constexpr (g == 10 || g == 16) {
                     constexpr int k = g == 10 ? 0 : 1;
                     int np = npack[k];
                     asm volatile("" : "+v"(np));
                     xin = ((inyx >> k) & 1) != 0 && 2 * bz + 3 + ((np >> 16) & 1) < p.in.D;
-                    xsrc = p.in.p + (xoff[k] + bz * xstep);
+                    xsrc = nm_eptr(p.in.p, (size_t)(xoff[k] + bz * xstep), H16);
                 }
                 if constexpr (g == 11 || g == 17) {
                     constexpr int k = g == 11 ? 0 : 1;
-                    xa[k] = *reinterpret_cast<const f32x4*>(xin && ca_ok ? xsrc : p.in.p); xb[k] = *reinterpret_cast<const f32x4*>(xin && cb_ok ? xsrc + 4 : p.in.p);
+                    xa[k] = *reinterpret_cast<const f32x4*>(xin && ca_ok ? xsrc : p.in.p);
+                    if constexpr (!H16) xb[k] = *reinterpret_cast<const f32x4*>(xin && cb_ok ? xsrc + 4 : p.in.p);
                 }
                 if constexpr (g >= 18) {
                     constexpr int item = (g - 18) / 14, c = (g - 18) % 14;          // item 0 = dY, 1 / 2 = X item 0 / 1
                     if constexpr (c == 0) {
                         const float* t;
                         if constexpr (item == 0) {
-                            ca = da; cb_ = db;
+                            ca = da; if constexpr (!H16) cb_ = db;
                             cka = ma_ok ? 1.f : 0.f; ckb = mb_ok ? 1.f : 0.f; cslope = p.dy.slope;
                             t = dtab + 8 * oct;
                         } else {
-                            ca = xa[item - 1]; cb_ = xb[item - 1];
+                            ca = xa[item - 1]; if constexpr (!H16) cb_ = xb[item - 1];
                             int np = npack[item - 1];
                             asm volatile("" : "+v"(np));
                             const bool in = ((inyx >> (item - 1)) & 1) != 0 && 2 * bz + 3 + ((np >> 16) & 1) < p.in.D;
                             cka = in && ca_ok ? 1.f : 0.f; ckb = in && cb_ok ? 1.f : 0.f; cslope = p.in.slope;
                             t = xtab + xn * 64 + 8 * oct;
                         }
-                        W16U_PIN4(ca); W16U_PIN4(cb_);
+                        W16U_PIN4(ca); if constexpr (!H16) W16U_PIN4(cb_);
                         csa = *reinterpret_cast<const f32x4*>(t); cha = *reinterpret_cast<const f32x4*>(t + 32);
                     } else if constexpr (c <= 12) {
                         constexpr int j = (c - 1) / 3, part = (c - 1) % 3, e = 2 * (j & 1);
@@ -1253,7 +1273,10 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
                                 const float* t = item == 0 ? dtab + 8 * oct : xtab + xn * 64 + 8 * oct;
                                 csa = *reinterpret_cast<const f32x4*>(t + 4); cha = *reinterpret_cast<const f32x4*>(t + 36);
                             }
-                            if constexpr (j < 2) { t0 = fmaf(ca[e], csa[e], cha[e]); t1 = fmaf(ca[e + 1], csa[e + 1], cha[e + 1]); }
+                            if constexpr (H16) {        // channel pair j of the raw item: dword j
+                                const unsigned u = __builtin_bit_cast(unsigned, ca[j]);
+                                t0 = fmaf(nm_bf_lo(u), csa[e], cha[e]); t1 = fmaf(nm_bf_hi(u), csa[e + 1], cha[e + 1]);
+                            } else if constexpr (j < 2) { t0 = fmaf(ca[e], csa[e], cha[e]); t1 = fmaf(ca[e + 1], csa[e + 1], cha[e + 1]); }
                             else { t0 = fmaf(cb_[e], csa[e], cha[e]); t1 = fmaf(cb_[e + 1], csa[e + 1], cha[e + 1]); }
                             u0 = t0 * cslope; u1 = t1 * cslope;
                         } else if constexpr (part == 1) {
@@ -1356,11 +1379,11 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
     }
 }
 
-template <int DBG, bool SINGLE = false>
+template <int DBG, bool SINGLE = false, bool H16 = false>
 __global__ __launch_bounds__(512, 1) void wgrad16z_kernel(WgradParams p) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (w < 3) wgrad16z_run<4, DBG, SINGLE>(p, w);
-    else wgrad16z_run<3, DBG, SINGLE>(p, w);
+    if (w < 3) wgrad16z_run<4, DBG, SINGLE, H16>(p, w);
+    else wgrad16z_run<3, DBG, SINGLE, H16>(p, w);
 }
 
 // ---- first layer, sparse form ----------------------------------------------------------------------------------------------------
@@ -1425,7 +1448,7 @@ __global__ __launch_bounds__(256) void wgrad_k5occ_sparse_kernel(const float* __
 // bricks empty, which is what makes the dense form cheaper than the gather above (3.3 ms per step: every occupied voxel pulls 125 x
 // COUT dy values through L2 with no reuse between neighbours).  Persistent workgroups, accumulators across bricks, per-workgroup
 // partials in the gather's layout, the same fixed-order reduce.
-template <int COUT>
+template <int COUT, bool HD = false>        // HD: dy is stored as bfloat16
 __global__ __launch_bounds__(256) void wgrad_k5occ_mfma_kernel(const float* __restrict__ occ, const float* __restrict__ dy, int N, int G,
                                                                float* __restrict__ part) {
     extern __shared__ float lds[];
@@ -1476,7 +1499,7 @@ __global__ __launch_bounds__(256) void wgrad_k5occ_mfma_kernel(const float* __re
             for (int u = 0; u < 8; ++u) {
                 const int idx = tid + 256 * (i0 + u), vox = idx / C4, c4 = idx % C4;
                 const int z = vox >> 6, y = (vox >> 3) & 7, x = vox & 7;
-                v[u] = *reinterpret_cast<const f32x4*>(dy + ((((size_t)n * G + oz0 + z) * G + oy0 + y) * G + ox0 + x) * COUT + 4 * c4);
+                v[u] = nm_ld4<HD>(dy, ((((size_t)n * G + oz0 + z) * G + oy0 + y) * G + ox0 + x) * COUT + 4 * c4);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(dys + (size_t)(tid + 256 * (i0 + u)) * 4) = v[u];
@@ -1517,10 +1540,10 @@ __global__ __launch_bounds__(256) void wgrad_k5occ_sparse_reduce_kernel(const fl
     }
 }
 // out[i] = sum_n x[n*per + i]
-__global__ __launch_bounds__(256) void sum_frames4_kernel(const float* __restrict__ x, int N, size_t per4, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sum_frames4_kernel(const float* __restrict__ x, int N, size_t per4, float* __restrict__ out, int h) {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per4; i += (size_t)gridDim.x * 256) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int n = 0; n < N; ++n) s += *reinterpret_cast<const f32x4*>(x + ((size_t)n * per4 + i) * 4);
+        for (int n = 0; n < N; ++n) s += nm_ld4(x, ((size_t)n * per4 + i) * 4, h);
         *reinterpret_cast<f32x4*>(out + i * 4) = s;
     }
 }
@@ -1568,9 +1591,9 @@ __global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restri
         const int VB = nm_gnb_vb(voxels), v0 = blk * VB, v1 = min(voxels, v0 + VB);
         for (int v = v0 + vl; v < v1; v += lanes) {
             const size_t o = ((size_t)n * voxels + v) * C + c;
-            const float yy = y.p[o];
+            const float yy = nm_ld1(y.p, o, y.h);
             const float z = fmaf(yy, sc, shf);
-            const float dz = (dA[o] * mm) * (z > 0.f ? 1.0f : y.slope);
+            const float dz = (nm_ld1(dA, o, y.h) * mm) * (z > 0.f ? 1.0f : y.slope);
             s1 += dz; s2 += dz * yy;
         }
     }
@@ -1589,6 +1612,8 @@ __global__ __launch_bounds__(256) void gnb_partials_kernel(const float* __restri
 // thread and reached 0.54 of the HBM rate on the 64^3 layers (2 reads of 2.1 GB in 1.6 ms).
 // (dv, wv: dA given as the outer product dv[n][voxel] * wv[channel] instead of a tensor - the decoder's last conv layer, whose
 //  incoming gradient is the 1x1 tail conv's weight row times one scalar per voxel: 67 MB instead of 2.1 GB, read twice)
+// H: y and dA are stored as bfloat16 (16-bit storage mode): 8-byte loads of the same four channels
+template <bool H>
 __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restrict__ dA, TensorRef y, int voxels, float* __restrict__ part,
                                                             const float* __restrict__ dmul, const float* __restrict__ dv, const float* __restrict__ wv) {
     __shared__ f32x4 sh[256 * 2];
@@ -1601,14 +1626,14 @@ __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restr
         f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, shf = f32x4{0.f, 0.f, 0.f, 0.f};
         if (y.scale) { sc = *reinterpret_cast<const f32x4*>(y.scale + (size_t)n * C + c); shf = *reinterpret_cast<const f32x4*>(y.shift + (size_t)n * C + c); }
         const int VB = nm_gnb_vb(voxels), v0 = blk * VB, v1 = min(voxels, v0 + VB);
-        const float* yp = y.p + (size_t)n * voxels * C + c;
-        const float* dp = dA + (size_t)n * voxels * C + c;
+        const float* yp = nm_eptr(y.p, (size_t)n * voxels * C + c, H);
+        const float* dp = nm_eptr(dA, (size_t)n * voxels * C + c, H);
         const float* dvp = dv + (size_t)n * voxels;
         f32x4 w4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (dv) w4 = *reinterpret_cast<const f32x4*>(wv + c);
         auto grad = [&](int vv) __attribute__((always_inline)) {
             if (dv) { const float d = dvp[vv]; return f32x4{d * w4[0], d * w4[1], d * w4[2], d * w4[3]}; }
-            return *reinterpret_cast<const f32x4*>(dp + (size_t)vv * C);
+            return nm_ld4<H>(dp, (size_t)vv * C);
         };
         auto add = [&](const f32x4& yy, const f32x4& dd, int u) __attribute__((always_inline)) {
 #pragma unroll
@@ -1623,13 +1648,13 @@ __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restr
             f32x4 yy[4], dd[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                yy[u] = *reinterpret_cast<const f32x4*>(yp + (size_t)(v + u * lanes) * C);
+                yy[u] = nm_ld4<H>(yp, (size_t)(v + u * lanes) * C);
                 dd[u] = grad(v + u * lanes);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) add(yy[u], dd[u], u & 1);
         }
-        for (; v < v1; v += lanes) add(*reinterpret_cast<const f32x4*>(yp + (size_t)v * C), grad(v), 0);
+        for (; v < v1; v += lanes) add(nm_ld4<H>(yp, (size_t)v * C), grad(v), 0);
     }
     sh[threadIdx.x * 2] = s1[0] + s1[1]; sh[threadIdx.x * 2 + 1] = s2[0] + s2[1];
     __syncthreads();
@@ -1777,13 +1802,13 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
     for (unsigned r = (blockIdx.x * 256u + threadIdx.x) * 4u; r < per_frame; r += gridDim.x * 1024u) {
         const size_t e = n * per_frame + r;
         const int c = (int)(r % (unsigned)y.C);
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(y.p + e);
+        const f32x4 yy = nm_ld4(y.p, e, y.h);
         f32x4 d;
         if (dv) {
             const float dd = dv[n * (per_frame / (unsigned)y.C) + r / (unsigned)y.C];
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(wv + c);
             d = f32x4{dd * w4[0], dd * w4[1], dd * w4[2], dd * w4[3]};
-        } else d = *reinterpret_cast<const f32x4*>(dA + e);
+        } else d = nm_ld4(dA, e, y.h);
         d[0] *= mm; d[1] *= mm; d[2] *= mm; d[3] *= mm;
         if (y.slope != 1.0f) {
             f32x4 z = yy;
@@ -1801,7 +1826,7 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[j] = fmaf(cf[j * 4], d[j], fmaf(cf[j * 4 + 1], yy[j], cf[j * 4 + 2]));
         }
-        *reinterpret_cast<f32x4*>(dy + e) = d;
+        nm_st4(dy, e, d, y.h);
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
     }
     if (amax) block_absmax(mx, amax);
@@ -1812,7 +1837,7 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
 // once instead of per 16-byte item, and four items' tensor loads are in flight before the first is used.  The generic kernel's loop
 // is one item per iteration behind three dependent waits (tensor loads, scale / shift, coefficients) and runs at 4.9 TB/s on
 // occupancy alone.  Identity operands (scale 1 / shift 0, slope 1) leave the values as they are; same arithmetic per element.
-template <bool RANK1, bool COEF>
+template <bool RANK1, bool COEF, bool H>
 __global__ __launch_bounds__(256) void gnb_apply4_kernel(const float* __restrict__ dA, TensorRef y, const float* __restrict__ coef,
                                                          float* __restrict__ dy, unsigned* __restrict__ amax, const float* __restrict__ dmul,
                                                          const float* __restrict__ dv, const float* __restrict__ wv) {
@@ -1831,10 +1856,10 @@ __global__ __launch_bounds__(256) void gnb_apply4_kernel(const float* __restrict
         for (int j = 0; j < 4; ++j) { c1[j] = cf[j * 4]; c2[j] = cf[j * 4 + 1]; c3[j] = cf[j * 4 + 2]; }
     }
     const float slope = y.slope;
-    const float* yp = y.p + n * per_frame;
-    const float* dp = dA + n * per_frame;
+    const float* yp = nm_eptr(y.p, n * per_frame, H);
+    const float* dp = nm_eptr(dA, n * per_frame, H);
     const float* dvp = dv + n * (per_frame / C);
-    float* op = dy + n * per_frame;
+    float* op = nm_eptr(dy, n * per_frame, H);
     auto one = [&](const f32x4& yy, f32x4 d, unsigned r) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1843,7 +1868,7 @@ __global__ __launch_bounds__(256) void gnb_apply4_kernel(const float* __restrict
             d[j] = z > 0.f ? d[j] : d[j] * slope;
             if (COEF) d[j] = fmaf(c1[j], d[j], fmaf(c2[j], yy[j], c3[j]));
         }
-        *reinterpret_cast<f32x4*>(op + r) = d;
+        nm_st4<H>(op, r, d);
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
     };
     unsigned r = r0;
@@ -1852,28 +1877,28 @@ __global__ __launch_bounds__(256) void gnb_apply4_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const unsigned ru = r + u * step;
-            yy[u] = *reinterpret_cast<const f32x4*>(yp + ru);
+            yy[u] = nm_ld4<H>(yp, ru);
             if (RANK1) { const float q = dvp[ru / C]; dd[u] = f32x4{q * w4[0], q * w4[1], q * w4[2], q * w4[3]}; }
-            else dd[u] = *reinterpret_cast<const f32x4*>(dp + ru);
+            else dd[u] = nm_ld4<H>(dp, ru);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) one(yy[u], dd[u], r + u * step);
     }
     for (; r < per_frame; r += step) {
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(yp + r);
+        const f32x4 yy = nm_ld4<H>(yp, r);
         f32x4 dd;
         if (RANK1) { const float q = dvp[r / C]; dd = f32x4{q * w4[0], q * w4[1], q * w4[2], q * w4[3]}; }
-        else dd = *reinterpret_cast<const f32x4*>(dp + r);
+        else dd = nm_ld4<H>(dp, r);
         one(yy, dd, r);
     }
     if (amax) block_absmax(mx, amax);
 }
 
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ amax, const float* __restrict__ dmul) {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ amax, const float* __restrict__ dmul, int h) {
     const float mm = dmul ? fabsf(*dmul) : 1.0f;
     float mx = 0.f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 d = nm_ld4(x, i * 4, h);
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
     }
     block_absmax(mx * mm, amax);
@@ -1891,12 +1916,12 @@ __global__ void make_scale_kernel(const unsigned* __restrict__ amax, int count, 
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc2[0] = sc; sc2[1] = 1.0f / sc; }
 }
 
-__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ x, size_t n4, const float* __restrict__ mul) {
+__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ x, size_t n4, const float* __restrict__ mul, int h) {
     const float m = *mul;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 d = *reinterpret_cast<f32x4*>(x + i * 4);
+        f32x4 d = nm_ld4(x, i * 4, h);
         d[0] *= m; d[1] *= m; d[2] *= m; d[3] *= m;
-        *reinterpret_cast<f32x4*>(x + i * 4) = d;
+        nm_st4(x, i * 4, d, h);
     }
 }
 
@@ -1908,7 +1933,7 @@ __device__ __forceinline__ void up_adj_w(int j, int I, float (&w)[4]) {
 }
 
 __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __restrict__ dfine, int N, int D, int H, int W, int C,
-                                                                float* __restrict__ dcoarse, const float* __restrict__ mul) {
+                                                                float* __restrict__ dcoarse, const float* __restrict__ mul, int hf, int hc) {
     const float mm = mul ? *mul : 1.0f;
     const int cq = C / 4;
     const size_t total = (size_t)N * D * H * W * cq;
@@ -1929,18 +1954,18 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __r
                 if (wy[b] == 0.f) continue;
                 const size_t fy = (size_t)(2 * y + b - 1);
                 const float wzy = wz[a] * wy[b];
-                const float* row = dfine + (((n * 2 * D + fz) * 2 * H + fy) * 2 * W) * C + q * 4;
+                const size_t row = (((n * 2 * D + fz) * 2 * H + fy) * 2 * W) * C + q * 4;
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     if (wx[cc] == 0.f) continue;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(row + (size_t)(2 * x + cc - 1) * C);
+                    const f32x4 v = nm_ld4(dfine, row + (size_t)(2 * x + cc - 1) * C, hf);
                     const float wt = wzy * wx[cc];
                     acc[0] += wt * v[0]; acc[1] += wt * v[1]; acc[2] += wt * v[2]; acc[3] += wt * v[3];
                 }
             }
         }
         acc[0] *= mm; acc[1] *= mm; acc[2] *= mm; acc[3] *= mm;
-        *reinterpret_cast<f32x4*>(dcoarse + i * 4) = acc;
+        nm_st4(dcoarse, i * 4, acc, hc);
     }
 }
 
@@ -1954,7 +1979,7 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __r
 #define UA_FY 10
 #define UA_FX 18
 __global__ __launch_bounds__(256) void upsample2_adjoint_tile_kernel(const float* __restrict__ dfine, int N, int D, int H, int W, int C,
-                                                                     float* __restrict__ dcoarse, const float* __restrict__ mul) {
+                                                                     float* __restrict__ dcoarse, const float* __restrict__ mul, int hf, int hc) {
     __shared__ f32x4 tile[UA_FZ * UA_FY * UA_FX * 4];
     const float mm = mul ? *mul : 1.0f;
     const int tid = threadIdx.x;
@@ -1982,7 +2007,7 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_tile_kernel(const float
             const int gz = fz0 + fz, gy = fy0 + fy, gx = fx0 + fx;
             reg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (i < ITEMS && (unsigned)gz < (unsigned)FD && (unsigned)gy < (unsigned)FH && (unsigned)gx < (unsigned)FW)
-                reg[k] = *reinterpret_cast<const f32x4*>(dfine + (((n * FD + gz) * FH + gy) * FW + gx) * C + c0 + 4 * iq);
+                reg[k] = nm_ld4(dfine, (((n * FD + gz) * FH + gy) * FW + gx) * C + c0 + 4 * iq, hf);
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) { const int i = tid + 256 * k; if (i < ITEMS) tile[i] = reg[k]; }
@@ -2002,7 +2027,7 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_tile_kernel(const float
                 }
             }
         acc[0] *= mm; acc[1] *= mm; acc[2] *= mm; acc[3] *= mm;
-        *reinterpret_cast<f32x4*>(dcoarse + (((n * D + z0 + lz) * H + y0 + ly) * W + x0 + lx) * C + c0 + 4 * q) = acc;
+        nm_st4(dcoarse, (((n * D + z0 + lz) * H + y0 + ly) * W + x0 + lx) * C + c0 + 4 * q, acc, hc);
     }
 }
 
@@ -2014,20 +2039,20 @@ __global__ void flip_weight_kernel(const float* __restrict__ w, int Cout, int Ci
     }
 }
 
-__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n, int h) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) nm_st1(dst, i, nm_ld1(dst, i, h) + nm_ld1(src, i, h), h);
 }
 // dst = dst * (*dmul) + src * (*smul)   (null multiplier = 1): the un-scaling of a data-gradient conv's result folded into the add
 // that joins it with the other branch (one pass instead of scale_by + axpy)
 __global__ __launch_bounds__(256) void axpby4_kernel(float* __restrict__ dst, const float* __restrict__ dmul, const float* __restrict__ src,
-                                                     const float* __restrict__ smul, size_t n4) {
+                                                     const float* __restrict__ smul, size_t n4, int h) {
     const float a = dmul ? *dmul : 1.0f, b = smul ? *smul : 1.0f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 d = *reinterpret_cast<f32x4*>(dst + i * 4);
-        const f32x4 x = *reinterpret_cast<const f32x4*>(src + i * 4);
+        f32x4 d = nm_ld4(dst, i * 4, h);
+        const f32x4 x = nm_ld4(src, i * 4, h);
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = fmaf(d[j], a, x[j] * b);
-        *reinterpret_cast<f32x4*>(dst + i * 4) = d;
+        nm_st4(dst, i * 4, d, h);
     }
 }
 
@@ -2078,7 +2103,7 @@ WgradPlan plan_wgrad(int N, int OD, int OH, int OW, int M, int Nc, int ks, int s
     return q;
 }
 
-template <int MODE, int NTW>
+template <int MODE, int NTW, bool HX = false, bool HD = false>
 int launch_wgrad_t(const WgradPlan& q, hipStream_t s) {
     {   // the kernel's per-thread item tables: 8 dY items, 20 input items (5 in MODE 2)
         const int BV = q.p.BZ * q.p.BY * q.p.BX, HV = q.p.HZ * q.p.HY * q.p.HX;
@@ -2089,17 +2114,23 @@ int launch_wgrad_t(const WgradPlan& q, hipStream_t s) {
     }
     static NmDeviceOnce attr_set;
     if (!attr_set.done()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<MODE, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<MODE, NTW, HX, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             nm_set_error("wgrad: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
         }
         attr_set.mark();
     }
-    hipLaunchKernelGGL((wgrad_kernel<MODE, NTW>), dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
+    hipLaunchKernelGGL((wgrad_kernel<MODE, NTW, HX, HD>), dim3(q.p.S, q.m_tiles * q.p.n_tiles), dim3(256), q.lds, s, q.p);
     return nm_check_hip(hipGetLastError(), "wgrad launch");
 }
 
 
 int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
+    // 16-bit storage: both operands bfloat16, on the z-walking kernel only (every layer of >= 32^3 voxels has nbz >= 16)
+    const bool h16 = q.p.in.h || q.p.dy.h;
+    if (h16 && !(q.p.in.h && q.p.dy.h && nm_conv_single() && nm_ls().wgrad_tr && nm_ls().wgrad_z && q.p.nbz >= 2 && q.p.in.N <= 96)) {
+        nm_set_error("wgrad16: bfloat16 operands (in %d, dy %d) need conv mode 4, both tensors bfloat16 and the wgrad16z kernel", q.p.in.h, q.p.dy.h);
+        return NM_ERR_UNSUPPORTED;
+    }
     if (nm_ls().wgrad_tr && q.p.in.N <= 96) {                       // (the per-frame scale / shift table of wgrad16t_kernel lives in LDS: 256 B per frame)
         static bool attr_t = false;
         if (!attr_t) {
@@ -2126,7 +2157,8 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     nm_set_error("wgrad16z: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
                 }
                 attr_z = true;
@@ -2134,7 +2166,8 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
             const WgradParams& pz = q.p;                  // (plan_wgrad bounded S by the column count)
             const size_t ldsz = WZ_LDS + (size_t)q.p.in.N * 64 * sizeof(float) + 64 + 256;   // tiles, X affine table, dummy item, dY affine table
             const dim3 gz(pz.S, q.m_tiles * q.p.n_tiles);
-            if (q.p.dbg == 1) hipLaunchKernelGGL(wgrad16z_kernel<1>, gz, dim3(512), ldsz, s, pz);
+            if (h16) hipLaunchKernelGGL((wgrad16z_kernel<0, true, true>), gz, dim3(512), ldsz, s, pz);
+            else if (q.p.dbg == 1) hipLaunchKernelGGL(wgrad16z_kernel<1>, gz, dim3(512), ldsz, s, pz);
             else if (q.p.dbg == 2) hipLaunchKernelGGL(wgrad16z_kernel<2>, gz, dim3(512), ldsz, s, pz);
             else if (nm_conv_single()) hipLaunchKernelGGL((wgrad16z_kernel<0, true>), gz, dim3(512), ldsz, s, pz);
             else hipLaunchKernelGGL(wgrad16z_kernel<0>, gz, dim3(512), ldsz, s, pz);
@@ -2173,9 +2206,14 @@ int run_wgrad(WgradPlan& q, float* ws, float* dW, int cin_real, int taps, hipStr
     if (q.lds > 160 * 1024) { nm_set_error("wgrad: LDS tile of %zu bytes", q.lds); return NM_ERR_UNSUPPORTED; }
     q.p.part = ws;
     int rc;
+    const bool h16 = q.p.in.h || q.p.dy.h;
+    if (h16 && !(q.mode == 3 || (q.mode == 0 && q.p.ks == 2 && q.p.in.h) || (q.mode == 2 && !q.p.in.h))) {
+        nm_set_error("wgrad: no kernel for bfloat16 operands (in %d, dy %d) with ks=%d mode=%d", q.p.in.h, q.p.dy.h, q.p.ks, q.mode); return NM_ERR_UNSUPPORTED;
+    }
     if (q.mode == 3) rc = launch_wgrad16(q, s);
-    else if (q.mode == 2) rc = launch_wgrad_t<2, 7>(q, s);
+    else if (q.mode == 2) rc = q.p.dy.h ? launch_wgrad_t<2, 7, false, true>(q, s) : launch_wgrad_t<2, 7>(q, s);
     else if (q.mode == 1) rc = launch_wgrad_t<1, 1>(q, s);
+    else if (q.p.ks == 2 && h16) rc = q.p.dy.h ? launch_wgrad_t<0, 2, true, true>(q, s) : launch_wgrad_t<0, 2, true, false>(q, s);
     else if (q.p.ks == 2) rc = launch_wgrad_t<0, 2>(q, s);
     else if (q.p.ks == 3) rc = launch_wgrad_t<0, 7>(q, s);
     else { nm_set_error("wgrad: ks=%d unsupported", q.p.ks); return NM_ERR_UNSUPPORTED; }
@@ -2222,11 +2260,20 @@ int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride
         if (!attr_set.done()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k1_kernel<6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 nm_set_error("wgrad_k1: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
             }
             attr_set.mark();
         }
+        if (in.h != dy.h) { nm_set_error("wgrad_k1: the two tensors must have the same element type (in %d, dy %d)", in.h, dy.h); return NM_ERR_UNSUPPORTED; }
+        if (in.h) {
+            if (T <= 4) hipLaunchKernelGGL((wgrad_k1_kernel<1, true>), dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
+            else if (T <= 8) hipLaunchKernelGGL((wgrad_k1_kernel<2, true>), dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
+            else hipLaunchKernelGGL((wgrad_k1_kernel<6, true>), dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
+        } else
         if (T <= 4) hipLaunchKernelGGL(wgrad_k1_kernel<1>, dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
         else if (T <= 8) hipLaunchKernelGGL(wgrad_k1_kernel<2>, dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
         else hipLaunchKernelGGL(wgrad_k1_kernel<6>, dim3(S), dim3(256), ldsb, s, p, m_tiles, n_tiles);
@@ -2258,11 +2305,11 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
     WgradPlan q = plan_wgrad(1, G, G, G, C, 4, 5, 1, true);
     float* part = dense_ws + ((q.ws_floats + 63) & ~(size_t)63);
     // coordinate channels: one frame holding the sum of dy over the frames, empty occupancy
-    hipLaunchKernelGGL(sum_frames4_kernel, dim3(grid_for(G3 * C / 4)), dim3(256), 0, s, dy.p, N, G3 * C / 4, dysum);
+    hipLaunchKernelGGL(sum_frames4_kernel, dim3(grid_for(G3 * C / 4)), dim3(256), 0, s, dy.p, N, G3 * C / 4, dysum, dy.h);
     int rc = nm_check_hip(hipMemsetAsync(zocc, 0, G3 * sizeof(float), s), "wgrad_k5occ: memset");
     if (rc) return rc;
     TensorRef in1 = in; in1.p = zocc; in1.N = 1;
-    TensorRef dy1 = dy; dy1.p = dysum; dy1.N = 1;
+    TensorRef dy1 = dy; dy1.p = dysum; dy1.N = 1; dy1.h = 0;         // (the frame sum is fp32)
     q.p.in = in1; q.p.dy = dy1; q.p.pad = 2;
     if ((rc = run_wgrad(q, dense_ws, dW, 4, 125, s))) return rc;
     // occupancy channel: matrix cores over the non-empty bricks (sparse_occ 1, grids that are whole 4x8x8 bricks), else the gather
@@ -2270,6 +2317,7 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
         static NmDeviceOnce attr_set;
         if (!attr_set.done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k5occ_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_k5occ_mfma_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(wgrad_k5occ_mfma)");
             attr_set.mark();
         }
@@ -2277,11 +2325,16 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
         // MFMA steps, no double buffering) - 512 / 1024 / 2048 workgroups: 915 / 794 / 637 us (+ 24 / 46 / 92 us of reduce)
         const int blocks = min(2048, N * chunks);                  // (the partial buffer is sized for N * chunks blocks)
         const size_t ldsb = (size_t)(8 * 12 * 12 + 8 + 256 * C) * sizeof(float);
+        if (dy.h) {
+            if (C == 32) hipLaunchKernelGGL((wgrad_k5occ_mfma_kernel<32, true>), dim3(blocks), dim3(256), ldsb, s, occ, dy.p, N, G, part);
+            else hipLaunchKernelGGL((wgrad_k5occ_mfma_kernel<64, true>), dim3(blocks), dim3(256), ldsb, s, occ, dy.p, N, G, part);
+        } else
         if (C == 32) hipLaunchKernelGGL((wgrad_k5occ_mfma_kernel<32>), dim3(blocks), dim3(256), ldsb, s, occ, dy.p, N, G, part);
         else hipLaunchKernelGGL((wgrad_k5occ_mfma_kernel<64>), dim3(blocks), dim3(256), ldsb, s, occ, dy.p, N, G, part);
         hipLaunchKernelGGL(wgrad_k5occ_sparse_reduce_kernel, dim3((125 * C + 255) / 256), dim3(256), 0, s, part, blocks, C, dW);
         return nm_check_hip(hipGetLastError(), "wgrad_k5occ mfma launch");
     }
+    if (dy.h) { nm_set_error("wgrad_k5occ: the gather form has no bfloat16 instantiation (grids that are whole 4x8x8 bricks take the MFMA form)"); return NM_ERR_UNSUPPORTED; }
     if (C == 32) hipLaunchKernelGGL((wgrad_k5occ_sparse_kernel<32>), dim3(N * chunks), dim3(256), 0, s, occ, dy.p, G, chunks, part);
     else hipLaunchKernelGGL((wgrad_k5occ_sparse_kernel<64>), dim3(N * chunks), dim3(256), 0, s, occ, dy.p, G, chunks, part);
     hipLaunchKernelGGL(wgrad_k5occ_sparse_reduce_kernel, dim3((125 * C + 255) / 256), dim3(256), 0, s, part, N * chunks, C, dW);
@@ -2294,9 +2347,10 @@ int nm_launch_gnb_partials(const float* dA, const TensorRef& y, float* part, hip
     if (y.C > 256 || y.C <= 0) { nm_set_error("gnb_partials: C=%d unsupported", y.C); return NM_ERR_ARG; }
     const int voxels = y.D * y.H * y.W;
     if (dv && !(y.C % 4 == 0 && 1024 % y.C == 0)) { nm_set_error("gnb_partials: outer-product gradient needs C %% 4 == 0 and 1024 %% C == 0"); return NM_ERR_ARG; }
-    if (y.C % 4 == 0 && 1024 % y.C == 0)
-        hipLaunchKernelGGL(gnb_partials4_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul, dv, wv);
-    else
+    if (y.C % 4 == 0 && 1024 % y.C == 0) {
+        if (y.h) hipLaunchKernelGGL(gnb_partials4_kernel<true>, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul, dv, wv);
+        else hipLaunchKernelGGL(gnb_partials4_kernel<false>, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul, dv, wv);
+    } else
         hipLaunchKernelGGL(gnb_partials_kernel, dim3(nm_gnb_blocks_per_frame(voxels), y.N), dim3(256), 0, s, dA, y, voxels, part, dA_mul);
     return nm_check_hip(hipGetLastError(), "gnb_partials launch");
 }
@@ -2345,19 +2399,21 @@ int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, 
     const unsigned bx = (unsigned)min((frame4 + 255) / 256, (size_t)max(1, 4096 / max(y.N, 1)));
     if (nm_ls().gnb_apply4 && 1024 % y.C == 0) {
         const dim3 g(bx, y.N);
-        if (dv) { if (coef) hipLaunchKernelGGL((gnb_apply4_kernel<true, true>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
-                  else hipLaunchKernelGGL((gnb_apply4_kernel<true, false>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv); }
-        else if (coef) hipLaunchKernelGGL((gnb_apply4_kernel<false, true>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
-        else hipLaunchKernelGGL((gnb_apply4_kernel<false, false>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
+#define NM_GNB_APPLY4(R, Cf) do { if (y.h) hipLaunchKernelGGL((gnb_apply4_kernel<R, Cf, true>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv); \
+                                 else hipLaunchKernelGGL((gnb_apply4_kernel<R, Cf, false>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv); } while (0)
+        if (dv) { if (coef) NM_GNB_APPLY4(true, true); else NM_GNB_APPLY4(true, false); }
+        else if (coef) NM_GNB_APPLY4(false, true);
+        else NM_GNB_APPLY4(false, false);
+#undef NM_GNB_APPLY4
         return nm_check_hip(hipGetLastError(), "gnb_apply4 launch");
     }
     hipLaunchKernelGGL(gnb_apply_kernel, dim3(bx, y.N), dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv);
     return nm_check_hip(hipGetLastError(), "gnb_apply launch");
 }
 
-int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s, const float* mul) {
+int nm_launch_absmax(const float* x, size_t n, unsigned* amax, hipStream_t s, const float* mul, int h) {
     if (n % 4) { nm_set_error("absmax: n %% 4 != 0"); return NM_ERR_ARG; }
-    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, amax, mul);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, amax, mul, h);
     return nm_check_hip(hipGetLastError(), "absmax launch");
 }
 
@@ -2366,21 +2422,21 @@ int nm_launch_make_scale(const unsigned* amax, int count, float* scale, float* s
     return nm_check_hip(hipGetLastError(), "make_scale launch");
 }
 
-int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s) {
+int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s, int h) {
     if (n % 4) { nm_set_error("scale_by: n %% 4 != 0"); return NM_ERR_ARG; }
-    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, mul);
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, n / 4, mul, h);
     return nm_check_hip(hipGetLastError(), "scale_by launch");
 }
 
-int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s, const float* mul) {
+int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s, const float* mul, int hf, int hc) {
     if (C % 4) { nm_set_error("upsample2_adjoint: C %% 4 != 0"); return NM_ERR_ARG; }
     const size_t total = (size_t)N * D * H * W * (C / 4);
     if (C % 16 == 0 && D % UA_BZ == 0 && H % UA_BY == 0 && W % UA_BX == 0 && total >= 16384) {
         const size_t blocks = (size_t)N * (D / UA_BZ) * (H / UA_BY) * (W / UA_BX);
-        hipLaunchKernelGGL(upsample2_adjoint_tile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse, mul);
+        hipLaunchKernelGGL(upsample2_adjoint_tile_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse, mul, hf, hc);
         return nm_check_hip(hipGetLastError(), "upsample2_adjoint launch");
     }
-    hipLaunchKernelGGL(upsample2_adjoint_kernel, dim3(grid_for(total)), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse, mul);
+    hipLaunchKernelGGL(upsample2_adjoint_kernel, dim3(grid_for(total)), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse, mul, hf, hc);
     return nm_check_hip(hipGetLastError(), "upsample2_adjoint launch");
 }
 
@@ -2390,13 +2446,13 @@ int nm_launch_flip_weight(const float* w, int Cout, int Cin, int csel, int ks, f
     return nm_check_hip(hipGetLastError(), "flip_weight launch");
 }
 
-int nm_launch_axpby(float* dst, const float* dst_mul, const float* src, const float* src_mul, size_t n, hipStream_t s) {
+int nm_launch_axpby(float* dst, const float* dst_mul, const float* src, const float* src_mul, size_t n, hipStream_t s, int h) {
     if (n % 4) { nm_set_error("axpby: n %% 4 != 0"); return NM_ERR_ARG; }
-    hipLaunchKernelGGL(axpby4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, dst, dst_mul, src, src_mul, n / 4);
+    hipLaunchKernelGGL(axpby4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, dst, dst_mul, src, src_mul, n / 4, h);
     return nm_check_hip(hipGetLastError(), "axpby launch");
 }
 
-int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, src, n);
+int nm_launch_axpy(float* dst, const float* src, size_t n, hipStream_t s, int h) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, src, n, h);
     return nm_check_hip(hipGetLastError(), "axpy launch");
 }

@@ -208,10 +208,10 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TensorRef x, const fl
             const f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + cq);
             const f32x4 sh4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + cq);
             const f32x4 wv = *reinterpret_cast<const f32x4*>(w14 + cq);
-            const float* pw = x.p + ((size_t)f * G3 + blockIdx.x * (size_t)256 + (threadIdx.x & ~63) + (lane >> 3)) * C + cq;
+            const size_t pw = ((size_t)f * G3 + blockIdx.x * (size_t)256 + (threadIdx.x & ~63) + (lane >> 3)) * C + cq;      // element offset (x may be bf16)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                f32x4 a = *reinterpret_cast<const f32x4*>(pw + (size_t)i * 8 * C);
+                f32x4 a = nm_ld4(x.p, pw + (size_t)i * 8 * C, x.h);
                 float part4 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part4 += lrelu(a[j] * sc[j] + sh4[j], x.slope) * wv[j];
@@ -221,9 +221,9 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TensorRef x, const fl
                 acc = ((lane & 7) == i) ? part4 : acc;
             }
         } else {
-            const float* px = x.p + ((size_t)f * G3 + v) * C;
+            const size_t px = ((size_t)f * G3 + v) * C;
             for (int c = 0; c < C; c += 4) {
-                f32x4 a = *reinterpret_cast<const f32x4*>(px + c);
+                f32x4 a = nm_ld4(x.p, px + c, x.h);
                 f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + c);
                 f32x4 sh4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + c);
                 f32x4 wv = *reinterpret_cast<const f32x4*>(w14 + c);

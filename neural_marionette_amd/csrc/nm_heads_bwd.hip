@@ -39,10 +39,10 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TensorRef x, const float*
     for (int it = 0; it < NM_TAILB_VPB / 256; ++it) {
         const size_t v = v0 + it * 256 + threadIdx.x;
         if (v >= G3) break;
-        const float* px = x.p + ((size_t)f * G3 + v) * C;
+        const size_t px = ((size_t)f * G3 + v) * C;        // element offset: x (and dA, the same shape) may be stored as bfloat16
         float acc = 0.f;
         for (int c = 0; c < C; c += 4) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(px + c);
+            f32x4 a = nm_ld4(x.p, px + c, x.h);
             const f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + c);
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + c);
 #pragma unroll
@@ -54,9 +54,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TensorRef x, const float*
         // BCELoss backward (ATen): (p - y) / max(p (1 - p), 1e-12); sigmoid: * p (1 - p); * 10; tanh: * (1 - th^2)
         const float pq = (1.0f - p) * p;
         const float dv = coef * ((p - y) / fmaxf(pq, 1e-12f)) * pq * 10.0f * (1.0f - th * th);
-        float* pd = dA + ((size_t)f * G3 + v) * C;
         for (int c = 0; c < C; c += 4) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(px + c);
+            f32x4 a = nm_ld4(x.p, px + c, x.h);
             const f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + c);
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + c);
             f32x4 o;
@@ -65,7 +64,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TensorRef x, const float*
                 mine[c + j] += dv * lrelu(fmaf(a[j], sc[j], s4[j]), x.slope);
                 o[j] = dv * w14[c + j];
             }
-            *reinterpret_cast<f32x4*>(pd + c) = o;
+            nm_st4(dA, px + c, o, x.h);
         }
         mine[C] += dv;
     }
@@ -97,12 +96,12 @@ __global__ __launch_bounds__(256) void tail_bwd32_kernel(TensorRef x, const floa
     for (int it = 0; it < NM_TAILB_VPB / 256; ++it) {
         const size_t v = v0 + it * 256 + threadIdx.x;
         if (v >= G3) break;
-        const float* px = x.p + ((size_t)f * G3 + v) * C;
+        const size_t px = ((size_t)f * G3 + v) * C;
         float a[C];
         float dot = 0.f;
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(px + c);
+            const f32x4 r = nm_ld4(x.p, px + c, x.h);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { a[c + j] = lrelu(fmaf(r[j], sc[c + j], sf[c + j]), x.slope); dot += a[c + j] * w[c + j]; }
         }
@@ -116,13 +115,12 @@ __global__ __launch_bounds__(256) void tail_bwd32_kernel(TensorRef x, const floa
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] += dv * a[c];
         } else {
-            float* pd = dA + ((size_t)f * G3 + v) * C;
 #pragma unroll
             for (int c = 0; c < C; c += 4) {
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc[c + j] += dv * a[c + j]; o[j] = dv * w[c + j]; }
-                *reinterpret_cast<f32x4*>(pd + c) = o;
+                nm_st4(dA, px + c, o, x.h);
             }
         }
         acc[C] += dv;

@@ -309,11 +309,16 @@ struct Net {
         if (!p && !rc) { nm_set_error("workspace overflow (needed > %zu bytes)", ws.cap); rc = NM_ERR_STATE; }
         return p;
     }
+    // 16-bit storage (conv mode 4): in the TRAINING forward a tensor the library allocates itself is bfloat16 when a frame of it has at
+    // least store16_min voxels (32^3: everything above the hourglass); the inference forward keeps its fp32 workspace
+    int h16(size_t voxels_per_frame) const { return keep && nm_ls().store16 && voxels_per_frame >= (size_t)nm_ls().store16_min ? 1 : 0; }
+    float* alloc_e(size_t elems, int h) { return alloc(h ? (elems + 1) / 2 : elems); }      // `elems` elements of fp32 (h = 0) or bfloat16
 };
 
 TensorRef mk(const float* p, int N, int D, int H, int W, int C, const float* sc = nullptr, const float* sh = nullptr, float slope = 1.0f) {
     TensorRef t; t.p = p; t.scale = sc; t.shift = sh; t.slope = slope; t.N = N; t.D = D; t.H = H; t.W = W; t.C = C; return t;
 }
+TensorRef with_h(TensorRef t, int h) { t.h = h; return t; }
 size_t vox(const TensorRef& t) { return (size_t)t.D * t.H * t.W; }
 
 // conv (+ optional GroupNorm statistics): returns the lazy output
@@ -325,7 +330,8 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
     g.OD = (us * in.D + 2 * pad - w.ks) / stride + 1; g.OH = (us * in.H + 2 * pad - w.ks) / stride + 1; g.OW = (us * in.W + 2 * pad - w.ks) / stride + 1;
     g.Cout = w.Cout; g.Co_pad = w.Co_pad; g.up2c = up2 ? w.wup : nullptr;
     const size_t ov = (size_t)g.OD * g.OH * g.OW;
-    float* out = out_buf ? out_buf : n.alloc((size_t)in.N * ov * w.Cout);
+    const int oh = out_buf ? 0 : n.h16(ov);                    // (a caller-named output buffer is always fp32)
+    float* out = out_buf ? out_buf : n.alloc_e((size_t)in.N * ov * w.Cout, oh);
     float *part = nullptr, *scale = nullptr, *shift = nullptr;
     const int nblk = nm_conv_blocks_per_frame(g, in.C);
     double* chsum = nullptr;
@@ -337,21 +343,22 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
     if (n.live()) {
         if (in.C != w.Cin_pad) { nm_set_error("conv_gn: input has %d channels, layer expects %d", in.C, w.Cin_pad); n.rc = NM_ERR_STATE; }
         else {
-            n.run(nm_launch_conv(in, w.wp, w.bias, out, g, part, n.s, w.Cin, w.wp16));
+            n.run(nm_launch_conv(in, w.wp, w.bias, out, g, part, n.s, w.Cin, w.wp16, oh));
             if (gn) n.run(nm_launch_gn_finalize(part, in.N, nblk, w.Cout, gn->groups, (double)ov * (w.Cout / gn->groups),
                                                 gn->gamma, gn->beta, 1e-5f, scale, shift, n.s, chsum));
-            if (gn && nm_ls().gn_diag) n.run(nm_launch_gn_direct(out, in.N, (int)ov, w.Cout, gn->groups, gn->gamma, gn->beta, 1e-5f, scale, shift, n.s, chsum));
+            if (gn && nm_ls().gn_diag && !oh) n.run(nm_launch_gn_direct(out, in.N, (int)ov, w.Cout, gn->groups, gn->gamma, gn->beta, 1e-5f, scale, shift, n.s, chsum));
         }
     }
-    TensorRef o = mk(out, in.N, g.OD, g.OH, g.OW, w.Cout, scale, shift, slope_after);
+    TensorRef o = with_h(mk(out, in.N, g.OD, g.OH, g.OW, w.Cout, scale, shift, slope_after), oh);
     if (rec) { rec->w = &w; rec->gn = gn; rec->in = in; rec->out = o; rec->fpart = part; rec->nblk = nblk; rec->chsum = chsum; rec->stride = stride; rec->pad = pad; rec->up2 = up2; }
     return o;
 }
 
 TensorRef add2(Net& n, const TensorRef& a, const TensorRef* b, float* out_buf = nullptr) {
-    float* out = out_buf ? out_buf : n.alloc((size_t)a.N * vox(a) * a.C);
-    if (n.live()) n.run(nm_launch_apply2(a, b, out, n.s));
-    return mk(out, a.N, a.D, a.H, a.W, a.C);
+    const int oh = out_buf ? 0 : n.h16(vox(a));
+    float* out = out_buf ? out_buf : n.alloc_e((size_t)a.N * vox(a) * a.C, oh);
+    if (n.live()) n.run(nm_launch_apply2(a, b, out, n.s, oh));
+    return with_h(mk(out, a.N, a.D, a.H, a.W, a.C), oh);
 }
 
 // Res3DBlock (vox_modules.py:22-47): GN(conv3(lrelu(GN(conv3 x)))) + skip(x); the trailing
@@ -368,13 +375,18 @@ TensorRef res(Net& n, const TensorRef& x, const ResW& w, float* out_buf = nullpt
         o.p2 = sk.p; o.scale2 = sk.scale; o.shift2 = sk.shift; o.slope2 = sk.slope;
         return o;
     }
-    float* out = out_buf ? out_buf : n.alloc((size_t)x.N * vox(x) * w.c2.Cout);
+    const int oh = out_buf ? 0 : n.h16(vox(x));
+    float* out = out_buf ? out_buf : n.alloc_e((size_t)x.N * vox(x) * w.c2.Cout, oh);
     const size_t m = n.ws.mark();
     TensorRef r1 = conv_gn(n, x, w.c1, &w.n1, 1, 1, LRELU, nullptr, false, rec ? &rec->c1 : nullptr);
     TensorRef r2 = conv_gn(n, r1, w.c2, &w.n2, 1, 1, 1.0f, nullptr, false, rec ? &rec->c2 : nullptr);
     TensorRef sk = w.has_skip ? conv_gn(n, x, w.cs, &w.ns, 1, 0, 1.0f, nullptr, false, rec ? &rec->cs : nullptr) : x;
     if (rec) rec->has_skip = w.has_skip;
-    TensorRef o = add2(n, r2, &sk, out);
+    TensorRef o;
+    {   // (add2 with the block's own output buffer and ITS element type)
+        if (n.live()) n.run(nm_launch_apply2(r2, &sk, out, n.s, oh));
+        o = with_h(mk(out, r2.N, r2.D, r2.H, r2.W, r2.C), oh);
+    }
     n.release(m);
     return o;
 }
@@ -387,6 +399,8 @@ TensorRef pool(Net& n, const TensorRef& x, const PoolW& w, ConvRec* rec = nullpt
 TensorRef up(Net& n, const TensorRef& x, const UpW& w, int outpad, UpRec* rec = nullptr) {
     const int OD = 2 * x.D + outpad, OH = 2 * x.H + outpad, OW = 2 * x.W + outpad;
     const size_t ov = (size_t)OD * OH * OW;
+    const int oh = n.h16(ov);
+    if (oh && !n.rc) { nm_set_error("16-bit storage: a transposed-conv block of %zu voxels per frame (the hourglass must stay below the storage threshold)", ov); n.rc = NM_ERR_UNSUPPORTED; }
     float* out = n.alloc((size_t)x.N * ov * w.Cout);
     const int nblk = nm_stats_blocks_per_frame((int)ov);
     float* part = n.alloc((size_t)x.N * nblk * w.Cout * 2);
@@ -464,7 +478,8 @@ TensorRef hourglass(Net& n, const TensorRef& x0, const HourglassW& w, int Ng, Hg
 TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w, FeatRec* rec = nullptr) {
     const int Cout = w.c0.Cout;
     const size_t G3 = (size_t)G * G * G;
-    float* out = n.alloc((size_t)N * G3 * Cout);
+    const int oh = rec ? n.h16(G3) : 0;
+    float* out = n.alloc_e((size_t)N * G3 * Cout, oh);
     const int nblk = nm_occ_blocks_per_frame(G);
     float* part = n.alloc((size_t)N * nblk * Cout * 2);
     // inference: bricks with an empty occupancy halo (most of the grid around one figure) are neither computed nor written; the pool
@@ -477,12 +492,12 @@ TensorRef first_layer(Net& n, const float* occ, int N, int G, const FeatNetW& w,
     float* scale = n.alloc((size_t)N * Cout); float* shift = n.alloc((size_t)N * Cout);
     double* chsum = (rec && nm_gn_finalize_has_chsum(Cout, w.n0.groups)) ? reinterpret_cast<double*>(n.alloc((size_t)N * Cout * 4)) : nullptr;
     if (n.live()) {
-        n.run(nm_launch_conv_k5occ(occ, N, G, w.occ_w, w.field, out, Cout, w.c0.Co_pad, part, n.s, bmap, sparse ? w.field_part : nullptr, bflags));
+        n.run(nm_launch_conv_k5occ(occ, N, G, w.occ_w, w.field, out, Cout, w.c0.Co_pad, part, n.s, bmap, sparse ? w.field_part : nullptr, bflags, oh));
         n.run(nm_launch_gn_finalize(part, N, nblk, Cout, w.n0.groups, (double)G3 * (Cout / w.n0.groups), w.n0.gamma, w.n0.beta,
                                     1e-5f, scale, shift, n.s, chsum));
-        if (nm_ls().gn_diag && !sparse) n.run(nm_launch_gn_direct(out, N, (int)G3, Cout, w.n0.groups, w.n0.gamma, w.n0.beta, 1e-5f, scale, shift, n.s, chsum));
+        if (nm_ls().gn_diag && !sparse && !oh) n.run(nm_launch_gn_direct(out, N, (int)G3, Cout, w.n0.groups, w.n0.gamma, w.n0.beta, 1e-5f, scale, shift, n.s, chsum));
     }
-    TensorRef o = mk(out, N, G, G, G, Cout, scale, shift, LRELU);
+    TensorRef o = with_h(mk(out, N, G, G, G, Cout, scale, shift, LRELU), oh);
     if (sparse) { o.alt = w.field; o.brickmap = bmap; }
     if (rec) { rec->w = &w; rec->occ = occ; rec->N = N; rec->G = G; rec->first = o; rec->fpart0 = part; rec->nblk0 = nblk; rec->chsum0 = chsum; }
     return o;
@@ -690,6 +705,8 @@ struct Bwd {
     size_t need_slot = 0, need_scratch = 0, need_sc = 0;  // sizing pass: what the walk asked for
     static size_t r64(size_t n) { return (n + 63) & ~(size_t)63; }
     float* fake() const { return reinterpret_cast<float*>((uintptr_t)256); }
+    // (element counts -> floats for a tensor of the given storage type)
+    static size_t fl(size_t elems, int h) { return h ? (elems + 1) / 2 : elems; }
     float* dy_alloc(size_t n) {
         last_slot = -1;
         if (!async_w) return alloc(n);
@@ -728,7 +745,8 @@ struct Bwd {
 };
 
 size_t numel_of(const TensorRef& t) { return (size_t)t.N * t.D * t.H * t.W * t.C; }
-TensorRef plain(const float* p, const TensorRef& like) { return mk(p, like.N, like.D, like.H, like.W, like.C); }
+// a tensor of `like`'s shape AND storage type without a pending affine (gradients are stored like the tensor they belong to)
+TensorRef plain(const float* p, const TensorRef& like) { return with_h(mk(p, like.N, like.D, like.H, like.W, like.C), like.h); }
 
 // GroupNorm(+LeakyReLU) backward of a lazy tensor: returns dy (gradient of the raw conv output) and writes the gradients of
 // gamma / beta and of the bias of the producing conv
@@ -742,7 +760,7 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
     float* dy = nullptr;
     b.last_slot = -1;
     if (gn) {
-        dy = b.dy_alloc(numel_of(out));
+        dy = b.dy_alloc(Bwd::fl(numel_of(out), out.h));
         const size_t m = b.ws.mark();
         float* bpart = b.alloc((size_t)N * nbb * C * 2);
         float* coef = b.alloc((size_t)N * C * 4);
@@ -763,10 +781,10 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
     if (dv) { nm_set_error("detector_backward: outer-product gradient into a layer without GroupNorm"); b.rc = NM_ERR_STATE; return nullptr; }
     const float* res = dA;
     if (out.slope != 1.0f || dA_mul) {
-        dy = b.alloc(numel_of(out));
+        dy = b.alloc(Bwd::fl(numel_of(out), out.h));
         if (b.live()) b.run(nm_launch_gnb_apply(dA, out, nullptr, dy, b.s, amax, dA_mul));
         res = dy;
-    } else if (amax && b.live()) b.run(nm_launch_absmax(dA, numel_of(out), amax, b.s));
+    } else if (amax && b.live()) b.run(nm_launch_absmax(dA, numel_of(out), amax, b.s, nullptr, out.h));
     const size_t m = b.ws.mark();
     float* bpart = b.alloc((size_t)N * nbb * C * 2);
     float* gbias = b.grad(bias_key, C);
@@ -819,7 +837,9 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
                 const float* dA_dv = nullptr, const float* dA_wv = nullptr) {
     const ConvW& w = *r.w;
     const TensorRef& in = r.in;
-    float* din = need_din ? b.alloc((size_t)in.N * in.D * in.H * in.W * w.csel) : nullptr;
+    // storage types: the input's gradient like the input; the fine-grid tensors of a fused-upsample layer like its output
+    const int h_in = in.h, h_fine = r.out.h;
+    float* din = need_din ? b.alloc(Bwd::fl((size_t)in.N * in.D * in.H * in.W * w.csel, h_in)) : nullptr;
     float* sc2_keep = out_mul ? b.alloc(64) : nullptr;           // outlives this call (allocated below the mark)
     if (out_mul) *out_mul = nullptr;
     const size_t m = b.ws.mark();
@@ -831,7 +851,7 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
     const TensorRef dyT = plain(dy, r.out);
     const TensorRef dyS = ds.apply(b, dyT);
     // weight gradient; on the third stream when everything it reads outlives this call (Bwd::async_w)
-    const size_t up_floats = r.up2 ? Bwd::r64(numel_of(in) * 8) : 0;
+    const size_t up_floats = r.up2 ? Bwd::r64(Bwd::fl(numel_of(in) * 8, h_fine)) : 0;
     const size_t wg_floats = nm_wgrad_ws_floats(in.N, r.out.D, r.out.H, r.out.W, w.Cout, in.C, w.ks, r.stride);
     bool side = b.async_w && slot >= 0 && (!ds.amax || ds.pool);
     if (side && b.ws.dry) b.need_scratch = std::max(b.need_scratch, up_floats + Bwd::r64(wg_floats));
@@ -846,8 +866,8 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
             b.run(nm_check_hip(hipStreamWaitEvent(s3, b.c->ev_dy, 0), "backward: weight-gradient stream wait"));
             TensorRef a = in;
             if (r.up2) {
-                b.run(nm_launch_upsample2(in, b.sscratch, s3));
-                a = mk(b.sscratch, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C);
+                b.run(nm_launch_upsample2(in, b.sscratch, s3, h_fine));
+                a = with_h(mk(b.sscratch, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C), h_fine);
             }
             b.run(nm_launch_wgrad(a, dyS, w.ks, r.stride, r.pad, w.Cin, b.sscratch + up_floats, gw, s3, ds.inv(), split ? 1 : 0));
             b.run(nm_check_hip(hipEventRecord(b.c->ev_w[slot], s3), "backward: weight-gradient done event"));
@@ -860,9 +880,9 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
         const size_t m2 = b.ws.mark();
         TensorRef a = in;
         if (r.up2) {
-            float* upb = b.alloc(numel_of(in) * 8);
-            if (b.live()) b.run(nm_launch_upsample2(in, upb, b.s));
-            a = mk(upb, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C);
+            float* upb = b.alloc(Bwd::fl(numel_of(in) * 8, h_fine));
+            if (b.live()) b.run(nm_launch_upsample2(in, upb, b.s, h_fine));
+            a = with_h(mk(upb, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C), h_fine);
         }
         float* wsb = b.alloc(wg_floats);
         float* gw = b.grad(w.key + ".weight", (int64_t)w.Cout * w.Cin * w.ks * w.ks * w.ks);
@@ -874,19 +894,19 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
             const int us = r.up2 ? 2 : 1;
             ConvGeom g; g.ks = w.ks; g.stride = 1; g.pad = w.ks - 1 - r.pad; g.OD = us * in.D; g.OH = us * in.H; g.OW = us * in.W;
             g.Cout = w.csel; g.Co_pad = w.cd_pad;
-            float* dfine = r.up2 ? b.alloc((size_t)in.N * g.OD * g.OH * g.OW * w.csel) : din;
+            float* dfine = r.up2 ? b.alloc(Bwd::fl((size_t)in.N * g.OD * g.OH * g.OW * w.csel, h_fine)) : din;
             if (b.live()) {
                 if (!w.wd) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
             }
             if (b.live()) {
-                b.run(nm_launch_conv(dyS, w.wd, b.zb, dfine, g, nullptr, b.s, w.Cout, w.wd16));
-                if (r.up2) b.run(nm_launch_upsample2_adjoint(dfine, in.N, in.D, in.H, in.W, w.csel, din, b.s, ds.inv()));
-                else if (ds.inv() && !out_mul) b.run(nm_launch_scale_by(din, (size_t)in.N * in.D * in.H * in.W * w.csel, ds.inv(), b.s));
+                b.run(nm_launch_conv(dyS, w.wd, b.zb, dfine, g, nullptr, b.s, w.Cout, w.wd16, r.up2 ? h_fine : h_in));
+                if (r.up2) b.run(nm_launch_upsample2_adjoint(dfine, in.N, in.D, in.H, in.W, w.csel, din, b.s, ds.inv(), h_fine, h_in));
+                else if (ds.inv() && !out_mul) b.run(nm_launch_scale_by(din, (size_t)in.N * in.D * in.H * in.W * w.csel, ds.inv(), b.s, h_in));
             }
             if (out_mul && !r.up2) *out_mul = ds.inv();
         } else if (b.live()) {      // k2 s2 pool conv: the transposed conv
             if (!w.wt) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
-            else b.run(nm_launch_convT2(dyT, w.wt, b.zb, din, w.Cin, in.D, in.H, in.W, b.s));
+            else b.run(nm_launch_convT2(dyT, w.wt, b.zb, din, w.Cin, in.D, in.H, in.W, b.s, h_in));
         }
     }
     if (side && !side_first) side_wgrad();
@@ -904,14 +924,16 @@ float* res_bwd(Bwd& b, const ResRec& r, const float* dOut) {
     const float *mx = nullptr, *ms = nullptr;
     float* dx = conv_bwd(b, r.c1, d1, true, m1, &mx);
     const size_t n = numel_of(r.c1.in);
+    const int hx = r.c1.in.h;              // storage type of the block input's gradient (dOut of a block without skip conv has the same shape, hence the same type)
     const float* other = dOut;
     if (r.has_skip) other = conv_bwd(b, r.cs, dOut, true, nullptr, &ms);
     if (b.live()) {
-        if ((mx || ms) && n % 4 == 0) b.run(nm_launch_axpby(dx, mx, other, ms, n, b.s));
+        if (!r.has_skip && r.c2.out.h != hx) { nm_set_error("res_bwd: block input and output gradients differ in storage type"); b.rc = NM_ERR_STATE; return dx; }
+        if ((mx || ms) && n % 4 == 0) b.run(nm_launch_axpby(dx, mx, other, ms, n, b.s, hx));
         else {
-            if (mx) b.run(nm_launch_scale_by(dx, n, mx, b.s));
-            if (ms) b.run(nm_launch_scale_by(const_cast<float*>(other), n, ms, b.s));
-            b.run(nm_launch_axpy(dx, other, n, b.s));
+            if (mx) b.run(nm_launch_scale_by(dx, n, mx, b.s, hx));
+            if (ms) b.run(nm_launch_scale_by(const_cast<float*>(other), n, ms, b.s, hx));
+            b.run(nm_launch_axpy(dx, other, n, b.s, hx));
         }
     }
     return dx;
@@ -1014,7 +1036,7 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         // the gradient of the decoder's last activated tensor is d14's weight row times one factor per voxel: with 32 channels and a
         // GroupNorm behind the layer only the factors are stored (67 MB for 2.1 GB) and its GroupNorm backward forms the products
         const bool rank1 = C == 32 && t.d11.gn != nullptr && nm_ls().tail_rank1;
-        float* dA = rank1 ? nullptr : b.alloc((size_t)F * G3 * C);
+        float* dA = rank1 ? nullptr : b.alloc(Bwd::fl((size_t)F * G3 * C, x.h));
         float* dvox = rank1 ? b.alloc((size_t)F * G3) : nullptr;
         float* part = b.alloc((size_t)F * tb * (C + 1));
         float* g14 = b.alloc(C + 1);
@@ -1371,6 +1393,15 @@ int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T,
     if (!c->training) { nm_set_error("detector_forward_train: call nm_ctx_set_training(ctx, 1) and nm_ctx_set_weights first"); return NM_ERR_STATE; }
     if (!vox || !keypoints || !heatmaps || !first_feature || !recon || !losses11 || B <= 0 || T <= 0) {
         nm_set_error("detector_forward_train: null / non-positive argument"); return NM_ERR_ARG;
+    }
+    if (nm_ls().store16) {
+        // 16-bit storage keeps the hourglass (and everything the heads, keypoints and VRNN read) in fp32: the g = G / 4 grid must stay
+        // below the storage threshold (G <= 124 at the default 32^3)
+        const size_t g = (size_t)c->cfg.grid_size / 4;
+        if (g * g * g >= (size_t)nm_ls().store16_min) {
+            nm_set_error("detector_forward_train: conv mode 4 (bfloat16 storage) needs (grid_size / 4)^3 < %d voxels", nm_ls().store16_min);
+            return NM_ERR_UNSUPPORTED;
+        }
     }
     if (!c->tape) c->tape = new TrainTape();
     TrainTape& t = *c->tape;

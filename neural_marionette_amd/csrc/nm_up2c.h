@@ -13,4 +13,4 @@ int nm_launch_up2c_compose(const float* w_oidhw, int Cout, int Cin, int Co_pad, 
 int nm_up2c_blocks_per_frame(int ID, int IH, int IW);
 // in: the coarse lazy tensor (N, ID, IH, IW, Cin); out: (N, 2ID, 2IH, 2IW, Cout) raw conv result; part: [N][blocks][Cout][2] or null
 int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bias, float* out, int Cout, int Co_pad,
-                        float* part, hipStream_t s);
+                        float* part, hipStream_t s, int out_h = 0 /* 1: bfloat16 output (then the input must be bfloat16 too: in.h) */);

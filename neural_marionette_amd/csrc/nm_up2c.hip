@@ -90,6 +90,22 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, const f32x4& sc, const f32x4& sh,
     return v;
 }
 
+// 16-bit storage (conv mode 4): eight bfloat16 channels arrive as ONE 16-byte load (kept raw in an f32x4) and are widened where
+// they are used; IH = false: the two fp32 quads as before
+template <bool IH>
+__device__ __forceinline__ void ld8_raw(const float* base, size_t e, f32x4& a, f32x4& b) {
+    if constexpr (IH) a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(base) + e);
+    else { a = *reinterpret_cast<const f32x4*>(base + e); b = *reinterpret_cast<const f32x4*>(base + e + 4); }
+}
+template <bool IH>
+__device__ __forceinline__ void widen8(f32x4& a, f32x4& b) {
+    if constexpr (IH) {
+        const unsigned u0 = __builtin_bit_cast(unsigned, a[0]), u1 = __builtin_bit_cast(unsigned, a[1]), u2 = __builtin_bit_cast(unsigned, a[2]), u3 = __builtin_bit_cast(unsigned, a[3]);
+        a = f32x4{nm_bf_lo(u0), nm_bf_hi(u0), nm_bf_lo(u1), nm_bf_hi(u1)};
+        b = f32x4{nm_bf_lo(u2), nm_bf_hi(u2), nm_bf_lo(u3), nm_bf_hi(u3)};
+    }
+}
+
 // ---- composite weight sets -------------------------------------------------------------------------------------------------
 // set e: e < 8: S = {} (main), parity p = e (pz = e>>2, py = (e>>1)&1, px = e&1); else S = 1 + (e-8)/8 as a bit mask
 // (x = 1, y = 2, z = 4) of the axes whose tap leaves the volume, p = (e-8) % 8.  A set holds 3^(free axes) coarse taps (z, y, x
@@ -170,8 +186,10 @@ __device__ __forceinline__ constexpr int tap_off(int t) { return (t / 9) * ZP + 
 // one workgroup per CU has nothing else to run meanwhile).  One workgroup barrier per step.
 struct StepPos { int n, br, nh, cg, cz0, cy0, cx0; };
 
-template <bool SINGLE>
+// IO: bit 0 = bfloat16 input, bit 1 = bfloat16 output (16-bit storage; the shell kernels then read-modify-write bfloat16 values)
+template <bool SINGLE, int IO = 0>
 __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
+    constexpr bool IH16 = (IO & 1) != 0, OH16 = (IO & 2) != 0;
     extern __shared__ f32x4 lds_raw[];
     half8* tile = reinterpret_cast<half8*>(lds_raw);               // [buffer][chunk*4 + hl*2 + h][HVP] x 16 B, slot = hz*ZP + hy*HX + hx
 
@@ -228,8 +246,7 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
         if (v < NV) {
             const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
             const int gz = min(max(s.cz0 - 1 + hz, 0), p.ID - 1), gy = min(max(s.cy0 - 1 + hy, 0), p.IH - 1), gx = min(max(s.cx0 - 1 + hx, 0), p.IW - 1);
-            const float* src = p.in + ((((size_t)s.n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + s.cg * CG + s_oct * 8;
-            pr_a = *reinterpret_cast<const f32x4*>(src); pr_b = *reinterpret_cast<const f32x4*>(src + 4);
+            ld8_raw<IH16>(p.in, ((((size_t)s.n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + s.cg * CG + s_oct * 8, pr_a, pr_b);
         }
     };
     auto commit = [&](half8* buf, int k) {
@@ -238,6 +255,7 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
         if (v < NV) {
             const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
             half8 hi, lo;
+            widen8<IH16>(pr_a, pr_b);
             split8(act4(pr_a, sca, sha, affine, p.in_slope), act4(pr_b, scb, shb, affine, p.in_slope), hi, lo);
             const int slot = hz * ZP + hy * HX + hx;
             buf[s_plane * HVP + slot] = hi;
@@ -336,8 +354,33 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
             const bool border_brick = cs.cz0 == 0 || cs.cz0 + BZ == p.ID || cs.cy0 == 0 || cs.cy0 + BY == p.IH || cs.cx0 == 0 || cs.cx0 + BX == p.IW;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float* base = p.out + ((((size_t)cs.n * OD + 2 * cs.cz0 + pz) * OH + 2 * (cs.cy0 + 2 * j) + py) * OW + 2 * cs.cx0 + px) * sX + co;
-                if (!border_brick) {
+                float* base = nm_eptr(p.out, ((((size_t)cs.n * OD + 2 * cs.cz0 + pz) * OH + 2 * (cs.cy0 + 2 * j) + py) * OW + 2 * cs.cx0 + px) * sX + co, OH16);
+                if constexpr (OH16) {
+                    // bfloat16: the lanes of neighbouring channels exchange values so that each stores ONE packed dword per register pair
+                    // (even lanes the channel pair of row r, odd lanes of row r + 1 - one x step further)
+                    const bool odd = (l31 & 1) != 0;
+                    unsigned short* bq = reinterpret_cast<unsigned short*>(base) - (odd ? 1 : 0);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int x = 4 * ((r >> 2) & 1) + (r & 3), zb = (r >> 3) & 1, yb = (0x96 >> (h + 2 * (r >> 2))) & 1;
+                        const float v0 = __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r]) + bv;
+                        const float v1 = __builtin_fmaf(accl[j][r + 1], 1.0f / UP2C_SPLIT_SCALE, acc[j][r + 1]) + bv;
+                        const float send = odd ? v0 : v1;
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));
+                        const unsigned pk = odd ? nm_pk_bf16(recv, v1) : nm_pk_bf16(v0, recv);
+                        *reinterpret_cast<unsigned*>(bq + (size_t)(2 * zb) * sZ + (size_t)(2 * yb) * sY + (size_t)(2 * (x + (odd ? 1 : 0))) * sX) = pk;
+                        float m0 = v0, m1 = v1;
+                        if (border_brick) {
+                            const int oz = 2 * (cs.cz0 + zb) + pz, oy = 2 * (cs.cy0 + 2 * j + yb) + py, ox0 = 2 * (cs.cx0 + x) + px, ox1 = ox0 + 2;
+                            const bool zy = oz == 0 || oz == OD - 1 || oy == 0 || oy == OH - 1;
+                            if (zy || ox0 == 0 || ox0 == OW - 1) m0 = 0.f;
+                            if (zy || ox1 == 0 || ox1 == OW - 1) m1 = 0.f;
+                        }
+                        s += m0; ss = __builtin_fmaf(m0, m0, ss);
+                        s += m1; ss = __builtin_fmaf(m1, m1, ss);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (!border_brick) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         // register r of lane half h is row (r & 3) + 4 h + 8 (r >> 2) of the tile (see arow)
@@ -385,8 +428,9 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
 constexpr int FP = 36;                                // slots per staged line (34 used)
 constexpr int FPV = 3 * FP + 1;                       // slots per plane
 
-template <bool SINGLE>
+template <bool SINGLE, int IO = 0>
 __global__ __launch_bounds__(256, 4) void conv_up2c_face_kernel(Up2cParams p, int TY, int TX) {
+    constexpr bool IH16 = (IO & 1) != 0, OH16 = (IO & 2) != 0;
     extern __shared__ f32x4 lds_raw[];
     half8* tile = reinterpret_cast<half8*>(lds_raw);               // [chunk*4 + hl*2 + h][FPV], slot = across * FP + along
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -418,8 +462,9 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_face_kernel(Up2cParams p, in
         const int oct = i % noct, v = i / noct, s = v % 34, a = v / 34;
         const int ca = min(max(f + a - 1, 0), AC - 1), cl = min(max(tl * 32 - 1 + s, 0), LA - 1);
         const int gz = type == 2 ? fb : ca, gy = type == 0 ? cl : (type == 1 ? fb : ca), gx = type == 0 ? fb : cl;
-        const float* src = p.in + ((((size_t)n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + oct * 8;
-        f32x4 va = *reinterpret_cast<const f32x4*>(src), vb = *reinterpret_cast<const f32x4*>(src + 4);
+        f32x4 va, vb;
+        ld8_raw<IH16>(p.in, ((((size_t)n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + oct * 8, va, vb);
+        widen8<IH16>(va, vb);
         half8 hi, lo;
         split8(act4(va, sca, sha, affine, p.in_slope), act4(vb, scb, shb, affine, p.in_slope), hi, lo);
         const int pl = (oct >> 1) * 4 + (oct & 1);
@@ -472,9 +517,9 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_face_kernel(Up2cParams p, in
             if (row_owned(rho)) {
                 const int u = tl * 32 + rho;
                 const int rz = type == 2 ? fb : f, ry = type == 0 ? u : (type == 1 ? fb : f), rx = type == 0 ? fb : u;
-                float* dst = p.out + ((((size_t)n * OD + 2 * rz + pz) * OH + 2 * ry + py) * OW + 2 * rx + px) * p.Cout + co;
-                const float v = *dst + (acc[r] + accl[r] * (1.0f / UP2C_SPLIT_SCALE));
-                *dst = v;
+                const size_t dst = ((((size_t)n * OD + 2 * rz + pz) * OH + 2 * ry + py) * OW + 2 * rx + px) * p.Cout + co;
+                const float v = nm_ld1<OH16>(p.out, dst) + (acc[r] + accl[r] * (1.0f / UP2C_SPLIT_SCALE));
+                nm_st1<OH16>(p.out, dst, v);
                 s += v; ss += v * v;
             }
         }
@@ -488,8 +533,9 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_face_kernel(Up2cParams p, in
 // conv_up2c_edge_kernel: one wave per item = 32 cells of one parity class on one of the twelve edges (the eight corners belong to
 // the edges along z).  For every non-empty subset S of a row's border axes the signed set (S, parity) is applied with the rows
 // outside the subset's cells zeroed; operands straight from global memory (a few thousand items in all).
-template <bool SINGLE>
+template <bool SINGLE, int IO = 0>
 __global__ __launch_bounds__(256, 4) void conv_up2c_edge_kernel(Up2cParams p, int TZ, int TY, int TX, int slot0) {
+    constexpr bool IH16 = (IO & 1) != 0, OH16 = (IO & 2) != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int nXY = 8 * TZ, nXZ = 8 * TY, nYZ = 8 * TX, per_frame = nXY + nXZ + nYZ;
@@ -547,14 +593,14 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_edge_kernel(Up2cParams p, in
 #pragma unroll
                         for (int a = 0; a < 3; ++a) if (!((S >> a) & 1)) { d[a] = qd % 3 - 1; qd /= 3; }
                         const int gz = min(max(iz + d[2], 0), p.ID - 1), gy = min(max(iy + d[1], 0), p.IH - 1), gx = min(max(ix + d[0], 0), p.IW - 1);
-                        const float* src = p.in + ((((size_t)n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + cbase;
-                        va[u] = *reinterpret_cast<const f32x4*>(src); vb[u] = *reinterpret_cast<const f32x4*>(src + 4);
+                        ld8_raw<IH16>(p.in, ((((size_t)n * p.ID + gz) * p.IH + gy) * p.IW + gx) * p.Cin + cbase, va[u], vb[u]);
                         const half8* wt = wq + ((size_t)c * ntaps + t) * kstride;
                         wh[u] = wt[0]; wl[u] = wt[2 * plane];
                     }
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
                         if (t0 + u < ntaps) {
+                            widen8<IH16>(va[u], vb[u]);
                             f32x4 xa = act4(va[u], sca, sha, affine, p.in_slope), xb2 = act4(vb[u], scb, shb, affine, p.in_slope);
                             if (!rowon) { xa = f32x4{0.f, 0.f, 0.f, 0.f}; xb2 = xa; }
                             half8 hi, lo;
@@ -576,9 +622,9 @@ __global__ __launch_bounds__(256, 4) void conv_up2c_edge_kernel(Up2cParams p, in
             int rz, ry, rx, rb; bool ro;
             cell(rho, rz, ry, rx, ro, rb);
             if (ro) {
-                float* dst = p.out + ((((size_t)n * OD + 2 * rz + pz) * OH + 2 * ry + py) * OW + 2 * rx + px) * p.Cout + co;
-                const float v = *dst + (acc[r] + accl[r] * (1.0f / UP2C_SPLIT_SCALE));
-                *dst = v;
+                const size_t dst = ((((size_t)n * OD + 2 * rz + pz) * OH + 2 * ry + py) * OW + 2 * rx + px) * p.Cout + co;
+                const float v = nm_ld1<OH16>(p.out, dst) + (acc[r] + accl[r] * (1.0f / UP2C_SPLIT_SCALE));
+                nm_st1<OH16>(p.out, dst, v);
                 s += v; ss += v * v;
             }
         }
@@ -617,17 +663,22 @@ int nm_up2c_blocks_per_frame(int ID, int IH, int IW) {
 }
 
 int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bias, float* out, int Cout, int Co_pad, float* part,
-                        hipStream_t s) {
+                        hipStream_t s, int out_h) {
     if (!nm_up2c_eligible(in.D, in.H, in.W, in.C, Cout, 3, 1, 1) || !packed) { nm_set_error("conv_up2c: shape not eligible"); return NM_ERR_ARG; }
     if ((in.scale == nullptr) != (in.shift == nullptr)) { nm_set_error("conv_up2c: scale/shift must come together"); return NM_ERR_ARG; }
     static NmDeviceOnce attr_set;
     if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_up2c)");
         attr_set.mark();
     }
     const bool single = nm_conv_single() != 0;
+    const bool io16 = in.h || out_h;
+    if (io16 && !(in.h && out_h && single)) {
+        nm_set_error("conv_up2c: 16-bit storage needs conv mode 4 and bfloat16 input AND output (got %d / %d)", in.h, out_h); return NM_ERR_UNSUPPORTED;
+    }
     if (g_cus == 0) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nm_check_hip(hipErrorUnknown, "device query");
@@ -642,7 +693,8 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     p.nblk = nm_up2c_blocks_per_frame(in.D, in.H, in.W);
     p.diag = nm_ls().up2c_diag;
     const int bricks = p.nbz * p.nby * p.nbx, total = p.N * bricks;
-    if (single) hipLaunchKernelGGL(conv_up2c_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    if (io16) hipLaunchKernelGGL((conv_up2c_kernel<true, 3>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    else if (single) hipLaunchKernelGGL(conv_up2c_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else hipLaunchKernelGGL(conv_up2c_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     int rc = nm_check_hip(hipGetLastError(), "conv_up2c launch");
     if (rc) return rc;
@@ -650,12 +702,14 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     int TZ, TY, TX; shell_tiles(in.D, in.H, in.W, TZ, TY, TX);
     const int fg = face_groups(in.D, in.H, in.W), ei = edge_items(in.D, in.H, in.W);
     const size_t face_lds = (size_t)(in.C / 16 * 4) * FPV * 16;
-    if (single) hipLaunchKernelGGL(conv_up2c_face_kernel<true>, dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
+    if (io16) hipLaunchKernelGGL((conv_up2c_face_kernel<true, 3>), dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
+    else if (single) hipLaunchKernelGGL(conv_up2c_face_kernel<true>, dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
     else hipLaunchKernelGGL(conv_up2c_face_kernel<false>, dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
     rc = nm_check_hip(hipGetLastError(), "conv_up2c_face launch");
     if (rc) return rc;
     const long long items = (long long)p.N * ei;
-    if (single) hipLaunchKernelGGL(conv_up2c_edge_kernel<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
+    if (io16) hipLaunchKernelGGL((conv_up2c_edge_kernel<true, 3>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
+    else if (single) hipLaunchKernelGGL(conv_up2c_edge_kernel<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
     else hipLaunchKernelGGL(conv_up2c_edge_kernel<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
     return nm_check_hip(hipGetLastError(), "conv_up2c_edge launch");
 }

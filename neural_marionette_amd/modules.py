@@ -38,9 +38,9 @@ from .spec import DETECTOR_LOSS_KEYS, FEAT_DIM, HotPathOptions, param_spec
 Priority = namedtuple("Priority", ["values", "indices"])   # what torch.topk returns in the reference
 
 
-CONV_MODES = {"fp32": 0, "0": 0, "exact": 0, "split16": 1, "1": 1, "f16": 3, "3": 3, "auto": 1}
+CONV_MODES = {"fp32": 0, "0": 0, "exact": 0, "split16": 1, "1": 1, "f16": 3, "3": 3, "bf16": 4, "4": 4, "auto": 1}
 NM_ERR_RANGE = -5
-CONV_MODE_NAMES = ("split16", "fp32", "f16", "auto")
+CONV_MODE_NAMES = ("split16", "fp32", "f16", "bf16", "auto")
 
 
 class Engine:
@@ -590,7 +590,10 @@ class NeuralMarionette(nn.Module):
         """'split16' (default): convs with Cin % 16 == 0 on the fp16 matrix cores, operands split hi/lo, fp32
         accumulate (fp32-equivalent accuracy); 'fp32': exact fp32 MFMA everywhere; 'f16': the split16 kernels with the
         hi x hi product only - operands rounded to fp16, fp32 accumulation and storage (autocast-class accuracy, the
-        reduced-precision training mode; outside the 1e-4 parity contract); 'auto': split16, but the first conv-running call after
+        reduced-precision training mode; outside the 1e-4 parity contract); 'bf16': 'f16' arithmetic with bfloat16 STORAGE of the
+        training path's activations and activation gradients (BASELINE config 3 as named: every tensor of >= 32^3 voxels per frame
+        the training forward keeps, fp32 master weights / GroupNorm statistics / accumulators / Adam; the inference forward is
+        'f16'); 'auto': split16, but the first conv-running call after
         every weight change is range-checked synchronously and re-run on the exact fp32 path if an activation left the fp16 range
         (fp32 then stays selected until the weights change).  In every mode the library's deferred range guard makes a LATER call
         raise NmError when an earlier one produced non-finite values (no per-call host synchronisation)."""
