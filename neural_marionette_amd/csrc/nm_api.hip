@@ -69,7 +69,7 @@ int nm_ctx_reserve(nm_ctx* ctx, size_t bytes) {
     int rc = nm_check_hip(hipStreamSynchronize(ctx->stream), "reserve: stream sync");
     if (rc) return rc;
     if (ctx->ws.base) { (void)hipFree(ctx->ws.base); ctx->ws.base = nullptr; ctx->ws.cap = 0; }
-    size_t want = bytes + bytes / 16 + (1 << 20);
+    size_t want = bytes + (bytes / 16 < ((size_t)64 << 20) ? bytes / 16 : ((size_t)64 << 20)) + (1 << 20);      // growth slack, at most 64 MB (1/16 of a 10 GB training arena was 0.66 GB)
     rc = nm_check_hip(hipMalloc(reinterpret_cast<void**>(&ctx->ws.base), want), "reserve: hipMalloc workspace");
     if (rc) return rc;
     ctx->ws.cap = want;

@@ -45,6 +45,9 @@ typedef float nm_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned nm_pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(nm_f32x2{a, b}, nm_bf16x2));
 }
+// bits of a float passed BY VALUE: __builtin_bit_cast applied directly to an element of an ext_vector reached through a reference
+// (`a[1]` of an `f32x4&`) was compiled as a read of element 0 by hipcc 7.0 - always go through this
+__device__ __forceinline__ unsigned nm_fbits(float f) { return __builtin_bit_cast(unsigned, f); }
 __device__ __forceinline__ float nm_bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float nm_bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 __device__ __forceinline__ f32x4 nm_bf4_to_f32(nm_u32x2 u) { return f32x4{nm_bf_lo(u[0]), nm_bf_hi(u[0]), nm_bf_lo(u[1]), nm_bf_hi(u[1])}; }

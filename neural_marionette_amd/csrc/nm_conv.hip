@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
             if constexpr (IN2) split8(act2(b.ra[mt], a.sca, a.sha, b.qa[mt], a.s2a, a.h2a), act2(b.rb[mt], a.scb, a.shb, b.qb[mt], a.s2b, a.h2b), ah, al);
             else if constexpr (IH) {
                 const f32x4 q = b.ra[mt];
-                const unsigned u0 = __builtin_bit_cast(unsigned, q[0]), u1 = __builtin_bit_cast(unsigned, q[1]), u2 = __builtin_bit_cast(unsigned, q[2]), u3 = __builtin_bit_cast(unsigned, q[3]);
+                const unsigned u0 = nm_fbits(q[0]), u1 = nm_fbits(q[1]), u2 = nm_fbits(q[2]), u3 = nm_fbits(q[3]);
                 split8(act1(f32x4{nm_bf_lo(u0), nm_bf_hi(u0), nm_bf_lo(u1), nm_bf_hi(u1)}, a.sca, a.sha),
                        act1(f32x4{nm_bf_lo(u2), nm_bf_hi(u2), nm_bf_lo(u3), nm_bf_hi(u3)}, a.scb, a.shb), ah, al);
             } else split8(act1(b.ra[mt], a.sca, a.sha), act1(b.rb[mt], a.scb, a.shb), ah, al);

@@ -1122,7 +1122,7 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
                              char* hi, char* lo) __attribute__((always_inline)) {
         unsigned h[4], l[4];
         if constexpr (H16) {
-            const unsigned u0 = __builtin_bit_cast(unsigned, a[0]), u1 = __builtin_bit_cast(unsigned, a[1]), u2 = __builtin_bit_cast(unsigned, a[2]), u3 = __builtin_bit_cast(unsigned, a[3]);
+            const unsigned u0 = nm_fbits(a[0]), u1 = nm_fbits(a[1]), u2 = nm_fbits(a[2]), u3 = nm_fbits(a[3]);
             a = f32x4{nm_bf_lo(u0), nm_bf_hi(u0), nm_bf_lo(u1), nm_bf_hi(u1)};
             b = f32x4{nm_bf_lo(u2), nm_bf_hi(u2), nm_bf_lo(u3), nm_bf_hi(u3)};
         }
@@ -1274,7 +1274,7 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
                                 csa = *reinterpret_cast<const f32x4*>(t + 4); cha = *reinterpret_cast<const f32x4*>(t + 36);
                             }
                             if constexpr (H16) {        // channel pair j of the raw item: dword j
-                                const unsigned u = __builtin_bit_cast(unsigned, ca[j]);
+                                const unsigned u = nm_fbits(ca[j]);
                                 t0 = fmaf(nm_bf_lo(u), csa[e], cha[e]); t1 = fmaf(nm_bf_hi(u), csa[e + 1], cha[e + 1]);
                             } else if constexpr (j < 2) { t0 = fmaf(ca[e], csa[e], cha[e]); t1 = fmaf(ca[e + 1], csa[e + 1], cha[e + 1]); }
                             else { t0 = fmaf(cb_[e], csa[e], cha[e]); t1 = fmaf(cb_[e + 1], csa[e + 1], cha[e + 1]); }

@@ -1379,7 +1379,7 @@ static int reserve_wside(nm_ctx* c) {
     int rc = nm_check_hip(hipDeviceSynchronize(), "reserve: device sync");
     if (rc) return rc;
     if (c->wside) { (void)hipFree(c->wside); c->wside = nullptr; c->wside_floats = 0; }
-    const size_t got = want + want / 16 + 4096;
+    const size_t got = want + (want / 16 < ((size_t)16 << 20) ? want / 16 : ((size_t)16 << 20)) + 4096;      // (floats: at most 64 MB of growth slack)
     rc = nm_check_hip(hipMalloc(reinterpret_cast<void**>(&c->wside), got * sizeof(float)), "reserve: hipMalloc weight-gradient side block");
     if (rc) return rc;
     c->wside_floats = got;

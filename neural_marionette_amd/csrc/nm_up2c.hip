@@ -100,7 +100,7 @@ __device__ __forceinline__ void ld8_raw(const float* base, size_t e, f32x4& a, f
 template <bool IH>
 __device__ __forceinline__ void widen8(f32x4& a, f32x4& b) {
     if constexpr (IH) {
-        const unsigned u0 = __builtin_bit_cast(unsigned, a[0]), u1 = __builtin_bit_cast(unsigned, a[1]), u2 = __builtin_bit_cast(unsigned, a[2]), u3 = __builtin_bit_cast(unsigned, a[3]);
+        const unsigned u0 = nm_fbits(a[0]), u1 = nm_fbits(a[1]), u2 = nm_fbits(a[2]), u3 = nm_fbits(a[3]);
         a = f32x4{nm_bf_lo(u0), nm_bf_hi(u0), nm_bf_lo(u1), nm_bf_hi(u1)};
         b = f32x4{nm_bf_lo(u2), nm_bf_hi(u2), nm_bf_lo(u3), nm_bf_hi(u3)};
     }
@@ -671,14 +671,17 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_up2c)");
         attr_set.mark();
     }
     const bool single = nm_conv_single() != 0;
     const bool io16 = in.h || out_h;
-    if (io16 && !(in.h && out_h && single)) {
-        nm_set_error("conv_up2c: 16-bit storage needs conv mode 4 and bfloat16 input AND output (got %d / %d)", in.h, out_h); return NM_ERR_UNSUPPORTED;
+    if (io16 && !single) {
+        nm_set_error("conv_up2c: 16-bit storage (input %d / output %d) needs conv mode 4", in.h, out_h); return NM_ERR_UNSUPPORTED;
     }
+    const int io = (in.h ? 1 : 0) | (out_h ? 2 : 0);
     if (g_cus == 0) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nm_check_hip(hipErrorUnknown, "device query");
@@ -693,7 +696,9 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     p.nblk = nm_up2c_blocks_per_frame(in.D, in.H, in.W);
     p.diag = nm_ls().up2c_diag;
     const int bricks = p.nbz * p.nby * p.nbx, total = p.N * bricks;
-    if (io16) hipLaunchKernelGGL((conv_up2c_kernel<true, 3>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    if (io == 3) hipLaunchKernelGGL((conv_up2c_kernel<true, 3>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    else if (io == 2) hipLaunchKernelGGL((conv_up2c_kernel<true, 2>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    else if (io == 1) hipLaunchKernelGGL((conv_up2c_kernel<true, 1>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else if (single) hipLaunchKernelGGL(conv_up2c_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else hipLaunchKernelGGL(conv_up2c_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     int rc = nm_check_hip(hipGetLastError(), "conv_up2c launch");
@@ -702,13 +707,17 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     int TZ, TY, TX; shell_tiles(in.D, in.H, in.W, TZ, TY, TX);
     const int fg = face_groups(in.D, in.H, in.W), ei = edge_items(in.D, in.H, in.W);
     const size_t face_lds = (size_t)(in.C / 16 * 4) * FPV * 16;
-    if (io16) hipLaunchKernelGGL((conv_up2c_face_kernel<true, 3>), dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
+    if (io == 3) hipLaunchKernelGGL((conv_up2c_face_kernel<true, 3>), dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
+    else if (io == 2) hipLaunchKernelGGL((conv_up2c_face_kernel<true, 2>), dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
+    else if (io == 1) hipLaunchKernelGGL((conv_up2c_face_kernel<true, 1>), dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
     else if (single) hipLaunchKernelGGL(conv_up2c_face_kernel<true>, dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
     else hipLaunchKernelGGL(conv_up2c_face_kernel<false>, dim3((unsigned)(p.N * fg)), dim3(256), face_lds, s, p, TY, TX);
     rc = nm_check_hip(hipGetLastError(), "conv_up2c_face launch");
     if (rc) return rc;
     const long long items = (long long)p.N * ei;
-    if (io16) hipLaunchKernelGGL((conv_up2c_edge_kernel<true, 3>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
+    if (io == 3) hipLaunchKernelGGL((conv_up2c_edge_kernel<true, 3>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
+    else if (io == 2) hipLaunchKernelGGL((conv_up2c_edge_kernel<true, 2>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
+    else if (io == 1) hipLaunchKernelGGL((conv_up2c_edge_kernel<true, 1>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
     else if (single) hipLaunchKernelGGL(conv_up2c_edge_kernel<true>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
     else hipLaunchKernelGGL(conv_up2c_edge_kernel<false>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, p, TZ, TY, TX, 8 * bricks + 4 * fg);
     return nm_check_hip(hipGetLastError(), "conv_up2c_edge launch");
