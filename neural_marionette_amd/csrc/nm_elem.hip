@@ -14,8 +14,11 @@ namespace {
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// HSEL: -1 run-time storage type (t.h, a uniform branch per load), 0 / 1 compile-time fp32 / bfloat16 (the batched loaders)
+template <int HSEL = -1>
 __device__ __forceinline__ f32x4 load_t(const TensorRef& t, size_t n, size_t vox_in_frame_times_C_plus_c, int c) {
-    f32x4 v = nm_ld4(t.p, n * ((size_t)t.D * t.H * t.W * t.C) + vox_in_frame_times_C_plus_c, t.h);     // (fp32 or bf16 storage)
+    const size_t e = n * ((size_t)t.D * t.H * t.W * t.C) + vox_in_frame_times_C_plus_c;
+    f32x4 v = HSEL < 0 ? nm_ld4(t.p, e, t.h) : (HSEL ? nm_ld4<true>(t.p, e) : nm_ld4<false>(t.p, e));     // (fp32 or bf16 storage)
     if (t.scale) {
         f32x4 sc = *reinterpret_cast<const f32x4*>(t.scale + n * t.C + c);
         f32x4 sh = *reinterpret_cast<const f32x4*>(t.shift + n * t.C + c);
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void convT2_lds_kernel(TensorRef in, const flo
 // data gradient of the first pool, whose 2.1 GB output takes 0.5 ms to write) and re-reads the input once per tap.
 // OH16: bfloat16 output - two lanes that hold neighbouring channels exchange values (one DPP move per register pair) so that every lane
 // stores ONE packed dword per two accumulator registers: even lanes the channel pair of voxel row r, odd lanes that of row r + 1
-template <bool OH16>
+template <bool OH16, bool IH16 = false>
 __global__ __launch_bounds__(256) void convT2_mfma_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ out, int Cout, int tiles_per_frame, int total_tiles) {
     extern __shared__ float xs_all[];
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void convT2_mfma_kernel(TensorRef in, const fl
         for (int i0 = lane; i0 < items; i0 += 256) {
             f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; v[u] = i < items ? nm_ld4(in.p, src + (size_t)i * 4, in.h) : f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; v[u] = i < items ? nm_ld4<IH16>(in.p, src + (size_t)i * 4) : f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + 64 * u;
@@ -394,7 +397,8 @@ __global__ __launch_bounds__(256) void upsample2_kernel(TensorRef in, float* __r
 // The same with the 3x3x3 neighbourhoods shared through LDS: a block owns 2 x 4 x 4 coarse cells and 32 channels; the clamped
 // 4 x 6 x 6 coarse halo is loaded and activated once (4.5 loads per cell instead of 27), every thread then interpolates its cell's
 // eight children from LDS and writes 128-byte voxel rows.  Used when C % 32 == 0 and the extents are multiples of the tile.
-__global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float* __restrict__ out, int tz, int ty, int tx, int oh) {
+template <bool IH, bool OH>
+__global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float* __restrict__ out, int tz, int ty, int tx) {
     __shared__ f32x4 tile[4 * 6 * 6 * 8];          // [hz][hy][hx][quad]
     const int D = in.D, H = in.H, W = in.W, chunks = in.C / 32;
     int b = blockIdx.x;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float
         const int q = i & 7; int v = i >> 3;
         const int hx = v % 6, hy = (v / 6) % 6, hz = v / 36;
         const int gz = min(max(z0 - 1 + hz, 0), D - 1), gy = min(max(y0 - 1 + hy, 0), H - 1), gx = min(max(x0 - 1 + hx, 0), W - 1);
-        tile[i] = load_t(in, n, (((size_t)gz * H + gy) * W + gx) * in.C + c0 + 4 * q, c0 + 4 * q);
+        tile[i] = load_t<IH ? 1 : 0>(in, n, (((size_t)gz * H + gy) * W + gx) * in.C + c0 + 4 * q, c0 + 4 * q);
     }
     __syncthreads();
     const int q = threadIdx.x & 7, cell = threadIdx.x >> 3;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float
             const f32x4 v0 = row[0], v1 = row[8], v2 = row[16];
             fx[a][bb][0] = 0.25f * v0 + 0.75f * v1; fx[a][bb][1] = 0.75f * v1 + 0.25f * v2;
         }
-    const int OH = 2 * H, OW = 2 * W;
+    const int OHt = 2 * H, OW = 2 * W;
     const int z = z0 + cz, y = y0 + cy, x = x0 + cx;
 #pragma unroll
     for (int kx = 0; kx < 2; ++kx) {
@@ -431,9 +435,9 @@ __global__ __launch_bounds__(256) void upsample2_tile_kernel(TensorRef in, float
 #pragma unroll
         for (int ky = 0; ky < 2; ++ky) {
             const f32x4 o0 = 0.25f * fy[0][ky] + 0.75f * fy[1][ky], o1 = 0.75f * fy[1][ky] + 0.25f * fy[2][ky];
-            const size_t base = ((((size_t)n * 2 * D + 2 * z) * OH + 2 * y + ky) * OW + 2 * x + kx) * in.C + c0 + 4 * q;
-            nm_st4(out, base, o0, oh);
-            nm_st4(out, base + (size_t)OH * OW * in.C, o1, oh);
+            const size_t base = ((((size_t)n * 2 * D + 2 * z) * OHt + 2 * y + ky) * OW + 2 * x + kx) * in.C + c0 + 4 * q;
+            nm_st4<OH>(out, base, o0);
+            nm_st4<OH>(out, base + (size_t)OHt * OW * in.C, o1);
         }
     }
 }
@@ -596,13 +600,18 @@ int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, flo
         if (!attr_set.done()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_mfma_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(convT2_mfma)");
             attr_set.mark();
         }
         const int tpf = (int)(fvox / 32), tiles = (int)(cvox / 32);
         const size_t ldsb = (size_t)4 * 32 * (in.C + 4) * sizeof(float);
-        if (out_h) hipLaunchKernelGGL(convT2_mfma_kernel<true>, dim3((unsigned)min((tiles + 3) / 4, 2048)), dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
-        else hipLaunchKernelGGL(convT2_mfma_kernel<false>, dim3((unsigned)min((tiles + 3) / 4, 2048)), dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
+        const dim3 gm((unsigned)min((tiles + 3) / 4, 2048));
+        if (out_h && in.h) hipLaunchKernelGGL((convT2_mfma_kernel<true, true>), gm, dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
+        else if (out_h) hipLaunchKernelGGL((convT2_mfma_kernel<true, false>), gm, dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
+        else if (in.h) hipLaunchKernelGGL((convT2_mfma_kernel<false, true>), gm, dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
+        else hipLaunchKernelGGL((convT2_mfma_kernel<false, false>), gm, dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles);
         return nm_check_hip(hipGetLastError(), "convT2_mfma launch");
     }
     if (OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && 256 % (Cout / 4) == 0 && (size_t)in.C * Cout * 4 <= 48 * 1024 && cvox >= 65536) {
@@ -619,7 +628,11 @@ int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s, int out_
     if (in.C % 4) { nm_set_error("upsample2: C %% 4 != 0"); return NM_ERR_ARG; }
     if (in.C % 32 == 0 && in.D % 2 == 0 && in.H % 4 == 0 && in.W % 4 == 0) {
         const int tz = in.D / 2, ty = in.H / 4, tx = in.W / 4;
-        hipLaunchKernelGGL(upsample2_tile_kernel, dim3((unsigned)((size_t)in.N * tz * ty * tx * (in.C / 32))), dim3(256), 0, s, in, out, tz, ty, tx, out_h);
+        const dim3 g((unsigned)((size_t)in.N * tz * ty * tx * (in.C / 32)));
+        if (in.h && out_h) hipLaunchKernelGGL((upsample2_tile_kernel<true, true>), g, dim3(256), 0, s, in, out, tz, ty, tx);
+        else if (in.h) hipLaunchKernelGGL((upsample2_tile_kernel<true, false>), g, dim3(256), 0, s, in, out, tz, ty, tx);
+        else if (out_h) hipLaunchKernelGGL((upsample2_tile_kernel<false, true>), g, dim3(256), 0, s, in, out, tz, ty, tx);
+        else hipLaunchKernelGGL((upsample2_tile_kernel<false, false>), g, dim3(256), 0, s, in, out, tz, ty, tx);
         return nm_check_hip(hipGetLastError(), "upsample2 launch");
     }
     size_t total = (size_t)in.N * in.D * in.H * in.W * (in.C / 4);
