@@ -46,7 +46,9 @@ NmLaunchState::NmLaunchState()
       lazy_res(env_int("NM355_LAZY_RES", 1)),         // 0: every residual sum is materialised by apply2 (A/B)
       adjust_split(env_int("NM355_ADJUST_SPLIT", 1)), // 0: the decoder's first 1x1 conv runs over the materialised 184-channel tensor in inference too (A/B)
       hg_core(env_int("NM355_HG_CORE", 1)),           // 0: the two lowest hourglass levels as separate launches in inference too (A/B)
-      f16p_dma(env_int("NM355_F16P_DMA", 0)) { store16_min = env_int("NM355_STORE16_MIN", 32768); }         // 1: conv_f16p2's producers copy the weights by LDS-DMA instead of through registers (A/B)
+      f16p_dma(env_int("NM355_F16P_DMA", 0)),         // 1: conv_f16p2's producers copy the weights by LDS-DMA instead of through registers (A/B)
+      clip_occ_mfma(env_int("NM355_CLIP_OCC_MFMA", 1))   // 0: the clip-mean net's first-layer weight gradient as the dense all-frames kernel (A/B)
+{ store16_min = env_int("NM355_STORE16_MIN", 32768); }
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
     return nm_tls_ls ? *nm_tls_ls : outside;

@@ -1979,7 +1979,11 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_kernel(const float* __r
 #define UA_FY 10
 #define UA_FX 18
 // HF / HC: storage type of the fine / coarse tensor as template parameters (a load under a run-time flag is a branch, and the 17 loads
-// of a thread's batch then complete one by one: 1.8 ms per launch instead of 0.5)
+// of a thread's batch then complete one by one: 1.8 ms per launch instead of 0.5).
+// bfloat16 fine tensor (HF): a pass covers 32 channels instead of 16 - the same 4320 16-byte items (8 channels each) fill the same 69 KB
+// tile, kept RAW in LDS and widened (shift / mask) when read; a voxel's 64 contiguous bytes are fetched by four lanes (with 16 channels
+// per pass the bfloat16 tensor gave 32-byte pieces at a 128-byte stride: half the sectors of every request unused) and the tensor is
+// walked in half as many passes.
 template <bool HF, bool HC>
 __global__ __launch_bounds__(256) void upsample2_adjoint_tile_kernel(const float* __restrict__ dfine, int N, int D, int H, int W, int C,
                                                                      float* __restrict__ dcoarse, const float* __restrict__ mul) {
@@ -1994,12 +1998,13 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_tile_kernel(const float
     const int z0 = bz * UA_BZ, y0 = by * UA_BY, x0 = bx * UA_BX;
     const int fz0 = 2 * z0 - 1, fy0 = 2 * y0 - 1, fx0 = 2 * x0 - 1;
     const int FD = 2 * D, FH = 2 * H, FW = 2 * W;
-    // this thread's output: coarse voxel (tid >> 2) of the brick, channel quad tid & 3 of the chunk
+    // this thread's output: coarse voxel (tid >> 2) of the brick, item tid & 3 of the chunk (4 channels, 8 with a bfloat16 fine tensor)
     const int q = tid & 3, v = tid >> 2, lx = v & 7, ly = (v >> 3) & 3, lz = v >> 5;
     float wz[4], wy[4], wx[4];
     up_adj_w(z0 + lz, D, wz); up_adj_w(y0 + ly, H, wy); up_adj_w(x0 + lx, W, wx);
     constexpr int ITEMS = UA_FZ * UA_FY * UA_FX * 4, PER = (ITEMS + 255) / 256;       // 4320 16-byte items, 17 per thread
-    for (int c0 = 0; c0 < C; c0 += 16) {
+    constexpr int CH = HF ? 32 : 16, IC = HF ? 8 : 4;                                  // channels per pass / per item
+    for (int c0 = 0; c0 < C; c0 += CH) {
         __syncthreads();
         f32x4 reg[PER];
 #pragma unroll
@@ -2008,14 +2013,17 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_tile_kernel(const float
             const int iq = i & 3, fv = i >> 2;
             const int fx = fv % UA_FX, fy = (fv / UA_FX) % UA_FY, fz = fv / (UA_FX * UA_FY);
             const int gz = fz0 + fz, gy = fy0 + fy, gx = fx0 + fx;
-            reg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < ITEMS && (unsigned)gz < (unsigned)FD && (unsigned)gy < (unsigned)FH && (unsigned)gx < (unsigned)FW)
-                reg[k] = nm_ld4<HF>(dfine, (((n * FD + gz) * FH + gy) * FW + gx) * C + c0 + 4 * iq);
+            reg[k] = f32x4{0.f, 0.f, 0.f, 0.f};                  // (all-zero bits are zeros in both element types)
+            if (i < ITEMS && (unsigned)gz < (unsigned)FD && (unsigned)gy < (unsigned)FH && (unsigned)gx < (unsigned)FW) {
+                const size_t e = (((n * FD + gz) * FH + gy) * FW + gx) * C + c0 + IC * iq;
+                if constexpr (HF) reg[k] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(dfine) + e);
+                else reg[k] = *reinterpret_cast<const f32x4*>(dfine + e);
+            }
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) { const int i = tid + 256 * k; if (i < ITEMS) tile[i] = reg[k]; }
         __syncthreads();
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = acc;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -2026,11 +2034,17 @@ __global__ __launch_bounds__(256) void upsample2_adjoint_tile_kernel(const float
                 for (int cc = 0; cc < 4; ++cc) {
                     const f32x4 t = row[cc * 4];
                     const float wt = wzy * wx[cc];
-                    acc[0] += wt * t[0]; acc[1] += wt * t[1]; acc[2] += wt * t[2]; acc[3] += wt * t[3];
+                    if constexpr (HF) {
+                        const unsigned u0 = nm_fbits(t[0]), u1 = nm_fbits(t[1]), u2 = nm_fbits(t[2]), u3 = nm_fbits(t[3]);
+                        acc[0] += wt * nm_bf_lo(u0); acc[1] += wt * nm_bf_hi(u0); acc[2] += wt * nm_bf_lo(u1); acc[3] += wt * nm_bf_hi(u1);
+                        acc2[0] += wt * nm_bf_lo(u2); acc2[1] += wt * nm_bf_hi(u2); acc2[2] += wt * nm_bf_lo(u3); acc2[3] += wt * nm_bf_hi(u3);
+                    } else { acc[0] += wt * t[0]; acc[1] += wt * t[1]; acc[2] += wt * t[2]; acc[3] += wt * t[3]; }
                 }
             }
         acc[0] *= mm; acc[1] *= mm; acc[2] *= mm; acc[3] *= mm;
-        nm_st4<HC>(dcoarse, (((n * D + z0 + lz) * H + y0 + ly) * W + x0 + lx) * C + c0 + 4 * q, acc);
+        const size_t eo = (((n * D + z0 + lz) * H + y0 + ly) * W + x0 + lx) * C + c0 + IC * q;
+        nm_st4<HC>(dcoarse, eo, acc);
+        if constexpr (HF) { acc2[0] *= mm; acc2[1] *= mm; acc2[2] *= mm; acc2[3] *= mm; nm_st4<HC>(dcoarse, eo + 4, acc2); }
     }
 }
 
@@ -2434,7 +2448,7 @@ int nm_launch_scale_by(float* x, size_t n, const float* mul, hipStream_t s, int 
 int nm_launch_upsample2_adjoint(const float* dfine, int N, int D, int H, int W, int C, float* dcoarse, hipStream_t s, const float* mul, int hf, int hc) {
     if (C % 4) { nm_set_error("upsample2_adjoint: C %% 4 != 0"); return NM_ERR_ARG; }
     const size_t total = (size_t)N * D * H * W * (C / 4);
-    if (C % 16 == 0 && D % UA_BZ == 0 && H % UA_BY == 0 && W % UA_BX == 0 && total >= 16384) {
+    if (C % (hf ? 32 : 16) == 0 && D % UA_BZ == 0 && H % UA_BY == 0 && W % UA_BX == 0 && total >= 16384) {
         const size_t blocks = (size_t)N * (D / UA_BZ) * (H / UA_BY) * (W / UA_BX);
         if (hf && hc) hipLaunchKernelGGL((upsample2_adjoint_tile_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse, mul);
         else if (hf) hipLaunchKernelGGL((upsample2_adjoint_tile_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, dfine, N, D, H, W, C, dcoarse, mul);

@@ -781,7 +781,9 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
     if (dv) { nm_set_error("detector_backward: outer-product gradient into a layer without GroupNorm"); b.rc = NM_ERR_STATE; return nullptr; }
     const float* res = dA;
     if (out.slope != 1.0f || dA_mul) {
-        dy = b.alloc(Bwd::fl(numel_of(out), out.h));
+        // (from the dY ring when the weight gradients run on their own stream: the layer's weight gradient - the decoder's 179 -> 128
+        //  1x1 conv is 1.6 ms of fp32 matrix work - then leaves the main stream's chain like those of the layers with a GroupNorm)
+        dy = b.dy_alloc(Bwd::fl(numel_of(out), out.h));
         if (b.live()) b.run(nm_launch_gnb_apply(dA, out, nullptr, dy, b.s, amax, dA_mul));
         res = dy;
     } else if (amax && b.live()) b.run(nm_launch_absmax(dA, numel_of(out), amax, b.s, nullptr, out.h));
@@ -1118,7 +1120,10 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         const size_t saved_peak = b2.ws.peak;
         b2.ws.peak = b2.ws.top;
         float* dfclip = conv_bwd(b2, t.clip_head, dchead, true);
-        feature_net_bwd(b2, t.clip, dfclip, false);       // the clip-mean grid is the union of T frames: not sparse
+        // (the clip-mean grid is the union of T frames, 15-30 % dense: the gather form of the sparse first-layer gradient loses there, but
+        //  the matrix-core form - frame-summed dY for the coordinate channels, non-empty bricks for the occupancy channel, exact fp32
+        //  products - does not depend on 0 / 1 occupancies)
+        feature_net_bwd(b2, t.clip, dfclip, nm_ls().clip_occ_mfma != 0);
         const size_t local_peak = b2.ws.peak;
         b2.ws.peak = saved_peak > local_peak ? saved_peak : local_peak;
         b2.ws.top = local_peak;

@@ -210,17 +210,15 @@ def test_conv3d_backward_valu_transposition_wgrad_variant():
 def test_conv3d_backward_older_kernel_variants(env):
     """The A/B partners of the round-3 defaults stay under parity: wgrad16u_kernel (bricks in any order, full halo per brick) and
     wgrad16t_kernel (conditional staging loads) against the default wgrad16z_kernel, and the decoder tail's backward with its
-    [F][G^3][32] gradient materialised (NM355_TAIL_RANK1=0; that one re-runs the detector gradient fixtures), and the GroupNorm
-    backward with the one-voxel-at-a-time apply kernel and its gamma / beta / bias sums launched per layer (same fixtures), and the
-    weight gradients inside the main stream's chain / enqueued on their own stream in front of the data gradient (same fixtures).  The
+    [F][G^3][32] gradient materialised (NM355_TAIL_RANK1=0; that one re-runs the reference's gradient fixture G8), and the GroupNorm
+    backward with the one-voxel-at-a-time apply kernel and its gamma / beta / bias sums launched per layer (same fixture), and the
+    weight gradients inside the main stream's chain / enqueued on their own stream in front of the data gradient (same fixture).  The
     switches are read when a context is created: child processes."""
     import os, subprocess, sys
     here = os.path.abspath(__file__)
-    if "NM355_TAIL_RANK1" in env:
-        target = [os.path.join(os.path.dirname(here), "test_train_detector_gpu.py"), "-k", "test_detector_gradients_vs_oracle_autograd or test_detector_gradients_vs_reference_fixture"]
-    elif "NM355_GNB_APPLY4" in env or "NM355_WGRAD_ASYNC" in env:       # (the all-losses case + the reference's own gradients: every backward path once)
-        target = [os.path.join(os.path.dirname(here), "test_train_detector_gpu.py"), "-k",
-                  "(test_detector_gradients_vs_oracle_autograd and aist) or test_detector_gradients_vs_reference_fixture"]
+    if "NM355_TAIL_RANK1" in env or "NM355_GNB_APPLY4" in env or "NM355_WGRAD_ASYNC" in env:
+        # the reference's own gradients of the all-losses case (fixture G8: no oracle run in the child): every backward path once
+        target = [os.path.join(os.path.dirname(here), "test_train_detector_gpu.py"), "-k", "test_detector_gradients_vs_reference_fixture"]
     else:
         target = [here, "-k", "test_conv3d_backward and (split16 or f16) and k3 and not variant"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + target, env=dict(os.environ, **env), capture_output=True, text=True,

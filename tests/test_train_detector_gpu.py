@@ -40,9 +40,25 @@ def _setup(G=32, B=2, T=4, seed=11, variant="peaky", K=24):
     return o, sd, vox
 
 
+_ORACLE_GRAD_CACHE = {}
+
+
 def _oracle_grads(o, sd, vox, weights, affinity_on=True, double=False):
     """Autograd of the oracle.  double=True: the same graph in fp64 — the reference value the fp32 gradients of both
-    implementations scatter around (the fp32 oracle itself is 1e-3 relative away from it on the deepest layers)."""
+    implementations scatter around (the fp32 oracle itself is 1e-3 relative away from it on the deepest layers).
+    Cached per (weights, clip, loss weighting) for the session: several tests compare different conv modes against the same
+    fp64 gradient (10-15 s of CPU each)."""
+    key = (o.grid_size, o.nkeypoints, tuple(vox.shape), float(vox.sum()), float(sd["kypt_detector.affinity_params"].double().sum()),
+           float(sd["kypt_detector.kypt_to_vox.decode_voxel_from_combined_representation.11.weight"].double().abs().sum()),
+           tuple(sorted(weights.items())), affinity_on, double)
+    if key in _ORACLE_GRAD_CACHE:
+        return _ORACLE_GRAD_CACHE[key]
+    res = _oracle_grads_uncached(o, sd, vox, weights, affinity_on, double)
+    _ORACLE_GRAD_CACHE[key] = res
+    return res
+
+
+def _oracle_grads_uncached(o, sd, vox, weights, affinity_on=True, double=False):
     if double:
         sd, vox = {k: v.double() for k, v in sd.items()}, vox.double()
     names = [k for k in sd if k.startswith("kypt_detector.")]

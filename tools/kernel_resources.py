@@ -14,9 +14,10 @@ out = subprocess.run([LLVM + "/llvm-readelf", "--notes", elf], capture_output=Tr
 for k in re.split(r"\n\s+- \.agpr_count", out)[1:]:
     g = lambda key: re.search(r"\." + key + r":\s+(\S+)", k)
     name, sp, ps, vg, lds = g("name"), g("vgpr_spill_count"), g("private_segment_fixed_size"), g("vgpr_count"), g("group_segment_fixed_size")
+    ag = re.match(r":\s+(\d+)", k)          # (the split consumed the key of .agpr_count: its value leads the chunk)
     if not name:
         continue
     if "--all" in sys.argv or int(ps.group(1)) > 0 or int(sp.group(1)) > 0:
         dn = subprocess.run(["c++filt", name.group(1)], capture_output=True, text=True).stdout.strip()
         dn = re.sub(r"\(anonymous namespace\)::", "", dn)
-        print("%-110s vgpr %3s spill %3s scratch %5s lds %6s" % (re.sub(r"\(.*", "", dn)[:110], vg.group(1), sp.group(1), ps.group(1), lds.group(1)))
+        print("%-100s vgpr %3s agpr %3s spill %3s scratch %5s lds %6s" % (re.sub(r"\(.*", "", dn)[:100], vg.group(1), ag.group(1) if ag else "?", sp.group(1), ps.group(1), lds.group(1)))
