@@ -47,7 +47,8 @@ NmLaunchState::NmLaunchState()
       adjust_split(env_int("NM355_ADJUST_SPLIT", 1)), // 0: the decoder's first 1x1 conv runs over the materialised 184-channel tensor in inference too (A/B)
       hg_core(env_int("NM355_HG_CORE", 1)),           // 0: the two lowest hourglass levels as separate launches in inference too (A/B)
       f16p_dma(env_int("NM355_F16P_DMA", 0)),         // 1: conv_f16p2's producers copy the weights by LDS-DMA instead of through registers (A/B)
-      clip_occ_mfma(env_int("NM355_CLIP_OCC_MFMA", 1))   // 0: the clip-mean net's first-layer weight gradient as the dense all-frames kernel (A/B)
+      clip_occ_mfma(env_int("NM355_CLIP_OCC_MFMA", 1)),  // 0: the clip-mean net's first-layer weight gradient as the dense all-frames kernel (A/B)
+      vrnn_chain(env_int("NM355_VRNN_CHAIN", 1))         // 0: the prior steps of a rollout as three launches per step instead of one persistent launch (A/B)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); }
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
@@ -225,11 +226,16 @@ int nm_ctx_check_nonfinite(nm_ctx* ctx) { NmScope nm_scope_(ctx);
     if (!rc) rc = nm_check_hip(hipMemcpy(&v, ctx->nf_flag, sizeof(v), hipMemcpyDeviceToHost), "check_nonfinite: read");
     if (rc) return rc;
     for (int i = 0; i < 4; ++i) {          // the stream is drained: every pending status copy has landed; this report consumes them
-        if (ctx->nf_busy[i] && ctx->nf_host[i]) v = 1;
+        if (ctx->nf_busy[i] && ctx->nf_host[i]) v |= ctx->nf_host[i];
         ctx->nf_busy[i] = false; ctx->nf_host[i] = 0;
     }
     if (!v) return NM_OK;
     (void)hipMemset(ctx->nf_flag, 0, sizeof(unsigned));
+    if (v & 2u) {
+        nm_set_error("the persistent rollout kernel timed out waiting for its workgroups since the last check (its outputs are invalid); "
+                     "NM355_VRNN_CHAIN=0 selects the launch-per-phase steps");
+        return NM_ERR_STATE;
+    }
     nm_set_error("a convolution produced non-finite values since the last check: %s", nm_conv_get_mode() != 0
                  ? "in the split-fp16 conv mode an activation beyond the fp16 range (|x| >= 65520) or a non-finite input does that - "
                    "set conv mode 'fp32' (exact fp32 MFMA, no range limit) and run again"

@@ -108,6 +108,7 @@ struct nm_ctx {
     uint64_t nf_seq[4] = {0, 0, 0, 0};     // call number of the slot's copy
     const char* nf_who[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t nf_calls = 0;                 // forward-type calls so far
+    unsigned nf_last = 0;                  // status bits of the slot that tripped (1: non-finite conv statistics, 2: rollout time-out)
     int range_check = 1;                   // NM355_RANGE_CHECK=0 switches the deferred guard off (A/B)
     Arena ws;                              // activations / scratch, reset per call
     Arena ws2;                             // scratch of work issued on stream2 (VRNN beside the decoder)
@@ -141,6 +142,9 @@ struct NmScope {
     NmScope& operator=(const NmScope&) = delete;
 };
 
+// deferred status (nm_net.hip): poll at the entry of an ABI call, post behind a call that can set the status word
+int nm_nf_poll(nm_ctx* c);
+void nm_nf_post(nm_ctx* c, const char* who);
 int nm_ctx_reserve(nm_ctx* ctx, size_t bytes);        // grow the workspace (synchronises)
 float* nm_ctx_weight_alloc(nm_ctx* ctx, size_t floats);
 

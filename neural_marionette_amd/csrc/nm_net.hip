@@ -1162,13 +1162,24 @@ int with_workspace(nm_ctx* c, Fn&& graph) {
     return graph();
 }
 
+int check_ready(nm_ctx* c, const char* who) {
+    if (!c) { nm_set_error("%s: null ctx", who); return NM_ERR_ARG; }
+    if (!c->has_weights) { nm_set_error("%s: nm_ctx_set_weights has not been called", who); return NM_ERR_STATE; }
+    nm_elem_set_nonfinite_flag(c->nf_flag);        // GroupNorm finalisation reports non-finite conv statistics into this ctx's status word
+    int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
+    if (!rc) rc = nm_nf_poll(c);
+    return rc;
+}
+
+}  // namespace
+
 // ---- deferred range guard (include/nm355.h "Range / finiteness status") -----------------------------------------------------------
 // nf_post: behind a forward-type call, on its stream: status word -> pinned host slot, event.  nf_poll: at the entry of every later
 // call: slots whose event has completed are read (hipEventQuery, no wait); a slot two or more calls old is waited for - the device
 // is at least one whole call behind it, so the wait returns at once and the host never runs more than ~2 calls ahead of a report.
 // A set slot clears the device word, drops the younger slots (they saw the same sticky word) and fails the CURRENT call with
 // NM_ERR_RANGE naming the call that overflowed: its outputs, handed out earlier, hold NaN / inf.
-int nf_poll(nm_ctx* c) {
+int nm_nf_poll(nm_ctx* c) {
     if (!c->range_check || !c->nf_host) return NM_OK;
     int bad = -1;
     for (int i = 0; i < 4; ++i) {
@@ -1178,7 +1189,7 @@ int nf_poll(nm_ctx* c) {
         if (e == hipErrorNotReady) continue;
         if (e != hipSuccess) return nm_check_hip(e, "range guard: status event");
         c->nf_busy[i] = false;
-        if (c->nf_host[i] && (bad < 0 || c->nf_seq[i] < c->nf_seq[bad])) bad = i;
+        if (c->nf_host[i] && (bad < 0 || c->nf_seq[i] < c->nf_seq[bad])) { bad = i; c->nf_last = c->nf_host[i]; }
         else c->nf_host[i] = 0;
     }
     if (bad < 0) return NM_OK;
@@ -1188,6 +1199,11 @@ int nf_poll(nm_ctx* c) {
         c->nf_busy[i] = false; c->nf_host[i] = 0;
     }
     (void)hipMemsetAsync(c->nf_flag, 0, sizeof(unsigned), c->stream);
+    if (c->nf_last & 2u) {
+        nm_set_error("call #%llu (%s): the persistent rollout kernel timed out waiting for its workgroups (its outputs are invalid); "
+                     "NM355_VRNN_CHAIN=0 selects the launch-per-phase steps", (unsigned long long)seq, who);
+        return NM_ERR_STATE;
+    }
     nm_set_error("call #%llu (%s) produced non-finite values - its outputs are invalid: %s", (unsigned long long)seq, who,
                  nm_conv_get_mode() != 0
                  ? "in the split-fp16 conv mode an activation beyond the fp16 range (|x| >= 65520) or a non-finite input does that where the "
@@ -1195,7 +1211,7 @@ int nf_poll(nm_ctx* c) {
                  : "the input or the weights hold inf / NaN (exact fp32 mode has no range limit of its own)");
     return NM_ERR_RANGE;
 }
-void nf_post(nm_ctx* c, const char* who) {
+void nm_nf_post(nm_ctx* c, const char* who) {
     ++c->nf_calls;
     if (!c->range_check || !c->nf_host) return;
     int k = -1;
@@ -1207,16 +1223,6 @@ void nf_post(nm_ctx* c, const char* who) {
     c->nf_busy[k] = true; c->nf_seq[k] = c->nf_calls; c->nf_who[k] = who;
 }
 
-int check_ready(nm_ctx* c, const char* who) {
-    if (!c) { nm_set_error("%s: null ctx", who); return NM_ERR_ARG; }
-    if (!c->has_weights) { nm_set_error("%s: nm_ctx_set_weights has not been called", who); return NM_ERR_STATE; }
-    nm_elem_set_nonfinite_flag(c->nf_flag);        // GroupNorm finalisation reports non-finite conv statistics into this ctx's status word
-    int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
-    if (!rc) rc = nf_poll(c);
-    return rc;
-}
-
-}  // namespace
 
 void nm_net_free_tape(nm_ctx* c) { delete c->tape; c->tape = nullptr; }
 
@@ -1332,7 +1338,7 @@ int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32
         nm_set_error("detector_forward: null / non-positive argument"); return NM_ERR_ARG;
     }
     rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11); });
-    if (!rc) nf_post(c, "nm_detector_forward");
+    if (!rc) nm_nf_post(c, "nm_detector_forward");
     return rc;
 }
 
@@ -1361,7 +1367,7 @@ int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t 
     rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11, &hook); });
     if (rc) return rc;
     rc = nm_check_hip(hipStreamWaitEvent(c->stream, c->ev_side, 0), "join side stream");
-    if (!rc) nf_post(c, "nm_forward_fused");
+    if (!rc) nm_nf_post(c, "nm_forward_fused");
     return rc;
 }
 
@@ -1373,7 +1379,7 @@ int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* fir
         nm_set_error("decode_from_keypoints: null / non-positive argument"); return NM_ERR_ARG;
     }
     rc = with_workspace(c, [&]() { return decode_graph(c, keypoints, first_feature, first_frame, B, Tg, gen); });
-    if (!rc) nf_post(c, "nm_decode_from_keypoints");
+    if (!rc) nm_nf_post(c, "nm_decode_from_keypoints");
     return rc;
 }
 
@@ -1424,7 +1430,7 @@ int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T,
     t.fwd_top = c->ws.top;
     std::swap(c->ws, c->ws_t);
     t.valid = rc == NM_OK;
-    if (!rc) nf_post(c, "nm_detector_forward_train");
+    if (!rc) nm_nf_post(c, "nm_detector_forward_train");
     return rc;
 }
 

@@ -586,6 +586,312 @@ __global__ __launch_bounds__(1024) void vrnn_prior_mid_kernel(MidArgs a) {
     }
 }
 
+// ---- the prior steps of a rollout as ONE persistent launch (BASELINE north_star: "one kernel per timestep"; here: one per rollout) -----
+// vis_generation.py:97-127 / hsvrnn_bvh.py:208-225.  A prior step is h-phase -> middle phases -> GRU, three all-to-all hand-offs per
+// step.  As launches (the default until round 4: 3 per step inside a captured graph, 19.9-21 us per step at B = 1) every launch
+// re-streams its weights from L2 / Infinity Cache - 3.9 MB (h-phase), 343 KB (middle) and 1.4 MB (GRU) per step - and pays a dispatch.
+// The weights do not depend on the step, so here NW = 64 worker workgroups and B <= 4 middle workgroups (512 threads each, one per CU,
+// all resident: 68 of 256 CUs) load their weight rows into REGISTERS (the heads' 87 KB into LDS) once and then run the whole chain:
+//   workers: wave gw (of 512) owns h-phase rows gw + 512 i (prior0 | root0_h | joint0_h | W_hh: 1920 rows x 512) and GRU unit j = gw;
+//   middle workgroup b: vrnn_prior_mid_kernel's four phases for batch element b.
+// Hand-offs as DATA-TAGGED GRANULES (MI355X_MICROARCH.md, persistent-kernel price list: "granules for latency", handoff-1to1 0.8-1.0 us
+// against 1.3-2.2 us for payload + flag): every value handed over is one naturally aligned 8-byte {value, step tag} written by ONE
+// sc1 (agent-scope, write-through) store; a consumer loads the granules it needs with sc1 loads (they bypass the CU's L1, which another
+// CU's stores never refresh) and repeats the loads until every tag is the step's - no counters, no fences, no barrier between
+// workgroups.  A first version with three counters per step (sc1 payload, drained, one atomic add per workgroup, sc1 poll, sc1 loads)
+// measured 21.2 us per step at B = 1 - no better than three launches: each hop was a store drain, an atomic, a poll and a dependent
+// load, ~7 us (profiles/r04_rollout_ab.txt).  The granule buffers are zeroed before the launch (tag 0 = never written); a buffer is
+// rewritten only after every reader of its previous contents has produced the values the writer itself waited for (the dependency
+// chain of the step), so an exact tag match is unambiguous.  Every spin is bounded: after NM_CHAIN_SPIN polls a wave sets the abort word
+// and bit 1 of the context's status word, every workgroup leaves, and the next library call fails - a rollout must never hang the device.
+// Arithmetic per output row is the row kernels' (dot_seg for n = 512 / 96 + 128, wave_reduce's xor tree, the same epilogues): outputs are
+// bit-identical to the launch-per-phase step (tools/diag_chain.py, tests/test_network_gpu.py::test_config5_rollout64).
+#define NM_CHAIN_NW 64                 // worker workgroups of 8 waves: 512 waves; 4 h-phase rows (1920 / 512, the last waves fewer) and ONE GRU unit (H = 512) per wave
+#define NM_CHAIN_T 512                 // threads per workgroup: two waves per SIMD, 256 registers each (the middle role keeps 2 x 16 weight quads per lane)
+#define NM_CHAIN_PAIRS 16              // row pairs per wave and matrix phase of the middle role: 8 waves x 16 pairs x 2 rows = 256 rows
+#define NM_CHAIN_SPIN (1 << 20)
+typedef unsigned long long nm_gran;    // {float value (low dword), step tag (high dword)}
+struct ChainArgs {
+    const float *w_prior0, *b_prior0, *w_root0, *b_root0, *w_joint0, *b_joint0, *w_hh, *b_hh, *w_ih, *b_ih;
+    MidArgs mid;                        // weights / tree / offset of the middle phases (its data pointers are not used)
+    const float* h0; int ldh0;          // [B][ldh0] state before the first step (written before the launch: plain loads)
+    const float* eps;                   // [T][B][Z]
+    float* out_kp; int ldkp;            // [B][ldkp], step t at column t * 4K          (the call's output, plain stores)
+    float* h_out;                       // [B][H] state after the last step             (plain stores)
+    nm_gran *g_hid, *g_rh, *g_jh;       // [B][128] x 3   h-phase -> middle
+    nm_gran* g_gh;                      // [B][3H]        h-phase -> GRU
+    nm_gran* g_kpz;                     // [B][4K + Z]    middle -> GRU
+    nm_gran* g_h[2];                    // [B][H] x 2     GRU of step t -> h-phase / GRU of step t + 1 (buffer t & 1)
+    unsigned* abort;                    // zero before the launch; 1: some wave timed out
+    unsigned* status;                   // the context's status word: bit 1 = a spin timed out
+    int B, T, K, Z, H;
+    int backoff;                        // s_sleep(2) units between polls
+};
+
+__device__ __forceinline__ void gran_store(nm_gran* p, float v, unsigned tag) {
+    __hip_atomic_store(p, (nm_gran)__builtin_bit_cast(unsigned, v) | ((nm_gran)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A lane's granule loads of one poll as ONE asm statement: all loads issued (16-byte sc1 loads = two neighbouring granules, 8-byte = one),
+// then one wait - the compiler must not touch a destination between its load and the wait (an untracked load's register is stale until
+// then), hence a single statement with early-clobber outputs
+__device__ __forceinline__ void gran_ld_2q1(const nm_gran* p0, const nm_gran* p1, const nm_gran* s0, f32x4& a0, f32x4& a1, nm_f32x2& b0) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx2 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0) : "v"(p0), "v"(p1), "v"(s0) : "memory");
+}
+__device__ __forceinline__ void gran_ld_4q1(const nm_gran* p0, const nm_gran* p1, const nm_gran* p2, const nm_gran* p3, const nm_gran* s0,
+                                            f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, nm_f32x2& b0) {
+    asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx2 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(s0) : "memory");
+}
+__device__ __forceinline__ void gran_ld_4q4(const nm_gran* p0, const nm_gran* p1, const nm_gran* p2, const nm_gran* p3, const nm_gran* s0,
+                                            const nm_gran* s1, const nm_gran* s2, const nm_gran* s3, f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3,
+                                            nm_f32x2& b0, nm_f32x2& b1, nm_f32x2& b2, nm_f32x2& b3) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx2 %4, %12, off sc1\n\tglobal_load_dwordx2 %5, %13, off sc1\n\t"
+                 "global_load_dwordx2 %6, %14, off sc1\n\tglobal_load_dwordx2 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(s0), "v"(s1), "v"(s2), "v"(s3) : "memory");
+}
+// polls until `ok` holds in every lane of the wave (the body re-issues the lane's loads and re-evaluates ok); false: aborted
+#define NM_CHAIN_POLL(LOADS, OKEXPR)                                                                                  \
+    {                                                                                                                \
+        int spins_ = 0; bool alive_ = true;                                                                          \
+        for (;;) {                                                                                                   \
+            LOADS;                                                                                                   \
+            if (__all(OKEXPR)) break;                                                                                \
+            if ((++spins_ & 63) == 0) {                                                                              \
+                if (__hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { alive_ = false; break; }   \
+                if (spins_ > NM_CHAIN_SPIN) {                                                                        \
+                    __hip_atomic_store(a.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                       \
+                    __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                   \
+                    alive_ = false; break;                                                                           \
+                }                                                                                                    \
+            }                                                                                                        \
+            for (int sl_ = 0; sl_ < a.backoff; ++sl_) __builtin_amdgcn_s_sleep(2);                                   \
+        }                                                                                                            \
+        if (!alive_) { wave_alive = false; }                                                                         \
+    }
+
+__global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs a) {
+    __shared__ int s_dead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, T = a.T, K = a.K, Z = a.Z, H = a.H, S4 = 4 * K;
+    bool wave_alive = true;
+    if (tid == 0) s_dead = 0;
+    if ((int)blockIdx.x >= NM_CHAIN_NW) {
+        // =========================== middle workgroup of batch element b ========================================================
+        const MidArgs& m = a.mid;
+        __shared__ __attribute__((aligned(16))) float s_z[128], s_hr[128], s_hj[128], s_root[36], s_rot[192];
+        __shared__ float s_Rl[32 * 9], s_Rg[32 * 9], s_pos[32 * 3];
+        __shared__ FkTables tb;
+        const int half = lane >> 5, l32 = lane & 31, b = (int)blockIdx.x - NM_CHAIN_NW;
+        const int R0 = 3 + K, J6 = 6 * K, rows_c = R0 + J6;
+        // weights of the distribution (A) and decoder-hidden (B) phases in registers, those of the heads (C: 3 + 7K rows x 128) in LDS - all
+        // three in registers (3 x 16 quads) overflow the 256 a 512-thread workgroup has per lane
+        extern __shared__ f32x4 s_wc[];                                  // [rows_c][32 quads]
+        f32x4 wa[NM_CHAIN_PAIRS], wb[NM_CHAIN_PAIRS];
+#pragma unroll
+        for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+            const int p = wave * NM_CHAIN_PAIRS + u;
+            wa[u] = *reinterpret_cast<const f32x4*>(m.w_p2 + (size_t)(p + half * Z) * 128 + l32 * 4);
+            wb[u] = *reinterpret_cast<const f32x4*>((half ? m.w_joint0 : m.w_root0) + (size_t)p * (H + Z) + H + l32 * 4);
+            const int r = min(p * 2 + half, rows_c - 1);
+            const float* pc = r < R0 ? m.w_root2 + (size_t)r * 128 : m.w_joint2 + (size_t)(r - R0) * 128;
+            if (p * 2 + half < rows_c) s_wc[(p * 2 + half) * 32 + l32] = *reinterpret_cast<const f32x4*>(pc + l32 * 4);
+        }
+        const int pl = wave * NM_CHAIN_PAIRS + (l32 < NM_CHAIN_PAIRS ? l32 : 0);
+        const float bias_a = m.b_p2[pl], bias_a2 = m.b_p2[pl + Z];
+        const int rl = min(pl * 2 + half, rows_c - 1);
+        const float bias_c = *(rl < R0 ? m.b_root2 + rl : m.b_joint2 + (rl - R0));
+        fk_tables_load(tb, m.lvl_joint, m.lvl_start, m.parents, m.offset + (size_t)b * K * 3, K, m.nlevels, tid);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const unsigned tag = (unsigned)t + 1u;
+            const float epsv = a.eps[((size_t)t * B + b) * Z + pl];                       // (an input of the call: plain load)
+            // this lane's inputs of the step: hid_prior[4 l32 .. +3] (two granule pairs) and rh / jh [pl]
+            f32x4 g0, g1; nm_f32x2 ga;
+            const nm_gran* ph = a.g_hid + (size_t)b * 128 + l32 * 4;
+            const nm_gran* pa = (half ? a.g_jh : a.g_rh) + (size_t)b * 128 + pl;
+            NM_CHAIN_POLL(gran_ld_2q1(ph, ph + 2, pa, g0, g1, ga),
+                          nm_fbits(g0[1]) == tag && nm_fbits(g0[3]) == tag && nm_fbits(g1[1]) == tag && nm_fbits(g1[3]) == tag && nm_fbits(ga[1]) == tag);
+            if (!wave_alive) s_dead = 1;
+            const f32x4 xh = {g0[0], g0[2], g1[0], g1[2]};
+            const float add_b = ga[0];
+            // ---- A (vrnn_prior_mid_kernel) ----
+            {
+                float mine = 0.f, other = 0.f;
+#pragma unroll
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+                    const float v = half_reduce(dot4(wa[u], xh));
+                    const float o = __shfl_xor(v, 32);
+                    if (l32 == u) { mine = v; other = o; }
+                }
+                if (!half && l32 < NM_CHAIN_PAIRS) {
+                    const int p = wave * NM_CHAIN_PAIRS + l32;
+                    const float mu = mine + bias_a, sraw = other + bias_a2;
+                    const float sg = softplus(sraw) + 1e-4f;
+                    const float z = mu + epsv * sg;
+                    s_z[p] = z;
+                    gran_store(a.g_kpz + (size_t)b * (S4 + Z) + S4 + p, z, tag);
+                }
+            }
+            __syncthreads();
+            if (s_dead) return;                                          // (uniform: read behind the barrier)
+            // ---- B ----
+            {
+                const f32x4 xz = *reinterpret_cast<const f32x4*>(s_z + l32 * 4);
+                float mine = 0.f;
+#pragma unroll
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+                    const float v = half_reduce(dot4(wb[u], xz));
+                    if (l32 == u) mine = v;
+                }
+                if (l32 < NM_CHAIN_PAIRS) (half ? s_hj : s_hr)[wave * NM_CHAIN_PAIRS + l32] = lrelu(mine + add_b, 0.01f);
+            }
+            __syncthreads();
+            // ---- C ----
+            {
+                const f32x4 xr = *reinterpret_cast<const f32x4*>(s_hr + l32 * 4);
+                const f32x4 xj = *reinterpret_cast<const f32x4*>(s_hj + l32 * 4);
+                float mine = 0.f;
+#pragma unroll
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+                    const int r = (wave * NM_CHAIN_PAIRS + u) * 2 + half;
+                    const f32x4 wq = s_wc[min(r, rows_c - 1) * 32 + l32];
+                    const float v = half_reduce(dot4(wq, r < R0 ? xr : xj));
+                    if (l32 == u) mine = v;
+                }
+                if (l32 < NM_CHAIN_PAIRS) {
+                    const int r = (wave * NM_CHAIN_PAIRS + l32) * 2 + half;
+                    if (r < R0) s_root[r] = tanhf(mine + bias_c);
+                    else if (r < rows_c) s_rot[r - R0] = mine + bias_c;
+                }
+            }
+            __syncthreads();
+            // ---- D: forward kinematics ----
+            if (tid < K) {
+                const float* p = s_rot + tid * 6;
+                float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
+                float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
+                x0 /= nx; x1 /= nx; x2 /= nx;
+                float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+                float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
+                z0 /= nz; z1 /= nz; z2 /= nz;
+                float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
+                float* R = s_Rl + tid * 9;
+                R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
+            }
+            __syncthreads();
+            fk_levels(tb, m.nlevels, s_Rl, s_Rg, s_pos, s_root, 36, K, 1, 0, 0, tid, NM_CHAIN_T);
+            if (tid < S4) {
+                const int k = tid >> 2, c = tid & 3;
+                const float v = c < 3 ? s_pos[k * 3 + c] : (s_root[3 + k] + 1.0f) * 0.5f;
+                a.out_kp[(size_t)b * a.ldkp + (size_t)t * S4 + tid] = v;           // the call's output (read after the launch)
+                gran_store(a.g_kpz + (size_t)b * (S4 + Z) + tid, v, tag);           // the GRU's input
+            }
+            __syncthreads();                                             // (the LDS state of this step is dead; s_z .. are rewritten next step)
+        }
+        return;
+    }
+    // =============================== worker workgroup (waves are independent: no workgroup barrier below) ==========================
+    const int gw = (int)blockIdx.x * (NM_CHAIN_T / 64) + wave;       // global wave index, 0 .. 8 NW - 1
+    constexpr int NWV = NM_CHAIN_NW * (NM_CHAIN_T / 64);
+    constexpr int HR = 4;                                            // h-phase rows per wave: 1920 <= 512 x 4
+    // ---- h-phase rows r = gw + NWV * i: [0,128) prior0 (lrelu) -> hid, [128,256) root0 -> rh, [256,384) joint0 -> jh, [384,1920) W_hh -> gh
+    f32x4 wh[HR][2]; float bh[HR];
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+        const int r = min(gw + NWV * i, 383 + 3 * H);
+        const float* wr; const float* br;
+        if (r < 128) { wr = a.w_prior0 + (size_t)r * H; br = a.b_prior0 + r; }
+        else if (r < 256) { wr = a.w_root0 + (size_t)(r - 128) * (H + Z); br = a.b_root0 + (r - 128); }
+        else if (r < 384) { wr = a.w_joint0 + (size_t)(r - 256) * (H + Z); br = a.b_joint0 + (r - 256); }
+        else { wr = a.w_hh + (size_t)(r - 384) * H; br = a.b_hh + (r - 384); }
+        wh[i][0] = *reinterpret_cast<const f32x4*>(wr + lane * 4);
+        wh[i][1] = *reinterpret_cast<const f32x4*>(wr + 256 + lane * 4);
+        bh[i] = *br;
+    }
+    // ---- GRU unit j = gw (H <= NWV): rows j, H + j, 2H + j of W_ih over [keypoints (4K) | z (Z)]; lane < 4K / 4 holds the keypoint
+    // quad, lane < Z / 4 the latent quad (dot_seg's lane -> column assignment for n = 4K and n = Z)
+    const int in = S4 + Z, j = gw, jc = min(j, H - 1);
+    f32x4 wk[3], wz[3]; float bi[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float* w = a.w_ih + (size_t)(g * H + jc) * in;
+        wk[g] = *reinterpret_cast<const f32x4*>(w + (lane * 4 < S4 ? lane * 4 : 0));
+        wz[g] = *reinterpret_cast<const f32x4*>(w + S4 + (lane * 4 < Z ? lane * 4 : 0));
+        bi[g] = a.b_ih[g * H + jc];
+    }
+    const bool kq = lane * 4 < S4, zq = lane * 4 < Z;
+    for (int t = 0; t < T && wave_alive; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        // ---- h-phase of step t for every batch element: h_t[b] columns 4 lane .. +3 and 256 + 4 lane .. +3 (t = 0: the call's input, plain)
+#pragma unroll 1
+        for (int b = 0; b < B && wave_alive; ++b) {
+            f32x4 x0, x1;
+            if (t == 0) {
+                x0 = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * a.ldh0 + lane * 4);
+                x1 = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * a.ldh0 + 256 + lane * 4);
+            } else {
+                const nm_gran* ph = a.g_h[(t - 1) & 1] + (size_t)b * H;
+                f32x4 q0, q1, q2, q3; nm_f32x2 qj;
+                NM_CHAIN_POLL(gran_ld_4q1(ph + lane * 4, ph + lane * 4 + 2, ph + 256 + lane * 4, ph + 256 + lane * 4 + 2, ph + jc, q0, q1, q2, q3, qj),
+                              nm_fbits(q0[1]) == (unsigned)t && nm_fbits(q0[3]) == (unsigned)t && nm_fbits(q1[1]) == (unsigned)t && nm_fbits(q1[3]) == (unsigned)t &&
+                              nm_fbits(q2[1]) == (unsigned)t && nm_fbits(q2[3]) == (unsigned)t && nm_fbits(q3[1]) == (unsigned)t && nm_fbits(q3[3]) == (unsigned)t);
+                x0 = f32x4{q0[0], q0[2], q1[0], q1[2]}; x1 = f32x4{q2[0], q2[2], q3[0], q3[2]};
+            }
+            if (!wave_alive) break;
+#pragma unroll
+            for (int i = 0; i < HR; ++i) {
+                const int r = gw + NWV * i;
+                float acc = 0.f;
+                acc += dot4(wh[i][0], x0);
+                acc += dot4(wh[i][1], x1);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+                if (lane == 0 && r < 384 + 3 * H) {
+                    const float v = acc + bh[i];
+                    if (r < 128) gran_store(a.g_hid + (size_t)b * 128 + r, lrelu(v, 0.01f), tag);
+                    else if (r < 256) gran_store(a.g_rh + (size_t)b * 128 + (r - 128), v, tag);
+                    else if (r < 384) gran_store(a.g_jh + (size_t)b * 128 + (r - 256), v, tag);
+                    else gran_store(a.g_gh + (size_t)b * 3 * H + (r - 384), v, tag);
+                }
+            }
+        }
+        // ---- GRU unit j of step t: keypoints | latent of the middle workgroups, W_hh h + b_hh of three h-phase rows
+#pragma unroll 1
+        for (int b = 0; b < B && wave_alive && j < H; ++b) {
+            const nm_gran* pk = a.g_kpz + (size_t)b * (S4 + Z);
+            const nm_gran* pg = a.g_gh + (size_t)b * 3 * H;
+            // (h_t[b][j] for the blend: its granule carries tag t - it was complete when this wave ran the h-phase; t = 0: the call's input)
+            const nm_gran* pp = t == 0 ? pg + jc : a.g_h[(t - 1) & 1] + (size_t)b * H + jc;
+            f32x4 k0, k1, z0, z1; nm_f32x2 gr, gz, gn, gp;
+            NM_CHAIN_POLL(gran_ld_4q4(pk + (kq ? lane * 4 : 0), pk + (kq ? lane * 4 : 0) + 2, pk + S4 + (zq ? lane * 4 : 0), pk + S4 + (zq ? lane * 4 : 0) + 2,
+                                      pg + jc, pg + H + jc, pg + 2 * H + jc, pp, k0, k1, z0, z1, gr, gz, gn, gp),
+                          nm_fbits(k0[1]) == tag && nm_fbits(k0[3]) == tag && nm_fbits(k1[1]) == tag && nm_fbits(k1[3]) == tag &&
+                          nm_fbits(z0[1]) == tag && nm_fbits(z0[3]) == tag && nm_fbits(z1[1]) == tag && nm_fbits(z1[3]) == tag &&
+                          nm_fbits(gr[1]) == tag && nm_fbits(gz[1]) == tag && nm_fbits(gn[1]) == tag && (t == 0 || nm_fbits(gp[1]) == (unsigned)t));
+            if (!wave_alive) break;
+            const float hpv = t == 0 ? a.h0[(size_t)b * a.ldh0 + jc] : gp[0];
+            const f32x4 xkq = {k0[0], k0[2], k1[0], k1[2]}, xzq = {z0[0], z0[2], z1[0], z1[2]};
+            float ar = 0.f, az = 0.f, an = 0.f;
+            if (kq) { ar += dot4(wk[0], xkq); az += dot4(wk[1], xkq); an += dot4(wk[2], xkq); }
+            if (zq) { ar += dot4(wz[0], xzq); az += dot4(wz[1], xzq); an += dot4(wz[2], xzq); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { ar += __shfl_xor(ar, off); az += __shfl_xor(az, off); an += __shfl_xor(an, off); }
+            if (lane == 0) {
+                const float rg = sigmoidf((ar + bi[0]) + gr[0]);
+                const float zg = sigmoidf((az + bi[1]) + gz[0]);
+                const float ng = tanhf((an + bi[2]) + rg * gn[0]);
+                const float hn = (hpv - ng) * zg + ng;
+                gran_store(a.g_h[t & 1] + (size_t)b * H + j, hn, tag);
+                if (t == T - 1) a.h_out[(size_t)b * H + j] = hn;
+            }
+        }
+    }
+}
+
 // ---- posterior step of encode (inference), middle phases: one workgroup per (sample, batch element) ---------------------------------
 // NOT the default (NM355_VRNN_POSTMID=1 selects it; parity-tested): measured against the six-launch step once the row kernels had
 // been fixed (pick_nb), it loses - encode alone 52.6 us per timestep against 40.7, and in the forward +0.4 ms: a 1024-thread,
@@ -1272,7 +1578,9 @@ int ready(nm_ctx* c, const char* who, bool need_tree) {
     if (!c) { nm_set_error("%s: null ctx", who); return NM_ERR_ARG; }
     if (!c->has_weights) { nm_set_error("%s: nm_ctx_set_weights has not been called", who); return NM_ERR_STATE; }
     if (need_tree && !c->vrnn.has_tree) { nm_set_error("%s: nm_vrnn_set_tree has not been called (the reference builds it in encode())", who); return NM_ERR_STATE; }
-    return nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
+    int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
+    if (!rc) rc = nm_nf_poll(c);            // deferred status of earlier calls (range guard, rollout time-out)
+    return rc;
 }
 
 int max_fk_lds(nm_ctx* c, int S) {
@@ -1579,7 +1887,7 @@ int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grad
 // the weight buffers were re-allocated or the tree changed (epochs below); weight VALUES may change freely (same buffers).
 struct RolloutBufs {
     StepBufs sb;
-    float *kp_cond, *eps_post, *eps_prior, *out_cond, *out_gen, *h_in, *offset, *hbuf[2], *zbuf;
+    float *kp_cond, *eps_post, *eps_prior, *out_cond, *out_gen, *h_in, *offset, *hbuf[2], *zbuf, *chain_g;         // chain_g: the persistent rollout kernel's granule buffers (+ its abort word)
 };
 struct RolloutGraph {
     int kind, B, Tcond, Ttot, S;
@@ -1610,7 +1918,7 @@ static size_t rollout_floats(int B, int Tcond, int Ttot, int S, int K, int Z, in
     const size_t S4 = (size_t)K * 4, Tg = Ttot - Tcond;
     return (size_t)B * (4 * 128 + 3 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K + 9 * K + 1) + (B >= NM_GEMM_MIN_BATCH ? (size_t)B * 3 * H : 0)
          + (size_t)B * Tcond * S4 * 2 + (size_t)Tcond * S * B * Z + Tg * B * Z + (size_t)B * Tg * S4 + (size_t)B * K * 3 + 3 * (size_t)B * H + (size_t)B * Z
-         + 64 * 32;          // (256-byte alignment of each of the ~28 pieces)
+         + 2 * (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) + 64 + 64 * 33;          // (256-byte alignment of each of the ~29 pieces)
 }
 static RolloutBufs carve_rollout(Arena& ws, int B, int Tcond, int Ttot, int S, int K, int Z, int H) {
     RolloutBufs r;
@@ -1620,6 +1928,7 @@ static RolloutBufs carve_rollout(Arena& ws, int B, int Tcond, int Ttot, int S, i
     r.out_cond = ws.f((size_t)B * Tcond * S4 + 1); r.out_gen = ws.f((size_t)B * Tg * S4 + 1);
     r.h_in = ws.f((size_t)B * H); r.offset = ws.f((size_t)B * K * 3);
     r.hbuf[0] = ws.f((size_t)B * H); r.hbuf[1] = ws.f((size_t)B * H); r.zbuf = ws.f((size_t)B * Z);
+    r.chain_g = ws.f(2 * (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) + 64);
     return r;
 }
 
@@ -1635,7 +1944,10 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         hipLaunchKernelGGL(broadcast_rows_kernel, dim3((H * B + 255) / 256), dim3(256), 0, c->stream, c->vrnn.h0, H, r.hbuf[0], H, B);
         h = r.hbuf[0]; nxt = 1;
     }
-    for (int t = 0; t < Ttot; ++t) {
+    // the prior steps as ONE persistent launch (vrnn_prior_chain_kernel) when the shape allows: weights register-resident for the whole
+    // chain, three counter hand-offs per step instead of three launches (NM355_VRNN_CHAIN=0: the launch-per-phase steps, A/B)
+    const bool chain = nm_ls().vrnn_chain && nm_ls().vrnn_mid && Tg >= 1 && B <= 4 && K % 8 == 0 && K <= 32 && Z == 128 && H == 512 && c->vrnn_cnt && c->nf_flag;
+    for (int t = 0; t < (chain ? Tcond : Ttot); ++t) {
         StepIO io;
         const bool post = t < Tcond;
         io.h = h; io.ldh = H;
@@ -1648,6 +1960,41 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         io.hout = r.hbuf[nxt]; io.ldho = H; io.want_prior = false;
         if ((rc = vrnn_step(c, r.sb, io, B, S))) return rc;
         h = io.hout; nxt ^= 1;
+    }
+    if (chain) {
+        const VrnnW& w = c->vrnn;
+        ChainArgs a;
+        a.w_prior0 = w.prior0.w; a.b_prior0 = w.prior0.b; a.w_root0 = w.root0.w; a.b_root0 = w.root0.b; a.w_joint0 = w.joint0.w; a.b_joint0 = w.joint0.b;
+        a.w_hh = w.w_hh; a.b_hh = w.b_hh; a.w_ih = w.w_ih; a.b_ih = w.b_ih;
+        MidArgs& m = a.mid;
+        m.hid_prior = m.rh = m.jh = m.eps = nullptr; m.offset = r.offset;
+        m.w_p2 = w.prior2.w; m.b_p2 = w.prior2.b; m.w_root0 = w.root0.w; m.w_joint0 = w.joint0.w;
+        m.w_root2 = w.root2.w; m.b_root2 = w.root2.b; m.w_joint2 = w.joint2.w; m.b_joint2 = w.joint2.b;
+        m.order = w.order; m.parents = w.parents; m.lvl_joint = w.lvl_joint; m.lvl_start = w.lvl_start; m.nlevels = w.nlevels;
+        m.out_kp = nullptr; m.ldkp = 0; m.out_z = nullptr; m.ldz = 0; m.B = B; m.K = K; m.Z = Z; m.H = H;
+        a.h0 = h; a.ldh0 = H; a.eps = r.eps_prior; a.out_kp = r.out_gen; a.ldkp = Tg * S4;
+        a.h_out = r.hbuf[nxt];
+        // granule buffers: [hid | rh | jh : B x 128 each][gh : B x 3H][kpz : B x (4K + Z)][h0 | h1 : B x H each][abort word]
+        nm_gran* gb = reinterpret_cast<nm_gran*>(r.chain_g);
+        a.g_hid = gb; a.g_rh = gb + (size_t)B * 128; a.g_jh = gb + (size_t)2 * B * 128; a.g_gh = gb + (size_t)3 * B * 128;
+        a.g_kpz = a.g_gh + (size_t)B * 3 * H; a.g_h[0] = a.g_kpz + (size_t)B * (S4 + Z); a.g_h[1] = a.g_h[0] + (size_t)B * H;
+        a.abort = reinterpret_cast<unsigned*>(a.g_h[1] + (size_t)B * H);
+        a.status = c->nf_flag;
+        a.B = B; a.T = Tg; a.K = K; a.Z = Z; a.H = H;
+        { static const int bo = getenv("NM355_CHAIN_BACKOFF") ? atoi(getenv("NM355_CHAIN_BACKOFF")) : 0; a.backoff = bo;     // (0 / 1 / 4 / 16 / 64 units: 17.0 / 18.0 / 17.3 / 19.5 / 25.9 us per step at B = 1) }
+        const size_t gbytes = (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) * sizeof(nm_gran) + 64;
+        if ((rc = nm_check_hip(hipMemsetAsync(r.chain_g, 0, gbytes, c->stream), "rollout: granule buffers"))) return rc;
+        {
+            static NmDeviceOnce attr_set;
+            if (!attr_set.done()) {
+                if ((rc = nm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_prior_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(vrnn_prior_chain)"))) return rc;
+                attr_set.mark();
+            }
+        }
+        hipLaunchKernelGGL(vrnn_prior_chain_kernel, dim3(NM_CHAIN_NW + B), dim3(NM_CHAIN_T), (size_t)(3 + 7 * K) * 128 * sizeof(float), c->stream, a);
+        if ((rc = nm_check_hip(hipGetLastError(), "vrnn_prior_chain launch"))) return rc;
+        *cur_out = nxt;                 // the last step's state, as plain floats
+        return NM_OK;
     }
     *cur_out = nxt ^ 1;                 // the hbuf holding the last state
     return nm_check_hip(hipGetLastError(), "rollout launches");
@@ -1731,6 +2078,7 @@ static int rollout_impl(nm_ctx* c, int kind, const float* kp_cond, const float* 
     RolloutBufs r;
     r.sb = alloc_step(c->ws, B, S, K, Z, H);
     r.hbuf[0] = c->ws.f((size_t)B * H); r.hbuf[1] = c->ws.f((size_t)B * H); r.zbuf = c->ws.f((size_t)B * Z);
+    r.chain_g = c->ws.f(2 * (size_t)B * (3 * 128 + 3 * H + K * 4 + Z + 2 * H) + 64);
     r.offset = kind == 0 ? c->ws.f((size_t)B * K * 3) : const_cast<float*>(offset_in);
     if (c->ws.overflow) { nm_set_error("vrnn rollout: workspace overflow"); return NM_ERR_STATE; }
     r.kp_cond = const_cast<float*>(kp_cond); r.eps_post = const_cast<float*>(eps_post); r.eps_prior = const_cast<float*>(eps_prior);
@@ -1748,7 +2096,9 @@ int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_po
         nm_set_error("vrnn_generate: bad argument"); return NM_ERR_ARG;
     }
     if ((rc = max_fk_lds(c, S))) return rc;
-    return rollout_impl(c, 0, keypoints_cond, eps_post, eps_prior, nullptr, nullptr, B, Tcond, Ttot, S, out_cond, out_gen, h_last);
+    rc = rollout_impl(c, 0, keypoints_cond, eps_post, eps_prior, nullptr, nullptr, B, Tcond, Ttot, S, out_cond, out_gen, h_last);
+    if (!rc) nm_nf_post(c, "nm_vrnn_generate");
+    return rc;
 }
 
 int nm_vrnn_rollout(nm_ctx* c, const float* h_in, const float* offset, const float* eps, int32_t B, int32_t T, float* kp_out, float* h_out) { NmScope nm_scope_(c);
@@ -1756,7 +2106,9 @@ int nm_vrnn_rollout(nm_ctx* c, const float* h_in, const float* offset, const flo
     if (rc) return rc;
     if (!h_in || !offset || !eps || !kp_out || B <= 0 || T <= 0) { nm_set_error("vrnn_rollout: bad argument"); return NM_ERR_ARG; }
     if ((rc = max_fk_lds(c, 1))) return rc;
-    return rollout_impl(c, 1, nullptr, nullptr, eps, h_in, offset, B, 0, T, 1, nullptr, kp_out, h_out);
+    rc = rollout_impl(c, 1, nullptr, nullptr, eps, h_in, offset, B, 0, T, 1, nullptr, kp_out, h_out);
+    if (!rc) nm_nf_post(c, "nm_vrnn_rollout");
+    return rc;
 }
 
 int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* kp_obs, const float* offset, const float* eps,

@@ -375,6 +375,46 @@ def test_config5_rollout64(B):
     print("config-5 B=%d: %.1f us per VRNN step (eager, %d steps)" % (B, us, Tt))
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 4])
+def test_persistent_rollout_is_bit_identical_to_launch_per_phase_steps(B):
+    """vrnn_prior_chain_kernel (round 4; BASELINE north_star "one kernel per timestep" - here the whole prior chain of a rollout is ONE
+    persistent launch, weights register-resident, data-tagged granule hand-offs) against the three-launches-per-step path
+    (NM355_VRNN_CHAIN=0, read when a context is created): HSVRNNBVH.generate and HSVRNNBVH.rollout, keypoints and the final state bit
+    for bit, both contexts alive in one process; the launch-per-phase path itself is held to the oracle by test_config5_rollout64."""
+    o = HotPathOptions(grid_size=32, Tcond=5)
+    sd = synth.make_state_dict(o, seed=21, variant="default")
+    nets = {}
+    for name, chain in (("launches", "0"), ("chain", "1")):
+        os.environ["NM355_VRNN_CHAIN"] = chain
+        try:
+            nets[name] = _net(o, sd)
+            with torch.no_grad():          # (creates the context while the switch is set)
+                nets[name].kypt_detector.get_affinity()
+        finally:
+            del os.environ["NM355_VRNN_CHAIN"]
+    K, Z, Tc, Tt = o.nkeypoints, o.nlatent_kypt, 5, 37
+    g = torch.Generator().manual_seed(B)
+    kp = (torch.rand(B, Tc, K, 4, generator=g) * 1.6 - 0.8).cuda()
+    e_post = synth.make_eps((Tc, 10, B, Z), seed=50).cuda(); e_prior = synth.make_eps((Tt - Tc, B, Z), seed=51).cuda()
+    with torch.no_grad():
+        aff = O.affinity_v3(sd["kypt_detector.affinity_params"]).cuda()
+        outs = {n: net.dyna_module.generate(kp, aff, Ttot=Tt, Tcond=Tc, eps_post=e_post, eps_prior=e_prior) for n, net in nets.items()}
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs["chain"]["keypoints_gen"]).all()
+        assert torch.equal(outs["chain"]["keypoints_gen"], outs["launches"]["keypoints_gen"])
+        assert torch.equal(outs["chain"]["keypoints_cond"], outs["launches"]["keypoints_cond"])
+        h = (torch.randn(B, o.nhidden_kypt, generator=g) * 0.1).cuda()
+        eps = synth.make_eps((33, B, Z), seed=77).cuda()
+        r = {n: net.dyna_module.rollout(h, net.dyna_module.get_offset(kp), eps) for n, net in nets.items()}
+        # twice through the captured graph (the granule buffers are re-zeroed by the graph's memset node)
+        r2 = nets["chain"].dyna_module.rollout(h, nets["chain"].dyna_module.get_offset(kp), eps)
+        torch.cuda.synchronize()
+    assert torch.equal(r["chain"][0], r["launches"][0]) and torch.equal(r["chain"][1], r["launches"][1])
+    assert torch.equal(r2[0], r["launches"][0]) and torch.equal(r2[1], r["launches"][1])
+    for n in nets.values():
+        n.check_finite()               # (also consumes a rollout time-out status, if any: bit 1 of the status word)
+
+
 @pytest.mark.parametrize("G,N,scale", [(64, 20000, 1.0), (64, 5000, 0.9), (96, 3000, 1.0)])
 def test_voxelize_on_device_bit_exact(G, N, scale):
     """episodic normalisation + voxelisation; integer voxel indices must be bit-exact against the
