@@ -1981,7 +1981,8 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         a.abort = reinterpret_cast<unsigned*>(a.g_h[1] + (size_t)B * H);
         a.status = c->nf_flag;
         a.B = B; a.T = Tg; a.K = K; a.Z = Z; a.H = H;
-        { static const int bo = getenv("NM355_CHAIN_BACKOFF") ? atoi(getenv("NM355_CHAIN_BACKOFF")) : 0; a.backoff = bo;     // (0 / 1 / 4 / 16 / 64 units: 17.0 / 18.0 / 17.3 / 19.5 / 25.9 us per step at B = 1) }
+        // poll back-off in s_sleep(2) units (0 / 1 / 4 / 16 / 64: 17.0 / 18.0 / 17.3 / 19.5 / 25.9 us per step at B = 1)
+        { static const int bo = getenv("NM355_CHAIN_BACKOFF") ? atoi(getenv("NM355_CHAIN_BACKOFF")) : 0; a.backoff = bo; }
         const size_t gbytes = (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) * sizeof(nm_gran) + 64;
         if ((rc = nm_check_hip(hipMemsetAsync(r.chain_g, 0, gbytes, c->stream), "rollout: granule buffers"))) return rc;
         {
