@@ -193,11 +193,20 @@ def test_g4_generate32(golden_dir):
     out = net.generate(vox.cuda(), ACTS, eps_post=e_post.cuda(), eps_prior=e_prior.cuda())
     torch.cuda.synchronize()
     assert np.array_equal(net.dyna_module.parents.cpu().numpy(), g["parents"])
-    e = _err(out["keypoints"], g["keypoints"])
-    print("generate keypoints err %.3e" % e)
-    assert e < 1e-3                      # end-to-end through detector + FK chain + rollout
-    assert _err(out["keypoints"][:, :Tc], g["keypoints"][:, :Tc]) < KP_TOL
-    assert _err(out["gen"][..., ::2, ::2, ::2], g["gen_sub"]) < 2e-2
+    # The parity CLAIM is per step (north_star: 1e-4): the conditioned steps and the FIRST generated step - one VRNN step away from
+    # states that are themselves within tolerance - must be within 1e-4.  The later free-running steps feed their own output back
+    # through a random-weight recurrence, which amplifies fp32 rounding differences step over step (SURVEY 7 'Error amplification';
+    # the teacher-forced per-step bound over 64 steps is test_config5_rollout64): they are held to the SAME 1e-4 and to the measured
+    # amplification of the first-step error (x3.4 over the generated steps on MI355X: 4.8e-7 -> 1.6e-6), not to a looser tolerance.
+    e_cond = _err(out["keypoints"][:, :Tc], g["keypoints"][:, :Tc])
+    e_first = _err(out["keypoints"][:, Tc:Tc + 1], g["keypoints"][:, Tc:Tc + 1])
+    e_free = _err(out["keypoints"], g["keypoints"])
+    amp = e_free / max(e_first, 1e-7)
+    print("generate: conditioned steps %.3e, first generated step %.3e, free-running over %d steps %.3e (amplification x%.1f)" % (e_cond, e_first, T - Tc, e_free, amp))
+    assert e_cond < KP_TOL and e_first < KP_TOL and e_free < KP_TOL
+    assert amp < 10.0, amp
+    # decoded occupancy of the generated frames: the decoder is Lipschitz ~20 in the keypoints (sharpness-10 sigmoid): same amplification
+    assert _err(out["gen"][..., ::2, ::2, ::2], g["gen_sub"]) < 20.0 * max(e_free, 1e-5) + 1e-3
     assert out["A_hats"] is None
 
 
@@ -288,6 +297,34 @@ def test_config2_full_size_vs_oracle(mode, path):
     torch.cuda.synchronize()
     for k in ("keypoints", "recon", "heatmaps", "z_kypts", "h_kypts"):
         assert torch.equal(out[k], out2[k]), f"non-deterministic {k}"
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_bernoulli_clip_64cubed_vs_oracle(path):
+    """The second synthetic generator of SURVEY 8(d) at the bench grid: Bernoulli(p = 0.03) occupancy, 64^3, B = 1, T = 3
+    (the trajectory term of the graph loss is undefined - NaN in the reference as well - for fewer than three frames).  No 4x8x8
+    brick of such a clip is empty, so the inference path's sparse first layer and the pool conv behind it run dense - the input class
+    the figure clips never exercise at this size."""
+    o = HotPathOptions(grid_size=64)
+    sd = synth.make_state_dict(o, seed=9, variant="peaky")
+    vox = synth.bernoulli_clip(1, 3, 64, p=0.03, seed=5)
+    eps = synth.make_eps((3, 10, 1, o.nlatent_kypt), seed=6)
+    key = ("bern64",)
+    if key not in _ORACLE_CACHE:
+        with torch.no_grad():
+            _ORACLE_CACHE[key] = O.nm_forward(sd, o, vox, eps)
+    ref = _ORACLE_CACHE[key]
+    net = _net(o, sd)
+    out = _call(path, net, vox.cuda(), ACTS, eps=eps.cuda())
+    torch.cuda.synchronize()
+    e_kp, e_z = _err(out["keypoints"], ref["keypoints"]), _err(out["z_kypts"], ref["z_kypts"])
+    print("bernoulli 64^3 (%s): keypoints %.3e latents %.3e" % (path, e_kp, e_z))
+    assert e_kp < KP_TOL and e_z < KP_TOL and _err(out["h_kypts"], ref["h_kypts"]) < KP_TOL
+    assert np.array_equal(out["best_idx"].cpu().numpy(), ref["best_idx"].numpy().astype(np.int32))
+    _check_losses(out, [float(ref[k]) for k in DETECTOR_LOSS_KEYS])
+    margin = (ref["recon"] - 0.5).abs()
+    mism = (((out["recon"].cpu() >= 0.5) != (ref["recon"] >= 0.5)) & (margin > 1e-3)).sum().item()
+    assert mism == 0
 
 
 @pytest.mark.parametrize("path", PATHS)
@@ -450,9 +487,14 @@ def test_generation_driver_vs_oracle():
     with torch.no_grad():
         ref = O.sample_generation(sd, o, vox, Tg, S, e_post, e_prior)
     assert _err(out["keypoints_cond"], ref["keypoints_cond"]) < KP_TOL
+    # per-step claim on the conditioned steps and the first two generated steps (1e-4); the free-running tail is held to the measured
+    # amplification of that error through the recurrence (see test_g4_generate32)
+    e_first = _err(out["keypoints_gen"][:, :2], ref["keypoints_gen"][:, :2])
     e = _err(out["keypoints_gen"], ref["keypoints_gen"])
-    print("generation driver: generated keypoints err %.3e" % e)
-    assert e < 1e-3 and _err(out["keypoints_gen"][:, :2], ref["keypoints_gen"][:, :2]) < KP_TOL
+    amp = e / max(e_first, 1e-7)
+    print("generation driver: first two generated steps %.3e, all %d generated steps %.3e (amplification x%.1f)" % (e_first, Tg, e, amp))
+    assert e_first < KP_TOL and e < KP_TOL               # measured 1.4e-6 -> 2.2e-6 (x1.6)
+    assert amp < 10.0, amp
     assert out["voxels"].shape == (S, Tc + Tg, 1, 32, 32, 32)
     margin = (ref["voxels_raw"] - 0.5).abs()
     mism = ((out["voxels"].cpu() != ref["voxels"]) & (margin > 1e-3)).sum().item()
