@@ -48,7 +48,8 @@ NmLaunchState::NmLaunchState()
       hg_core(env_int("NM355_HG_CORE", 1)),           // 0: the two lowest hourglass levels as separate launches in inference too (A/B)
       f16p_dma(env_int("NM355_F16P_DMA", 0)),         // 1: conv_f16p2's producers copy the weights by LDS-DMA instead of through registers (A/B)
       clip_occ_mfma(env_int("NM355_CLIP_OCC_MFMA", 1)),  // 0: the clip-mean net's first-layer weight gradient as the dense all-frames kernel (A/B)
-      vrnn_chain(env_int("NM355_VRNN_CHAIN", 1))         // 0: the prior steps of a rollout as three launches per step instead of one persistent launch (A/B)
+      vrnn_chain(env_int("NM355_VRNN_CHAIN", 1)),        // 0: the prior steps of a rollout as three launches per step instead of one persistent launch (A/B)
+      wgrad_k2f16(env_int("NM355_WGRAD_K2F16", 1))      // 0: the k2 s2 weight gradients on the fp32-MFMA kernel in every conv mode (A/B)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); }
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
@@ -547,7 +548,7 @@ int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
     TensorRef a = make_ref(in, in_scale, in_shift, in_slope, N, D, H, W, Cin);
     TensorRef dyT = make_ref(dy, nullptr, nullptr, 1.0f, N, OD, OH, OW, Cout);
     float* ws = ctx->ws.f(wsf);
-    if ((rc = nm_launch_wgrad(dyT, a, 2, 2, 0, Cout, ws, d_weight, s))) return rc;       // roles swapped: [Cin][Cout][8] = IODHW
+    if ((rc = nm_launch_wgrad(dyT, a, 2, 2, 0, Cout, ws, d_weight, s, nullptr, nm_conv_get_mode() != 0))) return rc;       // roles swapped: [Cin][Cout][8] = IODHW
     float* bp = ctx->ws.f((size_t)N * nbb * Cout * 2);
     if ((rc = nm_launch_gnb_partials(dy, dyT, bp, s))) return rc;
     if ((rc = nm_launch_sum_partials(bp, N * nbb, Cout, d_bias, s))) return rc;

@@ -508,6 +508,189 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(WgradParams p) {
     }
 }
 
+// ---- k2 s2 weight gradient (pool convs; transposed convs with the roles swapped) on the f16 matrix cores -------------------------
+// dW[co][tap][ci] = sum_v dY[v][co] * act(X[2v + tap][ci]): a GEMM with K = all coarse voxels, M = Cout, N = 8 taps x Cin, and no halo -
+// every fine voxel belongs to exactly one (coarse voxel, tap).  wgrad_kernel ran it on v_mfma_f32_32x32x2_f32 with one workgroup per
+// 32 x 32 channel tile pair (each staging its own slices: the 64^3 -> 32^3 layer took 1.5 ms in 16-bit storage, 1.34 GB of tensors,
+// and held up the GroupNorm passes of the main queue beside it).  Here a workgroup owns a 32-channel slice of X and ALL of dY's
+// channels (MT tiles of 32), so X - the large tensor - is read exactly once; brick = 1 x 8 x 8 coarse voxels = 2 x 16 x 16 fine.
+// The staging transposes into [channel][fine row][x parity][8 halves] / [channel][coarse row][8 halves] planes (16-B operand
+// reads: 8 consecutive coarse x = 8 K elements of v_mfma_f32_32x32x16_f16), split hi + lo * 2^-11 with three products as in
+// wgrad16_kernel (SINGLE: hi only, conv modes 3 / 4).  Wave w takes the taps (dz, dy) = (w >> 1, w & 1), both dx: per k-step MT dY
+// operands + 2 X operands for 2 MT MFMAs.  The next brick's loads are issued before the MFMA phase and converted after it.
+// HX / HD: X / dY stored as bfloat16 (16-byte loads of 8 channels).  Partials in wgrad_kernel's layout (same reduce).
+#define W2_PA (32 * 32 + 16)
+#define W2_PD (8 * 16 + 16)
+__host__ __device__ constexpr size_t w2_lds_bytes(int mt, bool single) { return (size_t)(single ? 1 : 2) * (32 * W2_PA + (size_t)mt * 32 * W2_PD); }
+
+template <int MT, bool SINGLE, bool HX, bool HD>
+__global__ __launch_bounds__(256) void wgrad16k2_kernel(WgradParams p) {
+    extern __shared__ char lds8[];
+    char* X_hi = lds8; char* D_hi = X_hi + 32 * W2_PA;
+    char* X_lo = D_hi + MT * 32 * W2_PD; char* D_lo = X_lo + 32 * W2_PA;         // (SINGLE: never touched)
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, w = tid >> 6;
+    const int nt = blockIdx.y, n0 = nt * 32;
+    const int OD = p.dy.D, OH = p.dy.H, OW = p.dy.W, nby = OH >> 3, nbx = OW >> 3;
+    const int per_frame = OD * nby * nbx, total = p.in.N * per_frame;
+    f32x16 acc[2][MT], accl[2][MT];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[d][m][r] = 0.f; accl[d][m][r] = 0.f; }
+    // staging tasks.  X: one fine row (2 x 16 rows of 16 voxels) x one channel group per thread - fp32: 8 quads x 16 voxels; bfloat16:
+    // 4 octets x 2 half rows of 8 voxels.  dY: one coarse row of 8 voxels x one channel group (threads beyond 8 rows idle).
+    constexpr int XL = HX ? 8 : 16, XG = HX ? 8 : 4, DG = HD ? 8 : 4;
+    const int frow = tid >> 3, xg = HX ? (tid & 3) : (tid & 7), xh = HX ? ((tid >> 2) & 1) : 0;
+    const int xc = n0 + XG * xg;
+    const bool xok = xc < p.Nc;
+    constexpr int DQ = MT * 32 / DG;                      // channel groups per dY voxel
+    const int drow = tid / DQ, dg = tid % DQ, dc = DG * dg;
+    const bool dok = drow < 8 && dc < p.M;
+    u32x4 xr[XL], dr[8];
+    int n_st = 0;                                         // frame of the brick held in xr / dr
+    auto fetch = [&](int b) __attribute__((always_inline)) {
+        const int n = b / per_frame; int r = b % per_frame;
+        const int bx = r % nbx; r /= nbx;
+        const int by = r % nby, oz = r / nby;
+        n_st = n;
+#pragma unroll
+        for (int x = 0; x < XL; ++x) xr[x] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int x = 0; x < 8; ++x) dr[x] = u32x4{0u, 0u, 0u, 0u};
+        if (xok) {
+            const size_t e = ((((size_t)n * p.in.D + 2 * oz + (frow >> 4)) * p.in.H + 16 * by + (frow & 15)) * p.in.W + 16 * bx + 8 * xh) * p.in.C + xc;
+            const char* src = reinterpret_cast<const char*>(p.in.p) + e * (HX ? 2 : 4);
+            const size_t pitch = (size_t)p.in.C * (HX ? 2 : 4);
+#pragma unroll
+            for (int x = 0; x < XL; ++x) xr[x] = *reinterpret_cast<const u32x4*>(src + x * pitch);
+        }
+        if (dok) {
+            const size_t e = ((((size_t)n * OD + oz) * OH + 8 * by + drow) * OW + 8 * bx) * p.dy.C + dc;
+            const char* src = reinterpret_cast<const char*>(p.dy.p) + e * (HD ? 2 : 4);
+            const size_t pitch = (size_t)p.dy.C * (HD ? 2 : 4);
+#pragma unroll
+            for (int x = 0; x < 8; ++x) dr[x] = *reinterpret_cast<const u32x4*>(src + x * pitch);
+        }
+    };
+    // channel j of the group out of the raw words of voxel x
+    auto xval = [&](int x, int j) __attribute__((always_inline)) -> float {
+        if constexpr (HX) return (j & 1) ? nm_bf_hi(xr[x][j >> 1]) : nm_bf_lo(xr[x][j >> 1]);
+        else return __builtin_bit_cast(float, (unsigned)xr[x][j]);
+    };
+    auto dval = [&](int x, int j) __attribute__((always_inline)) -> float {
+        if constexpr (HD) return (j & 1) ? nm_bf_hi(dr[x][j >> 1]) : nm_bf_lo(dr[x][j >> 1]);
+        else return __builtin_bit_cast(float, (unsigned)dr[x][j]);
+    };
+    auto store = [&]() __attribute__((always_inline)) {
+        {
+            float sc[XG], sh[XG];
+#pragma unroll
+            for (int j = 0; j < XG; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+            if (p.in.scale && xok) {
+#pragma unroll
+                for (int j = 0; j < XG; j += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.in.scale + (size_t)n_st * p.in.C + xc + j);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.in.shift + (size_t)n_st * p.in.C + xc + j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sc[j + i] = a[i]; sh[j + i] = c[i]; }
+                }
+            }
+            const float slope = p.in.slope;
+#pragma unroll
+            for (int j = 0; j < XG; ++j) {
+                unsigned hi[2][XL / 4], lo[2][XL / 4];
+#pragma unroll
+                for (int i = 0; i < XL / 4; ++i)
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        float a0 = fmaf(xval(4 * i + par, j), sc[j], sh[j]), a1 = fmaf(xval(4 * i + 2 + par, j), sc[j], sh[j]);
+                        if (slope != 1.0f) { a0 = fmaxf(a0, a0 * slope); a1 = fmaxf(a1, a1 * slope); }
+                        if (!xok) { a0 = 0.f; a1 = 0.f; }
+                        hi[par][i] = pack_split(a0, a1, lo[par][i]);
+                    }
+                char* dh = X_hi + (XG * xg + j) * W2_PA + frow * 32 + xh * 8;
+                char* dl = X_lo + (XG * xg + j) * W2_PA + frow * 32 + xh * 8;
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    if constexpr (HX) {
+                        *reinterpret_cast<nm_u32x2*>(dh + par * 16) = nm_u32x2{hi[par][0], hi[par][1]};
+                        if constexpr (!SINGLE) *reinterpret_cast<nm_u32x2*>(dl + par * 16) = nm_u32x2{lo[par][0], lo[par][1]};
+                    } else {
+                        *reinterpret_cast<u32x4*>(dh + par * 16) = u32x4{hi[par][0], hi[par][1], hi[par][2], hi[par][3]};
+                        if constexpr (!SINGLE) *reinterpret_cast<u32x4*>(dl + par * 16) = u32x4{lo[par][0], lo[par][1], lo[par][2], lo[par][3]};
+                    }
+                }
+            }
+        }
+        if (drow < 8) {
+            float sc[DG], sh[DG];
+#pragma unroll
+            for (int j = 0; j < DG; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+            if (p.dy.scale && dok) {
+#pragma unroll
+                for (int j = 0; j < DG; j += 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.dy.scale + (size_t)n_st * p.dy.C + dc + j);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.dy.shift + (size_t)n_st * p.dy.C + dc + j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sc[j + i] = a[i]; sh[j + i] = c[i]; }
+                }
+            }
+            const float slope = p.dy.slope;
+#pragma unroll
+            for (int j = 0; j < DG; ++j) {
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float a0 = fmaf(dval(2 * i, j), sc[j], sh[j]), a1 = fmaf(dval(2 * i + 1, j), sc[j], sh[j]);
+                    if (slope != 1.0f) { a0 = fmaxf(a0, a0 * slope); a1 = fmaxf(a1, a1 * slope); }
+                    if (!dok) { a0 = 0.f; a1 = 0.f; }
+                    hi[i] = pack_split(a0, a1, lo[i]);
+                }
+                *reinterpret_cast<u32x4*>(D_hi + (dc + j) * W2_PD + drow * 16) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                if constexpr (!SINGLE) *reinterpret_cast<u32x4*>(D_lo + (dc + j) * W2_PD + drow * 16) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            }
+        }
+    };
+    int b = blockIdx.x;
+    if (b < total) fetch(b);
+    const int tap_row = (w >> 1) * 16 + (w & 1);           // fine row of coarse row 0 for this wave's (dz, dy)
+    const char* bh_base = X_hi + l31 * W2_PA + tap_row * 32; const char* bl_base = X_lo + l31 * W2_PA + tap_row * 32;
+    const char* ah_base = D_hi + l31 * W2_PD; const char* al_base = D_lo + l31 * W2_PD;
+    for (; b < total; b += p.S) {
+        __syncthreads();
+        store();
+        __syncthreads();
+        if (b + p.S < total) fetch(b + p.S);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int row = 2 * s4 + lh;
+            const half8 bh0 = *reinterpret_cast<const half8*>(bh_base + row * 64), bh1 = *reinterpret_cast<const half8*>(bh_base + row * 64 + 16);
+            half8 bl0 = bh0, bl1 = bh1;
+            if constexpr (!SINGLE) { bl0 = *reinterpret_cast<const half8*>(bl_base + row * 64); bl1 = *reinterpret_cast<const half8*>(bl_base + row * 64 + 16); }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const half8 ah = *reinterpret_cast<const half8*>(ah_base + m * 32 * W2_PD + row * 16);
+                half8 al = ah;
+                if constexpr (!SINGLE) al = *reinterpret_cast<const half8*>(al_base + m * 32 * W2_PD + row * 16);
+                W16_MMA(acc[0][m], accl[0][m], ah, al, bh0, bl0)
+                W16_MMA(acc[1][m], accl[1][m], ah, al, bh1, bl1)
+            }
+        }
+    }
+    // partial buffer: [slot][tile = m * n_tiles + nt][tap][32 x 32]
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m * 32 >= p.M) continue;
+            float* dst = p.part + (((size_t)blockIdx.x * ((p.M + 31) / 32) * gridDim.y + (size_t)m * gridDim.y + nt) * 8 + 2 * w + d) * 1024;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((r >> 2) * 8 + lh * 4 + (r & 3)) * 32 + l31] = acc[d][m][r] + accl[d][m][r] * (1.0f / W16_SPLIT);
+        }
+}
+
 // ---- wgrad16t: the same weight gradient through transposing LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------
 // wgrad16_kernel spends ~35-45 % of its time turning the channels-last tiles into [channel][voxel] planes with VALU before the first
 // MFMA, because v_mfma_f32_32x32x16_f16 wants 8 consecutive K (= voxels) of one channel per lane.  ds_read_b64_tr_b16 delivers a
@@ -2250,10 +2433,33 @@ static bool k1_wide_eligible(int OD, int OH, int OW, int M, int Nc, int ks, int 
     return ks == 1 && stride == 1 && (OD * OH * OW) % 64 == 0 && m_tiles * n_tiles <= 24 && (size_t)64 * (m_tiles * 32 + n_tiles * 32 + 8) * 4 <= 150 * 1024;
 }
 
+// wgrad16k2_kernel: k2 s2 p0 layers whose fine grid is exactly twice the coarse one, whole 8 x 8 coarse (y, x) bricks, <= 128 dY channels
+static bool k2f16_shape_eligible(int OD, int OH, int OW, int M, int ks, int stride) {
+    return nm_ls().wgrad_k2f16 && ks == 2 && stride == 2 && OH % 8 == 0 && OW % 8 == 0 && OD > 0 && M <= 128;
+}
+static int k2f16_slots(int N, int OD, int OH, int OW, int Nc) {
+    const int n_tiles = (Nc + 31) / 32, total = N * OD * (OH / 8) * (OW / 8);
+    return max(1, min(total, 512 / n_tiles));
+}
+template <int MT, bool SINGLE, bool HX, bool HD>
+static int launch_k2f16_t(const WgradParams& p, dim3 grid, hipStream_t s) {
+    static NmDeviceOnce attr_set;
+    const size_t ldsb = w2_lds_bytes(MT, SINGLE);
+    if (!attr_set.done()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16k2_kernel<MT, SINGLE, HX, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            nm_set_error("wgrad16k2: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
+        }
+        attr_set.mark();
+    }
+    hipLaunchKernelGGL((wgrad16k2_kernel<MT, SINGLE, HX, HD>), grid, dim3(256), ldsb, s, p);
+    return nm_check_hip(hipGetLastError(), "wgrad16k2 launch");
+}
+
 size_t nm_wgrad_ws_floats(int N, int OD, int OH, int OW, int M, int Nc, int ks, int stride) {
     size_t a = plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false).ws_floats;
     if (k1_wide_eligible(OD, OH, OW, M, Nc, ks, stride)) a = max(a, (size_t)K1_WGS * ((M + 31) / 32) * ((Nc + 31) / 32) * 1024);
     if (wgrad16_eligible(OD, OH, OW, ks, stride)) a = max(a, plan_wgrad(N, OD, OH, OW, M, Nc, ks, stride, false, true).ws_floats);
+    if (k2f16_shape_eligible(OD, OH, OW, M, ks, stride)) a = max(a, (size_t)k2f16_slots(N, OD, OH, OW, Nc) * ((M + 31) / 32) * ((Nc + 31) / 32) * 8 * 1024);
     return a;
 }
 static int k5s_chunks(int G) { return (int)(((size_t)G * G * G + K5S_CHUNK - 1) / K5S_CHUNK); }
@@ -2298,6 +2504,31 @@ int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride
         if (rc) return rc;
         const int totalw = dy.C * cin_real;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min((totalw + 255) / 256, 4096)), dim3(256), 0, s, ws, S, T, n_tiles, 1, dy.C, cin_real, 1, 0, mul, dW);
+        return nm_check_hip(hipGetLastError(), "wgrad reduce launch");
+    }
+    if (allow_f16 && pad == 0 && k2f16_shape_eligible(dy.D, dy.H, dy.W, dy.C, ks, stride) && in.D == 2 * dy.D && in.H == 2 * dy.H && in.W == 2 * dy.W &&
+        (!in.h || in.C % 8 == 0) && (!dy.h || (dy.C % 8 == 0 && in.h)) && (!(in.h || dy.h) || nm_conv_single())) {
+        WgradParams p; p.in = in; p.dy = dy; p.part = ws; p.ks = 2; p.stride = 2; p.pad = 0; p.M = dy.C; p.Nc = in.C; p.dbg = 0;
+        const int m_tiles = (dy.C + 31) / 32, n_tiles = (in.C + 31) / 32;
+        p.n_tiles = n_tiles; p.groups = 8;
+        p.S = k2f16_slots(in.N, dy.D, dy.H, dy.W, in.C);
+        const dim3 grid(p.S, n_tiles);
+        const bool single = nm_conv_single();
+        int rc;
+        if (m_tiles <= 2) {
+            if (!single) rc = launch_k2f16_t<2, false, false, false>(p, grid, s);
+            else if (dy.h) rc = launch_k2f16_t<2, true, true, true>(p, grid, s);
+            else if (in.h) rc = launch_k2f16_t<2, true, true, false>(p, grid, s);
+            else rc = launch_k2f16_t<2, true, false, false>(p, grid, s);
+        } else {
+            if (!single) rc = launch_k2f16_t<4, false, false, false>(p, grid, s);
+            else if (dy.h) rc = launch_k2f16_t<4, true, true, true>(p, grid, s);
+            else if (in.h) rc = launch_k2f16_t<4, true, true, false>(p, grid, s);
+            else rc = launch_k2f16_t<4, true, false, false>(p, grid, s);
+        }
+        if (rc) return rc;
+        const int totalw = dy.C * cin_real * 8;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(min((totalw + 255) / 256, 4096)), dim3(256), 0, s, ws, p.S, m_tiles * n_tiles, n_tiles, 8, dy.C, cin_real, 8, 0, mul, dW);
         return nm_check_hip(hipGetLastError(), "wgrad reduce launch");
     }
     WgradPlan q = plan_wgrad(in.N, dy.D, dy.H, dy.W, dy.C, in.C, ks, stride, false, f16);

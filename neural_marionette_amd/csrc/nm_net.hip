@@ -847,7 +847,8 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
     const size_t m = b.ws.mark();
     const bool split = nm_conv_get_mode() != 0;          // split-fp16 kernels: dy is read pre-scaled by a power of two
     DyScale ds;
-    ds.prepare(b, split && r.stride == 1 && (w.ks == 3 || (need_din && w.wd16)), r.out.N * r.out.C, sc2_keep);
+    // (the k2 s2 pool convs: their weight gradient runs on the f16 matrix cores as well, wgrad16k2_kernel)
+    ds.prepare(b, split && ((r.stride == 1 && (w.ks == 3 || (need_din && w.wd16))) || (r.stride == 2 && w.ks == 2 && nm_ls().wgrad_k2f16)), r.out.N * r.out.C, sc2_keep);
     const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, r.chsum, w.key + ".bias", dA, ds.amax, dA_mul, dA_dv, dA_wv);
     const int slot = b.last_slot;                        // >= 0: dY sits in the ring (Bwd::dy_alloc)
     const TensorRef dyT = plain(dy, r.out);
@@ -956,9 +957,9 @@ float* up_bwd(Bwd& b, const UpRec& r, const float* dA) {
     ConvGeom g; g.ks = 2; g.stride = 2; g.pad = 0; g.OD = in.D; g.OH = in.H; g.OW = in.W; g.Cout = w.Cin; g.Co_pad = w.cd_pad;
     if (b.live()) {
         if (!w.wd) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
-        else b.run(nm_launch_wgrad(dyT, in, 2, 2, 0, w.Cout, wsb, gw, b.s));      // roles swapped: [Cin][Cout][8] = IODHW
     }
     const TensorRef dyS = ds.apply(b, dyT);
+    if (b.live() && w.wd) b.run(nm_launch_wgrad(dyS, in, 2, 2, 0, w.Cout, wsb, gw, b.s, ds.inv(), ds.amax ? 1 : 0));      // roles swapped: [Cin][Cout][8] = IODHW
     if (b.live()) {
         b.run(nm_launch_conv(dyS, w.wd, b.zb, din, g, nullptr, b.s, w.Cout, w.wd16));
         if (ds.inv()) b.run(nm_launch_scale_by(din, numel_of(in), ds.inv(), b.s));

@@ -47,6 +47,11 @@ BWD_CASES = [
     # pool data gradient on the LDS-weight transposed-conv kernel (>= 65536 coarse voxels)
     (32, 32, 2, 2, 0, 32, 5, True, False, 32),
     (64, 64, 2, 2, 0, 32, 3, False, False, 64),
+    # k2 s2 weight gradient on the f16 matrix cores (wgrad16k2_kernel: coarse (y, x) extents whole 8 x 8 bricks): four dY channel tiles,
+    # ragged channel tiles on both sides, a non-cubic brick count
+    (64, 128, 2, 2, 0, 16, 2, True, False, 64),
+    (48, 72, 2, 2, 0, 16, 3, True, False, 48),
+    (96, 40, 2, 2, 0, 16, 2, False, False, 96),
     # hourglass floor of a 32^3 grid: 1^3 and 2^3 volumes
     (72, 72, 3, 1, 1, 1, 8, True, False, 72),
     (48, 72, 1, 1, 0, 1, 8, False, False, 48),
@@ -133,7 +138,8 @@ def test_conv5_occ_backward(ctx, Cout, G, N, frac, sparse):
 
 
 @pytest.mark.parametrize("Cin,Cout,size,outpad,prologue,N", [(72, 48, 1, 0, True, 8), (72, 48, 2, 0, True, 3), (48, 32, 4, 0, False, 2), (32, 64, 8, 0, True, 2),
-                                                             (72, 48, 2, 1, True, 2), (48, 32, 5, 1, False, 2)])
+                                                             (72, 48, 2, 1, True, 2), (48, 32, 5, 1, False, 2),
+                                                             (128, 64, 8, 0, True, 3), (72, 48, 16, 0, False, 2)])      # (wgrad16k2_kernel, roles swapped)
 def test_convT2_backward(ctx, Cin, Cout, size, outpad, prologue, N):
     from neural_marionette_amd import _lib
     g = torch.Generator().manual_seed(Cin * 3 + Cout + size + outpad)
