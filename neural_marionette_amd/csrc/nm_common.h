@@ -139,7 +139,7 @@ struct NmLaunchState {
     unsigned* nf_flag = nullptr;           // sticky device word gn_finalize ORs a 1 into (null: no reporting)
     // A/B and diagnostic switches (NM355_SUPERTILE, _SMALL16, _KSPLIT, _OCC16, _POOL16, _F16P2, _F16P, _WGRAD_TR, _UP2C, _UP2C_DIAG,
     // _VRNN_MID, _VRNN_GEMM, _VRNN_GRAPH, _SPARSE_FIRST)
-    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, pool_q, occ_flags, gnb_apply4, defer_sums, wgrad_async, wgrad_wgs, wgrad_tr, wgrad_u, tail_rank1, wgrad_z, up2c, up2c_diag, vrnn_mid, vrnn_postmid, vrnn_nb, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res, adjust_split, hg_core, f16p_dma, clip_occ_mfma, vrnn_chain, wgrad_k2f16;
+    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, pool_q, occ_flags, gnb_apply4, defer_sums, wgrad_async, wgrad_wgs, wgrad_tr, wgrad_u, tail_rank1, wgrad_z, up2c, up2c_diag, vrnn_mid, vrnn_postmid, vrnn_nb, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res, adjust_split, hg_core, f16p_dma, clip_occ_mfma, vrnn_chain, wgrad_k2f16, convt_f16;
     NmLaunchState();
 };
 NmLaunchState& nm_ls();        // the state of the context whose ABI call runs on this thread
@@ -203,8 +203,11 @@ int nm_launch_gn_partials(const float* x, int N, int voxels, int C, float* part,
 int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStream_t s, int out_h = 0 /* 1: out is bfloat16 */);
 // w_t: weights transposed to [tap][Cin][Cout] by nm_launch_transpose_convT_weight
 int nm_launch_transpose_convT_weight(const float* w_iodhw, int Cin, int Cout, float* out, hipStream_t s);
+// out_mul (device scalar the result is multiplied by before the bias is added) exists on the f16 matrix-core kernel only: callers test
+// nm_convT2_f16_eligible first
 int nm_launch_convT2(const TensorRef& in, const float* w_t, const float* bias, float* out,
-                     int Cout, int OD, int OH, int OW, hipStream_t s, int out_h = 0);
+                     int Cout, int OD, int OH, int OW, hipStream_t s, int out_h = 0, const float* out_mul = nullptr);
+bool nm_convT2_f16_eligible(const TensorRef& in, int Cout, int OD, int OH, int OW, int out_h);
 int nm_launch_upsample2(const TensorRef& in, float* out, hipStream_t s, int out_h = 0);
 int nm_launch_pack_input(const float* vox, int B, int T, int G, int mean_over_t, float* out,
                          hipStream_t s);

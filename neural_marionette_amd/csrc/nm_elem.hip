@@ -343,6 +343,153 @@ __global__ __launch_bounds__(256) void convT2_mfma_kernel(TensorRef in, const fl
     }
 }
 
+// The same op on the f16 matrix cores (conv modes 1 / 3 / 4): v_mfma_f32_32x32x16_f16 with the operands split into fp16 hi + lo * 2^-11
+// and three products (SINGLE: hi only), the arithmetic of the convolutions (nm_conv.hip).  The fp32 form above runs Cin / 2 MFMAs of 64
+// cycles per (tap, 32-channel tile) - 0.73 ms for the first pool's data gradient (64 -> 32 channels onto 64^3, 69 GFLOP), whose
+// 1.07 GB of bfloat16 output take 0.2 ms to write; here it is Cin / 16 MFMAs of 32 cycles (x3 split).  The A operand needs 8
+// consecutive input channels of one voxel per lane - channels-last memory as it is: every lane loads its own operand words straight
+// from global memory (no LDS tile), applies the pending GroupNorm affine + LeakyReLU from a per-wave LDS table and keeps the Cin / 16
+// packed operands in registers for all 8 taps.  The weights ([tap][ci][co] fp32) are converted once per workgroup into LDS planes
+// [tap][co][ci] fp16 (row pitch + 16 B: conflict-free 16-B operand reads).  out_mul: device scalar the result is multiplied by (the
+// inverse of the power-of-two scale a gradient input carries, DyScale).
+typedef unsigned ct_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ct_half2 __attribute__((ext_vector_type(2)));
+typedef float ct_f32x2 __attribute__((ext_vector_type(2)));
+#define CT_SPLIT 2048.0f
+__device__ __forceinline__ unsigned ct_pack_split(float v0, float v1, unsigned& lo_out) {
+    ct_half2 hh = __builtin_convertvector(ct_f32x2{v0, v1}, ct_half2);
+    asm volatile("" : "+v"(hh));
+    ct_half2 ll;
+    ll[0] = (_Float16)__builtin_fmaf((float)hh[0], -CT_SPLIT, v0 * CT_SPLIT);
+    ll[1] = (_Float16)__builtin_fmaf((float)hh[1], -CT_SPLIT, v1 * CT_SPLIT);
+    lo_out = __builtin_bit_cast(unsigned, ll);
+    return __builtin_bit_cast(unsigned, hh);
+}
+#define CT_MAX_KS 8            // Cin <= 128
+template <bool SINGLE, bool OH16, bool IH16>
+__global__ __launch_bounds__(256) void convT2_f16_kernel(TensorRef in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int Cout, int tiles_per_frame, int total_tiles,
+                                                         const float* __restrict__ out_mul) {
+    extern __shared__ char ct_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, wv = tid >> 6;
+    const int Cin = in.C, ks = Cin >> 4, WP = Cin * 2 + 16;
+    char* W_hi = ct_lds; char* W_lo = W_hi + (size_t)8 * Cout * WP;
+    float* tab = reinterpret_cast<float*>(ct_lds + (size_t)(SINGLE ? 1 : 2) * 8 * Cout * WP) + (size_t)wv * 2 * Cin;    // this wave's scale[Cin], shift[Cin]
+    for (int i = tid; i < 8 * Cin * Cout; i += 256) {
+        const int co = i % Cout, ci = (i / Cout) % Cin, a = i / (Cout * Cin);
+        const float v = w[i];
+        const _Float16 h = (_Float16)v;
+        *reinterpret_cast<_Float16*>(W_hi + ((size_t)a * Cout + co) * WP + ci * 2) = h;
+        if constexpr (!SINGLE) *reinterpret_cast<_Float16*>(W_lo + ((size_t)a * Cout + co) * WP + ci * 2) = (_Float16)__builtin_fmaf((float)h, -CT_SPLIT, v * CT_SPLIT);
+    }
+    __syncthreads();
+    const float mul = out_mul ? *out_mul : 1.0f;
+    const int OH = 2 * in.H, OW = 2 * in.W;
+    const size_t out_frame = (size_t)8 * in.D * in.H * in.W * Cout, in_frame = (size_t)in.D * in.H * in.W * Cin;
+    int n_tab = -1;
+    for (int t = blockIdx.x * 4 + wv; t < total_tiles; t += gridDim.x * 4) {
+        const int n = t / tiles_per_frame, v0 = (t % tiles_per_frame) * 32;
+        if (in.scale && n != n_tab) {
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < Cin; c += 64) { tab[c] = in.scale[(size_t)n * Cin + c]; tab[Cin + c] = in.shift[(size_t)n * Cin + c]; }
+            __builtin_amdgcn_wave_barrier();
+            n_tab = n;
+        }
+        // this lane's operand words: voxel v0 + l31, channels 16 s + 8 lh .. + 8 for every k-step s
+        ct_u32x4 ah[CT_MAX_KS], al[CT_MAX_KS];
+        {
+            const size_t e0 = (size_t)n * in_frame + (size_t)(v0 + l31) * Cin + 8 * lh;
+            f32x4 r0[CT_MAX_KS], r1[CT_MAX_KS];
+#pragma unroll
+            for (int s = 0; s < CT_MAX_KS; ++s) {
+                if (s < ks) {
+                    if constexpr (IH16) {
+                        const ct_u32x4 q = *reinterpret_cast<const ct_u32x4*>(reinterpret_cast<const unsigned short*>(in.p) + e0 + 16 * s);
+                        r0[s] = f32x4{nm_bf_lo(q[0]), nm_bf_hi(q[0]), nm_bf_lo(q[1]), nm_bf_hi(q[1])};
+                        r1[s] = f32x4{nm_bf_lo(q[2]), nm_bf_hi(q[2]), nm_bf_lo(q[3]), nm_bf_hi(q[3])};
+                    } else {
+                        r0[s] = *reinterpret_cast<const f32x4*>(in.p + e0 + 16 * s);
+                        r1[s] = *reinterpret_cast<const f32x4*>(in.p + e0 + 16 * s + 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < CT_MAX_KS; ++s) {
+                if (s < ks) {
+                    f32x4 x0 = r0[s], x1 = r1[s];
+                    if (in.scale) {
+                        const int c = 16 * s + 8 * lh;
+                        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(tab + c), sc1 = *reinterpret_cast<const f32x4*>(tab + c + 4);
+                        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(tab + Cin + c), sh1 = *reinterpret_cast<const f32x4*>(tab + Cin + c + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { x0[j] = fmaf(x0[j], sc0[j], sh0[j]); x1[j] = fmaf(x1[j], sc1[j], sh1[j]); }
+                    }
+                    if (in.slope != 1.0f) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { x0[j] = x0[j] > 0.f ? x0[j] : x0[j] * in.slope; x1[j] = x1[j] > 0.f ? x1[j] : x1[j] * in.slope; }
+                    }
+                    unsigned l0, l1, l2, l3;
+                    const unsigned h0 = ct_pack_split(x0[0], x0[1], l0), h1 = ct_pack_split(x0[2], x0[3], l1);
+                    const unsigned h2 = ct_pack_split(x1[0], x1[1], l2), h3 = ct_pack_split(x1[2], x1[3], l3);
+                    ah[s] = ct_u32x4{h0, h1, h2, h3}; al[s] = ct_u32x4{l0, l1, l2, l3};
+                }
+            }
+        }
+        unsigned obase[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = v0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ix = v % in.W, iy = (v / in.W) % in.H, iz = v / (in.W * in.H);
+            obase[r] = (unsigned)((((size_t)2 * iz * OH + 2 * iy) * OW + 2 * ix) * Cout);
+        }
+        float* outn = nm_eptr(out, (size_t)n * out_frame, OH16);
+        for (int a = 0; a < 8; ++a) {
+            const unsigned toff = (unsigned)(((size_t)(a >> 2) * OH + ((a >> 1) & 1)) * OW + (a & 1)) * Cout;
+            for (int co0 = 0; co0 < Cout; co0 += 32) {
+                f32x16 acc, accl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accl[r] = 0.f; }
+                const char* bh_p = W_hi + ((size_t)a * Cout + co0 + l31) * WP + 16 * lh;
+                const char* bl_p = W_lo + ((size_t)a * Cout + co0 + l31) * WP + 16 * lh;
+#pragma unroll
+                for (int s = 0; s < CT_MAX_KS; ++s) {
+                    if (s < ks) {
+                        const nm_half8 bh = *reinterpret_cast<const nm_half8*>(bh_p + 32 * s);
+                        const nm_half8 xa = __builtin_bit_cast(nm_half8, ah[s]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, bh, acc, 0, 0, 0);
+                        if constexpr (!SINGLE) {
+                            const nm_half8 bl = *reinterpret_cast<const nm_half8*>(bl_p + 32 * s);
+                            accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, bl, accl, 0, 0, 0);
+                            accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(nm_half8, al[s]), bh, accl, 0, 0, 0);
+                        }
+                    }
+                }
+                const float bv = bias[co0 + l31];
+                auto fin = [&](int r) __attribute__((always_inline)) {
+                    float v = acc[r];
+                    if constexpr (!SINGLE) v += accl[r] * (1.0f / CT_SPLIT);
+                    return v * mul + bv;
+                };
+                if constexpr (OH16) {
+                    const bool odd = (l31 & 1) != 0;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float mine0 = fin(r), mine1 = fin(r + 1);
+                        const float send = odd ? mine0 : mine1;
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                        const unsigned pk = odd ? nm_pk_bf16(recv, mine1) : nm_pk_bf16(mine0, recv);
+                        const size_t e = (size_t)(odd ? obase[r + 1] : obase[r]) + toff + co0 + (l31 & ~1);
+                        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(outn) + e) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) outn[(size_t)obase[r] + toff + co0 + l31] = fin(r);
+                }
+            }
+        }
+    }
+}
+
 // trilinear x2, align_corners=False: src = (dst + 0.5) / 2 - 0.5 clamped at 0
 __device__ __forceinline__ void up_idx(int o, int I, int& i0, int& i1, float& l1) {
     float src = 0.5f * ((float)o + 0.5f) - 0.5f;
@@ -585,8 +732,31 @@ int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStre
     return nm_check_hip(hipGetLastError(), "apply2 launch");
 }
 
+static size_t convT2_f16_lds(int Cin, int Cout, bool single) { return (size_t)(single ? 1 : 2) * 8 * Cout * (Cin * 2 + 16) + (size_t)4 * 2 * Cin * sizeof(float); }
+bool nm_convT2_f16_eligible(const TensorRef& in, int Cout, int OD, int OH, int OW, int out_h) {
+    const size_t cvox = (size_t)in.N * in.D * in.H * in.W, fvox = (size_t)in.D * in.H * in.W;
+    return nm_ls().convt_f16 && nm_conv_get_mode() != 0 && OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && Cout % 32 == 0 && in.C <= 128 && in.C % 16 == 0 &&
+           fvox % 32 == 0 && cvox >= 4096 && fvox * 8 * Cout < ((size_t)1 << 31) && (!(in.h || out_h) || nm_conv_single()) &&
+           convT2_f16_lds(in.C, Cout, nm_conv_single() != 0) <= 150 * 1024;
+}
+template <bool SINGLE, bool OH16, bool IH16>
+static int launch_convT2_f16(const TensorRef& in, const float* w, const float* bias, float* out, int Cout, int tpf, int tiles, size_t ldsb,
+                             hipStream_t s, const float* out_mul) {
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convT2_f16_kernel<SINGLE, OH16, IH16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(convT2_f16)");
+        attr_set.mark();
+    }
+    // persistent workgroups (each converts the weights into its LDS once): as many as fit the chip, at most one per four tiles
+    const int per_cu = ldsb <= 40 * 1024 ? 3 : (ldsb <= 76 * 1024 ? 2 : 1);
+    const dim3 g((unsigned)min((tiles + 3) / 4, 256 * per_cu));
+    hipLaunchKernelGGL((convT2_f16_kernel<SINGLE, OH16, IH16>), g, dim3(256), ldsb, s, in, w, bias, out, Cout, tpf, tiles, out_mul);
+    return nm_check_hip(hipGetLastError(), "convT2_f16 launch");
+}
+
 int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, float* out, int Cout, int OD, int OH,
-                     int OW, hipStream_t s, int out_h) {
+                     int OW, hipStream_t s, int out_h, const float* out_mul) {
     if (Cout % 4 || in.C % 4) { nm_set_error("convT2: channels must be multiples of 4"); return NM_ERR_ARG; }
     if (OD < 2 * in.D || OD > 2 * in.D + 1 || OH < 2 * in.H || OH > 2 * in.H + 1 || OW < 2 * in.W || OW > 2 * in.W + 1) {
         nm_set_error("convT2: bad output size"); return NM_ERR_ARG;
@@ -594,6 +764,19 @@ int nm_launch_convT2(const TensorRef& in, const float* w, const float* bias, flo
     size_t total = (size_t)in.N * OD * OH * OW * (Cout / 4);
     const size_t cvox = (size_t)in.N * in.D * in.H * in.W;
     const size_t fvox = (size_t)in.D * in.H * in.W;
+    if (nm_convT2_f16_eligible(in, Cout, OD, OH, OW, out_h)) {
+        const bool single = nm_conv_single();
+        const size_t ldsb = convT2_f16_lds(in.C, Cout, single);
+        {
+            const int tpf = (int)(fvox / 32), tiles = (int)(cvox / 32);
+            if (!single) return launch_convT2_f16<false, false, false>(in, w, bias, out, Cout, tpf, tiles, ldsb, s, out_mul);
+            if (out_h && in.h) return launch_convT2_f16<true, true, true>(in, w, bias, out, Cout, tpf, tiles, ldsb, s, out_mul);
+            if (out_h) return launch_convT2_f16<true, true, false>(in, w, bias, out, Cout, tpf, tiles, ldsb, s, out_mul);
+            if (in.h) return launch_convT2_f16<true, false, true>(in, w, bias, out, Cout, tpf, tiles, ldsb, s, out_mul);
+            return launch_convT2_f16<true, false, false>(in, w, bias, out, Cout, tpf, tiles, ldsb, s, out_mul);
+        }
+    }
+    if (out_mul) { nm_set_error("convT2: an output multiplier exists on the f16 matrix-core kernel only (conv mode != 0, Cin %% 16 == 0, Cin <= 128, Cout %% 32 == 0)"); return NM_ERR_UNSUPPORTED; }
     if (OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && Cout % 32 == 0 && in.C <= 128 && in.C % 8 == 0 && fvox % 32 == 0 && cvox >= 4096 &&
         fvox * 8 * Cout < ((size_t)1 << 31)) {
         static NmDeviceOnce attr_set;

@@ -909,6 +909,8 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
             if (out_mul && !r.up2) *out_mul = ds.inv();
         } else if (b.live()) {      // k2 s2 pool conv: the transposed conv
             if (!w.wt) { nm_set_error("detector_backward: weights were not packed for training (nm_ctx_set_training)"); b.rc = NM_ERR_STATE; }
+            else if (ds.amax && nm_convT2_f16_eligible(dyS, w.Cin, in.D, in.H, in.W, h_in))           // f16 matrix cores: dY pre-scaled, the result un-scaled in the epilogue
+                b.run(nm_launch_convT2(dyS, w.wt, b.zb, din, w.Cin, in.D, in.H, in.W, b.s, h_in, ds.inv()));
             else b.run(nm_launch_convT2(dyT, w.wt, b.zb, din, w.Cin, in.D, in.H, in.W, b.s, h_in));
         }
     }
