@@ -734,9 +734,10 @@ int nm_launch_apply2(const TensorRef& a, const TensorRef* b, float* out, hipStre
 
 static size_t convT2_f16_lds(int Cin, int Cout, bool single) { return (size_t)(single ? 1 : 2) * 8 * Cout * (Cin * 2 + 16) + (size_t)4 * 2 * Cin * sizeof(float); }
 bool nm_convT2_f16_eligible(const TensorRef& in, int Cout, int OD, int OH, int OW, int out_h) {
-    const size_t cvox = (size_t)in.N * in.D * in.H * in.W, fvox = (size_t)in.D * in.H * in.W;
+    // (a per-FRAME size rule: which arithmetic a layer gets must not depend on the batch size - batch additivity of the gradients)
+    const size_t fvox = (size_t)in.D * in.H * in.W;
     return nm_ls().convt_f16 && nm_conv_get_mode() != 0 && OD == 2 * in.D && OH == 2 * in.H && OW == 2 * in.W && Cout % 32 == 0 && in.C <= 128 && in.C % 16 == 0 &&
-           fvox % 32 == 0 && cvox >= 4096 && fvox * 8 * Cout < ((size_t)1 << 31) && (!(in.h || out_h) || nm_conv_single()) &&
+           fvox % 32 == 0 && fvox >= 512 && fvox * 8 * Cout < ((size_t)1 << 31) && (!(in.h || out_h) || nm_conv_single()) &&
            convT2_f16_lds(in.C, Cout, nm_conv_single() != 0) <= 150 * 1024;
 }
 template <bool SINGLE, bool OH16, bool IH16>

@@ -303,11 +303,16 @@ def test_conv5_occupancy_first_layer(ctx, G, Cout, N, mode):
     assert e < REL, f"GroupNorm rel err {e:.3e}"
 
 
-@pytest.mark.parametrize("Cin,Cout,size,outpad,groups", [(72, 48, 2, 0, 3), (48, 32, 5, 1, 2), (32, 64, 8, 0, 4), (32, 128, 3, 1, 8), (32, 64, 32, 0, 4)])
-def test_convT2(ctx, Cin, Cout, size, outpad, groups):
+@pytest.mark.parametrize("mode", [0, 1, 3], ids=["fp32mfma", "split16", "f16"])
+@pytest.mark.parametrize("Cin,Cout,size,outpad,groups,N", [(72, 48, 2, 0, 3, 2), (48, 32, 5, 1, 2, 2), (32, 64, 8, 0, 4, 2), (32, 128, 3, 1, 8, 2), (32, 64, 32, 0, 4, 2),
+                                                            # the f16 matrix-core kernel (conv modes 1 / 3: Cin % 16 == 0, Cout % 32 == 0, >= 4096 coarse voxels)
+                                                            (64, 32, 16, 0, 4, 3), (128, 64, 8, 0, 4, 8), (48, 96, 16, 0, 4, 1)])
+def test_convT2(ctx, Cin, Cout, size, outpad, groups, N, mode):
     from neural_marionette_amd import _lib
+    if mode != 1 and Cin * Cout * size < 64 * 32 * 16 and size != 8:
+        pytest.skip("small shapes: every mode runs the same fp32 kernel (covered in split16)")
+    _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, mode), "set_conv_mode")
     g = torch.Generator().manual_seed(Cin * 131 + Cout)
-    N = 2
     x = torch.randn(N, Cin, size, size, size, generator=g)
     w = torch.randn(Cin, Cout, 2, 2, 2, generator=g) / (Cin * 8) ** 0.5
     b = torch.randn(Cout, generator=g) * 0.1
@@ -318,15 +323,26 @@ def test_convT2(ctx, Cin, Cout, size, outpad, groups):
     out = torch.full((N, od, od, od, Cout), float("nan")).cuda()
     gsc = torch.zeros(N, Cout).cuda(); gsh = torch.zeros(N, Cout).cuda()
     xd, wd, bd, gd, btd = to_cl(x), dev(w), dev(b), dev(gam), dev(bet)
-    _lib.check(ctx.lib.nm_op_convT2(ctx.handle, _lib.ptr(xd), N, size, size, size, Cin, _lib.ptr(wd), _lib.ptr(bd),
-                                    Cout, outpad, _lib.ptr(out), groups, _lib.ptr(gd), _lib.ptr(btd),
-                                    _lib.ptr(gsc), _lib.ptr(gsh)), "op_convT2")
-    torch.cuda.synchronize()
+    try:
+        _lib.check(ctx.lib.nm_op_convT2(ctx.handle, _lib.ptr(xd), N, size, size, size, Cin, _lib.ptr(wd), _lib.ptr(bd),
+                                        Cout, outpad, _lib.ptr(out), groups, _lib.ptr(gd), _lib.ptr(btd),
+                                        _lib.ptr(gsc), _lib.ptr(gsh)), "op_convT2")
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, 1), "set_conv_mode")
     got = from_cl(out, Cout)
+    assert torch.isfinite(got).all(), "unwritten / non-finite outputs"
     e = relerr(got, ref)
-    assert e < REL, f"convT raw rel err {e:.3e}"
     refn = F.group_norm(ref, groups, gam, bet, 1e-5)
     gotn = got * gsc.cpu()[:, :, None, None, None] + gsh.cpu()[:, :, None, None, None]
+    if mode == 3:
+        # sharp against the product of the operands rounded to fp16 (the mode's definition) where the f16 kernel runs, else against fp32
+        ref16 = F.conv_transpose3d(x.half().double(), w.half().double(), b.double(), stride=2, output_padding=outpad).float()
+        e16 = relerr(got, ref16)
+        assert min(e, e16) < REL, f"f16-product convT: rel err {e16:.3e} to the rounded-operand product, {e:.3e} to fp32"
+        assert e < F16_REL and relerr(gotn, refn) < F16_REL
+        return
+    assert e < REL, f"convT raw rel err {e:.3e}"
     e = relerr(gotn, refn)
     assert e < REL, f"convT GroupNorm rel err {e:.3e}"
 

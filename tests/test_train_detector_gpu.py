@@ -500,10 +500,10 @@ def test_gradient_properties_f16_mode_at_64cubed():
         scale = max(avg.abs().max().item(), 1e-6 * gmax)
         worst = max(worst, (v.double() - avg).abs().max().item() / scale)
     print("f16 mode, 64^3: batch additivity worst relative deviation %.2e" % worst)
-    # (not the 2e-3 of the fp32-equivalent modes: the data-gradient operands are rounded to fp16 relative to a power-of-two scale taken
-    # from the batch's largest |dy|, so a clip's small gradient entries round differently alone and in a batch - measured 7.6e-3, within
-    # the mode's stated accuracy of 2e-2)
-    assert worst < 2e-2
+    # (the 2e-3 of the fp32-equivalent modes: measured 2.1e-4.  Rounds 2-3 measured 7.6e-3 here and blamed the batch-wide power-of-two
+    # scale of dy; it was the transposed-conv kernel choice, made on the BATCH's voxel count, that gave the 8^3 level fp32 arithmetic
+    # alone and fp16 arithmetic in a batch - the f16 kernel's rule is per frame now, nm_convT2_f16_eligible)
+    assert worst < 2e-3
     l2, g2, _ = _hip_grads(o, sd, vox, AIST, mode="f16")
     assert l2 == l_ab
     for k, v in g_ab.items():
