@@ -50,7 +50,8 @@ NmLaunchState::NmLaunchState()
       clip_occ_mfma(env_int("NM355_CLIP_OCC_MFMA", 1)),  // 0: the clip-mean net's first-layer weight gradient as the dense all-frames kernel (A/B)
       vrnn_chain(env_int("NM355_VRNN_CHAIN", 1)),        // 0: the prior steps of a rollout as three launches per step instead of one persistent launch (A/B)
       wgrad_k2f16(env_int("NM355_WGRAD_K2F16", 1)),     // 0: the k2 s2 weight gradients on the fp32-MFMA kernel in every conv mode (A/B)
-      convt_f16(env_int("NM355_CONVT_F16", 1))          // 0: the transposed convs (and the pool convs' data gradient) on the fp32-MFMA kernel in every conv mode (A/B)
+      convt_f16(env_int("NM355_CONVT_F16", 1)),         // 0: the transposed convs (and the pool convs' data gradient) on the fp32-MFMA kernel in every conv mode (A/B)
+      clip_late(env_int("NM355_CLIP_LATE", 1))          // 0: the clip-mean net is enqueued before the per-frame encoder instead of behind its first chunk(s) (A/B)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); }
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)

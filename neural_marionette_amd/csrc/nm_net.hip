@@ -600,36 +600,61 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
     float* frame_sums = n.alloc((size_t)F * 3);
     float* aff = affinity_on ? (affinity ? affinity : n.alloc((size_t)N * K * K)) : nullptr;
 
-    {   // spatio-temporal heat-map from the clip mean, once per clip (kypt_detector.py:311-316).  Only B frames of
-        // small, latency-bound launches: issued on the side stream so that it runs beside the per-frame encoder.  Its
-        // scratch stays allocated (no release) until the call ends because the two streams run concurrently.
+    // spatio-temporal heat-map from the clip mean, once per clip (kypt_detector.py:311-316).  Only B frames of small, latency-bound
+    // launches: issued on the side stream so that it runs beside the per-frame encoder.  Its scratch - every byte it ever touches, its
+    // released temporaries included - stays out of reach of the main stream until the call ends, because the two streams run
+    // concurrently.
+    // ORDER OF ENQUEUE: the block is ~90 launches, about a millisecond of host time, and a forward call starts with the queues empty
+    // (the previous call's results were read): enqueued first, it left the main stream without work for the first 1.7-1.8 ms of every
+    // call while the chip ran 4-frame kernels (gpurun_out timelines, rounds 3-4).  So the per-frame encoder's first chunk(s) go first
+    // and the clip block is enqueued behind them; its scratch region is reserved BEFORE (sized by a nested measuring pass of the same
+    // code) so that nothing the main stream allocates in between can alias it.
+    auto clip_block = [&]() {
         Net n2(c, c->stream2);
         n2.keep = n.keep;
-        if (n.live()) {
-            n.run(nm_check_hip(hipEventRecord(c->ev_fork, n.s), "fork event"));
-            n.run(nm_check_hip(hipStreamWaitEvent(c->stream2, c->ev_fork, 0), "side stream wait"));
-        }
         float* in = n2.alloc((size_t)B * G3);
         float* fclip = n2.alloc((size_t)B * g3 * 2 * FEAT);
         if (n2.live()) n2.run(nm_launch_mean_t(vox_in, B, T, G3, in, n2.s));
-        const size_t saved_peak = n2.ws.peak;
-        n2.ws.peak = n2.ws.top;
         feature_net(n2, in, B, G, d.clip, g, fclip, tape ? &tape->clip : nullptr);
-        const size_t local_peak = n2.ws.peak;                        // high-water mark of the clip net's scratch
-        n2.ws.peak = saved_peak > local_peak ? saved_peak : local_peak;
-        n2.ws.top = local_peak;                                      // keep that scratch out of reach of the main stream
         conv_gn(n2, mk(fclip, B, g, g, g, 2 * FEAT), d.clip_head, nullptr, 1, 0, 1.0f, clip_head, false, tape ? &tape->clip_head : nullptr);
         if (tape) tape->clip_in = in;
         if (n2.live()) n2.run(nm_check_hip(hipEventRecord(c->ev_clip, c->stream2), "clip event"));
         n.run(n2.rc);
+    };
+    if (n.live()) {
+        n.run(nm_check_hip(hipEventRecord(c->ev_fork, n.s), "fork event"));
+        n.run(nm_check_hip(hipStreamWaitEvent(c->stream2, c->ev_fork, 0), "side stream wait"));
     }
+    const size_t clip_r0 = n.ws.top;
+    size_t clip_need = 0;
+    {   // measuring pass: the block's high-water mark above clip_r0
+        const size_t sv_peak = n.ws.peak; const bool sv_dry = n.ws.dry, sv_of = n.ws.overflow;
+        n.ws.dry = true; n.ws.peak = n.ws.top;
+        clip_block();
+        clip_need = ((n.ws.peak - clip_r0) + 255) & ~(size_t)255;
+        n.ws.top = clip_r0; n.ws.peak = sv_peak; n.ws.dry = sv_dry; n.ws.overflow = sv_of;
+    }
+    auto run_clip_block = [&]() {
+        const size_t top_now = n.ws.top;
+        n.ws.top = clip_r0;
+        clip_block();
+        if (n.ws.top > clip_r0 + clip_need && !n.rc) { nm_set_error("detector_forward: the clip net outgrew its reserved scratch"); n.rc = NM_ERR_STATE; }
+        n.ws.top = top_now;
+    };
+    (void)n.ws.alloc_bytes(clip_need);                          // reserve [clip_r0, clip_r0 + clip_need)
+    n.ws.top = clip_r0 + clip_need;
+    const int clip_after = nm_ls().clip_late ? (tape ? 1 : 2) : 0;     // per-frame chunks enqueued before the clip block
+    if (clip_after == 0) run_clip_block();
     const size_t chunk = tape ? (size_t)F : FRAME_CHUNK;       // training keeps every activation: one pass over all frames
+    int chunks_done = 0;
     for (size_t f0 = 0; f0 < (size_t)F; f0 += chunk) {   // per-frame encoder (kypt_detector.py:330-336)
         const int nf = (int)(((size_t)F - f0) < chunk ? ((size_t)F - f0) : chunk);
         const size_t m = n.ws.mark();
         feature_net(n, vox_in + f0 * G3, nf, G, d.frame, g, feat + f0 * g3 * FEAT, tape ? &tape->frame : nullptr);
         n.release(m);
+        if (++chunks_done == clip_after) run_clip_block();
     }
+    if (chunks_done < clip_after) run_clip_block();
     {   // heads -> heat-maps -> keypoints (kypt_detector.py:336-347)
         const size_t m = n.ws.mark();
         float* head = n.alloc((size_t)F * g3 * K);
