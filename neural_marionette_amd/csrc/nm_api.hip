@@ -2,6 +2,7 @@
 // points used by the unit parity tests.  The network-level entry points live in
 // nm_net.hip / nm_vrnn.hip.
 #include "nm_ctx.h"
+#include <mutex>
 #include "nm_grad.h"
 #include "nm_up2c.h"
 #include <cstdarg>
@@ -116,6 +117,42 @@ static hipError_t create_wgrad_stream(hipStream_t* s) {
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
+// The two side streams (clip-mean net / VRNN beside the frame stack; weight gradients) are shared by all contexts of a process on a
+// device.  HIP maps streams onto a few hardware queues round-robin (4 by default): a SECOND context with streams of its own got queues
+// that the runtime arbitrates differently and its bf16 training step ran at 48 ms instead of 44 (same kernels, same durations when
+// alone; 53 ms with GPU_MAX_HW_QUEUES=8, 44 with 3: tools/time_train_steps.py) - bench.py's train_bf16, measured in a second context,
+// showed it.  Sharing adds ordering between contexts used concurrently from different threads, never a missing dependency (each
+// context keeps its own events).  NM355_OWN_STREAMS=1 / NM355_WGRAD_PRIO=1: streams per context as before.
+#define NM_MAX_DEVICES 16
+static std::mutex g_side_mu;
+static hipStream_t g_side[NM_MAX_DEVICES][2];
+static int g_side_refs[NM_MAX_DEVICES];
+static bool own_streams() { const char* e = getenv("NM355_OWN_STREAMS"); const char* p = getenv("NM355_WGRAD_PRIO"); return (e && atoi(e) != 0) || (p && atoi(p) != 0); }
+static hipError_t acquire_side_streams(int dev, hipStream_t* s2, hipStream_t* s3, bool* shared) {
+    if (own_streams() || dev < 0 || dev >= NM_MAX_DEVICES) {
+        *shared = false;
+        hipError_t e = hipStreamCreateWithFlags(s2, hipStreamNonBlocking);
+        return e != hipSuccess ? e : create_wgrad_stream(s3);
+    }
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if (g_side_refs[dev] == 0) {
+        hipError_t e = hipStreamCreateWithFlags(&g_side[dev][0], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_side[dev][1], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    ++g_side_refs[dev];
+    *s2 = g_side[dev][0]; *s3 = g_side[dev][1]; *shared = true;
+    return hipSuccess;
+}
+static void release_side_streams(int dev, hipStream_t s2, hipStream_t s3, bool shared) {
+    if (!shared) { if (s2) (void)hipStreamDestroy(s2); if (s3) (void)hipStreamDestroy(s3); return; }
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if (--g_side_refs[dev] == 0) {
+        (void)hipStreamDestroy(g_side[dev][0]); (void)hipStreamDestroy(g_side[dev][1]);
+        g_side[dev][0] = g_side[dev][1] = nullptr;
+    }
+}
+
 int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
     if (!out || !cfg) { nm_set_error("ctx_create: null argument"); return NM_ERR_ARG; }
     if (cfg->grid_size < 32 || cfg->grid_size % 8) { nm_set_error("ctx_create: grid_size %d unsupported", cfg->grid_size); return NM_ERR_UNSUPPORTED; }
@@ -152,8 +189,7 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
         delete c;
         return NM_ERR_HIP;
     }
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        create_wgrad_stream(&c->stream3) != hipSuccess ||
+    if (acquire_side_streams(cfg->device, &c->stream2, &c->stream3, &c->side_shared) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_w[2], hipEventDisableTiming) != hipSuccess ||
@@ -168,6 +204,7 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
         hipEventCreateWithFlags(&c->ev_nf[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nf[3], hipEventDisableTiming) != hipSuccess) {
         nm_set_error("ctx_create: could not create the side stream / events");
+        if (c->stream2 || c->stream3) release_side_streams(cfg->device, c->stream2, c->stream3, c->side_shared);
         delete c;
         return NM_ERR_HIP;
     }
@@ -193,8 +230,7 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     nm_vrnn_free_graphs(ctx);
     nm_net_free_tape(ctx);
     nm_vrnn_free_tape(ctx);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->stream2 || ctx->stream3) release_side_streams(ctx->cfg.device, ctx->stream2, ctx->stream3, ctx->side_shared);
     if (ctx->wside) (void)hipFree(ctx->wside);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side, ctx->ev_w[0], ctx->ev_w[1], ctx->ev_w[2], ctx->ev_dy, ctx->ev_wjoin}) if (e) (void)hipEventDestroy(e);
     for (const NmProfRec& r : ctx->ls.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

@@ -94,6 +94,7 @@ struct nm_ctx {
     // stream's arena frames (a ring of dY buffers, the re-materialised upsample + slot workspace, the operand-scale vectors) live in one
     // ctx-owned block sized by the sizing pass of nm_detector_forward_train
     hipStream_t stream3 = nullptr;
+    bool side_shared = false;              // stream2 / stream3 are the process-wide pair of this device (nm_api.hip acquire_side_streams)
     hipEvent_t ev_w[3] = {nullptr, nullptr, nullptr}, ev_dy = nullptr, ev_wjoin = nullptr;
     float* wside = nullptr; size_t wside_floats = 0;                     // the block and its capacity
     size_t wside_slot = 0, wside_scratch = 0, wside_sc = 0;              // floats per ring slot / scratch / scale pool (last sizing pass)

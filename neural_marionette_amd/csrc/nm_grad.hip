@@ -1827,17 +1827,20 @@ __global__ __launch_bounds__(256) void gnb_partials4_kernel(const float* __restr
             }
         };
         int v = v0 + vl;
-        for (; v + 3 * lanes < v1; v += 4 * lanes) {
-            f32x4 yy[4], dd[4];
+        // (bfloat16: eight voxels in flight - the same bytes per thread as four fp32 ones; with four the 64^3 layers ran at 2.1 TB/s)
+        constexpr int U = H ? 8 : 4;
+        for (; v + (U - 1) * lanes < v1; v += U * lanes) {
+            f32x4 yy[U], dd[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 yy[u] = nm_ld4<H>(yp, (size_t)(v + u * lanes) * C);
                 dd[u] = grad(v + u * lanes);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) add(yy[u], dd[u], u & 1);
+            for (int u = 0; u < U; ++u) add(yy[u], dd[u], u & 1);
         }
-        for (; v < v1; v += lanes) add(nm_ld4<H>(yp, (size_t)v * C), grad(v), 0);
+        // (the tail alternates the two accumulators like the main loop: the order of the sums does not depend on U)
+        for (int u = 0; v < v1; v += lanes, ++u) add(nm_ld4<H>(yp, (size_t)v * C), grad(v), u & 1);
     }
     sh[threadIdx.x * 2] = s1[0] + s1[1]; sh[threadIdx.x * 2 + 1] = s2[0] + s2[1];
     __syncthreads();

@@ -2042,14 +2042,16 @@ static int rollout_impl(nm_ctx* c, int kind, const float* kp_cond, const float* 
             if (ok) {
                 // capture the launch sequence on the side stream (a capture cannot run on the legacy default stream, which the caller's
                 // stream may be); relaxed mode: other threads of the process (torch's allocator) stay free to call the runtime
-                hipStream_t main = c->stream;
-                ok = hipStreamSynchronize(c->stream2) == hipSuccess && hipStreamBeginCapture(c->stream2, hipStreamCaptureModeRelaxed) == hipSuccess;
+                // (a stream of its own for the capture: the side streams are shared by the contexts of a process, nm_api.hip)
+                hipStream_t main = c->stream, cap = nullptr;
+                ok = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) == hipSuccess && hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed) == hipSuccess;
                 if (ok) {
-                    c->stream = c->stream2;
+                    c->stream = cap;
                     const int r2 = rollout_steps(c, g->rb, kind, B, Tcond, Ttot, S, &g->cur);
                     c->stream = main;
-                    ok = hipStreamEndCapture(c->stream2, &g->graph) == hipSuccess && r2 == NM_OK && g->graph;
+                    ok = hipStreamEndCapture(cap, &g->graph) == hipSuccess && r2 == NM_OK && g->graph;
                 }
+                if (cap) (void)hipStreamDestroy(cap);
                 if (ok) ok = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) == hipSuccess;
             }
             if (!ok) {                                          // no graph on this runtime: the eager launch sequence below is the same work
