@@ -52,6 +52,7 @@ NmLaunchState::NmLaunchState()
       vrnn_chain(env_int("NM355_VRNN_CHAIN", 1)),        // 0: the prior steps of a rollout as three launches per step instead of one persistent launch (A/B)
       wgrad_k2f16(env_int("NM355_WGRAD_K2F16", 1)),     // 0: the k2 s2 weight gradients on the fp32-MFMA kernel in every conv mode (A/B)
       convt_f16(env_int("NM355_CONVT_F16", 1)),         // 0: the transposed convs (and the pool convs' data gradient) on the fp32-MFMA kernel in every conv mode (A/B)
+      k5_two(env_int("NM355_K5_TWO", 1)),               // 0: the two halves of the first layer's weight gradient one after the other on the main stream (A/B)
       clip_late(env_int("NM355_CLIP_LATE", 1))          // 0: the clip-mean net is enqueued before the per-frame encoder instead of behind its first chunk(s) (A/B)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); }
 NmLaunchState& nm_ls() {
@@ -195,6 +196,7 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
         hipEventCreateWithFlags(&c->ev_w[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_dy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_wjoin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_k5, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_clip, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_kp, hipEventDisableTiming) != hipSuccess ||
@@ -232,7 +234,7 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     nm_vrnn_free_tape(ctx);
     if (ctx->stream2 || ctx->stream3) release_side_streams(ctx->cfg.device, ctx->stream2, ctx->stream3, ctx->side_shared);
     if (ctx->wside) (void)hipFree(ctx->wside);
-    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side, ctx->ev_w[0], ctx->ev_w[1], ctx->ev_w[2], ctx->ev_dy, ctx->ev_wjoin}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_clip, ctx->ev_kp, ctx->ev_side, ctx->ev_w[0], ctx->ev_w[1], ctx->ev_w[2], ctx->ev_dy, ctx->ev_wjoin, ctx->ev_k5}) if (e) (void)hipEventDestroy(e);
     for (const NmProfRec& r : ctx->ls.prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : ctx->ls.event_pool) (void)hipEventDestroy(e);
     delete ctx;

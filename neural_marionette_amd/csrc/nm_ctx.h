@@ -95,7 +95,7 @@ struct nm_ctx {
     // ctx-owned block sized by the sizing pass of nm_detector_forward_train
     hipStream_t stream3 = nullptr;
     bool side_shared = false;              // stream2 / stream3 are the process-wide pair of this device (nm_api.hip acquire_side_streams)
-    hipEvent_t ev_w[3] = {nullptr, nullptr, nullptr}, ev_dy = nullptr, ev_wjoin = nullptr;
+    hipEvent_t ev_w[3] = {nullptr, nullptr, nullptr}, ev_dy = nullptr, ev_wjoin = nullptr, ev_k5 = nullptr;
     float* wside = nullptr; size_t wside_floats = 0;                     // the block and its capacity
     size_t wside_slot = 0, wside_scratch = 0, wside_sc = 0;              // floats per ring slot / scratch / scale pool (last sizing pass)
     hipEvent_t ev_user_decoder = nullptr;  // caller's event, recorded by nm_detector_backward once the decoder's gradients are complete

@@ -17,7 +17,9 @@ size_t nm_wgrad_k5occ_ws_floats(int N, int G, int M);
 // sparse_occ: the occupancy is a few per cent dense (per-frame grids): its channel is gathered over the occupied voxels and the
 // coordinate channels take the dense kernel on one frame of frame-summed dy; 0: dense kernel over all frames (the clip-mean grid
 // of the spatio-temporal net is the union of T frames, 15-30 % dense: the gather took 11.7 ms there against 0.5 ms)
-int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s, int sparse_occ = 1);
+// s_coord + the two events (optional): the coordinate channels' part runs on that stream beside the occupancy channel's kernel
+int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s, int sparse_occ = 1,
+                          hipStream_t s_coord = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 
 // ---- GroupNorm + LeakyReLU backward ------------------------------------------------------------------------------------
 // y: the raw conv output with its forward scale/shift/slope (lazy tensor);  dA: gradient w.r.t. the activated values.

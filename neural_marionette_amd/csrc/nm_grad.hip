@@ -750,6 +750,10 @@ __global__ __launch_bounds__(512, 1) void wgrad16t_kernel(WgradParams p) {
         const int n = i >> 6, which = (i >> 5) & 1, c = n0 + (i & 31);
         xtab[i] = p.in.scale ? (c < p.Nc ? (which ? p.in.shift : p.in.scale)[(size_t)n * p.in.C + c] : 0.f) : (which ? 0.f : 1.f);
     }
+    // (the table is read by other threads than those that wrote it, first in the prologue below: without this barrier a wave that ran
+    //  ahead converted its first items with whatever the previous workgroup left in LDS - a run-to-run difference of ~1e-4 in the
+    //  weight gradient of one layer, one run in ~80 when the kernel ran alone and one in ~5 beside the main stream's kernels; round 4)
+    __syncthreads();
     char* dummy = lds8 + WT_LDS + (size_t)p.in.N * 256;   // 32 B written by the threads without a fourth X item
     f32x4 xa[4], xb[4], da, db, dsa, dsb, dha, dhb;
     dsa = dsb = f32x4{1.f, 1.f, 1.f, 1.f}; dha = dhb = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -970,6 +974,10 @@ __device__ __forceinline__ void wgrad16u_run(const WgradParams& p, const int w) 
         const int n = i >> 6, which = (i >> 5) & 1, c = n0 + (i & 31);
         xtab[i] = p.in.scale ? (c < p.Nc ? (which ? p.in.shift : p.in.scale)[(size_t)n * p.in.C + c] : 0.f) : (which ? 0.f : 1.f);
     }
+    // (the table is read by other threads than those that wrote it, first in the prologue below: without this barrier a wave that ran
+    //  ahead converted its first items with whatever the previous workgroup left in LDS - a run-to-run difference of ~1e-4 in the
+    //  weight gradient of one layer, one run in ~80 when the kernel ran alone and one in ~5 beside the main stream's kernels; round 4)
+    __syncthreads();
     const int dummy_off = WT_LDS + p.in.N * 256;      // 32 B written by the threads without a fourth X item
     int xn = 0, xoz = 0, xoy = 0, xox = 0;
     auto locate = [&](int b) __attribute__((always_inline)) {
@@ -1265,6 +1273,10 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
         const int n = i >> 6, which = (i >> 5) & 1, c = n0 + (i & 31);
         xtab[i] = p.in.scale ? (c < p.Nc ? (which ? p.in.shift : p.in.scale)[(size_t)n * p.in.C + c] : 0.f) : (which ? 0.f : 1.f);
     }
+    // (the table is read by other threads than those that wrote it, first in the prologue below: without this barrier a wave that ran
+    //  ahead converted its first items with whatever the previous workgroup left in LDS - a run-to-run difference of ~1e-4 in the
+    //  weight gradient of one layer, one run in ~80 when the kernel ran alone and one in ~5 beside the main stream's kernels; round 4)
+    __syncthreads();
     const int dummy_off = WZ_LDS + p.in.N * 256;
     const bool ca_ok = n0 + 8 * oct < p.Nc, cb_ok = n0 + 8 * oct + 4 < p.Nc;
     const bool ma_ok = m0 + 8 * oct < p.M, mb_ok = m0 + 8 * oct + 4 < p.M;
@@ -2335,8 +2347,8 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
         return NM_ERR_UNSUPPORTED;
     }
     if (nm_ls().wgrad_tr && q.p.in.N <= 96) {                       // (the per-frame scale / shift table of wgrad16t_kernel lives in LDS: 256 B per frame)
-        static bool attr_t = false;
-        if (!attr_t) {
+        static NmDeviceOnce attr_t;
+        if (!attr_t.done()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16t_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -2350,13 +2362,13 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16u_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 nm_set_error("wgrad16t: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
             }
-            attr_t = true;
+            attr_t.mark();
         }
         const size_t ldsb = WT_LDS + (size_t)q.p.in.N * 64 * sizeof(float) + 64;
         const dim3 grid(q.p.S, q.m_tiles * q.p.n_tiles);
         if (nm_ls().wgrad_z && q.p.nbz >= 2) {
-            static bool attr_z = false;
-            if (!attr_z) {
+            static NmDeviceOnce attr_z;
+            if (!attr_z.done()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -2364,7 +2376,7 @@ int launch_wgrad16(const WgradPlan& q, hipStream_t s) {
                     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16z_kernel<0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     nm_set_error("wgrad16z: cannot raise the dynamic LDS limit"); return NM_ERR_HIP;
                 }
-                attr_z = true;
+                attr_z.mark();
             }
             const WgradParams& pz = q.p;                  // (plan_wgrad bounded S by the column count)
             const size_t ldsz = WZ_LDS + (size_t)q.p.in.N * 64 * sizeof(float) + 64 + 256;   // tiles, X affine table, dummy item, dY affine table
@@ -2541,7 +2553,8 @@ int nm_launch_wgrad(const TensorRef& in, const TensorRef& dy, int ks, int stride
     return run_wgrad(q, ws, dW, cin_real, ks * ks * ks, s, mul);
 }
 
-int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s, int sparse_occ) {
+int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, float* ws, float* dW, hipStream_t s, int sparse_occ,
+                          hipStream_t s_coord, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (dy.C % 4 || dy.D != G) { nm_set_error("wgrad_k5occ: bad dy"); return NM_ERR_ARG; }
     TensorRef in; in.p = occ; in.scale = in.shift = nullptr; in.slope = 1.0f; in.N = N; in.D = in.H = in.W = G; in.C = 1;
     const bool sparse = sparse_occ && (dy.C == 32 || dy.C == 64) && !dy.scale && dy.slope == 1.0f;
@@ -2555,14 +2568,24 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
     float* dysum = ws; float* zocc = dysum + G3 * C; float* dense_ws = zocc + ((G3 + 63) & ~(size_t)63);
     WgradPlan q = plan_wgrad(1, G, G, G, C, 4, 5, 1, true);
     float* part = dense_ws + ((q.ws_floats + 63) & ~(size_t)63);
-    // coordinate channels: one frame holding the sum of dy over the frames, empty occupancy
-    hipLaunchKernelGGL(sum_frames4_kernel, dim3(grid_for(G3 * C / 4)), dim3(256), 0, s, dy.p, N, G3 * C / 4, dysum, dy.h);
-    int rc = nm_check_hip(hipMemsetAsync(zocc, 0, G3 * sizeof(float), s), "wgrad_k5occ: memset");
+    // coordinate channels: one frame holding the sum of dy over the frames, empty occupancy.  s_coord (with its two events): that part
+    // on a second stream beside the occupancy channel's kernel below - the two are the serial tail of the backward pass (0.41 + 0.68 ms
+    // at 64^3 x 64 frames with nothing else left to run); the occupancy channel's final reduce waits for both.
+    const bool two = s_coord && ev_fork && ev_join && s_coord != s && sparse_occ == 1 && G % 8 == 0;
+    hipStream_t sc = two ? s_coord : s;
+    int rc;
+    if (two) {
+        if ((rc = nm_check_hip(hipEventRecord(ev_fork, s), "wgrad_k5occ: fork event"))) return rc;
+        if ((rc = nm_check_hip(hipStreamWaitEvent(sc, ev_fork, 0), "wgrad_k5occ: fork wait"))) return rc;
+    }
+    hipLaunchKernelGGL(sum_frames4_kernel, dim3(grid_for(G3 * C / 4)), dim3(256), 0, sc, dy.p, N, G3 * C / 4, dysum, dy.h);
+    rc = nm_check_hip(hipMemsetAsync(zocc, 0, G3 * sizeof(float), sc), "wgrad_k5occ: memset");
     if (rc) return rc;
     TensorRef in1 = in; in1.p = zocc; in1.N = 1;
     TensorRef dy1 = dy; dy1.p = dysum; dy1.N = 1; dy1.h = 0;         // (the frame sum is fp32)
     q.p.in = in1; q.p.dy = dy1; q.p.pad = 2;
-    if ((rc = run_wgrad(q, dense_ws, dW, 4, 125, s))) return rc;
+    if ((rc = run_wgrad(q, dense_ws, dW, 4, 125, sc))) return rc;
+    if (two && (rc = nm_check_hip(hipEventRecord(ev_join, sc), "wgrad_k5occ: join event"))) return rc;
     // occupancy channel: matrix cores over the non-empty bricks (sparse_occ 1, grids that are whole 4x8x8 bricks), else the gather
     if (sparse_occ == 1 && G % 8 == 0) {
         static NmDeviceOnce attr_set;
@@ -2582,6 +2605,7 @@ int nm_launch_wgrad_k5occ(const float* occ, int N, int G, const TensorRef& dy, f
         } else
         if (C == 32) hipLaunchKernelGGL((wgrad_k5occ_mfma_kernel<32>), dim3(blocks), dim3(256), ldsb, s, occ, dy.p, N, G, part);
         else hipLaunchKernelGGL((wgrad_k5occ_mfma_kernel<64>), dim3(blocks), dim3(256), ldsb, s, occ, dy.p, N, G, part);
+        if (two && (rc = nm_check_hip(hipStreamWaitEvent(s, ev_join, 0), "wgrad_k5occ: join wait"))) return rc;
         hipLaunchKernelGGL(wgrad_k5occ_sparse_reduce_kernel, dim3((125 * C + 255) / 256), dim3(256), 0, s, part, blocks, C, dW);
         return nm_check_hip(hipGetLastError(), "wgrad_k5occ mfma launch");
     }

@@ -1026,7 +1026,10 @@ void feature_net_bwd(Bwd& b, const FeatRec& r, const float* dFeat, bool sparse_o
     const float* dy = norm_bwd(b, r.first, &w.n0, r.fpart0, r.nblk0, r.chsum0, w.c0.key + ".bias", d_first);
     float* wsb = b.alloc(nm_wgrad_k5occ_ws_floats(r.N, r.G, w.c0.Cout));
     float* gw = b.grad(w.c0.key + ".weight", (int64_t)w.c0.Cout * 4 * 125);
-    if (b.live()) b.run(nm_launch_wgrad_k5occ(r.occ, r.N, r.G, plain(dy, r.first), wsb, gw, b.s, sparse_occ ? 1 : 0));
+    // (the main walk's first layer is the last thing the backward pass does: its two halves on two streams, nm_launch_wgrad_k5occ)
+    const bool two = b.async_w && nm_ls().k5_two && b.s == b.c->stream && b.c->stream3 && b.c->stream3 != b.s;
+    if (b.live()) b.run(nm_launch_wgrad_k5occ(r.occ, r.N, r.G, plain(dy, r.first), wsb, gw, b.s, sparse_occ ? 1 : 0,
+                                               two ? b.c->stream3 : nullptr, b.c->ev_dy, b.c->ev_k5));
     b.ws.release(m);
 }
 

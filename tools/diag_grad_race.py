@@ -1,0 +1,35 @@
+"""Which gradient entries differ between repeated evaluations of the same detector gradient (G = 32, B = 2, T = 3): the pattern of a
+cross-stream race.  usage: diag_grad_race.py [repeats]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import test_train_detector_gpu as T
+from neural_marionette_amd import NeuralMarionette
+o, sd, vox = T._setup(G=32, B=2, T=3, seed=73)
+net = NeuralMarionette(o); net.load_state_dict(sd); net = net.cuda().train(); net.anneal(1)
+acts = {"detector": True, "learner": False}
+net.control_active(acts)
+v = vox.cuda()
+def grads():
+    net.zero_grad()
+    out = net(v, acts)
+    loss = sum(w * out[k] for k, w in T.AIST.items())
+    loss.backward()
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().clone() for n, p in net.kypt_detector.named_parameters() if p.grad is not None}
+ref = grads()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+nbad = 0
+for i in range(n):
+    g = grads()
+    for k in ref:
+        if not torch.equal(ref[k], g[k]):
+            d = (ref[k] != g[k])
+            idx = d.nonzero()
+            nbad += 1
+            rel = ((ref[k] - g[k]).abs().max() / ref[k].abs().max()).item()
+            print("run %d: %s shape %s: %d entries differ, max rel %.2e; first idx %s last idx %s" % (i, k, tuple(ref[k].shape), idx.shape[0], rel, idx[0].tolist(), idx[-1].tolist()))
+            if idx.shape[1] == 5:
+                print("   distinct co:", sorted(set(idx[:, 0].tolist()))[:40], " distinct ci:", sorted(set(idx[:, 1].tolist()))[:70], " taps:", sorted(set((idx[:, 2] * 9 + idx[:, 3] * 3 + idx[:, 4]).tolist())))
+print("differing (run, tensor) pairs:", nbad)
