@@ -196,39 +196,69 @@ def test_gn_backward(ctx, C, groups, size, N, slope):
     assert (dbias.cpu() - ref_bias).abs().max().item() < REL * max(y.grad.abs().sum(dim=(0, 2, 3, 4)).max().item(), 1e-30)
 
 
+def _fresh_ctx():
+    from neural_marionette_amd import _lib
+    cfg = _lib.NmConfig(device=0, grid_size=64, nkeypoints=24, nlatent=128, nhidden=512, nneighbor=2,
+                        gaussian_sigma=1.5, sep_sigma=0.02, vol_fit_chamfer=1, use_graph_traj=1)
+    c = _lib.Context(cfg)
+    c.bind_stream()
+    return c
+
+
+class _switches:
+    """NM355_* switches are read when a context is created and belong to it: a variant's parity run sets them around the creation of
+    a fresh context, in this process (a child process per variant cost 6-8 s of interpreter + torch start-up each)."""
+    def __init__(self, env):
+        self.env = env
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+    def __exit__(self, *a):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+_K3_CASES = [c for c in BWD_CASES if c[2] == 3]
+
+
 def test_conv3d_backward_valu_transposition_wgrad_variant():
     """The older weight-gradient kernel (wgrad16_kernel, VALU transposition; A/B partner of the default wgrad16t_kernel,
-    profiles/r02_wgrad16t_ab.txt, and the path for more than 96 frames) is selected when the library loads, so its parity run is a
-    child process with NM355_WGRAD_TR=0."""
-    import os, subprocess, sys
-    env = dict(os.environ, NM355_WGRAD_TR="0")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-k", "test_conv3d_backward and split16 and k3 and not variant"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+    profiles/r02_wgrad16t_ab.txt, and the path for more than 96 frames): the k3 cases again on a context created with NM355_WGRAD_TR=0."""
+    with _switches({"NM355_WGRAD_TR": "0"}):
+        c = _fresh_ctx()
+    try:
+        for case in _K3_CASES:
+            test_conv3d_backward(c, case, 1)
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("env", [{"NM355_WGRAD_Z": "0"}, {"NM355_WGRAD_Z": "0", "NM355_WGRAD_U": "0"}, {"NM355_TAIL_RANK1": "0"},
                                  {"NM355_GNB_APPLY4": "0", "NM355_DEFER_SUMS": "0"}, {"NM355_WGRAD_ASYNC": "0"}, {"NM355_WGRAD_ASYNC": "2"}],
                          ids=["wgrad16u", "wgrad16t", "tail-gradient-tensor", "gnb-apply-and-sums-per-layer", "weight-gradients-in-the-main-stream",
                               "weight-gradients-enqueued-before-the-data-gradient"])
-def test_conv3d_backward_older_kernel_variants(env):
+def test_conv3d_backward_older_kernel_variants(env, golden_dir):
     """The A/B partners of the round-3 defaults stay under parity: wgrad16u_kernel (bricks in any order, full halo per brick) and
-    wgrad16t_kernel (conditional staging loads) against the default wgrad16z_kernel, and the decoder tail's backward with its
-    [F][G^3][32] gradient materialised (NM355_TAIL_RANK1=0; that one re-runs the reference's gradient fixture G8), and the GroupNorm
-    backward with the one-voxel-at-a-time apply kernel and its gamma / beta / bias sums launched per layer (same fixture), and the
-    weight gradients inside the main stream's chain / enqueued on their own stream in front of the data gradient (same fixture).  The
-    switches are read when a context is created: child processes."""
-    import os, subprocess, sys
-    here = os.path.abspath(__file__)
+    wgrad16t_kernel (conditional staging loads) against the default wgrad16z_kernel (the k3 cases in the split-fp16 and the f16 mode on a
+    fresh context), and - re-running the reference's gradient fixture G8 on a fresh network - the decoder tail's backward with its
+    [F][G^3][32] gradient materialised (NM355_TAIL_RANK1=0), the GroupNorm backward with the one-voxel-at-a-time apply kernel and its
+    gamma / beta / bias sums launched per layer, and the weight gradients inside the main stream's chain / enqueued on their own stream
+    in front of the data gradient.  The switches are read when a context is created."""
     if "NM355_TAIL_RANK1" in env or "NM355_GNB_APPLY4" in env or "NM355_WGRAD_ASYNC" in env:
-        # the reference's own gradients of the all-losses case (fixture G8: no oracle run in the child): every backward path once
-        target = [os.path.join(os.path.dirname(here), "test_train_detector_gpu.py"), "-k", "test_detector_gradients_vs_reference_fixture"]
-    else:
-        target = [here, "-k", "test_conv3d_backward and (split16 or f16) and k3 and not variant"]
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + target, env=dict(os.environ, **env), capture_output=True, text=True,
-                       timeout=1500, cwd=os.path.dirname(os.path.dirname(here)))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
-
+        from test_train_detector_gpu import test_detector_gradients_vs_reference_fixture as g8
+        with _switches(env):
+            g8(golden_dir)
+        return
+    with _switches(env):
+        c = _fresh_ctx()
+    try:
+        for case in _K3_CASES:
+            for mode in (1, 3):
+                test_conv3d_backward(c, case, mode)
+    finally:
+        c.close()

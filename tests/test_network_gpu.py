@@ -957,33 +957,48 @@ def test_odd_hourglass_levels_with_output_padding_vs_oracle(G, path):
         assert abs(float(out[k]) - r) <= 5e-5 * max(1.0, abs(r)), k
 
 
+class _switches:
+    """NM355_* switches are read when a context is created and belong to that context: a variant's parity run sets them around the
+    construction of its networks - in this process (a child process per variant cost 6-8 s of interpreter + torch start-up each)."""
+    def __init__(self, env):
+        self.env = env
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("env", [{"NM355_VRNN_POSTMID": "1"}, {"NM355_VRNN_NB": "8"}, {"NM355_VRNN_MID": "0"}],
                          ids=["posterior-mid-kernel", "rows-per-pass-8", "six-launch-prior-step"])
-def test_vrnn_kernel_variants_stay_under_parity(env):
+def test_vrnn_kernel_variants_stay_under_parity(env, golden_dir):
     """The VRNN's A/B partners: posterior steps as three launches (vrnn_post_mid_kernel: measured slower than the six-launch step and not
     the default), the 4- / 8-row instantiations of the row kernels (6x slower per launch than the 1- / 2-row ones, the
-    default since round 3) and prior steps as six launches.  Switches are read at context creation: child processes re-run the
-    VRNN parity tests (reference fixture G2 with exact best-of-10 indices, G4 generation, the rollouts, the submodule callables)."""
-    import subprocess
-    here = os.path.abspath(__file__)
-    sel = "test_g2_vrnn_unit_parity_on_reference_keypoints or test_g4_generate32 or test_config5_rollout64 or test_submodule_callables_vs_oracle or test_generation_driver_vs_oracle"
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-k", sel], env=dict(os.environ, **env), capture_output=True,
-                       text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(here)))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+    default since round 3) and prior steps as six launches.  Under the switch, the VRNN parity tests run again on fresh contexts
+    (reference fixture G2 with exact best-of-10 indices, G4 generation, the rollouts, the submodule callables, the generation driver)."""
+    with _switches(env):
+        test_g2_vrnn_unit_parity_on_reference_keypoints(golden_dir)
+        test_g4_generate32(golden_dir)
+        test_config5_rollout64(1)
+        test_config5_rollout64(3)
+        test_submodule_callables_vs_oracle()
+        test_generation_driver_vs_oracle()
 
 
 @pytest.mark.parametrize("env", [{"NM355_POOL_Q": "0"}, {"NM355_OCC_FLAGS": "0"}, {"NM355_OCC_FLAGS": "1"}],
                          ids=["pool-conv-f16s", "first-layer-no-flags", "first-layer-flags-no-row-walk"])
-def test_forward_kernel_variants_stay_under_parity(env):
+def test_forward_kernel_variants_stay_under_parity(env, golden_dir):
     """The forward's late round-3 A/B partners: the k2 s2 pool convs on conv_pool_f16s_kernel (conditional staging loads) instead of
     conv_pool_f16q_kernel, and the sparse first layer finding its empty bricks without the per-brick occupancy flags / with the flags
-    but one workgroup per brick instead of per x-row of bricks.  Child processes (switches are read at context creation) re-run the
-    reference fixtures G1 / G2 and the bit-identity of the inference shortcuts."""
-    import subprocess
-    here = os.path.abspath(__file__)
-    sel = "test_g1_config1_detector64 or test_g2_forward32_vs_reference_fixture or test_inference_shortcuts_are_bit_identical_to_the_plain_evaluation"
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-k", sel], env=dict(os.environ, **env), capture_output=True,
-                       text=True, timeout=1500, cwd=os.path.dirname(os.path.dirname(here)))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+    but one workgroup per brick instead of per x-row of bricks.  Under the switch (fresh contexts): the reference fixtures G1 / G2 in the
+    default arithmetic, both forward paths, and the bit-identity of the inference shortcuts."""
+    with _switches(env):
+        for path in PATHS:
+            test_g1_config1_detector64(golden_dir, "split16", path)
+            test_g2_forward32_vs_reference_fixture(golden_dir, "split16", path)
+        for G in (64, 96, 40):
+            test_inference_shortcuts_are_bit_identical_to_the_plain_evaluation(G)
