@@ -2035,7 +2035,7 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const float* __restrict_
 // once instead of per 16-byte item, and four items' tensor loads are in flight before the first is used.  The generic kernel's loop
 // is one item per iteration behind three dependent waits (tensor loads, scale / shift, coefficients) and runs at 4.9 TB/s on
 // occupancy alone.  Identity operands (scale 1 / shift 0, slope 1) leave the values as they are; same arithmetic per element.
-template <bool RANK1, bool COEF, bool H>
+template <bool RANK1, bool COEF, bool H, unsigned U = 4u>
 __global__ __launch_bounds__(256) void gnb_apply4_kernel(const float* __restrict__ dA, TensorRef y, const float* __restrict__ coef,
                                                          float* __restrict__ dy, unsigned* __restrict__ amax, const float* __restrict__ dmul,
                                                          const float* __restrict__ dv, const float* __restrict__ wv) {
@@ -2070,17 +2070,18 @@ __global__ __launch_bounds__(256) void gnb_apply4_kernel(const float* __restrict
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
     };
     unsigned r = r0;
-    for (; r + 3u * step < per_frame && r + 3u * step >= r; r += 4u * step) {
-        f32x4 yy[4], dd[4];
+    // U items in flight (bfloat16: eight 8-byte loads = the bytes of four fp32 ones; NM355_GNB_U8=0: four, A/B)
+    for (; r + (U - 1u) * step < per_frame && r + (U - 1u) * step >= r; r += U * step) {
+        f32x4 yy[U], dd[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (unsigned u = 0; u < U; ++u) {
             const unsigned ru = r + u * step;
             yy[u] = nm_ld4<H>(yp, ru);
             if (RANK1) { const float q = dvp[ru / C]; dd[u] = f32x4{q * w4[0], q * w4[1], q * w4[2], q * w4[3]}; }
             else dd[u] = nm_ld4<H>(dp, ru);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) one(yy[u], dd[u], r + u * step);
+        for (unsigned u = 0; u < U; ++u) one(yy[u], dd[u], r + u * step);
     }
     for (; r < per_frame; r += step) {
         const f32x4 yy = nm_ld4<H>(yp, r);
@@ -2674,7 +2675,8 @@ int nm_launch_gnb_apply(const float* dA, const TensorRef& y, const float* coef, 
     const unsigned bx = (unsigned)min((frame4 + 255) / 256, (size_t)max(1, 4096 / max(y.N, 1)));
     if (nm_ls().gnb_apply4 && 1024 % y.C == 0) {
         const dim3 g(bx, y.N);
-#define NM_GNB_APPLY4(R, Cf) do { if (y.h) hipLaunchKernelGGL((gnb_apply4_kernel<R, Cf, true>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv); \
+#define NM_GNB_APPLY4(R, Cf) do { if (y.h && nm_ls().gnb_u8) hipLaunchKernelGGL((gnb_apply4_kernel<R, Cf, true, 8u>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv); \
+                                 else if (y.h) hipLaunchKernelGGL((gnb_apply4_kernel<R, Cf, true>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv); \
                                  else hipLaunchKernelGGL((gnb_apply4_kernel<R, Cf, false>), g, dim3(256), 0, s, dA, y, coef, dy, amax, dA_mul, dv, wv); } while (0)
         if (dv) { if (coef) NM_GNB_APPLY4(true, true); else NM_GNB_APPLY4(true, false); }
         else if (coef) NM_GNB_APPLY4(false, true);
