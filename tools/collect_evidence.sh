@@ -17,13 +17,13 @@ tail -1 $E/bench_default.log > $E/${R}_bench.json.log
 CMD="python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/fwd -- $CMD > $E/fwd.log 2>&1
 cp $(find $E/fwd -name "*kernel_stats.csv" | head -1) $E/${R}_bench_kernel_stats.csv
-python3 tools/trace_timeline.py $E/fwd mean_t_kernel 2 --starved --list > $E/${R}_forward_timeline.txt 2>&1
+python3 tools/trace_timeline.py $E/fwd "conv_k5occ_f16_kernel<1" 2 --starved --list > $E/${R}_forward_timeline.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/train -- python3 bench.py --workload train --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $E/train.log 2>&1
 cp $(find $E/train -name "*kernel_stats.csv" | head -1) $E/${R}_train_kernel_stats.csv
-python3 tools/trace_timeline.py $E/train mean_t_kernel 2 --starved --list > $E/${R}_train_timeline.txt 2>&1
+python3 tools/trace_timeline.py $E/train "conv_k5occ_f16_kernel<1" 2 --starved --list > $E/${R}_train_timeline.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/trainb -- python3 bench.py --workload train --conv-mode bf16 --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $E/trainb.log 2>&1
 cp $(find $E/trainb -name "*kernel_stats.csv" | head -1) $E/${R}_train_bf16_kernel_stats.csv
-python3 tools/trace_timeline.py $E/trainb mean_t_kernel 2 --starved --list > $E/${R}_train_bf16_timeline.txt 2>&1
+python3 tools/trace_timeline.py $E/trainb "conv_k5occ_f16_kernel<1" 2 --starved --list > $E/${R}_train_bf16_timeline.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/c4 -- python3 tools/time_config4.py 96 > $E/c4.log 2>&1
 cp $(find $E/c4 -name "*kernel_stats.csv" | head -1) $E/${R}_config4_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/c5 -- python3 tools/time_rollout.py /tmp/ro.pt > $E/c5.log 2>&1
