@@ -98,7 +98,8 @@ def cpu_baseline(sd, opts, net, dev):
     """Oracle (kind 'port') on the bench's own shape (BASELINE config 2: B = 4 clips of 64^3 x T=16, full forward =
     detector + losses + VRNN encode).  Thread count: calibrated on a DETECTOR-dominated sample (one 64^3 clip, T = 4: the conv
     stacks are >95 % of the CPU time, as on the full shape; a 2-frame clip over-weights the VRNN's thousands of tiny ops and
-    picks too few threads) over {8, 16, 32, 64, 128, os.cpu_count()}; the two best counts are then both timed on the full shape
+    picks too few threads) over {8, 16, 32, 64, 128, os.cpu_count()} in ascending order (counts behind one that is already 3x slower than
+    the best are not timed); the two best counts are then both timed on the full shape
     and the faster one gets the remaining runs (median of three).  `cores` = the count used, `host_threads` = os.cpu_count()."""
     from neural_marionette_amd import synth
     from oracle import nm_oracle as O
@@ -108,9 +109,14 @@ def cpu_baseline(sd, opts, net, dev):
     vox = synth.figure_clip(nb, T, G, seed=1001)
     eps = synth.make_eps((T, S, nb, opts.nlatent_kypt), seed=1002)
     small_v, small_e = vox[:1, :4].contiguous(), eps[:4, :, :1].contiguous()
-    calib = {}
+    calib, skipped = {}, []
     with torch.no_grad():
         for thr in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)} | {default}):
+            # ascending; once a count is more than 3x slower than the best so far the larger ones are not timed (oversubscribed pools
+            # only get worse: 256 threads took 129 s for this 1 s sample on the round-4 evidence host, profiles/r04_bench.json.log)
+            if calib and calib[max(calib)] > 3.0 * min(calib.values()):      # (the largest count timed so far)
+                skipped.append(thr)
+                continue
             torch.set_num_threads(thr)
             O.nm_forward(sd, opts, small_v[:, :1], small_e[:1])           # warm this pool size
             t0 = time.perf_counter()
@@ -146,6 +152,7 @@ def cpu_baseline(sd, opts, net, dev):
                   best_idx_equal=bool((out["best_idx"].cpu().long() == ref["best_idx"].long()).all()))
     return dict(value=nb * T / med, unit="voxel-frames/s", cores=best_thr, host_threads=ncpu, kind="port", runs_s=[round(t, 3) for t in times],
                 thread_calibration_s={str(k): round(v, 3) for k, v in sorted(calib.items())},
+                thread_calibration_not_timed=[int(k) for k in skipped],
                 full_shape_first_run_s={str(k): round(v[0], 3) for k, v in runs.items()},
                 sample=f"{'median' if len(times) >= 3 else 'mean'} of {len(times)} x oracle.nm_forward on {nb} clips of 64^3 x T=16 (the bench shape) "
                        f"(detector + losses + VRNN encode), torch {torch.__version__} CPU ops, "
