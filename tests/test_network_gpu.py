@@ -398,7 +398,9 @@ def test_config5_rollout64(B):
     with torch.no_grad():
         aff = O.affinity_v3(sd["kypt_detector.affinity_params"])
         _, order, _, parents = O.build_tree(aff)
-        ref = O.vrnn_generate(sd, o, kp, order, parents, Tt, Tc, e_post, e_prior)
+        if ("c5", B) not in _ORACLE_CACHE:            # (the kernel-variant tests run this test again: one oracle rollout per session)
+            _ORACLE_CACHE[("c5", B)] = O.vrnn_generate(sd, o, kp, order, parents, Tt, Tc, e_post, e_prior)
+        ref = _ORACLE_CACHE[("c5", B)]
     d = net.dyna_module
     out = d.generate(kp.cuda(), aff.cuda(), Ttot=Tt, Tcond=Tc, eps_post=e_post.cuda(), eps_prior=e_prior.cuda())
     torch.cuda.synchronize()
@@ -509,7 +511,9 @@ def test_generation_driver_vs_oracle():
     out = net.sample_generation(vox.cuda(), Tgen=Tg, sample_num=S, eps_post=e_post.cuda(), eps_prior=e_prior.cuda())
     torch.cuda.synchronize()
     with torch.no_grad():
-        ref = O.sample_generation(sd, o, vox, Tg, S, e_post, e_prior)
+        if "gen_driver" not in _ORACLE_CACHE:
+            _ORACLE_CACHE["gen_driver"] = O.sample_generation(sd, o, vox, Tg, S, e_post, e_prior)
+        ref = _ORACLE_CACHE["gen_driver"]
     assert _err(out["keypoints_cond"], ref["keypoints_cond"]) < KP_TOL
     # per-step claim on the conditioned steps and the first two generated steps (1e-4); the free-running tail is held to the measured
     # amplification of that error through the recurrence (see test_g4_generate32)
