@@ -73,9 +73,14 @@ int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream);
  * reference's fp32 arithmetic (torch CPU ops under kypt_detector.py:81-169) stays finite.  The reference's networks never come
  * near that range (every conv input is a GroupNorm output, an occupancy or a Gaussian map), so the guard is a status word, not a
  * per-launch test: the GroupNorm finalisation of every conv ORs 1 into a ctx-owned device word when the conv's statistics are not
- * finite.  nm_ctx_check_nonfinite synchronises the ctx stream, returns NM_ERR_RANGE (and clears the word) if that happened since
- * the last check, 0 otherwise; the remedy is nm_set_conv_mode(ctx, 0) (exact fp32 MFMA, no range limit).  The op-level entry
- * point nm_op_conv3d is synchronous about it: it scans its result and re-runs the launch on the fp32 path by itself. */
+ * finite.  The word is READ AUTOMATICALLY (round 4): every forward-type entry point (nm_detector_forward[_train], nm_forward_fused,
+ * nm_vrnn_encode / generate / rollout ...) ends with a 4-byte copy of it into a pinned host slot behind an event, and every entry
+ * point begins by looking at the slots whose events have completed - no device synchronisation; a set bit makes THAT call fail
+ * with a message naming the call that produced the value and the remedy (nm_set_conv_mode(ctx, 0): exact fp32 MFMA, no range
+ * limit): NM_ERR_RANGE for bit 1 (non-finite conv statistics), NM_ERR_STATE for bit 2 (a persistent rollout kernel gave up a bounded
+ * wait - never a hang).  nm_ctx_check_nonfinite drains the pending slots synchronously with the same two codes, word cleared; 0
+ * otherwise.  NM355_RANGE_CHECK=0 removes the copies.  The op-level entry point nm_op_conv3d is synchronous about it: it
+ * scans its result and re-runs the launch on the fp32 path by itself.  (The Python shells add set_conv_mode('auto').) */
 int nm_ctx_check_nonfinite(nm_ctx* ctx);
 /* Replaces NeuralMarionette.load_state_dict / .cuda() for the HIP path: copies every
  * tensor and re-packs conv weights into the MFMA layout.  Must be called again after an
@@ -302,7 +307,7 @@ int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, in
  * all modes.  mode 3 = reduced precision for training at autocast-class accuracy (BASELINE.json config 3 names bf16): the
  * kernels of mode 1 with only the x_hi*w_hi product, i.e. operands rounded to fp16 (11 significant bits - three more than
  * bf16, same MFMA rate), fp32 accumulation, fp32 tensors, statistics, losses, master weights and optimiser; the layers mode 1
- * leaves on the fp32 cores (k = 1 / 2 weight gradients, volumes under 16^3, heads, VRNN) stay fp32.  Forward, data and weight
+ * leaves on the fp32 cores (k = 1 weight gradients, volumes under 16^3, heads, VRNN) stay fp32.  Forward, data and weight
  * gradients all follow the mode.  Outputs differ from the reference's fp32 path by ~1e-3 relative (tests state the bound);
  * the 1e-4 parity contract holds in modes 0-2 only.
  * mode 4 = BASELINE config 3 as named ("bf16"): mode 3's arithmetic with 16-BIT STORAGE of the training path - every activation the
