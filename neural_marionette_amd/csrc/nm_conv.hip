@@ -1779,6 +1779,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
         }
         using RawT = std::conditional_t<IH, nm_u32x2, f32x4>;
         RawT raw[NP]; f32x4 sc, sh, wreg[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) wreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};       // (SINGLE uses three of them; all five are operands of the counted waits)
         const bool has_affine = p.in_scale != nullptr;
         const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * EB;   // halo voxel (1,1,1): always inside
         // bit k: piece k of a brick's halo tile lies inside the volume
@@ -1841,10 +1843,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
         // direct-to-LDS copy of tap group g of (cout group cg, chunk cb) into weight buffer g: 18 one-KiB wave loads; every
         // producer wave issues five (two are issued twice) so that the counted waits are the same in all of them.  The
         // per-wave source / destination offsets inside a tap group are fixed: per call only a scalar base is computed.
-        unsigned dma_src[5], dma_dst[5];
+        // SINGLE (conv modes 3 / 4): the lo halves (j odd) are never read by the MFMA waves - nine hi pieces, three per wave (see conv_f16p2)
+        constexpr int NWP = SINGLE ? 3 : 5;
+        unsigned dma_src[NWP], dma_dst[NWP];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int j = (i < 4) ? pw + 4 * i : min(pw + 16, 17), t = j >> 1;
+        for (int i = 0; i < NWP; ++i) {
+            const int j = SINGLE ? 2 * min(pw + 4 * i, 8) : ((i < 4) ? pw + 4 * i : min(pw + 16, 17)), t = j >> 1;
             dma_src[i] = (unsigned)(((size_t)t * C16 * 4 + (j & 1) * 2) * plane + lane_off) * 16u;       // bytes, + lane part
             dma_dst[i] = (unsigned)(t * 128 + (j & 1) * 64 + lane) * 16u;
         }
@@ -1853,12 +1857,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
         auto load_b_group = [&](int cg, int cb, int g) {
             const float* base = reinterpret_cast<const float*>(w8 + ((size_t)(9 * g) * C16 * 4 + (size_t)cb * 4) * plane + cg * 32);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) wreg[i] = load16_untracked(base, dma_src[i]);
+            for (int i = 0; i < NWP; ++i) wreg[i] = load16_untracked(base, dma_src[i]);
         };
         auto store_b_group = [&](int g) {
             char* lbase = reinterpret_cast<char*>(ldb + g * GB);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) *reinterpret_cast<f32x4*>(lbase + dma_dst[i]) = wreg[i];
+            for (int i = 0; i < NWP; ++i) *reinterpret_cast<f32x4*>(lbase + dma_dst[i]) = wreg[i];
         };
 
         // The input runs two steps ahead of the MFMA waves: during step s the tile of step s+1 (loaded during step s-1) is
@@ -1892,7 +1896,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             // tap group 0: weights of this step's group 2; pieces 0-3.  Everything older than the 5 weight loads has landed
             // after the first wait (the tile of step s+1 and its affine were issued a step ago).
             load_b_group(cur.w.cg, cur.cb, 2);
-            NM_PRODUCER_WAIT(5);
+            if constexpr (SINGLE) { NM_PRODUCER_WAIT(3); } else { NM_PRODUCER_WAIT(5); }      // (the NWP weight loads are the youngest)
             NM_PSTAMP(1);
             static_for<4>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
             NM_PRODUCER_WAIT(4);                                    // the weight loads (older than the 4 new piece loads)
@@ -2210,6 +2214,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
         }
         using RawT = std::conditional_t<IH, nm_u32x2, f32x4>;
         RawT raw[NP]; f32x4 sc, sh, wreg[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};       // (SINGLE uses five of them; all nine are operands of the counted waits)
         const bool has_affine = p.in_scale != nullptr;
         const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * EB;   // halo voxel (1,1,1): always inside
         auto inside_mask = [&](const Work& w) {
@@ -2267,11 +2273,16 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
                 if constexpr (!SINGLE) dst[4 * HV] = lo4;
             }
         };
-        // tap group g of (cout group cg, chunk cb): 36 one-KiB wave pieces (tap t, plane r, 64 channels), nine per producer wave
-        unsigned w_src[9], w_dst[9];
+        // tap group g of (cout group cg, chunk cb): 36 one-KiB wave pieces (tap t, plane r, 64 channels), nine per producer wave.
+        // SINGLE (conv modes 3 / 4): the MFMA waves never read the lo planes r = 2, 3 - only the 18 hi pieces are copied, five per wave
+        // (the last two of the 20 slots repeat piece 17: identical bytes to the same place).  The weight copies are three quarters of a
+        // producer wave's issue slots, and in the one-product modes the producers, not the MFMA pipe, bound the kernel.
+        constexpr int NW = SINGLE ? 5 : 9;
+        unsigned w_src[NW], w_dst[NW];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int j = pw + 4 * i, t = j >> 2, r = j & 3;
+        for (int i = 0; i < NW; ++i) {
+            const int j = SINGLE ? min(pw + 4 * i, 17) : pw + 4 * i;
+            const int t = SINGLE ? j >> 1 : j >> 2, r = SINGLE ? j & 1 : j & 3;
             w_src[i] = (unsigned)(((size_t)t * C16 * 4 + r) * plane + lane) * 16u;
             w_dst[i] = (unsigned)(t * 256 + r * 64 + lane) * 16u;
         }
@@ -2283,21 +2294,22 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             const float* base = reinterpret_cast<const float*>(w8 + ((size_t)(9 * g) * C16 * 4 + (size_t)cb * 4) * plane + cg * 64);
             if (wdma) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    const int j = pw + 4 * i;
+                for (int i = 0; i < NW; ++i) {
+                    const int j = SINGLE ? min(pw + 4 * i, 17) : pw + 4 * i;
+                    const int t = SINGLE ? j >> 1 : j >> 2, r = SINGLE ? j & 1 : j & 3;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + w_src[i]),
-                                                     (__attribute__((address_space(3))) void*)(ldb + buf * GB + (j >> 2) * 256 + (j & 3) * 64), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(ldb + buf * GB + t * 256 + r * 64), 16, 0, 0);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) wreg[i] = load16_untracked(base, w_src[i]);
+                for (int i = 0; i < NW; ++i) wreg[i] = load16_untracked(base, w_src[i]);
             }
         };
         auto store_b_group = [&](int buf) {
             if (wdma) return;
             char* lbase = reinterpret_cast<char*>(ldb + buf * GB);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(lbase + w_dst[i]) = wreg[i];
+            for (int i = 0; i < NW; ++i) *reinterpret_cast<f32x4*>(lbase + w_dst[i]) = wreg[i];
         };
 
         Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
@@ -2329,7 +2341,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             // tap group 0: weights of this step's group 1 (into the buffer group 2 of the last step was read from); pieces 0-2.
             // Everything older than the 9 weight loads has landed after the first wait.
             load_b_group(cur.w.cg, cur.cb, 1, gpar ^ 1);
-            NM_PRODUCER2_WAIT(9);
+            if constexpr (SINGLE) { NM_PRODUCER2_WAIT(5); } else { NM_PRODUCER2_WAIT(9); }      // (NW weight loads are the youngest)
             static_for<3>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
             NM_PRODUCER2_WAIT(3);                                   // the weight loads (older than the 3 new piece loads)
             store_b_group(gpar ^ 1);
