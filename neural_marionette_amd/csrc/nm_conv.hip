@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                             split8(apply_act(p, pa[hz], sca, sha), apply_act(p, pb[hz], scb, shb), hi, lo);
                         }
                         ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
-                        ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
+                        if constexpr (!SINGLE) ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;      // (the one-product modes never read the lo planes)
                     }
                 } else {
                     // global loads of half the column first (HB planes x 8 channels), then activate / split / write
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                             if ((unsigned)(iz0 + hz) < (unsigned)p.ID)
                                 split8(apply_act(p, ra[j], sca, sha), apply_act(p, rb[j], scb, shb), hi, lo);
                             ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
-                            ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
+                            if constexpr (!SINGLE) ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;      // (the one-product modes never read the lo planes)
                         }
                     }
                 }
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(ConvParams p) {
                     half8 hi, lo;
                     split8(va, vb, hi, lo);
                     ldh[s_hh * p.HVp + hz * p.ZP + s_lds] = hi;
-                    ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;
+                    if constexpr (!SINGLE) ldh[(2 + s_hh) * p.HVp + hz * p.ZP + s_lds] = lo;      // (the one-product modes never read the lo planes)
                 }
             }
         }

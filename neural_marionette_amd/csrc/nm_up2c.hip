@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
             split8(act4(pr_a, sca, sha, affine, p.in_slope), act4(pr_b, scb, shb, affine, p.in_slope), hi, lo);
             const int slot = hz * ZP + hy * HX + hx;
             buf[s_plane * HVP + slot] = hi;
-            buf[(s_plane + 2) * HVP + slot] = lo;
+            if constexpr (!SINGLE) buf[(s_plane + 2) * HVP + slot] = lo;      // (the one-product modes never read the lo planes)
         }
     };
     auto ldw = [&](const char* base, size_t extra) { return *reinterpret_cast<const half8*>(base + extra + wlane); };
