@@ -8,7 +8,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 N, D, Cin, Cout = 64, 32, 64, 32
 cfg = _lib.NmConfig(device=0, grid_size=64, nkeypoints=24, nlatent=128, nhidden=512, nneighbor=2, gaussian_sigma=1.5, sep_sigma=0.02, vol_fit_chamfer=1, use_graph_traj=1)
 ctx = _lib.Context(cfg); ctx.bind_stream()
-_lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, 1), "mode")
+_lib.check(ctx.lib.nm_set_conv_mode(ctx.handle, int(os.environ.get("NM355_TIME_MODE", "1"))), "mode")
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(N, D, D, D, Cin, device="cuda", generator=g)
 w = torch.randn(Cout, Cin, 3, 3, 3, device="cuda", generator=g) / (Cin * 27) ** 0.5
