@@ -56,7 +56,7 @@ NmLaunchState::NmLaunchState()
       clip_late(env_int("NM355_CLIP_LATE", 1)),         // 0: the clip-mean net is enqueued before the per-frame encoder instead of behind its first chunk(s) (A/B)
       gnb_u8(env_int("NM355_GNB_U8", 1)),               // 0: four instead of eight items in flight in the bfloat16 GroupNorm-backward apply (A/B)
       adj_zwalk(env_int("NM355_ADJ_ZWALK", 1))          // 0: the trilinear upsample's adjoint on the 2 x 4 x 8 brick kernel (6 x 10 x 18 fine tile) instead of the z-walking one (A/B)
-{ store16_min = env_int("NM355_STORE16_MIN", 32768); }
+{ store16_min = env_int("NM355_STORE16_MIN", 32768); chain_spin = env_int("NM355_CHAIN_SPIN", 1 << 20); chain_drop = env_int("NM355_CHAIN_DROP_WG", 0); }
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
     return nm_tls_ls ? *nm_tls_ls : outside;
@@ -159,7 +159,9 @@ static void release_side_streams(int dev, hipStream_t s2, hipStream_t s3, bool s
 int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
     if (!out || !cfg) { nm_set_error("ctx_create: null argument"); return NM_ERR_ARG; }
     if (cfg->grid_size < 32 || cfg->grid_size % 8) { nm_set_error("ctx_create: grid_size %d unsupported", cfg->grid_size); return NM_ERR_UNSUPPORTED; }
-    if (cfg->nkeypoints <= 1 || cfg->nkeypoints > 32 || cfg->nkeypoints % 8) { nm_set_error("ctx_create: nkeypoints %d unsupported (multiple of 8, <= 32)", cfg->nkeypoints); return NM_ERR_UNSUPPORTED; }
+    // (any keypoint count in [2, 32]: the reference's dataset configs use 12 / 22 / 24 / 28, dataset/config.py:97,124, train.py:60; the
+    //  heat-map heads run zero-padded to a multiple of 8 channels inside the library, everything else takes K as it is)
+    if (cfg->nkeypoints <= 1 || cfg->nkeypoints > 32) { nm_set_error("ctx_create: nkeypoints %d unsupported (2 .. 32)", cfg->nkeypoints); return NM_ERR_UNSUPPORTED; }
     int ndev = 0;
     int rc = nm_check_hip(hipGetDeviceCount(&ndev), "ctx_create: hipGetDeviceCount");
     if (rc) return rc;
@@ -275,8 +277,12 @@ int nm_ctx_check_nonfinite(nm_ctx* ctx) { NmScope nm_scope_(ctx);
     if (!v) return NM_OK;
     (void)hipMemset(ctx->nf_flag, 0, sizeof(unsigned));
     if (v & 2u) {
+        // (as in nm_nf_poll: this context stops using the persistent chain; its captured graphs hold that launch and are dropped)
+        (void)hipDeviceSynchronize();
+        ctx->ls.vrnn_chain = 0;
+        nm_vrnn_free_graphs(ctx);
         nm_set_error("the persistent rollout kernel timed out waiting for its workgroups since the last check (its outputs are invalid); "
-                     "NM355_VRNN_CHAIN=0 selects the launch-per-phase steps");
+                     "this context now takes the launch-per-phase steps (as NM355_VRNN_CHAIN=0 does from the start) - repeat the call");
         return NM_ERR_STATE;
     }
     nm_set_error("a convolution produced non-finite values since the last check: %s", nm_conv_get_mode() != 0

@@ -130,6 +130,10 @@ struct NmLaunchState {
     bool store16 = false;      // mode 4 ('bf16'): mode 3's arithmetic + bfloat16 storage of the training path's large tensors
     int op_in_h = 0, op_out_h = 0;   // op-level entry points (nm_op_*): element type of the input-side / output-side tensors (nm_op_set_storage16)
     int store16_min = 32768;   // ... those with at least this many voxels per frame (NM355_STORE16_MIN; 32^3: everything above the hourglass)
+    // persistent rollout kernel (nm_vrnn.hip vrnn_prior_chain_kernel): polls before a spin gives up (NM355_CHAIN_SPIN), trailing
+    // workgroups NOT launched (NM355_CHAIN_DROP_WG: the test hook that stands in for a workgroup that never becomes resident), and the
+    // co-residency verdict of this context's device (-1: not asked yet, 0: the chain does not fit, 1: it does)
+    int chain_spin = 1 << 20, chain_drop = 0, chain_fits = -1;
     bool prof_on = false;
     hipStream_t prof_stream = nullptr;     // main stream of the profiled context; prof_all: launches on any stream are recorded
     bool prof_all = false;
@@ -169,6 +173,7 @@ int nm_launch_pack_conv_weight16(const float* w_oidhw, int Cout, int Cin, int ks
 struct NmPackJob {
     const float* src; float* wp; void* wp16;
     int Cout, Cin, ks, Cin_pad, Co_pad, src_cin, flip, blk0, nblk;
+    int src_rows;      // rows of `src` (its leading dimension's extent): reads beyond it are zeros (padded layers); 0 = no limit
 };
 int nm_pack_job_blocks(const NmPackJob& j);       // blocks the job takes in the launch (fills nothing)
 int nm_launch_pack_jobs(const NmPackJob* device_jobs, int njobs, int total_blocks, hipStream_t s);

@@ -2784,6 +2784,8 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const NmPackJob* __restr
     const int lb = blockIdx.x - j.blk0, taps = j.ks * j.ks * j.ks;
     auto W = [&](int co, int ci, int tap) -> float {
         if (co >= j.Cout || ci >= j.Cin) return 0.f;
+        // (a layer whose channel count is padded inside the library: the source tensor has fewer rows / columns than the packed form)
+        if (j.src_rows > 0 && ((j.flip ? ci : co) >= j.src_rows || (j.flip ? co : ci) >= j.src_cin)) return 0.f;
         return j.flip ? j.src[((size_t)ci * j.src_cin + co) * taps + (taps - 1 - tap)] : j.src[((size_t)co * j.src_cin + ci) * taps + tap];
     };
     const size_t total32 = (size_t)taps * j.Cin_pad * j.Co_pad;

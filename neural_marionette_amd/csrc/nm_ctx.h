@@ -29,13 +29,14 @@ struct Arena {
 // ---- network weights (ctx-owned device copies) -------------------------------------------
 struct ConvW {
     int Cin = 0, Cin_pad = 0, Cout = 0, Co_pad = 0, ks = 0;
+    int Cout_src = 0;         // rows of the state_dict weight / bias (< Cout when the library pads the layer's output channels: the heat-map heads)
     float* wp = nullptr;      // fp32 packed [tap][Cin/4][Co_pad][4]
     void* wp16 = nullptr;     // split-fp16 packed (Cin % 16 == 0 only), see nm_conv.hip
     float* bias = nullptr;
     void* wup = nullptr;      // fused-upsample layers: composite weight sets of nm_up2c.hip
     // training (nm_ctx_set_training): state_dict key prefix and the weights of the data-gradient convolution
     std::string key;
-    int csel = 0, cd_pad = 0;  // input channels that receive a gradient (Cin rounded down to 8) and their packed width
+    int csel = 0, cd_pad = 0;  // input channels that receive a gradient (Cin rounded down to 8, or what Loader::conv was asked for) and their packed width
     float* wd = nullptr;       // ks 1/3: flipped + transposed, fp32 packed [tap][Cout/4][cd_pad][4]
     void* wd16 = nullptr;      //         same, split-fp16 (Cout % 16 == 0)
     float* wt = nullptr;       // ks 2 (stride 2): [tap][Cout][Cin] for the transposed-conv kernel

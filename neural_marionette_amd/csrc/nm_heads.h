@@ -2,7 +2,7 @@
 #pragma once
 #include "nm_common.h"
 
-int nm_launch_heatmap(const float* head, const float* clip_head, const float* prop, int F, int T, int K, int g,
+int nm_launch_heatmap(const float* head, const float* clip_head, const float* prop, int F, int T, int K, int Kc /* channels per voxel of head / clip_head (>= K, % 4 == 0) */, int g,
                       float* heatmaps, float* part, hipStream_t s);
 int nm_launch_keypoints(const float* part, int F, int K, int g, float* keypoints, float* heat_mean, hipStream_t s);
 int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s);

@@ -37,8 +37,10 @@ __device__ __forceinline__ float block_sum256(float v, float* sh) {
 }
 
 // grid (F, g): one z-plane of one frame.  LDS: K * g * g floats.
+// head / clip_head rows hold Kc = K rounded up to 8 channels per voxel (the heads run zero-padded for keypoint counts that are not
+// multiples of 8): channels >= K are read with the quad they share and dropped.
 __global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ head, const float* __restrict__ clip_head,
-                                                      const float* __restrict__ prop, int T, int K, int g,
+                                                      const float* __restrict__ prop, int T, int K, int Kc, int g,
                                                       float* __restrict__ heatmaps, float* __restrict__ part) {
     extern __shared__ float tile[];                       // [K][g*g]
     const int f = blockIdx.x, z = blockIdx.y, b = f / T;
@@ -46,13 +48,14 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ 
     const float w0 = prop[0], w1 = prop[1], pb = prop[2];
     for (int v = threadIdx.x; v < g2; v += 256) {
         const size_t vox = (size_t)z * g2 + v;
-        const float* hp = head + ((size_t)f * g3 + vox) * K;
-        const float* cp = clip_head + ((size_t)b * g3 + vox) * K;
+        const float* hp = head + ((size_t)f * g3 + vox) * Kc;
+        const float* cp = clip_head + ((size_t)b * g3 + vox) * Kc;
         for (int k = 0; k < K; k += 4) {
             f32x4 a = *reinterpret_cast<const f32x4*>(hp + k);
             f32x4 c = *reinterpret_cast<const f32x4*>(cp + k);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (k + j >= K) break;
                 float hm = softplus(w0 * lrelu(a[j], 0.01f) + w1 * lrelu(c[j], 0.01f) + pb);
                 heatmaps[((size_t)f * K + k + j) * g3 + vox] = hm;
                 tile[(k + j) * g2 + v] = hm;
@@ -443,11 +446,11 @@ __global__ void affinity_kernel(const float* __restrict__ params, int N, int K, 
 
 }  // namespace
 
-int nm_launch_heatmap(const float* head, const float* clip_head, const float* prop, int F, int T, int K, int g,
+int nm_launch_heatmap(const float* head, const float* clip_head, const float* prop, int F, int T, int K, int Kc, int g,
                       float* heatmaps, float* part, hipStream_t s) {
-    if (K % 4 || K > 32) { nm_set_error("heatmap: K=%d unsupported", K); return NM_ERR_ARG; }
+    if (K < 1 || K > 32 || Kc % 4 || Kc < K) { nm_set_error("heatmap: K=%d (row pitch %d) unsupported", K, Kc); return NM_ERR_ARG; }
     size_t lds = (size_t)K * g * g * sizeof(float);
-    hipLaunchKernelGGL(heatmap_kernel, dim3(F, g), dim3(256), lds, s, head, clip_head, prop, T, K, g, heatmaps, part);
+    hipLaunchKernelGGL(heatmap_kernel, dim3(F, g), dim3(256), lds, s, head, clip_head, prop, T, K, Kc, g, heatmaps, part);
     return nm_check_hip(hipGetLastError(), "heatmap launch");
 }
 
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256) void adjust_gauss_kernel(const float* __restri
 }
 int nm_launch_adjust_gauss(const float* table, const float* keypoints, const float* base, const float* wg, int F, int T, int K, int g,
                            int Cout, float* out, hipStream_t s) {
-    if (K > 32 || K % 8 || Cout % 4 || 8 * (Cout / 4) != 256) { nm_set_error("adjust_gauss: unsupported K=%d Cout=%d", K, Cout); return NM_ERR_ARG; }
+    if (K > 32 || K < 1 || Cout % 4 || 8 * (Cout / 4) != 256) { nm_set_error("adjust_gauss: unsupported K=%d Cout=%d", K, Cout); return NM_ERR_ARG; }
     const int g3 = g * g * g;
     const dim3 grid((g3 + 63) / 64, F);
     if (K <= 8) hipLaunchKernelGGL(adjust_gauss_kernel<8>, grid, dim3(256), 0, s, table, keypoints, base, wg, T, K, g, Cout, out);

@@ -17,7 +17,7 @@ int nm_launch_combined_bwd(const float* dcomb, int Cd, const float* table, const
                            float width, float* ws, float* dfeat, float* dkp, hipStream_t s);
 size_t nm_heat_bwd_ws_floats(int F, int K, int g);
 int nm_launch_heat_bwd(const float* head, const float* clip_head, const float* prop, const float* heat_part, const float* heat_mean,
-                       const float* keypoints, const float* dkp, const float* dloss, int B, int T, int K, int g, float* ws, float* dhead,
+                       const float* keypoints, const float* dkp, const float* dloss, int B, int T, int K, int Kc /* channels per voxel of the head tensors (>= K) */, int g, float* ws, float* dhead,
                        float* dchead_t, float* dclip_head, float* dprop, hipStream_t s);
 // dinfl [B][K][K] (written when affinity != nullptr)
 int nm_launch_clip_loss_bwd(const float* keypoints, const float* affinity, const float* dloss, int B, int T, int K, int N, float sep_sigma,

@@ -271,7 +271,11 @@ __global__ __launch_bounds__(256) void first_feature_bwd_kernel(const float* __r
         const int q = (int)(i % cq); const size_t r = i / cq;
         const int v = (int)(r % g3), b = (int)(r / g3);
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < T; ++t) s += *reinterpret_cast<const f32x4*>(dcomb + (((size_t)(b * T + t)) * g3 + v) * Cd + K + q * 4);
+        if ((K & 3) == 0) for (int t = 0; t < T; ++t) s += *reinterpret_cast<const f32x4*>(dcomb + (((size_t)(b * T + t)) * g3 + v) * Cd + K + q * 4);
+        else for (int t = 0; t < T; ++t) {          // (keypoint counts that are not multiples of 4: the feature block starts off a 16-byte boundary)
+            const float* p = dcomb + (((size_t)(b * T + t)) * g3 + v) * Cd + K + q * 4;
+            s += f32x4{p[0], p[1], p[2], p[3]};
+        }
         f32x4* d = reinterpret_cast<f32x4*>(dfeat + (((size_t)b * T) * g3 + v) * Fd + q * 4);
         *d = *d + s;
     }
@@ -307,8 +311,9 @@ __global__ __launch_bounds__(64) void heat_bwd_prep_kernel(const float* __restri
     o[3] = dmean / (float)(g * g * g) - (A0 * kp[0] + A1 * kp[1] + A2 * kp[2]);
 }
 // grid (F, g): dhead[f][v][k], dchead_t[f][v][k] (summed over t afterwards), pp[(f*g+z)][3] = (sum du*lrelu(head), sum du*lrelu(chead), sum du)
+// (head / clip_head / dhead / dchead_t rows hold Kc = K rounded up to 8 channels; the gradients of the padded channels are zeros)
 __global__ __launch_bounds__(256) void heat_bwd_kernel(const float* __restrict__ head, const float* __restrict__ clip_head,
-                                                       const float* __restrict__ prop, const float* __restrict__ coef, int T, int K, int g,
+                                                       const float* __restrict__ prop, const float* __restrict__ coef, int T, int K, int Kc, int g,
                                                        float* __restrict__ dhead, float* __restrict__ dchead_t, float* __restrict__ pp) {
     __shared__ float sh[256];
     const int f = blockIdx.x, z = blockIdx.y, b = f / T;
@@ -316,19 +321,20 @@ __global__ __launch_bounds__(256) void heat_bwd_kernel(const float* __restrict__
     const float w0 = prop[0], w1 = prop[1], pb = prop[2];
     const float lz = lin_coord(z, g);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < g2 * K; i += 256) {
-        const int k = i % K, v = i / K;
+    for (int i = threadIdx.x; i < g2 * Kc; i += 256) {
+        const int k = i % Kc, v = i / Kc;
         const int x = v % g, y = v / g;
         const size_t vox = (size_t)z * g2 + v;
-        const float a = head[((size_t)f * g3 + vox) * K + k], c = clip_head[((size_t)b * g3 + vox) * K + k];
+        if (k >= K) { dhead[((size_t)f * g3 + vox) * Kc + k] = 0.f; dchead_t[((size_t)f * g3 + vox) * Kc + k] = 0.f; continue; }
+        const float a = head[((size_t)f * g3 + vox) * Kc + k], c = clip_head[((size_t)b * g3 + vox) * Kc + k];
         const float la = lrelu(a, 0.01f), lc = lrelu(c, 0.01f);
         const float u = w0 * la + w1 * lc + pb;
         const float sig = u > 20.f ? 1.0f : 1.0f / (1.0f + expf(-u));
         const float* cf = coef + ((size_t)f * K + k) * 4;
         const float dhm = cf[0] * lz + cf[1] * lin_coord(y, g) + cf[2] * lin_coord(x, g) + cf[3];
         const float du = dhm * sig;
-        dhead[((size_t)f * g3 + vox) * K + k] = du * w0 * (a > 0.f ? 1.0f : 0.01f);
-        dchead_t[((size_t)f * g3 + vox) * K + k] = du * w1 * (c > 0.f ? 1.0f : 0.01f);
+        dhead[((size_t)f * g3 + vox) * Kc + k] = du * w0 * (a > 0.f ? 1.0f : 0.01f);
+        dchead_t[((size_t)f * g3 + vox) * Kc + k] = du * w1 * (c > 0.f ? 1.0f : 0.01f);
         s0 += du * la; s1 += du * lc; s2 += du;
     }
     s0 = block_sum256(s0, sh); s1 = block_sum256(s1, sh); s2 = block_sum256(s2, sh);
@@ -608,14 +614,15 @@ int nm_launch_combined_bwd(const float* dcomb, int Cd, const float* table, const
 }
 
 int nm_launch_heat_bwd(const float* head, const float* clip_head, const float* prop, const float* heat_part, const float* heat_mean,
-                       const float* keypoints, const float* dkp, const float* dloss, int B, int T, int K, int g, float* ws, float* dhead,
+                       const float* keypoints, const float* dkp, const float* dloss, int B, int T, int K, int Kc, int g, float* ws, float* dhead,
                        float* dchead_t, float* dclip_head, float* dprop, hipStream_t s) {
     const int F = B * T;
+    if (K < 1 || K > 32 || Kc < K) { nm_set_error("heat_bwd: K=%d (row pitch %d) unsupported", K, Kc); return NM_ERR_ARG; }
     float* coef = ws;                         // [F][K][4]
     float* pp = ws + (size_t)F * K * 4;       // [F*g][3]
     hipLaunchKernelGGL(heat_bwd_prep_kernel, dim3(F), dim3(64), 0, s, heat_part, heat_mean, keypoints, dkp, dloss, F, K, g, coef);
-    hipLaunchKernelGGL(heat_bwd_kernel, dim3(F, g), dim3(256), 0, s, head, clip_head, prop, coef, T, K, g, dhead, dchead_t, pp);
-    const size_t per = (size_t)g * g * g * K;
+    hipLaunchKernelGGL(heat_bwd_kernel, dim3(F, g), dim3(256), 0, s, head, clip_head, prop, coef, T, K, Kc, g, dhead, dchead_t, pp);
+    const size_t per = (size_t)g * g * g * Kc;
     hipLaunchKernelGGL(sum_t_kernel, dim3(grid_for((size_t)B * per)), dim3(256), 0, s, dchead_t, B, T, per, dclip_head);
     hipLaunchKernelGGL(sum_rows_kernel, dim3(3), dim3(256), 0, s, pp, F * g, 3, dprop);
     return nm_check_hip(hipGetLastError(), "heat_bwd launch");

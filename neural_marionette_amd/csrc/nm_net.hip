@@ -76,9 +76,9 @@ struct Loader {
 
     // one launch for all the conv weight packs (forward layouts and, in training, the data-gradient layouts)
     std::vector<NmPackJob> packs;
-    void pack(const float* src, float* wp, void* wp16, int Cout, int Cin, int ks, int Cin_pad, int Co_pad, int src_cin, int flip) {
+    void pack(const float* src, float* wp, void* wp16, int Cout, int Cin, int ks, int Cin_pad, int Co_pad, int src_cin, int flip, int src_rows = 0) {
         NmPackJob j; j.src = src; j.wp = wp; j.wp16 = wp16; j.Cout = Cout; j.Cin = Cin; j.ks = ks; j.Cin_pad = Cin_pad; j.Co_pad = Co_pad;
-        j.src_cin = src_cin; j.flip = flip; j.blk0 = 0; j.nblk = 0;
+        j.src_cin = src_cin; j.flip = flip; j.blk0 = 0; j.nblk = 0; j.src_rows = src_rows;
         packs.push_back(j);
     }
     int flush_packs() {
@@ -136,10 +136,23 @@ struct Loader {
     }
     // pad16: the layer's input tensor is built by the library itself with Cin rounded up to 16 (the decoder's 179-channel combined
     // representation), which puts the layer on the split-fp16 kernels
-    ConvW conv(const std::string& p, int Cout, int Cin, int ks, bool pad16 = false) {
-        ConvW w; w.Cin = Cin; w.Cout = Cout; w.ks = ks; w.Cin_pad = pad16 ? ((Cin + 15) & ~15) : ((Cin + 7) & ~7); w.Co_pad = (Cout + 31) & ~31; w.key = p;
+    // cout_layer (> Cout): the layer runs with its output channels zero-padded to cout_layer inside the library (the heat-map heads
+    // for keypoint counts that are not multiples of 8: every tensor the conv kernels touch keeps C % 8 == 0); the state_dict tensors
+    // keep Cout rows (ConvW::Cout_src), the padded rows of the packed weights and of the bias are zeros.
+    // csel_min: input channels that need a data gradient (rounded up to 8; default: Cin rounded down to 8)
+    ConvW conv(const std::string& p, int Cout, int Cin, int ks, bool pad16 = false, int cout_layer = 0, int csel_min = 0) {
+        ConvW w; w.Cin = Cin; w.Cout = cout_layer > Cout ? cout_layer : Cout; w.Cout_src = Cout; w.ks = ks;
+        w.Cin_pad = pad16 ? ((Cin + 15) & ~15) : ((Cin + 7) & ~7); w.Co_pad = (w.Cout + 31) & ~31; w.key = p;
+        w.csel = csel_min > 0 ? std::min(w.Cin_pad, (csel_min + 7) & ~7) : (Cin & ~7);
         const float* src = get(p + ".weight", (int64_t)Cout * Cin * ks * ks * ks);
-        w.bias = copy(p + ".bias", Cout);
+        if (w.Cout == Cout) w.bias = copy(p + ".bias", Cout);
+        else {
+            const float* bsrc = get(p + ".bias", Cout);
+            w.bias = nm_ctx_weight_alloc(c, w.Cout);
+            if (!w.bias) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
+            (void)hipMemsetAsync(w.bias, 0, (size_t)w.Cout * sizeof(float), c->stream);      // (flush_copies runs behind it on the same stream)
+            if (bsrc) copies.push_back(CopyItem{w.bias, bsrc, (long long)Cout, 0});
+        }
         if (!src) return w;
         w.wp = nm_ctx_weight_alloc(c, nm_packed_weight_floats(ks, w.Cin_pad, w.Co_pad));
         if (!w.wp) { if (!rc) { nm_set_error("set_weights: hipMalloc failed"); rc = NM_ERR_HIP; } return w; }
@@ -151,7 +164,7 @@ struct Loader {
         if (ks == 5) {         // the first layers: packed at once - first_layer_tables() runs a conv with these weights inside set_weights
             r = nm_launch_pack_conv_weight(src, Cout, Cin, ks, w.wp, w.Cin_pad, w.Co_pad, c->stream);
             if (!r && w.wp16) r = nm_launch_pack_conv_weight16(src, Cout, Cin, ks, w.wp16, w.Co_pad, c->stream);
-        } else pack(src, w.wp, w.wp16, Cout, Cin, ks, w.Cin_pad, w.Co_pad, Cin, 0);
+        } else pack(src, w.wp, w.wp16, Cout, Cin, ks, w.Cin_pad, w.Co_pad, Cin, 0);      // (rows >= Cout of the packed form: zeros)
         if (!r && c->training && ks != 5) r = dgrad_packs(src, w);
         if (r && !rc) rc = r;
         return w;
@@ -160,7 +173,7 @@ struct Loader {
     // dX = convT2(dY, W) for the k2 s2 pool convs
     int dgrad_packs(const float* src, ConvW& w) {
         const int taps = w.ks * w.ks * w.ks;
-        w.csel = w.Cin & ~7; w.cd_pad = (w.csel + 31) & ~31;
+        w.cd_pad = (w.csel + 31) & ~31;
         if (w.ks == 2) {
             w.wt = nm_ctx_weight_alloc(c, (size_t)w.Cin * w.Cout * 8);
             if (!w.wt) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
@@ -174,7 +187,8 @@ struct Loader {
             if (!w.wd16) { nm_set_error("set_weights: hipMalloc failed"); return NM_ERR_HIP; }
         }
         // the flipped / transposed weight (csel "output" channels = the input channels the gradient is wanted for) read in place
-        pack(src, w.wd, w.wd16, w.csel, w.Cout, w.ks, w.Cout, w.cd_pad, w.Cin, 1);
+        // (src_rows: a padded layer's source has Cout_src rows, and csel may exceed Cin by the rounding - both read as zeros)
+        pack(src, w.wd, w.wd16, w.csel, w.Cout, w.ks, w.Cout, w.cd_pad, w.Cin, 1, w.Cout_src);
         (void)taps;
         return NM_OK;
     }
@@ -589,9 +603,10 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
     const DetectorW& d = c->det;
     const int K = c->cfg.nkeypoints, G = c->cfg.grid_size, g = G / 4, F = B * T, N = c->cfg.nneighbor;
     const size_t g3 = (size_t)g * g * g, G3 = (size_t)G * G * G;
+    const int Kc = d.head.Cout;                 // head / clip_head channels per voxel: K rounded up to 8 (padded channels are zeros)
     n.ws.release(0);
     float* feat = n.alloc((size_t)F * g3 * FEAT);
-    float* clip_head = n.alloc((size_t)B * g3 * K);
+    float* clip_head = n.alloc((size_t)B * g3 * Kc);
     float* heat_part = n.alloc((size_t)F * K * g * (2 * g + 2));
     float* heat_mean = n.alloc((size_t)F * K);
     float* clip_part = n.alloc((size_t)B * 5);
@@ -657,11 +672,11 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
     if (chunks_done < clip_after) run_clip_block();
     {   // heads -> heat-maps -> keypoints (kypt_detector.py:336-347)
         const size_t m = n.ws.mark();
-        float* head = n.alloc((size_t)F * g3 * K);
+        float* head = n.alloc((size_t)F * g3 * Kc);
         conv_gn(n, mk(feat, F, g, g, g, FEAT), d.head, nullptr, 1, 0, 1.0f, head, false, tape ? &tape->head : nullptr);
         if (n.live()) {
             n.run(nm_check_hip(hipStreamWaitEvent(n.s, c->ev_clip, 0), "join clip net"));
-            n.run(nm_launch_heatmap(head, clip_head, d.prop, F, T, K, g, heatmaps, heat_part, n.s));
+            n.run(nm_launch_heatmap(head, clip_head, d.prop, F, T, K, Kc, g, heatmaps, heat_part, n.s));
             n.run(nm_launch_keypoints(heat_part, F, K, g, keypoints, heat_mean, n.s));
             if (after_keypoints && n.ok()) n.run((*after_keypoints)());
         }
@@ -777,9 +792,10 @@ TensorRef plain(const float* p, const TensorRef& like) { return with_h(mk(p, lik
 // gamma / beta and of the bias of the producing conv
 // (amax, optional: device word that ends up holding max |dy|, for the operand scaling of the data-gradient conv)
 // dv / wv (optional): dA is the outer product dv[frame][voxel] * wv[channel] (the decoder's last conv layer) and is never materialised
+// c_real (< out.C): the layer's output channels are padded inside the library; the bias gradient has c_real entries (layers without GroupNorm)
 const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float* fpart, int nblk_f, const double* chsum,
                       const std::string& bias_key, const float* dA, unsigned* amax = nullptr, const float* dA_mul = nullptr,
-                      const float* dv = nullptr, const float* wv = nullptr) {
+                      const float* dv = nullptr, const float* wv = nullptr, int c_real = 0) {
     const int N = out.N, C = out.C, V = out.D * out.H * out.W;
     const int nbb = nm_gnb_blocks_per_frame(V);
     float* dy = nullptr;
@@ -814,10 +830,13 @@ const float* norm_bwd(Bwd& b, const TensorRef& out, const NormW* gn, const float
     } else if (amax && b.live()) b.run(nm_launch_absmax(dA, numel_of(out), amax, b.s, nullptr, out.h));
     const size_t m = b.ws.mark();
     float* bpart = b.alloc((size_t)N * nbb * C * 2);
-    float* gbias = b.grad(bias_key, C);
+    const bool padded = c_real > 0 && c_real < C;
+    float* gbias = b.grad(bias_key, padded ? c_real : C);
+    float* gb_all = padded ? b.alloc(C) : gbias;
     if (b.live()) {
         b.run(nm_launch_gnb_partials(res, plain(res, out), bpart, b.s));
-        b.run(nm_launch_sum_partials(bpart, N * nbb, C, gbias, b.s));
+        b.run(nm_launch_sum_partials(bpart, N * nbb, C, gb_all, b.s));
+        if (padded) b.run(nm_check_hip(hipMemcpyAsync(gbias, gb_all, (size_t)c_real * sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
     }
     b.ws.release(m);
     return res;
@@ -874,14 +893,16 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
     DyScale ds;
     // (the k2 s2 pool convs: their weight gradient runs on the f16 matrix cores as well, wgrad16k2_kernel)
     ds.prepare(b, split && ((r.stride == 1 && (w.ks == 3 || (need_din && w.wd16))) || (r.stride == 2 && w.ks == 2 && nm_ls().wgrad_k2f16)), r.out.N * r.out.C, sc2_keep);
-    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, r.chsum, w.key + ".bias", dA, ds.amax, dA_mul, dA_dv, dA_wv);
+    const bool padded = w.Cout_src > 0 && w.Cout_src < w.Cout;      // output channels padded inside the library (the heat-map heads)
+    if (padded && r.gn && !b.rc) { nm_set_error("detector_backward: a padded layer with GroupNorm"); b.rc = NM_ERR_STATE; }
+    const float* dy = norm_bwd(b, r.out, r.gn, r.fpart, r.nblk, r.chsum, w.key + ".bias", dA, ds.amax, dA_mul, dA_dv, dA_wv, padded ? w.Cout_src : 0);
     const int slot = b.last_slot;                        // >= 0: dY sits in the ring (Bwd::dy_alloc)
     const TensorRef dyT = plain(dy, r.out);
     const TensorRef dyS = ds.apply(b, dyT);
     // weight gradient; on the third stream when everything it reads outlives this call (Bwd::async_w)
     const size_t up_floats = r.up2 ? Bwd::r64(Bwd::fl(numel_of(in) * 8, h_fine)) : 0;
     const size_t wg_floats = nm_wgrad_ws_floats(in.N, r.out.D, r.out.H, r.out.W, w.Cout, in.C, w.ks, r.stride);
-    bool side = b.async_w && slot >= 0 && (!ds.amax || ds.pool);
+    bool side = b.async_w && slot >= 0 && (!ds.amax || ds.pool) && !padded;
     if (side && b.ws.dry) b.need_scratch = std::max(b.need_scratch, up_floats + Bwd::r64(wg_floats));
     if (side && !b.ws.dry && up_floats + wg_floats > b.sscratch_floats) side = false;
     // (enqueued BEHIND this layer's data gradient: started together with it, the two matrix-core kernels only share the CUs; started
@@ -913,8 +934,15 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
             a = with_h(mk(upb, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C), h_fine);
         }
         float* wsb = b.alloc(wg_floats);
-        float* gw = b.grad(w.key + ".weight", (int64_t)w.Cout * w.Cin * w.ks * w.ks * w.ks);
-        if (b.live()) b.run(nm_launch_wgrad(a, dyS, w.ks, r.stride, r.pad, w.Cin, wsb, gw, b.s, ds.inv(), split ? 1 : 0));
+        const size_t per_row = (size_t)w.Cin * w.ks * w.ks * w.ks;
+        float* gw = b.grad(w.key + ".weight", (int64_t)((padded ? w.Cout_src : w.Cout) * per_row));
+        // (a padded layer: the kernel writes all w.Cout rows - the padded ones are exact zeros, dY is zero there - into scratch and the
+        //  state_dict's rows are copied out)
+        float* gw_all = padded ? b.alloc((size_t)w.Cout * per_row) : gw;
+        if (b.live()) {
+            b.run(nm_launch_wgrad(a, dyS, w.ks, r.stride, r.pad, w.Cin, wsb, gw_all, b.s, ds.inv(), split ? 1 : 0));
+            if (padded) b.run(nm_check_hip(hipMemcpyAsync(gw, gw_all, (size_t)w.Cout_src * per_row * sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
+        }
         b.ws.release(m2);
     }
     if (need_din) {
@@ -1118,17 +1146,18 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         }
         b.ws.release(m);
     }
-    float* dchead = b.alloc((size_t)B * g3 * K);
+    const int Kc = d.head.Cout;                 // channels per voxel of the head tensors and their gradients (K rounded up to 8)
+    float* dchead = b.alloc((size_t)B * g3 * Kc);
     {   // keypoints <- heat-maps <- heads; head conv back into the frame features
         const size_t m = b.ws.mark();
-        float* dhead = b.alloc((size_t)F * g3 * K);
-        float* dchead_t = b.alloc((size_t)F * g3 * K);
+        float* dhead = b.alloc((size_t)F * g3 * Kc);
+        float* dchead_t = b.alloc((size_t)F * g3 * Kc);
         float* hws = b.alloc(nm_heat_bwd_ws_floats(F, K, g));
         float* gprop = b.alloc(4);
         float* gpw = b.grad(v2k + ".propagate_heatmaps.0.weight", 2);
         float* gpb = b.grad(v2k + ".propagate_heatmaps.0.bias", 1);
         if (b.live()) {
-            b.run(nm_launch_heat_bwd(t.head_out, t.clip_head_out, d.prop, t.heat_part, t.heat_mean, t.keypoints, dkp, dloss, B, T, K, g, hws,
+            b.run(nm_launch_heat_bwd(t.head_out, t.clip_head_out, d.prop, t.heat_part, t.heat_mean, t.keypoints, dkp, dloss, B, T, K, Kc, g, hws,
                                      dhead, dchead_t, dchead, gprop, b.s));
             b.run(nm_check_hip(hipMemcpyAsync(gpw, gprop, 2 * sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
             b.run(nm_check_hip(hipMemcpyAsync(gpb, gprop + 2, sizeof(float), hipMemcpyDeviceToDevice, b.s), "backward: copy"));
@@ -1231,8 +1260,14 @@ int nm_nf_poll(nm_ctx* c) {
     }
     (void)hipMemsetAsync(c->nf_flag, 0, sizeof(unsigned), c->stream);
     if (c->nf_last & 2u) {
+        // the chain's workgroups were not all resident (a busy or partitioned device): this context stops using it - later rollouts take
+        // the launch-per-phase steps, and the captured graphs that hold the persistent launch are dropped
+        (void)hipDeviceSynchronize();            // (rare error path: nothing of the aborted rollout may still reference the graphs' buffers)
+        c->ls.vrnn_chain = 0;
+        nm_vrnn_free_graphs(c);
         nm_set_error("call #%llu (%s): the persistent rollout kernel timed out waiting for its workgroups (its outputs are invalid); "
-                     "NM355_VRNN_CHAIN=0 selects the launch-per-phase steps", (unsigned long long)seq, who);
+                     "this context now takes the launch-per-phase steps (as NM355_VRNN_CHAIN=0 does from the start) - repeat the call",
+                     (unsigned long long)seq, who);
         return NM_ERR_STATE;
     }
     nm_set_error("call #%llu (%s) produced non-finite values - its outputs are invalid: %s", (unsigned long long)seq, who,
@@ -1272,9 +1307,12 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
     d.zeros = nm_ctx_weight_alloc(c, 512);
     if (d.zeros) (void)hipMemsetAsync(d.zeros, 0, 512 * sizeof(float), c->stream);
     d.frame = L.featnet(v + ".extract_features", FEAT);
-    d.head = L.conv(v + ".extract_heatmaps_from_features.0", K, FEAT, 1);
+    // (the two heat-map heads run with their K output channels zero-padded to Kc = K rounded up to 8: head / clip_head tensors and their
+    //  gradients have Kc channels per voxel; the heat-map kernels read channels < K only)
+    const int Kc = (K + 7) & ~7;
+    d.head = L.conv(v + ".extract_heatmaps_from_features.0", K, FEAT, 1, false, Kc);
     d.clip = L.featnet(v + ".extract_spatio_temporal_features", 2 * FEAT);
-    d.clip_head = L.conv(v + ".extract_spatio_temporal_heatmaps_from_features.0", K, 2 * FEAT, 1);
+    d.clip_head = L.conv(v + ".extract_spatio_temporal_heatmaps_from_features.0", K, 2 * FEAT, 1, false, Kc);
     {
         const float* pw = L.get(v + ".propagate_heatmaps.0.weight", 2);
         const float* pb = L.get(v + ".propagate_heatmaps.0.bias", 1);
@@ -1299,7 +1337,7 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
             }
         }
     }
-    d.adjust = L.conv(k2v + ".adjust_combined_representation.0", FEAT, FEAT + 2 * K + 3, 1);       // (pad16 = true puts it on conv_f16s: measured 648 us vs 319 us on the fp32 kernel, which stages all 184 channels per pass; a 1-tap layer has 6 MFMAs per staged 16-channel chunk)
+    d.adjust = L.conv(k2v + ".adjust_combined_representation.0", FEAT, FEAT + 2 * K + 3, 1, false, 0, FEAT + 2 * K);       // (pad16 = true puts it on conv_f16s: measured 648 us vs 319 us on the fp32 kernel, which stages all 184 channels per pass; a 1-tap layer has 6 MFMAs per staged 16-channel chunk)
     d.d1 = L.conv(dec + ".1", FEAT / 2, FEAT, 3); L.up2_sets(dec + ".1", d.d1, c->cfg.grid_size / 4); d.dn2 = L.norm(dec + ".2", FEAT / 2);
     d.d4 = L.conv(dec + ".4", FEAT / 2, FEAT / 2, 3); d.dn5 = L.norm(dec + ".5", FEAT / 2);
     d.d8 = L.conv(dec + ".8", FEAT / 4, FEAT / 2, 3); L.up2_sets(dec + ".8", d.d8, c->cfg.grid_size / 2); d.dn9 = L.norm(dec + ".9", FEAT / 4);

@@ -626,6 +626,7 @@ struct ChainArgs {
     unsigned* status;                   // the context's status word: bit 1 = a spin timed out
     int B, T, K, Z, H;
     int backoff;                        // s_sleep(2) units between polls
+    int spin_limit;                     // polls before a wave gives up (NM355_CHAIN_SPIN; default NM_CHAIN_SPIN)
 };
 
 __device__ __forceinline__ void gran_store(nm_gran* p, float v, unsigned tag) {
@@ -662,7 +663,7 @@ __device__ __forceinline__ void gran_ld_4q4(const nm_gran* p0, const nm_gran* p1
             if (__all(OKEXPR)) break;                                                                                \
             if ((++spins_ & 63) == 0) {                                                                              \
                 if (__hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { alive_ = false; break; }   \
-                if (spins_ > NM_CHAIN_SPIN) {                                                                        \
+                if (spins_ > a.spin_limit) {                                                                         \
                     __hip_atomic_store(a.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                       \
                     __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                   \
                     alive_ = false; break;                                                                           \
@@ -1498,7 +1499,7 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         add_job(J, hh, 0, io.h, H, io.ldh, nullptr, 0, 0, true, nullptr, 0, 1, sb.gh, 3 * H, 0, B);
         if ((rc = launch_jobs(J, s))) return rc;
     }
-    if (!post && B <= 64 && !io.tape && !io.out_R && !io.best && !io.kl && !io.rec && nm_ls().vrnn_mid && K % 8 == 0 && K <= 32 && Z == 128) {
+    if (!post && B <= 64 && !io.tape && !io.out_R && !io.best && !io.kl && !io.rec && nm_ls().vrnn_mid && K >= 2 && K <= 32 && Z == 128) {
         // 2-4 in one workgroup per batch element (prior steps of a rollout): see vrnn_prior_mid_kernel
         MidArgs a;
         a.hid_prior = sb.hid_prior; a.rh = sb.rh; a.jh = sb.jh; a.eps = io.eps; a.offset = io.offset;
@@ -1512,7 +1513,7 @@ int vrnn_step(nm_ctx* c, const StepBufs& sb, const StepIO& io, int B, int S) {
         if (io.hout && (rc = launch_gru(w.w_ih, w.b_ih, io.out_kp, S4, io.ldkp, io.out_z, Z, io.ldz, sb.gh, io.h, io.ldh, io.hout, io.ldho, H, B, s, nullptr, sb.gi))) return rc;
         return NM_OK;
     }
-    if (post && !io.tape && nm_ls().vrnn_postmid && c->vrnn_cnt && B <= 256 && (size_t)S * B <= 4096 && K % 8 == 0 && K <= 32 && Z == 128 && io.out_kp && io.out_z) {
+    if (post && !io.tape && nm_ls().vrnn_postmid && c->vrnn_cnt && B <= 256 && (size_t)S * B <= 4096 && K >= 2 && K <= 32 && Z == 128 && io.out_kp && io.out_z) {
         // 2-4 of a posterior step in one workgroup per (sample, clip), selection by the clip's last workgroup: vrnn_post_mid_kernel
         PostArgs a;
         a.hid_post = sb.hid_post; a.hid_prior = sb.hid_prior; a.rh = sb.rh; a.jh = sb.jh; a.eps = io.eps; a.offset = io.offset;
@@ -1946,7 +1947,27 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
     }
     // the prior steps as ONE persistent launch (vrnn_prior_chain_kernel) when the shape allows: weights register-resident for the whole
     // chain, three counter hand-offs per step instead of three launches (NM355_VRNN_CHAIN=0: the launch-per-phase steps, A/B)
-    const bool chain = nm_ls().vrnn_chain && nm_ls().vrnn_mid && Tg >= 1 && B <= 4 && K % 8 == 0 && K <= 32 && Z == 128 && H == 512 && c->vrnn_cnt && c->nf_flag;
+    bool chain = nm_ls().vrnn_chain && nm_ls().vrnn_mid && Tg >= 1 && B <= 4 && K >= 2 && K <= 32 && Z == 128 && H == 512 && c->vrnn_cnt && c->nf_flag;
+    const size_t chain_lds = (size_t)(3 + 7 * K) * 128 * sizeof(float);
+    if (chain) {
+        // Co-residency: the kernel's workgroups spin on each other, so ALL of them must be resident at once - an ordinary launch does not
+        // promise that.  Asked once per context: workgroups of this shape (512 threads at up to 256 registers, the heads' weights in
+        // dynamic LDS) per CU x the device's CUs must cover the NM_CHAIN_NW workers + 4 middle workgroups; a partition with fewer CUs
+        // (CPX mode: 32) takes the launch-per-phase steps.  A device that is busy with OTHER work when the chain starts is what the
+        // bounded spins are for: the time-out is reported by the next call and switches the chain off for this context (nm_nf_poll).
+        if (nm_ls().chain_fits < 0) {
+            static NmDeviceOnce attr_set;
+            if (!attr_set.done()) {
+                if ((rc = nm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_prior_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(vrnn_prior_chain)"))) return rc;
+                attr_set.mark();
+            }
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&vrnn_prior_chain_kernel), NM_CHAIN_T, (size_t)(3 + 7 * 32) * 128 * sizeof(float)) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+            nm_ls().chain_fits = ((long long)per_cu * cus >= NM_CHAIN_NW + 4) ? 1 : 0;
+        }
+        chain = nm_ls().chain_fits == 1;
+    }
     for (int t = 0; t < (chain ? Tcond : Ttot); ++t) {
         StepIO io;
         const bool post = t < Tcond;
@@ -1983,16 +2004,13 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         a.B = B; a.T = Tg; a.K = K; a.Z = Z; a.H = H;
         // poll back-off in s_sleep(2) units (0 / 1 / 4 / 16 / 64: 17.0 / 18.0 / 17.3 / 19.5 / 25.9 us per step at B = 1)
         { static const int bo = getenv("NM355_CHAIN_BACKOFF") ? atoi(getenv("NM355_CHAIN_BACKOFF")) : 0; a.backoff = bo; }
+        a.spin_limit = nm_ls().chain_spin > 0 ? nm_ls().chain_spin : NM_CHAIN_SPIN;
         const size_t gbytes = (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) * sizeof(nm_gran) + 64;
         if ((rc = nm_check_hip(hipMemsetAsync(r.chain_g, 0, gbytes, c->stream), "rollout: granule buffers"))) return rc;
-        {
-            static NmDeviceOnce attr_set;
-            if (!attr_set.done()) {
-                if ((rc = nm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_prior_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(vrnn_prior_chain)"))) return rc;
-                attr_set.mark();
-            }
-        }
-        hipLaunchKernelGGL(vrnn_prior_chain_kernel, dim3(NM_CHAIN_NW + B), dim3(NM_CHAIN_T), (size_t)(3 + 7 * K) * 128 * sizeof(float), c->stream, a);
+        // (NM355_CHAIN_DROP_WG, test hook: the last workgroups are not launched - what a workgroup that never becomes resident looks like
+        //  to the others; their spins run into the limit, the abort word ends the kernel, bit 1 of the status word reports it)
+        const int drop = std::min(std::max(nm_ls().chain_drop, 0), B);
+        hipLaunchKernelGGL(vrnn_prior_chain_kernel, dim3(NM_CHAIN_NW + B - drop), dim3(NM_CHAIN_T), chain_lds, c->stream, a);
         if ((rc = nm_check_hip(hipGetLastError(), "vrnn_prior_chain launch"))) return rc;
         *cur_out = nxt;                 // the last step's state, as plain floats
         return NM_OK;

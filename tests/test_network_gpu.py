@@ -1006,3 +1006,88 @@ def test_forward_kernel_variants_stay_under_parity(env, golden_dir):
             test_g2_forward32_vs_reference_fixture(golden_dir, "split16", path)
         for G in (64, 96, 40):
             test_inference_shortcuts_are_bit_identical_to_the_plain_evaluation(G)
+
+
+def test_persistent_rollout_timeout_is_reported_and_the_context_falls_back():
+    """vrnn_prior_chain_kernel's workgroups spin on each other, so all of them must be resident; one that never starts (a busy
+    or partitioned device) must neither hang the device nor go unnoticed.  NM355_CHAIN_DROP_WG=1 (test hook, read when a context is
+    created) does not launch the last middle workgroup - exactly what the others see of a workgroup that is not resident; with a small
+    spin limit the kernel gives up within milliseconds.  The next library call reports NM_ERR_STATE naming the rollout, the context
+    stops using the chain, and the repeated call equals the launch-per-phase result bit for bit."""
+    o = HotPathOptions(grid_size=32, Tcond=5)
+    sd = synth.make_state_dict(o, seed=21, variant="default")
+    with _switches({"NM355_VRNN_CHAIN": "0"}):
+        ref_net = _net(o, sd)
+        with torch.no_grad():
+            ref_net.kypt_detector.get_affinity()
+    with _switches({"NM355_CHAIN_DROP_WG": "1", "NM355_CHAIN_SPIN": "20000"}):
+        net = _net(o, sd)
+        with torch.no_grad():
+            net.kypt_detector.get_affinity()
+    B, K, Z = 2, o.nkeypoints, o.nlatent_kypt
+    g = torch.Generator().manual_seed(5)
+    kp = (torch.rand(B, 5, K, 4, generator=g) * 1.6 - 0.8).cuda()
+    h = (torch.randn(B, o.nhidden_kypt, generator=g) * 0.1).cuda()
+    eps = synth.make_eps((12, B, Z), seed=77).cuda()
+    with torch.no_grad():
+        aff = O.affinity_v3(sd["kypt_detector.affinity_params"]).cuda()
+        for n in (ref_net, net):
+            n.dyna_module.encode(kp, aff, eps=torch.zeros(5, 10, B, Z).cuda())      # builds the tree
+        want = ref_net.dyna_module.rollout(h, ref_net.dyna_module.get_offset(kp), eps)
+        off = net.dyna_module.get_offset(kp)
+        net.dyna_module.rollout(h, off, eps)                   # aborted inside the kernel: outputs invalid, status bit 1 raised
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="timed out"):
+            net.check_finite()
+        got = net.dyna_module.rollout(h, off, eps)             # launch-per-phase steps now
+        torch.cuda.synchronize()
+        net.check_finite()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+def test_persistent_rollout_long_chain_stays_bit_identical():
+    """the chain's readers fetch two 8-byte {value, tag} granules per 16-byte sc1 load and rely on each granule being
+    observed whole (stated in nm_vrnn.hip); a torn read - new tag, stale value - would put a wrong h or z into the recurrence and every
+    later step would differ.  6 000 steps at B = 4 (~1.5 M granule polls per worker wave) through the persistent chain against the
+    launch-per-phase steps, bit for bit, while a second context keeps the device busy with forwards from another thread."""
+    import threading
+    o = HotPathOptions(grid_size=32, Tcond=5)
+    sd = synth.make_state_dict(o, seed=22, variant="default")
+    with _switches({"NM355_VRNN_CHAIN": "0"}):
+        ref_net = _net(o, sd)
+        with torch.no_grad():
+            ref_net.kypt_detector.get_affinity()
+    net = _net(o, sd)
+    busy = _net(o, sd)
+    B, K, Z, T = 4, o.nkeypoints, o.nlatent_kypt, 6000
+    g = torch.Generator().manual_seed(6)
+    kp = (torch.rand(B, 5, K, 4, generator=g) * 1.6 - 0.8).cuda()
+    h = (torch.randn(B, o.nhidden_kypt, generator=g) * 0.1).cuda()
+    eps = (synth.make_eps((T, B, Z), seed=78) * 0.05).cuda()      # (small noise: the free-running state stays bounded)
+    vox = synth.figure_clip(1, 3, 32, seed=9).cuda()
+    stop = threading.Event()
+
+    def hammer():
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s), torch.no_grad():
+            e = torch.zeros(3, 10, 1, Z, device="cuda")
+            while not stop.is_set():
+                busy(vox, ACTS, eps=e)
+                s.synchronize()
+    with torch.no_grad():
+        aff = O.affinity_v3(sd["kypt_detector.affinity_params"]).cuda()
+        for n in (ref_net, net):
+            n.dyna_module.encode(kp, aff, eps=torch.zeros(5, 10, B, Z).cuda())
+        busy(vox, ACTS, eps=torch.zeros(3, 10, 1, Z, device="cuda"))
+        want = ref_net.dyna_module.rollout(h, ref_net.dyna_module.get_offset(kp), eps)
+        torch.cuda.synchronize()
+        th = threading.Thread(target=hammer); th.start()
+        try:
+            got = [net.dyna_module.rollout(h, net.dyna_module.get_offset(kp), eps) for _ in range(3)]
+            torch.cuda.synchronize()
+        finally:
+            stop.set(); th.join()
+    net.check_finite()
+    assert torch.isfinite(want[0]).all()
+    for r in got:
+        assert torch.equal(r[0], want[0]) and torch.equal(r[1], want[1])

@@ -285,3 +285,63 @@ def test_eval_metrics_restatement_matches_reference():
     closest, counts = O.semantic_votes(kp, gt)
     assert np.array_equal(counts.numpy(), se["scores"].astype(np.int64))
     assert O.semantic_log(counts) == se["scores_log"]
+
+
+# ---- keypoint counts of the reference's other dataset configs (dataset/config.py:97 panda K = 12, :124 hanco K = 28 with
+# gaussian_sigma = 1.0; train.py:60 default 22): the shells construct, the state_dict layout is the reference's, and the oracle stays
+# bit-identical to the reference there - so the GPU parity tests of tests/test_keypoint_counts_gpu.py are pinned for those K too.
+def _opt_k(G, K, sigma=None):
+    opt = _opt(G)
+    opt.nkeypoints = K
+    if sigma is not None:
+        opt.gaussian_sigma = sigma
+    return opt
+
+
+@pytest.mark.parametrize("K", [12, 22, 28])
+def test_state_dict_layout_other_keypoint_counts(ref_modules, K):
+    NeuralMarionette, _ = ref_modules
+    import neural_marionette_amd as nm
+    opt = _opt_k(64, K)
+    torch.manual_seed(5); ref = NeuralMarionette(opt)
+    torch.manual_seed(5); net = nm.NeuralMarionette(opt)
+    sa, sb = ref.state_dict(), net.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sa.items()] == [(k, tuple(v.shape)) for k, v in sb.items()]
+    assert [(k, tuple(v.shape)) for k, v in sa.items()] == [(k, tuple(s)) for k, s in param_spec(HotPathOptions(nkeypoints=K))]
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert tuple(sa["kypt_detector.affinity_params"].shape) == (2, K, K - 1)
+    assert tuple(sa["kypt_detector.kypt_to_vox.adjust_combined_representation.0.weight"].shape) == (128, 128 + 2 * K + 3, 1, 1, 1)
+    assert tuple(sa["dyna_module.joint_matrix_decoder.2.weight"].shape) == (6 * K, 128)
+
+
+@pytest.mark.parametrize("K,sigma", [(12, None), (22, None), (28, 1.0)])
+def test_full_forward_32_other_keypoint_counts(ref_modules, K, sigma):
+    NeuralMarionette, _ = ref_modules
+    import torch.distributions.normal as tdn
+    G, B, T = 32, 2, 4
+    opt = _opt_k(G, K, sigma)
+    o = HotPathOptions.from_any(opt)
+    assert o.nkeypoints == K
+    sd = synth.make_state_dict(o, seed=40 + K, variant="peaky")
+    gen = torch.Generator().manual_seed(K)
+    sd["kypt_detector.affinity_params"] = torch.randn(sd["kypt_detector.affinity_params"].shape, generator=gen)
+    net = NeuralMarionette(opt).eval()
+    net.load_state_dict(sd)
+    net.anneal(1)
+    vox = synth.figure_clip(B, T, G, seed=2)
+    eps = synth.make_eps((T, 10, B, 128), seed=3)
+    it = iter(eps)
+    old = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: next(it).clone()
+    try:
+        with torch.no_grad():
+            ref = net(vox, {"detector": True, "learner": True})
+    finally:
+        tdn._standard_normal = old
+    with torch.no_grad():
+        mine = O.nm_forward(sd, o, vox, eps)
+    for k in ("recon", "keypoints", "heatmaps", "affinity", "first_feature", "kypt_recon", "R", "z_kypts", "h_kypts"):
+        assert torch.equal(ref[k], mine[k]), k
+    for k in DETECTOR_LOSS_KEYS + ("kl_kypt", "kypt_recon_loss"):
+        assert float(ref[k]) == float(mine[k]), k
+    assert np.array_equal(net.dyna_module.parents.numpy(), mine["parents"])
