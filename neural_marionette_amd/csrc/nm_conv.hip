@@ -2497,6 +2497,350 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
     }
 }
 
+// ---- conv_f16q2: the one-product form (conv modes 3 / 4) of conv_f16p2, re-balanced (round 5) ---------------------------------------
+// In the one-product modes conv_f16p2<SINGLE> keeps the three-product kernel's schedule with two thirds of the MFMAs deleted: a tap
+// group is 36 MFMAs per wave (1 152 cycles) instead of 108, but the producers still fetch each group's weights one group ahead -
+// an L2 round trip plus the register -> LDS copy no longer fits under a group, and three workgroup barriers per step expose it
+// (stand-alone 64 -> 64 @32^3: 0.19-0.31 of the f16 peak, the producers' arrival at the barriers is the step).  Here the schedule is
+// built for one MFMA per staged operand:
+//   * hi-only tiles halve the LDS footprint, so a WHOLE step's weights (27 taps x 16 channels x 64 outputs = 54 KB) are double
+//     buffered and fetched one full step ahead of their use; halo tile two steps ahead as before;
+//   * ONE workgroup barrier per step instead of three;
+//   * bfloat16 input (mode 4): a producer piece is a 16-byte load of EIGHT channels (one ds_write_b128 per piece, 5 pieces per
+//     thread and step instead of 10 eight-byte ones);
+//   * the MFMA waves keep operands two taps ahead (three register sets, counted lgkmcnt waits): a tap is only four MFMAs.
+// Arithmetic per output element (k order: channel chunk outer, tap inner; epilogue) is conv_f16p2<SINGLE>'s: bit-identical results.
+//   LDS: halo [2][h0 | h1][600] x 16 B, weights [2][27 taps][h0 | h1][64] x 16 B, GroupNorm scratch, bias: 148 KB + bias.
+// DBG (diagnostic instantiations, NM355_Q2_DBG): 1 no MFMAs, 2 producers only keep the barriers, 3 no epilogue stores, 4 no weight copies, 5 no input staging,
+// 6 = 2 + no operand reads inside the tap loop, 7 = 2 + no epilogue, 8 input pieces loaded but not converted / stored, 9 converted / stored but not loaded
+template <int IO = 0, int DBG = 0>
+__global__ __launch_bounds__(512, 1) void conv_f16q2_kernel(ConvParams p) {
+    constexpr bool IH = (IO & 1) != 0, OH = (IO & 2) != 0;
+    constexpr unsigned EB = IH ? 2u : 4u;                           // bytes per input element
+    constexpr int HV = 600, ZP = 100, HX = 10;
+    constexpr int WB = 27 * 2 * 64;                                 // half8 slots of one step's weights
+    constexpr int NP = IH ? 5 : 10;                                 // 16-byte input pieces per producer thread and step
+    constexpr int NCH = IH ? 8 : 4;                                 // channels per piece
+    constexpr int NWL = 14;                                         // 1-KiB weight pieces per producer wave and step (54 / 4, the last two slots repeat piece 53)
+    constexpr int NA = IH ? 4 : 2;                                  // affine loads per step
+    extern __shared__ f32x4 lds[];
+    half8* ldh = reinterpret_cast<half8*>(lds);                     // [2][2][HV]
+    half8* ldb = ldh + 4 * HV;                                      // [2][WB]
+    float* red = reinterpret_cast<float*>(ldb + 2 * WB);            // [4 waves][64 channels][2]
+    float* lbias = red + 512;                                       // [Cout]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int C16 = p.Cin >> 4;
+    const int ncg = p.Cout >> 6;
+    const int nbx = p.OW >> 3, nby = p.OH >> 3, nbz = p.OD >> 2, nbr = nbx * nby * nbz;
+    const int total = p.N * nbr * ncg;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int id_first = (int)blockIdx.x * per, id_last = min(total, id_first + per);
+    if (id_first >= id_last) return;
+
+    struct Work { int n, oz0, oy0, ox0, cg; };
+    const bool tiled = p.st_x != 0;
+    auto decode = [&](int id) {
+        Work w;
+        if (tiled) {
+            const BrickPos bp = super_tile_item(p, (int)blockIdx.x, id - id_first, per, nbz, nby, nbx);
+            w.cg = 0; w.n = bp.n; w.ox0 = bp.bx << 3; w.oy0 = bp.by << 3; w.oz0 = bp.bz << 2;
+            return w;
+        }
+        w.cg = id % ncg; const int bid = id / ncg;
+        w.n = bid / nbr; const int br = bid % nbr;
+        w.ox0 = (br % nbx) << 3; w.oy0 = ((br / nbx) % nby) << 3; w.oz0 = (br / (nbx * nby)) << 2;
+        return w;
+    };
+    auto next_work = [&](Work w, int id) {
+        if (tiled) return decode(id);
+        if (++w.cg == ncg) {
+            w.cg = 0;
+            if ((w.ox0 += 8) == p.OW) { w.ox0 = 0; if ((w.oy0 += 8) == p.OH) { w.oy0 = 0; if ((w.oz0 += 4) == p.OD) { w.oz0 = 0; ++w.n; } } }
+        }
+        return w;
+    };
+    struct Step { Work w; int id, cb; };
+    auto advance = [&](Step& st) {                                  // false (and st unchanged) on the block's last step
+        if (st.cb + 1 < C16) { ++st.cb; return true; }
+        if (st.id + 1 >= id_last) return false;
+        st.cb = 0; ++st.id; st.w = next_work(st.w, st.id);
+        return true;
+    };
+
+    if (wave >= 4) {
+        // =========================== producer waves ===========================================================
+        const int pt = tid - 256, pw = wave - 4;
+        const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+        const size_t plane = (size_t)p.Co_pad;
+        // piece k of this thread: halo voxel v, channel group sub (fp32 input: a quad of the chunk's 16 channels, v = pt / 4 + 64 k;
+        // bfloat16 input: one of its two octets, v = pt / 2 + 128 k)
+        const int sub = IH ? (pt & 1) : (pt & 3);
+        int pc_slot[NP], pc_rel[NP], pc_pos[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int v = IH ? (pt >> 1) + 128 * k : (pt >> 2) + 64 * k, vc = min(v, HV - 1);
+            const int hz = vc / 100, r = vc % 100, hy = r / 10, hx = r % 10;
+            pc_slot[k] = (IH ? sub : (sub >> 1)) * HV + hz * ZP + hy * HX + hx;
+            pc_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin + NCH * sub;
+            pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
+        }
+        // two register sets for the input pieces (and their affine): a tile's loads are issued TWO producer iterations before its
+        // conversion - one full step of cover.  (With one set the loads of step s + 2 were issued between the conversions of step
+        // s + 1 and consumed at the top of the next iteration: half a step of cover for an HBM round trip; loads alone or conversions
+        // alone cost the kernel nothing, together +0.15 ms on 64 -> 64 @32^3 - tools/diag_f16q2.py variants 8 / 9.)
+        f32x4 raw[2][NP], sc[2][NA / 2], sh[2][NA / 2], wreg[NWL];
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) wreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool has_affine = p.in_scale != nullptr;
+        const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * EB;   // halo voxel (1,1,1): always inside
+        auto inside_mask = [&](const Work& w) {
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int hz = pc_pos[k] & 0xff, hy = (pc_pos[k] >> 8) & 0xff, hx = pc_pos[k] >> 16;
+                const bool in = pc_pos[k] >= 0 && (unsigned)(w.oz0 - 1 + hz) < (unsigned)p.ID && (unsigned)(w.oy0 - 1 + hy) < (unsigned)p.IH &&
+                                (unsigned)(w.ox0 - 1 + hx) < (unsigned)p.IW;
+                m |= (in ? 1u : 0u) << k;
+            }
+            return m;
+        };
+        auto tile_base = [&](const Work& w, int cb) {
+            return nm_eptr(p.in, (size_t)(((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin + cb * 16), IH);
+        };
+        auto load_piece = [&](const float* base, unsigned mask, auto K, auto SET) {
+            constexpr int k = decltype(K)::value, set = decltype(SET)::value;
+            raw[set][k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * EB : rel111);
+        };
+        auto load_affine = [&](const Work& w, int cb, auto SET) {   // always NA loads: the waits below count instructions
+            constexpr int set = decltype(SET)::value;
+            const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 : p.in;
+            const float* ph = has_affine ? p.in_shift + (size_t)w.n * p.Cin + cb * 16 : p.in;
+#pragma unroll
+            for (int q = 0; q < NA / 2; ++q) {
+                sc[set][q] = load16_untracked(ps, 4u * (unsigned)(NCH * sub + 4 * q));
+                sh[set][q] = load16_untracked(ph, 4u * (unsigned)(NCH * sub + 4 * q));
+            }
+        };
+        // a tensor without a pending affine gets the identity, once per step (behind the wait that covers the loads above): the
+        // conversion below is then branch- and select-free (x * 1 + 0 is x)
+        auto fix_affine = [&](auto SET) {
+            constexpr int set = decltype(SET)::value;
+            if (!has_affine) {
+#pragma unroll
+                for (int q = 0; q < NA / 2; ++q) { sc[set][q] = f32x4{1.f, 1.f, 1.f, 1.f}; sh[set][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+        };
+        // counted waits: one asm statement that the compiler must order every use of the named registers behind
+#define NM_Q2_REGS_W "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]), "+v"(wreg[3]), "+v"(wreg[4]), "+v"(wreg[5]), "+v"(wreg[6]), \
+                     "+v"(wreg[7]), "+v"(wreg[8]), "+v"(wreg[9]), "+v"(wreg[10]), "+v"(wreg[11]), "+v"(wreg[12]), "+v"(wreg[13])
+#define NM_Q2_WAIT_W(N) asm volatile("s_waitcnt vmcnt(" #N ")" : NM_Q2_REGS_W :: "memory")
+#define NM_Q2_WAIT_SET_H(S, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(raw[S][0]), "+v"(raw[S][1]), "+v"(raw[S][2]), "+v"(raw[S][3]), "+v"(raw[S][4]), \
+                             "+v"(sc[S][0]), "+v"(sc[S][1]), "+v"(sh[S][0]), "+v"(sh[S][1]) :: "memory")
+#define NM_Q2_WAIT_SET_F(S, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(raw[S][0]), "+v"(raw[S][1]), "+v"(raw[S][2]), "+v"(raw[S][3]), "+v"(raw[S][4]), \
+                             "+v"(raw[S][5]), "+v"(raw[S][6]), "+v"(raw[S][7]), "+v"(raw[S][8]), "+v"(raw[S][9]), "+v"(sc[S][0]), "+v"(sh[S][0]) :: "memory")
+#define NM_Q2_WAIT_SET(S, NH, NF) do { if constexpr (IH) { NM_Q2_WAIT_SET_H(S, NH); } else { NM_Q2_WAIT_SET_F(S, NF); } } while (0)
+#define NM_Q2_WAIT_WP(NH, NF) do { if constexpr (IH) { NM_Q2_WAIT_W(NH); } else { NM_Q2_WAIT_W(NF); } } while (0)
+        auto convert = [&](int buf, unsigned mask, auto K, auto SET) {   // activate, round to fp16, write piece k into halo buffer buf
+            constexpr int k = decltype(K)::value, set = decltype(SET)::value;
+            const bool keep = ((mask >> k) & 1) != 0;               // padding is zero AFTER the activation: selected on the packed halves
+            unsigned pk[NCH / 2];
+#pragma unroll
+            for (int e = 0; e < NCH; e += 2) {
+                float v0, v1;
+                // (by value: bit_cast of a vector element through a reference reads element 0)
+                if constexpr (IH) { const float rf = raw[set][k][e >> 1]; const unsigned u = nm_fbits(rf); v0 = nm_bf_lo(u); v1 = nm_bf_hi(u); }
+                else { v0 = raw[set][k][e]; v1 = raw[set][k][e + 1]; }
+                v0 = __builtin_fmaf(v0, sc[set][e >> 2][e & 3], sh[set][e >> 2][e & 3]); v1 = __builtin_fmaf(v1, sc[set][e >> 2][(e & 3) + 1], sh[set][e >> 2][(e & 3) + 1]);
+                v0 = fmaxf(v0, v0 * p.in_slope); v1 = fmaxf(v1, v1 * p.in_slope);
+                half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
+                asm volatile("" : "+v"(hv));
+                pk[e >> 1] = keep ? __builtin_bit_cast(unsigned, hv) : 0u;
+            }
+            if (pc_pos[k] >= 0) {
+                if constexpr (IH) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<u32x4*>(ldh + buf * 2 * HV + pc_slot[k]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                } else {
+                    reinterpret_cast<nm_u32x2*>(ldh + buf * 2 * HV + pc_slot[k])[sub & 1] = nm_u32x2{pk[0], pk[1]};
+                }
+            }
+        };
+        // the step's weights: 54 one-KiB wave pieces (tap t, plane r of (cout group cg, chunk cb)), piece j = pw + 4 i of producer wave pw
+        const unsigned wst_t = (unsigned)((size_t)C16 * 4 * plane * 16), wst_r = (unsigned)(plane * 16);
+        const bool wdma = p.wdma != 0;
+        auto load_w = [&](int cg, int cb, int buf) {
+            const float* base = reinterpret_cast<const float*>(w8 + ((size_t)cb * 4) * plane + cg * 64);
+            static_for<NWL>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                const int j = min(pw + 4 * i, 53), t = j >> 1, r = j & 1;
+                const unsigned src = (unsigned)t * wst_t + (unsigned)r * wst_r + (unsigned)lane * 16u;
+                if (wdma) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + src),
+                                                           (__attribute__((address_space(3))) void*)(ldb + buf * WB + j * 64), 16, 0, 0);
+                else wreg[i] = load16_untracked(base, src);
+            });
+        };
+        auto store_w = [&](int buf) {
+            if (wdma) return;
+            static_for<NWL>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                const int j = min(pw + 4 * i, 53);
+                *reinterpret_cast<f32x4*>(ldb + buf * WB + j * 64 + lane) = wreg[i];
+            });
+        };
+
+        Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+        int hb = 0;                                                 // buffers (halo and weights alike) of the step the MFMA waves run
+        Step s1 = cur; bool has1 = advance(s1);
+        Step s2 = s1;  bool has2 = has1 && advance(s2);
+        Step s3 = s2;  bool has3 = has2 && advance(s3);
+        unsigned m1 = inside_mask(cur.w), m2, m3;
+        for (int c = pt; c < p.Cout; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
+        // prologue: first tile + first step's weights in the open; the tiles of steps s1 (set 0) and s2 (set 1) in flight
+        load_w(cur.w.cg, 0, 0);
+        load_affine(cur.w, 0, ic<0>{});
+        { const float* b = tile_base(cur.w, 0); static_for<NP>([&](auto K) { load_piece(b, m1, K, ic<0>{}); }); }
+        NM_Q2_WAIT_SET(0, 0, 0);
+        NM_Q2_WAIT_W(0);
+        fix_affine(ic<0>{});
+        store_w(0);
+        static_for<NP>([&](auto K) { convert(0, m1, K, ic<0>{}); });
+        m1 = inside_mask(s1.w);
+        load_affine(s1.w, s1.cb, ic<0>{});
+        { const float* b = tile_base(s1.w, s1.cb); static_for<NP>([&](auto K) { load_piece(b, m1, K, ic<0>{}); }); }
+        m2 = inside_mask(s2.w);
+        load_affine(s2.w, s2.cb, ic<1>{});
+        { const float* b = tile_base(s2.w, s2.cb); static_for<NP>([&](auto K) { load_piece(b, m2, K, ic<1>{}); }); }
+        lds_barrier();
+        // one producer iteration = one step of the MFMA waves (`cur`): set SET holds the tile of s1 (converted now into the other
+        // halo buffer) and is refilled with the tile of s3; the other set holds s2.  false after the block's last step.
+        auto iter = [&](auto SET) -> bool {
+            constexpr int set = decltype(SET)::value;
+            m3 = (s3.w.n != s2.w.n || s3.w.oz0 != s2.w.oz0 || s3.w.oy0 != s2.w.oy0 || s3.w.ox0 != s2.w.ox0) ? inside_mask(s3.w) : m2;
+            const float* b3 = tile_base(s3.w, s3.cb);
+            // weights of step s1 into the other buffer (read last during the step before this one)
+            if constexpr (DBG != 2 && DBG != 4 && DBG < 6) load_w(s1.w.cg, s1.cb, hb ^ 1);
+            // in order: [tile s1 -> this set][tile s2 -> other set][these NWL weight loads]: this set has landed once only the
+            // other set's loads and the weight loads are outstanding
+            NM_Q2_WAIT_SET(set, 23, 26);
+            fix_affine(SET);
+            if constexpr (DBG != 2 && DBG != 5 && DBG < 6) {
+                static_for<NP>([&](auto K) { if constexpr (DBG != 8) convert(hb ^ 1, m1, K, SET); if constexpr (DBG != 9) load_piece(b3, m3, K, SET); });
+                if constexpr (DBG != 9) load_affine(s3.w, s3.cb, SET);
+            }
+            NM_Q2_WAIT_WP(9, 12);                                   // the weight loads: only this iteration's NP + NA loads are younger
+            if constexpr (DBG != 2 && DBG != 4 && DBG < 6) store_w(hb ^ 1);
+            lds_barrier();                                          // publishes tile + weights of s1; the MFMA waves are done with `cur`
+            if (cur.cb == C16 - 1 && DBG != 7) lds_barrier();       // the MFMA waves' epilogue barrier of a finished brick
+            if (!has1) return false;
+            cur = s1; s1 = s2; has1 = has2; s2 = s3; has2 = has3; has3 = has3 && advance(s3);
+            m1 = m2; m2 = m3; hb ^= 1;
+            return true;
+        };
+        for (;;) { if (!iter(ic<0>{})) break; if (!iter(ic<1>{})) break; }
+        NM_Q2_WAIT_W(0);                                            // loads still in flight for steps that do not exist
+        return;
+    }
+
+    // =============================== MFMA waves ===============================================================
+    __builtin_amdgcn_s_setprio(3);
+    int arow0;
+    {
+        const int c = l31 >> 2;
+        const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
+        arow0 = z * ZP + (2 * wave) * HX + x;
+    }
+    const int vx = ((((0x96 >> (l31 >> 2)) & 1) << 2) + (l31 & 3)), vz = l31 >> 3;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+    int hb = 0;
+    lds_barrier();                                                  // the producers' prologue
+
+    constexpr int YO = HX * 16;                                     // brick row 2 wave -> 2 wave + 1
+    half8 a0[3], a1[3], b0[3], b1[3];                               // operands of three taps in flight (index = tap % 3)
+    for (;;) {
+        Step nxt = cur;
+        const bool has_next = advance(nxt);
+        const unsigned va = (unsigned)(size_t)(ldh + hb * 2 * HV + h * HV + arow0);
+        const unsigned vb = (unsigned)(size_t)(ldb + hb * WB + h * 64 + l31);
+        // taps 0 and 1 (the tile and the weights were published by the barrier just passed)
+        a0[0] = lds_read16_untracked<0>(va); a1[0] = lds_read16_untracked<YO>(va);
+        b0[0] = lds_read16_untracked<0>(vb); b1[0] = lds_read16_untracked<32 * 16>(vb);
+        a0[1] = lds_read16_untracked<16>(va); a1[1] = lds_read16_untracked<16 + YO>(va);
+        b0[1] = lds_read16_untracked<128 * 16>(vb); b1[1] = lds_read16_untracked<128 * 16 + 32 * 16>(vb);
+        static_for<27>([&](auto TT) {
+            constexpr int tt = decltype(TT)::value, i = tt % 3, u = tt + 2, j = u % 3;
+            // in-order LDS returns: at most the four reads of tap tt + 1 may still be outstanding
+            if constexpr (tt < 26 && DBG != 6) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[i]), "+v"(a1[i]), "+v"(b0[i]), "+v"(b1[i]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[i]), "+v"(a1[i]), "+v"(b0[i]), "+v"(b1[i]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr bool more = u < 27 && DBG != 6;
+            constexpr int AO = more ? ((u / 9) * ZP + ((u % 9) / 3) * HX + (u % 3)) * 16 : 0;
+            constexpr int BO = more ? u * 128 * 16 : 0;
+#define NM_Q2_MFMA(ACC, B, A) if constexpr (DBG != 1) { NM_MFMA2(ACC, B, A); } else { asm volatile("" :: "v"(B), "v"(A)); __builtin_amdgcn_sched_barrier(0); }
+            NM_Q2_MFMA(acc[0][0], b0[i], a0[i]); if constexpr (more) a0[j] = lds_read16_untracked<AO>(va);
+            NM_Q2_MFMA(acc[0][1], b1[i], a0[i]); if constexpr (more) a1[j] = lds_read16_untracked<AO + YO>(va);
+            NM_Q2_MFMA(acc[1][0], b0[i], a1[i]); if constexpr (more) b0[j] = lds_read16_untracked<BO>(vb);
+            NM_Q2_MFMA(acc[1][1], b1[i], a1[i]); if constexpr (more) b1[j] = lds_read16_untracked<BO + 32 * 16>(vb);
+        });
+        asm volatile("s_barrier" ::: "memory");                     // the producers publish the next step's tile and weights
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur.cb == C16 - 1 && (DBG != 7 || acc[0][0][0] == 12345.678f)) {
+            // ---- epilogue of the finished brick (exposed): transposed accumulators -> 16-byte stores, DPP partial sums
+            const Work& w = cur.w;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float s1[16], s2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const size_t dst = ((((size_t)w.n * p.OD + w.oz0 + vz) * p.OH + w.oy0 + 2 * wave + mt) * p.OW + w.ox0 + vx) * (size_t)p.Cout +
+                                       w.cg * 64 + nt * 32 + 4 * h;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + w.cg * 64 + nt * 32 + 8 * k4 + 4 * h);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (acc[mt][nt][4 * k4 + e] + 0.f * (1.0f / NM_SPLIT_SCALE)) + b4[e];      // (conv_f16p2<SINGLE>'s expression: its correction accumulator is zero)
+                            s1[4 * k4 + e] += v[e]; s2[4 * k4 + e] += v[e] * v[e];
+                            acc[mt][nt][4 * k4 + e] = 0.f;
+                        }
+                        if constexpr (DBG != 3) nm_st4<OH>(p.out, dst + 8 * k4, v);
+                        else if (v[0] == 12345.678f) nm_st4<OH>(p.out, dst + 8 * k4, v);
+                    }
+                }
+                if (p.part) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float a = dpp_sum32(s1[r]), b = dpp_sum32(s2[r]);
+                        if (l31 == 16) *reinterpret_cast<f32x2*>(red + (wave * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2) = f32x2{a, b};
+                    }
+                }
+            }
+            lds_barrier();                                          // (matched by the producers)
+            if (p.part && tid < 64) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a += red[(q * 64 + tid) * 2]; b += red[(q * 64 + tid) * 2 + 1]; }
+                const int br = ((w.oz0 >> 2) * nby + (w.oy0 >> 3)) * nbx + (w.ox0 >> 3);
+                float* dp = p.part + (((size_t)w.n * nbr + br) * p.Cout + w.cg * 64 + tid) * 2;
+                dp[0] = a; dp[1] = b;
+            }
+        }
+        if (!has_next) break;
+        cur = nxt; hb ^= 1;
+    }
+}
+
 // OIDHW fp32 -> split fp16 [tap][Cin/16][hi|lo][lane half][Co_pad][8]
 __global__ void pack_conv_weight16_kernel(const float* __restrict__ w, int Cout, int Cin, int ks, _Float16* __restrict__ packed,
                                           int Co_pad) {
@@ -2746,9 +3090,54 @@ int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, 
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p2 launch");
 }
+// the one-product modes' own kernel (conv_f16q2_kernel); the caller has checked conv mode 3 / 4
+template <int IO, int DBG = 0>
+int launch_f16q2_impl(const ConvParams& p_in, int work_items, hipStream_t s) {
+    ConvParams p = p_in;
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16q2_kernel<IO, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16q2)");
+        attr_set.mark();
+    }
+    if (g_num_cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nm_check_hip(hipErrorUnknown, "device query");
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const size_t lds_bytes = (size_t)4 * 600 * 16 + (size_t)2 * 27 * 2 * 64 * 16 + (size_t)(512 + p.Cout) * sizeof(float);
+    if (lds_bytes > 160 * 1024) { nm_set_error("conv_f16q2: %d output channels exceed the LDS budget", p.Cout); return NM_ERR_UNSUPPORTED; }
+    ProfRec rec;
+    rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
+    const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+    if (prof_rec) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 9;
+        (void)hipEventRecord(rec.a, s);
+    }
+    dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
+    if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
+    hipLaunchKernelGGL((conv_f16q2_kernel<IO, DBG>), grid, dim3(512), lds_bytes, s, p);
+    if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+    return nm_check_hip(hipGetLastError(), "conv_f16q2 launch");
+}
 template <bool UP2>
 int launch_f16p2(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
     const int io = (p.in_h ? 1 : 0) | (p.out_h ? 2 : 0);
+    if constexpr (!UP2) {
+        if (nm_ls().single && nm_ls().f16q2 && (io == 0 || io == 3) && p.Cout <= 1024) {
+#ifdef NM_Q2_DIAG
+            static const int dbg = getenv("NM355_Q2_DBG") ? atoi(getenv("NM355_Q2_DBG")) : 0;      // ablations of tools/diag_f16q2.py (diagnostic build only)
+            if (io == 3) switch (dbg) {
+                case 1: return launch_f16q2_impl<3, 1>(p, work_items, s); case 2: return launch_f16q2_impl<3, 2>(p, work_items, s);
+                case 3: return launch_f16q2_impl<3, 3>(p, work_items, s); case 4: return launch_f16q2_impl<3, 4>(p, work_items, s);
+                case 5: return launch_f16q2_impl<3, 5>(p, work_items, s); case 6: return launch_f16q2_impl<3, 6>(p, work_items, s);
+                case 7: return launch_f16q2_impl<3, 7>(p, work_items, s); case 8: return launch_f16q2_impl<3, 8>(p, work_items, s);
+                case 9: return launch_f16q2_impl<3, 9>(p, work_items, s); default: break;
+            }
+#endif
+            return io ? launch_f16q2_impl<3>(p, work_items, s) : launch_f16q2_impl<0>(p, work_items, s);
+        }
+    }
     if (io) {                                                       // 16-bit storage: both tensors bfloat16 (layers at >= 32^3 and their data gradients)
         if (io != 3 || !nm_ls().single) return io16_unsupported("conv_f16p2", p);
         return launch_f16p2_impl<UP2, true, 3>(p, lds_bytes, work_items, s);
