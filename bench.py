@@ -150,7 +150,8 @@ def cpu_baseline(sd, opts, net, dev):
     lat = max((out[k].cpu().double() - ref[k].double()).abs().max().item() for k in ("z_kypts", "h_kypts"))
     parity = dict(kypt_l2=l2, latent_linf=lat, kypt_recon_linf=(out["kypt_recon"].cpu().double() - ref["kypt_recon"].double()).abs().max().item(),
                   best_idx_equal=bool((out["best_idx"].cpu().long() == ref["best_idx"].long()).all()))
-    return dict(value=nb * T / med, unit="voxel-frames/s", cores=best_thr, host_threads=ncpu, kind="port", runs_s=[round(t, 3) for t in times],
+    return dict(value=nb * T / med, unit="voxel-frames/s", cores=best_thr, threads_used=best_thr, host_threads=ncpu, **host_cpu_limits(),
+                kind="port", runs_s=[round(t, 3) for t in times],
                 thread_calibration_s={str(k): round(v, 3) for k, v in sorted(calib.items())},
                 thread_calibration_not_timed=[int(k) for k in skipped],
                 full_shape_first_run_s={str(k): round(v[0], 3) for k, v in runs.items()},
@@ -160,16 +161,48 @@ def cpu_baseline(sd, opts, net, dev):
                        f"os.cpu_count() = {ncpu})"), parity
 
 
+def host_cpu_limits():
+    """What the process may actually use of the host: the scheduler affinity mask and the cgroup CPU quota (a 256-thread host whose
+    container is limited to a few cores explains a CPU baseline near an 8-core machine's)."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                quota = f.read().strip()
+            if path.endswith("cfs_quota_us"):
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    quota = quota + " " + f.read().strip()
+            break
+        except Exception:
+            continue
+    cores = None
+    if quota:
+        q = quota.split()
+        if q[0] not in ("max", "-1") and len(q) > 1 and float(q[1]) > 0:
+            cores = float(q[0]) / float(q[1])
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), None)
+    except Exception:
+        pass
+    return dict(affinity_cpus=aff, cgroup_cpu_max=quota, cgroup_cpu_cores=cores, cpu_model=model)
+
+
 STEP_TFLOP = 99.15e-3 * B_PER_GPU * T          # algorithmic TFLOP of one forward step on one GPU (BASELINE.md)
 # PMC summaries are only read from this round's files under profiles/ (tools/collect_evidence.sh <round> writes them; the round can be
 # overridden with NM355_ROUND for a re-run of an older tree)
-ROUND = os.environ.get("NM355_ROUND", "r04")
+ROUND = os.environ.get("NM355_ROUND", "r05")
 
 
 def prof_families(lib, h, _lib):
     """{kernel family: (event-timed ms total, algorithmic flops total, launches)} of the context's current profiler window."""
     fam = {}
-    for v in range(13):
+    for v in range(15):
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         _lib.check(lib.nm_prof_read(h, v, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
         if n.value:
@@ -295,7 +328,28 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
     step = lambda: tr.step(vox, sync=False)
     ms = timed(step, 2, 5) * 1e3
     mem2 = (C.c_size_t * 4)()
-    _lib.check(net_b._engine.ctx.lib.nm_ctx_memory(net_b._engine.ctx.handle, mem2), "ctx_memory")
+    lib_b, h_b = net_b._engine.ctx.lib, net_b._engine.ctx.handle
+    _lib.check(lib_b.nm_ctx_memory(h_b, mem2), "ctx_memory")
+    # its own roofline: three more steps with every matrix-core launch on either stream bracketed by HIP events (durations include the
+    # contention between the step's three queues); one MFMA per algorithmic product in this mode, so issued = algorithmic
+    tr.bucket.time_collectives = True
+    _lib.check(lib_b.nm_prof_enable(h_b, 2), "prof_enable")
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(dev)
+    _lib.check(lib_b.nm_prof_enable(h_b, 0), "prof_enable")
+    fam_b = prof_families(lib_b, h_b, _lib)
+    ar_ms = tr.bucket.last_allreduce_ms()
+    top_b = [dict(kernel=nm, ms_per_step=m3 / 3.0, launches_per_step=n3 / 3.0, algorithmic_tflop_per_step=fl3 / 3.0 / 1e12,
+                  achieved_tflops=fl3 / (m3 * 1e-3) / 1e12, frac_of_f16_mfma_peak=fl3 / (m3 * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS)
+             for nm, (m3, fl3, n3) in sorted(fam_b.items(), key=lambda kv: -kv[1][0])[:3] if m3 > 0]
+    roof_b = None
+    if top_b:
+        roof_b = dict(bound="mfma", kernel=top_b[0]["kernel"], achieved=top_b[0]["achieved_tflops"], peak=F16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                      frac=top_b[0]["frac_of_f16_mfma_peak"], top3=top_b,
+                      matrix_core_ms_per_step_all_families=sum(v[0] for v in fam_b.values()) / 3.0,
+                      note="event-timed launches of the step's conv / weight-gradient families on all three queues (durations include their "
+                           "mutual contention); one f16 MFMA per algorithmic product in this mode: issued = algorithmic")
     del tr, net_b
     out["train_bf16"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=5, warmup=2,
                              workload="the `train` step in conv mode 'bf16' (BASELINE configs[2]: 64^3, T=16, B=4 clips per GPU, bf16)",
@@ -305,6 +359,9 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
                              n_gpus=world, algorithmic_tflop_per_step=3.0 * STEP_TFLOP,
                              frac_of_f16_mfma_peak=3.0 * STEP_TFLOP / (ms * 1e-3) / F16_MFMA_PEAK_TFLOPS,
                              training_arena_gb=mem2[1] / 1e9, weight_gradient_side_block_gb=mem2[2] / 1e9,
+                             roofline=roof_b, allreduce_ms=ar_ms,
+                             allreduce_note=("event pair on the bucket's side stream around the step's two gradient all-reduce chunks (RCCL)" if ar_ms is not None
+                                             else "no collective was issued (one rank without a process group): measured when N > 1"),
                              note="memory: ctx-owned arenas of this mode's own context (nm_ctx_memory); the fp32-storage figures are in train_memory_gb")
     with torch.no_grad():
         net.load_state_dict(saved)
@@ -496,7 +553,7 @@ def main():
         frames = world * B_PER_GPU * T * args.steps
         # dominant kernel = the conv family with the largest event-timed total per step over BOTH streams (what a rocprof summary
         # ranks by); its `achieved` comes from its launches on the ctx stream inside the timed region (clean durations)
-        is_split = lambda nm: nm.startswith("conv_f16") or nm.startswith("conv_pool_f16") or nm.startswith("conv_up2c")
+        is_split = lambda nm: nm.startswith("conv_f16") or nm.startswith("conv_pool_f16") or nm.startswith("conv_up2c") or nm.startswith("wgrad16")
         ranked = sorted(fam_all.items(), key=lambda kv: -kv[1][0])
         top3 = []
         for nm, (ms_a, fl_a, n_a) in ranked[:3]:
@@ -524,6 +581,8 @@ def main():
             if split:
                 roof["issued"] = 3.0 * ach
                 roof["frac_issued"] = 3.0 * ach / peak
+                roof["split_ceiling_tflops"] = peak / 3.0          # three MFMA products per algorithmic product: what 100 % MFMA issue would give
+                roof["frac_of_split_ceiling"] = ach / (peak / 3.0)
                 roof["algorithmic_vs_fp32_mfma_peak"] = ach / FP32_MFMA_PEAK_TFLOPS
         cpu, parity = (None, {})
         if world == 1 and not args.no_cpu_baseline and args.workload == "forward":

@@ -333,7 +333,7 @@ int nm_prof_enable(nm_ctx* ctx, int32_t on) { NmScope nm_scope_(ctx);
 }
 
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) { NmScope nm_scope_(ctx);
-    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 12) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
+    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 14) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
     long long n = 0;
     int rc = nm_conv_prof_collect(variant, ms_total, flops_total, &n);
     if (rc) { nm_set_error("prof_read: event query failed"); return rc; }
@@ -342,11 +342,11 @@ int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_t
 }
 
 const char* nm_prof_kernel_name(int32_t variant) {
-    static const char* names[13] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
+    static const char* names[15] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
                                    "conv_k5occ_kernel", "conv_f16s_kernel<2,1>", "conv_f16s_kernel<2,2>", "conv_f16p_kernel",
                                    "conv_pool_f16s_kernel", "conv_f16p2_kernel", "conv_f16s_kernel<2,1,3,up2>", "conv_f16s_kernel<2,2,3,up2>",
-                                   "conv_up2c_kernel"};
-    return (variant >= 0 && variant < 13) ? names[variant] : "";
+                                   "conv_up2c_kernel", "wgrad16_kernel", "conv_f16q2_kernel"};
+    return (variant >= 0 && variant < 15) ? names[variant] : "";
 }
 
 int nm_host_linspace(int32_t n, float* out) {

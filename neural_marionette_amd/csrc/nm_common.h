@@ -189,6 +189,13 @@ bool nm_conv_pool16_eligible(int Cin, int OD, int OH, int OW, bool have_w16);
 void nm_conv_prof_enable(int on, hipStream_t stream);
 int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, long long* launches);
 void nm_conv_prof_reset();
+// a launch (sequence) outside nm_conv.hip bracketed for the same profiler: begin records the first event when the profiler is on for
+// stream s, end the second and files the record under `variant` (nm_prof_kernel_name)
+struct NmProfScope {
+    bool on = false; NmProfRec rec{}; hipStream_t s = nullptr;
+    NmProfScope(hipStream_t stream, double flops, int variant);
+    ~NmProfScope();
+};
 
 // ---- nm_elem.hip -------------------------------------------------------------------
 int nm_launch_gn_finalize(const float* part, int N, int nblk, int C, int groups, double count,

@@ -3111,7 +3111,7 @@ int launch_f16q2_impl(const ConvParams& p_in, int work_items, hipStream_t s) {
     rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
     const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
     if (prof_rec) {
-        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 9;
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 14;
         (void)hipEventRecord(rec.a, s);
     }
     dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
@@ -3266,6 +3266,18 @@ int nm_conv_prof_collect(int variant, double* ms_total, double* flops_total, lon
     }
     *ms_total = ms; *flops_total = fl; *launches = n;
     return NM_OK;
+}
+
+NmProfScope::NmProfScope(hipStream_t stream, double flops, int variant) : s(stream) {
+    on = flops > 0.0 && NM_PROF_ON(stream) && flops >= nm_ls().prof_min_flops;
+    if (!on) return;
+    rec.a = prof_event(); rec.b = prof_event(); rec.variant = variant; rec.flops = flops;
+    (void)hipEventRecord(rec.a, s);
+}
+NmProfScope::~NmProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.b, s);
+    nm_ls().prof.push_back(rec);
 }
 
 void nm_conv_prof_reset() {

@@ -2541,6 +2541,8 @@ int run_wgrad(WgradPlan& q, float* ws, float* dW, int cin_real, int taps, hipStr
     if (h16 && !(q.mode == 3 || (q.mode == 0 && q.p.ks == 2 && q.p.in.h) || (q.mode == 2 && !q.p.in.h))) {
         nm_set_error("wgrad: no kernel for bfloat16 operands (in %d, dy %d) with ks=%d mode=%d", q.p.in.h, q.p.dy.h, q.p.ks, q.mode); return NM_ERR_UNSUPPORTED;
     }
+    // (the split-fp16 k3 weight gradients are a profiler family of their own, nm_prof_kernel_name 13: kernel + its fixed-order reduce)
+    NmProfScope prof(s, q.mode == 3 ? 2.0 * q.p.in.N * (double)q.p.dy.D * q.p.dy.H * q.p.dy.W * q.p.M * (double)cin_real * taps : 0.0, 13);
     if (q.mode == 3) rc = launch_wgrad16(q, s);
     else if (q.mode == 2) rc = q.p.dy.h ? launch_wgrad_t<2, 7, false, true>(q, s) : launch_wgrad_t<2, 7>(q, s);
     else if (q.mode == 1) rc = launch_wgrad_t<1, 1>(q, s);

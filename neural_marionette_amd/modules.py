@@ -58,12 +58,20 @@ class Engine:
         self._named = None
         # conv arithmetic: 1 = split-fp16 MFMA with fp32-equivalent accuracy (default), 0 = exact fp32 MFMA, 3 = fp16 products
         # with fp32 accumulation (reduced precision, for training)
-        self.conv_mode = CONV_MODES.get(os.environ.get("NM355_CONV_MODE", "split16").lower(), 1)
-        # 'auto' (set_conv_mode): split16 with a synchronous range probe on the first conv-running call after every weight change;
-        # a call that overflows the fp16 range is re-run on the exact fp32 path, which then stays selected until the weights change
-        self.auto = os.environ.get("NM355_CONV_MODE", "").lower() == "auto"
+        env_mode = os.environ.get("NM355_CONV_MODE")
+        self.conv_mode = CONV_MODES.get((env_mode or "split16").lower(), 1)
+        # 'auto': split16 with a synchronous range probe on the first conv-running call after every weight change; a call that
+        # overflows the fp16 range is re-run on the exact fp32 path, which then stays selected until the weights change.  This is the
+        # DEFAULT (round 5): a script that makes one plain call and reads its outputs must never see NaN where the reference's fp32
+        # arithmetic stays finite; the cost is one device synchronisation per weight change, none in steady-state inference.
+        # set_conv_mode('split16' | 'fp32' | 'f16' | 'bf16') (or NM355_CONV_MODE) selects a mode explicitly and switches the probe
+        # off - bench.py and the trainers' steps run that way, covered by the deferred guard of include/nm355.h.
+        self.auto = env_mode is None or env_mode.lower() == "auto"
+        self.auto_explicit = env_mode is not None and env_mode.lower() == "auto"
         self._probe = True
         self._auto_fp32 = False
+        self._wstamp = None          # identity + version of every weight tensor at the last upload (survives set_training / a new context)
+        self.suppress_probe = False  # the trainers' steps (weights change every step): no synchronous probe unless 'auto' was asked for
         self.training_packs = False     # detector-mode training: set_weights also packs the data-gradient weights
 
     # -- plumbing ---------------------------------------------------------------------------
@@ -110,11 +118,15 @@ class Engine:
         sd = self._named
         # (the conv mode and the training switch decide which derived tables set_weights builds: part of the stamp)
         wstamp = tuple((t.data_ptr(), t._version) for _, t in sd)
-        if self._stamp is not None and wstamp != self._stamp[2:] and self.auto:
-            self._probe = True                      # new weights: the next conv-running call is range-probed again ...
-            if self._auto_fp32:                     # ... starting over on the split path
-                self._auto_fp32 = False
-                _lib.check(self.ctx.lib.nm_set_conv_mode(self.ctx.handle, self.conv_mode), "set_conv_mode")
+        if wstamp != self._wstamp:
+            # (compared against its own record, not against _stamp: set_training() and a re-created context clear _stamp, and a weight
+            #  change that coincided with such a toggle must still re-arm the probe and drop a stale fp32 fallback - ADVICE r4)
+            self._wstamp = wstamp
+            if self.auto:
+                self._probe = True                      # new weights: the next conv-running call is range-probed again ...
+                if self._auto_fp32:                     # ... starting over on the split path
+                    self._auto_fp32 = False
+                    _lib.check(self.ctx.lib.nm_set_conv_mode(self.ctx.handle, self.conv_mode), "set_conv_mode")
         stamp = (0 if (self.auto and self._auto_fp32) else self.conv_mode, self.training_packs) + wstamp
         if stamp == self._stamp:
             return
@@ -141,7 +153,7 @@ class Engine:
         one after a weight change is also probed synchronously: if it overflowed it is re-run here on the exact fp32 path (all of a
         call's outputs are rewritten), and fp32 stays selected until the weights change."""
         self.call(fn, *args)
-        if not (self.auto and self._probe):
+        if not (self.auto and self._probe) or (self.suppress_probe and not self.auto_explicit):
             return
         self._probe = False
         rc = self.ctx.lib.nm_ctx_check_nonfinite(self.ctx.handle)
@@ -587,7 +599,8 @@ class NeuralMarionette(nn.Module):
             self.kypt_detector.anneal(nepoch)
 
     def set_conv_mode(self, mode: str) -> None:
-        """'split16' (default): convs with Cin % 16 == 0 on the fp16 matrix cores, operands split hi/lo, fp32
+        """Without a call of this method (and without NM355_CONV_MODE) the mode is 'auto' (below).
+        'split16': convs with Cin % 16 == 0 on the fp16 matrix cores, operands split hi/lo, fp32
         accumulate (fp32-equivalent accuracy); 'fp32': exact fp32 MFMA everywhere; 'f16': the split16 kernels with the
         hi x hi product only - operands rounded to fp16, fp32 accumulation and storage (autocast-class accuracy, the
         reduced-precision training mode; outside the 1e-4 parity contract); 'bf16': 'f16' arithmetic with bfloat16 STORAGE of the
@@ -602,6 +615,7 @@ class NeuralMarionette(nn.Module):
         eng = self._engine
         eng.conv_mode = CONV_MODES[mode]
         eng.auto, eng._probe, eng._auto_fp32 = mode == "auto", True, False
+        eng.auto_explicit = mode == "auto"
 
     def check_finite(self) -> None:
         """Synchronises and raises NmError if a convolution has produced non-finite values since the last check - in the default

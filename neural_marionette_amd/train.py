@@ -75,6 +75,10 @@ class GradBucket:
             self.chunks.append((start, off)); start = off; cur += 1
         self.comm_stream = torch.cuda.Stream(dev) if self.flat.is_cuda else None
         self._pending = []
+        # bench.py: event pair around a step's collectives on the side stream (first chunk's start .. last chunk's end)
+        self.time_collectives = False
+        self._ev_t0 = self._ev_t1 = None
+        self._t0_set = False
 
     def chunk(self, i) -> torch.Tensor:
         a, b = self.chunks[i]
@@ -93,7 +97,13 @@ class GradBucket:
         else:
             self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
         with torch.cuda.stream(self.comm_stream):
+            if self.time_collectives and not self._t0_set:
+                if self._ev_t0 is None:
+                    self._ev_t0, self._ev_t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self._ev_t0.record(self.comm_stream); self._t0_set = True
             self._pending.append(dist.all_reduce(self.chunk(i), op=dist.ReduceOp.SUM, async_op=True))
+            if self.time_collectives:
+                self._ev_t1.record(self.comm_stream)
 
     def finish(self) -> None:
         """Wait for the started collectives (stream-ordered on the GPU) and turn the sums into means."""
@@ -102,9 +112,30 @@ class GradBucket:
         for w in self._pending:
             w.wait()
         self._pending = []
+        self._t0_set = False
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
         self.flat.mul_(1.0 / dist.get_world_size())
+
+    def last_allreduce_ms(self):
+        """Side-stream time from the start of the last step's first collective to the end of its last one (None when the step
+        issued none: no process group, or one rank without ``always_reduce``).  Synchronises on the end event."""
+        if not self.time_collectives or self._ev_t0 is None:
+            return None
+        self._ev_t1.synchronize()
+        return float(self._ev_t0.elapsed_time(self._ev_t1))
+
+
+def _drop_nonfinite_step_(flat: torch.Tensor) -> None:
+    """The library's range guard is deferred: a conv that overflowed the fp16 range in step n (conv modes 'split16' / 'f16' / 'bf16')
+    is reported at the first library call of step n + 1 (include/nm355.h "Range / finiteness status") - after this step's Adam
+    update.  So that the update of such a step cannot destroy the master weights and the Adam moments, a gradient bucket that holds
+    ANY non-finite entry is zeroed as a whole, on the device, without a synchronisation (two passes over <= 34 MB): the step then
+    only decays the moments, the parameters stay finite, and the next call raises NM_ERR_RANGE naming the call that overflowed
+    (set_conv_mode('auto') re-runs such a call in exact fp32 instead).  After a collective: every rank zeroes (NaN spreads through the sum)."""
+    ok = torch.isfinite(flat).all()
+    flat.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
+    flat.mul_(ok.to(flat.dtype))
 
 
 def adam_step_(eng, params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps) -> None:
@@ -152,7 +183,13 @@ class LearnerTrainer:
         bucket.flat.zero_()
         for n, p in self.named:
             p.grad = bucket.views[n]                  # autograd accumulates in place into an existing .grad
-        log = net(vox, {"detector": False, "learner": True}, eps=eps)
+        # (no synchronous range probe per step - the weights change every step - unless conv mode 'auto' was asked for explicitly: the
+        #  deferred guard reports an overflow at the next call and _drop_nonfinite_step_ keeps it out of the optimizer state)
+        net._engine.suppress_probe = True
+        try:
+            log = net(vox, {"detector": False, "learner": True}, eps=eps)
+        finally:
+            net._engine.suppress_probe = False
         loss = sum(w * log[k] for k, w in self.weights.items())
         loss.backward()
         for n, p in self.named:                       # (autograd replaces .grad instead of accumulating in some modes: keep the bucket authoritative)
@@ -160,6 +197,7 @@ class LearnerTrainer:
                 bucket.views[n].copy_(p.grad); p.grad = bucket.views[n]
         bucket.reduce_chunk(0)
         bucket.finish()
+        _drop_nonfinite_step_(bucket.flat)
         grads = [bucket.views[n] for n, _ in self.named]
         eng = net._engine
         eng.ready()
@@ -245,8 +283,12 @@ class DetectorTrainer:
         ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev); recon = torch.empty(B, T, 1, G, G, G, device=dev)
         aff = torch.empty(det.nneighbor, K, K, 1, device=dev) if det.affinity_start else None
         losses = torch.empty(len(self.loss_keys), device=dev)
-        eng.call_conv("nm_detector_forward_train", _lib.ptr(vox), B, T, int(det.affinity_start), _lib.ptr(kp), _lib.ptr(hm), _lib.ptr(ff),
-                 _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses))
+        eng.suppress_probe = True                   # (see LearnerTrainer.step)
+        try:
+            eng.call_conv("nm_detector_forward_train", _lib.ptr(vox), B, T, int(det.affinity_start), _lib.ptr(kp), _lib.ptr(hm), _lib.ptr(ff),
+                          _lib.ptr(recon), _lib.ptr(aff), _lib.ptr(losses))
+        finally:
+            eng.suppress_probe = False
         wvec = self._weight_vector(dev)
         if self._ev is None:
             self._ev = torch.cuda.Event()
@@ -283,6 +325,7 @@ class DetectorTrainer:
         losses = self._forward_backward(vox, named, bucket)
         bucket.reduce_chunk(1)
         bucket.finish()
+        _drop_nonfinite_step_(bucket.flat)
         live = [(n, p) for n, p in named if p.requires_grad]          # frozen parameters: gradient computed, not applied
         params = [p for _, p in live]
         grads = [bucket.views[n] for n, _ in live]
