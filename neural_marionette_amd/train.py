@@ -170,8 +170,9 @@ class LearnerTrainer:
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
 
-    def step(self, vox, eps=None, sync: bool = True):
+    def step(self, vox, eps=None, sync: bool = True, global_clips: Optional[int] = None):
         """One training step.  sync=True returns python floats (waits for the device); sync=False returns 0-dim device tensors.
+        global_clips: as DetectorTrainer.step (uneven clip split: the loss that is back-propagated is scaled by this rank's share).
         Gradients land in a persistent GradBucket (every p.grad is a view of the flat buffer autograd accumulates into), which is
         what the collective reduces: one all-reduce of 1.53 M floats, no torch.cat, no copy back - the DetectorTrainer's scheme."""
         net = self.net
@@ -191,7 +192,9 @@ class LearnerTrainer:
         finally:
             net._engine.suppress_probe = False
         loss = sum(w * log[k] for k, w in self.weights.items())
-        loss.backward()
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        scale = 1.0 if global_clips is None else float(vox.shape[0]) * world / float(global_clips)
+        (loss * scale if scale != 1.0 else loss).backward()
         for n, p in self.named:                       # (autograd replaces .grad instead of accumulating in some modes: keep the bucket authoritative)
             if p.grad is not None and p.grad.data_ptr() != bucket.views[n].data_ptr():
                 bucket.views[n].copy_(p.grad); p.grad = bucket.views[n]
@@ -239,6 +242,7 @@ class DetectorTrainer:
         self._wvec = None
         self._wvec_key = None
         self._ev = None
+        self._rank_scale = 1.0
         self.reset_optimizer()
 
     def _named(self):
@@ -290,6 +294,8 @@ class DetectorTrainer:
         finally:
             eng.suppress_probe = False
         wvec = self._weight_vector(dev)
+        if self._rank_scale != 1.0:                 # uneven clip split: this rank's share of the global clip mean (see step())
+            wvec = wvec * self._rank_scale
         if self._ev is None:
             self._ev = torch.cuda.Event()
             self._ev.record()                       # (creates the HIP event; the library re-records it)
@@ -313,9 +319,16 @@ class DetectorTrainer:
         eng.ready()
         adam_step_(eng, params, grads, m, v, self.t, self.lr, self.betas, self.eps)
 
-    def step(self, vox, sync: bool = True):
+    def step(self, vox, sync: bool = True, global_clips: Optional[int] = None):
         """One training step.  sync=True returns python floats (waits for the device); sync=False returns 0-dim device tensors and
-        lets the host run ahead into the next step."""
+        lets the host run ahead into the next step.
+        global_clips: total number of clips of the step over all ranks when the ranks hold DIFFERENT numbers of clips (a batch that
+        does not divide by the world size, dist.clip_shard).  Every loss is a mean over clips, so the single-process gradient of the
+        whole batch is the clip-weighted mean of the ranks' gradients: this rank's dL/dloss vector is scaled by
+        clips_here * world / global_clips (one multiply of 11 numbers - every gradient the backward kernels write is linear in it),
+        and the bucket's sum / world is then that weighted mean.  None: equal shares (the bench's 4 clips per GPU)."""
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        self._rank_scale = 1.0 if global_clips is None else float(vox.shape[0]) * world / float(global_clips)
         named = self._named()
         key = tuple((n, p.data_ptr()) for n, p in named)
         if self.bucket is None or key != self._bucket_key:
@@ -336,7 +349,7 @@ class DetectorTrainer:
             if id(p) not in self.state:
                 self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
         self._adam(params, grads, [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params])
-        loss = (losses * self._weight_vector(losses.device)).sum()
+        loss = (losses * self._weight_vector(losses.device)).sum()      # (this rank's clips; dist.mean_losses gives the global figure)
         log = {k: losses[i] for i, k in enumerate(self.loss_keys) if k in self.weights}
         if not sync:
             return {"loss": loss, **log}

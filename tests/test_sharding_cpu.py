@@ -213,3 +213,78 @@ def test_bench_adopts_world_size_when_gpus_is_not_given():
     r, lines = _bench("--dist-selftest", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["distributed"]["world_size"] == 1
+
+
+# ---- multi-GPU readiness without the node (round 5): the launcher with EIGHT ranks, and the trainer's clip-weighted mean on an uneven
+# ---- split over four ranks --------------------------------------------------------------------------------------------------------
+def test_bench_gpus8_dist_selftest_gloo():
+    """`python bench.py --gpus 8 --dist-selftest`: the 8-rank launch the driver's scaling run uses (child torch.distributed.run on
+    127.0.0.1, rendezvous, barrier, all-reduce of ones = 8, MAX-reduce over ranks), on gloo here."""
+    r, lines = _bench("--gpus", "8", "--dist-selftest", env={"OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["distributed"]["world_size"] == 8 and d["distributed"]["ranks_seen_by_allreduce"] == 8
+    assert d["distributed"]["backend"] == "gloo" and d["max_over_ranks_checks"] is True
+
+
+def _clip_grad(name, shape, clip):
+    g = torch.Generator().manual_seed((sum(name.encode()) * 104729 + 31 * clip) % (2 ** 31))
+    return torch.randn(*shape, generator=g)
+
+
+def _uneven_worker(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from neural_marionette_amd import NeuralMarionette, HotPathOptions
+    from neural_marionette_amd.train import DetectorTrainer
+    a, b = clip_shard(n_clips, rank, world)
+
+    class CpuStandIn(DetectorTrainer):
+        def _forward_backward(self, vox, named, bucket):
+            # what the HIP step produces: the gradient of THIS rank's clip mean, times the rank's share of the global mean (the
+            # library's backward is linear in the dL/dloss vector, which step() scales by self._rank_scale)
+            for n, p in named:
+                local = sum(_clip_grad(n, p.shape, c) for c in range(a, b)) / (b - a)
+                bucket.views[n].copy_(local * self._rank_scale)
+            bucket.reduce_chunk(0)
+            return torch.full((11,), float(rank))
+
+        def _adam(self, params, grads, m, v):
+            b1, b2 = self.betas
+            for p, g, mm, vv in zip(params, grads, m, v):
+                mm.mul_(b1).add_(g, alpha=1 - b1); vv.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (vv / (1 - b2 ** self.t)).sqrt_().add_(self.eps)
+                p.data.addcdiv_(mm / (1 - b1 ** self.t), denom, value=-self.lr)
+
+    torch.manual_seed(3)
+    net = NeuralMarionette(HotPathOptions(grid_size=32))
+    tr = CpuStandIn(net, lr=1e-2)
+    tr.step(torch.zeros(b - a, 2, 1, 32, 32, 32), global_clips=n_clips)
+    assert abs(tr._rank_scale - (b - a) * world / n_clips) < 1e-12
+    worst = 0.0
+    for n, p in net.kypt_detector.named_parameters():
+        name = "kypt_detector." + n
+        want = sum(_clip_grad(name, p.shape, c) for c in range(n_clips)) / n_clips      # the single-process gradient of the 6-clip batch
+        worst = max(worst, float((p.grad - want).abs().max()))
+    if rank == 0:
+        q.put(worst)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_detector_trainer_uneven_clip_split_world4_is_the_clip_weighted_mean():
+    """B = 6 clips over 4 ranks (2 + 2 + 1 + 1, dist.clip_shard): with ``global_clips`` the bucket's sum / world is the CLIP-weighted
+    mean - the gradient a single process computes on all 6 clips (every loss is a mean over clips, train.py:376-412) - not the mean of
+    the ranks' local means."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 4, port, 6, q)) for r in range(4)]
+    for p in procs: p.start()
+    worst = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert worst < 1e-6, worst

@@ -285,12 +285,77 @@ def test_detector_gradients_bf16_storage_vs_fp64_oracle():
     assert abs(loss - ref_loss) <= 2e-3 * max(1.0, abs(ref_loss))
     assert (out["keypoints"].detach().cpu().double() - ref_out["keypoints"].double()).abs().max().item() < 5e-3
     assert d64 < 4e-2, d64
+    # per tensor: relative L2 distance to the fp64 gradient (a cosine of 0.9 would pass a tensor that is 44 % wrong).  Stated bound:
+    # 0.30 for every tensor with a non-negligible gradient - the deep hourglass convs in front of a GroupNorm, whose backward removes
+    # the common mode, are the worst (mode 'f16' with fp32 storage: 0.25, tests/test_train_detector_gpu.py); measured values printed
     gmax = max(r.abs().max().item() for r in ref.values())
+    worst = ("", 0.0)
     for k, r in ref.items():
         if r.abs().max().item() > 1e-4 * gmax:
             gg, rr = got[k].double().flatten(), r.double().flatten()
-            cos = (gg @ rr).item() / (gg.norm().item() * rr.norm().item())
-            assert cos > 0.9, (k, cos)
+            rel = ((gg - rr).norm() / rr.norm()).item()
+            if rel > worst[1]:
+                worst = (k, rel)
+            assert rel < 0.30, (k, rel)
+    print("bf16 storage: worst per-tensor relative L2 %.3f at %s" % (worst[1], worst[0]))
+
+
+_TRAJ = {}
+
+
+def _oracle_trajectory(steps):
+    """Loss trajectory of `steps` detector-mode training steps of the fp32 oracle (torch.optim.Adam, lr 4e-4, AIST weights: the op
+    sequence of train.py:388-404) at 32^3, B = 2, T = 4; cached per session."""
+    if steps in _TRAJ:
+        return _TRAJ[steps]
+    from oracle import nm_oracle as O
+    o, sd, vox = _setup(seed=41)
+    names = [k for k in sd if k.startswith("kypt_detector.")]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+    sd2 = dict(sd); sd2.update(leaf)
+    opt = torch.optim.Adam([leaf[k] for k in names], lr=4e-4)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        out = O.detector_forward(sd2, o, vox, affinity_on=True)
+        loss = sum(w * out[k] for k, w in AIST.items())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    _TRAJ[steps] = losses
+    return losses
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_twenty_step_adam_trajectory_vs_fp32_oracle(mode):
+    """BASELINE config 3's precision over an optimisation trajectory, not one step: 20 detector-mode Adam steps (lr 4e-4, AIST
+    weights) in conv modes 'f16' and 'bf16' (storage threshold at 16^3: first layer, pools, the 16^3 residual block and the decoder in
+    bfloat16) against the fp32 oracle trained with torch.optim.Adam on the CPU.  Stated bound: every step's loss within 1e-2 relative
+    of the oracle's at that step; the loss must have gone down; all parameters finite."""
+    from neural_marionette_amd import NeuralMarionette
+    from neural_marionette_amd.train import DetectorTrainer
+    steps = 20
+    ref = _oracle_trajectory(steps)
+    o, sd, vox = _setup(seed=41)
+    if mode == "bf16":
+        os.environ["NM355_STORE16_MIN"] = "4096"
+    try:
+        net = NeuralMarionette(o)
+        net.load_state_dict(sd)
+        net = net.cuda().train()
+        net.anneal(1)
+        net.set_conv_mode(mode)
+        tr = DetectorTrainer(net, lr=4e-4)
+        losses = [tr.step(vox.cuda())["loss"] for _ in range(steps)]
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("NM355_STORE16_MIN", None)
+    rel = [abs(a - b) / abs(b) for a, b in zip(losses, ref)]
+    print("%s 20-step trajectory: loss %.4f -> %.4f (oracle %.4f -> %.4f), worst relative deviation %.2e at step %d"
+          % (mode, losses[0], losses[-1], ref[0], ref[-1], max(rel), rel.index(max(rel))))
+    assert max(rel) < 1e-2, list(zip(losses, ref))
+    assert losses[-1] < losses[0]
+    assert all(torch.isfinite(p).all() for p in net.parameters())
 
 
 def test_config3_in_its_named_precision_at_the_bench_shape():
