@@ -67,17 +67,20 @@ def _check_losses(out, ref_losses, tol=2e-5):
         assert e <= tol * max(1.0, abs(r)), f"{k}: got {float(out[k])} want {r}"
 
 
-def _check_occupancy_set(out_recon, ref_recon, margin=1e-4, what=""):
-    """'Thresholded occupancy exact' as SET equality: every voxel whose oracle value is further than `margin` from 0.5 (the
-    reconstruction's measured error is <= 6e-6: a 15x guard) must fall on the same side of the threshold - a pair of compensating
-    flips passes a count comparison but not this.  Voxels inside the margin are reported, not compared."""
+def _check_occupancy_set(out_recon, ref_recon, margin=3e-5, what=""):
+    """'Thresholded occupancy exact' as SET equality: every voxel whose oracle value is further than `margin` from 0.5 must fall on
+    the same side of the threshold - a pair of compensating flips passes a count comparison but not this.  The margin is tied to the
+    measured error of the reconstruction (asserted below: at most margin / 2), not chosen freely; the voxels inside it (a 1e-4
+    fraction of a sigmoid(10 x) field at this margin) are reported, not compared."""
     rr = ref_recon
+    err = (out_recon.cpu() - rr).abs().max().item()
     near = (rr - 0.5).abs() <= margin
     mism = (((out_recon.cpu() >= 0.5) != (rr >= 0.5)) & ~near).sum().item()
-    print("%s thresholded occupancy: %d occupied voxels in the oracle, %d voxels within %.0e of the threshold (not compared), %d mismatches outside it"
-          % (what, int((rr >= 0.5).sum()), int(near.sum()), margin, mism))
+    print("%s thresholded occupancy: recon max err %.2e, %d occupied voxels in the oracle, %d voxels within %.0e of the threshold (not compared), "
+          "%d mismatches outside it" % (what, err, int((rr >= 0.5).sum()), int(near.sum()), margin, mism))
+    assert err <= 0.5 * margin, err
     assert mism == 0
-    assert int(near.sum()) <= 1e-5 * rr.numel() + 8          # the margin must not swallow the test
+    assert int(near.sum()) <= 1e-4 * rr.numel() + 8          # the margin must not swallow the test
 
 
 @pytest.mark.parametrize("path", PATHS)
