@@ -1513,7 +1513,17 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int nblk = p.nbz * p.nby * p.nbx;
-    const int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
+    int n = blockIdx.x / nblk, br = blockIdx.x % nblk;
+    if (p.in_map && (nblk & 7) == 0) {
+        // Brick-sparse input (the sparse first layer's output): most bricks of most frames read the SAME weight-only field brick
+        // (262 KB of a 33.5 MB field that no L2 holds).  In frame-major order the 64 frames' reads of one brick position are 1 024
+        // workgroups apart and every frame pulls the field through the fabric again (round 4: 2.15 GB fetched for a 0.33 GB tensor).
+        // Here workgroup ids walk the FRAMES of one brick position first, and a brick position's workgroups all share blockIdx % 8 -
+        // the XCD - so the field brick is fetched into that XCD's L2 once and the other frames hit it there.  Same work per
+        // workgroup, same results.
+        const int g = (int)blockIdx.x, q = g >> 3;
+        n = q % p.N; br = (q / p.N) * 8 + (g & 7);
+    }
     const int bxi = br % p.nbx, byi = (br / p.nbx) % p.nby, bzi = br / (p.nbx * p.nby);
     const int oz0 = bzi << 2, oy0 = byi << 3, ox0 = bxi << 3;
     const int co_base = blockIdx.y * (NT * 32);

@@ -28,6 +28,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define HG_SPLIT 2048.0f
+#define HG_THREADS 512
+#define HG_MAX_ITEMS 16            // (pair, K part) items of a conv: 4 KB of LDS scratch each
 __device__ int g_hg_diag = 0;          // NM355_HG_DIAG: phase ablations (wrong results, timing only); set by nm_launch_hg_core
 // Address spaces, explicitly: behind a (non-inlined) function boundary a pointer is generic, every access a FLAT instruction that
 // counts on both the LDS and the vector-memory counter - the LDS operand reads of a k-step then wait for the weight prefetches of
@@ -57,9 +59,17 @@ __device__ __forceinline__ float hg_lrelu(float v, float slope) { return fmaxf(v
 // columns = output channels (32 per tile), K = (tap, 16-channel chunk); the (row tile, column tile) pairs are dealt to the 4 waves.
 // Weights: [tap][chunk][hi h0 | hi h1 | lo h0 | lo h1][Co_pad] half8 (the pack of nm_launch_pack_conv_weight16), fetched PF k-steps
 // ahead (an L2 round trip is ~10 k-steps of MFMA work for one wave).
-#define HG_PF 12
-__device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp_, int Dout_, const NmHgConv& L, int stride_, int pad_, const float* zeros) {
+#define HG_PF 8
+// Round 5: 512 threads per workgroup (8 waves, two per SIMD - one workgroup per CU either way, and a launch is 64 frames on 256 CUs;
+// 1024 threads leave 128 registers per lane, which this k-loop spills).
+// A conv has only mtiles x ntiles = 2 .. 4 (row tile, column tile) pairs - one or none per wave with four waves - so its K range
+// (tap, 16-channel chunk) is cut into KS = waves / pairs parts: item (pair, part) accumulates its k-steps and parks the 32 x 32 partial
+// tile in LDS (`scratch`, 4 KB per item), the workgroup then sums the KS partials of every output in part order and adds the bias.
+// Two waves per SIMD hide part of each other's operand / weight latency: the weight prefetch is 8 k-steps deep instead of 12 (registers).
+__device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp_, int Dout_, const NmHgConv& L, int stride_, int pad_, const float* zeros,
+                         float* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
+    const int nwaves = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
     // everything that drives the loop structure in SGPRs (the layer record arrives through memory: without this the tap decode
     // and the loop bounds are per-lane VALU arithmetic - measured 4x the MFMA time of a k-step)
     const int sp = __builtin_amdgcn_readfirstlane(sp_), Din = __builtin_amdgcn_readfirstlane(Din_), dp = __builtin_amdgcn_readfirstlane(dp_);
@@ -68,14 +78,19 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
     const int Co_pad = __builtin_amdgcn_readfirstlane(L.Co_pad);
     const int Vout = Dout * Dout * Dout, mtiles = (Vout + 31) >> 5, ntiles = Co_pad >> 5;
     const int nchunk = (Cin + 15) >> 4, nk = (g_hg_diag & 2) ? 1 : ks * ks * ks * nchunk;          // (diagnostic bit 2: one k-step per conv - timing only)
+    const int pairs = mtiles * ntiles;
+    const int KS = max(1, min(min(nwaves / pairs, HG_MAX_ITEMS / pairs), nk));                     // K parts per pair
     glb_half8* w8 = (glb_half8*)L.w16;
     const lds_float* srcl = (const lds_float*)src;
     lds_float* dstl = (lds_float*)dst;
+    lds_float* scr = (lds_float*)scratch;
     const lds_float* zl = (const lds_float*)zeros;
     glb_float* biasg = (glb_float*)L.bias;
     const size_t plane = (size_t)Co_pad;
-    for (int pr = wave; pr < mtiles * ntiles; pr += 4) {
+    for (int it = wave; it < pairs * KS; it += nwaves) {
+        const int pr = it / KS, kp = it % KS;
         const int mt = pr / ntiles, nt = pr % ntiles;
+        const int kbeg = (int)((long long)nk * kp / KS), kend = (int)((long long)nk * (kp + 1) / KS), nkl = kend - kbeg;
         const int m = mt * 32 + l31;
         const bool rowok = m < Vout;
         const int ox = m % Dout, oy = (m / Dout) % Dout, oz = m / (Dout * Dout);
@@ -88,26 +103,26 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
             mz |= ((unsigned)(iz0 + t) < (unsigned)Din) << t; my |= ((unsigned)(iy0 + t) < (unsigned)Din) << t; mx |= ((unsigned)(ix0 + t) < (unsigned)Din) << t;
         }
         if (!rowok) mz = 0;
-        f32x16 acc, accl, accm;            // hi x hi, hi x lo, lo x hi: three independent accumulation chains (one wave per SIMD: a dependent
-#pragma unroll                     // MFMA pair per k-step would wait out the matrix pipe's latency twice)
+        f32x16 acc, accl, accm;            // hi x hi, hi x lo, lo x hi: three independent accumulation chains
+#pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accl[r] = 0.f; accm[r] = 0.f; }
-        glb_half8* wl = w8 + (size_t)h * plane + nt * 32 + l31;            // + k * 4 * plane per k-step (tap-major, chunk-minor)
+        glb_half8* wl = w8 + (size_t)h * plane + nt * 32 + l31 + (size_t)kbeg * 4 * plane;   // + k * 4 * plane per k-step (tap-major, chunk-minor)
         half8 bh[HG_PF], bl[HG_PF];
 #pragma unroll
         for (int u = 0; u < HG_PF; ++u) {
-            const int k = u < nk ? u : nk - 1;
+            const int k = u < nkl ? u : nkl - 1;
             bh[u] = wl[(size_t)k * 4 * plane]; bl[u] = wl[(size_t)k * 4 * plane + 2 * plane];
         }
         // branch-free k-loop (a load or an MFMA under a condition makes hipcc drain every outstanding weight load at the join): the
         // k-steps are padded to a multiple of the prefetch depth; a padding step multiplies zeros by the last step's weights.
-        // (tz, ty, tx, cb) advance as scalar counters - no division per k-step.
-        const int nkp = (nk + HG_PF - 1) / HG_PF * HG_PF;
-        int tz = 0, ty = 0, tx = 0, cb = 0;
-        // the LDS operand of k-step k + 1 is requested before k-step k is split and multiplied (one wave per SIMD: nothing else hides
-        // the LDS latency in front of ~25 dependent VALU instructions)
+        // (tz, ty, tx, cb) advance as scalar counters - one division per item, none per k-step.
+        const int nkp = (nkl + HG_PF - 1) / HG_PF * HG_PF;
+        int cb = kbeg % nchunk, tap0 = kbeg / nchunk;
+        int tx = tap0 % ks, ty = (tap0 / ks) % ks, tz = tap0 / (ks * ks);
+        // the LDS operand of k-step k + 1 is requested before k-step k is split and multiplied
         auto a_addr = [&](int k) -> const lds_float* {
             const int toff = ((tz * Din + ty) * Din + tx) * sp + cb * 16;                     // scalar
-            const bool ok = k < nk && (((mz >> tz) & (my >> ty) & (mx >> tx)) & 1);
+            const bool ok = k < nkl && (((mz >> tz) & (my >> ty) & (mx >> tx)) & 1);
             return ok ? srcl + (off0 + toff) : zl;                                            // (taps outside the volume / padding steps read zeros)
         };
         auto advance = [&]() {
@@ -127,7 +142,7 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
                 half8 ah, al;
                 hg_split8(a, b, ah, al);
                 const half8 wh = bh[u], wlo = bl[u];
-                const int kn = k + HG_PF < nk ? k + HG_PF : nk - 1;            // (the tail re-reads the last k-step)
+                const int kn = k + HG_PF < nkl ? k + HG_PF : nkl - 1;          // (the tail re-reads the last k-step)
                 bh[u] = wl[(size_t)kn * 4 * plane]; bl[u] = wl[(size_t)kn * 4 * plane + 2 * plane];
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
                 accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wlo, accl, 0, 0, 0);
@@ -135,16 +150,23 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
                 a = an; b = bn;
             }
         }
-        // accumulator layout (activations first): lane holds column n = nt*32 + l31, rows (r & 3) + 8 (r >> 2) + 4 h
-        const int n = nt * 32 + l31;
-        const float bv = n < Cout ? biasg[n] : 0.f;
-        if (n < dp) {
+        // accumulator layout (activations first): lane holds column l31 of the tile, rows (r & 3) + 8 (r >> 2) + 4 h: partial tile
+        // [row][32 columns] of item `it`
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < Vout) dstl[row * dp + n] = n < Cout ? (acc[r] + (accl[r] + accm[r]) * (1.0f / HG_SPLIT)) + bv : 0.f;
-            }
+        for (int r = 0; r < 16; ++r) scr[it * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[r] + (accl[r] + accm[r]) * (1.0f / HG_SPLIT);
+    }
+    __syncthreads();
+    // dst[row][n] = sum over the pair's K parts (in part order) + bias; channels Cout .. dp - 1 zeroed
+    for (int i = threadIdx.x; i < Vout * dp; i += blockDim.x) {
+        const int row = i / dp, n = i % dp;
+        float v = 0.f;
+        if (n < Cout) {
+            const int pr = (row >> 5) * ntiles + (n >> 5);
+            v = scr[(pr * KS) * 1024 + (row & 31) * 32 + (n & 31)];
+            for (int q = 1; q < KS; ++q) v += scr[(pr * KS + q) * 1024 + (row & 31) * 32 + (n & 31)];
+            v += biasg[n];
         }
+        dstl[i] = v;
     }
     __syncthreads();
 }
@@ -159,7 +181,7 @@ __device__ void gn_lds(float* buf, int pitch_, int V_, int C_, const NmHgNorm& g
     if (g_hg_diag & 1) return;                                      // (diagnostic bit 1: no GroupNorm - timing only)
     const int cpg = C / groups, tid = threadIdx.x, vlanes = 256 / pitch;
     const int c = tid % pitch, vl = tid / pitch;
-    const bool active = vl < vlanes && c < C;
+    const bool active = tid < 256 && vl < vlanes && c < C;
     const int grp = active ? c / cpg : 0;
     lds_float* bl = (lds_float*)buf;
     const lds_float* al = (const lds_float*)add;
@@ -172,7 +194,7 @@ __device__ void gn_lds(float* buf, int pitch_, int V_, int C_, const NmHgNorm& g
     for (int pass = 0; pass < 2; ++pass) {
         double s = 0.0;
         if (active) for (int v = vl; v < V; v += vlanes) { const double d = (double)bl[v * pitch + c] - mean; s += pass ? d * d : d; }
-        part[tid] = s;
+        if (tid < 256) part[tid] = s;
         __syncthreads();
         if (tid < C) { double t = 0.0; for (int l = 0; l < vlanes; ++l) t += part[l * pitch + tid]; chs[tid] = t; }
         __syncthreads();
@@ -197,21 +219,21 @@ __device__ void gn_lds(float* buf, int pitch_, int V_, int C_, const NmHgNorm& g
 
 // Res3DBlock: out = GN(conv3(lrelu(GN(conv3 x)))) + skip(x), skip = identity or GN(conv1 x); x in `xin`, result left in `t2`
 // (t1 is scratch; xin is preserved)
-__device__ void res_lds(const float* xin, int xp, float* t1, float* t2, int pitch, int D, const NmHgRes& r, double* red, const float* zeros) {
+__device__ void res_lds(const float* xin, int xp, float* t1, float* t2, int pitch, int D, const NmHgRes& r, double* red, const float* zeros, float* scratch) {
     const int V = D * D * D;
-    conv_lds(xin, xp, D, t1, pitch, D, r.c1, 1, 1, zeros);
+    conv_lds(xin, xp, D, t1, pitch, D, r.c1, 1, 1, zeros, scratch);
     gn_lds(t1, pitch, V, r.c1.Cout, r.n1, 0.01f, nullptr, 0, red);
-    conv_lds(t1, pitch, D, t2, pitch, D, r.c2, 1, 1, zeros);
+    conv_lds(t1, pitch, D, t2, pitch, D, r.c2, 1, 1, zeros, scratch);
     if (r.has_skip) {
         gn_lds(t2, pitch, V, r.c2.Cout, r.n2, 1.0f, nullptr, 0, red);
-        conv_lds(xin, xp, D, t1, pitch, D, r.cs, 1, 0, zeros);
+        conv_lds(xin, xp, D, t1, pitch, D, r.cs, 1, 0, zeros, scratch);
         gn_lds(t1, pitch, V, r.cs.Cout, r.ns, 1.0f, t2, pitch, red);        // t1 = GN(cs x) + t2
-        for (int i = threadIdx.x; i < V * pitch; i += 256) t2[i] = t1[i];
+        for (int i = threadIdx.x; i < V * pitch; i += blockDim.x) t2[i] = t1[i];
         __syncthreads();
     } else gn_lds(t2, pitch, V, r.c2.Cout, r.n2, 1.0f, xin, xp, red);      // t2 = GN(c2 ..) + x
 }
 
-__global__ __launch_bounds__(256) void hg_core_kernel(NmHgCoreParams p) {
+__global__ __launch_bounds__(HG_THREADS) void hg_core_kernel(NmHgCoreParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int D2 = p.D2, D3 = p.D3, V2 = D2 * D2 * D2, V3 = D3 * D3 * D3;
@@ -220,13 +242,15 @@ __global__ __launch_bounds__(256) void hg_core_kernel(NmHgCoreParams p) {
     float* C0 = B2 + (size_t)V2 * P2; float* C1 = C0 + (size_t)V3 * P3; float* C2 = C1 + (size_t)V3 * P3;
     double* red = reinterpret_cast<double*>(C2 + (size_t)V3 * P3);      // 360 doubles of reduction scratch behind the tensors (all sizes are multiples of 16 floats)
     const float* zeros = reinterpret_cast<const float*>(red + 360);     // 16 zero floats: what an out-of-volume tap reads
-    for (int i = tid; i < 3 * V2 * P2 + 3 * V3 * P3 + 720 + 16; i += 256) lds[i] = 0.f;   // (padding channels and the zero block must read as zeros)
+    float* scratch = const_cast<float*>(zeros) + 16;                     // HG_MAX_ITEMS partial tiles of conv_lds
+    const int NT = blockDim.x;
+    for (int i = tid; i < 3 * V2 * P2 + 3 * V3 * P3 + 720 + 16; i += NT) lds[i] = 0.f;   // (padding channels and the zero block must read as zeros)
     __syncthreads();
     // a2: the pool conv's raw output with its pending GroupNorm + LeakyReLU, [V2][Cin0]
     {
         const int C = p.Cin0;
         const float* src = p.in + (size_t)n * V2 * C;
-        for (int i = tid; i < V2 * C; i += 256) {
+        for (int i = tid; i < V2 * C; i += NT) {
             const int v = i / C, c = i % C;
             float y = src[i];
             if (p.in_scale) y = fmaf(y, p.in_scale[(size_t)n * C + c], p.in_shift[(size_t)n * C + c]);
@@ -235,16 +259,16 @@ __global__ __launch_bounds__(256) void hg_core_kernel(NmHgCoreParams p) {
         }
         __syncthreads();
     }
-    res_lds(B0, P2, B1, B2, P2, D2, p.e2, red, zeros);                  // e2 -> B2
-    res_lds(B2, P2, B0, B1, P2, D2, p.s3, red, zeros);                  // s3 -> B1   (B0 scratch; a2 is dead)
-    conv_lds(B2, P2, D2, C0, P3, D3, p.p3, 2, 0, zeros);               // pool3(e2) -> C0
+    res_lds(B0, P2, B1, B2, P2, D2, p.e2, red, zeros, scratch);                  // e2 -> B2
+    res_lds(B2, P2, B0, B1, P2, D2, p.s3, red, zeros, scratch);                  // s3 -> B1   (B0 scratch; a2 is dead)
+    conv_lds(B2, P2, D2, C0, P3, D3, p.p3, 2, 0, zeros, scratch);               // pool3(e2) -> C0
     gn_lds(C0, P3, V3, p.p3.Cout, p.np3, 0.01f, nullptr, 0, red);
-    res_lds(C0, P3, C1, C2, P3, D3, p.e3, red, zeros);                  // e3 -> C2
-    res_lds(C2, P3, C0, C1, P3, D3, p.d3, red, zeros);                  // d3 -> C1
+    res_lds(C0, P3, C1, C2, P3, D3, p.e3, red, zeros, scratch);                  // e3 -> C2
+    res_lds(C2, P3, C0, C1, P3, D3, p.d3, red, zeros, scratch);                  // d3 -> C1
     // ConvTranspose3d k2 s2 (+ output_padding): out[2i + a] = sum_ci d3[i][ci] W[a][ci][co] + b; the padding planes hold the bias only
     {
         const int Co = p.u3_Cout, Ci = p.u3_Cin;
-        for (int i = tid; i < V2 * Co; i += 256) {
+        for (int i = tid; i < V2 * Co; i += NT) {
             const int v = i / Co, co = i % Co;
             const int ox = v % D2, oy = (v / D2) % D2, oz = v / (D2 * D2);
             float acc = p.u3_bias[co];
@@ -266,22 +290,23 @@ __global__ __launch_bounds__(256) void hg_core_kernel(NmHgCoreParams p) {
             }
             B0[(size_t)v * P2 + co] = acc;
         }
-        for (int i = tid; i < V2 * (P2 - Co); i += 256) B0[(size_t)(i / (P2 - Co)) * P2 + Co + i % (P2 - Co)] = 0.f;
+        for (int i = tid; i < V2 * (P2 - Co); i += NT) B0[(size_t)(i / (P2 - Co)) * P2 + Co + i % (P2 - Co)] = 0.f;
         __syncthreads();
         gn_lds(B0, P2, V2, Co, p.nu3, 0.01f, B1, P2, red);       // x = lrelu(GN(.)) + s3 -> B0
     }
-    res_lds(B0, P2, B1, B2, P2, D2, p.d2, red, zeros);                  // out -> B2
+    res_lds(B0, P2, B1, B2, P2, D2, p.d2, red, zeros, scratch);                  // out -> B2
     {
         const int C = p.d2.c2.Cout;
         float* dst = p.out + (size_t)n * V2 * C;
-        for (int i = tid; i < V2 * C; i += 256) dst[i] = B2[(size_t)(i / C) * P2 + i % C];
+        for (int i = tid; i < V2 * C; i += NT) dst[i] = B2[(size_t)(i / C) * P2 + i % C];
     }
 }
 
 }  // namespace
 
 size_t nm_hg_core_lds_bytes(const NmHgCoreParams& p) {
-    return ((size_t)3 * p.D2 * p.D2 * p.D2 * p.pitch2 + (size_t)3 * p.D3 * p.D3 * p.D3 * p.pitch3) * sizeof(float) + 360 * sizeof(double) + 16 * sizeof(float);
+    return ((size_t)3 * p.D2 * p.D2 * p.D2 * p.pitch2 + (size_t)3 * p.D3 * p.D3 * p.D3 * p.pitch3) * sizeof(float) + 360 * sizeof(double) + 16 * sizeof(float) +
+           (size_t)HG_MAX_ITEMS * 1024 * sizeof(float);
 }
 
 int nm_launch_hg_core(const NmHgCoreParams& p, hipStream_t s) {
@@ -298,6 +323,6 @@ int nm_launch_hg_core(const NmHgCoreParams& p, hipStream_t s) {
     const int diag = e ? atoi(e) : 0;
     int dev = 0; (void)hipGetDevice(&dev); dev &= 63;
     if (diag + 1 != diag_set[dev]) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hg_diag), &diag, sizeof(int)); diag_set[dev] = diag + 1; }
-    hipLaunchKernelGGL(hg_core_kernel, dim3(p.N), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(hg_core_kernel, dim3(p.N), dim3(HG_THREADS), lds, s, p);
     return nm_check_hip(hipGetLastError(), "hg_core launch");
 }
