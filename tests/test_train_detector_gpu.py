@@ -388,20 +388,32 @@ def test_config3_per_gpu_shape_training_step():
     assert set(log) >= {"loss", *[k for k in DETECTOR_LOSS_WEIGHTS]}
 
 
-def test_vanishing_loss_weights_give_finite_proportional_gradients():
+@pytest.mark.parametrize("mode", [None, "f16", "bf16"])
+def test_vanishing_loss_weights_give_finite_proportional_gradients(mode):
     """Power-of-two operand scaling of the data-gradient convs (nm_grad.hip make_scale): with loss weights of 1e-30 every dy is
     ~1e-30 and the scale 2^k must stay finite in both directions (the exponent is clamped to +-100): gradients finite and
-    proportional to the unscaled ones."""
+    proportional to the unscaled ones.  Also in the one-product modes: there the k2 s2 weight gradients (wgrad16k2) and
+    the transposed convs / pool data gradients (convT2_f16) run on the f16 matrix cores too, and a dY of 1e-30 that reached them
+    unscaled would flush to zero in fp16 - every dY they see must have gone through the same power-of-two scaling ('bf16': storage
+    threshold at 16^3 so that the 32^3 tensors and their gradients are bfloat16)."""
+    import os
     o, sd, vox = _setup(G=32, B=1, T=3, seed=95)
-    _, g1, _ = _hip_grads(o, sd, vox, AIST)
-    tiny = {k: w * 1e-30 for k, w in AIST.items()}
-    _, g2, _ = _hip_grads(o, sd, vox, tiny)
+    if mode == "bf16":
+        os.environ["NM355_STORE16_MIN"] = "4096"
+    try:
+        _, g1, _ = _hip_grads(o, sd, vox, AIST, mode=mode)
+        tiny = {k: w * 1e-30 for k, w in AIST.items()}
+        _, g2, _ = _hip_grads(o, sd, vox, tiny, mode=mode)
+    finally:
+        os.environ.pop("NM355_STORE16_MIN", None)
     gmax = max(v.abs().max().item() for v in g1.values())
+    # (bfloat16 gradient storage rounds g and 1e-30 g independently: 2^-8 relative instead of fp32's 2^-24)
+    tol = 1e-3 if mode != "bf16" else 2e-2
     for k, v in g1.items():
         assert torch.isfinite(g2[k]).all(), k
         scale = max(v.abs().max().item(), 1e-6 * gmax)
         e = (g2[k].double() * 1e30 - v.double()).abs().max().item() / scale
-        assert e < 1e-3, (k, e)
+        assert e < tol, (k, e, mode)
 
 
 def test_trainer_with_frozen_parameters():
