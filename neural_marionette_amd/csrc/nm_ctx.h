@@ -129,6 +129,7 @@ struct nm_ctx {
     struct TrainTape* tape = nullptr;      // what the backward pass needs of the last training forward (nm_net.hip)
     void* vtape = nullptr;                 // VrnnTape of the last nm_vrnn_encode_train (nm_vrnn.hip)
     void* vgraphs = nullptr;               // cache of captured rollout graphs (nm_vrnn.hip)
+    bool in_fused = false;                 // nm_forward_fused is running the VRNN encode on the side stream beside the decoder
     int32_t* vrnn_cnt = nullptr;           // 256 arrival counters of vrnn_post_mid_kernel (zero between launches)
     DetectorW det;
     VrnnW vrnn;

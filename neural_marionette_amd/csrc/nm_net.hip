@@ -1427,7 +1427,9 @@ int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t 
         std::swap(c->ws, c->ws2);
         hipStream_t main = c->stream;
         c->stream = c->stream2;
+        c->in_fused = true;
         r = nm_vrnn_encode(c, keypoints, eps, B, T, S, kypt_recon, R, z, h, scalars2, best_idx);
+        c->in_fused = false;
         c->stream = main;
         std::swap(c->ws, c->ws2);
         if (!r) r = nm_check_hip(hipEventRecord(c->ev_side, c->stream2), "side event");

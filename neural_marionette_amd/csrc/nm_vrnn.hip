@@ -902,6 +902,372 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs 
     }
 }
 
+// ---- the posterior steps of HSVRNNBVH.encode as ONE persistent launch (round 5; BASELINE north_star "one kernel per timestep") --------
+// hsvrnn_bvh.py:86-135.  The step of vrnn_prior_chain_kernel with the posterior's extra stage: S samples per clip are decoded and the
+// one nearest to the detected keypoints is kept.  Roles (512 threads each, one workgroup per CU, all resident):
+//   * NM_CHAIN_NW worker workgroups: wave gw owns h-phase row gw (one of prior0 | post0 | root0_h | joint0_h, 128 rows each; the
+//     post0 rows also take the detected keypoints' 4K columns) and W_hh rows gw + 512 i, and GRU unit j = gw;
+//   * S x B sample workgroups: workgroup (s, b) = vrnn_post_mid_kernel's phases for sample s of clip b (posterior parameters from
+//     hid_post[b], z = mu + eps[t][s][b] sigma, decoder hidden layers, heads, kinematics, squared distance to the observation); it
+//     publishes its keypoints | latent and LAST its distance as granules, then polls the clip's S distances itself: the nearest sample
+//     (lowest index on ties: fk_kernel's scan) writes the step's outputs - keypoints, latent, rotations, index, distance - from its
+//     own LDS, so nothing but the distances crosses workgroups for the selection;
+//   * B statistics workgroups: the prior's and the posterior's parameters of clip b (both second layers register-resident) and the
+//     KL term of the step - off the recurrence's critical path, read by nobody inside the launch.
+// A GRU wave polls the S distance granules of its clip, picks the same sample and reads THAT sample's keypoint | latent granules.
+// Hand-offs, tags, bounded spins and the abort word are vrnn_prior_chain_kernel's; arithmetic per row, the kinematic chain, the
+// distance sum (joint order), the argmin and the KL tree are the launch-per-phase step's: outputs bit-identical to it.
+struct PostChainArgs {
+    const float *w_prior0, *b_prior0, *w_post0, *b_post0, *w_root0, *b_root0, *w_joint0, *b_joint0, *w_hh, *b_hh, *w_ih, *b_ih;
+    const float *w_q2, *b_q2, *w_p2, *b_p2;     // second layers of the posterior / prior MLPs
+    MidArgs mid;                        // decoder weights / tree / offset (its data pointers are not used)
+    const float* h0;                    // [H] init_kypt_rnn_state (every clip starts from it)
+    const float* obs; int ldobs;        // detected keypoints [B][ldobs], step t at column t * 4K
+    const float* eps;                   // [T][S][B][Z]
+    float* out_kp; int ldkp;            // [B][ldkp], step t at column t * 4K
+    float* out_z; int ldz;              // [B][ldz], step t at column t * Z
+    float* out_R; int ldR;              // [B][ldR], step t at column t * 9K (or null)
+    float* out_h; int ldh;              // [B][ldh]: state after step t at column (t + 1) * H (column 0 is written by the caller)
+    int32_t* best; int ldbest;          // [B][ldbest] (or null)
+    float *kl, *rec; int ldstat;        // per (clip, step) sums (kl may be null)
+    nm_gran *g_hidq, *g_hidp, *g_rh, *g_jh;    // [B][128] x 4   h-phase -> sample / statistics workgroups
+    nm_gran* g_gh;                      // [B][3H]        h-phase -> GRU
+    nm_gran* g_kpz;                     // [S][B][4K + Z] sample workgroup -> GRU
+    nm_gran* g_d;                       // [S][B]         sample workgroup -> GRU and the clip's other sample workgroups
+    nm_gran* g_h[2];                    // [B][H] x 2     GRU of step t -> h-phase / GRU of step t + 1 (buffer t & 1)
+    unsigned* abort; unsigned* status;
+    int B, S, T, K, Z, H;
+    int nstat;                          // statistics workgroups: B (encode: KL) or 0 (the conditioning steps of generate)
+    int backoff, spin_limit;
+};
+
+__device__ __forceinline__ void gran_ld_1(const nm_gran* p, nm_f32x2& v) {
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+}
+
+__global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainArgs a) {
+    __shared__ int s_dead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = a.B, S = a.S, T = a.T, K = a.K, Z = a.Z, H = a.H, S4 = 4 * K;
+    bool wave_alive = true;
+    if (tid == 0) s_dead = 0;
+    const int role = (int)blockIdx.x - NM_CHAIN_NW;        // < 0 worker, [0, B) statistics workgroup of clip b, then S B sample workgroups s * B + b
+    const int nstat = a.nstat;
+    if (role >= 0 && role < nstat) {
+        // =========================== statistics workgroup of clip b: prior / posterior parameters, KL ===========================
+        const int half = lane >> 5, l32 = lane & 31, b = role;
+        __shared__ float s_red[256];
+        f32x4 wq[NM_CHAIN_PAIRS], wp[NM_CHAIN_PAIRS];
+#pragma unroll
+        for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+            const int p = wave * NM_CHAIN_PAIRS + u;
+            wq[u] = *reinterpret_cast<const f32x4*>(a.w_q2 + (size_t)(p + half * Z) * 128 + l32 * 4);
+            wp[u] = *reinterpret_cast<const f32x4*>(a.w_p2 + (size_t)(p + half * Z) * 128 + l32 * 4);
+        }
+        const int pl = wave * NM_CHAIN_PAIRS + (l32 < NM_CHAIN_PAIRS ? l32 : 0);
+        const float bq = a.b_q2[pl], bq2 = a.b_q2[pl + Z], bp = a.b_p2[pl], bp2 = a.b_p2[pl + Z];
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const unsigned tag = (unsigned)t + 1u;
+            f32x4 q0, q1, p0, p1; nm_f32x2 dummy;
+            const nm_gran* pq = a.g_hidq + (size_t)b * 128 + l32 * 4;
+            const nm_gran* pp = a.g_hidp + (size_t)b * 128 + l32 * 4;
+            NM_CHAIN_POLL(gran_ld_4q1(pq, pq + 2, pp, pp + 2, pq, q0, q1, p0, p1, dummy),
+                          nm_fbits(q0[1]) == tag && nm_fbits(q0[3]) == tag && nm_fbits(q1[1]) == tag && nm_fbits(q1[3]) == tag &&
+                          nm_fbits(p0[1]) == tag && nm_fbits(p0[3]) == tag && nm_fbits(p1[1]) == tag && nm_fbits(p1[3]) == tag);
+            if (!wave_alive) s_dead = 1;
+            const f32x4 xq = {q0[0], q0[2], q1[0], q1[2]}, xp = {p0[0], p0[2], p1[0], p1[2]};
+            float qm = 0.f, qs = 0.f, pm = 0.f, ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+                const float vq = half_reduce(dot4(wq[u], xq)), oq = __shfl_xor(vq, 32);
+                const float vp = half_reduce(dot4(wp[u], xp)), op = __shfl_xor(vp, 32);
+                if (l32 == u) { qm = vq; qs = oq; pm = vp; ps = op; }
+            }
+            if (tid < 256) s_red[tid] = 0.f;
+            __syncthreads();
+            if (s_dead) return;
+            if (!half && l32 < NM_CHAIN_PAIRS) {
+                const int p = wave * NM_CHAIN_PAIRS + l32;
+                const float qmu = qm + bq, qsg = softplus(qs + bq2) + 1e-4f, pmu = pm + bp, psg = softplus(ps + bp2) + 1e-4f;
+                const float ratio = qsg / psg, vr = ratio * ratio, dm = (qmu - pmu) / psg;
+                s_red[p] = 0.f + 0.5f * (((vr + dm * dm) - 1.0f) - logf(vr));
+            }
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) { if (tid < st) s_red[tid] += s_red[tid + st]; __syncthreads(); }
+            if (tid == 0 && a.kl) a.kl[(size_t)b * a.ldstat + t] = s_red[0];
+            __syncthreads();
+        }
+        return;
+    }
+    if (role >= 0) {
+        // =========================== sample workgroup (s, b) =====================================================================
+        const MidArgs& m = a.mid;
+        __shared__ __attribute__((aligned(16))) float s_z[128], s_hr[128], s_hj[128], s_root[36], s_rot[192];
+        __shared__ float s_Rl[32 * 9], s_Rg[32 * 9], s_pos[32 * 3], s_dk[32];
+        __shared__ int s_win;
+        __shared__ FkTables tb;
+        const int half = lane >> 5, l32 = lane & 31, smp = (role - nstat) / B, b = (role - nstat) % B;
+        const int R0 = 3 + K, J6 = 6 * K, rows_c = R0 + J6;
+        extern __shared__ f32x4 s_wc[];                                  // [rows_c][32 quads]
+        f32x4 wa[NM_CHAIN_PAIRS], wb[NM_CHAIN_PAIRS];
+#pragma unroll
+        for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+            const int p = wave * NM_CHAIN_PAIRS + u;
+            wa[u] = *reinterpret_cast<const f32x4*>(a.w_q2 + (size_t)(p + half * Z) * 128 + l32 * 4);
+            wb[u] = *reinterpret_cast<const f32x4*>((half ? m.w_joint0 : m.w_root0) + (size_t)p * (H + Z) + H + l32 * 4);
+            const int r = min(p * 2 + half, rows_c - 1);
+            const float* pc = r < R0 ? m.w_root2 + (size_t)r * 128 : m.w_joint2 + (size_t)(r - R0) * 128;
+            if (p * 2 + half < rows_c) s_wc[(p * 2 + half) * 32 + l32] = *reinterpret_cast<const f32x4*>(pc + l32 * 4);
+        }
+        const int pl = wave * NM_CHAIN_PAIRS + (l32 < NM_CHAIN_PAIRS ? l32 : 0);
+        const float bias_a = a.b_q2[pl], bias_a2 = a.b_q2[pl + Z];
+        const int rl = min(pl * 2 + half, rows_c - 1);
+        const float bias_c = *(rl < R0 ? m.b_root2 + rl : m.b_joint2 + (rl - R0));
+        fk_tables_load(tb, m.lvl_joint, m.lvl_start, m.parents, m.offset + (size_t)b * K * 3, K, m.nlevels, tid);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const unsigned tag = (unsigned)t + 1u;
+            const float epsv = a.eps[(((size_t)t * S + smp) * B + b) * Z + pl];             // (inputs of the call: plain loads)
+            const float obsv = a.obs[(size_t)b * a.ldobs + (size_t)t * S4 + min(tid, S4 - 1)];
+            f32x4 g0, g1; nm_f32x2 ga;
+            const nm_gran* ph = a.g_hidq + (size_t)b * 128 + l32 * 4;
+            const nm_gran* pa = (half ? a.g_jh : a.g_rh) + (size_t)b * 128 + pl;
+            NM_CHAIN_POLL(gran_ld_2q1(ph, ph + 2, pa, g0, g1, ga),
+                          nm_fbits(g0[1]) == tag && nm_fbits(g0[3]) == tag && nm_fbits(g1[1]) == tag && nm_fbits(g1[3]) == tag && nm_fbits(ga[1]) == tag);
+            if (!wave_alive) s_dead = 1;
+            const f32x4 xh = {g0[0], g0[2], g1[0], g1[2]};
+            const float add_b = ga[0];
+            // ---- A: posterior parameters and this workgroup's sample ----
+            {
+                float mine = 0.f, other = 0.f;
+#pragma unroll
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+                    const float v = half_reduce(dot4(wa[u], xh));
+                    const float o = __shfl_xor(v, 32);
+                    if (l32 == u) { mine = v; other = o; }
+                }
+                if (!half && l32 < NM_CHAIN_PAIRS) {
+                    const int p = wave * NM_CHAIN_PAIRS + l32;
+                    const float mu = mine + bias_a, sraw = other + bias_a2;
+                    const float sg = softplus(sraw) + 1e-4f;
+                    const float z = mu + epsv * sg;
+                    s_z[p] = z;
+                    gran_store(a.g_kpz + ((size_t)smp * B + b) * (S4 + Z) + S4 + p, z, tag);
+                }
+            }
+            __syncthreads();
+            if (s_dead) return;                                          // (uniform: read behind the barrier)
+            // ---- B ----
+            {
+                const f32x4 xz = *reinterpret_cast<const f32x4*>(s_z + l32 * 4);
+                float mine = 0.f;
+#pragma unroll
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+                    const float v = half_reduce(dot4(wb[u], xz));
+                    if (l32 == u) mine = v;
+                }
+                if (l32 < NM_CHAIN_PAIRS) (half ? s_hj : s_hr)[wave * NM_CHAIN_PAIRS + l32] = lrelu(mine + add_b, 0.01f);
+            }
+            __syncthreads();
+            // ---- C ----
+            {
+                const f32x4 xr = *reinterpret_cast<const f32x4*>(s_hr + l32 * 4);
+                const f32x4 xj = *reinterpret_cast<const f32x4*>(s_hj + l32 * 4);
+                float mine = 0.f;
+#pragma unroll
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
+                    const int r = (wave * NM_CHAIN_PAIRS + u) * 2 + half;
+                    const f32x4 wq = s_wc[min(r, rows_c - 1) * 32 + l32];
+                    const float v = half_reduce(dot4(wq, r < R0 ? xr : xj));
+                    if (l32 == u) mine = v;
+                }
+                if (l32 < NM_CHAIN_PAIRS) {
+                    const int r = (wave * NM_CHAIN_PAIRS + l32) * 2 + half;
+                    if (r < R0) s_root[r] = tanhf(mine + bias_c);
+                    else if (r < rows_c) s_rot[r - R0] = mine + bias_c;
+                }
+            }
+            __syncthreads();
+            // ---- D: forward kinematics ----
+            if (tid < K) {
+                const float* p = s_rot + tid * 6;
+                float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
+                float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
+                x0 /= nx; x1 /= nx; x2 /= nx;
+                float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+                float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
+                z0 /= nz; z1 /= nz; z2 /= nz;
+                float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
+                float* R = s_Rl + tid * 9;
+                R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
+            }
+            __syncthreads();
+            fk_levels(tb, m.nlevels, s_Rl, s_Rg, s_pos, s_root, 36, K, 1, 0, 0, tid, NM_CHAIN_T);
+            // ---- E: keypoints, distance to the observation (per-joint terms, summed in joint order) ----
+            float kpv = 0.f;
+            if (tid < S4) {
+                const int k = tid >> 2, c = tid & 3;
+                kpv = c < 3 ? s_pos[k * 3 + c] : (s_root[3 + k] + 1.0f) * 0.5f;
+                gran_store(a.g_kpz + ((size_t)smp * B + b) * (S4 + Z) + tid, kpv, tag);
+            }
+            {
+                const float u = obsv - kpv, q = u * u;
+                const float q1 = __shfl_down(q, 1), q2 = __shfl_down(q, 2), q3 = __shfl_down(q, 3);
+                if (tid < S4 && (tid & 3) == 0) s_dk[tid >> 2] = ((q + q1) + q2) + q3;
+            }
+            __syncthreads();
+            // ---- F: publish the distance (last), then find the clip's nearest sample; the winner writes the step's outputs ----
+            if (wave == 0) {
+                float d = 0.f;
+                if (lane == 0) {
+                    for (int k = 0; k < K; ++k) d += s_dk[k];
+                    gran_store(a.g_d + (size_t)smp * B + b, d, tag);
+                }
+                nm_f32x2 gd;
+                const nm_gran* pd = a.g_d + (size_t)min(lane, S - 1) * B + b;
+                NM_CHAIN_POLL(gran_ld_1(pd, gd), nm_fbits(gd[1]) == tag);
+                // first minimum in sample order (fk_kernel's scan): butterfly over (distance, index), the lower index wins a tie
+                float bd = lane < S ? gd[0] : INFINITY; int bi = lane < S ? lane : 1 << 20;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(bd, off); const int oi = __shfl_xor(bi, off);
+                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                }
+                if (lane == 0) {
+                    s_win = (wave_alive && bi == smp) ? 1 : 0;
+                    if (!wave_alive) s_dead = 1;
+                    if (s_win) {
+                        if (a.best) a.best[(size_t)b * a.ldbest + t] = bi;
+                        if (a.rec) a.rec[(size_t)b * a.ldstat + t] = bd;
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_dead) return;
+            if (s_win) {
+                if (tid < S4) a.out_kp[(size_t)b * a.ldkp + (size_t)t * S4 + tid] = kpv;
+                if (tid < Z) a.out_z[(size_t)b * a.ldz + (size_t)t * Z + tid] = s_z[tid];
+                if (a.out_R && tid < K * 9) a.out_R[(size_t)b * a.ldR + (size_t)t * K * 9 + tid] = s_Rg[tid];
+            }
+            __syncthreads();                                             // (the LDS state of this step is dead)
+        }
+        return;
+    }
+    // =============================== worker workgroup (waves are independent: no workgroup barrier below) ==========================
+    const int gw = (int)blockIdx.x * (NM_CHAIN_T / 64) + wave;       // global wave index, 0 .. 511
+    constexpr int NWV = NM_CHAIN_NW * (NM_CHAIN_T / 64);
+    constexpr int HR = 4;
+    // ---- h-phase rows: i = 0: row gw of [prior0 | post0 | root0_h | joint0_h] (128 each); i = 1 .. 3: W_hh rows gw + 512 (i - 1)
+    f32x4 wh[HR][2]; float bh[HR];
+    f32x4 wobs = {0.f, 0.f, 0.f, 0.f};                               // post0 rows: the detected keypoints' columns H .. H + 4K
+    const int sect = gw >> 7, rsec = gw & 127;                       // section of row gw and its row inside the section
+    const bool oq = sect == 1 && lane * 4 < S4;
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+        const float* wr; const float* br;
+        if (i == 0) {
+            if (sect == 0) { wr = a.w_prior0 + (size_t)rsec * H; br = a.b_prior0 + rsec; }
+            else if (sect == 1) { wr = a.w_post0 + (size_t)rsec * (H + S4); br = a.b_post0 + rsec; }
+            else if (sect == 2) { wr = a.w_root0 + (size_t)rsec * (H + Z); br = a.b_root0 + rsec; }
+            else { wr = a.w_joint0 + (size_t)rsec * (H + Z); br = a.b_joint0 + rsec; }
+        } else { const int r = gw + NWV * (i - 1); wr = a.w_hh + (size_t)r * H; br = a.b_hh + r; }
+        wh[i][0] = *reinterpret_cast<const f32x4*>(wr + lane * 4);
+        wh[i][1] = *reinterpret_cast<const f32x4*>(wr + 256 + lane * 4);
+        bh[i] = *br;
+        if (i == 0 && sect == 1) wobs = *reinterpret_cast<const f32x4*>(wr + H + (oq ? lane * 4 : 0));
+    }
+    const int in = S4 + Z, j = gw, jc = min(j, H - 1);
+    f32x4 wk[3], wz[3]; float bi3[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float* w = a.w_ih + (size_t)(g * H + jc) * in;
+        wk[g] = *reinterpret_cast<const f32x4*>(w + (lane * 4 < S4 ? lane * 4 : 0));
+        wz[g] = *reinterpret_cast<const f32x4*>(w + S4 + (lane * 4 < Z ? lane * 4 : 0));
+        bi3[g] = a.b_ih[g * H + jc];
+    }
+    const bool kq = lane * 4 < S4, zq = lane * 4 < Z;
+    for (int t = 0; t < T && wave_alive; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+#pragma unroll 1
+        for (int b = 0; b < B && wave_alive; ++b) {
+            f32x4 x0, x1;
+            if (t == 0) {
+                x0 = *reinterpret_cast<const f32x4*>(a.h0 + lane * 4);
+                x1 = *reinterpret_cast<const f32x4*>(a.h0 + 256 + lane * 4);
+            } else {
+                const nm_gran* ph = a.g_h[(t - 1) & 1] + (size_t)b * H;
+                f32x4 q0, q1, q2, q3; nm_f32x2 qj;
+                NM_CHAIN_POLL(gran_ld_4q1(ph + lane * 4, ph + lane * 4 + 2, ph + 256 + lane * 4, ph + 256 + lane * 4 + 2, ph + jc, q0, q1, q2, q3, qj),
+                              nm_fbits(q0[1]) == (unsigned)t && nm_fbits(q0[3]) == (unsigned)t && nm_fbits(q1[1]) == (unsigned)t && nm_fbits(q1[3]) == (unsigned)t &&
+                              nm_fbits(q2[1]) == (unsigned)t && nm_fbits(q2[3]) == (unsigned)t && nm_fbits(q3[1]) == (unsigned)t && nm_fbits(q3[3]) == (unsigned)t);
+                x0 = f32x4{q0[0], q0[2], q1[0], q1[2]}; x1 = f32x4{q2[0], q2[2], q3[0], q3[2]};
+            }
+            if (!wave_alive) break;
+            f32x4 xo = {0.f, 0.f, 0.f, 0.f};
+            if (oq) xo = *reinterpret_cast<const f32x4*>(a.obs + (size_t)b * a.ldobs + (size_t)t * S4 + lane * 4);
+#pragma unroll
+            for (int i = 0; i < HR; ++i) {
+                float acc = 0.f;
+                acc += dot4(wh[i][0], x0);
+                acc += dot4(wh[i][1], x1);
+                if (i == 0 && oq) acc += dot4(wobs, xo);             // (dot_seg's second segment: the lanes that hold a keypoint quad)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+                if (lane == 0) {
+                    const float v = acc + bh[i];
+                    if (i == 0) {
+                        if (sect == 0) gran_store(a.g_hidp + (size_t)b * 128 + rsec, lrelu(v, 0.01f), tag);
+                        else if (sect == 1) gran_store(a.g_hidq + (size_t)b * 128 + rsec, lrelu(v, 0.01f), tag);
+                        else if (sect == 2) gran_store(a.g_rh + (size_t)b * 128 + rsec, v, tag);
+                        else gran_store(a.g_jh + (size_t)b * 128 + rsec, v, tag);
+                    } else gran_store(a.g_gh + (size_t)b * 3 * H + gw + NWV * (i - 1), v, tag);
+                }
+            }
+        }
+        // ---- GRU unit j of step t: the nearest sample's keypoints | latent, W_hh h + b_hh of three h-phase rows
+#pragma unroll 1
+        for (int b = 0; b < B && wave_alive && j < H; ++b) {
+            nm_f32x2 gd;
+            const nm_gran* pd = a.g_d + (size_t)min(lane, S - 1) * B + b;
+            NM_CHAIN_POLL(gran_ld_1(pd, gd), nm_fbits(gd[1]) == tag);
+            if (!wave_alive) break;
+            float bd = lane < S ? gd[0] : INFINITY; int bi = lane < S ? lane : 1 << 20;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float od = __shfl_xor(bd, off); const int oi = __shfl_xor(bi, off);
+                if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+            }
+            bi = __builtin_amdgcn_readfirstlane(bi);                       // (wave-uniform also when a NaN distance broke the order)
+            const nm_gran* pk = a.g_kpz + ((size_t)bi * B + b) * (S4 + Z);
+            const nm_gran* pg = a.g_gh + (size_t)b * 3 * H;
+            const nm_gran* pp = t == 0 ? pg + jc : a.g_h[(t - 1) & 1] + (size_t)b * H + jc;
+            f32x4 k0, k1, z0, z1; nm_f32x2 gr, gz, gn, gp;
+            NM_CHAIN_POLL(gran_ld_4q4(pk + (kq ? lane * 4 : 0), pk + (kq ? lane * 4 : 0) + 2, pk + S4 + (zq ? lane * 4 : 0), pk + S4 + (zq ? lane * 4 : 0) + 2,
+                                      pg + jc, pg + H + jc, pg + 2 * H + jc, pp, k0, k1, z0, z1, gr, gz, gn, gp),
+                          nm_fbits(k0[1]) == tag && nm_fbits(k0[3]) == tag && nm_fbits(k1[1]) == tag && nm_fbits(k1[3]) == tag &&
+                          nm_fbits(z0[1]) == tag && nm_fbits(z0[3]) == tag && nm_fbits(z1[1]) == tag && nm_fbits(z1[3]) == tag &&
+                          nm_fbits(gr[1]) == tag && nm_fbits(gz[1]) == tag && nm_fbits(gn[1]) == tag && (t == 0 || nm_fbits(gp[1]) == (unsigned)t));
+            if (!wave_alive) break;
+            const float hpv = t == 0 ? a.h0[jc] : gp[0];
+            const f32x4 xkq = {k0[0], k0[2], k1[0], k1[2]}, xzq = {z0[0], z0[2], z1[0], z1[2]};
+            float ar = 0.f, az = 0.f, an = 0.f;
+            if (kq) { ar += dot4(wk[0], xkq); az += dot4(wk[1], xkq); an += dot4(wk[2], xkq); }
+            if (zq) { ar += dot4(wz[0], xzq); az += dot4(wz[1], xzq); an += dot4(wz[2], xzq); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { ar += __shfl_xor(ar, off); az += __shfl_xor(az, off); an += __shfl_xor(an, off); }
+            if (lane == 0) {
+                const float rg = sigmoidf((ar + bi3[0]) + gr[0]);
+                const float zg = sigmoidf((az + bi3[1]) + gz[0]);
+                const float ng = tanhf((an + bi3[2]) + rg * gn[0]);
+                const float hn = (hpv - ng) * zg + ng;
+                gran_store(a.g_h[t & 1] + (size_t)b * H + j, hn, tag);
+                a.out_h[(size_t)b * a.ldh + (size_t)(t + 1) * H + j] = hn;
+            }
+        }
+    }
+}
+
 // ---- posterior step of encode (inference), middle phases: one workgroup per (sample, batch element) ---------------------------------
 // NOT the default (NM355_VRNN_POSTMID=1 selects it; parity-tested): measured against the six-launch step once the row kernels had
 // been fixed (pick_nb), it loses - encode alone 52.6 us per timestep against 40.7, and in the forward +0.4 ms: a 1024-thread,
@@ -1659,6 +2025,71 @@ int nm_vrnn_offsets(nm_ctx* c, const float* keypoints, int32_t B, int32_t T, flo
     return nm_check_hip(hipGetLastError(), "offsets launch");
 }
 
+// ---- host side of vrnn_post_chain_kernel ----------------------------------------------------------------------------------------------
+static size_t post_chain_gran_floats(int B, int S, int K, int Z, int H) {
+    const size_t nd = ((size_t)S * B + 1) & ~(size_t)1;
+    return 2 * ((size_t)B * (4 * 128 + 5 * H) + (size_t)S * B * (4 * K + Z) + nd) + 64;
+}
+// Can the chain run: shape limits, and EVERY workgroup resident at once - the kernel's workgroups spin on each other and an ordinary launch
+// does not promise co-residency: workgroups of this shape (512 threads at up to 256 registers, the heads' weights in dynamic LDS) per
+// CU x the device's CUs must cover the NM_CHAIN_NW workers + S B sample + nstat statistics workgroups (asked once per context).
+static bool post_chain_fits(nm_ctx* c, int B, int S, int nstat, int& rc) {
+    const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden;
+    rc = NM_OK;
+    if (!(nm_ls().vrnn_chain && S >= 1 && S <= 16 && (size_t)S * B <= 96 && B <= 16 && K >= 2 && K <= 32 && Z == 128 && H == 512 && c->nf_flag)) return false;
+    if (nm_ls().post_chain_fits < 0) {
+        static NmDeviceOnce attr_set;
+        if (!attr_set.done()) {
+            if ((rc = nm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_post_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(vrnn_post_chain)"))) return false;
+            attr_set.mark();
+        }
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&vrnn_post_chain_kernel), NM_CHAIN_T, (size_t)(3 + 7 * 32) * 128 * sizeof(float)) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        nm_ls().post_chain_fits = per_cu * cus;         // resident workgroups the device can hold
+    }
+    return nm_ls().post_chain_fits >= NM_CHAIN_NW + S * B + nstat;
+}
+// T posterior steps from init_kypt_rnn_state: obs [B][ldobs] (step t at column t * 4K), eps [T][S][B][Z]; out_h [B][ldh] receives the
+// state after step t at column (t + 1) * H.  out_R / best / kl / rec may be null (kl null: no statistics workgroups).  `gran`:
+// post_chain_gran_floats() floats of scratch (zeroed here, on the stream).
+static int launch_post_chain(nm_ctx* c, const float* obs, int ldobs, const float* eps, const float* offset, int B, int T, int S,
+                             float* out_kp, int ldkp, float* out_z, int ldz, float* out_R, int ldR, float* out_h, int ldh,
+                             int32_t* best, int ldbest, float* kl, float* rec, int ldstat, float* gran) {
+    const VrnnW& w = c->vrnn;
+    const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4;
+    const size_t nd = ((size_t)S * B + 1) & ~(size_t)1;              // (an even count: the arrays behind it are read in 16-byte granule pairs)
+    const size_t ngran = (size_t)B * (4 * 128 + 3 * H + 2 * H) + (size_t)S * B * (S4 + Z) + nd;
+    nm_gran* gb = reinterpret_cast<nm_gran*>(gran);
+    PostChainArgs a;
+    a.w_prior0 = w.prior0.w; a.b_prior0 = w.prior0.b; a.w_post0 = w.post0.w; a.b_post0 = w.post0.b;
+    a.w_root0 = w.root0.w; a.b_root0 = w.root0.b; a.w_joint0 = w.joint0.w; a.b_joint0 = w.joint0.b;
+    a.w_hh = w.w_hh; a.b_hh = w.b_hh; a.w_ih = w.w_ih; a.b_ih = w.b_ih;
+    a.w_q2 = w.post2.w; a.b_q2 = w.post2.b; a.w_p2 = w.prior2.w; a.b_p2 = w.prior2.b;
+    MidArgs& m = a.mid;
+    m.hid_prior = m.rh = m.jh = m.eps = nullptr; m.offset = offset;
+    m.w_p2 = w.prior2.w; m.b_p2 = w.prior2.b; m.w_root0 = w.root0.w; m.w_joint0 = w.joint0.w;
+    m.w_root2 = w.root2.w; m.b_root2 = w.root2.b; m.w_joint2 = w.joint2.w; m.b_joint2 = w.joint2.b;
+    m.order = w.order; m.parents = w.parents; m.lvl_joint = w.lvl_joint; m.lvl_start = w.lvl_start; m.nlevels = w.nlevels;
+    m.out_kp = nullptr; m.ldkp = 0; m.out_z = nullptr; m.ldz = 0; m.B = B; m.K = K; m.Z = Z; m.H = H;
+    a.h0 = w.h0; a.obs = obs; a.ldobs = ldobs; a.eps = eps;
+    a.out_kp = out_kp; a.ldkp = ldkp; a.out_z = out_z; a.ldz = ldz; a.out_R = out_R; a.ldR = ldR;
+    a.out_h = out_h; a.ldh = ldh; a.best = best; a.ldbest = ldbest; a.kl = kl; a.rec = rec; a.ldstat = ldstat;
+    a.g_hidq = gb; a.g_hidp = gb + (size_t)B * 128; a.g_rh = gb + (size_t)2 * B * 128; a.g_jh = gb + (size_t)3 * B * 128;
+    a.g_gh = gb + (size_t)4 * B * 128; a.g_kpz = a.g_gh + (size_t)B * 3 * H; a.g_d = a.g_kpz + (size_t)S * B * (S4 + Z);
+    a.g_h[0] = a.g_d + nd; a.g_h[1] = a.g_h[0] + (size_t)B * H;
+    a.abort = reinterpret_cast<unsigned*>(a.g_h[1] + (size_t)B * H);
+    a.status = c->nf_flag;
+    a.B = B; a.S = S; a.T = T; a.K = K; a.Z = Z; a.H = H; a.nstat = kl ? B : 0;
+    { static const int bo = getenv("NM355_CHAIN_BACKOFF") ? atoi(getenv("NM355_CHAIN_BACKOFF")) : 0; a.backoff = bo; }
+    a.spin_limit = nm_ls().chain_spin > 0 ? nm_ls().chain_spin : NM_CHAIN_SPIN;
+    int rc;
+    if ((rc = nm_check_hip(hipMemsetAsync(gb, 0, ngran * sizeof(nm_gran) + 64, c->stream), "vrnn post chain: granule buffers"))) return rc;
+    const int drop = std::min(std::max(nm_ls().chain_drop, 0), B);          // (NM355_CHAIN_DROP_WG, test hook: see rollout_steps)
+    hipLaunchKernelGGL(vrnn_post_chain_kernel, dim3(NM_CHAIN_NW + a.nstat + S * B - drop), dim3(NM_CHAIN_T), (size_t)(3 + 7 * K) * 128 * sizeof(float), c->stream, a);
+    return nm_check_hip(hipGetLastError(), "vrnn_post_chain launch");
+}
+
 static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
                        float* R, float* z, float* h, float* scalars2, int32_t* best_idx, bool train) {
     int rc = ready(c, "vrnn_encode", true);
@@ -1668,7 +2099,8 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
     }
     if ((rc = max_fk_lds(c, S))) return rc;
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4;
-    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z + K * 3 + 2 * T) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K + 9 * K + 1)) * sizeof(float) + 64 * 256;
+    size_t need = ((size_t)B * (4 * 128 + 6 * H + 4 * Z + K * 3 + 2 * T) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K + 9 * K + 1)) * sizeof(float) + 64 * 256 +
+                  ((size_t)B * (4 * 128 + 5 * H) + (size_t)S * B * (S4 + Z + 1)) * sizeof(nm_gran) + 4096;          // (+ the posterior chain's granule buffers)
     if ((rc = nm_ctx_reserve(c, need))) return rc;
     c->ws.release(0);
     StepBufs sb = alloc_step(c->ws, B, S, K, Z, H);
@@ -1679,7 +2111,21 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
     if (train) { tpp->valid = false; if ((rc = tape_reserve(*tpp, B, T, S, K, Z, H, c->stream))) return rc; }
     if ((rc = nm_vrnn_offsets(c, keypoints, B, T, offset))) return rc;
     hipLaunchKernelGGL(broadcast_rows_kernel, dim3((H * B + 255) / 256), dim3(256), 0, c->stream, c->vrnn.h0, H, h, (T + 1) * H, B);
-    for (int t = 0; t < T; ++t) {
+    // The T posterior steps as ONE persistent launch (vrnn_post_chain_kernel) when the shape allows and every workgroup of it can be
+    // resident.  Stand-alone encode only (NM355_VRNN_POST_CHAIN: 0 off, 1 default, 2 also inside nm_forward_fused): beside the decoder's
+    // one-workgroup-per-CU persistent convolutions the chain's ~100 spinning workgroups take their CUs for the whole encode, where the
+    // launch-per-phase steps run in the gaps for free (A/B: profiles/r05_encode_ab.txt: +0.17 ms per forward step).  The training forward
+    // keeps the launches (it fills the tape).
+    const int pc = nm_ls().vrnn_post_chain;
+    bool chain = !train && pc && (pc >= 2 || !c->in_fused) && post_chain_fits(c, B, S, B, rc);
+    if (rc) return rc;
+    if (chain) {
+        float* gran = c->ws.f(post_chain_gran_floats(B, S, K, Z, H));
+        if (c->ws.overflow) { nm_set_error("vrnn_encode: workspace overflow"); return NM_ERR_STATE; }
+        if ((rc = launch_post_chain(c, keypoints, T * S4, eps, offset, B, T, S, kypt_recon, T * S4, z, T * Z, R, T * K * 9, h, (T + 1) * H, best_idx, T,
+                                    kl, rec, T, gran))) return rc;
+    }
+    for (int t = 0; t < (chain ? 0 : T); ++t) {
         StepIO io;
         io.h = h + (size_t)t * H; io.ldh = (T + 1) * H;
         io.obs = keypoints + (size_t)t * S4; io.ldobs = T * S4;
@@ -1898,6 +2344,7 @@ int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grad
 struct RolloutBufs {
     StepBufs sb;
     float *kp_cond, *eps_post, *eps_prior, *out_cond, *out_gen, *h_in, *offset, *hbuf[2], *zbuf, *chain_g;         // chain_g: the persistent rollout kernel's granule buffers (+ its abort word)
+    float *pc_z = nullptr, *pc_h = nullptr, *pc_g = nullptr;     // posterior chain of the conditioning steps: latents [B][Tcond Z], states [B][(Tcond + 1) H], granules
 };
 struct RolloutGraph {
     int kind, B, Tcond, Ttot, S;
@@ -1928,7 +2375,8 @@ static size_t rollout_floats(int B, int Tcond, int Ttot, int S, int K, int Z, in
     const size_t S4 = (size_t)K * 4, Tg = Ttot - Tcond;
     return (size_t)B * (4 * 128 + 3 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K + 9 * K + 1) + (B >= NM_GEMM_MIN_BATCH ? (size_t)B * 3 * H : 0)
          + (size_t)B * Tcond * S4 * 2 + (size_t)Tcond * S * B * Z + Tg * B * Z + (size_t)B * Tg * S4 + (size_t)B * K * 3 + 3 * (size_t)B * H + (size_t)B * Z
-         + 2 * (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) + 64 + 64 * 33;          // (256-byte alignment of each of the ~29 pieces)
+         + 2 * (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) + 64 + 64 * 36          // (256-byte alignment of each of the ~32 pieces)
+         + (size_t)B * Tcond * Z + (size_t)B * (Tcond + 1) * H + post_chain_gran_floats(B, S, K, Z, H);
 }
 static RolloutBufs carve_rollout(Arena& ws, int B, int Tcond, int Ttot, int S, int K, int Z, int H) {
     RolloutBufs r;
@@ -1939,6 +2387,7 @@ static RolloutBufs carve_rollout(Arena& ws, int B, int Tcond, int Ttot, int S, i
     r.h_in = ws.f((size_t)B * H); r.offset = ws.f((size_t)B * K * 3);
     r.hbuf[0] = ws.f((size_t)B * H); r.hbuf[1] = ws.f((size_t)B * H); r.zbuf = ws.f((size_t)B * Z);
     r.chain_g = ws.f(2 * (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) + 64);
+    r.pc_z = ws.f((size_t)B * Tcond * Z + 1); r.pc_h = ws.f((size_t)B * (Tcond + 1) * H); r.pc_g = ws.f(post_chain_gran_floats(B, S, K, Z, H));
     return r;
 }
 
@@ -1958,6 +2407,19 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
     // chain, three counter hand-offs per step instead of three launches (NM355_VRNN_CHAIN=0: the launch-per-phase steps, A/B)
     bool chain = nm_ls().vrnn_chain && nm_ls().vrnn_mid && Tg >= 1 && B <= 4 && K >= 2 && K <= 32 && Z == 128 && H == 512 && c->vrnn_cnt && c->nf_flag;
     const size_t chain_lds = (size_t)(3 + 7 * K) * 128 * sizeof(float);
+    // the conditioning (posterior) steps of generate as ONE persistent launch too (vrnn_post_chain_kernel without statistics workgroups:
+    // generate evaluates no prior during conditioning, hsvrnn_bvh.py:171-202): a whole HSVRNNBVH.generate is then two kernels
+    int t_first = 0;
+    rc = NM_OK;
+    if (kind == 0 && Tcond >= 1 && r.pc_g && nm_ls().vrnn_post_chain && nm_ls().vrnn_mid && post_chain_fits(c, B, S, 0, rc)) {
+        if ((rc = launch_post_chain(c, r.kp_cond, Tcond * S4, r.eps_post, r.offset, B, Tcond, S, r.out_cond, Tcond * S4, r.pc_z, Tcond * Z, nullptr, 0,
+                                    r.pc_h, (Tcond + 1) * H, nullptr, 0, nullptr, nullptr, 0, r.pc_g))) return rc;
+        // the state after the last conditioning step, as the dense [B][H] the prior steps take
+        if ((rc = nm_check_hip(hipMemcpy2DAsync(r.hbuf[0], (size_t)H * sizeof(float), r.pc_h + (size_t)Tcond * H, (size_t)(Tcond + 1) * H * sizeof(float),
+                                                (size_t)H * sizeof(float), B, hipMemcpyDeviceToDevice, c->stream), "rollout: state copy"))) return rc;
+        h = r.hbuf[0]; nxt = 1; t_first = Tcond;
+    }
+    if (rc) return rc;
     if (chain) {
         // Co-residency: the kernel's workgroups spin on each other, so ALL of them must be resident at once - an ordinary launch does not
         // promise that.  Asked once per context: workgroups of this shape (512 threads at up to 256 registers, the heads' weights in
@@ -1977,7 +2439,7 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         }
         chain = nm_ls().chain_fits == 1;
     }
-    for (int t = 0; t < (chain ? Tcond : Ttot); ++t) {
+    for (int t = t_first; t < (chain ? Tcond : Ttot); ++t) {
         StepIO io;
         const bool post = t < Tcond;
         io.h = h; io.ldh = H;
@@ -2103,12 +2565,13 @@ static int rollout_impl(nm_ctx* c, int kind, const float* kp_cond, const float* 
         }
     }
     // eager: the same launch sequence straight onto the ctx stream, working on the caller's buffers
-    if ((rc = nm_ctx_reserve(c, rollout_floats(B, 0, 0, S, K, Z, H) * sizeof(float) + 4096))) return rc;
+    if ((rc = nm_ctx_reserve(c, (rollout_floats(B, 0, 0, S, K, Z, H) + (size_t)B * Tcond * Z + (size_t)B * (Tcond + 1) * H + 1024) * sizeof(float) + 4096))) return rc;
     c->ws.release(0);
     RolloutBufs r;
     r.sb = alloc_step(c->ws, B, S, K, Z, H);
     r.hbuf[0] = c->ws.f((size_t)B * H); r.hbuf[1] = c->ws.f((size_t)B * H); r.zbuf = c->ws.f((size_t)B * Z);
     r.chain_g = c->ws.f(2 * (size_t)B * (3 * 128 + 3 * H + K * 4 + Z + 2 * H) + 64);
+    if (kind == 0) { r.pc_z = c->ws.f((size_t)B * Tcond * Z + 1); r.pc_h = c->ws.f((size_t)B * (Tcond + 1) * H); r.pc_g = c->ws.f(post_chain_gran_floats(B, S, K, Z, H)); }
     r.offset = kind == 0 ? c->ws.f((size_t)B * K * 3) : const_cast<float*>(offset_in);
     if (c->ws.overflow) { nm_set_error("vrnn rollout: workspace overflow"); return NM_ERR_STATE; }
     r.kp_cond = const_cast<float*>(kp_cond); r.eps_post = const_cast<float*>(eps_post); r.eps_prior = const_cast<float*>(eps_prior);

@@ -1140,3 +1140,70 @@ def test_first_plain_call_never_returns_nan_where_fp32_would_not():
         out3 = net(vox, acts)
     assert net._engine._auto_fp32 and torch.equal(out3["recon"], want["recon"])
     net.check_finite()
+
+
+@pytest.mark.parametrize("B,S,K,T", [(1, 10, 24, 16), (4, 10, 24, 16), (3, 3, 24, 5), (2, 10, 12, 7), (2, 16, 22, 4), (4, 1, 28, 3)])
+def test_persistent_encode_is_bit_identical_to_launch_per_phase_steps(B, S, K, T):
+    """vrnn_post_chain_kernel (round 5; BASELINE north_star "GRU / prior / posterior MLPs fused into one kernel per timestep" - here
+    all T posterior steps of a stand-alone HSVRNNBVH.encode are ONE persistent launch: worker, sample and statistics workgroups,
+    data-tagged granule hand-offs, best-of-S selection by the sample workgroups themselves) against the six-launches-per-step path
+    (NM355_VRNN_POST_CHAIN=0, read when a context is created): every output of encode bit for bit - reconstructed keypoints, rotations,
+    latents, all T + 1 states, best-of-S indices, the KL and reconstruction scalars - and the launch path itself is held to the oracle
+    by the G2 / config-2 tests."""
+    o = HotPathOptions(grid_size=32, nkeypoints=K)
+    sd = synth.make_state_dict(o, seed=21 + K, variant="default")
+    gen = torch.Generator().manual_seed(K)
+    sd["kypt_detector.affinity_params"] = torch.randn(sd["kypt_detector.affinity_params"].shape, generator=gen)
+    nets = {}
+    for name, sw in (("launches", "0"), ("chain", "1")):
+        with _switches({"NM355_VRNN_POST_CHAIN": sw}):
+            nets[name] = _net(o, sd)
+            with torch.no_grad():
+                nets[name].kypt_detector.get_affinity()
+    Z = o.nlatent_kypt
+    g = torch.Generator().manual_seed(B * 100 + S)
+    kp = (torch.rand(B, T, K, 4, generator=g) * 1.6 - 0.8).cuda()
+    eps = synth.make_eps((T, S, B, Z), seed=50 + S).cuda()
+    with torch.no_grad():
+        aff = O.affinity_v3(sd["kypt_detector.affinity_params"]).cuda()
+        outs = {n: net.dyna_module.encode(kp, aff, SAMPLE_NUM=S, eps=eps) for n, net in nets.items()}
+        again = nets["chain"].dyna_module.encode(kp, aff, SAMPLE_NUM=S, eps=eps)
+        torch.cuda.synchronize()
+    for k in ("kypt_recon", "R", "z_kypts", "h_kypts", "best_idx", "kl_kypt", "kypt_recon_loss"):
+        assert torch.isfinite(outs["chain"][k].float()).all(), k
+        assert torch.equal(outs["chain"][k], outs["launches"][k]), k
+        assert torch.equal(again[k], outs["launches"][k]), k
+    for n in nets.values():
+        n.check_finite()
+
+
+def test_persistent_encode_timeout_is_reported_and_the_context_falls_back():
+    """The posterior chain's version of the rollout time-out test: the last sample workgroup is not launched (NM355_CHAIN_DROP_WG=1),
+    its clip's other sample workgroups and every GRU wave run into the spin limit, the status word reports it, the context stops
+    using the persistent kernels and the repeated call equals the launch-per-phase result."""
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=21, variant="default")
+    with _switches({"NM355_VRNN_POST_CHAIN": "0"}):
+        ref_net = _net(o, sd)
+        with torch.no_grad():
+            ref_net.kypt_detector.get_affinity()
+    with _switches({"NM355_CHAIN_DROP_WG": "1", "NM355_CHAIN_SPIN": "20000"}):
+        net = _net(o, sd)
+        with torch.no_grad():
+            net.kypt_detector.get_affinity()
+    B, T, S, K, Z = 2, 4, 10, o.nkeypoints, o.nlatent_kypt
+    g = torch.Generator().manual_seed(5)
+    kp = (torch.rand(B, T, K, 4, generator=g) * 1.6 - 0.8).cuda()
+    eps = synth.make_eps((T, S, B, Z), seed=77).cuda()
+    with torch.no_grad():
+        aff = O.affinity_v3(sd["kypt_detector.affinity_params"]).cuda()
+        want = ref_net.dyna_module.encode(kp, aff, eps=eps)
+        net.dyna_module.encode(kp, aff, eps=eps)               # aborted inside the kernel
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="timed out"):
+            net.check_finite()
+        got = net.dyna_module.encode(kp, aff, eps=eps)         # launch-per-phase steps now
+        torch.cuda.synchronize()
+        net.check_finite()
+    for k in ("kypt_recon", "z_kypts", "h_kypts", "best_idx"):
+        assert torch.equal(got[k], want[k]), k
