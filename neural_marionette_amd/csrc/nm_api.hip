@@ -58,6 +58,7 @@ NmLaunchState::NmLaunchState()
       adj_zwalk(env_int("NM355_ADJ_ZWALK", 1)),        // 0: the trilinear upsample's adjoint on the 2 x 4 x 8 brick kernel (6 x 10 x 18 fine tile) instead of the z-walking one (A/B)
       f16q2(env_int("NM355_F16Q2", 1)),                 // 0: the one-product modes (3 / 4) keep conv_f16p2<SINGLE> instead of their own kernel conv_f16q2 (A/B)
       vrnn_post_chain(env_int("NM355_VRNN_POST_CHAIN", 1))   // 0: the posterior steps of a stand-alone encode as six launches each; 1: one persistent launch (vrnn_post_chain_kernel); 2: inside nm_forward_fused too (A/B)
+      , conv_wgs(env_int("NM355_CONV_WGS", 0))              // > 0: the persistent producer / consumer convs launch at most this many workgroups (co-residency A/B: CUs left free for the other queues)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); chain_spin = env_int("NM355_CHAIN_SPIN", 1 << 20); chain_drop = env_int("NM355_CHAIN_DROP_WG", 0); }
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)

@@ -3056,7 +3056,8 @@ int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, h
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 7;
         (void)hipEventRecord(rec.a, s);
     }
-    dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
+    // persistent: one workgroup per CU (NM355_CONV_WGS caps the count: the co-residency A/B of DESIGN 5 - CUs left to the other queues)
+    dim3 grid((unsigned)min(work_items, nm_ls().conv_wgs > 0 ? min(nm_ls().conv_wgs, g_num_cus) : g_num_cus));
     if (p.Cout == 32) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p_kernel<UP2, SINGLE, IO>), grid, dim3(512), lds_bytes, s, p);
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
@@ -3094,7 +3095,8 @@ int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, 
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 9;
         (void)hipEventRecord(rec.a, s);
     }
-    dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
+    // persistent: one workgroup per CU (NM355_CONV_WGS caps the count: the co-residency A/B of DESIGN 5 - CUs left to the other queues)
+    dim3 grid((unsigned)min(work_items, nm_ls().conv_wgs > 0 ? min(nm_ls().conv_wgs, g_num_cus) : g_num_cus));
     if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16p2_kernel<UP2, SINGLE, IO>), grid, dim3(512), lds_bytes, s, p);
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
@@ -3124,7 +3126,8 @@ int launch_f16q2_impl(const ConvParams& p_in, int work_items, hipStream_t s) {
         rec.a = prof_event(); rec.b = prof_event(); rec.variant = 14;
         (void)hipEventRecord(rec.a, s);
     }
-    dim3 grid((unsigned)min(work_items, g_num_cus));               // persistent: one workgroup per CU
+    // persistent: one workgroup per CU (NM355_CONV_WGS caps the count: the co-residency A/B of DESIGN 5 - CUs left to the other queues)
+    dim3 grid((unsigned)min(work_items, nm_ls().conv_wgs > 0 ? min(nm_ls().conv_wgs, g_num_cus) : g_num_cus));
     if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
     hipLaunchKernelGGL((conv_f16q2_kernel<IO, DBG>), grid, dim3(512), lds_bytes, s, p);
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
