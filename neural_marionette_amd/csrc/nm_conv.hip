@@ -2676,27 +2676,38 @@ __global__ __launch_bounds__(512, 1) void conv_f16q2_kernel(ConvParams p) {
                 }
             }
         };
-        // the step's weights: 54 one-KiB wave pieces (tap t, plane r of (cout group cg, chunk cb)), piece j = pw + 4 i of producer wave pw
+        // the step's weights: 54 one-KiB wave pieces (tap t, plane r of (cout group cg, chunk cb)), piece j = pw + 4 i of producer wave pw:
+        // r = pw & 1 for every piece of the wave and t = (pw >> 1) + 2 i, so a piece's source is src0 + i * wstep and its LDS slot
+        // dst0 + 256 i - one add per load, an immediate offset per store (slots 54, 55 - i = 13 of waves 2, 3 - repeat the wave's piece 12:
+        // identical bytes to the same place)
         const unsigned wst_t = (unsigned)((size_t)C16 * 4 * plane * 16), wst_r = (unsigned)(plane * 16);
+        const unsigned wsrc0 = (unsigned)(pw >> 1) * wst_t + (unsigned)(pw & 1) * wst_r + (unsigned)lane * 16u, wstep = 2u * wst_t;
+        const int ilast = pw < 2 ? 13 : 12;
         const bool wdma = p.wdma != 0;
         auto load_w = [&](int cg, int cb, int buf) {
             const float* base = reinterpret_cast<const float*>(w8 + ((size_t)cb * 4) * plane + cg * 64);
-            static_for<NWL>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                const int j = min(pw + 4 * i, 53), t = j >> 1, r = j & 1;
-                const unsigned src = (unsigned)t * wst_t + (unsigned)r * wst_r + (unsigned)lane * 16u;
-                if (wdma) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + src),
-                                                           (__attribute__((address_space(3))) void*)(ldb + buf * WB + j * 64), 16, 0, 0);
-                else wreg[i] = load16_untracked(base, src);
-            });
+            if (wdma) {
+                static_for<NWL>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    const int ii = i < 13 ? i : ilast;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + wsrc0 + (unsigned)ii * wstep),
+                                                     (__attribute__((address_space(3))) void*)(ldb + buf * WB + pw * 64 + ii * 256), 16, 0, 0);
+                });
+            } else {
+                static_for<NWL>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    wreg[i] = load16_untracked(base, wsrc0 + (unsigned)(i < 13 ? i : ilast) * wstep);
+                });
+            }
         };
         auto store_w = [&](int buf) {
             if (wdma) return;
-            static_for<NWL>([&](auto I) {
+            half8* dst0 = ldb + buf * WB + pw * 64 + lane;
+            static_for<13>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                const int j = min(pw + 4 * i, 53);
-                *reinterpret_cast<f32x4*>(ldb + buf * WB + j * 64 + lane) = wreg[i];
+                *reinterpret_cast<f32x4*>(dst0 + i * 256) = wreg[i];
             });
+            *reinterpret_cast<f32x4*>(dst0 + ilast * 256) = wreg[13];
         };
 
         Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;

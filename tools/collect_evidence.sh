@@ -42,7 +42,15 @@ for M in split16 bf16; do
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $E/pm -- $PCMD > $E/pm.log 2>&1
 python3 tools/pmc_mfma.py $(find $E/pm -name "*.db" | head -1) $E/${R}_pmc_mfma.json > $E/pmc_mfma_summary.txt 2>&1
-rm -rf $E/fwd $E/train $E/trainb $E/c4 $E/c5 $E/tf $E/tw $E/pm
+# matrix-core utilisation of the training step in BASELINE config 3's precision (the one-product kernels)
+TBCMD="python3 bench.py --workload train --conv-mode bf16 --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $E/pmb -- $TBCMD > $E/pmb.log 2>&1
+python3 tools/pmc_mfma.py $(find $E/pmb -name "*.db" | head -1) $E/${R}_pmc_mfma_train_bf16.json > $E/pmc_mfma_train_bf16_summary.txt 2>&1
+# same-call A/Bs of the round: posterior chain (encode alone, and forced on inside the fused forward), one-product conv kernel
+python3 tools/time_encode_ab.py 2>&1 | grep -v amdgpu.ids > $E/${R}_encode_ab.txt
+python3 tools/ab_f16q2.py 64 2>&1 | grep -v amdgpu.ids > $E/${R}_f16q2_ab.txt
+if [ -f neural_marionette_amd/libnm355_diag.so ]; then python3 tools/diag_f16q2.py 0,1,2,3,5,6,7,8,9,0 2>&1 | grep -v amdgpu.ids >> $E/${R}_f16q2_ab.txt; fi
+rm -rf $E/fwd $E/train $E/trainb $E/c4 $E/c5 $E/tf $E/tw $E/pm $E/pmb
 # stamp the tree id into every summary
 python3 tools/tree_id.py --stamp "$TREE" $E/${R}_*.json $E/${R}_*.csv $E/${R}_*.txt $E/${R}_bench.json.log
-head -12 $E/pmc_traffic_summary.txt; head -10 $E/pmc_mfma_summary.txt; tail -c 600 $E/${R}_bench.json.log
+head -12 $E/pmc_traffic_summary.txt; head -10 $E/pmc_mfma_summary.txt; head -12 $E/pmc_mfma_train_bf16_summary.txt; tail -c 600 $E/${R}_bench.json.log
