@@ -63,22 +63,36 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
-    // per (k, row y): sum over x;  per (k, col x): sum over y   of (hm + 1e-6)
+    // Marginal sums of the plane by WAVEFRONT SHUFFLES (BASELINE north_star: "wavefront shuffles for the ... keypoint heatmap
+    // reduction"): wave w takes the keypoints k = w, w + 4, ...; a plane row lives in a group of GP lanes (GP = 8 / 16 / 32 >= g), 64 / GP
+    // rows per pass.  Row y: sum over x of (hm + 1e-6) - an xor butterfly inside the group; column x: every lane adds its rows in
+    // registers, the groups are combined by a butterfly across them; the plane totals (with and without the 1e-6) by butterflies over
+    // the whole wave.  (Rounds 1-4 walked rows, columns and totals with serial LDS loops - 3 g^2 dependent adds per keypoint on one lane
+    // each; the association order differs, which moves keypoints by ~1e-7 - see tests/test_network_gpu.py::_check_losses for what that
+    // does to the trajectory loss of a clip whose keypoints barely move.)
     const int stride = 2 * g + 2;
-    for (int task = threadIdx.x; task < K * g * 2; task += 256) {
-        int k = task / (2 * g), r = task % (2 * g);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int GP = g <= 8 ? 8 : (g <= 16 ? 16 : 32), rpp = 64 / GP;
+    const int grp = lane / GP, x = lane % GP;
+    for (int k = wave; k < K; k += 4) {
         const float* tk = tile + k * g2;
-        float s = 0.f;
-        if (r < g) { for (int x = 0; x < g; ++x) s += tk[r * g + x] + 1e-6f; }
-        else { int x = r - g; for (int y = 0; y < g; ++y) s += tk[y * g + x] + 1e-6f; }
-        part[(((size_t)f * K + k) * g + z) * stride + r] = s;
-    }
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float* tk = tile + k * g2;
-        float s = 0.f, s6 = 0.f;
-        for (int v = 0; v < g2; ++v) { s += tk[v]; s6 += tk[v] + 1e-6f; }
-        float* dst = part + (((size_t)f * K + k) * g + z) * stride + 2 * g;
-        dst[0] = s; dst[1] = s6;
+        float* dst = part + (((size_t)f * K + k) * g + z) * stride;
+        float col = 0.f, tot = 0.f;
+        for (int y0 = 0; y0 < g; y0 += rpp) {
+            const int y = y0 + grp;
+            const bool ok = x < g && y < g;
+            const float h = ok ? tk[y * g + x] : 0.f;
+            const float h6 = ok ? h + 1e-6f : 0.f;
+            col += h6; tot += h;
+            float r = h6;
+            for (int off = GP >> 1; off > 0; off >>= 1) r += __shfl_xor(r, off);
+            if (x == 0 && y < g) dst[y] = r;
+        }
+        for (int off = GP; off < 64; off <<= 1) col += __shfl_xor(col, off);          // the column's rows of the other groups
+        if (grp == 0 && x < g) dst[g + x] = col;
+        float tot6 = grp == 0 ? col : 0.f;                                            // (columns x >= g hold zeros)
+        for (int off = 32; off > 0; off >>= 1) { tot += __shfl_xor(tot, off); tot6 += __shfl_xor(tot6, off); }
+        if (lane == 0) { dst[2 * g] = tot; dst[2 * g + 1] = tot6; }
     }
 }
 
@@ -448,7 +462,7 @@ __global__ void affinity_kernel(const float* __restrict__ params, int N, int K, 
 
 int nm_launch_heatmap(const float* head, const float* clip_head, const float* prop, int F, int T, int K, int Kc, int g,
                       float* heatmaps, float* part, hipStream_t s) {
-    if (K < 1 || K > 32 || Kc % 4 || Kc < K) { nm_set_error("heatmap: K=%d (row pitch %d) unsupported", K, Kc); return NM_ERR_ARG; }
+    if (K < 1 || K > 32 || Kc % 4 || Kc < K || g > 32) { nm_set_error("heatmap: K=%d (row pitch %d), g=%d unsupported", K, Kc, g); return NM_ERR_ARG; }
     size_t lds = (size_t)K * g * g * sizeof(float);
     hipLaunchKernelGGL(heatmap_kernel, dim3(F, g), dim3(256), lds, s, head, clip_head, prop, T, K, Kc, g, heatmaps, part);
     return nm_check_hip(hipGetLastError(), "heatmap launch");

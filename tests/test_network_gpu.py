@@ -60,10 +60,49 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name), allow_pickle=False)
 
 
-def _check_losses(out, ref_losses, tol=2e-5):
+def _traj_conditioning(kp_ref, e_kp):
+    """First-order bound on how far the trajectory term of the graph loss (kypt_detector_utils.py:228-265) can move when every keypoint
+    coordinate moves by at most e_kp: the term is a weighted mean (weights <= 1) of (1 - cos(v_i, v_j)) / 2 over keypoint pairs, v the
+    frame-to-frame velocity (and the acceleration); a perturbation d of v turns it by at most |d| / |v|, so each pair's term moves by at
+    most (|d_i| / |v_i| + |d_j| / |v_j|) / 2 and the mean over pairs by at most mean_i(|d_i| / |v_i|); |d| <= 2 sqrt(3) e_kp for a
+    velocity, 4 sqrt(3) e_kp for an acceleration.  Returns (bound, median |v|).
+    WHY this is here (round-4 verdict item 6d): the synthetic clips barely move their keypoints - velocities of 4e-6 ... 2e-4 voxel-grid
+    units, median 3e-5 on g5 - so a keypoint change of 1e-7 (one fp32 ulp of a coordinate ~0.5 is 6e-8: what ANY change of summation order
+    in the heat-map marginals produces) turns those velocity vectors by 1e-3 rad and moves this loss by ~1e-3 relative; measured on
+    g5 with the CPU oracle: +-1e-7 uniform keypoint noise -> 8.0e-4 mean / 1.65e-3 max relative change.  A 2e-5 bound on this one loss
+    is therefore a bound on the summation order, not on the kernel; the order-free checks below replace it."""
+    kp = torch.as_tensor(np.asarray(kp_ref)).double()[..., :3]
+    vel = kp[:, 1:] - kp[:, :-1]
+    acc = vel[:, 1:] - vel[:, :-1]
+    s3 = 3.0 ** 0.5
+    bv = (2 * s3 * e_kp / vel.norm(dim=-1).clamp_min(1e-6)).mean().item()
+    ba = (4 * s3 * e_kp / acc.norm(dim=-1).clamp_min(1e-6)).mean().item()
+    return min(bv, 1.0) + min(ba, 1.0), vel.norm(dim=-1).median().item()
+
+
+def _check_losses(out, ref_losses, tol=2e-5, ref_kp=None):
+    """Ten of the eleven detector losses: 2e-5 against the fixture / oracle value.  graph_traj_loss: (A) 2e-5 against the ORACLE's loss
+    function evaluated on the HIP path's own keypoints and affinity - the loss kernel itself, free of what sits in front of it;
+    (B) against the fixture value within the conditioning bound of _traj_conditioning for the keypoint error actually measured."""
     for i, k in enumerate(DETECTOR_LOSS_KEYS):
         r = float(ref_losses[i])
         e = abs(float(out[k]) - r)
+        if k == "graph_traj_loss" and ref_kp is not None and np.isfinite(r) and out.get("affinity") is not None:
+            own = float(O.loss_graph_traj_v1(out["keypoints"].detach().float().cpu(), out["affinity"].detach().float().cpu()))
+            assert abs(float(out[k]) - own) <= tol * max(1.0, abs(own)), f"{k}: got {float(out[k])}, oracle on the same keypoints {own}"
+            e_kp = _err(out["keypoints"], ref_kp)
+            worst, vmed = _traj_conditioning(ref_kp, e_kp)
+            # the worst case is far from typical: take the measured sensitivity too - the oracle's loss on the reference keypoints
+            # under 8 draws of uniform +-e_kp noise - and allow 4x the largest change seen, capped by the worst-case bound
+            kr, gen = torch.as_tensor(np.asarray(ref_kp)).float(), torch.Generator().manual_seed(0)
+            aff = out["affinity"].detach().float().cpu()
+            base = float(O.loss_graph_traj_v1(kr, aff))
+            seen = max(abs(float(O.loss_graph_traj_v1(kr + (torch.rand(kr.shape, generator=gen) * 2 - 1) * e_kp, aff)) - base) for _ in range(8))
+            bound = min(worst, 4 * seen)
+            print("graph_traj_loss %.8f (oracle on the same keypoints %.8f, fixture %.8f): keypoint err %.2e, median |v| %.2e, "
+                  "worst-case bound %.2e, 4x measured sensitivity %.2e" % (float(out[k]), own, r, e_kp, vmed, worst, 4 * seen))
+            assert e <= tol * max(1.0, abs(r)) + bound, f"{k}: got {float(out[k])} want {r} (bound {bound})"
+            continue
         assert e <= tol * max(1.0, abs(r)), f"{k}: got {float(out[k])} want {r}"
 
 
@@ -105,7 +144,7 @@ def test_g2_forward32_vs_reference_fixture(golden_dir, mode, path):
     assert _err(out["recon"][..., ::2, ::2, ::2], g["recon_sub"]) < 1e-3
     occ = (out["recon"] >= 0.5).sum(dim=(2, 3, 4, 5)).cpu().numpy()
     assert np.array_equal(occ, g["recon_occ"]), "thresholded occupancy must match exactly"
-    _check_losses(out, g["losses"])
+    _check_losses(out, g["losses"], ref_kp=g["keypoints"])
     # skeleton built on the host from the device affinity
     assert np.array_equal(net.dyna_module.parents.cpu().numpy(), g["parents"])
     # end-to-end VRNN (detector error amplified by the FK chain is reported, unit parity is the next test)
@@ -178,7 +217,7 @@ def test_g1_config1_detector64(golden_dir, mode, path):
     assert _err(out["recon"][..., ::4, ::4, ::4], g["recon_sub"]) < 1e-3
     occ = (out["recon"] >= 0.5).sum(dim=(2, 3, 4, 5)).cpu().numpy()
     assert np.array_equal(occ, g["recon_occ"])
-    _check_losses(out, g["losses"])
+    _check_losses(out, g["losses"], ref_kp=g["keypoints"])
 
 
 @pytest.mark.parametrize("path", PATHS)
@@ -192,7 +231,7 @@ def test_g5_odd_hourglass40(golden_dir, path):
     torch.cuda.synchronize()
     assert _err(out["keypoints"], g["keypoints"]) < KP_TOL
     assert _err(out["heatmaps"], g["heatmaps"]) < 1e-4 * max(1.0, np.abs(g["heatmaps"]).max())
-    _check_losses(out, g["losses"])
+    _check_losses(out, g["losses"], ref_kp=g["keypoints"])
 
 
 def test_g4_generate32(golden_dir):
@@ -357,7 +396,7 @@ def test_bernoulli_clip_64cubed_vs_oracle(path):
     print("bernoulli 64^3 (%s): keypoints %.3e latents %.3e" % (path, e_kp, e_z))
     assert e_kp < KP_TOL and e_z < KP_TOL and _err(out["h_kypts"], ref["h_kypts"]) < KP_TOL
     assert np.array_equal(out["best_idx"].cpu().numpy(), ref["best_idx"].numpy().astype(np.int32))
-    _check_losses(out, [float(ref[k]) for k in DETECTOR_LOSS_KEYS])
+    _check_losses(out, [float(ref[k]) for k in DETECTOR_LOSS_KEYS], ref_kp=ref["keypoints"])
     margin = (ref["recon"] - 0.5).abs()
     mism = (((out["recon"].cpu() >= 0.5) != (ref["recon"] >= 0.5)) & (margin > 1e-3)).sum().item()
     assert mism == 0
