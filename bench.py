@@ -202,7 +202,7 @@ ROUND = os.environ.get("NM355_ROUND", "r05")
 def prof_families(lib, h, _lib):
     """{kernel family: (event-timed ms total, algorithmic flops total, launches)} of the context's current profiler window."""
     fam = {}
-    for v in range(15):
+    for v in range(16):
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
         _lib.check(lib.nm_prof_read(h, v, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
         if n.value:

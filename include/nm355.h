@@ -339,7 +339,7 @@ int nm_op_set_storage16(nm_ctx* ctx, int32_t in_h, int32_t out_h);
  * 7 = conv_f16p_kernel, 8 = conv_pool_f16s_kernel, 9 = conv_f16p2_kernel (algorithmic fp32-equivalent flops, i.e. 1/3 of the issued MFMA flops); 4 = the
  * first-layer occupancy kernel conv_k5occ_kernel, credited with the reference's dense 4-channel k5 work; 12 = conv_up2c_kernel (main + shell
  * launches); 13 = wgrad16_kernel, the split-fp16 k3 weight-gradient kernels with their fixed-order reduce (2*voxels*Cout*Cin*27);
- * 14 = conv_f16q2_kernel, the one-product modes' 64-channel conv). */
+ * 14 = conv_f16q2_kernel, the one-product modes' 64-channel conv; 15 = conv_f16r_kernel, their 32-output-channel conv with resident weights). */
 int nm_prof_enable(nm_ctx* ctx, int32_t on);
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches);
 const char* nm_prof_kernel_name(int32_t variant);

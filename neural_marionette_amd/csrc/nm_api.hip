@@ -58,6 +58,8 @@ NmLaunchState::NmLaunchState()
       adj_zwalk(env_int("NM355_ADJ_ZWALK", 1)),        // 0: the trilinear upsample's adjoint on the 2 x 4 x 8 brick kernel (6 x 10 x 18 fine tile) instead of the z-walking one (A/B)
       f16q2(env_int("NM355_F16Q2", 1)),                 // 0: the one-product modes (3 / 4) keep conv_f16p2<SINGLE> instead of their own kernel conv_f16q2 (A/B)
       vrnn_post_chain(env_int("NM355_VRNN_POST_CHAIN", 1))   // 0: the posterior steps of a stand-alone encode as six launches each; 1: one persistent launch (vrnn_post_chain_kernel); 2: inside nm_forward_fused too (A/B)
+      , f16r(env_int("NM355_F16R", 1))                      // 0: the one-product modes keep conv_f16p<SINGLE> on the 32-output-channel layers instead of conv_f16r (resident weights; A/B)
+      , up2_mat(env_int("NM355_UP2_MAT", 1))                // 0: the one-product training forward keeps the fused-upsample staging on its 32-output layer instead of materialising the upsampled input for conv_f16r (A/B)
       , conv_wgs(env_int("NM355_CONV_WGS", 0))              // > 0: the persistent producer / consumer convs launch at most this many workgroups (co-residency A/B: CUs left free for the other queues)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); chain_spin = env_int("NM355_CHAIN_SPIN", 1 << 20); chain_drop = env_int("NM355_CHAIN_DROP_WG", 0); }
 NmLaunchState& nm_ls() {
@@ -335,7 +337,7 @@ int nm_prof_enable(nm_ctx* ctx, int32_t on) { NmScope nm_scope_(ctx);
 }
 
 int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) { NmScope nm_scope_(ctx);
-    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 14) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
+    if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 15) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
     long long n = 0;
     int rc = nm_conv_prof_collect(variant, ms_total, flops_total, &n);
     if (rc) { nm_set_error("prof_read: event query failed"); return rc; }
@@ -344,11 +346,11 @@ int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_t
 }
 
 const char* nm_prof_kernel_name(int32_t variant) {
-    static const char* names[15] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
+    static const char* names[16] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
                                    "conv_k5occ_kernel", "conv_f16s_kernel<2,1>", "conv_f16s_kernel<2,2>", "conv_f16p_kernel",
                                    "conv_pool_f16s_kernel", "conv_f16p2_kernel", "conv_f16s_kernel<2,1,3,up2>", "conv_f16s_kernel<2,2,3,up2>",
-                                   "conv_up2c_kernel", "wgrad16_kernel", "conv_f16q2_kernel"};
-    return (variant >= 0 && variant < 15) ? names[variant] : "";
+                                   "conv_up2c_kernel", "wgrad16_kernel", "conv_f16q2_kernel", "conv_f16r_kernel"};
+    return (variant >= 0 && variant < 16) ? names[variant] : "";
 }
 
 int nm_host_linspace(int32_t n, float* out) {

@@ -2661,9 +2661,15 @@ __global__ __launch_bounds__(512, 1) void conv_f16q2_kernel(ConvParams p) {
                 // (by value: bit_cast of a vector element through a reference reads element 0)
                 if constexpr (IH) { const float rf = raw[set][k][e >> 1]; const unsigned u = nm_fbits(rf); v0 = nm_bf_lo(u); v1 = nm_bf_hi(u); }
                 else { v0 = raw[set][k][e]; v1 = raw[set][k][e + 1]; }
-                v0 = __builtin_fmaf(v0, sc[set][e >> 2][e & 3], sh[set][e >> 2][e & 3]); v1 = __builtin_fmaf(v1, sc[set][e >> 2][(e & 3) + 1], sh[set][e >> 2][(e & 3) + 1]);
-                v0 = fmaxf(v0, v0 * p.in_slope); v1 = fmaxf(v1, v1 * p.in_slope);
-                half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
+                // the pair's affine and slope product as PACKED fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two elements per issue
+                // slot - the producers are bound by vector issue); the same fma / mul / max per element
+                f32x2 vv = f32x2{v0, v1};
+                const f32x4 sq = sc[set][e >> 2], hq = sh[set][e >> 2];
+                const f32x2 s2 = (e & 2) ? f32x2{sq[2], sq[3]} : f32x2{sq[0], sq[1]}, h2 = (e & 2) ? f32x2{hq[2], hq[3]} : f32x2{hq[0], hq[1]};
+                vv = __builtin_elementwise_fma(vv, s2, h2);
+                const f32x2 vs = vv * f32x2{p.in_slope, p.in_slope};
+                vv = f32x2{fmaxf(vv[0], vs[0]), fmaxf(vv[1], vs[1])};
+                half2v hv = __builtin_convertvector(vv, half2v);
                 asm volatile("" : "+v"(hv));
                 pk[e >> 1] = keep ? __builtin_bit_cast(unsigned, hv) : 0u;
             }
@@ -2854,6 +2860,282 @@ __global__ __launch_bounds__(512, 1) void conv_f16q2_kernel(ConvParams p) {
                 for (int q = 0; q < 4; ++q) { a += red[(q * 64 + tid) * 2]; b += red[(q * 64 + tid) * 2 + 1]; }
                 const int br = ((w.oz0 >> 2) * nby + (w.oy0 >> 3)) * nbx + (w.ox0 >> 3);
                 float* dp = p.part + (((size_t)w.n * nbr + br) * p.Cout + w.cg * 64 + tid) * 2;
+                dp[0] = a; dp[1] = b;
+            }
+        }
+        if (!has_next) break;
+        cur = nxt; hb ^= 1;
+    }
+}
+
+// ---- conv_f16r: the one-product modes' kernel for the 32-output-channel layers, weights RESIDENT in LDS (round 5) -------------------
+// conv_f16p<SINGLE> runs the Cout = 32 layers (the decoder's 32 -> 32 @64^3 conv, the data gradients that end in 32 channels) with the
+// three-product kernel's schedule: 9-tap weight groups streamed per step, three barriers per step, at 0.26 of the time on the matrix
+// pipe (profiles/r05_pmc_mfma_train_bf16.json) - 2.3 ms per 64-frame launch at 64^3.  A 32-channel layer's hi-only weights are small:
+// 27 taps x Cin x 32 outputs x 2 B = 55 KB (Cin = 32) or 110 KB (Cin = 64).  Here they are loaded ONCE per workgroup and stay; the
+// producer waves only stage halo tiles (conv_f16q2's two-register-set pipeline: a tile's loads are issued two steps ahead), one
+// workgroup barrier per 16-channel step, and the MFMA waves keep operands three taps ahead (a tap is two MFMAs here).
+//   LDS: halo [2][h0 | h1][600] x 16 B = 38 KB, weights [27 taps][C16][h0 | h1][32] x 16 B, GroupNorm scratch, bias.
+// k order per output element: channel chunk outer, tap inner (conv_f16q2's); epilogue identical.
+template <int IO, int C16T>
+__global__ __launch_bounds__(512, 1) void conv_f16r_kernel(ConvParams p) {
+    constexpr bool IH = (IO & 1) != 0, OH = (IO & 2) != 0;
+    constexpr unsigned EB = IH ? 2u : 4u;                           // bytes per input element
+    constexpr int HV = 600, ZP = 100, HX = 10;
+    constexpr int NP = IH ? 5 : 10;                                 // 16-byte input pieces per producer thread and step
+    constexpr int NCH = IH ? 8 : 4;                                 // channels per piece
+    constexpr int NA = IH ? 4 : 2;                                  // affine loads per step
+    constexpr int TS = C16T * 64;                                   // half8 slots of one tap: [C16T][h0 | h1][32]
+    extern __shared__ f32x4 lds[];
+    half8* ldh = reinterpret_cast<half8*>(lds);                     // [2][2][HV]
+    half8* ldb = ldh + 4 * HV;                                      // [27][C16T][2][32]
+    float* red = reinterpret_cast<float*>(ldb + 27 * TS);           // [4 waves][32 channels][2]
+    float* lbias = red + 256;                                       // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int nbx = p.OW >> 3, nby = p.OH >> 3, nbz = p.OD >> 2, nbr = nbx * nby * nbz;
+    const int total = p.N * nbr;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int id_first = (int)blockIdx.x * per, id_last = min(total, id_first + per);
+    if (id_first >= id_last) return;
+
+    struct Work { int n, oz0, oy0, ox0; };
+    const bool tiled = p.st_x != 0;
+    auto decode = [&](int id) {
+        Work w;
+        if (tiled) {
+            const BrickPos bp = super_tile_item(p, (int)blockIdx.x, id - id_first, per, nbz, nby, nbx);
+            w.n = bp.n; w.ox0 = bp.bx << 3; w.oy0 = bp.by << 3; w.oz0 = bp.bz << 2;
+            return w;
+        }
+        w.n = id / nbr; const int br = id % nbr;
+        w.ox0 = (br % nbx) << 3; w.oy0 = ((br / nbx) % nby) << 3; w.oz0 = (br / (nbx * nby)) << 2;
+        return w;
+    };
+    auto next_work = [&](Work w, int id) {
+        if (tiled) return decode(id);
+        if ((w.ox0 += 8) == p.OW) { w.ox0 = 0; if ((w.oy0 += 8) == p.OH) { w.oy0 = 0; if ((w.oz0 += 4) == p.OD) { w.oz0 = 0; ++w.n; } } }
+        return w;
+    };
+    struct Step { Work w; int id, cb; };
+    auto advance = [&](Step& st) {                                  // false (and st unchanged) on the block's last step
+        if (st.cb + 1 < C16T) { ++st.cb; return true; }
+        if (st.id + 1 >= id_last) return false;
+        st.cb = 0; ++st.id; st.w = next_work(st.w, st.id);
+        return true;
+    };
+
+    if (wave >= 4) {
+        // =========================== producer waves ===========================================================
+        const int pt = tid - 256, pw = wave - 4;
+        const half8* __restrict__ w8 = reinterpret_cast<const half8*>(p.w);
+        const size_t plane = (size_t)p.Co_pad;
+        // the layer's weights, once: 1-KiB pieces (tap t, chunk cb) = the hi planes of both lane halves x 32 outputs
+        for (int j = pw; j < 27 * C16T; j += 4) ldb[j * 64 + lane] = w8[((size_t)j * 4 + (lane >> 5)) * plane + (lane & 31)];
+        for (int c = pt; c < 32; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
+        const int sub = IH ? (pt & 1) : (pt & 3);
+        int pc_slot[NP], pc_rel[NP], pc_pos[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int v = IH ? (pt >> 1) + 128 * k : (pt >> 2) + 64 * k, vc = min(v, HV - 1);
+            const int hz = vc / 100, r = vc % 100, hy = r / 10, hx = r % 10;
+            pc_slot[k] = (IH ? sub : (sub >> 1)) * HV + hz * ZP + hy * HX + hx;
+            pc_rel[k] = ((hz * p.IH + hy) * p.IW + hx) * p.Cin + NCH * sub;
+            pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
+        }
+        f32x4 raw[2][NP], sc[2][NA / 2], sh[2][NA / 2];
+        const bool has_affine = p.in_scale != nullptr;
+        const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * EB;   // halo voxel (1,1,1): always inside
+        auto inside_mask = [&](const Work& w) {
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int hz = pc_pos[k] & 0xff, hy = (pc_pos[k] >> 8) & 0xff, hx = pc_pos[k] >> 16;
+                const bool in = pc_pos[k] >= 0 && (unsigned)(w.oz0 - 1 + hz) < (unsigned)p.ID && (unsigned)(w.oy0 - 1 + hy) < (unsigned)p.IH &&
+                                (unsigned)(w.ox0 - 1 + hx) < (unsigned)p.IW;
+                m |= (in ? 1u : 0u) << k;
+            }
+            return m;
+        };
+        auto tile_base = [&](const Work& w, int cb) {
+            return nm_eptr(p.in, (size_t)(((((long long)w.n * p.ID + (w.oz0 - 1)) * p.IH + (w.oy0 - 1)) * p.IW + (w.ox0 - 1)) * (long long)p.Cin + cb * 16), IH);
+        };
+        auto load_piece = [&](const float* base, unsigned mask, auto K, auto SET) {
+            constexpr int k = decltype(K)::value, set = decltype(SET)::value;
+            raw[set][k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * EB : rel111);
+        };
+        auto load_affine = [&](const Work& w, int cb, auto SET) {   // always NA loads: the waits below count instructions
+            constexpr int set = decltype(SET)::value;
+            const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 : p.in;
+            const float* ph = has_affine ? p.in_shift + (size_t)w.n * p.Cin + cb * 16 : p.in;
+#pragma unroll
+            for (int q = 0; q < NA / 2; ++q) {
+                sc[set][q] = load16_untracked(ps, 4u * (unsigned)(NCH * sub + 4 * q));
+                sh[set][q] = load16_untracked(ph, 4u * (unsigned)(NCH * sub + 4 * q));
+            }
+        };
+        auto fix_affine = [&](auto SET) {
+            constexpr int set = decltype(SET)::value;
+            if (!has_affine) {
+#pragma unroll
+                for (int q = 0; q < NA / 2; ++q) { sc[set][q] = f32x4{1.f, 1.f, 1.f, 1.f}; sh[set][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+        };
+        auto convert = [&](int buf, unsigned mask, auto K, auto SET) {   // activate, round to fp16, write piece k into halo buffer buf
+            constexpr int k = decltype(K)::value, set = decltype(SET)::value;
+            const bool keep = ((mask >> k) & 1) != 0;               // padding is zero AFTER the activation: selected on the packed halves
+            unsigned pk[NCH / 2];
+#pragma unroll
+            for (int e = 0; e < NCH; e += 2) {
+                float v0, v1;
+                if constexpr (IH) { const float rf = raw[set][k][e >> 1]; const unsigned u = nm_fbits(rf); v0 = nm_bf_lo(u); v1 = nm_bf_hi(u); }
+                else { v0 = raw[set][k][e]; v1 = raw[set][k][e + 1]; }
+                f32x2 vv = f32x2{v0, v1};
+                const f32x4 sq = sc[set][e >> 2], hq = sh[set][e >> 2];
+                const f32x2 s2 = (e & 2) ? f32x2{sq[2], sq[3]} : f32x2{sq[0], sq[1]}, h2 = (e & 2) ? f32x2{hq[2], hq[3]} : f32x2{hq[0], hq[1]};
+                vv = __builtin_elementwise_fma(vv, s2, h2);
+                const f32x2 vs = vv * f32x2{p.in_slope, p.in_slope};
+                vv = f32x2{fmaxf(vv[0], vs[0]), fmaxf(vv[1], vs[1])};
+                half2v hv = __builtin_convertvector(vv, half2v);
+                asm volatile("" : "+v"(hv));
+                pk[e >> 1] = keep ? __builtin_bit_cast(unsigned, hv) : 0u;
+            }
+            if (pc_pos[k] >= 0) {
+                if constexpr (IH) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<u32x4*>(ldh + buf * 2 * HV + pc_slot[k]) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                } else {
+                    reinterpret_cast<nm_u32x2*>(ldh + buf * 2 * HV + pc_slot[k])[sub & 1] = nm_u32x2{pk[0], pk[1]};
+                }
+            }
+        };
+
+        Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+        int hb = 0;                                                 // halo buffer of the step the MFMA waves run
+        Step s1 = cur; bool has1 = advance(s1);
+        Step s2 = s1;  bool has2 = has1 && advance(s2);
+        Step s3 = s2;  bool has3 = has2 && advance(s3);
+        unsigned m1 = inside_mask(cur.w), m2, m3;
+        // prologue: first tile in the open; the tiles of steps s1 (set 0) and s2 (set 1) in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the weight loads above are the compiler's)
+        load_affine(cur.w, 0, ic<0>{});
+        { const float* b = tile_base(cur.w, 0); static_for<NP>([&](auto K) { load_piece(b, m1, K, ic<0>{}); }); }
+        NM_Q2_WAIT_SET(0, 0, 0);
+        fix_affine(ic<0>{});
+        static_for<NP>([&](auto K) { convert(0, m1, K, ic<0>{}); });
+        m1 = inside_mask(s1.w);
+        load_affine(s1.w, s1.cb, ic<0>{});
+        { const float* b = tile_base(s1.w, s1.cb); static_for<NP>([&](auto K) { load_piece(b, m1, K, ic<0>{}); }); }
+        m2 = inside_mask(s2.w);
+        load_affine(s2.w, s2.cb, ic<1>{});
+        { const float* b = tile_base(s2.w, s2.cb); static_for<NP>([&](auto K) { load_piece(b, m2, K, ic<1>{}); }); }
+        lds_barrier();
+        // one producer iteration = one step of the MFMA waves (`cur`): set SET holds the tile of s1 (converted now into the other
+        // halo buffer) and is refilled with the tile of s3; the other set holds s2.  false after the block's last step.
+        auto iter = [&](auto SET) -> bool {
+            constexpr int set = decltype(SET)::value;
+            m3 = (s3.w.n != s2.w.n || s3.w.oz0 != s2.w.oz0 || s3.w.oy0 != s2.w.oy0 || s3.w.ox0 != s2.w.ox0) ? inside_mask(s3.w) : m2;
+            const float* b3 = tile_base(s3.w, s3.cb);
+            NM_Q2_WAIT_SET(set, 9, 12);                             // only the other set's NP + NA loads are younger
+            fix_affine(SET);
+            static_for<NP>([&](auto K) { convert(hb ^ 1, m1, K, SET); load_piece(b3, m3, K, SET); });
+            load_affine(s3.w, s3.cb, SET);
+            lds_barrier();                                          // publishes the tile of s1; the MFMA waves are done with `cur`
+            if (cur.cb == C16T - 1) lds_barrier();                  // the MFMA waves' epilogue barrier of a finished brick
+            if (!has1) return false;
+            cur = s1; s1 = s2; has1 = has2; s2 = s3; has2 = has3; has3 = has3 && advance(s3);
+            m1 = m2; m2 = m3; hb ^= 1;
+            return true;
+        };
+        for (;;) { if (!iter(ic<0>{})) break; if (!iter(ic<1>{})) break; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // loads still in flight for steps that do not exist
+        return;
+    }
+
+    // =============================== MFMA waves ===============================================================
+    __builtin_amdgcn_s_setprio(3);
+    int arow0;
+    {
+        const int c = l31 >> 2;
+        const int x = (((0x96 >> c) & 1) << 2) + (l31 & 3), z = c >> 1;
+        arow0 = z * ZP + (2 * wave) * HX + x;
+    }
+    const int vx = ((((0x96 >> (l31 >> 2)) & 1) << 2) + (l31 & 3)), vz = l31 >> 3;
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+    int hb = 0;
+    lds_barrier();                                                  // the producers' prologue (weights, bias, first tile)
+
+    constexpr int YO = HX * 16;                                     // brick row 2 wave -> 2 wave + 1
+    half8 a0[4], a1[4], b0[4];                                      // operands of four taps in flight (index = tap % 4)
+    for (;;) {
+        Step nxt = cur;
+        const bool has_next = advance(nxt);
+        const unsigned va = (unsigned)(size_t)(ldh + hb * 2 * HV + h * HV + arow0);
+        unsigned vbz[3];
+        vbz[0] = (unsigned)(size_t)(ldb + cur.cb * 64 + h * 32 + l31);
+        vbz[1] = vbz[0] + 9 * TS * 16; vbz[2] = vbz[0] + 18 * TS * 16;
+        // taps 0, 1, 2 (the tile was published by the barrier just passed)
+        a0[0] = lds_read16_untracked<0>(va);  a1[0] = lds_read16_untracked<YO>(va);      b0[0] = lds_read16_untracked<0>(vbz[0]);
+        a0[1] = lds_read16_untracked<16>(va); a1[1] = lds_read16_untracked<16 + YO>(va); b0[1] = lds_read16_untracked<TS * 16>(vbz[0]);
+        a0[2] = lds_read16_untracked<32>(va); a1[2] = lds_read16_untracked<32 + YO>(va); b0[2] = lds_read16_untracked<2 * TS * 16>(vbz[0]);
+        static_for<27>([&](auto TT) {
+            constexpr int tt = decltype(TT)::value, i = tt % 4, u = tt + 3, j = u % 4;
+            // in-order LDS returns: at most the reads of the next two taps may still be outstanding
+            if constexpr (tt < 25) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[i]), "+v"(a1[i]), "+v"(b0[i]) :: "memory");
+            else if constexpr (tt == 25) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a0[i]), "+v"(a1[i]), "+v"(b0[i]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[i]), "+v"(a1[i]), "+v"(b0[i]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr bool more = u < 27;
+            constexpr int AO = more ? ((u / 9) * ZP + ((u % 9) / 3) * HX + (u % 3)) * 16 : 0;
+            constexpr int BO = more ? (u % 9) * TS * 16 : 0;
+            constexpr int BZ = more ? u / 9 : 0;
+            NM_MFMA2(acc[0], b0[i], a0[i]); if constexpr (more) { a0[j] = lds_read16_untracked<AO>(va); a1[j] = lds_read16_untracked<AO + YO>(va); }
+            NM_MFMA2(acc[1], b0[i], a1[i]); if constexpr (more) b0[j] = lds_read16_untracked<BO>(vbz[BZ]);
+        });
+        asm volatile("s_barrier" ::: "memory");                     // the producers publish the next step's tile
+        __builtin_amdgcn_sched_barrier(0);
+        if (cur.cb == C16T - 1) {
+            // ---- epilogue of the finished brick (exposed): transposed accumulators -> 16-byte stores, DPP partial sums
+            const Work& w = cur.w;
+            float s1[16], s2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const size_t dst = ((((size_t)w.n * p.OD + w.oz0 + vz) * p.OH + w.oy0 + 2 * wave + mt) * p.OW + w.ox0 + vx) * (size_t)p.Cout + 4 * h;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + 8 * k4 + 4 * h);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[mt][4 * k4 + e] + b4[e];
+                        s1[4 * k4 + e] += v[e]; s2[4 * k4 + e] += v[e] * v[e];
+                        acc[mt][4 * k4 + e] = 0.f;
+                    }
+                    nm_st4<OH>(p.out, dst + 8 * k4, v);
+                }
+            }
+            if (p.part) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = dpp_sum32(s1[r]), b = dpp_sum32(s2[r]);
+                    if (l31 == 16) *reinterpret_cast<f32x2*>(red + (wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2) = f32x2{a, b};
+                }
+            }
+            lds_barrier();                                          // (matched by the producers)
+            if (p.part && tid < 32) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a += red[(q * 32 + tid) * 2]; b += red[(q * 32 + tid) * 2 + 1]; }
+                const int br = ((w.oz0 >> 2) * nby + (w.oy0 >> 3)) * nbx + (w.ox0 >> 3);
+                float* dp = p.part + (((size_t)w.n * nbr + br) * p.Cout + tid) * 2;
                 dp[0] = a; dp[1] = b;
             }
         }
@@ -3144,6 +3426,35 @@ int launch_f16q2_impl(const ConvParams& p_in, int work_items, hipStream_t s) {
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16q2 launch");
 }
+// the one-product modes' kernel for the 32-output-channel layers (conv_f16r_kernel: resident weights); Cin = 16 C16T
+template <int IO, int C16T>
+int launch_f16r_impl(const ConvParams& p_in, int work_items, hipStream_t s) {
+    ConvParams p = p_in;
+    static NmDeviceOnce attr_set;
+    if (!attr_set.done()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16r_kernel<IO, C16T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16r)");
+        attr_set.mark();
+    }
+    if (g_num_cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nm_check_hip(hipErrorUnknown, "device query");
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const size_t lds_bytes = (size_t)4 * 600 * 16 + (size_t)27 * C16T * 64 * 16 + (size_t)(256 + 32) * sizeof(float);
+    ProfRec rec;
+    rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
+    const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
+    if (prof_rec) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.variant = 15;
+        (void)hipEventRecord(rec.a, s);
+    }
+    dim3 grid((unsigned)min(work_items, nm_ls().conv_wgs > 0 ? min(nm_ls().conv_wgs, g_num_cus) : g_num_cus));
+    choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);
+    hipLaunchKernelGGL((conv_f16r_kernel<IO, C16T>), grid, dim3(512), lds_bytes, s, p);
+    if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
+    return nm_check_hip(hipGetLastError(), "conv_f16r launch");
+}
 template <bool UP2>
 int launch_f16p2(const ConvParams& p, size_t lds_bytes, int work_items, hipStream_t s) {
     const int io = (p.in_h ? 1 : 0) | (p.out_h ? 2 : 0);
@@ -3386,6 +3697,14 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
         p.w = static_cast<const float*>(w_packed16);
         const size_t lds_bytes = (size_t)8 * 600 * 16 + (size_t)2 * 9 * 4 * 64 * 16 + (size_t)(512 + g.Cout) * sizeof(float);
         return launch_f16p2<false>(p, lds_bytes, work, s);
+    }
+    if (nm_ls().conv_mode == 1 && nm_ls().single && nm_ls().f16r && nm_ls().f16p && w_packed16 && (in.C == 32 || in.C == 64) && g.ks == 3 && g.stride == 1 &&
+        g.pad == 1 && !g.up2 && g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout == 32 && (p.in_h != 0) == (p.out_h != 0)) {
+        // one-product modes, 32 output channels: the layer's weights stay in LDS (conv_f16r_kernel)
+        const int work = in.N * (g.OD / 4) * (g.OH / 8) * (g.OW / 8);
+        p.w = static_cast<const float*>(w_packed16);
+        if (in.C == 32) return p.in_h ? launch_f16r_impl<3, 2>(p, work, s) : launch_f16r_impl<0, 2>(p, work, s);
+        return p.in_h ? launch_f16r_impl<3, 4>(p, work, s) : launch_f16r_impl<0, 4>(p, work, s);
     }
     if (nm_ls().conv_mode == 1 && nm_ls().f16p && w_packed16 && in.C % 16 == 0 && g.ks == 3 && g.stride == 1 && g.pad == 1 && !g.up2 &&
         g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16 && g.Cout % 32 == 0 && (nm_ls().f16p == 1 || nm_ls().f16p_all || g.Cout == 32)) {

@@ -1417,7 +1417,8 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
             // block behind the k-step's MFMAs.  g 0 dY request, 10-11 / 16-17 the two X requests, 18-31 / 32-45 / 46-59 the conversions of
             // dY / X0 / X1 (14 pieces each: table reads, 4 x (affine + slope, max + mask, split), stores).
             f32x4 ca, cb_, csa, cha;
-            float cka = 0.f, ckb = 0.f, cslope = 1.f, t0 = 0.f, t1 = 0.f, u0 = 0.f, u1 = 0.f;
+            float cka = 0.f, ckb = 0.f, cslope = 1.f;
+            f32x2 tt = f32x2{0.f, 0.f}, uu = tt;             // a channel pair through the affine / slope / mask as PACKED fp32 instructions (two elements per issue slot)
             unsigned ch[4], cl[4];
             const float* xsrc = nullptr; bool xin = false;
             auto piece = [&](auto GG) __attribute__((always_inline)) {
@@ -1468,16 +1469,18 @@ __device__ __forceinline__ void wgrad16z_run(const WgradParams& p, const int w) 
                                 const float* t = item == 0 ? dtab + 8 * oct : xtab + xn * 64 + 8 * oct;
                                 csa = *reinterpret_cast<const f32x4*>(t + 4); cha = *reinterpret_cast<const f32x4*>(t + 36);
                             }
+                            const f32x2 s2 = f32x2{csa[e], csa[e + 1]}, h2 = f32x2{cha[e], cha[e + 1]};
                             if constexpr (H16) {        // channel pair j of the raw item: dword j
                                 const unsigned u = nm_fbits(ca[j]);
-                                t0 = fmaf(nm_bf_lo(u), csa[e], cha[e]); t1 = fmaf(nm_bf_hi(u), csa[e + 1], cha[e + 1]);
-                            } else if constexpr (j < 2) { t0 = fmaf(ca[e], csa[e], cha[e]); t1 = fmaf(ca[e + 1], csa[e + 1], cha[e + 1]); }
-                            else { t0 = fmaf(cb_[e], csa[e], cha[e]); t1 = fmaf(cb_[e + 1], csa[e + 1], cha[e + 1]); }
-                            u0 = t0 * cslope; u1 = t1 * cslope;
+                                tt = f32x2{nm_bf_lo(u), nm_bf_hi(u)};
+                            } else if constexpr (j < 2) tt = f32x2{ca[e], ca[e + 1]};
+                            else tt = f32x2{cb_[e], cb_[e + 1]};
+                            tt = __builtin_elementwise_fma(tt, s2, h2);
+                            uu = tt * f32x2{cslope, cslope};
                         } else if constexpr (part == 1) {
                             const float k = j < 2 ? cka : ckb;
-                            t0 = fmaxf(t0, u0) * k; t1 = fmaxf(t1, u1) * k;
-                        } else ch[j] = pack_split(t0, t1, cl[j]);
+                            tt = f32x2{fmaxf(tt[0], uu[0]), fmaxf(tt[1], uu[1])} * f32x2{k, k};
+                        } else ch[j] = pack_split(tt[0], tt[1], cl[j]);
                     } else {
                         char* hi; char* lo_;
                         if constexpr (item == 0) { hi = lds8 + WZ_D0 + ndbuf + tid * 16; lo_ = hi + WT_DB; }

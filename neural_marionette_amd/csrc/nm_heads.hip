@@ -197,12 +197,15 @@ __device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* 
     a = (sh[0] + sh[3]) + (sh[6] + sh[9]); b = (sh[1] + sh[4]) + (sh[7] + sh[10]); c = (sh[2] + sh[5]) + (sh[8] + sh[11]);
 }
 
-// grid (ceil(G3/256), F).  x: raw 32-channel tensor with pending GN affine + lrelu.
+// grid (ceil(G3 / 1024), F).  x: raw 32-channel tensor with pending GN affine + lrelu.  A block walks FOUR 256-voxel tiles (rounds
+// 1-4: one, with three block reductions behind it - 0.49 ms for the 1.07 GB of a 32-frame pass at 64^3, 2.2 TB/s; the reductions and the
+// 32 KB a block moved between two barriers were the kernel), two tiles' loads in flight, one three-way block reduction at the end.
+#define NM_TAIL_TILES 4
 __global__ __launch_bounds__(256) void decoder_tail_kernel(TensorRef x, const float* __restrict__ w14, const float* __restrict__ first_frames,
                                                            int ff_stride_frames, int T, const float* __restrict__ target,
                                                            const float* __restrict__ keypoints, int K, int G,
                                                            float* __restrict__ recon, float* __restrict__ part) {
-    __shared__ float sh[256];
+    __shared__ float sh[12];
     __shared__ float kp[32 * 3];
     const int f = blockIdx.y, b = f / T;
     const size_t G3 = (size_t)G * G * G;
@@ -213,31 +216,73 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TensorRef x, const fl
     // 8 (l & 7) + (l >> 3) of its wave's 64.
     const bool coop = (C == 32) && (G3 % 256 == 0);
     const int lane = threadIdx.x & 63;
-    const size_t v = coop ? blockIdx.x * (size_t)256 + (threadIdx.x & ~63) + (lane & 7) * 8 + (lane >> 3)
-                          : blockIdx.x * (size_t)256 + threadIdx.x;
+    const size_t tile0 = blockIdx.x * (size_t)(256 * NM_TAIL_TILES);
     if (keypoints && threadIdx.x < K * 3) kp[threadIdx.x] = keypoints[((size_t)f * K + threadIdx.x / 3) * 4 + threadIdx.x % 3];
     __syncthreads();
     float bce = 0.f, cham = 0.f, cnt = 0.f;
-    if (v < G3) {
-        float acc = 0.f;
-        if (coop) {
-            const int cq = (lane & 7) * 4;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + cq);
-            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + cq);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w14 + cq);
-            const size_t pw = ((size_t)f * G3 + blockIdx.x * (size_t)256 + (threadIdx.x & ~63) + (lane >> 3)) * C + cq;      // element offset (x may be bf16)
+    const float bias = w14[C];
+    // the voxel's tail: tanh, first-frame residual, sigmoid, losses
+    auto finish = [&](size_t v, float acc) __attribute__((always_inline)) {
+        acc += bias;
+        const float ff = first_frames[((size_t)b * ff_stride_frames) * G3 + v];
+        const float pre = 10.0f * ((tanhf(acc) + ff) - 0.5f);
+        const float p = 1.0f / (1.0f + expf(-pre));
+        recon[(size_t)f * G3 + v] = p;
+        if (target) {
+            const float y = target[(size_t)f * G3 + v];
+            bce += (y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f);
+            if (keypoints && y != 0.f) {
+                int xx = (int)(v % G), yy = (int)((v / G) % G), zz = (int)(v / ((size_t)G * G));
+                float cz = lin_coord(zz, G), cy = lin_coord(yy, G), cx = lin_coord(xx, G);
+                float best = INFINITY;
+                for (int k = 0; k < K; ++k) {
+                    float d0 = cz - kp[k * 3], d1 = cy - kp[k * 3 + 1], d2 = cx - kp[k * 3 + 2];
+                    best = fminf(best, (d0 * d0 + d1 * d1) + d2 * d2);
+                }
+                cham += best * y; cnt += y;
+            }
+        }
+    };
+    if (coop) {
+        const int cq = (lane & 7) * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(x.scale + (size_t)f * C + cq);
+        const f32x4 sh4 = *reinterpret_cast<const f32x4*>(x.shift + (size_t)f * C + cq);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w14 + cq);
+        auto fetch = [&](size_t t0, f32x4 (&a)[8]) __attribute__((always_inline)) {
+            const size_t pw = ((size_t)f * G3 + t0 + (threadIdx.x & ~63) + (lane >> 3)) * C + cq;      // element offset (x may be bf16)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = nm_ld4(x.p, pw + (size_t)i * 8 * C, x.h);
+        };
+        auto dot = [&](const f32x4 (&a)[8]) __attribute__((always_inline)) {
+            float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                f32x4 a = nm_ld4(x.p, pw + (size_t)i * 8 * C, x.h);
                 float part4 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) part4 += lrelu(a[j] * sc[j] + sh4[j], x.slope) * wv[j];
+                for (int j = 0; j < 4; ++j) part4 += lrelu(a[i][j] * sc[j] + sh4[j], x.slope) * wv[j];
                 part4 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part4), 0xB1, 0xf, 0xf, true));
                 part4 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part4), 0x4E, 0xf, 0xf, true));
                 part4 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part4), 0x141, 0xf, 0xf, true));
                 acc = ((lane & 7) == i) ? part4 : acc;
             }
-        } else {
+            return acc;
+        };
+        const size_t vin = (threadIdx.x & ~63) + (lane & 7) * 8 + (lane >> 3);                          // the lane's voxel inside a tile
+        for (int t = 0; t < NM_TAIL_TILES; t += 2) {
+            const size_t ta = tile0 + (size_t)t * 256, tb = ta + 256;
+            if (ta >= G3) break;
+            f32x4 a[8], c[8];
+            const bool two = tb < G3;
+            fetch(ta, a);
+            if (two) fetch(tb, c);
+            finish(ta + vin, dot(a));
+            if (two) finish(tb + vin, dot(c));
+        }
+    } else {
+        for (int t = 0; t < NM_TAIL_TILES; ++t) {
+            const size_t v = tile0 + (size_t)t * 256 + threadIdx.x;
+            if (v >= G3) break;
+            float acc = 0.f;
             const size_t px = ((size_t)f * G3 + v) * C;
             for (int c = 0; c < C; c += 4) {
                 f32x4 a = nm_ld4(x.p, px + c, x.h);
@@ -248,32 +293,14 @@ __global__ __launch_bounds__(256) void decoder_tail_kernel(TensorRef x, const fl
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc += lrelu(a[j], x.slope) * wv[j];
             }
-        }
-        acc += w14[C];
-        const float ff = first_frames[((size_t)b * ff_stride_frames) * G3 + v];
-        const float pre = 10.0f * ((tanhf(acc) + ff) - 0.5f);
-        const float p = 1.0f / (1.0f + expf(-pre));
-        recon[(size_t)f * G3 + v] = p;
-        if (target) {
-            const float y = target[(size_t)f * G3 + v];
-            bce = (y - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - y * fmaxf(logf(p), -100.0f);
-            if (keypoints && y != 0.f) {
-                int xx = (int)(v % G), yy = (int)((v / G) % G), zz = (int)(v / ((size_t)G * G));
-                float cz = lin_coord(zz, G), cy = lin_coord(yy, G), cx = lin_coord(xx, G);
-                float best = INFINITY;
-                for (int k = 0; k < K; ++k) {
-                    float d0 = cz - kp[k * 3], d1 = cy - kp[k * 3 + 1], d2 = cx - kp[k * 3 + 2];
-                    best = fminf(best, (d0 * d0 + d1 * d1) + d2 * d2);
-                }
-                cham = best * y; cnt = y;
-            }
+            finish(v, acc);
         }
     }
     if (part) {
-        float s0 = block_sum256(bce, sh), s1 = block_sum256(cham, sh), s2 = block_sum256(cnt, sh);
+        block_sum3(bce, cham, cnt, sh);
         if (threadIdx.x == 0) {
             float* dst = part + ((size_t)f * gridDim.x + blockIdx.x) * 3;
-            dst[0] = s0; dst[1] = s1; dst[2] = s2;
+            dst[0] = bce; dst[1] = cham; dst[2] = cnt;
         }
     }
 }
@@ -589,7 +616,7 @@ int nm_launch_combined(const float* table, const float* keypoints, const float* 
     return nm_check_hip(hipGetLastError(), "combined launch");
 }
 
-int nm_tail_blocks(int G) { return (int)(((size_t)G * G * G + 255) / 256); }
+int nm_tail_blocks(int G) { return (int)(((size_t)G * G * G + 256 * NM_TAIL_TILES - 1) / (256 * NM_TAIL_TILES)); }
 
 int nm_launch_decoder_tail(const TensorRef& x, const float* w14, const float* first_frames, int ff_stride_frames, int T,
                            const float* target, const float* keypoints, int K, int G, float* recon, float* part,

@@ -25,7 +25,8 @@
 // ---- what a training forward leaves behind for nm_detector_backward (all pointers into ctx->ws_t or caller buffers) --------
 struct ConvRec {
     const ConvW* w = nullptr; const NormW* gn = nullptr;
-    TensorRef in{}, out{};                       // lazy input / lazy output (raw conv result + pending GN affine + slope)
+    TensorRef in{}, out{};
+    TensorRef upmat{};        // up2 layers whose forward materialised the upsampled (activated) input: that tensor (p == nullptr: fused staging, the backward pass rebuilds it)                       // lazy input / lazy output (raw conv result + pending GN affine + slope)
     const float* fpart = nullptr; int nblk = 0;  // forward GroupNorm partial sums of the conv epilogue
     const double* chsum = nullptr;               // their per-channel totals (left by the forward finalisation when it can)
     int stride = 1, pad = 0; bool up2 = false;
@@ -345,6 +346,19 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
     g.Cout = w.Cout; g.Co_pad = w.Co_pad; g.up2c = up2 ? w.wup : nullptr;
     const size_t ov = (size_t)g.OD * g.OH * g.OW;
     const int oh = out_buf ? 0 : n.h16(ov);                    // (a caller-named output buffer is always fp32)
+    // One-product training modes, a fused-upsample layer with 32 outputs (the decoder's 64 -> 32 @64^3): the upsampled, activated input
+    // is materialised ONCE here - the backward pass needs exactly that tensor for the weight gradient and used to rebuild it - and the
+    // layer runs as a plain conv on conv_f16r (resident weights) instead of the composite-weight kernel's one-product instantiation
+    // (conv_up2c<.., 3>: 2 x 2.4 ms per step at 0.44 of the time on the matrix pipe, profiles/r05_pmc_mfma_train_bf16.json).
+    TensorRef src = in;
+    const bool mat = up2 && rec && n.keep && !out_buf && nm_ls().single && nm_ls().up2_mat && nm_ls().f16r && w.wp16 && w.ks == 3 && stride == 1 && pad == 1 &&
+                     w.Cout == 32 && (in.C == 32 || in.C == 64) && g.OD % 4 == 0 && g.OH % 8 == 0 && g.OW % 8 == 0 && g.OD >= 16;
+    if (mat) {
+        float* upb = n.alloc_e((size_t)in.N * ov * in.C, oh);
+        if (n.live()) n.run(nm_launch_upsample2(in, upb, n.s, oh));
+        src = with_h(mk(upb, in.N, g.OD, g.OH, g.OW, in.C), oh);
+        g.up2 = 0; g.up2c = nullptr;
+    }
     float* out = out_buf ? out_buf : n.alloc_e((size_t)in.N * ov * w.Cout, oh);
     float *part = nullptr, *scale = nullptr, *shift = nullptr;
     const int nblk = nm_conv_blocks_per_frame(g, in.C);
@@ -357,14 +371,14 @@ TensorRef conv_gn(Net& n, const TensorRef& in, const ConvW& w, const NormW* gn, 
     if (n.live()) {
         if (in.C != w.Cin_pad) { nm_set_error("conv_gn: input has %d channels, layer expects %d", in.C, w.Cin_pad); n.rc = NM_ERR_STATE; }
         else {
-            n.run(nm_launch_conv(in, w.wp, w.bias, out, g, part, n.s, w.Cin, w.wp16, oh));
+            n.run(nm_launch_conv(src, w.wp, w.bias, out, g, part, n.s, w.Cin, w.wp16, oh));
             if (gn) n.run(nm_launch_gn_finalize(part, in.N, nblk, w.Cout, gn->groups, (double)ov * (w.Cout / gn->groups),
                                                 gn->gamma, gn->beta, 1e-5f, scale, shift, n.s, chsum));
             if (gn && nm_ls().gn_diag && !oh) n.run(nm_launch_gn_direct(out, in.N, (int)ov, w.Cout, gn->groups, gn->gamma, gn->beta, 1e-5f, scale, shift, n.s, chsum));
         }
     }
     TensorRef o = with_h(mk(out, in.N, g.OD, g.OH, g.OW, w.Cout, scale, shift, slope_after), oh);
-    if (rec) { rec->w = &w; rec->gn = gn; rec->in = in; rec->out = o; rec->fpart = part; rec->nblk = nblk; rec->chsum = chsum; rec->stride = stride; rec->pad = pad; rec->up2 = up2; }
+    if (rec) { rec->w = &w; rec->gn = gn; rec->in = in; rec->out = o; rec->fpart = part; rec->nblk = nblk; rec->chsum = chsum; rec->stride = stride; rec->pad = pad; rec->up2 = up2; rec->upmat = mat ? src : TensorRef{}; }
     return o;
 }
 
@@ -900,7 +914,8 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
     const TensorRef dyT = plain(dy, r.out);
     const TensorRef dyS = ds.apply(b, dyT);
     // weight gradient; on the third stream when everything it reads outlives this call (Bwd::async_w)
-    const size_t up_floats = r.up2 ? Bwd::r64(Bwd::fl(numel_of(in) * 8, h_fine)) : 0;
+    const bool up_rebuild = r.up2 && !r.upmat.p;         // (the forward kept the upsampled input: conv_gn, one-product modes)
+    const size_t up_floats = up_rebuild ? Bwd::r64(Bwd::fl(numel_of(in) * 8, h_fine)) : 0;
     const size_t wg_floats = nm_wgrad_ws_floats(in.N, r.out.D, r.out.H, r.out.W, w.Cout, in.C, w.ks, r.stride);
     bool side = b.async_w && slot >= 0 && (!ds.amax || ds.pool) && !padded;
     if (side && b.ws.dry) b.need_scratch = std::max(b.need_scratch, up_floats + Bwd::r64(wg_floats));
@@ -913,8 +928,8 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
             hipStream_t s3 = b.c->stream3;
             b.run(nm_check_hip(hipEventRecord(b.c->ev_dy, b.s), "backward: dY-ready event"));
             b.run(nm_check_hip(hipStreamWaitEvent(s3, b.c->ev_dy, 0), "backward: weight-gradient stream wait"));
-            TensorRef a = in;
-            if (r.up2) {
+            TensorRef a = r.up2 && !up_rebuild ? r.upmat : in;
+            if (up_rebuild) {
                 b.run(nm_launch_upsample2(in, b.sscratch, s3, h_fine));
                 a = with_h(mk(b.sscratch, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C), h_fine);
             }
@@ -927,8 +942,8 @@ float* conv_bwd(Bwd& b, const ConvRec& r, const float* dA, bool need_din, const 
     if (side && side_first) side_wgrad();
     if (!side) {
         const size_t m2 = b.ws.mark();
-        TensorRef a = in;
-        if (r.up2) {
+        TensorRef a = r.up2 && !up_rebuild ? r.upmat : in;
+        if (up_rebuild) {
             float* upb = b.alloc(Bwd::fl(numel_of(in) * 8, h_fine));
             if (b.live()) b.run(nm_launch_upsample2(in, upb, b.s, h_fine));
             a = with_h(mk(upb, in.N, 2 * in.D, 2 * in.H, 2 * in.W, in.C), h_fine);

@@ -66,6 +66,9 @@ CONV_CASES = [
     (64, 32, 3, 1, 1, 16, 40, True, 2),
     (16, 32, 3, 1, 1, 24, 2, False, 2),
     (32, 96, 3, 1, 1, 16, 33, False, 3),
+    # conv_f16r in the one-product mode (32 output channels, weights resident in LDS; Cin = 64 is the (64, 32, .., 16, 40) case above)
+    (32, 32, 3, 1, 1, 32, 3, True, 2),
+    (32, 32, 3, 1, 1, 16, 5, False, 2),
     # conv_pool_f16s (k2 s2, lanes load their own operands): two N tiles, ragged bricks, Cout not a multiple of 32
     (64, 64, 2, 2, 0, 16, 2, True, 4),
     (32, 32, 2, 2, 0, 20, 2, True, 2),

@@ -45,8 +45,8 @@ FWD_CASES = [
     # Cin, Cout, ks, stride, pad, size, N, up2, in16, out16, kernel the case is meant to reach
     (64, 64, 3, 1, 1, 32, 2, 0, 1, 1, "conv_f16p2"),
     (32, 64, 3, 1, 1, 16, 3, 0, 1, 1, "conv_f16p2 (two channel chunks, several bricks per workgroup)"),
-    (32, 32, 3, 1, 1, 32, 2, 0, 1, 1, "conv_f16p"),
-    (64, 32, 3, 1, 1, 16, 5, 0, 1, 1, "conv_f16p (four chunks)"),
+    (32, 32, 3, 1, 1, 32, 2, 0, 1, 1, "conv_f16r (one-product modes, 32 output channels: resident weights)"),
+    (64, 32, 3, 1, 1, 16, 5, 0, 1, 1, "conv_f16r (four chunks)"),
     (32, 64, 1, 1, 0, 32, 2, 0, 1, 1, "conv_f16s k1, two N tiles"),
     (64, 32, 1, 1, 0, 32, 2, 0, 1, 1, "conv_f16s k1, one N tile"),
     (128, 64, 3, 1, 1, 8, 2, 1, 0, 1, "conv_f16s fused upsample, fp32 in / bf16 out"),
@@ -362,7 +362,8 @@ def test_config3_in_its_named_precision_at_the_bench_shape():
     """BASELINE config 3's per-GPU shard in bfloat16 storage: 64^3, T = 16, B = 4.  No oracle at this size: (1) batch additivity (the
     4-clip gradient is the mean of the single-clip gradients: every loss is a mean over clips, GroupNorm is per frame) within the
     mode's accuracy, (2) two runs bit-identical, (3) whole-gradient L2 distance to the fp32-storage 'f16' mode at the same size,
-    (4) the training arena of the context (nm_ctx_memory) at most 11 GB - half of fp32 storage's 20.5 GB."""
+    (4) the training arena of the context (nm_ctx_memory) at most 13 GB against fp32 storage's 20.5 GB (10.6 GB of 16-bit tape, and the
+    decoder's upsampled 64^3 x 64-channel input - 2.1 GB - which the forward materialises once for its conv and its weight gradient)."""
     from neural_marionette_amd import _lib
     o, sd, vox = _setup(G=64, B=4, T=16, seed=91)
     net = None
@@ -385,7 +386,7 @@ def test_config3_in_its_named_precision_at_the_bench_shape():
     mem = (C.c_size_t * 4)()
     _lib.check(net._engine.ctx.lib.nm_ctx_memory(net._engine.ctx.handle, mem), "ctx_memory")
     print("bf16 storage, 64^3 B=4 T=16: training arena %.2f GB, weight-gradient side block %.2f GB" % (mem[1] / 1e9, mem[2] / 1e9))
-    assert mem[1] <= 11e9, mem[1]
+    assert mem[1] <= 13e9, mem[1]
     net = None
     acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in g_all.items()}
     for b in range(4):

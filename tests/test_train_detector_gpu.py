@@ -556,22 +556,18 @@ def test_gradient_is_bit_identical_over_many_evaluations():
 
 def test_seed_103_deviation_is_rounding_noise_amplification():
     """K = 32, seed 103: every HIP conv mode lands 3.3e-3 (relative to the tensor's largest entry) from the fp64 oracle on
-    the early layers of the per-frame net, where the neighbouring seeds give 1e-4 and torch's own fp32 autograd 6.5e-4.  Not a
-    selection / tie (checked: the affinity gradients agree to 1e-9, the intensity max over K has a 10 % margin, and the deviation
-    appears under the reconstruction loss alone), but the amplification of one-ulp forward differences through the GroupNorm backward
-    passes: measured HERE by evaluating the same gradient a second time with every GroupNorm scale / shift recomputed from the stored
-    tensor in fp64 (NM355_GN_DIAG=1, a diagnostic switch read when a context is created; the two sets of statistics differ by
-    <= 1.7e-7 relative, i.e. one fp32 ulp, on all 68 layers).  The distance between those two legitimate fp32 evaluations is the noise
-    amplitude of this case; the distance of either from the fp64 oracle must be of that size."""
+    the early layers of the per-frame net, where the neighbouring seeds give 1e-4.  Not a selection / tie (checked: the affinity
+    gradients agree to 1e-9, the intensity max over K has a 10 % margin, the deviation appears under the reconstruction loss alone):
+    the gradient of THIS weight set is ill-conditioned, measured here in fp64 alone, free of any fp32 evaluation order - the fp64
+    oracle's gradient moves by ~1e-3 (same metric) when every weight is perturbed by one fp32 ulp (6e-8 relative), against 1.6e-6 for
+    seed 104 under the same perturbation; torch's own fp32 autograd of the oracle sits 3.1e-3 from fp64 at seed 103 and 2e-4 at seed
+    104.  So the distance of a correct fp32 evaluation from fp64 is a few times that 1e-3 here, whatever its summation order.
+    (Rounds 2-4 measured the noise instead as the distance between two HIP evaluations whose GroupNorm statistics differ by one ulp
+    (NM355_GN_DIAG=1): 5e-4 ... 3e-3 in those trees, but 7.9e-5 after round 5 reordered the heat-map sums - the amplification of ONE
+    particular one-ulp change depends on the rounding realisation, so that figure is printed, not asserted.)"""
     import os
     o, sd, vox = _setup(G=32, B=1, T=3, seed=103, K=32)
     _, ref64, _ = _oracle_grads(o, sd, vox, AIST, double=True)
-    l_n, g_n, _ = _hip_grads(o, sd, vox, AIST, mode="fp32")
-    os.environ["NM355_GN_DIAG"] = "1"
-    try:
-        l_d, g_d, _ = _hip_grads(o, sd, vox, AIST, mode="fp32")
-    finally:
-        del os.environ["NM355_GN_DIAG"]
     gmax = max(r.abs().max().item() for r in ref64.values())
 
     def dist(a, b):
@@ -580,8 +576,31 @@ def test_seed_103_deviation_is_rounding_noise_amplification():
             scale = max(r.abs().max().item(), 1e-6 * gmax)
             w = max(w, (a[k].double() - b[k].double()).abs().max().item() / scale)
         return w
+    # conditioning in fp64: weights perturbed by one fp32 ulp (relative), rounded to fp32, evaluated in fp64
+    cond = []
+    for draw in (1, 2):
+        gen = torch.Generator().manual_seed(draw)
+        sdp = {k: ((v.double() * (1 + (torch.rand(v.shape, generator=gen, dtype=torch.float64) * 2 - 1) * 6e-8)).float() if v.is_floating_point() else v)
+               for k, v in sd.items()}
+        _, gp, _ = _oracle_grads_uncached(o, sdp, vox, AIST, double=True)
+        cond.append(dist(gp, ref64))
+    o4, sd4, vox4 = _setup(G=32, B=1, T=3, seed=104, K=32)
+    _, ref4, _ = _oracle_grads_uncached(o4, sd4, vox4, AIST, double=True)
+    gen = torch.Generator().manual_seed(1)
+    sd4p = {k: ((v.double() * (1 + (torch.rand(v.shape, generator=gen, dtype=torch.float64) * 2 - 1) * 6e-8)).float() if v.is_floating_point() else v)
+            for k, v in sd4.items()}
+    _, g4p, _ = _oracle_grads_uncached(o4, sd4p, vox4, AIST, double=True)
+    g4max = max(r.abs().max().item() for r in ref4.values())
+    cond104 = max((g4p[k].double() - r.double()).abs().max().item() / max(r.abs().max().item(), 1e-6 * g4max) for k, r in ref4.items())
+    l_n, g_n, _ = _hip_grads(o, sd, vox, AIST, mode="fp32")
+    os.environ["NM355_GN_DIAG"] = "1"
+    try:
+        l_d, g_d, _ = _hip_grads(o, sd, vox, AIST, mode="fp32")
+    finally:
+        del os.environ["NM355_GN_DIAG"]
     noise, d_n, d_d = dist(g_n, g_d), dist(g_n, ref64), dist(g_d, ref64)
-    print("seed 103: two fp32 evaluations (GroupNorm statistics one ulp apart) differ by %.2e; vs fp64: %.2e and %.2e; losses %.8f / %.8f" % (noise, d_n, d_d, l_n, l_d))
+    print("seed 103: fp64 gradient under a one-ulp weight perturbation moves by %.2e / %.2e (seed 104: %.2e); HIP fp32 vs fp64: %.2e and %.2e "
+          "(GroupNorm statistics one ulp apart; the two differ by %.2e); losses %.8f / %.8f" % (cond[0], cond[1], cond104, d_n, d_d, noise, l_n, l_d))
     assert abs(l_n - l_d) <= 1e-6 * abs(l_n)                  # the forward is insensitive to the one-ulp difference ...
-    assert noise > 5e-4                                        # ... the gradient of this case is not (neighbouring seeds: 1e-4 from fp64)
-    assert max(d_n, d_d) <= 2.0 * noise + 1e-3
+    assert min(cond) > 3e-4 and cond104 < 3e-5                 # ... this case's gradient is not, in exact arithmetic (its neighbour is)
+    assert max(d_n, d_d) <= 6.0 * max(cond)                    # a few such perturbations' worth (each layer's rounding is one)
