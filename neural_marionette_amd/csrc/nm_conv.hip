@@ -2889,8 +2889,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16r_kernel(ConvParams p) {
     extern __shared__ f32x4 lds[];
     half8* ldh = reinterpret_cast<half8*>(lds);                     // [2][2][HV]
     half8* ldb = ldh + 4 * HV;                                      // [27][C16T][2][32]
-    float* red = reinterpret_cast<float*>(ldb + 27 * TS);           // [4 waves][32 channels][2]
-    float* lbias = red + 256;                                       // [32]
+    float* red = reinterpret_cast<float*>(ldb + 27 * TS);           // [2 brick parities][4 waves][32 channels][2]
+    float* lbias = red + 512;                                       // [32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
     const int nbx = p.OW >> 3, nby = p.OH >> 3, nbz = p.OD >> 2, nbr = nbx * nby * nbz;
@@ -3041,7 +3041,6 @@ __global__ __launch_bounds__(512, 1) void conv_f16r_kernel(ConvParams p) {
             static_for<NP>([&](auto K) { convert(hb ^ 1, m1, K, SET); load_piece(b3, m3, K, SET); });
             load_affine(s3.w, s3.cb, SET);
             lds_barrier();                                          // publishes the tile of s1; the MFMA waves are done with `cur`
-            if (cur.cb == C16T - 1) lds_barrier();                  // the MFMA waves' epilogue barrier of a finished brick
             if (!has1) return false;
             cur = s1; s1 = s2; has1 = has2; s2 = s3; has2 = has3; has3 = has3 && advance(s3);
             m1 = m2; m2 = m3; hb ^= 1;
@@ -3049,6 +3048,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16r_kernel(ConvParams p) {
         };
         for (;;) { if (!iter(ic<0>{})) break; if (!iter(ic<1>{})) break; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // loads still in flight for steps that do not exist
+        lds_barrier();                                              // the MFMA waves' barrier behind the block's LAST epilogue (the others are deferred)
         return;
     }
 
@@ -3061,11 +3061,19 @@ __global__ __launch_bounds__(512, 1) void conv_f16r_kernel(ConvParams p) {
         arow0 = z * ZP + (2 * wave) * HX + x;
     }
     const int vx = ((((0x96 >> (l31 >> 2)) & 1) << 2) + (l31 & 3)), vz = l31 >> 3;
-    f32x16 acc[2];
+    // DEFERRED epilogue: a finished brick's accumulators stay where they are, the next brick's MFMAs go to a second set (32 registers -
+    // this kernel has room), and the finished brick's epilogue - bias, 16-byte stores, the GroupNorm partial sums by DPP: ~350 vector
+    // instructions per wave, in the open ~1 400 cycles per brick of 1 700 (Cin = 32) or 3 500 (Cin = 64) cycles of MFMAs - runs in
+    // pieces behind the MFMAs of the next brick's first two steps: channel quads 0, 1 during chunk 0, quads 2, 3 during chunk 1 (per
+    // quad: the two 4-value chunks mt = 0, 1, then four channel-sum reductions; half a unit per tap, a quarter behind each MFMA); the
+    // partial-sum row after chunk 1's barrier.  Same arithmetic per element and order of every sum as the exposed form.
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[st][mt][r] = 0.f;
 
     Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
     int hb = 0;
@@ -3073,20 +3081,78 @@ __global__ __launch_bounds__(512, 1) void conv_f16r_kernel(ConvParams p) {
 
     constexpr int YO = HX * 16;                                     // brick row 2 wave -> 2 wave + 1
     half8 a0[4], a1[4], b0[4];                                      // operands of four taps in flight (index = tap % 4)
-    for (;;) {
-        Step nxt = cur;
-        const bool has_next = advance(nxt);
+    Work pw = cur.w;                                                // the finished brick whose accumulators wait in the other set
+    bool pend = false;
+    int aset = 0;                                                   // accumulator set of the brick in work
+    float s1[4], s2[4];                                             // channel sums of the channel quad in work
+    f32x4 bq = f32x4{0.f, 0.f, 0.f, 0.f}, vch = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    // where a lane stores a channel's totals (+ a compile-time offset per channel): lanes 16 / 48 into the wave's row of `red`, the others
+    // into 8-byte slots behind the bias that nobody reads (no exec-mask branch inside the tap loop)
+    // (`red` is double buffered by brick parity: the row of brick k is read - part_row, by wave 0 - while the other waves may already be
+    //  storing the sums of brick k + 1 when a brick has only two steps)
+    unsigned rbase = l31 == 16 ? (unsigned)(size_t)red + (unsigned)((wave * 32 + 4 * h) * 8) : (unsigned)(size_t)(lbias + 32) + (unsigned)tid * 8u;
+    asm volatile("" : "+v"(rbase));
+    unsigned rcur = rbase;
+    int rpar = 0;
+    const unsigned bbase = (unsigned)(size_t)lbias + (unsigned)(4 * h) * 4u;
+    unsigned loff[2];                                               // the lane's element offset inside a brick's output (+ the brick's first element, + a channel offset)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { loff[mt] = (unsigned)(((vz * p.OH + 2 * wave + mt) * p.OW + vx) * p.Cout + 4 * h); asm volatile("" : "+v"(loff[mt])); }
+    size_t obrick = 0;                                              // first element of the pending brick
+    // quarter Q of unit U (0-23) of the pending brick, accumulator set SP: per channel quad k4 = U / 6 the chunks mt = 0, 1 (one value per
+    // quarter), then the quad's four channel-sum reductions
+    auto piece = [&](auto SP_, auto U_, auto Q_) __attribute__((always_inline)) {
+        constexpr int SP = decltype(SP_)::value, U = decltype(U_)::value, Q = decltype(Q_)::value;
+        constexpr int k4 = U / 6, w6 = U % 6;
+        if constexpr (w6 < 2) {
+            constexpr int mt = w6, r = 4 * k4 + Q;
+            const float v = acc[SP][mt][r] + bq[Q];
+            vch[Q] = v;
+            if constexpr (mt == 0) { s1[Q] = 0.f + v; s2[Q] = v * v; } else { s1[Q] += v; s2[Q] += v * v; }
+            acc[SP][mt][r] = 0.f;
+            if constexpr (Q == 3) nm_st4<OH>(p.out, obrick + loff[mt] + 8 * k4, vch);
+        } else {
+            constexpr int e = w6 - 2, r = 4 * k4 + e;
+            if constexpr (Q == 0) s1[e] = dpp_sum32(s1[e]);
+            if constexpr (Q == 1) s2[e] = dpp_sum32(s2[e]);
+            if constexpr (Q == 2) {
+                const unsigned rb_ = rcur; const f32x2 pr_ = f32x2{s1[e], s2[e]};           // (locals: asm operands cannot name captures of a generic lambda)
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(rb_), "v"(pr_), "n"(((r & 3) + 8 * (r >> 2)) * 8) : "memory");
+            }
+        }
+    };
+    // bias of channel quad K4: an untracked 16-byte LDS read (one more entry in the in-order LDS queue: the counted waits of the tap loop
+    // only ever wait for more), issued at least two taps ahead of its first use
+    auto load_bias = [&](auto K4_) __attribute__((always_inline)) {
+        constexpr int K4 = decltype(K4_)::value;
+        bq = __builtin_bit_cast(f32x4, lds_read16_untracked<8 * K4 * 4>(bbase));
+    };
+    auto part_row = [&]() __attribute__((always_inline)) {            // after the barrier that publishes the four waves' channel sums
+        if (p.part && tid < 32) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a += red[rpar * 256 + (q * 32 + tid) * 2]; b += red[rpar * 256 + (q * 32 + tid) * 2 + 1]; }
+            const int br = ((pw.oz0 >> 2) * nby + (pw.oy0 >> 3)) * nbx + (pw.ox0 >> 3);
+            float* dp = p.part + (((size_t)pw.n * nbr + br) * p.Cout + tid) * 2;
+            dp[0] = a; dp[1] = b;
+        }
+    };
+    // one step: MFMAs into set SC; PH = 1 / 2: units 12 (PH - 1) .. 12 (PH - 1) + 11 of the pending brick behind them (unit 12 (PH - 1) + tt / 2 at tap tt < 24)
+    auto run_step = [&](auto SC_, auto PH_) __attribute__((always_inline)) {
+        constexpr int SC = decltype(SC_)::value, PH = decltype(PH_)::value;
+        if constexpr (PH != 0) load_bias(ic<2 * (PH == 2 ? 1 : 0)>{});
         const unsigned va = (unsigned)(size_t)(ldh + hb * 2 * HV + h * HV + arow0);
         unsigned vbz[3];
         vbz[0] = (unsigned)(size_t)(ldb + cur.cb * 64 + h * 32 + l31);
         vbz[1] = vbz[0] + 9 * TS * 16; vbz[2] = vbz[0] + 18 * TS * 16;
-        // taps 0, 1, 2 (the tile was published by the barrier just passed)
         a0[0] = lds_read16_untracked<0>(va);  a1[0] = lds_read16_untracked<YO>(va);      b0[0] = lds_read16_untracked<0>(vbz[0]);
         a0[1] = lds_read16_untracked<16>(va); a1[1] = lds_read16_untracked<16 + YO>(va); b0[1] = lds_read16_untracked<TS * 16>(vbz[0]);
         a0[2] = lds_read16_untracked<32>(va); a1[2] = lds_read16_untracked<32 + YO>(va); b0[2] = lds_read16_untracked<2 * TS * 16>(vbz[0]);
-        static_for<27>([&](auto TT) {
+        static_for<27>([&](auto TT) __attribute__((always_inline)) {
             constexpr int tt = decltype(TT)::value, i = tt % 4, u = tt + 3, j = u % 4;
-            // in-order LDS returns: at most the reads of the next two taps may still be outstanding
+            // in-order LDS returns: at most the reads of the next two taps (and a bias read / channel-sum store) may still be outstanding
             if constexpr (tt < 25) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[i]), "+v"(a1[i]), "+v"(b0[i]) :: "memory");
             else if constexpr (tt == 25) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a0[i]), "+v"(a1[i]), "+v"(b0[i]) :: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[i]), "+v"(a1[i]), "+v"(b0[i]) :: "memory");
@@ -3095,53 +3161,44 @@ __global__ __launch_bounds__(512, 1) void conv_f16r_kernel(ConvParams p) {
             constexpr int AO = more ? ((u / 9) * ZP + ((u % 9) / 3) * HX + (u % 3)) * 16 : 0;
             constexpr int BO = more ? (u % 9) * TS * 16 : 0;
             constexpr int BZ = more ? u / 9 : 0;
-            NM_MFMA2(acc[0], b0[i], a0[i]); if constexpr (more) { a0[j] = lds_read16_untracked<AO>(va); a1[j] = lds_read16_untracked<AO + YO>(va); }
-            NM_MFMA2(acc[1], b0[i], a1[i]); if constexpr (more) b0[j] = lds_read16_untracked<BO>(vbz[BZ]);
+            constexpr bool pc = PH != 0 && tt < 24;
+            constexpr int U = 12 * (PH == 2 ? 1 : 0) + tt / 2, Q0 = (tt & 1) * 2;
+            NM_MFMA2(acc[SC][0], b0[i], a0[i]); if constexpr (more) { a0[j] = lds_read16_untracked<AO>(va); a1[j] = lds_read16_untracked<AO + YO>(va); }
+            if constexpr (pc) { piece(ic<SC ^ 1>{}, ic<U>{}, ic<Q0>{}); __builtin_amdgcn_sched_barrier(0); }
+            NM_MFMA2(acc[SC][1], b0[i], a1[i]); if constexpr (more) b0[j] = lds_read16_untracked<BO>(vbz[BZ]);
+            if constexpr (pc) { piece(ic<SC ^ 1>{}, ic<U>{}, ic<Q0 + 1>{}); __builtin_amdgcn_sched_barrier(0); }
+            // the phase's second channel quad: its bias two taps ahead of its first use (unit 6 of the phase = tap 12)
+            if constexpr (PH != 0 && tt == 9) { load_bias(ic<2 * (PH == 2 ? 1 : 0) + 1>{}); __builtin_amdgcn_sched_barrier(0); }
         });
+    };
+    // the block's last brick: its epilogue in the open (accumulator set SP)
+    auto flush = [&](auto SP_) __attribute__((always_inline)) {
+        static_for<24>([&](auto U_) __attribute__((always_inline)) {
+            constexpr int U = decltype(U_)::value;
+            if constexpr (U % 6 == 0) { load_bias(ic<U / 6>{}); asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq) :: "memory"); }
+            static_for<4>([&](auto Q_) __attribute__((always_inline)) { piece(SP_, U_, Q_); });
+        });
+    };
+    for (;;) {
+        Step nxt = cur;
+        const bool has_next = advance(nxt);
+        const int ph = pend ? (cur.cb == 0 ? 1 : (cur.cb == 1 ? 2 : 0)) : 0;
+        if (aset == 0) { if (ph == 0) run_step(ic<0>{}, ic<0>{}); else if (ph == 1) run_step(ic<0>{}, ic<1>{}); else run_step(ic<0>{}, ic<2>{}); }
+        else           { if (ph == 0) run_step(ic<1>{}, ic<0>{}); else if (ph == 1) run_step(ic<1>{}, ic<1>{}); else run_step(ic<1>{}, ic<2>{}); }
         asm volatile("s_barrier" ::: "memory");                     // the producers publish the next step's tile
         __builtin_amdgcn_sched_barrier(0);
+        if (ph == 2) { part_row(); pend = false; }
         if (cur.cb == C16T - 1) {
-            // ---- epilogue of the finished brick (exposed): transposed accumulators -> 16-byte stores, DPP partial sums
-            const Work& w = cur.w;
-            float s1[16], s2[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const size_t dst = ((((size_t)w.n * p.OD + w.oz0 + vz) * p.OH + w.oy0 + 2 * wave + mt) * p.OW + w.ox0 + vx) * (size_t)p.Cout + 4 * h;
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + 8 * k4 + 4 * h);
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[mt][4 * k4 + e] + b4[e];
-                        s1[4 * k4 + e] += v[e]; s2[4 * k4 + e] += v[e] * v[e];
-                        acc[mt][4 * k4 + e] = 0.f;
-                    }
-                    nm_st4<OH>(p.out, dst + 8 * k4, v);
-                }
-            }
-            if (p.part) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float a = dpp_sum32(s1[r]), b = dpp_sum32(s2[r]);
-                    if (l31 == 16) *reinterpret_cast<f32x2*>(red + (wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2) = f32x2{a, b};
-                }
-            }
-            lds_barrier();                                          // (matched by the producers)
-            if (p.part && tid < 32) {
-                float a = 0.f, b = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { a += red[(q * 32 + tid) * 2]; b += red[(q * 32 + tid) * 2 + 1]; }
-                const int br = ((w.oz0 >> 2) * nby + (w.oy0 >> 3)) * nbx + (w.ox0 >> 3);
-                float* dp = p.part + (((size_t)w.n * nbr + br) * p.Cout + tid) * 2;
-                dp[0] = a; dp[1] = b;
-            }
+            pend = true; pw = cur.w; aset ^= 1;
+            rpar ^= 1; rcur = rbase + (unsigned)rpar * 1024u;
+            obrick = ((((size_t)pw.n * p.OD + pw.oz0) * p.OH + pw.oy0) * p.OW + pw.ox0) * (size_t)p.Cout;
         }
         if (!has_next) break;
         cur = nxt; hb ^= 1;
     }
+    if (aset == 1) flush(ic<0>{}); else flush(ic<1>{});           // (aset was toggled behind the last brick: its sums sit in the other set)
+    lds_barrier();                                                  // (matched by the producers)
+    part_row();
 }
 
 // OIDHW fp32 -> split fp16 [tap][Cin/16][hi|lo][lane half][Co_pad][8]
@@ -3441,7 +3498,7 @@ int launch_f16r_impl(const ConvParams& p_in, int work_items, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return nm_check_hip(hipErrorUnknown, "device query");
         g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const size_t lds_bytes = (size_t)4 * 600 * 16 + (size_t)27 * C16T * 64 * 16 + (size_t)(256 + 32) * sizeof(float);
+    const size_t lds_bytes = (size_t)4 * 600 * 16 + (size_t)27 * C16T * 64 * 16 + (size_t)(512 + 32) * sizeof(float) + 2048 + 256 + 1024;      // (+ the store slots of the lanes that hold no total)
     ProfRec rec;
     rec.flops = 2.0 * p.N * (double)p.OD * p.OH * p.OW * p.Cout * (double)p.cin_real * 27.0;
     const bool prof_rec = NM_PROF_ON(s) && rec.flops >= nm_ls().prof_min_flops;
