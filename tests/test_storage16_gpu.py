@@ -300,6 +300,30 @@ def test_detector_gradients_bf16_storage_vs_fp64_oracle():
     print("bf16 storage: worst per-tensor relative L2 %.3f at %s" % (worst[1], worst[0]))
 
 
+def test_materialised_upsample_layer_matches_the_fused_staging():
+    """One-product training modes, the decoder's second fused-upsample layer (64 -> 32 channels): the forward materialises the
+    upsampled, activated input once (conv_f16r on it, the same tensor feeds the weight gradient) instead of running the composite-
+    weight kernel conv_up2c<.., 3> and rebuilding the tensor in the backward pass (NM355_UP2_MAT / NM355_F16R, read when a context is
+    created).  The two forms round differently (fp16 of the upsampled activations against fp16 of the composite weights): the loss
+    and the whole gradient agree within the mode's own distance from fp64, and each is as far from the fp64 oracle as the other."""
+    o, sd, vox = _setup(seed=11)
+    ref_loss, ref, _ = _oracle_grads(o, sd, vox, AIST, double=True)
+    res = {}
+    for mode in ("f16", "bf16"):
+        for mat in ("1", "0"):
+            os.environ["NM355_UP2_MAT"] = mat
+            os.environ["NM355_STORE16_MIN"] = "4096"
+            try:
+                res[mode, mat] = _hip_grads(o, sd, vox, AIST, mode=mode)[:2]
+            finally:
+                del os.environ["NM355_UP2_MAT"]; del os.environ["NM355_STORE16_MIN"]
+        (l1, g1), (l0, g0) = res[mode, "1"], res[mode, "0"]
+        d, d1, d0 = _l2(g1, g0), _l2(g1, ref), _l2(g0, ref)
+        print("%s: materialised vs fused upsample layer: loss %.6f / %.6f (fp64 %.6f), whole-gradient L2 between them %.3e, vs fp64 %.3e / %.3e" % (mode, l1, l0, ref_loss, d, d1, d0))
+        assert abs(l1 - l0) <= 1e-3 * abs(l0)
+        assert d < 4e-2 and d1 < 4e-2 and d1 < 1.5 * d0 + 5e-3
+
+
 _TRAJ = {}
 
 

@@ -46,10 +46,17 @@ python3 tools/pmc_mfma.py $(find $E/pm -name "*.db" | head -1) $E/${R}_pmc_mfma.
 TBCMD="python3 bench.py --workload train --conv-mode bf16 --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $E/pmb -- $TBCMD > $E/pmb.log 2>&1
 python3 tools/pmc_mfma.py $(find $E/pmb -name "*.db" | head -1) $E/${R}_pmc_mfma_train_bf16.json > $E/pmc_mfma_train_bf16_summary.txt 2>&1
-# same-call A/Bs of the round: posterior chain (encode alone, and forced on inside the fused forward), one-product conv kernel
+# same-call A/Bs of the round: posterior chain (encode alone, and forced on inside the fused forward), one-product conv kernels; training step with the
+# round's one-product changes switched off
 python3 tools/time_encode_ab.py 2>&1 | grep -v amdgpu.ids > $E/${R}_encode_ab.txt
 python3 tools/ab_f16q2.py 64 2>&1 | grep -v amdgpu.ids > $E/${R}_f16q2_ab.txt
+python3 tools/ab_f16r.py 64 2>&1 | grep -v amdgpu.ids > $E/${R}_f16r_ab.txt
 if [ -f neural_marionette_amd/libnm355_diag.so ]; then python3 tools/diag_f16q2.py 0,1,2,3,5,6,7,8,9,0 2>&1 | grep -v amdgpu.ids >> $E/${R}_f16q2_ab.txt; fi
+for M in bf16 f16; do
+  for SW in "" "NM355_F16R=0 NM355_UP2_MAT=0" "NM355_F16R=0 NM355_UP2_MAT=0 NM355_F16Q2=0"; do
+    echo "train $M [$SW]: $(env $SW python3 bench.py --workload train --conv-mode $M --steps 10 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c 'import sys,json; print(json.loads(sys.stdin.read())["ms_per_step"])') ms per step" >> $E/${R}_train_ab.txt
+  done
+done
 rm -rf $E/fwd $E/train $E/trainb $E/c4 $E/c5 $E/tf $E/tw $E/pm $E/pmb
 # stamp the tree id into every summary
 python3 tools/tree_id.py --stamp "$TREE" $E/${R}_*.json $E/${R}_*.csv $E/${R}_*.txt $E/${R}_bench.json.log
