@@ -377,6 +377,19 @@ def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
                                 dtype="f32 (VRNN), detector forward fp32-equivalent split-fp16", n_gpus=world)
     with torch.no_grad():
         net.load_state_dict(saved)
+    # the same step with the frozen detector run WITHOUT its voxel decoder and losses (LearnerTrainer(lean=True), nm_detector_keypoints):
+    # the learner's loss reads only keypoints and affinity; losses / gradients / updated weights bit-identical to the step above
+    # (tests/test_network_gpu.py::test_lean_learner_step_is_bit_identical_to_the_full_one).  Reported beside, not instead of, the
+    # reference-shaped step, which executes the whole detector forward under no_grad as neural_marionette.py:45-47 does.
+    lt2 = LearnerTrainer(net, lr=4e-4, lean=True)
+    lstep2 = lambda: lt2.step(vox, eps=eps, sync=False)
+    ms = timed(lstep2, 2, 5) * 1e3
+    out["train_learner_lean"] = dict(value=world * B_PER_GPU * T / (ms * 1e-3), unit="voxel-frames/s", ms_per_step=ms, steps=5, warmup=2,
+                                     workload="learner-mode training step with a keypoints-only detector pass (no voxel decoder, no detector losses: "
+                                              "the learner's loss does not read them); same weight update as train_learner",
+                                     dtype="f32 (VRNN), detector encoder fp32-equivalent split-fp16", n_gpus=world)
+    with torch.no_grad():
+        net.load_state_dict(saved)
     net.control_active({"detector": True, "learner": True})
     net.set_conv_mode("f16")
     net.eval()

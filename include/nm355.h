@@ -111,6 +111,14 @@ int nm_detector_forward(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int
                         float* keypoints, float* heatmaps, float* first_feature, float* recon,
                         float* affinity, float* losses11);
 
+/* The part of KyptDetector.forward the learner regime's loss reads (round 5): VoxToKyptNet (model/kypt_detector.py:299-364) and the
+ * affinity (:171-211) - keypoints, heat-maps, first-frame feature - WITHOUT KyptToVoxNet (:388-460) and the eleven losses.  The
+ * reference's learner-mode step (train.py:376-412 with pretrained_mode 1; model/neural_marionette.py:45-47) runs the whole detector
+ * under torch.no_grad() and reads only log['keypoints'] / the affinity from it; the outputs written here are bit-identical to
+ * nm_detector_forward's.  Same argument meaning as nm_detector_forward. */
+int nm_detector_keypoints(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t affinity_on,
+                          float* keypoints, float* heatmaps, float* first_feature, float* affinity);
+
 /* NeuralMarionette.forward with detector + learner active (model/neural_marionette.py:34-56) in one call:
  * nm_detector_forward followed by nm_vrnn_encode on the detected keypoints, with the VRNN issued on a
  * ctx-owned side stream as soon as the keypoints exist so that it runs beside the decoder (it does not

@@ -48,6 +48,7 @@ SIGNATURES = {
     "nm_workspace_bytes": (C.c_size_t, [C.c_void_p, _I, _I]),
     "nm_ctx_memory": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "nm_detector_forward": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "nm_detector_keypoints": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _P, _P, _P]),
     "nm_forward_fused": (C.c_int, [C.c_void_p, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_decode_from_keypoints": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _P]),
     "nm_get_affinity": (C.c_int, [C.c_void_p, _P]),

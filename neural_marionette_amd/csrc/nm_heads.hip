@@ -198,8 +198,8 @@ __device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* 
 }
 
 // grid (ceil(G3 / 1024), F).  x: raw 32-channel tensor with pending GN affine + lrelu.  A block walks FOUR 256-voxel tiles (rounds
-// 1-4: one, with three block reductions behind it - 0.49 ms for the 1.07 GB of a 32-frame pass at 64^3, 2.2 TB/s; the reductions and the
-// 32 KB a block moved between two barriers were the kernel), two tiles' loads in flight, one three-way block reduction at the end.
+// 1-4: one, with three block reductions behind it), two tiles' loads in flight, one three-way block reduction at the end: 482 -> 450 us
+// for the 2.15 GB of a 64-frame pass at 64^3 (4.8 TB/s: the kernel sits on the HBM roof of its fp32 input).
 #define NM_TAIL_TILES 4
 __global__ __launch_bounds__(256) void decoder_tail_kernel(TensorRef x, const float* __restrict__ w14, const float* __restrict__ first_frames,
                                                            int ff_stride_frames, int T, const float* __restrict__ target,

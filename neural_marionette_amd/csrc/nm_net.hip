@@ -702,13 +702,14 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
         n.run(nm_launch_cl_to_ncdhw_strided(ff, T, first_feature, n.s));
         if (affinity_on) n.run(nm_launch_affinity(d.affinity_params, N, K, aff, n.s));
     }
-    decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer != 0, recon, tail_part, tape);
+    // (recon == nullptr: the keypoints-only pass of nm_detector_keypoints - no voxel decoder, no losses)
+    if (recon) decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer != 0, recon, tail_part, tape);
     if (tape) {
         tape->B = B; tape->T = T; tape->affinity_on = affinity_on; tape->vox = vox_in; tape->feat = feat; tape->clip_head_out = clip_head;
         tape->heat_part = heat_part; tape->heat_mean = heat_mean; tape->tail_part = tail_part; tape->aff = aff;
         tape->keypoints = keypoints; tape->recon = recon;
     }
-    if (n.live()) {
+    if (n.live() && recon && losses) {
         n.run(nm_launch_clip_loss(keypoints, aff, B, T, K, N, c->cfg.sep_sigma, clip_part, n.s));
         n.run(nm_launch_loss_finalize(tail_part, tb, B, T, K, N, G, heat_mean, clip_part, aff, c->cfg.vol_fit_chamfer,
                                       c->cfg.use_graph_traj, frame_sums, losses, n.s));
@@ -1423,6 +1424,16 @@ int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32
     }
     rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11); });
     if (!rc) nm_nf_post(c, "nm_detector_forward");
+    return rc;
+}
+
+int nm_detector_keypoints(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints, float* heatmaps,
+                          float* first_feature, float* affinity) { NmScope nm_scope_(c);
+    int rc = check_ready(c, "detector_keypoints");
+    if (rc) return rc;
+    if (!vox || !keypoints || !heatmaps || !first_feature || B <= 0 || T <= 0) { nm_set_error("detector_keypoints: null / non-positive argument"); return NM_ERR_ARG; }
+    rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, nullptr, affinity, nullptr); });
+    if (!rc) nm_nf_post(c, "nm_detector_keypoints");
     return rc;
 }
 

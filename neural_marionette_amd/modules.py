@@ -294,6 +294,25 @@ class KyptDetector(nn.Module):
         out["first_feature"] = ff
         return out
 
+    def detect(self, seq):
+        """Keypoints only: VoxToKyptNet + the affinity (kypt_detector.py:299-364, :171-211) without the voxel decoder and the losses -
+        what the learner regime reads from the frozen detector (neural_marionette.py:45-47).  No gradients.  The tensors returned are
+        bit-identical to the same entries of forward()."""
+        eng = self._eng()
+        ctx = eng.ready()
+        dev = ctx.device
+        B, T = int(seq.shape[0]), int(seq.shape[1])
+        G, K, g = self.grid_size, self.nkeypoints, self.grid_size // 4
+        if tuple(seq.shape[2:]) != (1, G, G, G):
+            raise ValueError(f"expected seq of shape (B,T,1,{G},{G},{G}), got {tuple(seq.shape)}")
+        vox = _f32(seq, dev)
+        kp = torch.empty(B, T, K, 4, device=dev)
+        hm = torch.empty(B, T, K, g, g, g, device=dev)
+        ff = torch.empty(B, FEAT_DIM, g, g, g, device=dev)
+        aff = torch.empty(self.nneighbor, K, K, 1, device=dev) if self.affinity_start else None
+        eng.call_conv("nm_detector_keypoints", _lib.ptr(vox), B, T, int(self.affinity_start), _lib.ptr(kp), _lib.ptr(hm), _lib.ptr(ff), _lib.ptr(aff))
+        return dict(keypoints=kp, heatmaps=hm, affinity=aff, first_feature=ff)
+
     def get_affinity(self):
         """kypt_detector.py:171-211 (ver 3) -> (N,K,K,1)."""
         eng = self._eng()
@@ -726,8 +745,10 @@ class NeuralMarionette(nn.Module):
                     p.requires_grad = module_actives[name]
                 self.current_actives[name] = module_actives[name]
 
-    def forward(self, vox_seq, module_actives=None, eps=None):
-        """neural_marionette.py:34-56.  ``eps`` optionally injects the VRNN noise (T,S,B,Z)."""
+    def forward(self, vox_seq, module_actives=None, eps=None, detector_outputs="all"):
+        """neural_marionette.py:34-56.  ``eps`` optionally injects the VRNN noise (T,S,B,Z).  detector_outputs="keypoints" (learner
+        regime only, detector inactive): the frozen detector runs without its voxel decoder and losses (KyptDetector.detect) - the log
+        then lacks 'recon' and the eleven detector losses, which the learner's loss does not read."""
         log: Dict[str, torch.Tensor] = dict()
         keypoints = affinity = None
         d, det_m = self.dyna_module, self.kypt_detector
@@ -737,6 +758,8 @@ class NeuralMarionette(nn.Module):
         if module_actives["detector"] or module_actives["learner"]:
             if module_actives["detector"]:
                 det = self.kypt_detector(vox_seq)
+            elif detector_outputs == "keypoints":
+                det = self.kypt_detector.detect(vox_seq)
             else:
                 with torch.no_grad():           # neural_marionette.py:45-47
                     det = self.kypt_detector(vox_seq)

@@ -153,8 +153,12 @@ def adam_step_(eng, params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps) ->
 
 class LearnerTrainer:
     def __init__(self, net, lr: float = 4e-4, weights: Optional[Dict[str, float]] = None,
-                 betas=(0.9, 0.999), eps: float = 1e-8):
+                 betas=(0.9, 0.999), eps: float = 1e-8, lean: bool = False):
+        """lean=True: the frozen detector runs without its voxel decoder and losses (KyptDetector.detect) - the learner's loss reads only
+        the keypoints and the affinity; losses, gradients and updated weights are bit-identical to lean=False, which executes the whole
+        detector forward as the reference's step does (neural_marionette.py:45-47)."""
         self.net = net
+        self.lean = bool(lean)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.weights = dict(LEARNER_LOSS_WEIGHTS if weights is None else weights)
         net.control_active({"detector": False, "learner": True})
@@ -188,7 +192,7 @@ class LearnerTrainer:
         #  deferred guard reports an overflow at the next call and _drop_nonfinite_step_ keeps it out of the optimizer state)
         net._engine.suppress_probe = True
         try:
-            log = net(vox, {"detector": False, "learner": True}, eps=eps)
+            log = net(vox, {"detector": False, "learner": True}, eps=eps, detector_outputs="keypoints" if self.lean else "all")
         finally:
             net._engine.suppress_probe = False
         loss = sum(w * log[k] for k, w in self.weights.items())
