@@ -159,6 +159,11 @@ class LearnerTrainer:
         detector forward as the reference's step does (neural_marionette.py:45-47)."""
         self.net = net
         self.lean = bool(lean)
+        if self.lean and weights is not None:
+            from .spec import DETECTOR_LOSS_KEYS
+            bad = sorted(set(weights) & set(DETECTOR_LOSS_KEYS))
+            if bad:
+                raise ValueError(f"LearnerTrainer(lean=True) does not compute the detector losses {bad}: use lean=False to weight them")
         self.lr, self.betas, self.eps = lr, betas, eps
         self.weights = dict(LEARNER_LOSS_WEIGHTS if weights is None else weights)
         net.control_active({"detector": False, "learner": True})

@@ -71,6 +71,21 @@ def _oracle(K, sigma, seed):
 def test_forward_parity_other_keypoint_counts(K, sigma, seed, mode, path):
     """Full forward (detector + 11 losses + VRNN encode) at 32^3, B = 2, T = 4: the training forward and the inference forward (the
     split 1x1 conv of the combined representation, the fused hourglass core ...), split-fp16 and exact-fp32 conv modes."""
+    _forward_parity(K, sigma, seed, mode, path)
+
+
+# the ends of the range nm_ctx_create accepts (2 ... 32) and a count below one padding unit
+EDGE_CASES = [(2, 1.5, 302), (5, 1.5, 305), (32, 1.5, 332)]
+
+
+@pytest.mark.parametrize("path", ["train_fwd", "inference"])
+@pytest.mark.parametrize("K,sigma,seed", EDGE_CASES)
+def test_forward_parity_smallest_and_largest_keypoint_counts(K, sigma, seed, path):
+    """K = 2 (a two-node tree, one padded head of 8 channels holding 2), K = 5, K = 32 (the library's maximum, no padding)."""
+    _forward_parity(K, sigma, seed, "split16", path)
+
+
+def _forward_parity(K, sigma, seed, mode, path):
     o, sd, vox, eps = _setup(K, sigma, seed)
     net = _net(o, sd, mode)
     ref = _oracle(K, sigma, seed)
