@@ -59,7 +59,7 @@ struct Up2cParams {
     int Cout, Co_pad;
     int nbz, nby, nbx;           // bricks per frame
     int nblk;                    // partial blocks per frame (bricks + shell items)
-    int diag;                    // NM355_UP2C_DIAG (timing experiments only): 1 (unused), 2 no staging, 4 no shell launch, 8 no MFMA loop, 16 weights from one address, 32 no barriers
+    int diag;                    // NM355_UP2C_DIAG (timing experiments only): 1 (unused), 2 no staging, 4 no shell launch, 8 no MFMA loop, 16 weights from one address, 32 no barriers, 64 (with NM355_UP2C_X16=0) the 32x32x16 kernel with one accumulator
 };
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -187,7 +187,8 @@ __device__ __forceinline__ constexpr int tap_off(int t) { return (t / 9) * ZP + 
 struct StepPos { int n, br, nh, cg, cz0, cy0, cx0; };
 
 // IO: bit 0 = bfloat16 input, bit 1 = bfloat16 output (16-bit storage; the shell kernels then read-modify-write bfloat16 values)
-template <bool SINGLE, int IO = 0>
+// ONE (A/B arm of profiles/r06_mfma_shape_ab.txt): the three products in one accumulator as in conv_up2c_x16_kernel
+template <bool SINGLE, int IO = 0, bool ONE = false>
 __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
     constexpr bool IH16 = (IO & 1) != 0, OH16 = (IO & 2) != 0;
     extern __shared__ f32x4 lds_raw[];
@@ -323,20 +324,25 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
                 if (have_next && (ks == 10 || ks == 51) && !(p.diag & 32)) lds_barrier();
                 UP2C_SB();
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh[s], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (ONE) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh[s] * (_Float16)UP2C_SPLIT_SCALE, acc[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh[s], acc[j], 0, 0, 0);
+                }
                 UP2C_SB();
                 // A operands of the next k-step (after the last one: tap 0 of the other buffer)
                 const half8* xb = (ks == KS - 1) ? nb : tb;
                 const int nof = (ks == KS - 1) ? 0 : ((t < 26) ? c * 4 * HVP + tap_off((t + 1) % 27) : (c + 1) * 4 * HVP);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    accl[j] = nm_mfma_lo<SINGLE>(ah[j], bl[s], accl[j]);
+                    if constexpr (ONE) acc[j] = nm_mfma_lo<SINGLE>(ah[j], bl[s], acc[j]);
+                    else accl[j] = nm_mfma_lo<SINGLE>(ah[j], bl[s], accl[j]);
                     ah[j] = xb[arow[j] + nof];
                     UP2C_SB();
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    accl[j] = nm_mfma_lo<SINGLE>(al[j], bh[s], accl[j]);
+                    if constexpr (ONE) acc[j] = nm_mfma_lo<SINGLE>(al[j], bh[s], acc[j]);
+                    else accl[j] = nm_mfma_lo<SINGLE>(al[j], bh[s], accl[j]);
                     al[j] = xb[arow[j] + 2 * HVP + nof];
                     UP2C_SB();
                 }
@@ -363,8 +369,8 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const int x = 4 * ((r >> 2) & 1) + (r & 3), zb = (r >> 3) & 1, yb = (0x96 >> (h + 2 * (r >> 2))) & 1;
-                        const float v0 = __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r]) + bv;
-                        const float v1 = __builtin_fmaf(accl[j][r + 1], 1.0f / UP2C_SPLIT_SCALE, acc[j][r + 1]) + bv;
+                        const float v0 = (ONE ? acc[j][r] * (1.0f / UP2C_SPLIT_SCALE) : __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r])) + bv;
+                        const float v1 = (ONE ? acc[j][r + 1] * (1.0f / UP2C_SPLIT_SCALE) : __builtin_fmaf(accl[j][r + 1], 1.0f / UP2C_SPLIT_SCALE, acc[j][r + 1])) + bv;
                         const float send = odd ? v0 : v1;
                         const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, true));
                         const unsigned pk = odd ? nm_pk_bf16(recv, v1) : nm_pk_bf16(v0, recv);
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
                     for (int r = 0; r < 16; ++r) {
                         // register r of lane half h is row (r & 3) + 4 h + 8 (r >> 2) of the tile (see arow)
                         const int x = 4 * ((r >> 2) & 1) + (r & 3), zb = (r >> 3) & 1, yb = (0x96 >> (h + 2 * (r >> 2))) & 1;
-                        const float v = __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r]) + bv;
+                        const float v = (ONE ? acc[j][r] * (1.0f / UP2C_SPLIT_SCALE) : __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r])) + bv;
                         base[(size_t)(2 * zb) * sZ + (size_t)(2 * yb) * sY + (size_t)(2 * x) * sX] = v;
                         s += v; ss = __builtin_fmaf(v, v, ss);
                         __builtin_amdgcn_sched_barrier(0);
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void conv_up2c_kernel(Up2cParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int x = 4 * ((r >> 2) & 1) + (r & 3), zb = (r >> 3) & 1, yb = (0x96 >> (h + 2 * (r >> 2))) & 1;
-                        const float v = __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r]) + bv;
+                        const float v = (ONE ? acc[j][r] * (1.0f / UP2C_SPLIT_SCALE) : __builtin_fmaf(accl[j][r], 1.0f / UP2C_SPLIT_SCALE, acc[j][r])) + bv;
                         base[(size_t)(2 * zb) * sZ + (size_t)(2 * yb) * sY + (size_t)(2 * x) * sX] = v;
                         const int oz = 2 * (cs.cz0 + zb) + pz, oy = 2 * (cs.cy0 + 2 * j + yb) + py, ox = 2 * (cs.cx0 + x) + px;
                         const bool shell = oz == 0 || oz == OD - 1 || oy == 0 || oy == OH - 1 || ox == 0 || ox == OW - 1;
@@ -908,6 +914,7 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_x16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2c_x16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_up2c)");
@@ -939,6 +946,7 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     else if (nm_ls().up2c_x16 && single) hipLaunchKernelGGL(conv_up2c_x16_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else if (nm_ls().up2c_x16) hipLaunchKernelGGL(conv_up2c_x16_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else if (single) hipLaunchKernelGGL(conv_up2c_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    else if (nm_ls().up2c_diag & 64) hipLaunchKernelGGL((conv_up2c_kernel<false, 0, true>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else hipLaunchKernelGGL(conv_up2c_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     int rc = nm_check_hip(hipGetLastError(), "conv_up2c launch");
     if (rc) return rc;
