@@ -35,6 +35,7 @@ extern "C" {
 #define NM_ERR_STATE (-3)
 #define NM_ERR_UNSUPPORTED (-4)
 #define NM_ERR_RANGE (-5)       /* non-finite conv results (operand beyond the split-fp16 range, or non-finite input) */
+#define NM_ERR_INTERNAL (-6)    /* a C++ exception (std::bad_alloc, ...) was caught at the ABI: every entry point is a function-try-block, nothing unwinds into the caller */
 
 typedef struct nm_ctx nm_ctx;
 
@@ -61,6 +62,12 @@ typedef struct nm_named_tensor {
 
 int nm_abi_version(void);
 const char* nm_last_error(void);
+/* Errors: every entry point below is a function-try-block - a C++ exception raised inside the library (std::bad_alloc
+ * from a host container, ...) is caught at the boundary and reported as NM_ERR_INTERNAL with its message in nm_last_error(); nothing
+ * unwinds into the caller (ctypes / cgo / JNI would abort).  nm_abi_selftest_throw raises such an exception on purpose (kind 0:
+ * std::bad_alloc of a real allocation request, 1: std::length_error, 2: a non-std exception) and must return NM_ERR_INTERNAL; it needs
+ * no device (tests/test_abi_cpu.py). */
+int nm_abi_selftest_throw(int32_t kind);
 
 int nm_ctx_create(nm_ctx** out, const nm_config* cfg);
 int nm_ctx_destroy(nm_ctx* ctx);

@@ -40,6 +40,7 @@ _F = C.c_float
 SIGNATURES = {
     "nm_abi_version": (C.c_int, []),
     "nm_last_error": (C.c_char_p, []),
+    "nm_abi_selftest_throw": (C.c_int, [_I]),
     "nm_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NmConfig)]),
     "nm_ctx_destroy": (C.c_int, [C.c_void_p]),
     "nm_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -10,6 +10,9 @@
 #include <cstring>
 #include <cstdlib>
 #include <cmath>
+#include <new>
+#include <stdexcept>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -72,6 +75,14 @@ void nm_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int nm_abi_catch(const char* fn) noexcept {
+    try { throw; }
+    catch (const std::bad_alloc&) { nm_set_error("%s: out of host memory (std::bad_alloc)", fn); }
+    catch (const std::exception& e) { nm_set_error("%s: internal error: %s", fn, e.what()); }
+    catch (...) { nm_set_error("%s: internal error (unknown C++ exception)", fn); }
+    return NM_ERR_INTERNAL;
 }
 
 int nm_check_hip(hipError_t e, const char* what) {
@@ -162,7 +173,17 @@ static void release_side_streams(int dev, hipStream_t s2, hipStream_t s3, bool s
     }
 }
 
-int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
+// Test hook of the exception barrier (tests/test_abi_cpu.py; needs no device): throws inside an entry point exactly as a failing
+// std::vector / std::string / operator new of the real entry points would.  kind 0: std::bad_alloc from a real allocation request
+// (SIZE_MAX / 2 bytes), 1: std::length_error from std::vector::reserve, 2: a non-std exception.  Must return NM_ERR_INTERNAL.
+int nm_abi_selftest_throw(int32_t kind) try {
+    if (kind == 0) { volatile size_t n = ~(size_t)0 / 2; char* p = static_cast<char*>(::operator new(n)); p[0] = 1; ::operator delete(p); }
+    else if (kind == 1) { std::vector<double> v; v.reserve(v.max_size() + 1); }
+    else if (kind == 2) throw 42;
+    return NM_OK;
+} catch (...) { return nm_abi_catch("nm_abi_selftest_throw"); }
+
+int nm_ctx_create(nm_ctx** out, const nm_config* cfg) try {
     if (!out || !cfg) { nm_set_error("ctx_create: null argument"); return NM_ERR_ARG; }
     if (cfg->grid_size < 32 || cfg->grid_size % 8) { nm_set_error("ctx_create: grid_size %d unsupported", cfg->grid_size); return NM_ERR_UNSUPPORTED; }
     // (any keypoint count in [2, 32]: the reference's dataset configs use 12 / 22 / 24 / 28, dataset/config.py:97,124, train.py:60; the
@@ -222,9 +243,9 @@ int nm_ctx_create(nm_ctx** out, const nm_config* cfg) {
     }
     *out = c;
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_ctx_create"); }
 
-int nm_ctx_destroy(nm_ctx* ctx) {
+int nm_ctx_destroy(nm_ctx* ctx) try {
     if (!ctx) return NM_OK;
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipDeviceSynchronize();
@@ -249,9 +270,9 @@ int nm_ctx_destroy(nm_ctx* ctx) {
     for (hipEvent_t e : ctx->ls.event_pool) (void)hipEventDestroy(e);
     delete ctx;
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_ctx_destroy"); }
 
-int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) { NmScope nm_scope_(ctx);
+int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) try { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("set_stream: null ctx"); return NM_ERR_ARG; }
     hipStream_t ns = static_cast<hipStream_t>(hip_stream);
     if (ns != ctx->stream && ctx->stream_bound) {
@@ -267,9 +288,9 @@ int nm_ctx_set_stream(nm_ctx* ctx, void* hip_stream) { NmScope nm_scope_(ctx);
     ctx->stream = ns;
     ctx->stream_bound = true;
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_ctx_set_stream"); }
 
-int nm_ctx_check_nonfinite(nm_ctx* ctx) { NmScope nm_scope_(ctx);
+int nm_ctx_check_nonfinite(nm_ctx* ctx) try { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("check_nonfinite: null ctx"); return NM_ERR_ARG; }
     (void)hipSetDevice(ctx->cfg.device);
     unsigned v = 0;
@@ -296,9 +317,9 @@ int nm_ctx_check_nonfinite(nm_ctx* ctx) { NmScope nm_scope_(ctx);
                    "set conv mode 'fp32' (exact fp32 MFMA, no range limit) and run again"
                  : "the input or the weights hold inf / NaN (exact fp32 mode has no range limit of its own)");
     return NM_ERR_RANGE;
-}
+} catch (...) { return nm_abi_catch("nm_ctx_check_nonfinite"); }
 
-int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count) { NmScope nm_scope_(ctx);
+int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t count) try { NmScope nm_scope_(ctx);
     if (!ctx || !tensors || count <= 0) { nm_set_error("set_weights: bad arguments"); return NM_ERR_ARG; }
     std::map<std::string, std::pair<const float*, int64_t>> sd;
     for (int i = 0; i < count; ++i) {
@@ -307,44 +328,44 @@ int nm_ctx_set_weights(nm_ctx* ctx, const nm_named_tensor* tensors, int32_t coun
     }
     (void)hipSetDevice(ctx->cfg.device);
     return nm_net_set_weights(ctx, sd);
-}
+} catch (...) { return nm_abi_catch("nm_ctx_set_weights"); }
 
-int nm_ctx_set_training(nm_ctx* ctx, int32_t on) { NmScope nm_scope_(ctx);
+int nm_ctx_set_training(nm_ctx* ctx, int32_t on) try { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("set_training: null ctx"); return NM_ERR_ARG; }
     if (ctx->training != (on != 0)) { ctx->training = on != 0; ctx->has_weights = false; }     // the next call needs nm_ctx_set_weights again
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_ctx_set_training"); }
 
-int nm_set_conv_mode(nm_ctx* ctx, int32_t mode) {
+int nm_set_conv_mode(nm_ctx* ctx, int32_t mode) try {
     if (!ctx || mode < 0 || mode > 4) { nm_set_error("set_conv_mode: mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA), 2 (split-fp16, conv_f16p wherever eligible), 3 (fp16 products, fp32 accumulation) or 4 (mode 3 + bfloat16 storage of the training path's tensors)"); return NM_ERR_ARG; }
     NmScope sc(ctx);
     nm_conv_set_mode(mode);
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_set_conv_mode"); }
 
-int nm_get_conv_mode(nm_ctx* ctx) { NmScope sc(ctx); return nm_conv_get_mode(); }
+int nm_get_conv_mode(nm_ctx* ctx) try { NmScope sc(ctx); return nm_conv_get_mode(); } catch (...) { return nm_abi_catch("nm_get_conv_mode"); }
 
-int nm_op_set_storage16(nm_ctx* ctx, int32_t in_h, int32_t out_h) {
+int nm_op_set_storage16(nm_ctx* ctx, int32_t in_h, int32_t out_h) try {
     if (!ctx) { nm_set_error("op_set_storage16: null ctx"); return NM_ERR_ARG; }
     ctx->ls.op_in_h = in_h ? 1 : 0; ctx->ls.op_out_h = out_h ? 1 : 0;
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_op_set_storage16"); }
 
-int nm_prof_enable(nm_ctx* ctx, int32_t on) { NmScope nm_scope_(ctx);
+int nm_prof_enable(nm_ctx* ctx, int32_t on) try { NmScope nm_scope_(ctx);
     if (!ctx) { nm_set_error("prof_enable: null ctx"); return NM_ERR_ARG; }
     nm_conv_prof_enable(on, ctx->stream);         // 1: launches on the context's main stream, 2: side-stream launches too
     if (on) nm_conv_prof_reset();
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_prof_enable"); }
 
-int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) { NmScope nm_scope_(ctx);
+int nm_prof_read(nm_ctx* ctx, int32_t variant, double* ms_total, double* flops_total, int64_t* launches) try { NmScope nm_scope_(ctx);
     if (!ctx || !ms_total || !flops_total || !launches || variant < 0 || variant > 15) { nm_set_error("prof_read: bad argument"); return NM_ERR_ARG; }
     long long n = 0;
     int rc = nm_conv_prof_collect(variant, ms_total, flops_total, &n);
     if (rc) { nm_set_error("prof_read: event query failed"); return rc; }
     *launches = n;
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_prof_read"); }
 
 const char* nm_prof_kernel_name(int32_t variant) {
     static const char* names[16] = {"conv_mfma_kernel<1,1>", "conv_mfma_kernel<1,2>", "conv_mfma_kernel<2,1>", "conv_mfma_kernel<2,2>",
@@ -354,12 +375,12 @@ const char* nm_prof_kernel_name(int32_t variant) {
     return (variant >= 0 && variant < 16) ? names[variant] : "";
 }
 
-int nm_host_linspace(int32_t n, float* out) {
+int nm_host_linspace(int32_t n, float* out) try {
     if (n < 2 || !out) { nm_set_error("linspace: bad arguments"); return NM_ERR_ARG; }
     const float step = 2.0f / (float)(n - 1);
     for (int i = 0; i < n; ++i) out[i] = i < n / 2 ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(n - 1 - i), 1.0f);
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_host_linspace"); }
 
 // ---- op-level entry points -------------------------------------------------------------------
 static TensorRef make_ref(const float* p, const float* sc, const float* sh, float slope, int N, int D, int H, int W, int C) {
@@ -383,7 +404,7 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
                  const float* in_scale, const float* in_shift, float in_slope, const float* weight,
                  const float* bias, int32_t Cout, int32_t ks, int32_t stride, int32_t pad, float* out,
                  int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift,
-                 int32_t up2) { NmScope nm_scope_(ctx);
+                 int32_t up2) try { NmScope nm_scope_(ctx);
     if (!ctx || !in || !weight || !out) { nm_set_error("op_conv3d: null argument"); return NM_ERR_ARG; }
     const int Cin_pad = (Cin + 7) & ~7, Co_pad = (Cout + 31) & ~31;
     const int us = up2 ? 2 : 1;
@@ -435,10 +456,10 @@ int nm_op_conv3d(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     if (gn_groups > 0)
         rc = finish_gn(ctx, part, N, nblk_used, Cout, gn_groups, (double)g.OD * g.OH * g.OW * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_op_conv3d"); }
 
 int nm_op_conv5_occ(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, const float* weight, const float* bias, int32_t Cout,
-                    float* out, int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) { NmScope nm_scope_(ctx);
+                    float* out, int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) try { NmScope nm_scope_(ctx);
     if (!ctx || !occ || !weight || !bias || !out) { nm_set_error("op_conv5_occ: null argument"); return NM_ERR_ARG; }
     const int Co_pad = (Cout + 31) & ~31;
     const size_t G3 = (size_t)G * G * G;
@@ -460,11 +481,11 @@ int nm_op_conv5_occ(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, const f
     if ((rc = nm_launch_conv_k5occ(occ, N, G, wocc, field, out, Cout, Co_pad, gn_groups > 0 ? part : nullptr, s, nullptr, nullptr, nullptr, op_oh()))) return rc;
     if (gn_groups > 0) rc = finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)G3 * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_op_conv5_occ"); }
 
 int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                  const float* weight, const float* bias, int32_t Cout, int32_t outpad, float* out,
-                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) { NmScope nm_scope_(ctx);
+                 int32_t gn_groups, const float* gn_gamma, const float* gn_beta, float* gn_scale, float* gn_shift) try { NmScope nm_scope_(ctx);
     if (!ctx || !in || !weight || !out || !bias) { nm_set_error("op_convT2: null argument"); return NM_ERR_ARG; }
     const int OD = 2 * D + outpad, OH = 2 * H + outpad, OW = 2 * W + outpad;
     const int vox = OD * OH * OW, nblk = nm_stats_blocks_per_frame(vox);
@@ -480,31 +501,31 @@ int nm_op_convT2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, 
     rc = nm_launch_gn_partials(out, N, vox, Cout, part, ctx->stream, op_oh());
     if (rc) return rc;
     return finish_gn(ctx, part, N, nblk, Cout, gn_groups, (double)vox * (Cout / gn_groups), gn_gamma, gn_beta, gn_scale, gn_shift);
-}
+} catch (...) { return nm_abi_catch("nm_op_convT2"); }
 
 int nm_op_apply2(nm_ctx* ctx, const float* a, const float* a_scale, const float* a_shift, float a_slope,
                  const float* b, const float* b_scale, const float* b_shift, float b_slope, int32_t N,
-                 int32_t voxels, int32_t C, float* out) { NmScope nm_scope_(ctx);
+                 int32_t voxels, int32_t C, float* out) try { NmScope nm_scope_(ctx);
     if (!ctx || !a || !out) { nm_set_error("op_apply2: null argument"); return NM_ERR_ARG; }
     TensorRef ta = with_h(make_ref(a, a_scale, a_shift, a_slope, N, 1, 1, voxels, C), op_ih());
     TensorRef tb = with_h(make_ref(b, b_scale, b_shift, b_slope, N, 1, 1, voxels, C), op_ih());
     return nm_launch_apply2(ta, b ? &tb : nullptr, out, ctx->stream, op_oh());
-}
+} catch (...) { return nm_abi_catch("nm_op_apply2"); }
 
-int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out) { NmScope nm_scope_(ctx);
+int nm_op_upsample2(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, float* out) try { NmScope nm_scope_(ctx);
     if (!ctx || !in || !out) { nm_set_error("op_upsample2: null argument"); return NM_ERR_ARG; }
     return nm_launch_upsample2(with_h(make_ref(in, nullptr, nullptr, 1.0f, N, D, H, W, C), op_ih()), out, ctx->stream, op_oh());
-}
+} catch (...) { return nm_abi_catch("nm_op_upsample2"); }
 
-int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out) { NmScope nm_scope_(ctx);
+int nm_op_pack_input(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_t G, int32_t mean_over_t, float* out) try { NmScope nm_scope_(ctx);
     if (!ctx || !vox || !out) { nm_set_error("op_pack_input: null argument"); return NM_ERR_ARG; }
     return nm_launch_pack_input(vox, B, T, G, mean_over_t, out, ctx->stream);
-}
+} catch (...) { return nm_abi_catch("nm_op_pack_input"); }
 
-int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out) { NmScope nm_scope_(ctx);
+int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, int32_t C, float* out) try { NmScope nm_scope_(ctx);
     if (!ctx || !in || !out) { nm_set_error("op_cl_to_ncdhw: null argument"); return NM_ERR_ARG; }
     return nm_launch_cl_to_ncdhw(make_ref(in, nullptr, nullptr, 1.0f, N, 1, 1, voxels, C), out, ctx->stream);
-}
+} catch (...) { return nm_abi_catch("nm_op_cl_to_ncdhw"); }
 
 // ---- backward ops (unit parity of the detector-mode training kernels) ----------------------------------------------------
 // Gradients of  y = conv3d(up2? upsample2(a) : a, W) + b  with  a = lrelu(in*scale + shift):
@@ -512,7 +533,7 @@ int nm_op_cl_to_ncdhw(nm_ctx* ctx, const float* in, int32_t N, int32_t voxels, i
 int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                           const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
                           int32_t ks, int32_t stride, int32_t pad, int32_t up2, const float* dy, float* d_in,
-                          int32_t dgrad_channels, float* d_weight, float* d_bias) { NmScope nm_scope_(ctx);
+                          int32_t dgrad_channels, float* d_weight, float* d_bias) try { NmScope nm_scope_(ctx);
     if (!ctx || !in || !weight || !dy || !d_weight || !d_bias) { nm_set_error("op_conv3d_backward: null argument"); return NM_ERR_ARG; }
     if (Cout % 8) { nm_set_error("op_conv3d_backward: Cout %% 8 != 0"); return NM_ERR_ARG; }
     const int Cin_pad = (Cin + 7) & ~7, us = up2 ? 2 : 1, taps = ks * ks * ks;
@@ -565,11 +586,11 @@ int nm_op_conv3d_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
         return nm_launch_convT2(dyT, wt, zb, d_in, Cin, D, H, W, s, op_ih());
     }
     nm_set_error("op_conv3d_backward: unsupported geometry"); return NM_ERR_UNSUPPORTED;
-}
+} catch (...) { return nm_abi_catch("nm_op_conv3d_backward"); }
 
 // first layer: dW [Cout][4][125] and d_bias of conv5(cat[occ, coords]) given dy
 int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G, int32_t Cout, const float* dy,
-                             float* d_weight, float* d_bias, int32_t sparse_occ) { NmScope nm_scope_(ctx);
+                             float* d_weight, float* d_bias, int32_t sparse_occ) try { NmScope nm_scope_(ctx);
     if (!ctx || !occ || !dy || !d_weight || !d_bias) { nm_set_error("op_conv5_occ_backward: null argument"); return NM_ERR_ARG; }
     const size_t wsf = nm_wgrad_k5occ_ws_floats(N, G, Cout);
     const int nbb = nm_gnb_blocks_per_frame(G * G * G);
@@ -581,12 +602,12 @@ int nm_op_conv5_occ_backward(nm_ctx* ctx, const float* occ, int32_t N, int32_t G
     if ((rc = nm_launch_wgrad_k5occ(occ, N, G, dyT, ws, d_weight, ctx->stream, sparse_occ))) return rc;
     if ((rc = nm_launch_gnb_partials(dy, dyT, bp, ctx->stream))) return rc;
     return nm_launch_sum_partials(bp, N * nbb, Cout, d_bias, ctx->stream);
-}
+} catch (...) { return nm_abi_catch("nm_op_conv5_occ_backward"); }
 
 // Gradients of  y = convT3d_k2s2(a, W) + b  (a = lrelu(in*scale+shift)); weight IODHW
 int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                           const float* in_scale, const float* in_shift, float in_slope, const float* weight, int32_t Cout,
-                          int32_t outpad, const float* dy, float* d_in, float* d_weight, float* d_bias) { NmScope nm_scope_(ctx);
+                          int32_t outpad, const float* dy, float* d_in, float* d_weight, float* d_bias) try { NmScope nm_scope_(ctx);
     if (!ctx || !in || !weight || !dy || !d_in || !d_weight || !d_bias) { nm_set_error("op_convT2_backward: null argument"); return NM_ERR_ARG; }
     if (Cin % 8 || Cout % 8) { nm_set_error("op_convT2_backward: channels must be multiples of 8"); return NM_ERR_ARG; }
     const int OD = 2 * D + outpad, OH = 2 * H + outpad, OW = 2 * W + outpad;
@@ -613,11 +634,11 @@ int nm_op_convT2_backward(nm_ctx* ctx, const float* in, int32_t N, int32_t D, in
     if ((rc = nm_check_hip(hipMemsetAsync(zb, 0, ci_pad * sizeof(float), s), "memset"))) return rc;
     ConvGeom g; g.ks = 2; g.stride = 2; g.pad = 0; g.OD = D; g.OH = H; g.OW = W; g.Cout = Cin; g.Co_pad = ci_pad;
     return nm_launch_conv(dyT, wp, zb, d_in, g, nullptr, s, Cout, h16 ? wp16 : nullptr);
-}
+} catch (...) { return nm_abi_catch("nm_op_convT2_backward"); }
 
 // GroupNorm(groups) + LeakyReLU(slope) backward on a raw tensor y [N][voxels][C]: dy, dgamma, dbeta, and sum_v dy (the conv bias gradient)
 int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, int32_t C, int32_t groups, const float* gamma,
-                      const float* beta, float slope, const float* dA, float* dy, float* dgamma, float* dbeta, float* dbias) { NmScope nm_scope_(ctx);
+                      const float* beta, float slope, const float* dA, float* dy, float* dgamma, float* dbeta, float* dbias) try { NmScope nm_scope_(ctx);
     if (!ctx || !y || !gamma || !beta || !dA || !dy || !dgamma || !dbeta || !dbias) { nm_set_error("op_gn_backward: null argument"); return NM_ERR_ARG; }
     const int nbf = nm_stats_blocks_per_frame(voxels), nbb = nm_gnb_blocks_per_frame(voxels);
     int rc = nm_ctx_reserve(ctx, ((size_t)N * (nbf + nbb) * C * 2 + (size_t)N * C * 10) * sizeof(float) + 16384);
@@ -636,6 +657,6 @@ int nm_op_gn_backward(nm_ctx* ctx, const float* y, int32_t N, int32_t voxels, in
     if ((rc = nm_launch_sum_frames(dgn, N, C, 4, 1, dbeta, s))) return rc;
     if ((rc = nm_launch_sum_frames(dgn, N, C, 4, 2, dbias, s))) return rc;
     return nm_launch_gnb_apply(dA, yT, coef, dy, s);
-}
+} catch (...) { return nm_abi_catch("nm_op_gn_backward"); }
 
 }  // extern "C"

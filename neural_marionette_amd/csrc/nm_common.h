@@ -19,6 +19,7 @@
 #define NM_ERR_STATE (-3)
 #define NM_ERR_UNSUPPORTED (-4)
 #define NM_ERR_RANGE (-5)
+#define NM_ERR_INTERNAL (-6)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -116,6 +117,8 @@ struct NmDeviceOnce {
     void mark() { mask |= bit(); }
 };
 int nm_check_hip(hipError_t e, const char* what);
+// the catch-all of every extern "C" entry point (no C++ exception crosses the ABI): message for nm_last_error(), NM_ERR_INTERNAL
+int nm_abi_catch(const char* fn) noexcept;
 
 // ---- per-context launch state ---------------------------------------------------------
 // Everything a kernel launcher consults besides its arguments lives in the nm_ctx ("separate ctxs are

@@ -90,7 +90,7 @@ __global__ void semantic_kernel(const float* __restrict__ kypt, const float* __r
 
 extern "C" {
 
-int nm_eval_voxel_chamfer(nm_ctx* c, const float* gt_vox, const float* recon, int32_t B, int32_t T, int32_t G, double* per_frame) { NmScope nm_scope_(c);
+int nm_eval_voxel_chamfer(nm_ctx* c, const float* gt_vox, const float* recon, int32_t B, int32_t T, int32_t G, double* per_frame) try { NmScope nm_scope_(c);
     if (!c || !gt_vox || !recon || !per_frame || B <= 0 || T <= 0 || G < 2 || G > 1024) { nm_set_error("eval_voxel_chamfer: bad argument"); return NM_ERR_ARG; }
     int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
     if (rc) return rc;
@@ -124,16 +124,16 @@ int nm_eval_voxel_chamfer(nm_ctx* c, const float* gt_vox, const float* recon, in
     const double sc = 2.0 / (double)(G - 1);
     hipLaunchKernelGGL(chamfer_final_kernel, dim3((F + 63) / 64), dim3(64), 0, s, s_gt, s_rec, F, sc * sc, per_frame);
     return nm_check_hip(hipGetLastError(), "eval_voxel_chamfer launch");
-}
+} catch (...) { return nm_abi_catch("nm_eval_voxel_chamfer"); }
 
 int nm_eval_semantic(nm_ctx* c, const float* keypoints, const float* gt_keypoints, int32_t BT, int32_t K, int32_t Kg,
-                     int32_t* closest, int64_t* counts) { NmScope nm_scope_(c);
+                     int32_t* closest, int64_t* counts) try { NmScope nm_scope_(c);
     if (!c || !keypoints || !gt_keypoints || !closest || !counts || BT <= 0 || K <= 0 || Kg <= 0) { nm_set_error("eval_semantic: bad argument"); return NM_ERR_ARG; }
     int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
     if (rc) return rc;
     hipLaunchKernelGGL(semantic_kernel, dim3((BT * Kg + 127) / 128), dim3(128), 0, c->stream, keypoints, gt_keypoints, BT, K, Kg, closest,
                        reinterpret_cast<long long*>(counts));
     return nm_check_hip(hipGetLastError(), "eval_semantic launch");
-}
+} catch (...) { return nm_abi_catch("nm_eval_semantic"); }
 
 }  // extern "C"

@@ -1399,24 +1399,24 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
 
 extern "C" {
 
-size_t nm_workspace_bytes(nm_ctx* c, int32_t B, int32_t T) { NmScope nm_scope_(c);
+size_t nm_workspace_bytes(nm_ctx* c, int32_t B, int32_t T) try { NmScope nm_scope_(c);
     if (!c || !c->has_weights || B <= 0 || T <= 0) return 0;
     c->ws.dry = true; c->ws.peak = 0;
     float dummy = 0.f; float* dp = &dummy;
     (void)detector_graph(c, dp, B, T, 1, dp, dp, dp, dp, dp, dp);
     c->ws.dry = false;
     return c->ws.peak + 4096;
-}
+} catch (...) { if (c) c->ws.dry = false; (void)nm_abi_catch("nm_workspace_bytes"); return 0; }
 
-int nm_ctx_memory(nm_ctx* c, size_t out[4]) { NmScope nm_scope_(c);
+int nm_ctx_memory(nm_ctx* c, size_t out[4]) try { NmScope nm_scope_(c);
     if (!c || !out) { nm_set_error("ctx_memory: null argument"); return NM_ERR_ARG; }
     out[0] = c->ws.cap + c->ws2.cap; out[1] = c->ws_t.cap; out[2] = c->wside_floats * sizeof(float); out[3] = 0;
     for (size_t b : c->owned_bytes) out[3] += b;
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_ctx_memory"); }
 
 int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints,
-                        float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) { NmScope nm_scope_(c);
+                        float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) try { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_forward");
     if (rc) return rc;
     if (!vox || !keypoints || !heatmaps || !first_feature || !recon || !losses11 || B <= 0 || T <= 0) {
@@ -1425,21 +1425,21 @@ int nm_detector_forward(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32
     rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, recon, affinity, losses11); });
     if (!rc) nm_nf_post(c, "nm_detector_forward");
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_detector_forward"); }
 
 int nm_detector_keypoints(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints, float* heatmaps,
-                          float* first_feature, float* affinity) { NmScope nm_scope_(c);
+                          float* first_feature, float* affinity) try { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_keypoints");
     if (rc) return rc;
     if (!vox || !keypoints || !heatmaps || !first_feature || B <= 0 || T <= 0) { nm_set_error("detector_keypoints: null / non-positive argument"); return NM_ERR_ARG; }
     rc = with_workspace(c, [&]() { return detector_graph(c, vox, B, T, affinity_on, keypoints, heatmaps, first_feature, nullptr, affinity, nullptr); });
     if (!rc) nm_nf_post(c, "nm_detector_keypoints");
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_detector_keypoints"); }
 
 int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, const float* eps, int32_t S,
                      float* keypoints, float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11,
-                     float* kypt_recon, float* R, float* z, float* h, float* scalars2, int32_t* best_idx) { NmScope nm_scope_(c);
+                     float* kypt_recon, float* R, float* z, float* h, float* scalars2, int32_t* best_idx) try { NmScope nm_scope_(c);
     int rc = check_ready(c, "forward_fused");
     if (rc) return rc;
     if (!vox || !eps || !keypoints || !heatmaps || !first_feature || !recon || !losses11 || !kypt_recon || !R || !z || !h ||
@@ -1466,10 +1466,10 @@ int nm_forward_fused(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t 
     rc = nm_check_hip(hipStreamWaitEvent(c->stream, c->ev_side, 0), "join side stream");
     if (!rc) nm_nf_post(c, "nm_forward_fused");
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_forward_fused"); }
 
 int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* first_feature, const float* first_frame,
-                             int32_t B, int32_t Tg, float* gen) { NmScope nm_scope_(c);
+                             int32_t B, int32_t Tg, float* gen) try { NmScope nm_scope_(c);
     int rc = check_ready(c, "decode_from_keypoints");
     if (rc) return rc;
     if (!keypoints || !first_feature || !first_frame || !gen || B <= 0 || Tg <= 0) {
@@ -1478,7 +1478,7 @@ int nm_decode_from_keypoints(nm_ctx* c, const float* keypoints, const float* fir
     rc = with_workspace(c, [&]() { return decode_graph(c, keypoints, first_feature, first_frame, B, Tg, gen); });
     if (!rc) nm_nf_post(c, "nm_decode_from_keypoints");
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_decode_from_keypoints"); }
 
 // the ctx-owned block behind the weight-gradient stream (ring of dY buffers + scratch + scale pool), grown to the last sizing pass
 static int reserve_wside(nm_ctx* c) {
@@ -1495,7 +1495,7 @@ static int reserve_wside(nm_ctx* c) {
 }
 
 int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T, int32_t affinity_on, float* keypoints,
-                              float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) { NmScope nm_scope_(c);
+                              float* heatmaps, float* first_feature, float* recon, float* affinity, float* losses11) try { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_forward_train");
     if (rc) return rc;
     if (!c->training) { nm_set_error("detector_forward_train: call nm_ctx_set_training(ctx, 1) and nm_ctx_set_weights first"); return NM_ERR_STATE; }
@@ -1529,9 +1529,9 @@ int nm_detector_forward_train(nm_ctx* c, const float* vox, int32_t B, int32_t T,
     t.valid = rc == NM_OK;
     if (!rc) nm_nf_post(c, "nm_detector_forward_train");
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_detector_forward_train"); }
 
-int nm_detector_backward(nm_ctx* c, const float* dlosses11, const nm_named_grad* grads, int32_t count) { NmScope nm_scope_(c);
+int nm_detector_backward(nm_ctx* c, const float* dlosses11, const nm_named_grad* grads, int32_t count) try { NmScope nm_scope_(c);
     int rc = check_ready(c, "detector_backward");
     if (rc) return rc;
     if (!c->tape || !c->tape->valid) { nm_set_error("detector_backward: no training forward to back-propagate (or the weights changed since)"); return NM_ERR_STATE; }
@@ -1548,15 +1548,15 @@ int nm_detector_backward(nm_ctx* c, const float* dlosses11, const nm_named_grad*
     std::swap(c->ws, c->ws_t);
     t.valid = false;
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_detector_backward"); }
 
-int nm_ctx_set_backward_event(nm_ctx* c, void* hip_event) { NmScope nm_scope_(c);
+int nm_ctx_set_backward_event(nm_ctx* c, void* hip_event) try { NmScope nm_scope_(c);
     if (!c) { nm_set_error("set_backward_event: null ctx"); return NM_ERR_ARG; }
     c->ev_user_decoder = static_cast<hipEvent_t>(hip_event);
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_ctx_set_backward_event"); }
 
-int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, double scale, float* vox, int32_t* idx_out) { NmScope nm_scope_(c);
+int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, double scale, float* vox, int32_t* idx_out) try { NmScope nm_scope_(c);
     if (!c || !points || !vox || T <= 0 || N <= 0) { nm_set_error("voxelize_clip: bad argument"); return NM_ERR_ARG; }
     int rc = nm_check_hip(hipSetDevice(c->cfg.device), "hipSetDevice");
     if (rc) return rc;
@@ -1564,13 +1564,13 @@ int nm_voxelize_clip(nm_ctx* c, const double* points, int32_t T, int64_t N, doub
     c->ws.release(0);
     double* part = static_cast<double*>(c->ws.alloc_bytes(256 * 6 * sizeof(double)));
     return nm_launch_voxelize(points, T, (size_t)N, c->cfg.grid_size, scale, part, vox, idx_out, c->stream);
-}
+} catch (...) { return nm_abi_catch("nm_voxelize_clip"); }
 
-int nm_get_affinity(nm_ctx* c, float* affinity) { NmScope nm_scope_(c);
+int nm_get_affinity(nm_ctx* c, float* affinity) try { NmScope nm_scope_(c);
     int rc = check_ready(c, "get_affinity");
     if (rc) return rc;
     if (!affinity) { nm_set_error("get_affinity: null output"); return NM_ERR_ARG; }
     return nm_launch_affinity(c->det.affinity_params, c->cfg.nneighbor, c->cfg.nkeypoints, affinity, c->stream);
-}
+} catch (...) { return nm_abi_catch("nm_get_affinity"); }
 
 }  // extern "C"

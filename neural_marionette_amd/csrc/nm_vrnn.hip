@@ -1978,7 +1978,7 @@ void nm_vrnn_invalidate_tape(nm_ctx* c) { if (c->vtape) static_cast<VrnnTape*>(c
 
 extern "C" {
 
-int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) { NmScope nm_scope_(c);
+int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_set_tree", false);
     if (rc) return rc;
     const int K = c->cfg.nkeypoints;
@@ -2012,9 +2012,9 @@ int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) { 
     if (rc) return rc;
     c->vrnn.has_tree = true;
     return NM_OK;
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_set_tree"); }
 
-int nm_vrnn_offsets(nm_ctx* c, const float* keypoints, int32_t B, int32_t T, float* offset) { NmScope nm_scope_(c);
+int nm_vrnn_offsets(nm_ctx* c, const float* keypoints, int32_t B, int32_t T, float* offset) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_offsets", true);
     if (rc) return rc;
     if (!keypoints || !offset || B <= 0 || T <= 0) { nm_set_error("vrnn_offsets: bad argument"); return NM_ERR_ARG; }
@@ -2023,7 +2023,7 @@ int nm_vrnn_offsets(nm_ctx* c, const float* keypoints, int32_t B, int32_t T, flo
     hipLaunchKernelGGL(offsets_kernel, dim3(B), dim3(64), (size_t)K * T * sizeof(float), c->stream, keypoints, c->vrnn.offset_param,
                        c->vrnn.parents, T, K, offset);
     return nm_check_hip(hipGetLastError(), "offsets launch");
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_offsets"); }
 
 // ---- host side of vrnn_post_chain_kernel ----------------------------------------------------------------------------------------------
 static size_t post_chain_gran_floats(int B, int S, int K, int Z, int H) {
@@ -2159,21 +2159,21 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
 }
 
 int nm_vrnn_encode(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
-                   float* R, float* z, float* h, float* scalars2, int32_t* best_idx) { NmScope nm_scope_(c);
+                   float* R, float* z, float* h, float* scalars2, int32_t* best_idx) try { NmScope nm_scope_(c);
     return encode_impl(c, keypoints, eps, B, T, S, kypt_recon, R, z, h, scalars2, best_idx, false);
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_encode"); }
 
 int nm_vrnn_encode_train(nm_ctx* c, const float* keypoints, const float* eps, int32_t B, int32_t T, int32_t S, float* kypt_recon,
-                         float* R, float* z, float* h, float* scalars2, int32_t* best_idx) { NmScope nm_scope_(c);
+                         float* R, float* z, float* h, float* scalars2, int32_t* best_idx) try { NmScope nm_scope_(c);
     return encode_impl(c, keypoints, eps, B, T, S, kypt_recon, R, z, h, scalars2, best_idx, true);
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_encode_train"); }
 
 static int launch_wgrad(const float* dA, int ldA, int rows, WgSeg xa, WgSeg xb, int T, int B, float* dW, float* db, hipStream_t s) {
     hipLaunchKernelGGL(wgrad_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dA, ldA, rows, xa, xb, T, B, dW, db);
     return nm_check_hip(hipGetLastError(), "wgrad launch");
 }
 
-int nm_vrnn_encode_backward(nm_ctx* c, const float* dscal2, const nm_named_grad* grads, int32_t count) { NmScope nm_scope_(c);
+int nm_vrnn_encode_backward(nm_ctx* c, const float* dscal2, const nm_named_grad* grads, int32_t count) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_encode_backward", true);
     if (rc) return rc;
     VrnnTape& tp = ctx_tape(c);
@@ -2301,19 +2301,19 @@ int nm_vrnn_encode_backward(nm_ctx* c, const float* dscal2, const nm_named_grad*
     if ((rc = launch_wgrad(da_q, 128, 128, x_h, x_obs, T, B, g_q0, g_q0b, s))) return rc;
     if ((rc = launch_wgrad(da_p, 128, 128, x_h, none, T, B, g_p0, g_p0b, s))) return rc;
     return nm_check_hip(hipGetLastError(), "vrnn_encode_backward");
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_encode_backward"); }
 
 int nm_adam_step(nm_ctx* c, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, int32_t step, float lr,
-                 float beta1, float beta2, float eps) { NmScope nm_scope_(c);
+                 float beta1, float beta2, float eps) try { NmScope nm_scope_(c);
     if (!c || !param || !grad || !exp_avg || !exp_avg_sq || numel <= 0 || step <= 0) { nm_set_error("adam_step: bad argument"); return NM_ERR_ARG; }
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     int blocks = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, c->stream, param, grad, exp_avg, exp_avg_sq, (size_t)numel, lr, beta1, beta2, eps, bc1, bc2);
     return nm_check_hip(hipGetLastError(), "adam launch");
-}
+} catch (...) { return nm_abi_catch("nm_adam_step"); }
 
 int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                       const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps) { NmScope nm_scope_(c);
+                       const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps) try { NmScope nm_scope_(c);
     if (!c || !params || !grads || !exp_avg || !exp_avg_sq || !numels || count <= 0 || step <= 0) { nm_set_error("adam_step_multi: bad argument"); return NM_ERR_ARG; }
     c->host_table.resize((size_t)count * sizeof(AdamItem));
     AdamItem* items = reinterpret_cast<AdamItem*>(c->host_table.data());
@@ -2333,7 +2333,7 @@ int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grad
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, c->stream, dev, count, lr, beta1, beta2, eps, bc1, bc2);
     return nm_check_hip(hipGetLastError(), "adam_multi launch");
-}
+} catch (...) { return nm_abi_catch("nm_adam_step_multi"); }
 
 // ---- rollouts: nm_vrnn_generate (hsvrnn_bvh.py:158-234) and nm_vrnn_rollout (the prior loop of vis_generation.py:117-127) ------
 // A rollout is hundreds of dependent ~3 us launches; enqueued one by one the host (3-5 us per launch) is the bottleneck.  For the
@@ -2582,7 +2582,7 @@ static int rollout_impl(nm_ctx* c, int kind, const float* kp_cond, const float* 
 }
 
 int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_post, const float* eps_prior, int32_t B,
-                     int32_t Tcond, int32_t Ttot, int32_t S, float* out_cond, float* out_gen, float* h_last) { NmScope nm_scope_(c);
+                     int32_t Tcond, int32_t Ttot, int32_t S, float* out_cond, float* out_gen, float* h_last) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_generate", true);
     if (rc) return rc;
     if (!keypoints_cond || !eps_post || !out_cond || B <= 0 || Tcond <= 0 || Ttot < Tcond || S <= 0 || (Ttot > Tcond && (!eps_prior || !out_gen))) {
@@ -2592,9 +2592,9 @@ int nm_vrnn_generate(nm_ctx* c, const float* keypoints_cond, const float* eps_po
     rc = rollout_impl(c, 0, keypoints_cond, eps_post, eps_prior, nullptr, nullptr, B, Tcond, Ttot, S, out_cond, out_gen, h_last);
     if (!rc) nm_nf_post(c, "nm_vrnn_generate");
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_generate"); }
 
-int nm_vrnn_rollout(nm_ctx* c, const float* h_in, const float* offset, const float* eps, int32_t B, int32_t T, float* kp_out, float* h_out) { NmScope nm_scope_(c);
+int nm_vrnn_rollout(nm_ctx* c, const float* h_in, const float* offset, const float* eps, int32_t B, int32_t T, float* kp_out, float* h_out) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_rollout", true);
     if (rc) return rc;
     if (!h_in || !offset || !eps || !kp_out || B <= 0 || T <= 0) { nm_set_error("vrnn_rollout: bad argument"); return NM_ERR_ARG; }
@@ -2602,10 +2602,10 @@ int nm_vrnn_rollout(nm_ctx* c, const float* h_in, const float* offset, const flo
     rc = rollout_impl(c, 1, nullptr, nullptr, eps, h_in, offset, B, 0, T, 1, nullptr, kp_out, h_out);
     if (!rc) nm_nf_post(c, "nm_vrnn_rollout");
     return rc;
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_rollout"); }
 
 int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* kp_obs, const float* offset, const float* eps,
-                 int32_t B, int32_t S, float* kp_out, float* z_out, float* h_out) { NmScope nm_scope_(c);
+                 int32_t B, int32_t S, float* kp_out, float* z_out, float* h_out) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_step", true);
     if (rc) return rc;
     if (!h_in || !offset || !eps || !kp_out || !z_out || B <= 0 || (posterior && (!kp_obs || S <= 0))) {
@@ -2625,7 +2625,7 @@ int nm_vrnn_step(nm_ctx* c, int32_t posterior, const float* h_in, const float* k
     io.best = nullptr; io.ldbest = 0; io.kl = nullptr; io.rec = nullptr; io.ldstat = 0;
     io.hout = h_out; io.ldho = H; io.want_prior = false;
     return vrnn_step(c, sb, io, B, S);
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_step"); }
 
 // idx = argmin_r sum_d (rows[r][d] - target[r * tstride + d])^2  (first minimum), one block
 __global__ __launch_bounds__(256) void rows_argmin_kernel(const float* __restrict__ rows, const float* __restrict__ target, int tstride,
@@ -2650,13 +2650,13 @@ __global__ __launch_bounds__(256) void rows_argmin_kernel(const float* __restric
 }
 
 int nm_rows_argmin_dist(nm_ctx* c, const float* rows, const float* target, int32_t target_row_stride, int32_t B, int32_t D,
-                        int32_t* idx_out, float* dist_out) { NmScope nm_scope_(c);
+                        int32_t* idx_out, float* dist_out) try { NmScope nm_scope_(c);
     if (!c || !rows || !target || !idx_out || B <= 0 || D <= 0) { nm_set_error("rows_argmin_dist: bad argument"); return NM_ERR_ARG; }
     hipLaunchKernelGGL(rows_argmin_kernel, dim3(1), dim3(256), 0, c->stream, rows, target, target_row_stride, B, D, idx_out, dist_out);
     return nm_check_hip(hipGetLastError(), "rows_argmin launch");
-}
+} catch (...) { return nm_abi_catch("nm_rows_argmin_dist"); }
 
-int nm_vrnn_mlp(nm_ctx* c, int32_t which, const float* x, int32_t B, float* y) { NmScope nm_scope_(c);
+int nm_vrnn_mlp(nm_ctx* c, int32_t which, const float* x, int32_t B, float* y) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_mlp", false);
     if (rc) return rc;
     if (!x || !y || B <= 0 || which < 0 || which > 3) { nm_set_error("vrnn_mlp: bad argument"); return NM_ERR_ARG; }
@@ -2672,9 +2672,9 @@ int nm_vrnn_mlp(nm_ctx* c, int32_t which, const float* x, int32_t B, float* y) {
     LinJobs J2; J2.n = 0; J2.start[0] = 0;
     add_job(J2, *l2[which], 0, hid, 128, 128, nullptr, 0, 0, true, nullptr, 0, 1, y, l2[which]->out, which == 2 ? 2 : 0, B);
     return launch_jobs(J2, c->stream);
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_mlp"); }
 
-int nm_vrnn_gru(nm_ctx* c, const float* x, const float* h, int32_t B, float* h_out) { NmScope nm_scope_(c);
+int nm_vrnn_gru(nm_ctx* c, const float* x, const float* h, int32_t B, float* h_out) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_gru", false);
     if (rc) return rc;
     if (!x || !h || !h_out || B <= 0) { nm_set_error("vrnn_gru: bad argument"); return NM_ERR_ARG; }
@@ -2688,9 +2688,9 @@ int nm_vrnn_gru(nm_ctx* c, const float* x, const float* h, int32_t B, float* h_o
     add_job(J, hh, 0, h, H, H, nullptr, 0, 0, true, nullptr, 0, 1, gh, 3 * H, 0, B);
     if ((rc = launch_jobs(J, c->stream))) return rc;
     return launch_gru(w.w_ih, w.b_ih, x, in, in, nullptr, 0, 0, gh, h, H, h_out, H, H, B, c->stream);
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_gru"); }
 
-int nm_vrnn_fk(nm_ctx* c, const float* dec_in, const float* offset, int32_t B, float* kp, float* R) { NmScope nm_scope_(c);
+int nm_vrnn_fk(nm_ctx* c, const float* dec_in, const float* offset, int32_t B, float* kp, float* R) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_fk", true);
     if (rc) return rc;
     if (!dec_in || !offset || !kp || !R || B <= 0) { nm_set_error("vrnn_fk: bad argument"); return NM_ERR_ARG; }
@@ -2717,6 +2717,6 @@ int nm_vrnn_fk(nm_ctx* c, const float* dec_in, const float* offset, int32_t B, f
     size_t lds = ((size_t)K * 22 + 1) * sizeof(float);
     hipLaunchKernelGGL(fk_kernel, dim3(B), dim3(256), lds, c->stream, a);
     return nm_check_hip(hipGetLastError(), "fk launch");
-}
+} catch (...) { return nm_abi_catch("nm_vrnn_fk"); }
 
 }  // extern "C"
