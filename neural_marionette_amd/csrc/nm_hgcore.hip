@@ -66,8 +66,11 @@ __device__ __forceinline__ float hg_lrelu(float v, float slope) { return fmaxf(v
 // (tap, 16-channel chunk) is cut into KS = waves / pairs parts: item (pair, part) accumulates its k-steps and parks the 32 x 32 partial
 // tile in LDS (`scratch`, 4 KB per item), the workgroup then sums the KS partials of every output in part order and adds the bias.
 // Two waves per SIMD hide part of each other's operand / weight latency: the weight prefetch is 8 k-steps deep instead of 12 (registers).
+// `scratch` holds `sitems_` items (nm_hg_core_scratch_items: as many of HG_MAX_ITEMS as the frame's tensors leave room for).  A conv with
+// more (row tile, column tile) pairs than that (the 96^3 grid's 6^3 level: 14 pairs beside 153 KB of tensors) takes no K split and
+// stores its finished tiles straight from the accumulators (`direct`): no scratch at all.
 __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp_, int Dout_, const NmHgConv& L, int stride_, int pad_, const float* zeros,
-                         float* scratch) {
+                         float* scratch, int sitems_) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
     const int nwaves = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
     // everything that drives the loop structure in SGPRs (the layer record arrives through memory: without this the tap decode
@@ -79,7 +82,9 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
     const int Vout = Dout * Dout * Dout, mtiles = (Vout + 31) >> 5, ntiles = Co_pad >> 5;
     const int nchunk = (Cin + 15) >> 4, nk = (g_hg_diag & 2) ? 1 : ks * ks * ks * nchunk;          // (diagnostic bit 2: one k-step per conv - timing only)
     const int pairs = mtiles * ntiles;
-    const int KS = max(1, min(min(nwaves / pairs, HG_MAX_ITEMS / pairs), nk));                     // K parts per pair
+    const int sitems = __builtin_amdgcn_readfirstlane(sitems_);
+    const bool direct = sitems < pairs;                                                            // (uniform)
+    const int KS = direct ? 1 : max(1, min(min(nwaves / pairs, sitems / pairs), nk));              // K parts per pair; pairs * KS <= sitems
     glb_half8* w8 = (glb_half8*)L.w16;
     const lds_float* srcl = (const lds_float*)src;
     lds_float* dstl = (lds_float*)dst;
@@ -152,8 +157,26 @@ __device__ void conv_lds(const float* src, int sp_, int Din_, float* dst, int dp
         }
         // accumulator layout (activations first): lane holds column l31 of the tile, rows (r & 3) + 8 (r >> 2) + 4 h: partial tile
         // [row][32 columns] of item `it`
+        if (direct) {
+            const int n = nt * 32 + l31;
+            const float bv = n < Cout ? biasg[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) scr[it * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[r] + (accl[r] + accm[r]) * (1.0f / HG_SPLIT);
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < Vout && n < dp) dstl[row * dp + n] = n < Cout ? (acc[r] + (accl[r] + accm[r]) * (1.0f / HG_SPLIT)) + bv : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[it * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[r] + (accl[r] + accm[r]) * (1.0f / HG_SPLIT);
+        }
+    }
+    if (direct) {
+        // columns beyond the last column tile (dp > Co_pad: a 32-channel conv into a 48-pitch tensor) are padding: zero
+        const int ncov = ntiles * 32;
+        if (dp > ncov)
+            for (int i = threadIdx.x; i < Vout * (dp - ncov); i += blockDim.x) dstl[(i / (dp - ncov)) * dp + ncov + i % (dp - ncov)] = 0.f;
+        __syncthreads();
+        return;
     }
     __syncthreads();
     // dst[row][n] = sum over the pair's K parts (in part order) + bias; channels Cout .. dp - 1 zeroed
@@ -219,14 +242,14 @@ __device__ void gn_lds(float* buf, int pitch_, int V_, int C_, const NmHgNorm& g
 
 // Res3DBlock: out = GN(conv3(lrelu(GN(conv3 x)))) + skip(x), skip = identity or GN(conv1 x); x in `xin`, result left in `t2`
 // (t1 is scratch; xin is preserved)
-__device__ void res_lds(const float* xin, int xp, float* t1, float* t2, int pitch, int D, const NmHgRes& r, double* red, const float* zeros, float* scratch) {
+__device__ void res_lds(const float* xin, int xp, float* t1, float* t2, int pitch, int D, const NmHgRes& r, double* red, const float* zeros, float* scratch, int sitems) {
     const int V = D * D * D;
-    conv_lds(xin, xp, D, t1, pitch, D, r.c1, 1, 1, zeros, scratch);
+    conv_lds(xin, xp, D, t1, pitch, D, r.c1, 1, 1, zeros, scratch, sitems);
     gn_lds(t1, pitch, V, r.c1.Cout, r.n1, 0.01f, nullptr, 0, red);
-    conv_lds(t1, pitch, D, t2, pitch, D, r.c2, 1, 1, zeros, scratch);
+    conv_lds(t1, pitch, D, t2, pitch, D, r.c2, 1, 1, zeros, scratch, sitems);
     if (r.has_skip) {
         gn_lds(t2, pitch, V, r.c2.Cout, r.n2, 1.0f, nullptr, 0, red);
-        conv_lds(xin, xp, D, t1, pitch, D, r.cs, 1, 0, zeros, scratch);
+        conv_lds(xin, xp, D, t1, pitch, D, r.cs, 1, 0, zeros, scratch, sitems);
         gn_lds(t1, pitch, V, r.cs.Cout, r.ns, 1.0f, t2, pitch, red);        // t1 = GN(cs x) + t2
         for (int i = threadIdx.x; i < V * pitch; i += blockDim.x) t2[i] = t1[i];
         __syncthreads();
@@ -242,7 +265,8 @@ __global__ __launch_bounds__(HG_THREADS) void hg_core_kernel(NmHgCoreParams p) {
     float* C0 = B2 + (size_t)V2 * P2; float* C1 = C0 + (size_t)V3 * P3; float* C2 = C1 + (size_t)V3 * P3;
     double* red = reinterpret_cast<double*>(C2 + (size_t)V3 * P3);      // 360 doubles of reduction scratch behind the tensors (all sizes are multiples of 16 floats)
     const float* zeros = reinterpret_cast<const float*>(red + 360);     // 16 zero floats: what an out-of-volume tap reads
-    float* scratch = const_cast<float*>(zeros) + 16;                     // HG_MAX_ITEMS partial tiles of conv_lds
+    float* scratch = const_cast<float*>(zeros) + 16;                     // p.scratch_items partial tiles of conv_lds
+    const int sitems = p.scratch_items;
     const int NT = blockDim.x;
     for (int i = tid; i < 3 * V2 * P2 + 3 * V3 * P3 + 720 + 16; i += NT) lds[i] = 0.f;   // (padding channels and the zero block must read as zeros)
     __syncthreads();
@@ -259,12 +283,12 @@ __global__ __launch_bounds__(HG_THREADS) void hg_core_kernel(NmHgCoreParams p) {
         }
         __syncthreads();
     }
-    res_lds(B0, P2, B1, B2, P2, D2, p.e2, red, zeros, scratch);                  // e2 -> B2
-    res_lds(B2, P2, B0, B1, P2, D2, p.s3, red, zeros, scratch);                  // s3 -> B1   (B0 scratch; a2 is dead)
-    conv_lds(B2, P2, D2, C0, P3, D3, p.p3, 2, 0, zeros, scratch);               // pool3(e2) -> C0
+    res_lds(B0, P2, B1, B2, P2, D2, p.e2, red, zeros, scratch, sitems);                  // e2 -> B2
+    res_lds(B2, P2, B0, B1, P2, D2, p.s3, red, zeros, scratch, sitems);                  // s3 -> B1   (B0 scratch; a2 is dead)
+    conv_lds(B2, P2, D2, C0, P3, D3, p.p3, 2, 0, zeros, scratch, sitems);               // pool3(e2) -> C0
     gn_lds(C0, P3, V3, p.p3.Cout, p.np3, 0.01f, nullptr, 0, red);
-    res_lds(C0, P3, C1, C2, P3, D3, p.e3, red, zeros, scratch);                  // e3 -> C2
-    res_lds(C2, P3, C0, C1, P3, D3, p.d3, red, zeros, scratch);                  // d3 -> C1
+    res_lds(C0, P3, C1, C2, P3, D3, p.e3, red, zeros, scratch, sitems);                  // e3 -> C2
+    res_lds(C2, P3, C0, C1, P3, D3, p.d3, red, zeros, scratch, sitems);                  // d3 -> C1
     // ConvTranspose3d k2 s2 (+ output_padding): out[2i + a] = sum_ci d3[i][ci] W[a][ci][co] + b; the padding planes hold the bias only
     {
         const int Co = p.u3_Cout, Ci = p.u3_Cin;
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(HG_THREADS) void hg_core_kernel(NmHgCoreParams p) {
         __syncthreads();
         gn_lds(B0, P2, V2, Co, p.nu3, 0.01f, B1, P2, red);       // x = lrelu(GN(.)) + s3 -> B0
     }
-    res_lds(B0, P2, B1, B2, P2, D2, p.d2, red, zeros, scratch);                  // out -> B2
+    res_lds(B0, P2, B1, B2, P2, D2, p.d2, red, zeros, scratch, sitems);                  // out -> B2
     {
         const int C = p.d2.c2.Cout;
         float* dst = p.out + (size_t)n * V2 * C;
@@ -304,14 +328,27 @@ __global__ __launch_bounds__(HG_THREADS) void hg_core_kernel(NmHgCoreParams p) {
 
 }  // namespace
 
+static size_t hg_core_tensor_bytes(const NmHgCoreParams& p) {
+    return ((size_t)3 * p.D2 * p.D2 * p.D2 * p.pitch2 + (size_t)3 * p.D3 * p.D3 * p.D3 * p.pitch3) * sizeof(float) + 360 * sizeof(double) + 16 * sizeof(float);
+}
+// partial-tile items (4 KB each) the launch gets beside its tensors: HG_MAX_ITEMS where they fit under the 150 KB gate (the 64^3 / 88^3
+// grids), else what is left - possibly none (96^3: 153 280 B of tensors), and conv_lds stores directly
+int nm_hg_core_scratch_items(const NmHgCoreParams& p) {
+    const size_t t = hg_core_tensor_bytes(p), gate = (size_t)150 * 1024, hard = (size_t)158 * 1024;
+    if (t + (size_t)HG_MAX_ITEMS * 4096 <= gate) return HG_MAX_ITEMS;
+    if (t > hard) return -1;                       // does not fit at all
+    return t >= gate ? 0 : (int)((gate - t) / 4096);
+}
 size_t nm_hg_core_lds_bytes(const NmHgCoreParams& p) {
-    return ((size_t)3 * p.D2 * p.D2 * p.D2 * p.pitch2 + (size_t)3 * p.D3 * p.D3 * p.D3 * p.pitch3) * sizeof(float) + 360 * sizeof(double) + 16 * sizeof(float) +
-           (size_t)HG_MAX_ITEMS * 1024 * sizeof(float);
+    const int items = nm_hg_core_scratch_items(p);
+    return hg_core_tensor_bytes(p) + (size_t)(items > 0 ? items : 0) * 4096;
 }
 
 int nm_launch_hg_core(const NmHgCoreParams& p, hipStream_t s) {
     const size_t lds = nm_hg_core_lds_bytes(p);
-    if (lds > 150 * 1024) { nm_set_error("hg_core: %zu bytes of LDS per frame", lds); return NM_ERR_UNSUPPORTED; }
+    if (nm_hg_core_scratch_items(p) < 0 || p.scratch_items != nm_hg_core_scratch_items(p)) {
+        nm_set_error("hg_core: %zu bytes of LDS per frame / scratch items %d (expected %d)", lds, p.scratch_items, nm_hg_core_scratch_items(p)); return NM_ERR_UNSUPPORTED;
+    }
     static NmDeviceOnce attr_set;
     if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hg_core_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -468,7 +468,8 @@ static bool hg_core_params(const HourglassW& w, const TensorRef& a2, float* out,
     p.pitch2 = (c2 + 15) & ~15; p.pitch3 = (c3 + 15) & ~15;
     ok = ok && a2.D == a2.H && a2.H == a2.W && a2.D >= 2 && a2.D <= 6 && p.u3_w && w.u3.Cout == w.s3.c2.Cout && a2.C == w.e2.c1.Cin &&
          w.e2.c2.Cout == w.s3.c1.Cin && w.e2.c2.Cout == w.p3.c.Cin && w.p3.c.Cout == w.e3.c1.Cin && w.d3.c2.Cout == w.u3.Cin &&
-         w.u3.Cout == w.d2.c1.Cin && nm_hg_core_lds_bytes(p) <= 150 * 1024;
+         w.u3.Cout == w.d2.c1.Cin && nm_hg_core_scratch_items(p) >= 0;
+    p.scratch_items = ok ? nm_hg_core_scratch_items(p) : 0;
     return ok;
 }
 

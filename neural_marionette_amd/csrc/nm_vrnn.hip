@@ -930,15 +930,23 @@ struct PostChainArgs {
     float* out_h; int ldh;              // [B][ldh]: state after step t at column (t + 1) * H (column 0 is written by the caller)
     int32_t* best; int ldbest;          // [B][ldbest] (or null)
     float *kl, *rec; int ldstat;        // per (clip, step) sums (kl may be null)
-    nm_gran *g_hidq, *g_hidp, *g_rh, *g_jh;    // [B][128] x 4   h-phase -> sample / statistics workgroups
+    nm_gran *g_hidq, *g_rh, *g_jh;      // [B][128] x 3   h-phase -> sample workgroups
+    // h-phase -> statistics workgroups: one slot PER STEP ([T][B][128] each with statistics workgroups, else one slot that nobody reads).
+    // Nothing inside the launch waits for a statistics workgroup, so nothing may overwrite what it has not read yet: a single slot
+    // rewritten every step (round 5) let a statistics workgroup that fell one step behind - a contended device - poll for a tag that
+    // was gone, time out and abort the whole encode (advisor finding).  Written once, a slot can be read arbitrarily late.
+    nm_gran *g_sq, *g_hidp;
     nm_gran* g_gh;                      // [B][3H]        h-phase -> GRU
     nm_gran* g_kpz;                     // [S][B][4K + Z] sample workgroup -> GRU
-    nm_gran* g_d;                       // [S][B]         sample workgroup -> GRU and the clip's other sample workgroups
+    nm_gran* g_d[2];                    // [S][B] x 2     sample workgroup -> GRU and the clip's other sample workgroups (buffer t & 1: a sample workgroup may
+                                        //                still be reading step t's distances when a peer publishes step t + 1's; buffer t & 1 is rewritten at
+                                        //                step t + 2, which needs every sample's distance of step t + 1, i.e. every reader of step t done)
     nm_gran* g_h[2];                    // [B][H] x 2     GRU of step t -> h-phase / GRU of step t + 1 (buffer t & 1)
     unsigned* abort; unsigned* status;
     int B, S, T, K, Z, H;
     int nstat;                          // statistics workgroups: B (encode: KL) or 0 (the conditioning steps of generate)
     int backoff, spin_limit;
+    int stat_delay;                     // NM355_CHAIN_STAT_DELAY (test hook): s_sleep(127) units a statistics workgroup idles before every step - a lagging one
 };
 
 __device__ __forceinline__ void gran_ld_1(const nm_gran* p, nm_f32x2& v) {
@@ -969,9 +977,10 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
         __syncthreads();
         for (int t = 0; t < T; ++t) {
             const unsigned tag = (unsigned)t + 1u;
+            for (int sl = 0; sl < a.stat_delay; ++sl) __builtin_amdgcn_s_sleep(127);
             f32x4 q0, q1, p0, p1; nm_f32x2 dummy;
-            const nm_gran* pq = a.g_hidq + (size_t)b * 128 + l32 * 4;
-            const nm_gran* pp = a.g_hidp + (size_t)b * 128 + l32 * 4;
+            const nm_gran* pq = a.g_sq + ((size_t)t * B + b) * 128 + l32 * 4;
+            const nm_gran* pp = a.g_hidp + ((size_t)t * B + b) * 128 + l32 * 4;
             NM_CHAIN_POLL(gran_ld_4q1(pq, pq + 2, pp, pp + 2, pq, q0, q1, p0, p1, dummy),
                           nm_fbits(q0[1]) == tag && nm_fbits(q0[3]) == tag && nm_fbits(q1[1]) == tag && nm_fbits(q1[3]) == tag &&
                           nm_fbits(p0[1]) == tag && nm_fbits(p0[3]) == tag && nm_fbits(p1[1]) == tag && nm_fbits(p1[3]) == tag);
@@ -1122,10 +1131,10 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
                 float d = 0.f;
                 if (lane == 0) {
                     for (int k = 0; k < K; ++k) d += s_dk[k];
-                    gran_store(a.g_d + (size_t)smp * B + b, d, tag);
+                    gran_store(a.g_d[t & 1] + (size_t)smp * B + b, d, tag);
                 }
                 nm_f32x2 gd;
-                const nm_gran* pd = a.g_d + (size_t)min(lane, S - 1) * B + b;
+                const nm_gran* pd = a.g_d[t & 1] + (size_t)min(lane, S - 1) * B + b;
                 NM_CHAIN_POLL(gran_ld_1(pd, gd), nm_fbits(gd[1]) == tag);
                 // first minimum in sample order (fk_kernel's scan): butterfly over (distance, index), the lower index wins a tie
                 float bd = lane < S ? gd[0] : INFINITY; int bi = lane < S ? lane : 1 << 20;
@@ -1217,8 +1226,11 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
                 if (lane == 0) {
                     const float v = acc + bh[i];
                     if (i == 0) {
-                        if (sect == 0) gran_store(a.g_hidp + (size_t)b * 128 + rsec, lrelu(v, 0.01f), tag);
-                        else if (sect == 1) gran_store(a.g_hidq + (size_t)b * 128 + rsec, lrelu(v, 0.01f), tag);
+                        if (sect == 0) gran_store(a.g_hidp + ((size_t)(a.nstat ? t : 0) * B + b) * 128 + rsec, lrelu(v, 0.01f), tag);
+                        else if (sect == 1) {
+                            gran_store(a.g_hidq + (size_t)b * 128 + rsec, lrelu(v, 0.01f), tag);
+                            if (a.nstat) gran_store(a.g_sq + ((size_t)t * B + b) * 128 + rsec, lrelu(v, 0.01f), tag);
+                        }
                         else if (sect == 2) gran_store(a.g_rh + (size_t)b * 128 + rsec, v, tag);
                         else gran_store(a.g_jh + (size_t)b * 128 + rsec, v, tag);
                     } else gran_store(a.g_gh + (size_t)b * 3 * H + gw + NWV * (i - 1), v, tag);
@@ -1229,7 +1241,7 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
 #pragma unroll 1
         for (int b = 0; b < B && wave_alive && j < H; ++b) {
             nm_f32x2 gd;
-            const nm_gran* pd = a.g_d + (size_t)min(lane, S - 1) * B + b;
+            const nm_gran* pd = a.g_d[t & 1] + (size_t)min(lane, S - 1) * B + b;
             NM_CHAIN_POLL(gran_ld_1(pd, gd), nm_fbits(gd[1]) == tag);
             if (!wave_alive) break;
             float bd = lane < S ? gd[0] : INFINITY; int bi = lane < S ? lane : 1 << 20;
@@ -2026,10 +2038,12 @@ int nm_vrnn_offsets(nm_ctx* c, const float* keypoints, int32_t B, int32_t T, flo
 } catch (...) { return nm_abi_catch("nm_vrnn_offsets"); }
 
 // ---- host side of vrnn_post_chain_kernel ----------------------------------------------------------------------------------------------
-static size_t post_chain_gran_floats(int B, int S, int K, int Z, int H) {
-    const size_t nd = ((size_t)S * B + 1) & ~(size_t)1;
-    return 2 * ((size_t)B * (4 * 128 + 5 * H) + (size_t)S * B * (4 * K + Z) + nd) + 64;
+// Tstat: steps of a launch WITH statistics workgroups (encode: the KL term), 0 for the conditioning steps of generate / rollouts
+static size_t post_chain_granules(int B, int S, int K, int Z, int H, int Tstat) {
+    const size_t nd = ((size_t)S * B + 1) & ~(size_t)1;              // (an even count: the arrays behind it are read in 16-byte granule pairs)
+    return (size_t)B * (3 * 128 + 5 * H) + (size_t)S * B * (4 * K + Z) + 2 * nd + (size_t)2 * (Tstat > 0 ? Tstat : 1) * B * 128;
 }
+static size_t post_chain_gran_floats(int B, int S, int K, int Z, int H, int Tstat) { return 2 * post_chain_granules(B, S, K, Z, H, Tstat) + 64; }
 // Can the chain run: shape limits, and EVERY workgroup resident at once - the kernel's workgroups spin on each other and an ordinary launch
 // does not promise co-residency: workgroups of this shape (512 threads at up to 256 registers, the heads' weights in dynamic LDS) per
 // CU x the device's CUs must cover the NM_CHAIN_NW workers + S B sample + nstat statistics workgroups (asked once per context).
@@ -2058,8 +2072,9 @@ static int launch_post_chain(nm_ctx* c, const float* obs, int ldobs, const float
                              int32_t* best, int ldbest, float* kl, float* rec, int ldstat, float* gran) {
     const VrnnW& w = c->vrnn;
     const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4;
-    const size_t nd = ((size_t)S * B + 1) & ~(size_t)1;              // (an even count: the arrays behind it are read in 16-byte granule pairs)
-    const size_t ngran = (size_t)B * (4 * 128 + 3 * H + 2 * H) + (size_t)S * B * (S4 + Z) + nd;
+    const size_t nd = ((size_t)S * B + 1) & ~(size_t)1;
+    const int Tstat = kl ? T : 0;
+    const size_t ngran = post_chain_granules(B, S, K, Z, H, Tstat), nst = (size_t)(Tstat > 0 ? Tstat : 1) * B * 128;
     nm_gran* gb = reinterpret_cast<nm_gran*>(gran);
     PostChainArgs a;
     a.w_prior0 = w.prior0.w; a.b_prior0 = w.prior0.b; a.w_post0 = w.post0.w; a.b_post0 = w.post0.b;
@@ -2075,14 +2090,16 @@ static int launch_post_chain(nm_ctx* c, const float* obs, int ldobs, const float
     a.h0 = w.h0; a.obs = obs; a.ldobs = ldobs; a.eps = eps;
     a.out_kp = out_kp; a.ldkp = ldkp; a.out_z = out_z; a.ldz = ldz; a.out_R = out_R; a.ldR = ldR;
     a.out_h = out_h; a.ldh = ldh; a.best = best; a.ldbest = ldbest; a.kl = kl; a.rec = rec; a.ldstat = ldstat;
-    a.g_hidq = gb; a.g_hidp = gb + (size_t)B * 128; a.g_rh = gb + (size_t)2 * B * 128; a.g_jh = gb + (size_t)3 * B * 128;
-    a.g_gh = gb + (size_t)4 * B * 128; a.g_kpz = a.g_gh + (size_t)B * 3 * H; a.g_d = a.g_kpz + (size_t)S * B * (S4 + Z);
-    a.g_h[0] = a.g_d + nd; a.g_h[1] = a.g_h[0] + (size_t)B * H;
-    a.abort = reinterpret_cast<unsigned*>(a.g_h[1] + (size_t)B * H);
+    a.g_hidq = gb; a.g_rh = gb + (size_t)B * 128; a.g_jh = gb + (size_t)2 * B * 128;
+    a.g_gh = gb + (size_t)3 * B * 128; a.g_kpz = a.g_gh + (size_t)B * 3 * H; a.g_d[0] = a.g_kpz + (size_t)S * B * (S4 + Z); a.g_d[1] = a.g_d[0] + nd;
+    a.g_h[0] = a.g_d[1] + nd; a.g_h[1] = a.g_h[0] + (size_t)B * H;
+    a.g_sq = a.g_h[1] + (size_t)B * H; a.g_hidp = a.g_sq + nst;
+    a.abort = reinterpret_cast<unsigned*>(a.g_hidp + nst);
     a.status = c->nf_flag;
     a.B = B; a.S = S; a.T = T; a.K = K; a.Z = Z; a.H = H; a.nstat = kl ? B : 0;
     { static const int bo = getenv("NM355_CHAIN_BACKOFF") ? atoi(getenv("NM355_CHAIN_BACKOFF")) : 0; a.backoff = bo; }
     a.spin_limit = nm_ls().chain_spin > 0 ? nm_ls().chain_spin : NM_CHAIN_SPIN;
+    a.stat_delay = nm_ls().chain_stat_delay;
     int rc;
     if ((rc = nm_check_hip(hipMemsetAsync(gb, 0, ngran * sizeof(nm_gran) + 64, c->stream), "vrnn post chain: granule buffers"))) return rc;
     const int drop = std::min(std::max(nm_ls().chain_drop, 0), B);          // (NM355_CHAIN_DROP_WG, test hook: see rollout_steps)
@@ -2120,7 +2137,7 @@ static int encode_impl(nm_ctx* c, const float* keypoints, const float* eps, int3
     bool chain = !train && pc && (pc >= 2 || !c->in_fused) && post_chain_fits(c, B, S, B, rc);
     if (rc) return rc;
     if (chain) {
-        float* gran = c->ws.f(post_chain_gran_floats(B, S, K, Z, H));
+        float* gran = c->ws.f(post_chain_gran_floats(B, S, K, Z, H, T));
         if (c->ws.overflow) { nm_set_error("vrnn_encode: workspace overflow"); return NM_ERR_STATE; }
         if ((rc = launch_post_chain(c, keypoints, T * S4, eps, offset, B, T, S, kypt_recon, T * S4, z, T * Z, R, T * K * 9, h, (T + 1) * H, best_idx, T,
                                     kl, rec, T, gran))) return rc;
@@ -2376,7 +2393,7 @@ static size_t rollout_floats(int B, int Tcond, int Ttot, int S, int K, int Z, in
     return (size_t)B * (4 * 128 + 3 * H + 4 * Z) + (size_t)S * B * (Z + 256 + 3 + K + 6 * K + 9 * K + 1) + (B >= NM_GEMM_MIN_BATCH ? (size_t)B * 3 * H : 0)
          + (size_t)B * Tcond * S4 * 2 + (size_t)Tcond * S * B * Z + Tg * B * Z + (size_t)B * Tg * S4 + (size_t)B * K * 3 + 3 * (size_t)B * H + (size_t)B * Z
          + 2 * (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) + 64 + 64 * 36          // (256-byte alignment of each of the ~32 pieces)
-         + (size_t)B * Tcond * Z + (size_t)B * (Tcond + 1) * H + post_chain_gran_floats(B, S, K, Z, H);
+         + (size_t)B * Tcond * Z + (size_t)B * (Tcond + 1) * H + post_chain_gran_floats(B, S, K, Z, H, 0);
 }
 static RolloutBufs carve_rollout(Arena& ws, int B, int Tcond, int Ttot, int S, int K, int Z, int H) {
     RolloutBufs r;
@@ -2387,7 +2404,7 @@ static RolloutBufs carve_rollout(Arena& ws, int B, int Tcond, int Ttot, int S, i
     r.h_in = ws.f((size_t)B * H); r.offset = ws.f((size_t)B * K * 3);
     r.hbuf[0] = ws.f((size_t)B * H); r.hbuf[1] = ws.f((size_t)B * H); r.zbuf = ws.f((size_t)B * Z);
     r.chain_g = ws.f(2 * (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) + 64);
-    r.pc_z = ws.f((size_t)B * Tcond * Z + 1); r.pc_h = ws.f((size_t)B * (Tcond + 1) * H); r.pc_g = ws.f(post_chain_gran_floats(B, S, K, Z, H));
+    r.pc_z = ws.f((size_t)B * Tcond * Z + 1); r.pc_h = ws.f((size_t)B * (Tcond + 1) * H); r.pc_g = ws.f(post_chain_gran_floats(B, S, K, Z, H, 0));
     return r;
 }
 
@@ -2571,7 +2588,7 @@ static int rollout_impl(nm_ctx* c, int kind, const float* kp_cond, const float* 
     r.sb = alloc_step(c->ws, B, S, K, Z, H);
     r.hbuf[0] = c->ws.f((size_t)B * H); r.hbuf[1] = c->ws.f((size_t)B * H); r.zbuf = c->ws.f((size_t)B * Z);
     r.chain_g = c->ws.f(2 * (size_t)B * (3 * 128 + 3 * H + K * 4 + Z + 2 * H) + 64);
-    if (kind == 0) { r.pc_z = c->ws.f((size_t)B * Tcond * Z + 1); r.pc_h = c->ws.f((size_t)B * (Tcond + 1) * H); r.pc_g = c->ws.f(post_chain_gran_floats(B, S, K, Z, H)); }
+    if (kind == 0) { r.pc_z = c->ws.f((size_t)B * Tcond * Z + 1); r.pc_h = c->ws.f((size_t)B * (Tcond + 1) * H); r.pc_g = c->ws.f(post_chain_gran_floats(B, S, K, Z, H, 0)); }
     r.offset = kind == 0 ? c->ws.f((size_t)B * K * 3) : const_cast<float*>(offset_in);
     if (c->ws.overflow) { nm_set_error("vrnn rollout: workspace overflow"); return NM_ERR_STATE; }
     r.kp_cond = const_cast<float*>(kp_cond); r.eps_post = const_cast<float*>(eps_post); r.eps_prior = const_cast<float*>(eps_prior);

@@ -1061,6 +1061,50 @@ class _switches:
             else:
                 os.environ[k] = v
 
+def _conv_launches(net, vox, eps):
+    """launches of the profiled conv kernel families (all streams) during one inference forward"""
+    import ctypes as C
+    from neural_marionette_amd import _lib
+    with torch.no_grad():
+        net(vox, ACTS, eps=eps)               # (creates the context - under the caller's NM355_* switches - and builds the tree)
+        torch.cuda.synchronize()
+    lib, h = net._engine.ctx.lib, net._engine.ctx.handle
+    with torch.no_grad():
+        _lib.check(lib.nm_prof_enable(h, 2), "prof_enable")
+        net(vox, ACTS, eps=eps)
+        torch.cuda.synchronize()
+        _lib.check(lib.nm_prof_enable(h, 0), "prof_enable")
+    total = 0
+    for v in range(16):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(lib.nm_prof_read(h, v, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
+        total += n.value
+    return total
+
+
+@pytest.mark.parametrize("G", [64, 96])
+def test_fused_hourglass_core_runs_at_this_grid(G):
+    """The two lowest hourglass levels run as ONE launch (hg_core_kernel) in the inference forward - at 64^3 AND at BASELINE config 4's
+    96^3, where the level-2 tensors (6^3 voxels) leave no LDS for the K-split scratch of its convs and they store their tiles directly
+    (advisor finding, round 5: the scratch had silently pushed 96^3 back to ~38 separate launches).  Checked by launch count: a context
+    created with NM355_HG_CORE=0 issues 13 convs per feature net more; outputs agree to fp32 noise (different summation order)."""
+    o = HotPathOptions(grid_size=G)
+    sd = synth.make_state_dict(o, seed=8, variant="peaky")
+    B, T = 1, 2
+    vox = synth.figure_clip(B, T, G, seed=10).cuda()
+    eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=9).cuda()
+    fused = _net(o, sd)
+    n_fused = _conv_launches(fused, vox, eps)
+    with _switches({"NM355_HG_CORE": "0"}):
+        plain = _net(o, sd)
+        n_plain = _conv_launches(plain, vox, eps)
+    print("G=%d: %d profiled conv launches with hg_core, %d without" % (G, n_fused, n_plain))
+    assert n_plain - n_fused == 2 * 13, (n_fused, n_plain)
+    with torch.no_grad():
+        a = fused(vox, ACTS, eps=eps); b = plain(vox, ACTS, eps=eps)
+    assert _err(a["keypoints"], b["keypoints"]) < 2e-6 and _err(a["z_kypts"], b["z_kypts"]) < 2e-5
+
+
 
 @pytest.mark.parametrize("env", [{"NM355_VRNN_POSTMID": "1"}, {"NM355_VRNN_NB": "8"}, {"NM355_VRNN_MID": "0"}],
                          ids=["posterior-mid-kernel", "rows-per-pass-8", "six-launch-prior-step"])
@@ -1248,6 +1292,34 @@ def test_persistent_encode_is_bit_identical_to_launch_per_phase_steps(B, S, K, T
         assert torch.isfinite(outs["chain"][k].float()).all(), k
         assert torch.equal(outs["chain"][k], outs["launches"][k]), k
         assert torch.equal(again[k], outs["launches"][k]), k
+    for n in nets.values():
+        n.check_finite()
+
+
+def test_persistent_encode_with_lagging_statistics_workgroups():
+    """Advisor finding (round 5): nothing inside vrnn_post_chain_kernel waits for the statistics workgroups (prior / posterior
+    parameters + KL, off the critical path), and their inputs were single slots rewritten every step - one that fell a step behind on a
+    contended device polled for a tag that was gone, timed out and aborted the encode.  They now read per-step slots that are written
+    once; the sample workgroups' distance granules are double buffered.  NM355_CHAIN_STAT_DELAY makes every statistics workgroup idle
+    ~150 us before each step (a step is ~30 us: it ends up many steps behind): the call must complete with every output, the KL sum
+    included, bit-identical to the launch-per-phase path."""
+    o = HotPathOptions(grid_size=32)
+    sd = synth.make_state_dict(o, seed=21, variant="default")
+    B, T, S, K, Z = 4, 16, 10, o.nkeypoints, o.nlatent_kypt
+    nets = {}
+    for name, sw in (("launches", {"NM355_VRNN_POST_CHAIN": "0"}), ("lagging", {"NM355_VRNN_POST_CHAIN": "1", "NM355_CHAIN_STAT_DELAY": "40"})):
+        with _switches(sw):
+            nets[name] = _net(o, sd)
+            with torch.no_grad():
+                nets[name].kypt_detector.get_affinity()
+    kp = (torch.rand(B, T, K, 4, generator=torch.Generator().manual_seed(5)) * 1.6 - 0.8).cuda()
+    eps = synth.make_eps((T, S, B, Z), seed=51).cuda()
+    with torch.no_grad():
+        aff = O.affinity_v3(sd["kypt_detector.affinity_params"]).cuda()
+        outs = {n: net.dyna_module.encode(kp, aff, SAMPLE_NUM=S, eps=eps) for n, net in nets.items()}
+        torch.cuda.synchronize()
+    for k in ("kypt_recon", "R", "z_kypts", "h_kypts", "best_idx", "kl_kypt", "kypt_recon_loss"):
+        assert torch.equal(outs["lagging"][k], outs["launches"][k]), k
     for n in nets.values():
         n.check_finite()
 
