@@ -196,7 +196,7 @@ def host_cpu_limits():
 STEP_TFLOP = 99.15e-3 * B_PER_GPU * T          # algorithmic TFLOP of one forward step on one GPU
 # PMC summaries are only read from this round's files under profiles/ (tools/collect_evidence.sh <round> writes them; the round can be
 # overridden with NM355_ROUND for a re-run of an older tree)
-ROUND = os.environ.get("NM355_ROUND", "r05")
+ROUND = os.environ.get("NM355_ROUND", "r06")
 
 
 def prof_families(lib, h, _lib):
@@ -210,11 +210,24 @@ def prof_families(lib, h, _lib):
     return fam
 
 
+# FETCH_SIZE tallies 64 B per fabric read request (profiles/<round>_fetch_calib.txt, tools/calib/): contiguous streams leave the L2 as
+# 128-B requests (counter = bytes / 2 - MI355X_MICROARCH.md's x2), 64-B runs at a larger pitch as 64-B requests (counter = bytes).
+# Dominant read stream of each conv family -> the factor applied to its raw counter:
+FETCH_FACTOR = (
+    ("conv_up2c", 2.0, "staging loads 32 B per lane, 128 contiguous bytes per voxel (pattern pair32)"),
+    ("conv_pool_f16", 2.0, "32 contiguous bytes per lane (pattern pair32)"),
+    ("conv_f16", 1.0, "staging loads 16-B pieces, four lanes per (voxel, 16-channel chunk): 64-B runs at the voxel pitch (pattern seg64)"),
+    ("wgrad16", 1.0, "staging loads 16-B pieces in 64-B runs at the voxel pitch (pattern seg64)"),
+)
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from THIS round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in
-    separate runs, reduced by tools/pmc_traffic_all.py; a PMC pass cannot run inside this process).  `traffic` follows
-    MI355X_MICROARCH.md (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE); the raw figure and this access pattern's calibration are beside
-    it.  A file written in another round is refused: stale counters are worse than none."""
+    separate runs, reduced by tools/pmc_traffic_all.py; a PMC pass cannot run inside this process).  WRITE_SIZE is exact; FETCH_SIZE
+    counts 64 B per request whatever the request's size, so the read bytes lie between the raw counter and twice it: `traffic` applies
+    the factor calibrated for the kernel's dominant read stream (FETCH_FACTOR; calibration file of the same round), and the detail
+    carries both bounds.  Without this round's calibration file the figure is withheld (null) - an uncalibrated number is worse than
+    none.  A file written in another round is refused."""
     path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_traffic.json")
     try:
         pm = json.load(open(path))
@@ -228,10 +241,17 @@ def pmc_traffic(kernel):
     if rec is None:
         return None, dict(file=os.path.basename(path), note=f"no record for {kernel}")
     det = dict(file=os.path.basename(path), kernel=rec["kernel"], launches=rec["launches"], fetch_bytes_raw=rec["fetch_bytes_raw"],
-               fetch_bytes_x2=rec["fetch_bytes_x2"], write_bytes=rec["write_bytes"],
-               traffic_raw=rec["fetch_bytes_raw"] + rec["write_bytes"], traffic_x2=rec["fetch_bytes_x2"] + rec["write_bytes"],
-               calibration=pm.get("calibration"))
-    return det["traffic_x2"], det
+               write_bytes=rec["write_bytes"], traffic_lower_bound=rec["fetch_bytes_raw"] + rec["write_bytes"],
+               traffic_upper_bound=2 * rec["fetch_bytes_raw"] + rec["write_bytes"])
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_fetch_calib.json")))
+    except Exception:
+        det["note"] = f"no profiles/{ROUND}_fetch_calib.json: FETCH_SIZE uncalibrated this round, traffic withheld (bounds above)"
+        return None, det
+    fac, why = next(((f, w) for pre, f, w in FETCH_FACTOR if base.startswith(pre)), (2.0, "contiguous 16 B per lane (pattern contig16)"))
+    det.update(fetch_factor=fac, fetch_pattern=why, calibration={k: v["factor"] for k, v in cal.items()},
+               calibration_file=f"{ROUND}_fetch_calib.json")
+    return fac * rec["fetch_bytes_raw"] + rec["write_bytes"], det
 
 
 def extra_measurements(net, vox, eps, acts, dev, barrier, dist_on, world):
@@ -566,12 +586,15 @@ def main():
         frames = world * B_PER_GPU * T * args.steps
         # dominant kernel = the conv family with the largest event-timed total per step over BOTH streams (what a rocprof summary
         # ranks by); its `achieved` comes from its launches on the ctx stream inside the timed region (clean durations)
-        is_split = lambda nm: nm.startswith("conv_f16") or nm.startswith("conv_pool_f16") or nm.startswith("conv_up2c") or nm.startswith("wgrad16")
+        # f16 matrix-core families; THREE products per algorithmic product only in conv mode 1 (split-fp16) - the one-product modes
+        # (3 'f16' / 4 'bf16': conv_f16q2, conv_f16r and the SINGLE instantiations of the others) issue one (advisor finding, round 5)
+        is_f16 = lambda nm: nm.startswith("conv_f16") or nm.startswith("conv_pool_f16") or nm.startswith("conv_up2c") or nm.startswith("wgrad16")
+        is_split = lambda nm: eng.conv_mode == 1 and is_f16(nm) and not (nm.startswith("conv_f16q2") or nm.startswith("conv_f16r"))
         ranked = sorted(fam_all.items(), key=lambda kv: -kv[1][0])
         top3 = []
         for nm, (ms_a, fl_a, n_a) in ranked[:3]:
             ms_m, fl_m, n_m = fam_main.get(nm, (0.0, 0.0, 0))
-            pk = F16_MFMA_PEAK_TFLOPS if is_split(nm) else FP32_MFMA_PEAK_TFLOPS
+            pk = F16_MFMA_PEAK_TFLOPS if (is_f16(nm) and eng.conv_mode != 0) else FP32_MFMA_PEAK_TFLOPS
             top3.append(dict(kernel=nm, ms_per_step_all_streams=ms_a / 3.0, launches_per_step_all_streams=n_a / 3.0,
                              ms_per_step_ctx_stream=ms_m / args.steps, launches_per_step_ctx_stream=n_m / args.steps,
                              achieved_tflops_ctx_stream=(fl_m / (ms_m * 1e-3) / 1e12 if ms_m else None),
@@ -583,14 +606,16 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             traffic, traffic_detail = pmc_traffic(name)
             split = is_split(name)
-            peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            on_f16 = is_f16(name) and eng.conv_mode != 0
+            peak = F16_MFMA_PEAK_TFLOPS if on_f16 else FP32_MFMA_PEAK_TFLOPS
             roof = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=traffic,
                         traffic_detail=traffic_detail, top3=top3,
                         kernel=name, launches=n, avg_launch_ms=ms / n, kernel_time_share=ms * 1e-3 / dt,
                         note=("achieved = algorithmic fp32 conv FLOPs (2*voxels*Cout*Cin*k^3) / event-timed launch time; "
                               + ("this kernel issues 3 f16 MFMA products per algorithmic product (hi/lo operand split, "
                                  "f32 accumulate), so issued = 3 x achieved; peak = dense f16 MFMA"
-                                 if split else "peak = dense fp32 MFMA")))
+                                 if split else ("one f16 MFMA product per algorithmic product (operands rounded to fp16); peak = dense f16 MFMA"
+                                                if on_f16 else "peak = dense fp32 MFMA"))))
             if split:
                 roof["issued"] = 3.0 * ach
                 roof["frac_issued"] = 3.0 * ach / peak

@@ -28,7 +28,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $E/c4 -- python3 tools/t
 cp $(find $E/c4 -name "*kernel_stats.csv" | head -1) $E/${R}_config4_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/c5 -- python3 tools/time_rollout.py /tmp/ro.pt > $E/c5.log 2>&1
 cp $(find $E/c5 -name "*kernel_stats.csv" | head -1) $E/${R}_config5_rollout_kernel_stats.csv
-# PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+# FETCH_SIZE calibration on known byte counts (per access pattern), then the PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+bash tools/calib/run_fetch_calib.sh > $E/${R}_fetch_calib.txt 2>&1; cp gpurun_out/fetch_calib.json $E/${R}_fetch_calib.json
 PCMD="python3 bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $E/tf -- $PCMD > $E/tf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $E/tw -- $PCMD > $E/tw.log 2>&1

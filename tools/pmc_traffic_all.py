@@ -5,9 +5,8 @@ launch of every kernel, in the form bench.py's `roofline.traffic` reads (profile
 usage: pmc_traffic_all.py <fetch_dir> <write_dir> <round tag, e.g. r03> <out.json> [command that was profiled]
 
 FETCH_SIZE / WRITE_SIZE are in KB (x1024).  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports exactly half of the
-bytes of a wide coalesced streaming read -> `fetch_bytes_x2`; other access widths are uncalibrated, so the raw figure is kept too and
-the file carries a calibration on a known byte count in this library's own access pattern: conv_pool_f16q_kernel<1, ..> (conv_pool_f16s_kernel<1> before round 3's rewrite) reads its
-64 x 64^3 x 32-channel fp32 input (2.147 GB at the bench shape) exactly once, 32 contiguous bytes per lane."""
+bytes of a wide coalesced streaming read -> `fetch_bytes_x2`; streams of 64-B runs are counted exactly (round 6 calibration on known
+byte counts: tools/calib/, profiles/<round>_fetch_calib.txt), so both figures are kept and bench.py picks per kernel family."""
 import collections, csv, glob, json, re, sys
 
 fd, wd, rnd, out = sys.argv[1:5]
@@ -35,17 +34,12 @@ for k, d in fa.items():
     rows.append(dict(kernel=k, launches=n, fetch_bytes_raw=fr, fetch_bytes_x2=2 * fr, write_bytes=wr,
                      fetch_bytes_raw_max_launch=max(d.values()) * 1024))
 rows.sort(key=lambda r: -(r["fetch_bytes_x2"] + r["write_bytes"]) * r["launches"])
-cal = None
-pool = [r for r in rows if r["kernel"].startswith("conv_pool_f16q_kernel<1") or r["kernel"].startswith("conv_pool_f16s_kernel<1")]
-if pool:
-    known = 64 * 64 ** 3 * 32 * 4.0
-    cal = dict(kernel=pool[0]["kernel"], known_input_bytes=known, fetch_bytes_raw_largest_launch=pool[0]["fetch_bytes_raw_max_launch"],
-               raw_over_known=pool[0]["fetch_bytes_raw_max_launch"] / known,
-               note="the 64^3 x 32-channel pool launch reads its input exactly once (32 contiguous bytes per lane): raw / known is the "
-                    "factor FETCH_SIZE needs for this library's channels-last streams (the guide's x2 is for 16-byte-per-lane streams)")
+# calibration: tools/calib/run_fetch_calib.sh (known byte counts per access pattern) -> profiles/<round>_fetch_calib.json; bench.py applies it.
+# (Rounds 2-5 calibrated on the 64^3 x 32-channel pool launch "reading 2.147 GB once" - wrong in inference, where that launch reads a
+#  brick-sparse tensor and skips ~85 % of it: the 0.138 figure of profiles/r05_pmc_traffic.json says nothing about the counter.)
+cal = dict(note="FETCH_SIZE = 64 B per fabric read request: x2 for contiguous streams (128-B requests), x1 for 64-B runs; see <round>_fetch_calib.json")
 json.dump(dict(round=rnd, command=cmd, method=__doc__, calibration=cal, kernels=rows[:60]), open(out, "w"), indent=1)
 for r in rows[:16]:
     print("%-46s n=%4d fetch raw %8.1f MB (x2 %8.1f)  write %8.1f MB" % (r["kernel"][:46], r["launches"], r["fetch_bytes_raw"] / 1e6,
                                                                         r["fetch_bytes_x2"] / 1e6, r["write_bytes"] / 1e6))
-if cal:
-    print("calibration: raw/known = %.3f" % cal["raw_over_known"])
+
