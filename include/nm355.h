@@ -199,6 +199,13 @@ int nm_adam_step(nm_ctx* ctx, float* param, const float* grad, float* exp_avg, f
 int nm_adam_step_multi(nm_ctx* ctx, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numels, int32_t count, int32_t step, float lr,
                        float beta1, float beta2, float eps);
+/* the same with a device-side guard: `ok` points to ONE float on the device (written earlier on the ctx stream, e.g. "every gradient
+ * is finite"); 0.0f makes the launch a no-op - parameters, exp_avg and exp_avg_sq untouched, no host synchronisation - anything
+ * else (or a null pointer) applies the update.  The trainers of train.py pass the finiteness of their gradient bucket. */
+int nm_adam_step_multi_ok(nm_ctx* ctx, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numels, int32_t count, int32_t step, float lr,
+                       float beta1, float beta2, float eps,
+                          const float* ok);
 
 /* ---- training, detector mode (pretrained_mode = 0: train.py:270-276, the detector trains on its 11 losses) ----
  * nm_ctx_set_training(ctx, 1) makes nm_ctx_set_weights also pack the weights of the data-gradient convolutions

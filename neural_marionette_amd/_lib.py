@@ -68,6 +68,8 @@ SIGNATURES = {
     "nm_ctx_set_backward_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nm_adam_step_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_int64), _I, _I, _F, _F, _F, _F]),
+    "nm_adam_step_multi_ok": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_int64), _I, _I, _F, _F, _F, _F, _P]),
     "nm_vrnn_generate": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "nm_vrnn_rollout": (C.c_int, [C.c_void_p, _P, _P, _P, _I, _I, _P, _P]),
     "nm_vrnn_step": (C.c_int, [C.c_void_p, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),

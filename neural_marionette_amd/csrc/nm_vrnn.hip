@@ -1744,7 +1744,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 struct AdamItem { float* p; const float* g; float* m; float* v; long long numel; long long chunk0; };
 #define ADAM_CHUNK 4096
 __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamItem* __restrict__ items, int n, float lr, float b1, float b2, float eps,
-                                                         float bc1, float bc2) {
+                                                         float bc1, float bc2, const float* __restrict__ ok) {
+    if (ok && *ok == 0.f) return;            // a step whose gradient bucket was not finite: parameters and both moments stay as they are
     int lo = 0, hi = n - 1;                   // last item whose first chunk is <= blockIdx.x
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].chunk0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1; }
     const AdamItem it = items[lo];
@@ -2329,8 +2330,18 @@ int nm_adam_step(nm_ctx* c, float* param, const float* grad, float* exp_avg, flo
     return nm_check_hip(hipGetLastError(), "adam launch");
 } catch (...) { return nm_abi_catch("nm_adam_step"); }
 
+static int adam_multi_impl(nm_ctx* c, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                           const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps, const float* ok);
 int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                        const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps) try { NmScope nm_scope_(c);
+    return adam_multi_impl(c, params, grads, exp_avg, exp_avg_sq, numels, count, step, lr, beta1, beta2, eps, nullptr);
+} catch (...) { return nm_abi_catch("nm_adam_step_multi"); }
+int nm_adam_step_multi_ok(nm_ctx* c, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                          const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps, const float* ok) try { NmScope nm_scope_(c);
+    return adam_multi_impl(c, params, grads, exp_avg, exp_avg_sq, numels, count, step, lr, beta1, beta2, eps, ok);
+} catch (...) { return nm_abi_catch("nm_adam_step_multi_ok"); }
+static int adam_multi_impl(nm_ctx* c, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                           const int64_t* numels, int32_t count, int32_t step, float lr, float beta1, float beta2, float eps, const float* ok) {
     if (!c || !params || !grads || !exp_avg || !exp_avg_sq || !numels || count <= 0 || step <= 0) { nm_set_error("adam_step_multi: bad argument"); return NM_ERR_ARG; }
     c->host_table.resize((size_t)count * sizeof(AdamItem));
     AdamItem* items = reinterpret_cast<AdamItem*>(c->host_table.data());
@@ -2348,9 +2359,9 @@ int nm_adam_step_multi(nm_ctx* c, float* const* params, const float* const* grad
     AdamItem* dev = static_cast<AdamItem*>(c->ws.alloc_bytes(bytes));
     if ((rc = nm_check_hip(hipMemcpyAsync(dev, items, bytes, hipMemcpyHostToDevice, c->stream), "adam_step_multi: table upload"))) return rc;
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, c->stream, dev, count, lr, beta1, beta2, eps, bc1, bc2);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, c->stream, dev, count, lr, beta1, beta2, eps, bc1, bc2, ok);
     return nm_check_hip(hipGetLastError(), "adam_multi launch");
-} catch (...) { return nm_abi_catch("nm_adam_step_multi"); }
+}
 
 // ---- rollouts: nm_vrnn_generate (hsvrnn_bvh.py:158-234) and nm_vrnn_rollout (the prior loop of vis_generation.py:117-127) ------
 // A rollout is hundreds of dependent ~3 us launches; enqueued one by one the host (3-5 us per launch) is the bottleneck.  For the

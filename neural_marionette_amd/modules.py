@@ -153,7 +153,11 @@ class Engine:
         one after a weight change is also probed synchronously: if it overflowed it is re-run here on the exact fp32 path (all of a
         call's outputs are rewritten), and fp32 stays selected until the weights change."""
         self.call(fn, *args)
-        if not (self.auto and self._probe) or (self.suppress_probe and not self.auto_explicit):
+        # training forwards (the autograd path with ANY torch optimizer, not only the trainers' steps) change the weights every step: a
+        # synchronous probe per weight change would be one device synchronisation per step and, on overflow, a whole second forward -
+        # they rely on the deferred guard like the trainers unless 'auto' was asked for explicitly (advisor finding, round 5)
+        training_call = self.training_packs or fn.endswith("_train")
+        if not (self.auto and self._probe) or ((self.suppress_probe or training_call) and not self.auto_explicit):
             return
         self._probe = False
         rc = self.ctx.lib.nm_ctx_check_nonfinite(self.ctx.handle)

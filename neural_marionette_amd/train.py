@@ -126,28 +126,34 @@ class GradBucket:
         return float(self._ev_t0.elapsed_time(self._ev_t1))
 
 
-def _drop_nonfinite_step_(flat: torch.Tensor) -> None:
+def _bucket_ok(flat: torch.Tensor, check: bool, what: str) -> torch.Tensor:
     """The library's range guard is deferred: a conv that overflowed the fp16 range in step n (conv modes 'split16' / 'f16' / 'bf16')
     is reported at the first library call of step n + 1 (include/nm355.h "Range / finiteness status") - after this step's Adam
-    update.  So that the update of such a step cannot destroy the master weights and the Adam moments, a gradient bucket that holds
-    ANY non-finite entry is zeroed as a whole, on the device, without a synchronisation (two passes over <= 34 MB): the step then
-    only decays the moments, the parameters stay finite, and the next call raises NM_ERR_RANGE naming the call that overflowed
-    (set_conv_mode('auto') re-runs such a call in exact fp32 instead).  After a collective: every rank zeroes (NaN spreads through the sum)."""
+    update.  So that such a step cannot destroy the master weights and the Adam moments, the finiteness of the whole gradient bucket
+    (after the collective: NaN spreads through the sum, every rank sees the same verdict) is reduced to ONE device float - one read
+    pass over <= 34 MB, no synchronisation - and handed to the Adam launch (nm_adam_step_multi_ok), which does nothing at all when
+    it is 0: parameters, both moments untouched.  The host-side step counter still advances (bias corrections one step ahead for the
+    rest of the epoch - the price of not synchronising); step(check=True) reads the flag on the host instead, raises BEFORE the
+    optimizer and leaves the counter alone."""
     ok = torch.isfinite(flat).all()
-    flat.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
-    flat.mul_(ok.to(flat.dtype))
+    if check and not bool(ok):
+        raise _lib.NmError(f"{what}: the step's gradient bucket holds a non-finite entry - no optimizer update was applied "
+                           "(an activation left the split-fp16 range, or the input was not finite; set_conv_mode('auto') re-runs such a "
+                           "forward in exact fp32)")
+    return ok.to(torch.float32)
 
 
-def adam_step_(eng, params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps) -> None:
-    """torch.optim.Adam's update for a list of tensors in one library launch (nm_adam_step_multi); bumps the version counters so
-    that the engine re-uploads / re-packs the weights before the next forward."""
+def adam_step_(eng, params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps, ok: Optional[torch.Tensor] = None) -> None:
+    """torch.optim.Adam's update for a list of tensors in one library launch (nm_adam_step_multi_ok; ok: 0-dim device float, 0 = skip
+    the whole update on the device); bumps the version counters so that the engine re-uploads / re-packs the weights before the
+    next forward."""
     import ctypes as C
     n = len(params)
     arr = lambda ts: (C.c_void_p * n)(*[_lib.ptr(t) for t in ts])
     gs = [g.contiguous() for g in grads]
     with torch.no_grad():
-        eng.call("nm_adam_step_multi", arr([p.data for p in params]), arr(gs), arr(exp_avg), arr(exp_avg_sq),
-                 (C.c_int64 * n)(*[p.numel() for p in params]), n, step, lr, betas[0], betas[1], eps)
+        eng.call("nm_adam_step_multi_ok", arr([p.data for p in params]), arr(gs), arr(exp_avg), arr(exp_avg_sq),
+                 (C.c_int64 * n)(*[p.numel() for p in params]), n, step, lr, betas[0], betas[1], eps, _lib.ptr(ok) if ok is not None else None)
         torch._foreach_add_(list(params), 0.0)
 
 
@@ -179,8 +185,10 @@ class LearnerTrainer:
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
 
-    def step(self, vox, eps=None, sync: bool = True, global_clips: Optional[int] = None):
+    def step(self, vox, eps=None, sync: bool = True, global_clips: Optional[int] = None, check: bool = False):
         """One training step.  sync=True returns python floats (waits for the device); sync=False returns 0-dim device tensors.
+        check=True: the finiteness of the gradient bucket is read on the host (one synchronisation) and a non-finite step raises NmError
+        BEFORE the optimizer runs; default: the Adam launch skips itself on the device (_bucket_ok).
         global_clips: as DetectorTrainer.step (uneven clip split: the loss that is back-propagated is scaled by this rank's share).
         Gradients land in a persistent GradBucket (every p.grad is a view of the flat buffer autograd accumulates into), which is
         what the collective reduces: one all-reduce of 1.53 M floats, no torch.cat, no copy back - the DetectorTrainer's scheme."""
@@ -194,7 +202,7 @@ class LearnerTrainer:
         for n, p in self.named:
             p.grad = bucket.views[n]                  # autograd accumulates in place into an existing .grad
         # (no synchronous range probe per step - the weights change every step - unless conv mode 'auto' was asked for explicitly: the
-        #  deferred guard reports an overflow at the next call and _drop_nonfinite_step_ keeps it out of the optimizer state)
+        #  deferred guard reports an overflow at the next call and the Adam launch skips itself on the device when the bucket is not finite: _bucket_ok)
         net._engine.suppress_probe = True
         try:
             log = net(vox, {"detector": False, "learner": True}, eps=eps, detector_outputs="keypoints" if self.lean else "all")
@@ -209,12 +217,12 @@ class LearnerTrainer:
                 bucket.views[n].copy_(p.grad); p.grad = bucket.views[n]
         bucket.reduce_chunk(0)
         bucket.finish()
-        _drop_nonfinite_step_(bucket.flat)
+        ok = _bucket_ok(bucket.flat, check, "LearnerTrainer.step")
         grads = [bucket.views[n] for n, _ in self.named]
         eng = net._engine
         eng.ready()
         self.t += 1
-        adam_step_(eng, self.params, grads, self.m, self.v, self.t, self.lr, self.betas, self.eps)
+        adam_step_(eng, self.params, grads, self.m, self.v, self.t, self.lr, self.betas, self.eps, ok=ok)
         if not sync:
             return {"loss": loss.detach(), **{k: log[k].detach() for k in self.weights}}
         return {"loss": float(loss.detach()), **{k: float(log[k].detach()) for k in self.weights}}
@@ -323,14 +331,15 @@ class DetectorTrainer:
         self._keep = (vox, kp, recon, aff)          # read by the backward kernels (stream-ordered: freed no earlier than the next step)
         return losses
 
-    def _adam(self, params, grads, m, v):
+    def _adam(self, params, grads, m, v, ok=None):
         eng = self.net._engine
         eng.ready()
-        adam_step_(eng, params, grads, m, v, self.t, self.lr, self.betas, self.eps)
+        adam_step_(eng, params, grads, m, v, self.t, self.lr, self.betas, self.eps, ok=ok)
 
-    def step(self, vox, sync: bool = True, global_clips: Optional[int] = None):
+    def step(self, vox, sync: bool = True, global_clips: Optional[int] = None, check: bool = False):
         """One training step.  sync=True returns python floats (waits for the device); sync=False returns 0-dim device tensors and
-        lets the host run ahead into the next step.
+        lets the host run ahead into the next step.  check=True: a non-finite gradient bucket raises NmError before the optimizer
+        (one host synchronisation); default: the Adam launch skips itself on the device (_bucket_ok).
         global_clips: total number of clips of the step over all ranks when the ranks hold DIFFERENT numbers of clips (a batch that
         does not divide by the world size, dist.clip_shard).  Every loss is a mean over clips, so the single-process gradient of the
         whole batch is the clip-weighted mean of the ranks' gradients: this rank's dL/dloss vector is scaled by
@@ -347,7 +356,7 @@ class DetectorTrainer:
         losses = self._forward_backward(vox, named, bucket)
         bucket.reduce_chunk(1)
         bucket.finish()
-        _drop_nonfinite_step_(bucket.flat)
+        ok = _bucket_ok(bucket.flat, check, "DetectorTrainer.step")
         live = [(n, p) for n, p in named if p.requires_grad]          # frozen parameters: gradient computed, not applied
         params = [p for _, p in live]
         grads = [bucket.views[n] for n, _ in live]
@@ -357,7 +366,7 @@ class DetectorTrainer:
         for p in params:
             if id(p) not in self.state:
                 self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
-        self._adam(params, grads, [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params])
+        self._adam(params, grads, [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params], ok=ok)
         loss = (losses * self._weight_vector(losses.device)).sum()      # (this rank's clips; dist.mean_losses gives the global figure)
         log = {k: losses[i] for i, k in enumerate(self.loss_keys) if k in self.weights}
         if not sync:

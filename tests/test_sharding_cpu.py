@@ -107,10 +107,14 @@ def _trainer_worker(rank, world, port, q):
         def _forward_backward(self, vox, named, bucket):
             for n, p in named:
                 bucket.views[n].copy_(_stub_grad(n, p.shape, rank))
+            if getattr(self, "poison", False) and rank == 1:
+                bucket.flat[bucket.flat.numel() // 2] = float("inf")          # ONE rank's gradient overflowed
             bucket.reduce_chunk(0)                   # as the HIP step does once the decoder's gradients exist
             return torch.arange(11, dtype=torch.float32) * (rank + 1)
 
-        def _adam(self, params, grads, m, v):        # torch.optim.Adam's update, written out
+        def _adam(self, params, grads, m, v, ok=None):        # torch.optim.Adam's update, written out (ok == 0: nm_adam_step_multi_ok's no-op)
+            if ok is not None and float(ok) == 0.0:
+                return
             b1, b2 = self.betas
             for p, g, mm, vv in zip(params, grads, m, v):
                 mm.mul_(b1).add_(g, alpha=1 - b1); vv.mul_(b2).addcmul_(g, g, value=1 - b2)
@@ -134,6 +138,25 @@ def _trainer_worker(rank, world, port, q):
         assert p.grad.data_ptr() == tr.bucket.views[name].data_ptr()
         want = before[name] - 1e-2 * g / (g.abs() + 1e-8)                        # first Adam step: m_hat / (sqrt(v_hat) + eps)
         worst = max(worst, float((p.detach() - want).abs().max()))
+    # a step in which ONE rank's gradient holds an inf: the sum carries it to every rank, the bucket's finiteness flag is 0 on both and
+    # the optimizer leaves parameters and moments exactly as they are (no zeroed-gradient pseudo step); check=True raises instead
+    after1 = {k: v.clone() for k, v in net.state_dict().items()}
+    mom1 = {i: (m.clone(), v.clone()) for i, (m, v) in tr.state.items()}
+    tr.poison = True
+    tr.step(torch.zeros(1, 2, 1, 32, 32, 32))
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, after1[k]), k
+    for i, (m, v) in tr.state.items():
+        assert torch.equal(m, mom1[i][0]) and torch.equal(v, mom1[i][1])
+    raised = False
+    try:
+        tr.step(torch.zeros(1, 2, 1, 32, 32, 32), check=True)
+    except Exception as e:
+        raised = "non-finite" in str(e)
+    assert raised, "step(check=True) must raise on a non-finite gradient bucket"
+    tr.poison = False
+    tr.step(torch.zeros(1, 2, 1, 32, 32, 32))          # and training goes on
+    assert any(not torch.equal(v, after1[k]) for k, v in net.state_dict().items())
     if rank == 0:
         q.put((worst, float(out["loss"]), sorted(out)))
     dist.barrier()
