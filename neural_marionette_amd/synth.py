@@ -32,6 +32,9 @@ def make_state_dict(opts: HotPathOptions, seed: int = 0, variant: str = "default
                    random affinity logits.
       ``peaky``    like ``default`` but the heat-map heads are scaled up so the
                    detected keypoints spread over [-1, 1] instead of hugging 0.
+      ``tracking`` ``peaky`` with the occupancy channel of both first layers (input channel 0 of the k5 convs) scaled by 10: the
+                   keypoints follow the figure (frame-to-frame keypoint velocities ~3e-2 on the figure clips instead of 1e-5 ... 1e-2),
+                   which makes the trajectory term of the graph loss well conditioned (fixture G12).
       ``winit``    what a from-scratch detector run starts from (train.py:262,268 ->
                    utils/train_utils.py:248-264 of the reference): convs inside the
                    ``*Block`` containers (both feature nets) N(0, 0.001), the other convs
@@ -64,8 +67,10 @@ def make_state_dict(opts: HotPathOptions, seed: int = 0, variant: str = "default
             else:
                 b = 1.0 / math.sqrt(_fan_in(shape))
             a = rng.uniform(-b, b, size=shape)
-        if variant == "peaky" and ("heatmaps_from_features.0.weight" in name):
+        if variant in ("peaky", "tracking") and ("heatmaps_from_features.0.weight" in name):
             a = a * 12.0
+        if variant == "tracking" and name.endswith("features.0.block.0.weight"):
+            a[:, 0] = a[:, 0] * 10.0
         sd[name] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
     return sd
 

@@ -218,3 +218,54 @@ def test_g7_eval_metrics(golden_dir):
     closest, counts = O.semantic_votes(kp, gt)
     assert np.array_equal(counts.numpy(), g["semantic_scores"])
     assert O.semantic_log(counts) == g["semantic_log"]
+
+
+def _oracle_vs_full_forward_fixture(g, clips=None, tol=TOL):
+    """The oracle against a fixture of tools/make_golden.py::_full_forward_case (G9 / G10 / G12).  clips: evaluate only these clips of
+    the fixture's batch (clips are independent in the forward pass; ATen's CPU kernels may order sums differently at another batch
+    size, hence a tolerance and no bitwise claim here - the bitwise one is asserted when the fixture is written)."""
+    G, B, T, wseed, iseed, eseed = [int(v) for v in g["meta"]]
+    o = HotPathOptions(grid_size=G)
+    sd = synth.make_state_dict(o, seed=wseed, variant=str(g["variant"]))
+    vox = synth.figure_clip(B, T, G, seed=iseed)
+    eps = synth.make_eps((T, 10, B, o.nlatent_kypt), seed=eseed)
+    sel = list(range(B)) if clips is None else list(clips)
+    with torch.no_grad():
+        r = O.nm_forward(sd, o, vox[sel].contiguous(), eps[:, :, sel].contiguous())
+    for k in ("keypoints", "kypt_recon", "R", "z_kypts", "h_kypts"):
+        _close(r[k], g[k][sel], tol, what=k)
+    assert np.array_equal(np.asarray(r["best_idx"]).astype(np.int32), g["best_idx"][sel])
+    assert np.array_equal(r["parents"], g["parents"])
+    _close(r["heatmaps"][..., ::2, ::2, ::2], g["heatmaps_sub"][sel], tol, what="heatmaps")
+    _close(r["recon"][..., ::4, ::4, ::4], g["recon_sub4"][sel], tol, what="recon")
+    n = int(np.prod(g["recon_sum"].shape)) * G ** 3
+    occ = np.unpackbits(g["recon_occ_bits"])[:n].astype(bool).reshape(B, T, 1, G, G, G)[sel]
+    near = np.unpackbits(g["recon_near_bits"])[:n].astype(bool).reshape(B, T, 1, G, G, G)[sel]
+    assert int((((r["recon"].numpy() >= 0.5) != occ) & ~near).sum()) == 0
+    if clips is None:
+        _close([float(r[k]) for k in DETECTOR_LOSS_KEYS], g["losses"], tol, what="losses")
+
+
+def test_g12_tracking_clip_full_forward32(golden_dir):
+    g = _load(golden_dir, "g12_tracking32.npz")
+    assert float(g["keypoint_speed_median"]) > 1e-2          # what the fixture is for: keypoints that move (graph_traj_loss well conditioned)
+    _oracle_vs_full_forward_fixture(g)
+
+
+def test_g9_config2_one_clip_of_the_batch(golden_dir):
+    """BASELINE config 2's fixture (64^3, B = 4, T = 16; written by the reference in 16 s): the oracle on ONE of its four clips."""
+    _oracle_vs_full_forward_fixture(_load(golden_dir, "g9_config2_forward64.npz"), clips=[2])
+
+
+def test_g11_interpolation_driver(golden_dir):
+    g = _load(golden_dir, "g11_interpolation32.npz")
+    G, wseed, iseed = [int(v) for v in g["meta"]]
+    o = HotPathOptions(grid_size=G)
+    sd = synth.make_state_dict(o, seed=wseed, variant="peaky")
+    full = synth.figure_clip(1, 11, G, seed=iseed)[0]
+    T, S, rate, sa, sb = [int(v) for v in g["a_meta"]]
+    with torch.no_grad():
+        r = O.sample_interpolation(sd, o, full[:T], rate, S, synth.make_eps((T, S, 128), sa), synth.make_eps((T, S, 128), sb))
+    assert [tuple(p) for p in r["picks"]] == [tuple(int(x) for x in p) for p in g["a_picks"]]
+    _close(r["keypoints"], g["a_keypoints"], what="interpolation keypoints")
+    assert g["b_keypoints"].shape == (1, 5, 24, 4) and int(g["b_meta"][1]) == 10000

@@ -296,7 +296,146 @@ def case_g8():
     print("g8 ok", float(loss), n, "tensors")
 
 
-CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6, g7=case_g7, g8=case_g8)
+def _pack_recon(x, margin=3e-5):
+    """A decoded occupancy field (B,T,1,G,G,G) in the compact form the full-size fixtures carry: the thresholded set and the set of
+    voxels within `margin` of the threshold as packed bits (every voxel), the values themselves on a stride-4 sub-lattice."""
+    x = x.detach()
+    return dict(recon_occ_bits=np.packbits(_np(x >= 0.5).reshape(-1)), recon_near_bits=np.packbits(_np((x - 0.5).abs() <= margin).reshape(-1)),
+                recon_sub4=_sub(x, 4), recon_sum=_np(x.double().sum(dim=(2, 3, 4, 5))), recon_margin=np.float64(margin))
+
+
+def _full_forward_case(fname, G, B, T, wseed, iseed, eseed, variant="peaky"):
+    """The reference's full forward (detector + VRNN.encode, recorded eps) at a BASELINE configuration's size; best-of-S indices and
+    their margins come from the oracle run on the same inputs, which must equal the reference bit for bit (asserted here)."""
+    from oracle import nm_oracle as O
+    opt = _ref_opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=wseed, variant=variant)
+    net = _ref_net(opt, sd)
+    vox = synth.figure_clip(B, T, G, seed=iseed)
+    eps = synth.make_eps((T, S, B, o.nlatent_kypt), seed=eseed)
+    with torch.no_grad(), EpsFeed(eps):
+        r = net(vox, {"detector": True, "learner": True})
+    with torch.no_grad():
+        ro = O.nm_forward(sd, o, vox, eps)
+    for k in ("keypoints", "heatmaps", "recon", "z_kypts", "h_kypts", "kypt_recon", "R"):
+        assert torch.equal(r[k], ro[k]), k                       # the oracle IS the reference on these inputs
+    d = net.dyna_module
+    kp = r["keypoints"][..., :3]
+    vel = (kp[:, 1:] - kp[:, :-1]).norm(dim=-1)
+    np.savez_compressed(
+        os.path.join(OUT, fname),
+        meta=np.array([G, B, T, wseed, iseed, eseed]), variant=variant, clip="figure",
+        keypoints=_np(r["keypoints"]), heatmaps_sub=_sub(r["heatmaps"], 2), heatmaps_sum=_np(r["heatmaps"].double().sum(dim=(3, 4, 5))),
+        heatmaps_absmax=np.float64(r["heatmaps"].abs().max()),
+        first_feature_sub=_sub(r["first_feature"], 2), first_feature_absmax=np.float64(r["first_feature"].abs().max()),
+        losses=np.array([float(r[k]) for k in DETECTOR_LOSS_KEYS], dtype=np.float64),
+        affinity=_np(r["affinity"]),
+        kypt_recon=_np(r["kypt_recon"]), R=_np(r["R"]), z_kypts=_np(r["z_kypts"]), h_kypts=_np(r["h_kypts"]),
+        kl_kypt=np.float64(r["kl_kypt"]), kypt_recon_loss=np.float64(r["kypt_recon_loss"]),
+        best_idx=_np(ro["best_idx"]).astype(np.int32), keypoint_speed_median=np.float64(vel.median()),
+        parents=_np(d.parents), order=_np(d.priority.indices),
+        **_pack_recon(r["recon"]),
+    )
+    print(fname, "ok: recon_loss", float(r["recon_loss"]), "kl", float(r["kl_kypt"]), "median keypoint speed %.2e" % float(vel.median()))
+
+
+def case_g9():
+    """BASELINE config 2 as the bench and tests/test_network_gpu.py::test_config2_* run it: 64^3, B=4, T=16, weights seed 42, clip seed 77."""
+    _full_forward_case("g9_config2_forward64.npz", 64, 4, 16, 42, 77, 78)
+
+
+def case_g10():
+    """BASELINE config 4: 96^3, B=2, T=8 (hourglass 24 -> 12 -> 6 -> 3), weights seed 9, clip seed 31."""
+    _full_forward_case("g10_config4_forward96.npz", 96, 2, 8, 9, 31, 32)
+
+
+def case_g12():
+    """A clip whose keypoints MOVE (variant 'tracking': median frame-to-frame keypoint speed ~3e-2): the trajectory term of the graph
+    loss (kypt_detector_utils.py:228-265) is well conditioned there and is held to the plain 2e-5 like the other ten."""
+    _full_forward_case("g12_tracking32.npz", 32, 2, 6, 3, 5, 9, variant="tracking")
+
+
+def _ref_interpolation(net, vox, rate, Sn, ea, eb):
+    """The loop of vis_interpolation.py:80-143 on the reference's own sub-modules (the script imports open3d / cv2 and cannot be
+    imported): returns the selected keypoints (1, T, K, 4) and the (posterior, prior) picks of every key frame."""
+    import torch.distributions.normal as tdn
+    from torch.distributions.normal import Normal
+    import torch.nn.functional as F
+    dm = net.dyna_module
+    T = vox.shape[0]
+    draws = []
+    for t in range(T):
+        draws += [ea[t], eb[t]] if (t % rate == 0 or t == T - 1) else [ea[t]]
+    with torch.no_grad():
+        det = net.kypt_detector(vox[None])
+        kp = det["keypoints"]
+        Tn = kp.shape[1]
+        with EpsFeed([torch.zeros(S, 1, 128) for _ in range(Tn)]):
+            dm.encode(kp, det["affinity"])                   # builds the tree (its own draws are irrelevant)
+        K = kp.shape[2]
+        with EpsFeed(draws):
+            h = dm.init_kypt_rnn_state.expand(Sn, -1)
+            off = dm.get_offset(kp).expand(Sn, -1, -1, -1)
+            sel, pend, picks = [], [], []
+            for t in range(T):
+                flat = kp[:, t].clone().view(1, -1).expand(Sn, -1)
+                if t % rate == 0 or t == T - 1:
+                    mu, sg = torch.chunk(dm.extract_post_dist(torch.cat([h, flat], -1)), 2, -1)
+                    pm, ps = torch.chunk(dm.extract_prior_dist(h), 2, -1)
+                    z = Normal(mu, F.softplus(sg) + 1e-4).rsample()
+                    zc = Normal(pm, F.softplus(ps) + 1e-4).rsample()
+                    f, _ = dm.extract_kypt_from_latent_and_state(torch.cat([h, z], -1), off)
+                    fc, _ = dm.extract_kypt_from_latent_and_state(torch.cat([h, zc], -1), off)
+                    i = (f - flat).pow(2).sum(-1).argmin()
+                    f, z, h = f[i][None].expand(Sn, -1), z[i][None].expand(Sn, -1), h[i][None].expand(Sn, -1)
+                    j = (fc - f).pow(2).sum(-1).argmin()
+                    pend.append(flat)
+                    sel += [s_[j].view(K, 4) for s_ in pend]
+                    pend = []
+                    picks.append((int(i), int(j)))
+                else:
+                    pm, ps = torch.chunk(dm.extract_prior_dist(h), 2, -1)
+                    z = Normal(pm, F.softplus(ps) + 1e-4).rsample()
+                    f, _ = dm.extract_kypt_from_latent_and_state(torch.cat([h, z], -1), off)
+                    pend.append(f)
+                h = dm.kypt_rnn_cell(torch.cat([f, z], -1), h)
+            sel = torch.stack(sel, 0)[None].clone()
+            sel[0, :, :, -1] = sel[0, 0, :, -1]
+        dec = net.kypt_detector.decode_from_dyna(sel, det["first_feature"], vox[None, 0])["gen"][0]
+    return sel, picks, dec
+
+
+def case_g11():
+    """The interpolation driver (vis_interpolation.py:80-143) at S = 256 (T = 11, key frames every 5) and at the demo's S = 10 000
+    (T = 5, every 2) - the shape where the VRNN MLPs are real GEMMs: selected keypoints, the picks of every key frame with the relative
+    gap between the best and second-best candidate (from the oracle, which must reproduce the reference's picks and keypoints
+    exactly), thresholded voxels as packed bits."""
+    from oracle import nm_oracle as O
+    G, wseed, iseed = 32, 29, 8
+    opt = _ref_opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=wseed, variant="peaky")
+    net = _ref_net(opt, sd)
+    out = dict(meta=np.array([G, wseed, iseed]))
+    full = synth.figure_clip(1, 11, G, seed=iseed)[0]
+    for tag, T, Sn, rate, sa, sb in (("a", 11, 256, 5, 9, 10), ("b", 5, 10000, 2, 11, 12)):
+        vox = full[:T]
+        ea, eb = synth.make_eps((T, Sn, 128), sa), synth.make_eps((T, Sn, 128), sb)
+        sel, picks, dec = _ref_interpolation(net, vox, rate, Sn, ea, eb)
+        with torch.no_grad():
+            mine = O.sample_interpolation(sd, o, vox, rate, Sn, ea, eb)
+        assert torch.equal(mine["keypoints"], sel) and [tuple(p) for p in mine["picks"]] == picks, tag
+        assert torch.equal(mine["voxels_raw"], dec), tag
+        out.update({tag + "_meta": np.array([T, Sn, rate, sa, sb]), tag + "_keypoints": _np(sel), tag + "_picks": np.array(picks, dtype=np.int64),
+                    tag + "_margins": np.array(mine["margins"], dtype=np.float64),
+                    tag + "_vox_bits": np.packbits(_np(dec >= 0.5).reshape(-1)), tag + "_vox_near_bits": np.packbits(_np((dec - 0.5).abs() <= 1e-3).reshape(-1))})
+        print("g11", tag, "picks", picks, "margins", ["%.1e/%.1e" % tuple(m) for m in mine["margins"]])
+    np.savez_compressed(os.path.join(OUT, "g11_interpolation32.npz"), **out)
+    print("g11 ok")
+
+
+CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11, g12=case_g12)
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
