@@ -943,8 +943,10 @@ int nm_launch_conv_up2c(const TensorRef& in, const void* packed, const float* bi
     if (io == 3) hipLaunchKernelGGL((conv_up2c_kernel<true, 3>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else if (io == 2) hipLaunchKernelGGL((conv_up2c_kernel<true, 2>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else if (io == 1) hipLaunchKernelGGL((conv_up2c_kernel<true, 1>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
-    else if (nm_ls().up2c_x16 && single) hipLaunchKernelGGL(conv_up2c_x16_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
-    else if (nm_ls().up2c_x16) hipLaunchKernelGGL(conv_up2c_x16_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    // (the one-product modes keep the 32x32x16 kernel in fp32 storage too: their bfloat16-storage instantiations are bit-compared with
+    //  it, tests/test_storage16_gpu.py; NM355_UP2C_X16=2 forces the 16x16x32 form there as well - A/B)
+    else if (nm_ls().up2c_x16 >= 2 && single) hipLaunchKernelGGL(conv_up2c_x16_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
+    else if (nm_ls().up2c_x16 && !single) hipLaunchKernelGGL(conv_up2c_x16_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else if (single) hipLaunchKernelGGL(conv_up2c_kernel<true>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else if (nm_ls().up2c_diag & 64) hipLaunchKernelGGL((conv_up2c_kernel<false, 0, true>), dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);
     else hipLaunchKernelGGL(conv_up2c_kernel<false>, dim3((unsigned)min(total, g_cus)), dim3(512), LDS_BYTES, s, p);

@@ -215,23 +215,16 @@ def test_detector_gradients_other_keypoint_counts(K, mode):
     _compare(ref, got, tol=TOL)
 
 
-def test_detector_training_trajectory_vs_oracle():
-    """Three detector-mode training steps (Adam lr 4e-4, AIST weights): loss trajectory against the oracle trained with
-    torch.optim.Adam on the CPU (same op sequence as train.py:388-404)."""
-    from neural_marionette_amd.train import DetectorTrainer, DETECTOR_LOSS_WEIGHTS
-    o, sd, vox = _setup(seed=41)
-    names = [k for k in sd if k.startswith("kypt_detector.")]
-    leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
-    sd2 = dict(sd); sd2.update(leaf)
-    opt = torch.optim.Adam([leaf[k] for k in names], lr=4e-4)
-    ref_losses = []
-    for _ in range(3):
-        opt.zero_grad()
-        out = O.detector_forward(sd2, o, vox, affinity_on=True)
-        loss = sum(w * out[k] for k, w in DETECTOR_LOSS_WEIGHTS.items())
-        loss.backward()
-        opt.step()
-        ref_losses.append(float(loss.detach()))
+def test_detector_training_trajectory_vs_reference_fixture(golden_dir):
+    """Three detector-mode training steps (Adam lr 4e-4, AIST weights) against fixture G13 - the REFERENCE's own training run
+    (torch.optim.Adam on its autograd, train.py:376-412; tools/make_golden.py::case_g13): the loss of every step, and every updated
+    tensor after the third step on the fixture's sub-sample.  (Rounds 2-5 trained the CPU oracle on the GPU box here.)"""
+    import numpy as np, os
+    from neural_marionette_amd.train import DetectorTrainer
+    g = np.load(os.path.join(golden_dir, "g13_detector_training20.npz"), allow_pickle=False)
+    G, B, T, seed, _ = [int(v) for v in g["meta"]]
+    o, sd, vox = _setup(G=G, B=B, T=T, seed=seed)
+    ref_losses = [float(v) for v in g["losses"][:3]]
     net = NeuralMarionette(o)
     net.load_state_dict(sd)
     net = net.cuda().train()
@@ -239,7 +232,7 @@ def test_detector_training_trajectory_vs_oracle():
     tr = DetectorTrainer(net, lr=4e-4)
     losses = [tr.step(vox.cuda())["loss"] for _ in range(3)]
     torch.cuda.synchronize()
-    print("detector training losses", losses, "oracle", ref_losses)
+    print("detector training losses", losses, "reference", ref_losses)
     for a, b in zip(losses, ref_losses):
         assert abs(a - b) <= 2e-4 * abs(b), (losses, ref_losses)
     assert losses[2] < losses[0]
@@ -247,9 +240,11 @@ def test_detector_training_trajectory_vs_oracle():
     # legitimately end up 2 * lr * steps away; the bulk must agree far below lr
     num = den = 0.0
     for n, p in net.kypt_detector.named_parameters():
-        r = leaf["kypt_detector." + n].detach()
-        num += (p.detach().cpu() - r).abs().sum().item(); den += r.numel()
-    print("mean weight difference after 3 steps %.2e (lr 4e-4, each weight moved ~1e-3)" % (num / den))
+        r = g["w3:" + n]
+        f = p.detach().reshape(-1).double().cpu()
+        num += float((f[::997] - torch.from_numpy(r[2:])).abs().sum()); den += r.size - 2
+        assert abs(float(f.sum()) - r[0]) <= 1e-4 * max(1.0, float(r[1])), n
+    print("mean weight difference after 3 steps %.2e over %d sampled entries (lr 4e-4, each weight moved ~1e-3)" % (num / den, den))
     assert num / den < 2e-5
 
 
@@ -581,7 +576,7 @@ def test_seed_103_deviation_is_rounding_noise_amplification():
         return w
     # conditioning in fp64: weights perturbed by one fp32 ulp (relative), rounded to fp32, evaluated in fp64
     cond = []
-    for draw in (1, 2, 3):
+    for draw in (1, 2):
         gen = torch.Generator().manual_seed(draw)
         sdp = {k: ((v.double() * (1 + (torch.rand(v.shape, generator=gen, dtype=torch.float64) * 2 - 1) * 6e-8)).float() if v.is_floating_point() else v)
                for k, v in sd.items()}

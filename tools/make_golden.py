@@ -435,7 +435,51 @@ def case_g11():
     print("g11 ok")
 
 
-CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11, g12=case_g12)
+
+def case_g13():
+    """Detector-mode TRAINING by the reference itself (train.py:270-276, 376-412: pretrained_mode = 0, the 11 losses with the AIST
+    weights of train.py:177-181, torch.optim.Adam(lr 4e-4), no effective clipping): the loss of each of 20 consecutive steps at 32^3,
+    B=2, T=4 ('peaky' weights seed 41, random affinity logits, clip seed 43 - tests/test_train_detector_gpu.py::_setup(seed=41)), and
+    every detector tensor after step 3 as (sum, abs-sum, every 997th element).  The GPU tests compare DetectorTrainer's trajectory
+    with this instead of training the CPU oracle on the box (25 s + 160 s of the round-5 suite)."""
+    G, B, T, seed, steps = 32, 2, 4, 41, 20
+    opt = _ref_opt(G)
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=seed, variant="peaky")
+    gen = torch.Generator().manual_seed(seed + 1)
+    sd["kypt_detector.affinity_params"] = torch.randn(sd["kypt_detector.affinity_params"].shape, generator=gen)
+    vox = synth.figure_clip(B, T, G, seed=seed + 2)
+    net = _ref_net(opt, sd).train()
+    acts = {"detector": True, "learner": False}
+    net.control_active(acts)
+    w = dict(recon_loss=opt.recon_weight, sparsity_loss=opt.sparse_weight, separation_loss=opt.sep_weight, vol_fit_reg=opt.vol_reg_weight,
+             kypt_const_loss=opt.kypt_const_weight, local_const_loss=opt.local_const_weight, time_const_loss=opt.time_const_weight,
+             sparsity_const_loss=opt.sparsity_const_weight, intensity_const_loss=opt.intensity_const_weight,
+             graph_traj_loss=opt.graph_traj_weight, graph_vol_loss=opt.graph_vol_weight)
+    params = [p for p in net.kypt_detector.parameters() if p.requires_grad]
+    optim = torch.optim.Adam(params, lr=4e-4)
+    losses, per = [], []
+    out = dict(meta=np.array([G, B, T, seed, steps]), weights=np.array([float(w[k]) for k in DETECTOR_LOSS_KEYS]))
+    for it in range(steps):
+        optim.zero_grad()
+        log = net(vox, acts)
+        loss = sum(float(w[k]) * log[k] for k in DETECTOR_LOSS_KEYS)
+        loss.backward()
+        optim.step()
+        losses.append(float(loss))
+        per.append([float(log[k]) for k in DETECTOR_LOSS_KEYS])
+        if it == 2:
+            for name, p in net.kypt_detector.named_parameters():
+                f = p.detach().reshape(-1).double()
+                out["w3:" + name] = np.concatenate([[f.sum().item(), f.abs().sum().item()], f[::997].numpy()])
+        print("g13 step", it, losses[-1], flush=True)
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["per_loss"] = np.array(per, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g13_detector_training20.npz"), **out)
+    print("g13 ok", losses[0], "->", losses[-1])
+
+
+CASES = dict(g1=case_g1, g2=case_g2, g3=case_g3, g4=case_g4, g5=case_g5, g6=case_g6, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11, g12=case_g12, g13=case_g13)
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
