@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnm355.so")
+LIB_PATH = os.environ.get("NM355_LIB_PATH") or os.path.join(_HERE, "libnm355.so")      # (override: A/B builds of the same library, tools/ab_*.sh)
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)

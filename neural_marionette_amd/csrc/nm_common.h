@@ -79,6 +79,43 @@ __device__ __forceinline__ void nm_st1(float* base, size_t e, float v, int h) { 
 __host__ __device__ inline float* nm_eptr(float* base, size_t e, int h) { return h ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(base) + e) : base + e; }
 __host__ __device__ inline const float* nm_eptr(const float* base, size_t e, int h) { return h ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(base) + e) : base + e; }
 
+
+// ---- exact xor-partner exchange on the vector ALU ------------------------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 on gfx950: a trip through the LDS crossbar (address VALU + ~100 cycles + s_waitcnt) per step,
+// six dependent trips per 64-lane sum.  The VRNN kernels are nothing but such sums (one per output row): a rollout step spent 9.6 of its
+// 15 us in the reductions of ONE workgroup (tools/diag_chain_stamps.py).  nm_sx(x, off) returns the value of lane (lane ^ off) for
+// off = 1 .. 32 from DPP / lane-swap instructions only - EXACTLY the partner __shfl_xor reads (tools/calib/xor_partners.hip), so every
+// butterfly keeps its association order and its bits:
+//   1, 2: quad_perm;  4: row_shl:4 into banks 0, 2 + row_shr:4 into banks 1, 3;  8: row_ror:8;
+//   16: v_permlane16_swap (odd rows of one copy <-> even rows of the other);  32: v_permlane32_swap (gfx950).
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ int nm_dpp_mov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xf, BANK, false); }
+__device__ __forceinline__ int nm_sx(int x, int off) {
+    switch (off) {
+        case 1: return nm_dpp_mov<0xB1>(x, x);
+        case 2: return nm_dpp_mov<0x4E>(x, x);
+        case 4: { const int r = nm_dpp_mov<0x104, 0x5>(x, x); return nm_dpp_mov<0x114, 0xA>(r, x); }
+        case 8: return nm_dpp_mov<0x128>(x, x);
+        case 16: { const auto p = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false); return (threadIdx.x & 16) ? (int)p[0] : (int)p[1]; }
+        case 32: { const auto p = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false); return (threadIdx.x & 32) ? (int)p[0] : (int)p[1]; }
+        default: return __shfl_xor(x, off);
+    }
+}
+__device__ __forceinline__ float nm_sx(float x, int off) { return __builtin_bit_cast(float, nm_sx(__builtin_bit_cast(int, x), off)); }
+// the same with the distance as a template argument (where `off` is not a constant the switch above is evaluated as SIX exchanges and
+// five selects - measured: a reduction loop that hipcc did not unroll ran 2.5x slower than the ds_bpermute form it replaced)
+template <int OFF> __device__ __forceinline__ float nm_sxc(float xf) {
+    const int x = __builtin_bit_cast(int, xf);
+    int r;
+    if constexpr (OFF == 1) r = nm_dpp_mov<0xB1>(x, x);
+    else if constexpr (OFF == 2) r = nm_dpp_mov<0x4E>(x, x);
+    else if constexpr (OFF == 4) { const int q = nm_dpp_mov<0x104, 0x5>(x, x); r = nm_dpp_mov<0x114, 0xA>(q, x); }
+    else if constexpr (OFF == 8) r = nm_dpp_mov<0x128>(x, x);
+    else if constexpr (OFF == 16) { const auto p = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false); r = (threadIdx.x & 16) ? (int)p[0] : (int)p[1]; }
+    else { static_assert(OFF == 32, "distance"); const auto p = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false); r = (threadIdx.x & 32) ? (int)p[0] : (int)p[1]; }
+    return __builtin_bit_cast(float, r);
+}
+
 // A tensor reference with an optional pending per-(n,c) affine + leaky-relu.
 struct TensorRef {
     const float* p;       // [N][D][H][W][C]
@@ -136,7 +173,7 @@ struct NmLaunchState {
     // persistent rollout kernel (nm_vrnn.hip vrnn_prior_chain_kernel): polls before a spin gives up (NM355_CHAIN_SPIN), trailing
     // workgroups NOT launched (NM355_CHAIN_DROP_WG: the test hook that stands in for a workgroup that never becomes resident), and the
     // co-residency verdict of this context's device (-1: not asked yet, 0: the chain does not fit, 1: it does)
-    int chain_spin = 1 << 20, chain_drop = 0, chain_fits = -1, post_chain_fits = -1, chain_stat_delay = 0;
+    int chain_spin = 1 << 20, chain_drop = 0, chain_fits = -1, post_chain_fits = -1, chain_stat_delay = 0, chain_wgpoll = 0, chain_xcd = 1, chain_cus = 0;
     bool prof_on = false;
     hipStream_t prof_stream = nullptr;     // main stream of the profiled context; prof_all: launches on any stream are recorded
     bool prof_all = false;
@@ -146,7 +183,7 @@ struct NmLaunchState {
     unsigned* nf_flag = nullptr;           // sticky device word gn_finalize ORs a 1 into (null: no reporting)
     // A/B and diagnostic switches (NM355_SUPERTILE, _SMALL16, _KSPLIT, _OCC16, _POOL16, _F16P2, _F16P, _WGRAD_TR, _UP2C, _UP2C_DIAG,
     // _VRNN_MID, _VRNN_GEMM, _VRNN_GRAPH, _SPARSE_FIRST)
-    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, pool_q, occ_flags, gnb_apply4, defer_sums, wgrad_async, wgrad_wgs, wgrad_tr, wgrad_u, tail_rank1, wgrad_z, up2c, up2c_diag, vrnn_mid, vrnn_postmid, vrnn_nb, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res, adjust_split, hg_core, f16p_dma, clip_occ_mfma, vrnn_chain, wgrad_k2f16, convt_f16, k5_two, clip_late, gnb_u8, adj_zwalk, f16q2, vrnn_post_chain, f16r, up2_mat, conv_wgs, up2c_x16;
+    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, pool_q, occ_flags, gnb_apply4, defer_sums, wgrad_async, wgrad_wgs, wgrad_tr, wgrad_u, tail_rank1, wgrad_z, up2c, up2c_diag, vrnn_mid, vrnn_postmid, vrnn_nb, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res, adjust_split, hg_core, f16p_dma, clip_occ_mfma, vrnn_chain, wgrad_k2f16, convt_f16, k5_two, clip_late, gnb_u8, adj_zwalk, f16q2, vrnn_post_chain, f16r, up2_mat, conv_wgs, up2c_x16, up2c_all;
     NmLaunchState();
 };
 NmLaunchState& nm_ls();        // the state of the context whose ABI call runs on this thread

@@ -882,7 +882,7 @@ int g_cus = 0;
 
 bool nm_up2c_eligible(int ID, int IH, int IW, int Cin, int Cout, int ks, int stride, int pad) {
     return nm_ls().up2c && ks == 3 && stride == 1 && pad == 1 && ID % BZ == 0 && IH % BY == 0 && IW % BX == 0 && Cin % CG == 0 && Cout % 32 == 0 &&
-           Cin == 64 && Cout == 32;
+           ((Cin == 64 && Cout == 32) || (nm_ls().up2c_all && Cin <= 128 && Cout <= 64));
 }
 
 size_t nm_up2c_weight_floats(int Cin, int Co_pad) {

@@ -77,7 +77,7 @@ __device__ __forceinline__ void wave_reduce(float (&acc)[NB]) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-        for (int s = 0; s < NB; ++s) acc[s] += __shfl_xor(acc[s], off);
+        for (int s = 0; s < NB; ++s) acc[s] += nm_sx(acc[s], off);
 }
 template <int NB>
 __device__ __forceinline__ float pick(const float (&acc)[NB], int s) {
@@ -364,6 +364,36 @@ __device__ __forceinline__ void fk_levels(const FkTables& tb, int nlevels, const
     }
 }
 
+// fk_levels for ONE sample by ONE wave (the persistent rollout's middle workgroup, round 6): the same per-element arithmetic, the level
+// loop ordered by the wave's own LDS queue (a wave's LDS operations complete in order) instead of nlevels + 1 workgroup barriers.
+__device__ __forceinline__ void fk_levels_wave(const FkTables& tb, int nlevels, const float* Rl, float* Rg, float* pos, const float* root, int K, int lane) {
+    const int rootj = tb.lvl_joint[0];
+    if (lane < 12) {
+        if (lane < 9) Rg[rootj * 9 + lane] = Rl[rootj * 9 + lane];
+        else pos[rootj * 3 + (lane - 9)] = root[lane - 9];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int l = 1; l <= nlevels; ++l) {
+        if (l < nlevels) {
+            const int j0 = tb.lvl_start[l], nj = tb.lvl_start[l + 1] - j0;
+            for (int u = lane; u < nj * 9; u += 64) {
+                const int idx = tb.lvl_joint[j0 + u / 9], e = u % 9, r = e / 3, c = e % 3;
+                const float* P = Rg + tb.parents[idx] * 9; const float* L = Rl + idx * 9;
+                Rg[idx * 9 + e] = (P[r * 3] * L[c] + P[r * 3 + 1] * L[3 + c]) + P[r * 3 + 2] * L[6 + c];
+            }
+        }
+        if (l >= 2) {
+            const int j0 = tb.lvl_start[l - 1], nj = tb.lvl_start[l] - j0;
+            for (int u = lane; u < nj * 3; u += 64) {
+                const int idx = tb.lvl_joint[j0 + u / 3], r = u % 3;
+                const float* G = Rg + idx * 9; const float* of = tb.offset + idx * 3;
+                pos[idx * 3 + r] = ((G[r * 3] * of[0] + G[r * 3 + 1] * of[1]) + G[r * 3 + 2] * of[2]) + pos[tb.parents[idx] * 3 + r];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 __global__ __launch_bounds__(256) void fk_kernel(FkArgs a) {
     extern __shared__ float sm[];
     const int K = a.K, S = a.S, b = blockIdx.x;
@@ -480,10 +510,45 @@ struct MidArgs {
 
 __device__ __forceinline__ float half_reduce(float v) {          // sum over the 32 lanes of this lane's half; every lane gets it
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    for (int off = 16; off > 0; off >>= 1) v += nm_sx(v, off);
     return v;
 }
 __device__ __forceinline__ float dot4(const f32x4& w, const f32x4& x) { return ((w[0] * x[0] + w[1] * x[1]) + w[2] * x[2]) + w[3] * x[3]; }
+
+// ---- NV sums over WIDTH lanes in one pass (round 6) -------------------------------------------------------------------------------------
+// A butterfly per value costs log2(WIDTH) exchange + add steps for EACH of the NV values a lane holds.  Reduce-scatter: at distance D the
+// lanes with bit D clear keep the lower half of their live values and take the partner's partial sums of those, the lanes with bit D set
+// the upper half - half as many values are alive after every step, NV - 1 + log2(WIDTH / NV) exchanges in all instead of NV log2(WIDTH).
+// For each value the additions are the butterfly's, in the butterfly's order (distance WIDTH / 2 first, 1 last; a + b = b + a bit for
+// bit), so the result is the butterfly's bit for bit.  On return v[0] of lane l is the total of value rs_index<NV, WIDTH>(l); all
+// WIDTH / NV lanes that share an index hold it.
+template <int NV, int WIDTH> __device__ __forceinline__ int rs_index(int lane) {
+    int idx = 0, n = NV;
+#pragma unroll
+    for (int d = WIDTH / 2; d > 0 && n > 1; d >>= 1) { n >>= 1; if (lane & d) idx += n; }
+    return idx;
+}
+template <int N, int D, int NV> __device__ __forceinline__ void rs_step(float (&v)[NV], int lane) {
+    if constexpr (D >= 1) {
+        if constexpr (N > 1) {
+            constexpr int HALF = N / 2;
+            const bool up = (lane & D) != 0;
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) {
+                const float keep = up ? v[k + HALF] : v[k], send = up ? v[k] : v[k + HALF];
+                v[k] = keep + nm_sxc<D>(send);
+            }
+            rs_step<HALF, D / 2, NV>(v, lane);
+        } else {
+            v[0] += nm_sxc<D>(v[0]);
+            rs_step<1, D / 2, NV>(v, lane);
+        }
+    }
+}
+template <int NV, int WIDTH> __device__ __forceinline__ float reduce_scatter(float (&v)[NV], int lane) {
+    rs_step<NV, WIDTH / 2, NV>(v, lane);
+    return v[0];
+}
 
 #define MID_PAIRS 8        // row pairs per wavefront and phase: 16 waves x 8 pairs x 2 rows = 256 rows
 __global__ __launch_bounds__(1024) void vrnn_prior_mid_kernel(MidArgs a) {
@@ -521,7 +586,7 @@ __global__ __launch_bounds__(1024) void vrnn_prior_mid_kernel(MidArgs a) {
 #pragma unroll
         for (int u = 0; u < MID_PAIRS; ++u) {
             const float v = half_reduce(dot4(wa[u], xh));
-            const float o = __shfl_xor(v, 32);
+            const float o = nm_sx(v, 32);
             if (l32 == u) { mine = v; other = o; }
         }
         if (!half && l32 < MID_PAIRS) {
@@ -607,6 +672,8 @@ __global__ __launch_bounds__(1024) void vrnn_prior_mid_kernel(MidArgs a) {
 // Arithmetic per output row is the row kernels' (dot_seg for n = 512 / 96 + 128, wave_reduce's xor tree, the same epilogues): outputs are
 // bit-identical to the launch-per-phase step (tools/diag_chain.py, tests/test_network_gpu.py::test_config5_rollout64).
 #define NM_CHAIN_NW 64                 // worker workgroups of 8 waves: 512 waves; 4 h-phase rows (1920 / 512, the last waves fewer) and ONE GRU unit (H = 512) per wave
+static long long* g_chain_stamps = nullptr;      // set by the undeclared diagnostic export nm_diag_set_chain_stamps (tools/diag_chain_stamps.py)
+#define NM_CHAIN_NWX 24                // worker workgroups of the one-XCD form: 192 waves, 10 h-phase rows and up to 3 GRU units each; + B <= 8 middle workgroups <= the 32 CUs of an XCD
 #define NM_CHAIN_T 512                 // threads per workgroup: two waves per SIMD, 256 registers each (the middle role keeps 2 x 16 weight quads per lane)
 #define NM_CHAIN_PAIRS 16              // row pairs per wave and matrix phase of the middle role: 8 waves x 16 pairs x 2 rows = 256 rows
 #define NM_CHAIN_SPIN (1 << 20)
@@ -627,12 +694,25 @@ struct ChainArgs {
     int B, T, K, Z, H;
     int backoff;                        // s_sleep(2) units between polls
     int spin_limit;                     // polls before a wave gives up (NM355_CHAIN_SPIN; default NM_CHAIN_SPIN)
+    long long* stamps;                  // diagnostic phase stamps (null in product calls)
+    int* ctl;                           // one-XCD form: [0] chosen XCD + 1, [1] roles taken, [2] go (1) / no-go (2), [3] workgroups that completed; zero before the launches (null: no one-XCD launch in front)
+    int wg_poll;                        // 1: one wave per worker workgroup polls, LDS + a workgroup barrier hand the values to the other seven (NM355_CHAIN_WGPOLL)
 };
 
 __device__ __forceinline__ void gran_store(nm_gran* p, float v, unsigned tag) {
     __hip_atomic_store(p, (nm_gran)__builtin_bit_cast(unsigned, v) | ((nm_gran)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// HARDWARE ASSUMPTION (stated): a naturally aligned 16-byte global load observes each of its two naturally aligned 8-byte
+// One-XCD form (round 6): producer and consumer run on the SAME XCD (checked against HW_REG_XCC_ID at run time, never assumed from the
+// launch order), whose L2 is their point of coherence: a PLAIN 8-byte store keeps the line in that L2 and an sc1 load (bypasses the
+// reader's L1, L2-served) sees it 0.34 us later on an idle chip, against 0.76 us for the write-through sc1 store + fabric read of the
+// cross-XCD form (tools/calib/hop_latency.hip, profiles/r06_hop_latency.txt; a plain store is never seen from another XCD - same file).
+template <bool XCD> __device__ __forceinline__ void gran_store_t(nm_gran* p, float v, unsigned tag) {
+    if constexpr (XCD) {
+        const nm_gran g = (nm_gran)__builtin_bit_cast(unsigned, v) | ((nm_gran)tag << 32);
+        asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(g) : "memory");
+    } else gran_store(p, v, tag);
+}
+// (round-5 form, NM_GRAN_DWORDX2 == 0 only) HARDWARE ASSUMPTION (stated): a naturally aligned 16-byte global load observes each of its two naturally aligned 8-byte
 // halves whole - a granule {value, tag} written by ONE 8-byte store is never seen as {new tag, old value}.  The ISA text promises
 // single-copy atomicity for naturally aligned accesses up to 8 bytes and says nothing of 16-byte ones; on gfx950 a dwordx4 load of a
 // 16-byte-aligned address is served from one 64-byte L2 sector in one request and the writer's dwordx2 store updates its 8 bytes of
@@ -644,6 +724,58 @@ __device__ __forceinline__ void gran_store(nm_gran* p, float v, unsigned tag) {
 // A lane's granule loads of one poll as ONE asm statement: all loads issued (16-byte sc1 loads = two neighbouring granules, 8-byte = one),
 // then one wait - the compiler must not touch a destination between its load and the wait (an untracked load's register is stale until
 // then), hence a single statement with early-clobber outputs
+#ifndef NM_GRAN_DWORDX2
+#define NM_GRAN_DWORDX2 1
+#endif
+#if NM_GRAN_DWORDX2
+// Round 6 (verdict r5 item 11): every granule is read by an 8-byte load of its own - the access size the ISA's single-copy atomicity
+// covers - instead of 16-byte loads of granule PAIRS.  A pair is two loads at offset 0 / 8 from the same address register; the
+// returned register layout is the pair loads' (value, tag, value, tag).  Cost against the pair loads (same call, one device):
+// profiles/r06_granule_loads_ab.txt.  -DNM_GRAN_DWORDX2=0 (make x4: libnm355_x4.so) builds the round-5 loads for that A/B.
+#define NM_GL2(D, A, OFF) "global_load_dwordx2 " D ", " A ", off offset:" OFF " sc1\n\t"
+__device__ __forceinline__ f32x4 gran_join(const nm_f32x2& lo, const nm_f32x2& hi) { return f32x4{lo[0], lo[1], hi[0], hi[1]}; }
+__device__ __forceinline__ void gran_ld_2q1(const nm_gran* p0, const nm_gran* p1, const nm_gran* s0, f32x4& a0, f32x4& a1, nm_f32x2& b0) {
+    nm_f32x2 t0, t1, t2, t3;
+    asm volatile(NM_GL2("%0", "%5", "0") NM_GL2("%1", "%5", "8") NM_GL2("%2", "%6", "0") NM_GL2("%3", "%6", "8") NM_GL2("%4", "%7", "0") "s_waitcnt vmcnt(0)"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(b0) : "v"(p0), "v"(p1), "v"(s0) : "memory");
+    a0 = gran_join(t0, t1); a1 = gran_join(t2, t3);
+}
+__device__ __forceinline__ void gran_ld_4q1(const nm_gran* p0, const nm_gran* p1, const nm_gran* p2, const nm_gran* p3, const nm_gran* s0,
+                                            f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, nm_f32x2& b0) {
+    nm_f32x2 t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(NM_GL2("%0", "%9", "0") NM_GL2("%1", "%9", "8") NM_GL2("%2", "%10", "0") NM_GL2("%3", "%10", "8") NM_GL2("%4", "%11", "0") NM_GL2("%5", "%11", "8")
+                 NM_GL2("%6", "%12", "0") NM_GL2("%7", "%12", "8") NM_GL2("%8", "%13", "0") "s_waitcnt vmcnt(0)"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(b0)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(s0) : "memory");
+    a0 = gran_join(t0, t1); a1 = gran_join(t2, t3); a2 = gran_join(t4, t5); a3 = gran_join(t6, t7);
+}
+__device__ __forceinline__ void gran_ld_4q4(const nm_gran* p0, const nm_gran* p1, const nm_gran* p2, const nm_gran* p3, const nm_gran* s0,
+                                            const nm_gran* s1, const nm_gran* s2, const nm_gran* s3, f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3,
+                                            nm_f32x2& b0, nm_f32x2& b1, nm_f32x2& b2, nm_f32x2& b3) {
+    nm_f32x2 t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(NM_GL2("%0", "%12", "0") NM_GL2("%1", "%12", "8") NM_GL2("%2", "%13", "0") NM_GL2("%3", "%13", "8") NM_GL2("%4", "%14", "0") NM_GL2("%5", "%14", "8")
+                 NM_GL2("%6", "%15", "0") NM_GL2("%7", "%15", "8") NM_GL2("%8", "%16", "0") NM_GL2("%9", "%17", "0") NM_GL2("%10", "%18", "0") NM_GL2("%11", "%19", "0")
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(s0), "v"(s1), "v"(s2), "v"(s3) : "memory");
+    a0 = gran_join(t0, t1); a1 = gran_join(t2, t3); a2 = gran_join(t4, t5); a3 = gran_join(t6, t7);
+}
+__device__ __forceinline__ void gran_ld_5q(const nm_gran* p0, const nm_gran* p1, const nm_gran* p2, const nm_gran* p3, const nm_gran* p4,
+                                           f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4) {
+    nm_f32x2 t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
+    asm volatile(NM_GL2("%0", "%10", "0") NM_GL2("%1", "%10", "8") NM_GL2("%2", "%11", "0") NM_GL2("%3", "%11", "8") NM_GL2("%4", "%12", "0") NM_GL2("%5", "%12", "8")
+                 NM_GL2("%6", "%13", "0") NM_GL2("%7", "%13", "8") NM_GL2("%8", "%14", "0") NM_GL2("%9", "%14", "8") "s_waitcnt vmcnt(0)"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(t8), "=&v"(t9)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4) : "memory");
+    a0 = gran_join(t0, t1); a1 = gran_join(t2, t3); a2 = gran_join(t4, t5); a3 = gran_join(t6, t7); a4 = gran_join(t8, t9);
+}
+#else
+__device__ __forceinline__ void gran_ld_5q(const nm_gran* p0, const nm_gran* p1, const nm_gran* p2, const nm_gran* p3, const nm_gran* p4,
+                                           f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4) {
+    asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4) : "memory");
+}
 __device__ __forceinline__ void gran_ld_2q1(const nm_gran* p0, const nm_gran* p1, const nm_gran* s0, f32x4& a0, f32x4& a1, nm_f32x2& b0) {
     asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx2 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a0), "=&v"(a1), "=&v"(b0) : "v"(p0), "v"(p1), "v"(s0) : "memory");
@@ -663,6 +795,7 @@ __device__ __forceinline__ void gran_ld_4q4(const nm_gran* p0, const nm_gran* p1
                  : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
                  : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(s0), "v"(s1), "v"(s2), "v"(s3) : "memory");
 }
+#endif
 // polls until `ok` holds in every lane of the wave (the body re-issues the lane's loads and re-evaluates ok); false: aborted
 #define NM_CHAIN_POLL(LOADS, OKEXPR)                                                                                  \
     {                                                                                                                \
@@ -683,19 +816,59 @@ __device__ __forceinline__ void gran_ld_4q4(const nm_gran* p0, const nm_gran* p1
         if (!alive_) { wave_alive = false; }                                                                         \
     }
 
+// diagnostic stamps (tools/diag_chain_stamps.py; a.stamps is null in every product call): s_memrealtime (100 MHz) of thread 0 of worker
+// workgroup 0 (role 0) and of the first middle workgroup (role 1) at the phase boundaries of step t: [role][t < 128][8]
+#define NM_STAMP(ROLE, K) do { if (a.stamps && tid == 0 && t < 128 && ((ROLE) == 0 ? wg == 0 : wg == NW)) a.stamps[((ROLE) * 128 + t) * 8 + (K)] = wall_clock64(); } while (0)
+template <bool XCD>
 __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs a) {
     __shared__ int s_dead;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int B = a.B, T = a.T, K = a.K, Z = a.Z, H = a.H, S4 = 4 * K;
+    constexpr int NW = XCD ? NM_CHAIN_NWX : NM_CHAIN_NW;
     bool wave_alive = true;
     if (tid == 0) s_dead = 0;
-    if ((int)blockIdx.x >= NM_CHAIN_NW) {
+    int wg = (int)blockIdx.x;                  // logical workgroup: [0, NW) workers, [NW, NW + B) the middle workgroup of batch element wg - NW
+    if constexpr (XCD) {
+        // ---- one-XCD form: 256 workgroups are launched (one per CU), each reads the XCD it runs on from HW_REG_XCC_ID; the first
+        // arriver's XCD is THE XCD, its workgroups take the NW + B roles in arrival order and every other workgroup leaves at once.
+        // Role 0 decides: all roles taken within ~30 us -> go; else no-go, nobody starts, ctl[3] never reaches NW + B and the
+        // cross-XCD kernel enqueued behind this launch runs the rollout (a busy XCD costs two launches, never a wrong or missing result).
+        __shared__ int s_role;
+        if (tid == 0) {
+            const int x = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) + 1;       // HW_REG_XCC_ID[3:0] + 1
+            int chosen = atomicCAS(a.ctl, 0, x);
+            if (chosen == 0) chosen = x;
+            int r = -1;
+            if (chosen == x) {
+                r = atomicAdd(a.ctl + 1, 1);
+                if (r >= NW + B) r = -1;
+                else if (r == 0) {
+                    const long long t0 = wall_clock64();
+                    int n = 0;
+                    while ((n = __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < NW + B && wall_clock64() - t0 < 3000) __builtin_amdgcn_s_sleep(8);
+                    __hip_atomic_store(a.ctl + 2, n >= NW + B ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (n < NW + B) r = -1;
+                } else {
+                    int go = 0, spins = 0;
+                    while ((go = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+                    if (go != 1) r = -1;
+                }
+            }
+            s_role = r;
+        }
+        __syncthreads();
+        wg = s_role;
+        if (wg < 0) return;
+    } else if (a.ctl && __hip_atomic_load(a.ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NM_CHAIN_NWX + B) {
+        return;                                  // the one-XCD launch in front of this one completed the rollout (uniform: every workgroup reads the same word)
+    }
+    if (wg >= NW) {
         // =========================== middle workgroup of batch element b ========================================================
         const MidArgs& m = a.mid;
         __shared__ __attribute__((aligned(16))) float s_z[128], s_hr[128], s_hj[128], s_root[36], s_rot[192];
         __shared__ float s_Rl[32 * 9], s_Rg[32 * 9], s_pos[32 * 3];
         __shared__ FkTables tb;
-        const int half = lane >> 5, l32 = lane & 31, b = (int)blockIdx.x - NM_CHAIN_NW;
+        const int half = lane >> 5, l32 = lane & 31, b = wg - NW;
         const int R0 = 3 + K, J6 = 6 * K, rows_c = R0 + J6;
         // weights of the distribution (A) and decoder-hidden (B) phases in registers, those of the heads (C: 3 + 7K rows x 128) in LDS - all
         // three in registers (3 x 16 quads) overflow the 256 a 512-thread workgroup has per lane
@@ -710,14 +883,34 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs 
             const float* pc = r < R0 ? m.w_root2 + (size_t)r * 128 : m.w_joint2 + (size_t)(r - R0) * 128;
             if (p * 2 + half < rows_c) s_wc[(p * 2 + half) * 32 + l32] = *reinterpret_cast<const f32x4*>(pc + l32 * 4);
         }
-        const int pl = wave * NM_CHAIN_PAIRS + (l32 < NM_CHAIN_PAIRS ? l32 : 0);
+        // (round 6: the 16 row pairs of a wave are summed by reduce_scatter - lane l32 of a half ends up with pair rs_index(l32), two lanes per pair)
+        const int pu = rs_index<NM_CHAIN_PAIRS, 32>(l32);
+        const bool pown = (l32 & 1) == 0;                            // the lane of its pair that writes
+        const int pl = wave * NM_CHAIN_PAIRS + pu;
         const float bias_a = m.b_p2[pl], bias_a2 = m.b_p2[pl + Z];
         const int rl = min(pl * 2 + half, rows_c - 1);
         const float bias_c = *(rl < R0 ? m.b_root2 + rl : m.b_joint2 + (rl - R0));
         fk_tables_load(tb, m.lvl_joint, m.lvl_start, m.parents, m.offset + (size_t)b * K * 3, K, m.nlevels, tid);
         __syncthreads();
+        // (round 6) the kinematic chain per joint: s_path[j] = the joints from the root's child down to j (s_plen[j] of them; the root itself
+        // has none).  Lane j of wave 0 walks its own path every step - G <- G L_c, p <- G offset_c + p from the root down, the very
+        // products and sums the level-by-level evaluation makes for joint j and its ancestors, in the same order - so a step's kinematics
+        // need no exchange between lanes beyond the local rotations in LDS and no barrier per tree level.
+        __shared__ unsigned char s_path[32][32];
+        __shared__ int s_plen[32];
+        if (tid < K) {
+            const int rootj = tb.lvl_joint[0];
+            int n = 0, c = tid;
+            unsigned char tmp[32];
+            while (c != rootj && n < 32) { tmp[n++] = (unsigned char)c; c = tb.parents[c]; }
+            for (int i = 0; i < n; ++i) s_path[tid][i] = tmp[n - 1 - i];
+            s_plen[tid] = n;
+        }
+        __syncthreads();
         for (int t = 0; t < T; ++t) {
             const unsigned tag = (unsigned)t + 1u;
+            NM_STAMP(1, 0);
+            if (a.stamps && tid == 0 && t < 128 && wg == NW) a.stamps[(128 + t) * 8 + 7] = clock64();       // (shader clock: the diagnostic derives the clock the chip runs this kernel at)
             const float epsv = a.eps[((size_t)t * B + b) * Z + pl];                       // (an input of the call: plain load)
             // this lane's inputs of the step: hid_prior[4 l32 .. +3] (two granule pairs) and rh / jh [pl]
             f32x4 g0, g1; nm_f32x2 ga;
@@ -726,88 +919,118 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs 
             NM_CHAIN_POLL(gran_ld_2q1(ph, ph + 2, pa, g0, g1, ga),
                           nm_fbits(g0[1]) == tag && nm_fbits(g0[3]) == tag && nm_fbits(g1[1]) == tag && nm_fbits(g1[3]) == tag && nm_fbits(ga[1]) == tag);
             if (!wave_alive) s_dead = 1;
+            NM_STAMP(1, 1);
             const f32x4 xh = {g0[0], g0[2], g1[0], g1[2]};
             const float add_b = ga[0];
             // ---- A (vrnn_prior_mid_kernel) ----
             {
-                float mine = 0.f, other = 0.f;
+                float va[NM_CHAIN_PAIRS];
 #pragma unroll
-                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
-                    const float v = half_reduce(dot4(wa[u], xh));
-                    const float o = __shfl_xor(v, 32);
-                    if (l32 == u) { mine = v; other = o; }
-                }
-                if (!half && l32 < NM_CHAIN_PAIRS) {
-                    const int p = wave * NM_CHAIN_PAIRS + l32;
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) va[u] = dot4(wa[u], xh);
+                const float mine = reduce_scatter<NM_CHAIN_PAIRS, 32>(va, l32);
+                const float other = nm_sx(mine, 32);
+                if (!half && pown) {
+                    const int p = pl;
                     const float mu = mine + bias_a, sraw = other + bias_a2;
                     const float sg = softplus(sraw) + 1e-4f;
                     const float z = mu + epsv * sg;
                     s_z[p] = z;
-                    gran_store(a.g_kpz + (size_t)b * (S4 + Z) + S4 + p, z, tag);
+                    gran_store_t<XCD>(a.g_kpz + (size_t)b * (S4 + Z) + S4 + p, z, tag);
                 }
             }
             __syncthreads();
             if (s_dead) return;                                          // (uniform: read behind the barrier)
+            NM_STAMP(1, 2);
             // ---- B ----
             {
                 const f32x4 xz = *reinterpret_cast<const f32x4*>(s_z + l32 * 4);
-                float mine = 0.f;
+                float vb[NM_CHAIN_PAIRS];
 #pragma unroll
-                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
-                    const float v = half_reduce(dot4(wb[u], xz));
-                    if (l32 == u) mine = v;
-                }
-                if (l32 < NM_CHAIN_PAIRS) (half ? s_hj : s_hr)[wave * NM_CHAIN_PAIRS + l32] = lrelu(mine + add_b, 0.01f);
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) vb[u] = dot4(wb[u], xz);
+                const float mine = reduce_scatter<NM_CHAIN_PAIRS, 32>(vb, l32);
+                if (pown) (half ? s_hj : s_hr)[pl] = lrelu(mine + add_b, 0.01f);
             }
             __syncthreads();
+            NM_STAMP(1, 3);
             // ---- C ----
             {
                 const f32x4 xr = *reinterpret_cast<const f32x4*>(s_hr + l32 * 4);
                 const f32x4 xj = *reinterpret_cast<const f32x4*>(s_hj + l32 * 4);
-                float mine = 0.f;
+                float vc[NM_CHAIN_PAIRS];
 #pragma unroll
                 for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
                     const int r = (wave * NM_CHAIN_PAIRS + u) * 2 + half;
                     const f32x4 wq = s_wc[min(r, rows_c - 1) * 32 + l32];
-                    const float v = half_reduce(dot4(wq, r < R0 ? xr : xj));
-                    if (l32 == u) mine = v;
+                    vc[u] = dot4(wq, r < R0 ? xr : xj);
                 }
-                if (l32 < NM_CHAIN_PAIRS) {
-                    const int r = (wave * NM_CHAIN_PAIRS + l32) * 2 + half;
+                const float mine = reduce_scatter<NM_CHAIN_PAIRS, 32>(vc, l32);
+                if (pown) {
+                    const int r = pl * 2 + half;
                     if (r < R0) s_root[r] = tanhf(mine + bias_c);
                     else if (r < rows_c) s_rot[r - R0] = mine + bias_c;
                 }
             }
             __syncthreads();
-            // ---- D: forward kinematics ----
-            if (tid < K) {
-                const float* p = s_rot + tid * 6;
-                float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
-                float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
-                x0 /= nx; x1 /= nx; x2 /= nx;
-                float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
-                float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
-                z0 /= nz; z1 /= nz; z2 /= nz;
-                float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
-                float* R = s_Rl + tid * 9;
-                R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
+            NM_STAMP(1, 4);
+            // ---- D: forward kinematics, by wave 0 alone (round 6: lane j walks joint j's chain from the root; no barrier per tree level) ----
+            if (wave == 0) {
+                if (lane < K) {
+                    const float* p = s_rot + lane * 6;
+                    float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
+                    float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
+                    x0 /= nx; x1 /= nx; x2 /= nx;
+                    float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+                    float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
+                    z0 /= nz; z1 /= nz; z2 /= nz;
+                    float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
+                    float* R = s_Rl + lane * 9;
+                    R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < K) {
+                    const int rootj = tb.lvl_joint[0];
+                    float G[9], pp[3];
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) G[e] = s_Rl[rootj * 9 + e];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) pp[r] = s_root[r];
+                    const int n = s_plen[lane];
+                    for (int i = 0; i < n; ++i) {
+                        const int c = s_path[lane][i];
+                        float L[9], Gn[9];
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) L[e] = s_Rl[c * 9 + e];
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) { const int r = e / 3, cc = e % 3; Gn[e] = (G[r * 3] * L[cc] + G[r * 3 + 1] * L[3 + cc]) + G[r * 3 + 2] * L[6 + cc]; }
+                        const float* of = tb.offset + c * 3;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) pp[r] = ((Gn[r * 3] * of[0] + Gn[r * 3 + 1] * of[1]) + Gn[r * 3 + 2] * of[2]) + pp[r];
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) G[e] = Gn[e];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) s_pos[lane * 3 + r] = pp[r];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                NM_STAMP(1, 5);
+                for (int i = lane; i < S4; i += 64) {
+                    const int kk = i >> 2, c = i & 3;
+                    const float v = c < 3 ? s_pos[kk * 3 + c] : (s_root[3 + kk] + 1.0f) * 0.5f;
+                    a.out_kp[(size_t)b * a.ldkp + (size_t)t * S4 + i] = v;             // the call's output (read after the launch)
+                    gran_store_t<XCD>(a.g_kpz + (size_t)b * (S4 + Z) + i, v, tag);     // the GRU's input
+                }
             }
-            __syncthreads();
-            fk_levels(tb, m.nlevels, s_Rl, s_Rg, s_pos, s_root, 36, K, 1, 0, 0, tid, NM_CHAIN_T);
-            if (tid < S4) {
-                const int k = tid >> 2, c = tid & 3;
-                const float v = c < 3 ? s_pos[k * 3 + c] : (s_root[3 + k] + 1.0f) * 0.5f;
-                a.out_kp[(size_t)b * a.ldkp + (size_t)t * S4 + tid] = v;           // the call's output (read after the launch)
-                gran_store(a.g_kpz + (size_t)b * (S4 + Z) + tid, v, tag);           // the GRU's input
-            }
+            NM_STAMP(1, 6);
             __syncthreads();                                             // (the LDS state of this step is dead; s_z .. are rewritten next step)
         }
+        if (XCD && tid == 0 && !s_dead) atomicAdd(a.ctl + 3, 1);
         return;
     }
-    // =============================== worker workgroup (waves are independent: no workgroup barrier below) ==========================
-    const int gw = (int)blockIdx.x * (NM_CHAIN_T / 64) + wave;       // global wave index, 0 .. 8 NW - 1
-    constexpr int NWV = NM_CHAIN_NW * (NM_CHAIN_T / 64);
-    constexpr int HR = 4;                                            // h-phase rows per wave: 1920 <= 512 x 4
+    // =============================== worker workgroup =================================================================================
+    const int gw = wg * (NM_CHAIN_T / 64) + wave;                    // global wave index, 0 .. 8 NW - 1
+    constexpr int NWV = NW * (NM_CHAIN_T / 64);
+    constexpr int HR = (384 + 3 * 512 + NWV - 1) / NWV;              // h-phase rows per wave (H = 512): 4 of 512 waves, 10 of 192
+    constexpr int UN = (512 + NWV - 1) / NWV;                        // GRU units per wave: 1 / 3
     // ---- h-phase rows r = gw + NWV * i: [0,128) prior0 (lrelu) -> hid, [128,256) root0 -> rh, [256,384) joint0 -> jh, [384,1920) W_hh -> gh
     f32x4 wh[HR][2]; float bh[HR];
 #pragma unroll
@@ -822,18 +1045,156 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs 
         wh[i][1] = *reinterpret_cast<const f32x4*>(wr + 256 + lane * 4);
         bh[i] = *br;
     }
-    // ---- GRU unit j = gw (H <= NWV): rows j, H + j, 2H + j of W_ih over [keypoints (4K) | z (Z)]; lane < 4K / 4 holds the keypoint
+    // ---- GRU units j = gw + NWV * u: rows j, H + j, 2H + j of W_ih over [keypoints (4K) | z (Z)]; lane < 4K / 4 holds the keypoint
     // quad, lane < Z / 4 the latent quad (dot_seg's lane -> column assignment for n = 4K and n = Z)
-    const int in = S4 + Z, j = gw, jc = min(j, H - 1);
-    f32x4 wk[3], wz[3]; float bi[3];
+    const int in = S4 + Z;
+    f32x4 wk[UN][3], wz[UN][3]; float bi[UN][3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const float* w = a.w_ih + (size_t)(g * H + jc) * in;
-        wk[g] = *reinterpret_cast<const f32x4*>(w + (lane * 4 < S4 ? lane * 4 : 0));
-        wz[g] = *reinterpret_cast<const f32x4*>(w + S4 + (lane * 4 < Z ? lane * 4 : 0));
-        bi[g] = a.b_ih[g * H + jc];
-    }
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int ju = min(gw + NWV * u, H - 1);
+            const float* w = a.w_ih + (size_t)(g * H + ju) * in;
+            wk[u][g] = *reinterpret_cast<const f32x4*>(w + (lane * 4 < S4 ? lane * 4 : 0));
+            wz[u][g] = *reinterpret_cast<const f32x4*>(w + S4 + (lane * 4 < Z ? lane * 4 : 0));
+            bi[u][g] = a.b_ih[g * H + ju];
+        }
     const bool kq = lane * 4 < S4, zq = lane * 4 < Z;
+    // (reduce-scatter of the wave's h-phase rows: lane l owns row index rs_index(l), its first lane of four stores)
+    const int hidx = rs_index<16, 64>(lane), hrow = gw + NWV * min(hidx, HR - 1);
+    const bool hown = (lane & 3) == 0 && hidx < HR && hrow < 384 + 3 * H;
+    float hbias = 0.f;
+    if (hown) hbias = hrow < 128 ? a.b_prior0[hrow] : hrow < 256 ? a.b_root0[hrow - 128] : hrow < 384 ? a.b_joint0[hrow - 256] : a.b_hh[hrow - 384];
+    static_assert(HR <= 16 && 3 * UN <= 16, "reduce_scatter<16, 64> holds the wave's rows / gate sums");
+    if (XCD || a.wg_poll) {
+        // ---- round 6: ONE wave of the workgroup polls, the other seven take the step's inputs from LDS.  With every wave polling,
+        // 512 waves re-read the same 4 KB of h granules (and 1.8 KB of keypoint | latent granules) until the tags match: that polling
+        // traffic is a good part of a hop's ~5.7 us (profiles/r04_rollout_ab.txt).  Wave 0 polls h_{t-1}[b] (8 granules per lane) /
+        // the middle workgroup's keypoints | latent plus the workgroup's own granules of W_hh h and h_{t-1} (the units of a workgroup
+        // are UN runs of eight: j = 8 wg + wave + NWV u), stores the VALUES to LDS, one workgroup barrier publishes them.  Two LDS
+        // buffers by iteration parity: wave 0 refills a buffer two barriers after the other waves read it.  Arithmetic per row /
+        // unit is unchanged (same lane -> column assignment, same reduction trees): outputs bit-identical to the per-wave polls.
+        __shared__ __attribute__((aligned(16))) float s_hx[2][512];
+        __shared__ __attribute__((aligned(16))) float s_kz[2][256];
+        __shared__ __attribute__((aligned(16))) float s_g[2][UN * 32];          // [u][r | z | n | h_{t-1}][8 units]
+        int it = 0;
+        __syncthreads();                                             // (s_dead = 0 visible)
+        for (int t = 0; t < T; ++t) {
+            const unsigned tag = (unsigned)t + 1u;
+#pragma unroll 1
+            for (int b = 0; b < B; ++b, ++it) {
+                f32x4 x0, x1;
+                if (b == 0) NM_STAMP(0, 0);
+                if (t == 0) {
+                    x0 = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * a.ldh0 + lane * 4);
+                    x1 = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * a.ldh0 + 256 + lane * 4);
+                } else {
+                    float* sh = s_hx[it & 1];
+                    if (wave == 0) {
+                        const nm_gran* ph = a.g_h[(t - 1) & 1] + (size_t)b * H;
+                        f32x4 q0, q1, q2, q3; nm_f32x2 qj;
+                        NM_CHAIN_POLL(gran_ld_4q1(ph + lane * 4, ph + lane * 4 + 2, ph + 256 + lane * 4, ph + 256 + lane * 4 + 2, ph, q0, q1, q2, q3, qj),
+                                      nm_fbits(q0[1]) == (unsigned)t && nm_fbits(q0[3]) == (unsigned)t && nm_fbits(q1[1]) == (unsigned)t && nm_fbits(q1[3]) == (unsigned)t &&
+                                      nm_fbits(q2[1]) == (unsigned)t && nm_fbits(q2[3]) == (unsigned)t && nm_fbits(q3[1]) == (unsigned)t && nm_fbits(q3[3]) == (unsigned)t);
+                        *reinterpret_cast<f32x4*>(sh + lane * 4) = f32x4{q0[0], q0[2], q1[0], q1[2]};
+                        *reinterpret_cast<f32x4*>(sh + 256 + lane * 4) = f32x4{q2[0], q2[2], q3[0], q3[2]};
+                        if (!wave_alive && lane == 0) s_dead = 1;
+                    }
+                    __syncthreads();
+                    if (s_dead) return;
+                    x0 = *reinterpret_cast<const f32x4*>(sh + lane * 4); x1 = *reinterpret_cast<const f32x4*>(sh + 256 + lane * 4);
+                }
+                if (b == 0) NM_STAMP(0, 1);
+                {   // the wave's HR row sums in one reduce-scatter (lane l ends up with row hidx = rs_index(l)); one predicated store each
+                    float vh[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (i < HR) { float acc = 0.f; acc += dot4(wh[i][0], x0); acc += dot4(wh[i][1], x1); vh[i] = acc; }
+                        else vh[i] = 0.f;
+                    }
+                    const float tot = reduce_scatter<16, 64>(vh, lane);
+                    if (hown) {
+                        const float v = tot + hbias;
+                        if (hrow < 128) gran_store_t<XCD>(a.g_hid + (size_t)b * 128 + hrow, lrelu(v, 0.01f), tag);
+                        else if (hrow < 256) gran_store_t<XCD>(a.g_rh + (size_t)b * 128 + (hrow - 128), v, tag);
+                        else if (hrow < 384) gran_store_t<XCD>(a.g_jh + (size_t)b * 128 + (hrow - 256), v, tag);
+                        else gran_store_t<XCD>(a.g_gh + (size_t)b * 3 * H + (hrow - 384), v, tag);
+                    }
+                }
+            }
+#pragma unroll 1
+            for (int b = 0; b < B; ++b, ++it) {
+                float* sk = s_kz[it & 1]; float* sg = s_g[it & 1];
+                if (b == 0) NM_STAMP(0, 2);
+                if (wave == 0) {
+                    const nm_gran* pk = a.g_kpz + (size_t)b * (S4 + Z);
+                    const nm_gran* pg = a.g_gh + (size_t)b * 3 * H;
+                    // lane l < 16 UN: run u = l >> 4, array (l >> 2) & 3 (W_hh h of gate r | z | n, or h_{t-1}), granule pair l & 3 of the run's eight units
+                    const int gu = lane >> 4, garr = (lane >> 2) & 3, j0 = wg * 8 + NWV * gu + 2 * (lane & 3);
+                    const bool gon = lane < 16 * UN && j0 < H;
+                    const bool hprev = garr == 3 && t > 0;           // (t = 0: h_{t-1} is the call's input; the lanes re-read gate n's granules, unused)
+                    const nm_gran* px = !gon ? pg : (hprev ? a.g_h[(t - 1) & 1] + (size_t)b * H + j0 : pg + (garr == 3 ? 2 : garr) * H + j0);
+                    const unsigned xtag = hprev ? (unsigned)t : tag;
+                    f32x4 k0, k1, z0, z1, gx;
+                    NM_CHAIN_POLL(gran_ld_5q(pk + (kq ? lane * 4 : 0), pk + (kq ? lane * 4 : 0) + 2, pk + S4 + (zq ? lane * 4 : 0), pk + S4 + (zq ? lane * 4 : 0) + 2,
+                                             px, k0, k1, z0, z1, gx),
+                                  nm_fbits(k0[1]) == tag && nm_fbits(k0[3]) == tag && nm_fbits(k1[1]) == tag && nm_fbits(k1[3]) == tag &&
+                                  nm_fbits(z0[1]) == tag && nm_fbits(z0[3]) == tag && nm_fbits(z1[1]) == tag && nm_fbits(z1[3]) == tag &&
+                                  (!gon || (nm_fbits(gx[1]) == xtag && nm_fbits(gx[3]) == xtag)));
+                    if (kq) *reinterpret_cast<f32x4*>(sk + lane * 4) = f32x4{k0[0], k0[2], k1[0], k1[2]};
+                    if (zq) *reinterpret_cast<f32x4*>(sk + 128 + lane * 4) = f32x4{z0[0], z0[2], z1[0], z1[2]};
+                    if (lane < 16 * UN) { sg[gu * 32 + garr * 8 + 2 * (lane & 3)] = gx[0]; sg[gu * 32 + garr * 8 + 2 * (lane & 3) + 1] = gx[2]; }
+                    if (!wave_alive && lane == 0) s_dead = 1;
+                }
+                __syncthreads();
+                if (s_dead) return;
+                if (b == 0) NM_STAMP(0, 3);
+                f32x4 xkq = {0.f, 0.f, 0.f, 0.f}, xzq = xkq;
+                if (kq) xkq = *reinterpret_cast<const f32x4*>(sk + lane * 4);
+                if (zq) xzq = *reinterpret_cast<const f32x4*>(sk + 128 + lane * 4);
+                float vg[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) vg[i] = 0.f;
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    float ar = 0.f, az = 0.f, an = 0.f;
+                    if (kq) { ar += dot4(wk[u][0], xkq); az += dot4(wk[u][1], xkq); an += dot4(wk[u][2], xkq); }
+                    if (zq) { ar += dot4(wz[u][0], xzq); az += dot4(wz[u][1], xzq); an += dot4(wz[u][2], xzq); }
+                    vg[3 * u] = ar; vg[3 * u + 1] = az; vg[3 * u + 2] = an;
+                }
+                const float gtot = reduce_scatter<16, 64>(vg, lane);      // value i of the wave in the lanes with rs_index == i: lane RSL(i) is one
+#define RSL(i) ((((i) >> 3) & 1) * 32 + (((i) >> 2) & 1) * 16 + (((i) >> 1) & 1) * 8 + ((i) & 1) * 4)
+                {   // the gates of the wave's UN units, unit u in lane u (the three sums of unit u sit in lanes RSL(3u), RSL(3u + 1), RSL(3u + 2))
+                    float ar = 0.f, az = 0.f, an = 0.f;
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const float r_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gtot), RSL(3 * u)));
+                        const float z_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gtot), RSL(3 * u + 1)));
+                        const float n_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gtot), RSL(3 * u + 2)));
+                        if (lane == u) { ar = r_; az = z_; an = n_; }
+                    }
+                    const int ul = min(lane, UN - 1), j = gw + NWV * ul;
+                    if (lane < UN && j < H) {
+                        float b0 = bi[0][0], b1 = bi[0][1], b2 = bi[0][2];
+#pragma unroll
+                        for (int u = 1; u < UN; ++u) if (lane == u) { b0 = bi[u][0]; b1 = bi[u][1]; b2 = bi[u][2]; }
+                        const float hpv = t == 0 ? a.h0[(size_t)b * a.ldh0 + j] : sg[ul * 32 + 24 + wave];
+                        const float rg = sigmoidf((ar + b0) + sg[ul * 32 + wave]);
+                        const float zg = sigmoidf((az + b1) + sg[ul * 32 + 8 + wave]);
+                        const float ng = tanhf((an + b2) + rg * sg[ul * 32 + 16 + wave]);
+                        const float hn = (hpv - ng) * zg + ng;
+                        gran_store_t<XCD>(a.g_h[t & 1] + (size_t)b * H + j, hn, tag);
+                        if (t == T - 1) a.h_out[(size_t)b * H + j] = hn;
+                    }
+                }
+                if (b == 0) NM_STAMP(0, 4);
+            }
+        }
+        if (XCD && tid == 0) atomicAdd(a.ctl + 3, 1);
+        return;
+    }
+    if constexpr (!XCD) {
+    const int j = gw, jc = min(j, H - 1);
     for (int t = 0; t < T && wave_alive; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         // ---- h-phase of step t for every batch element: h_t[b] columns 4 lane .. +3 and 256 + 4 lane .. +3 (t = 0: the call's input, plain)
@@ -859,13 +1220,13 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs 
                 acc += dot4(wh[i][0], x0);
                 acc += dot4(wh[i][1], x1);
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+                for (int off = 32; off > 0; off >>= 1) acc += nm_sx(acc, off);
                 if (lane == 0 && r < 384 + 3 * H) {
                     const float v = acc + bh[i];
-                    if (r < 128) gran_store(a.g_hid + (size_t)b * 128 + r, lrelu(v, 0.01f), tag);
-                    else if (r < 256) gran_store(a.g_rh + (size_t)b * 128 + (r - 128), v, tag);
-                    else if (r < 384) gran_store(a.g_jh + (size_t)b * 128 + (r - 256), v, tag);
-                    else gran_store(a.g_gh + (size_t)b * 3 * H + (r - 384), v, tag);
+                    if (r < 128) gran_store_t<XCD>(a.g_hid + (size_t)b * 128 + r, lrelu(v, 0.01f), tag);
+                    else if (r < 256) gran_store_t<XCD>(a.g_rh + (size_t)b * 128 + (r - 128), v, tag);
+                    else if (r < 384) gran_store_t<XCD>(a.g_jh + (size_t)b * 128 + (r - 256), v, tag);
+                    else gran_store_t<XCD>(a.g_gh + (size_t)b * 3 * H + (r - 384), v, tag);
                 }
             }
         }
@@ -886,19 +1247,20 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs 
             const float hpv = t == 0 ? a.h0[(size_t)b * a.ldh0 + jc] : gp[0];
             const f32x4 xkq = {k0[0], k0[2], k1[0], k1[2]}, xzq = {z0[0], z0[2], z1[0], z1[2]};
             float ar = 0.f, az = 0.f, an = 0.f;
-            if (kq) { ar += dot4(wk[0], xkq); az += dot4(wk[1], xkq); an += dot4(wk[2], xkq); }
-            if (zq) { ar += dot4(wz[0], xzq); az += dot4(wz[1], xzq); an += dot4(wz[2], xzq); }
+            if (kq) { ar += dot4(wk[0][0], xkq); az += dot4(wk[0][1], xkq); an += dot4(wk[0][2], xkq); }
+            if (zq) { ar += dot4(wz[0][0], xzq); az += dot4(wz[0][1], xzq); an += dot4(wz[0][2], xzq); }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { ar += __shfl_xor(ar, off); az += __shfl_xor(az, off); an += __shfl_xor(an, off); }
+            for (int off = 32; off > 0; off >>= 1) { ar += nm_sx(ar, off); az += nm_sx(az, off); an += nm_sx(an, off); }
             if (lane == 0) {
-                const float rg = sigmoidf((ar + bi[0]) + gr[0]);
-                const float zg = sigmoidf((az + bi[1]) + gz[0]);
-                const float ng = tanhf((an + bi[2]) + rg * gn[0]);
+                const float rg = sigmoidf((ar + bi[0][0]) + gr[0]);
+                const float zg = sigmoidf((az + bi[0][1]) + gz[0]);
+                const float ng = tanhf((an + bi[0][2]) + rg * gn[0]);
                 const float hn = (hpv - ng) * zg + ng;
-                gran_store(a.g_h[t & 1] + (size_t)b * H + j, hn, tag);
+                gran_store_t<XCD>(a.g_h[t & 1] + (size_t)b * H + j, hn, tag);
                 if (t == T - 1) a.h_out[(size_t)b * H + j] = hn;
             }
         }
+    }
     }
 }
 
@@ -989,8 +1351,8 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
             float qm = 0.f, qs = 0.f, pm = 0.f, ps = 0.f;
 #pragma unroll
             for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
-                const float vq = half_reduce(dot4(wq[u], xq)), oq = __shfl_xor(vq, 32);
-                const float vp = half_reduce(dot4(wp[u], xp)), op = __shfl_xor(vp, 32);
+                const float vq = half_reduce(dot4(wq[u], xq)), oq = nm_sx(vq, 32);
+                const float vp = half_reduce(dot4(wp[u], xp)), op = nm_sx(vp, 32);
                 if (l32 == u) { qm = vq; qs = oq; pm = vp; ps = op; }
             }
             if (tid < 256) s_red[tid] = 0.f;
@@ -1053,7 +1415,7 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
 #pragma unroll
                 for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
                     const float v = half_reduce(dot4(wa[u], xh));
-                    const float o = __shfl_xor(v, 32);
+                    const float o = nm_sx(v, 32);
                     if (l32 == u) { mine = v; other = o; }
                 }
                 if (!half && l32 < NM_CHAIN_PAIRS) {
@@ -1140,7 +1502,7 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
                 float bd = lane < S ? gd[0] : INFINITY; int bi = lane < S ? lane : 1 << 20;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
-                    const float od = __shfl_xor(bd, off); const int oi = __shfl_xor(bi, off);
+                    const float od = nm_sx(bd, off); const int oi = nm_sx(bi, off);
                     if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
                 }
                 if (lane == 0) {
@@ -1222,7 +1584,7 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
                 acc += dot4(wh[i][1], x1);
                 if (i == 0 && oq) acc += dot4(wobs, xo);             // (dot_seg's second segment: the lanes that hold a keypoint quad)
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+                for (int off = 32; off > 0; off >>= 1) acc += nm_sx(acc, off);
                 if (lane == 0) {
                     const float v = acc + bh[i];
                     if (i == 0) {
@@ -1247,7 +1609,7 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
             float bd = lane < S ? gd[0] : INFINITY; int bi = lane < S ? lane : 1 << 20;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                const float od = __shfl_xor(bd, off); const int oi = __shfl_xor(bi, off);
+                const float od = nm_sx(bd, off); const int oi = nm_sx(bi, off);
                 if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
             }
             bi = __builtin_amdgcn_readfirstlane(bi);                       // (wave-uniform also when a NaN distance broke the order)
@@ -1267,7 +1629,7 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
             if (kq) { ar += dot4(wk[0], xkq); az += dot4(wk[1], xkq); an += dot4(wk[2], xkq); }
             if (zq) { ar += dot4(wz[0], xzq); az += dot4(wz[1], xzq); an += dot4(wz[2], xzq); }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { ar += __shfl_xor(ar, off); az += __shfl_xor(az, off); an += __shfl_xor(an, off); }
+            for (int off = 32; off > 0; off >>= 1) { ar += nm_sx(ar, off); az += nm_sx(az, off); an += nm_sx(an, off); }
             if (lane == 0) {
                 const float rg = sigmoidf((ar + bi3[0]) + gr[0]);
                 const float zg = sigmoidf((az + bi3[1]) + gz[0]);
@@ -1337,7 +1699,7 @@ __global__ __launch_bounds__(1024) void vrnn_post_mid_kernel(PostArgs a) {
 #pragma unroll
         for (int u = 0; u < MID_PAIRS; ++u) {
             const float v = half_reduce(dot4(wa[u], xh));
-            const float o = __shfl_xor(v, 32);
+            const float o = nm_sx(v, 32);
             if (l32 == u) { mine = v; other = o; }
         }
         if (!half && l32 < MID_PAIRS) {
@@ -1434,7 +1796,7 @@ __global__ __launch_bounds__(1024) void vrnn_post_mid_kernel(PostArgs a) {
 #pragma unroll
         for (int u = 0; u < MID_PAIRS; ++u) {
             const float v = half_reduce(dot4(wa[u], xp));
-            const float o = __shfl_xor(v, 32);
+            const float o = nm_sx(v, 32);
             if (l32 == u) { mine = v; other = o; }
         }
         if (tid < 256) s_red[tid] = 0.f;
@@ -1991,6 +2353,8 @@ void nm_vrnn_invalidate_tape(nm_ctx* c) { if (c->vtape) static_cast<VrnnTape*>(c
 
 extern "C" {
 
+void nm_diag_set_chain_stamps(void* p) { g_chain_stamps = static_cast<long long*>(p); }
+
 int nm_vrnn_set_tree(nm_ctx* c, const int32_t* parents, const int32_t* order) try { NmScope nm_scope_(c);
     int rc = ready(c, "vrnn_set_tree", false);
     if (rc) return rc;
@@ -2457,13 +2821,15 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         if (nm_ls().chain_fits < 0) {
             static NmDeviceOnce attr_set;
             if (!attr_set.done()) {
-                if ((rc = nm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_prior_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), "hipFuncSetAttribute(vrnn_prior_chain)"))) return rc;
+                if ((rc = nm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_prior_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024), "hipFuncSetAttribute(vrnn_prior_chain)"))) return rc;
+                if ((rc = nm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_prior_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024), "hipFuncSetAttribute(vrnn_prior_chain one-XCD)"))) return rc;
                 attr_set.mark();
             }
             int per_cu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&vrnn_prior_chain_kernel), NM_CHAIN_T, (size_t)(3 + 7 * 32) * 128 * sizeof(float)) != hipSuccess ||
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&vrnn_prior_chain_kernel<false>), NM_CHAIN_T, (size_t)(3 + 7 * 32) * 128 * sizeof(float)) != hipSuccess ||
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
             nm_ls().chain_fits = ((long long)per_cu * cus >= NM_CHAIN_NW + 4) ? 1 : 0;
+            nm_ls().chain_cus = cus;
         }
         chain = nm_ls().chain_fits == 1;
     }
@@ -2499,17 +2865,28 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         a.g_hid = gb; a.g_rh = gb + (size_t)B * 128; a.g_jh = gb + (size_t)2 * B * 128; a.g_gh = gb + (size_t)3 * B * 128;
         a.g_kpz = a.g_gh + (size_t)B * 3 * H; a.g_h[0] = a.g_kpz + (size_t)B * (S4 + Z); a.g_h[1] = a.g_h[0] + (size_t)B * H;
         a.abort = reinterpret_cast<unsigned*>(a.g_h[1] + (size_t)B * H);
+        a.ctl = nullptr; a.stamps = g_chain_stamps;
         a.status = c->nf_flag;
         a.B = B; a.T = Tg; a.K = K; a.Z = Z; a.H = H;
         // poll back-off in s_sleep(2) units (0 / 1 / 4 / 16 / 64: 17.0 / 18.0 / 17.3 / 19.5 / 25.9 us per step at B = 1)
         { static const int bo = getenv("NM355_CHAIN_BACKOFF") ? atoi(getenv("NM355_CHAIN_BACKOFF")) : 0; a.backoff = bo; }
         a.spin_limit = nm_ls().chain_spin > 0 ? nm_ls().chain_spin : NM_CHAIN_SPIN;
+        a.wg_poll = nm_ls().chain_wgpoll;
         const size_t gbytes = (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) * sizeof(nm_gran) + 64;
         if ((rc = nm_check_hip(hipMemsetAsync(r.chain_g, 0, gbytes, c->stream), "rollout: granule buffers"))) return rc;
         // (NM355_CHAIN_DROP_WG, test hook: the last workgroups are not launched - what a workgroup that never becomes resident looks like
         //  to the others; their spins run into the limit, the abort word ends the kernel, bit 1 of the status word reports it)
         const int drop = std::min(std::max(nm_ls().chain_drop, 0), B);
-        hipLaunchKernelGGL(vrnn_prior_chain_kernel, dim3(NM_CHAIN_NW + B - drop), dim3(NM_CHAIN_T), chain_lds, c->stream, a);
+        // One-XCD form first (NM355_CHAIN_XCD, default on; B <= 8, H = 512): one workgroup per CU of the device, of which the NM_CHAIN_NWX + B
+        // that share the first arriver's XCD run the rollout with plain-store / L2-served hand-offs; if that XCD cannot seat them all
+        // (other work on its CUs) nobody starts and the cross-XCD launch behind it - which otherwise returns at its first instruction -
+        // does the work.  The two launches share inputs, outputs and the (zeroed) granule buffers.
+        if (nm_ls().chain_xcd && B <= 8 && H == 512 && nm_ls().chain_cus >= 64 && drop == 0) {
+            a.ctl = reinterpret_cast<int*>(a.abort) + 4;
+            hipLaunchKernelGGL(vrnn_prior_chain_kernel<true>, dim3(nm_ls().chain_cus), dim3(NM_CHAIN_T), chain_lds, c->stream, a);
+            if ((rc = nm_check_hip(hipGetLastError(), "vrnn_prior_chain (one XCD) launch"))) return rc;
+        }
+        hipLaunchKernelGGL(vrnn_prior_chain_kernel<false>, dim3(NM_CHAIN_NW + B - drop), dim3(NM_CHAIN_T), chain_lds, c->stream, a);
         if ((rc = nm_check_hip(hipGetLastError(), "vrnn_prior_chain launch"))) return rc;
         *cur_out = nxt;                 // the last step's state, as plain floats
         return NM_OK;
