@@ -1391,11 +1391,25 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
             const float* pc = r < R0 ? m.w_root2 + (size_t)r * 128 : m.w_joint2 + (size_t)(r - R0) * 128;
             if (p * 2 + half < rows_c) s_wc[(p * 2 + half) * 32 + l32] = *reinterpret_cast<const f32x4*>(pc + l32 * 4);
         }
-        const int pl = wave * NM_CHAIN_PAIRS + (l32 < NM_CHAIN_PAIRS ? l32 : 0);
+        // (round 6, as in vrnn_prior_chain_kernel: the 16 row pairs of a wave summed by reduce_scatter - lane l32 holds pair rs_index(l32))
+        const int pu = rs_index<NM_CHAIN_PAIRS, 32>(l32);
+        const bool pown = (l32 & 1) == 0;
+        const int pl = wave * NM_CHAIN_PAIRS + pu;
         const float bias_a = a.b_q2[pl], bias_a2 = a.b_q2[pl + Z];
         const int rl = min(pl * 2 + half, rows_c - 1);
         const float bias_c = *(rl < R0 ? m.b_root2 + rl : m.b_joint2 + (rl - R0));
         fk_tables_load(tb, m.lvl_joint, m.lvl_start, m.parents, m.offset + (size_t)b * K * 3, K, m.nlevels, tid);
+        __syncthreads();
+        __shared__ unsigned char s_path[32][32];                         // joint j's chain from the root's child down to j (vrnn_prior_chain_kernel)
+        __shared__ int s_plen[32];
+        if (tid < K) {
+            const int rootj = tb.lvl_joint[0];
+            int n = 0, c = tid;
+            unsigned char tmp[32];
+            while (c != rootj && n < 32) { tmp[n++] = (unsigned char)c; c = tb.parents[c]; }
+            for (int i = 0; i < n; ++i) s_path[tid][i] = tmp[n - 1 - i];
+            s_plen[tid] = n;
+        }
         __syncthreads();
         for (int t = 0; t < T; ++t) {
             const unsigned tag = (unsigned)t + 1u;
@@ -1411,15 +1425,13 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
             const float add_b = ga[0];
             // ---- A: posterior parameters and this workgroup's sample ----
             {
-                float mine = 0.f, other = 0.f;
+                float va[NM_CHAIN_PAIRS];
 #pragma unroll
-                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
-                    const float v = half_reduce(dot4(wa[u], xh));
-                    const float o = nm_sx(v, 32);
-                    if (l32 == u) { mine = v; other = o; }
-                }
-                if (!half && l32 < NM_CHAIN_PAIRS) {
-                    const int p = wave * NM_CHAIN_PAIRS + l32;
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) va[u] = dot4(wa[u], xh);
+                const float mine = reduce_scatter<NM_CHAIN_PAIRS, 32>(va, l32);
+                const float other = nm_sxc<32>(mine);
+                if (!half && pown) {
+                    const int p = pl;
                     const float mu = mine + bias_a, sraw = other + bias_a2;
                     const float sg = softplus(sraw) + 1e-4f;
                     const float z = mu + epsv * sg;
@@ -1432,49 +1444,75 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
             // ---- B ----
             {
                 const f32x4 xz = *reinterpret_cast<const f32x4*>(s_z + l32 * 4);
-                float mine = 0.f;
+                float vb[NM_CHAIN_PAIRS];
 #pragma unroll
-                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
-                    const float v = half_reduce(dot4(wb[u], xz));
-                    if (l32 == u) mine = v;
-                }
-                if (l32 < NM_CHAIN_PAIRS) (half ? s_hj : s_hr)[wave * NM_CHAIN_PAIRS + l32] = lrelu(mine + add_b, 0.01f);
+                for (int u = 0; u < NM_CHAIN_PAIRS; ++u) vb[u] = dot4(wb[u], xz);
+                const float mine = reduce_scatter<NM_CHAIN_PAIRS, 32>(vb, l32);
+                if (pown) (half ? s_hj : s_hr)[pl] = lrelu(mine + add_b, 0.01f);
             }
             __syncthreads();
             // ---- C ----
             {
                 const f32x4 xr = *reinterpret_cast<const f32x4*>(s_hr + l32 * 4);
                 const f32x4 xj = *reinterpret_cast<const f32x4*>(s_hj + l32 * 4);
-                float mine = 0.f;
+                float vc[NM_CHAIN_PAIRS];
 #pragma unroll
                 for (int u = 0; u < NM_CHAIN_PAIRS; ++u) {
                     const int r = (wave * NM_CHAIN_PAIRS + u) * 2 + half;
                     const f32x4 wq = s_wc[min(r, rows_c - 1) * 32 + l32];
-                    const float v = half_reduce(dot4(wq, r < R0 ? xr : xj));
-                    if (l32 == u) mine = v;
+                    vc[u] = dot4(wq, r < R0 ? xr : xj);
                 }
-                if (l32 < NM_CHAIN_PAIRS) {
-                    const int r = (wave * NM_CHAIN_PAIRS + l32) * 2 + half;
+                const float mine = reduce_scatter<NM_CHAIN_PAIRS, 32>(vc, l32);
+                if (pown) {
+                    const int r = pl * 2 + half;
                     if (r < R0) s_root[r] = tanhf(mine + bias_c);
                     else if (r < rows_c) s_rot[r - R0] = mine + bias_c;
                 }
             }
             __syncthreads();
-            // ---- D: forward kinematics ----
-            if (tid < K) {
-                const float* p = s_rot + tid * 6;
-                float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
-                float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
-                x0 /= nx; x1 /= nx; x2 /= nx;
-                float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
-                float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
-                z0 /= nz; z1 /= nz; z2 /= nz;
-                float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
-                float* R = s_Rl + tid * 9;
-                R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
+            // ---- D: forward kinematics by wave 0, lane j walking joint j's chain from the root (round 6; vrnn_prior_chain_kernel) ----
+            if (wave == 0) {
+                if (lane < K) {
+                    const float* p = s_rot + lane * 6;
+                    float x0 = p[0], x1 = p[1], x2 = p[2], y0 = p[3], y1 = p[4], y2 = p[5];
+                    float nx = sqrtf((x0 * x0 + x1 * x1) + x2 * x2) + 1e-10f;
+                    x0 /= nx; x1 /= nx; x2 /= nx;
+                    float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+                    float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2) + 1e-10f;
+                    z0 /= nz; z1 /= nz; z2 /= nz;
+                    float yy0 = z1 * x2 - z2 * x1, yy1 = z2 * x0 - z0 * x2, yy2 = z0 * x1 - z1 * x0;
+                    float* R = s_Rl + lane * 9;
+                    R[0] = x0; R[1] = yy0; R[2] = z0; R[3] = x1; R[4] = yy1; R[5] = z1; R[6] = x2; R[7] = yy2; R[8] = z2;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < K) {
+                    const int rootj = tb.lvl_joint[0];
+                    float G[9], pp[3];
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) G[e] = s_Rl[rootj * 9 + e];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) pp[r] = s_root[r];
+                    const int n = s_plen[lane];
+                    for (int i = 0; i < n; ++i) {
+                        const int c = s_path[lane][i];
+                        float L[9], Gn[9];
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) L[e] = s_Rl[c * 9 + e];
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) { const int r = e / 3, cc = e % 3; Gn[e] = (G[r * 3] * L[cc] + G[r * 3 + 1] * L[3 + cc]) + G[r * 3 + 2] * L[6 + cc]; }
+                        const float* of = tb.offset + c * 3;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) pp[r] = ((Gn[r * 3] * of[0] + Gn[r * 3 + 1] * of[1]) + Gn[r * 3 + 2] * of[2]) + pp[r];
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) G[e] = Gn[e];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) s_pos[lane * 3 + r] = pp[r];
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) s_Rg[lane * 9 + e] = G[e];
+                }
             }
             __syncthreads();
-            fk_levels(tb, m.nlevels, s_Rl, s_Rg, s_pos, s_root, 36, K, 1, 0, 0, tid, NM_CHAIN_T);
             // ---- E: keypoints, distance to the observation (per-joint terms, summed in joint order) ----
             float kpv = 0.f;
             if (tid < S4) {
@@ -1577,16 +1615,21 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
             if (!wave_alive) break;
             f32x4 xo = {0.f, 0.f, 0.f, 0.f};
             if (oq) xo = *reinterpret_cast<const f32x4*>(a.obs + (size_t)b * a.ldobs + (size_t)t * S4 + lane * 4);
+            float vh[HR];
 #pragma unroll
             for (int i = 0; i < HR; ++i) {
                 float acc = 0.f;
                 acc += dot4(wh[i][0], x0);
                 acc += dot4(wh[i][1], x1);
                 if (i == 0 && oq) acc += dot4(wobs, xo);             // (dot_seg's second segment: the lanes that hold a keypoint quad)
+                vh[i] = acc;
+            }
+            // (round 6) the four row sums in one reduce-scatter: row i ends up in the lanes with bits 5:4 = i (rs_index<4, 64>), lane 16 i stores it
+            const float htot = reduce_scatter<HR, 64>(vh, lane);
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) acc += nm_sx(acc, off);
-                if (lane == 0) {
-                    const float v = acc + bh[i];
+            for (int i = 0; i < HR; ++i) {
+                if (lane == 32 * (i >> 1) + 16 * (i & 1)) {
+                    const float v = htot + bh[i];
                     if (i == 0) {
                         if (sect == 0) gran_store(a.g_hidp + ((size_t)(a.nstat ? t : 0) * B + b) * 128 + rsec, lrelu(v, 0.01f), tag);
                         else if (sect == 1) {
@@ -1628,8 +1671,13 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_post_chain_kernel(PostChainAr
             float ar = 0.f, az = 0.f, an = 0.f;
             if (kq) { ar += dot4(wk[0], xkq); az += dot4(wk[1], xkq); an += dot4(wk[2], xkq); }
             if (zq) { ar += dot4(wz[0], xzq); az += dot4(wz[1], xzq); an += dot4(wz[2], xzq); }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { ar += nm_sx(ar, off); az += nm_sx(az, off); an += nm_sx(an, off); }
+            {   // (round 6) the three gate sums in one reduce-scatter (a fourth, zero, pads it): sum i in the lanes with bits 5:4 = i
+                float vg[4] = {ar, az, an, 0.f};
+                const float gt = reduce_scatter<4, 64>(vg, lane);
+                ar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gt), 0));
+                az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gt), 16));
+                an = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gt), 32));
+            }
             if (lane == 0) {
                 const float rg = sigmoidf((ar + bi3[0]) + gr[0]);
                 const float zg = sigmoidf((az + bi3[1]) + gz[0]);
