@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ 
         for (int off = GP; off < 64; off <<= 1) col += __shfl_xor(col, off);          // the column's rows of the other groups
         if (grp == 0 && x < g) dst[g + x] = col;
         float tot6 = grp == 0 ? col : 0.f;                                            // (columns x >= g hold zeros)
-        for (int off = 32; off > 0; off >>= 1) { tot += __shfl_xor(tot, off); tot6 += __shfl_xor(tot6, off); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { tot += nm_sx(tot, off); tot6 += nm_sx(tot6, off); }
         if (lane == 0) { dst[2 * g] = tot; dst[2 * g + 1] = tot6; }
     }
 }
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void combined_kernel(const float* __restrict__
 // three block sums at once: xor-shuffle tree inside each wave, the four wave results through LDS (fixed order); valid in every thread
 __device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* sh /* >= 12 floats */) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    for (int o = 32; o > 0; o >>= 1) { a += nm_sx(a, o); b += nm_sx(b, o); c += nm_sx(c, o); }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { float* d = sh + (threadIdx.x >> 6) * 3; d[0] = a; d[1] = b; d[2] = c; }
     __syncthreads();
