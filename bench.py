@@ -42,6 +42,10 @@ def parse_args(argv=None):
     ap.add_argument("--conv-mode", choices=["split16", "fp32", "f16", "bf16"], default="split16",
                     help="split16: fp32-equivalent 3x f16 MFMA products (default); fp32: exact fp32 MFMA everywhere; f16: products of fp16-rounded "
                          "operands, fp32 storage; bf16: f16 arithmetic + bfloat16 storage of the training path (BASELINE config 3 as named)")
+    ap.add_argument("--ranks-on-one-gpu", type=int, default=0, metavar="R",
+                    help="DIAGNOSTIC (verdict r5 item 7b): R processes, one context each, ALL on device 0, gloo for the timing collectives - what R "
+                         "ranks sharing the host's launch path (and one GPU) cost: the aggregate voxel-frames/s against the one-process figure. "
+                         "Forces --no-extras --no-cpu-baseline; not a scaling number")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run only the multi-rank plumbing of this file (rendezvous, barrier, all-reduce of ones, MAX-reduce of the elapsed "
                          "time) and print it as one JSON line; backend gloo when no GPU is visible (tests/test_sharding_cpu.py)")
@@ -58,8 +62,9 @@ def launch_ranks(args, argv) -> int:
     env.setdefault("OMP_NUM_THREADS", "8")
     # --standalone: torch.distributed.run picks the rendezvous port itself (a bind-then-close probe here could lose it to another
     # process before the child binds); --local-addr: the container hostname may not resolve
+    nproc = args.ranks_on_one_gpu or args.gpus
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
-           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__), *argv]
+           f"--nproc-per-node={nproc}", os.path.abspath(__file__), *argv]
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for ln in child.stdout:
@@ -75,6 +80,8 @@ def launch_ranks(args, argv) -> int:
         return 3
     print(line, flush=True)
     d = json.loads(line).get("distributed", {})
+    if args.ranks_on_one_gpu:
+        return 0 if d.get("ranks_seen_by_allreduce") == args.ranks_on_one_gpu else 3
     if d.get("world_size") != args.gpus or d.get("ranks_seen_by_allreduce") != args.gpus:
         sys.stderr.write(f"bench.py: asked for {args.gpus} ranks, the all-reduce saw {d.get('ranks_seen_by_allreduce')} "
                          f"(world_size {d.get('world_size')})\n")
@@ -84,7 +91,7 @@ def launch_ranks(args, argv) -> int:
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
     _a = parse_args()
-    if (_a.gpus or 1) > 1:
+    if (_a.gpus or 1) > 1 or _a.ranks_on_one_gpu > 1:
         sys.exit(launch_ranks(_a, sys.argv[1:]))
 
 import torch  # noqa: E402  (after the launcher: the parent of an N-rank run never loads it)
@@ -496,6 +503,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    one_gpu = args.ranks_on_one_gpu > 0
+    if one_gpu:                           # diagnostic: every rank on device 0
+        if world != args.ranks_on_one_gpu:
+            raise SystemExit(f"bench.py: --ranks-on-one-gpu {args.ranks_on_one_gpu} but the launcher started WORLD_SIZE={world} ranks")
+        args.gpus, local = world, 0
+        args.no_extras = args.no_cpu_baseline = True
     if args.gpus is None:                 # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's rank count is the request
         args.gpus = world
     if world != args.gpus:                # an explicit --gpus that the launcher did not honour is an error
@@ -510,7 +523,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")          # (RCCL refuses two ranks on one device; the timing collectives carry host scalars)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     dev = torch.device("cuda", local)
@@ -555,8 +571,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     _lib.check(lib.nm_prof_enable(h, 0), "prof_enable")
+    cdev = torch.device("cpu") if one_gpu else dev      # where the collectives' scalars live
     if dist_on:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fam_main = prof_families(lib, h, _lib) if rank == 0 else {}        # timed region, launches on the ctx stream (clean durations)
@@ -574,7 +591,7 @@ def main():
     # what each rank saw (the driver can check that RCCL really spanned N devices)
     ranks_seen = world
     if dist_on:
-        seen = torch.ones(1, device=dev)
+        seen = torch.ones(1, device=cdev)
         dist.all_reduce(seen)
         ranks_seen = int(seen.item())
 
@@ -627,7 +644,8 @@ def main():
             cpu, parity = cpu_baseline(sd, opts, net, dev)
         line = dict(
             metric="voxel-frames/sec (64^3, T=16)", value=frames / dt, unit="voxel-frames/s",
-            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+            n_gpus=1 if one_gpu else world,
+            **(dict(diagnostic=f"{world} processes (one nm_ctx each) sharing device 0: aggregate of all of them; NOT a scaling figure", ranks_on_one_gpu=world) if one_gpu else {}), steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
             higher_is_better=True, scaling="weak", vs_baseline=None,
             dtype=("f32 (conv products as 3x f16-split MFMA with f32 accumulate, fp32-equivalent; everything else f32)"
                    if eng.conv_mode == 1 else ("f16 conv products (operands rounded to fp16, 1 MFMA per product), f32 accumulation and storage"

@@ -60,7 +60,7 @@ NmLaunchState::NmLaunchState()
       gnb_u8(env_int("NM355_GNB_U8", 1)),               // 0: four instead of eight items in flight in the bfloat16 GroupNorm-backward apply (A/B)
       adj_zwalk(env_int("NM355_ADJ_ZWALK", 1)),        // 0: the trilinear upsample's adjoint on the 2 x 4 x 8 brick kernel (6 x 10 x 18 fine tile) instead of the z-walking one (A/B)
       f16q2(env_int("NM355_F16Q2", 1)),                 // 0: the one-product modes (3 / 4) keep conv_f16p2<SINGLE> instead of their own kernel conv_f16q2 (A/B)
-      vrnn_post_chain(env_int("NM355_VRNN_POST_CHAIN", 1))   // 0: the posterior steps of a stand-alone encode as six launches each; 1: one persistent launch (vrnn_post_chain_kernel); 2: inside nm_forward_fused too (A/B)
+      vrnn_post_chain(env_int("NM355_VRNN_POST_CHAIN", 2))   // 0: the posterior steps of encode as six launches each; 1: one persistent launch (vrnn_post_chain_kernel) for a stand-alone encode only; 2 (default since round 6): inside nm_forward_fused too - 148 instead of 238 launches per forward step for +0.03 ... 0.13 ms (profiles/r06_forward_ab.txt)
       , f16r(env_int("NM355_F16R", 1))                      // 0: the one-product modes keep conv_f16p<SINGLE> on the 32-output-channel layers instead of conv_f16r (resident weights; A/B)
       , up2_mat(env_int("NM355_UP2_MAT", 1))                // 0: the one-product training forward keeps the fused-upsample staging on its 32-output layer instead of materialising the upsampled input for conv_f16r (A/B)
       , conv_wgs(env_int("NM355_CONV_WGS", 0))              // > 0: the persistent producer / consumer convs launch at most this many workgroups (co-residency A/B: CUs left free for the other queues)

@@ -56,3 +56,16 @@ def test_forward_line_under_torchrun_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["distributed"]["backend"] == "nccl" and d["distributed"]["world_size"] == 1 and d["distributed"]["ranks_seen_by_allreduce"] == 1
+
+
+def test_four_processes_sharing_one_gpu_keep_the_aggregate_throughput():
+    """Multi-rank readiness that one GPU can measure (verdict r5 item 7b): `bench.py --ranks-on-one-gpu 4` starts four ranks - four
+    processes, four library contexts, gloo for the barriers and the MAX-reduce of the elapsed time - that all enqueue the headline forward
+    on device 0.  If the per-rank host work (148 launches per step from Python through ctypes) were anywhere near the device time, four
+    processes contending for the launch path would lose aggregate throughput; measured on MI355X (16-core cgroup): 1.03 x the
+    one-process figure with four ranks, 0.96 x with eight (profiles/r06_ranks_on_one_gpu.txt).  Asserted: >= 0.9 x."""
+    one = _run("--steps", "8", "--warmup", "3", "--no-extras", "--no-cpu-baseline")
+    four = _run("--ranks-on-one-gpu", "4", "--steps", "8", "--warmup", "3")
+    assert four["ranks_on_one_gpu"] == 4 and four["distributed"]["ranks_seen_by_allreduce"] == 4 and four["distributed"]["backend"] == "gloo"
+    print("one process %.0f voxel-frames/s, four processes on the same GPU %.0f in aggregate (x%.2f)" % (one["value"], four["value"], four["value"] / one["value"]))
+    assert four["value"] >= 0.9 * one["value"], (one["value"], four["value"])

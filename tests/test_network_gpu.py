@@ -1158,8 +1158,8 @@ def test_vrnn_kernel_variants_stay_under_parity(env, golden_dir):
         test_generation_driver_vs_oracle()
 
 
-@pytest.mark.parametrize("env", [{"NM355_POOL_Q": "0"}, {"NM355_OCC_FLAGS": "0"}, {"NM355_OCC_FLAGS": "1"}],
-                         ids=["pool-conv-f16s", "first-layer-no-flags", "first-layer-flags-no-row-walk"])
+@pytest.mark.parametrize("env", [{"NM355_POOL_Q": "0"}, {"NM355_OCC_FLAGS": "0"}, {"NM355_OCC_FLAGS": "1"}, {"NM355_VRNN_POST_CHAIN": "1"}],
+                         ids=["pool-conv-f16s", "first-layer-no-flags", "first-layer-flags-no-row-walk", "posterior-steps-as-launches-in-the-fused-forward"])
 def test_forward_kernel_variants_stay_under_parity(env, golden_dir):
     """The forward's late round-3 A/B partners: the k2 s2 pool convs on conv_pool_f16s_kernel (conditional staging loads) instead of
     conv_pool_f16q_kernel, and the sparse first layer finding its empty bricks without the per-brick occupancy flags / with the flags
