@@ -47,17 +47,38 @@ python3 tools/pmc_mfma.py $(find $E/pm -name "*.db" | head -1) $E/${R}_pmc_mfma.
 TBCMD="python3 bench.py --workload train --conv-mode bf16 --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $E/pmb -- $TBCMD > $E/pmb.log 2>&1
 python3 tools/pmc_mfma.py $(find $E/pmb -name "*.db" | head -1) $E/${R}_pmc_mfma_train_bf16.json > $E/pmc_mfma_train_bf16_summary.txt 2>&1
-# same-call A/Bs of the round: posterior chain (encode alone, and forced on inside the fused forward), one-product conv kernels; training step with the
-# round's one-product changes switched off
-python3 tools/time_encode_ab.py 2>&1 | grep -v amdgpu.ids > $E/${R}_encode_ab.txt
-python3 tools/ab_f16q2.py 64 2>&1 | grep -v amdgpu.ids > $E/${R}_f16q2_ab.txt
-python3 tools/ab_f16r.py 64 2>&1 | grep -v amdgpu.ids > $E/${R}_f16r_ab.txt
-if [ -f neural_marionette_amd/libnm355_diag.so ]; then python3 tools/diag_f16q2.py 0,1,2,3,5,6,7,8,9,0 2>&1 | grep -v amdgpu.ids >> $E/${R}_f16q2_ab.txt; fi
-for M in bf16 f16; do
-  for SW in "" "NM355_F16R=0 NM355_UP2_MAT=0" "NM355_F16R=0 NM355_UP2_MAT=0 NM355_F16Q2=0"; do
-    echo "train $M [$SW]: $(env $SW python3 bench.py --workload train --conv-mode $M --steps 10 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c 'import sys,json; print(json.loads(sys.stdin.read())["ms_per_step"])') ms per step" >> $E/${R}_train_ab.txt
+# same-call A/Bs of the round (r06): MFMA shape of conv_up2c, hand-off latency by placement / store flavour, granule loads of the persistent
+# chains (needs libnm355_x4.so: make -C neural_marionette_amd/csrc x4), the rollout chain's forms + where a step's time goes, encode,
+# forward-step switches, R processes on one GPU
+bash tools/ab_mfma_shape.sh 7 > $E/${R}_mfma_shape_ab.txt 2>&1
+(hipcc -O3 -w --offload-arch=gfx950 tools/calib/hop_latency.hip -o /tmp/hop_latency && timeout 120 /tmp/hop_latency) > $E/${R}_hop_latency.txt 2>&1
+if [ -f neural_marionette_amd/libnm355_x4.so ]; then bash tools/ab_granule_loads.sh 2>&1 | grep -v amdgpu.ids > $E/${R}_granule_loads_ab.txt; fi
+{
+  echo "config-5 rollout (tools/time_rollout.py: generate, Tcond = 5 posterior + 64 prior steps), alternating, one call:"
+  for i in 1 2; do
+    echo "one-XCD chain (default)        : $(python3 tools/time_rollout.py /tmp/ro_x.pt 2>&1 | grep us/step | tr '\n' ';')"
+    echo "cross-XCD chain, one poller/WG : $(NM355_CHAIN_XCD=0 NM355_CHAIN_WGPOLL=1 python3 tools/time_rollout.py /tmp/ro_w.pt /tmp/ro_x.pt 2>&1 | grep -E 'us/step|identical' | tr '\n' ';')"
+    echo "cross-XCD chain, every wave polls: $(NM355_CHAIN_XCD=0 python3 tools/time_rollout.py /tmp/ro_c.pt /tmp/ro_x.pt 2>&1 | grep -E 'us/step|identical' | tr '\n' ';')"
+    echo "three launches per prior step  : $(NM355_VRNN_CHAIN=0 python3 tools/time_rollout.py /tmp/ro_l.pt /tmp/ro_x.pt 2>&1 | grep -E 'us/step|identical' | tr '\n' ';')"
   done
-done
+  echo; echo "where a prior step's time goes (tools/diag_chain_stamps.py, s_memrealtime stamps, steps 8..63 of a rollout):"
+  for X in 1 0; do NM355_CHAIN_XCD=$X NM355_CHAIN_WGPOLL=1 python3 tools/diag_chain_stamps.py 2>&1 | grep -v amdgpu.ids; done
+} > $E/${R}_rollout_ab.txt 2>&1
+python3 tools/time_encode_ab.py 2>&1 | grep -v amdgpu.ids > $E/${R}_encode_ab.txt
+{
+  echo "headline forward step (bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline), alternating runs in one call on one device:"
+  bash tools/ab_forward_env.sh "NM355_UP2C_X16=0" "NM355_UP2C_X16=1" 3
+  bash tools/ab_forward_env.sh "NM355_VRNN_POST_CHAIN=1" "NM355_VRNN_POST_CHAIN=2" 3
+  bash tools/ab_forward_env.sh "NM355_UP2C_ALL=0" "NM355_UP2C_ALL=1" 2
+} > $E/${R}_forward_ab.txt 2>&1
+{
+  echo "R processes (one nm_ctx each) on ONE GPU, bench.py --ranks-on-one-gpu R --steps 12 --warmup 4: aggregate voxel-frames/s"
+  for RK in 1 4 8; do
+    if [ $RK = 1 ]; then A=""; else A="--ranks-on-one-gpu $RK"; fi
+    python bench.py $A --steps 12 --warmup 4 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print("ranks", d.get("ranks_on_one_gpu",1), "ms/step %.2f" % d["ms_per_step"], "aggregate %.0f voxel-frames/s" % d["value"], d["distributed"])'
+  done
+  python3 tools/host_ahead.py 20 2>&1 | grep "host per step"
+} > $E/${R}_ranks_on_one_gpu.txt 2>&1
 rm -rf $E/fwd $E/train $E/trainb $E/c4 $E/c5 $E/tf $E/tw $E/pm $E/pmb
 # stamp the tree id into every summary
 python3 tools/tree_id.py --stamp "$TREE" $E/${R}_*.json $E/${R}_*.csv $E/${R}_*.txt $E/${R}_bench.json.log
