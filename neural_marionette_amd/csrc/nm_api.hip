@@ -67,8 +67,9 @@ NmLaunchState::NmLaunchState()
       , up2c_x16(env_int("NM355_UP2C_X16", 1))              // 0: conv_up2c stays on v_mfma_f32_32x32x16_f16 (A/B; 1: conv_up2c_x16_kernel, v_mfma_f32_16x16x32_f16, fp32-storage modes)
       , up2c_all(env_int("NM355_UP2C_ALL", 0))              // 1: the decoder's FIRST fused-upsample layer (128 -> 64 @16^3 -> 32^3) on the composite-weight kernel too (A/B)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); chain_spin = env_int("NM355_CHAIN_SPIN", 1 << 20); chain_drop = env_int("NM355_CHAIN_DROP_WG", 0); chain_stat_delay = env_int("NM355_CHAIN_STAT_DELAY", 0);
-  chain_wgpoll = env_int("NM355_CHAIN_WGPOLL", 0);      // 1: the cross-XCD rollout chain polls with one wave per workgroup (A/B)
-  chain_xcd = env_int("NM355_CHAIN_XCD", 1); }           // 0: no one-XCD launch in front of the cross-XCD rollout chain (A/B)
+  chain_wgpoll = env_int("NM355_CHAIN_WGPOLL", 1);      // 0: every wave of the cross-XCD rollout chain polls for itself (round 5; A/B)
+  chain_xcd_nogo = env_int("NM355_CHAIN_XCD_NOGO", 0);  // test hook: the one-XCD chain never starts (its fallback must do the work)
+  chain_xcd = env_int("NM355_CHAIN_XCD", 1); }           // 0: no one-XCD launch in front of the cross-XCD rollout chain (A/B); 1: for B = 1; 2: for B <= 8
 NmLaunchState& nm_ls() {
     static thread_local NmLaunchState outside;       // launchers reached outside an ABI call (none in the product path)
     return nm_tls_ls ? *nm_tls_ls : outside;

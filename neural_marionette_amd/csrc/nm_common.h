@@ -173,7 +173,7 @@ struct NmLaunchState {
     // persistent rollout kernel (nm_vrnn.hip vrnn_prior_chain_kernel): polls before a spin gives up (NM355_CHAIN_SPIN), trailing
     // workgroups NOT launched (NM355_CHAIN_DROP_WG: the test hook that stands in for a workgroup that never becomes resident), and the
     // co-residency verdict of this context's device (-1: not asked yet, 0: the chain does not fit, 1: it does)
-    int chain_spin = 1 << 20, chain_drop = 0, chain_fits = -1, post_chain_fits = -1, chain_stat_delay = 0, chain_wgpoll = 0, chain_xcd = 1, chain_cus = 0;
+    int chain_spin = 1 << 20, chain_drop = 0, chain_fits = -1, post_chain_fits = -1, chain_stat_delay = 0, chain_wgpoll = 1, chain_xcd_nogo = 0, chain_xcd = 1, chain_cus = 0;
     bool prof_on = false;
     hipStream_t prof_stream = nullptr;     // main stream of the profiled context; prof_all: launches on any stream are recorded
     bool prof_all = false;

@@ -696,6 +696,7 @@ struct ChainArgs {
     int spin_limit;                     // polls before a wave gives up (NM355_CHAIN_SPIN; default NM_CHAIN_SPIN)
     long long* stamps;                  // diagnostic phase stamps (null in product calls)
     int* ctl;                           // one-XCD form: [0] chosen XCD + 1, [1] roles taken, [2] go (1) / no-go (2), [3] workgroups that completed; zero before the launches (null: no one-XCD launch in front)
+    int force_nogo;                     // test hook: role 0 of the one-XCD form always decides no-go
     int wg_poll;                        // 1: one wave per worker workgroup polls, LDS + a workgroup barrier hand the values to the other seven (NM355_CHAIN_WGPOLL)
 };
 
@@ -846,8 +847,9 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs 
                     const long long t0 = wall_clock64();
                     int n = 0;
                     while ((n = __hip_atomic_load(a.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < NW + B && wall_clock64() - t0 < 3000) __builtin_amdgcn_s_sleep(8);
-                    __hip_atomic_store(a.ctl + 2, n >= NW + B ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (n < NW + B) r = -1;
+                    const bool go = n >= NW + B && !a.force_nogo;      // (force_nogo: NM355_CHAIN_XCD_NOGO, the test hook for "this XCD cannot seat the roles")
+                    __hip_atomic_store(a.ctl + 2, go ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!go) r = -1;
                 } else {
                     int go = 0, spins = 0;
                     while ((go = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
@@ -2919,7 +2921,7 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         // poll back-off in s_sleep(2) units (0 / 1 / 4 / 16 / 64: 17.0 / 18.0 / 17.3 / 19.5 / 25.9 us per step at B = 1)
         { static const int bo = getenv("NM355_CHAIN_BACKOFF") ? atoi(getenv("NM355_CHAIN_BACKOFF")) : 0; a.backoff = bo; }
         a.spin_limit = nm_ls().chain_spin > 0 ? nm_ls().chain_spin : NM_CHAIN_SPIN;
-        a.wg_poll = nm_ls().chain_wgpoll;
+        a.wg_poll = nm_ls().chain_wgpoll; a.force_nogo = nm_ls().chain_xcd_nogo;
         const size_t gbytes = (size_t)B * (3 * 128 + 3 * H + S4 + Z + 2 * H) * sizeof(nm_gran) + 64;
         if ((rc = nm_check_hip(hipMemsetAsync(r.chain_g, 0, gbytes, c->stream), "rollout: granule buffers"))) return rc;
         // (NM355_CHAIN_DROP_WG, test hook: the last workgroups are not launched - what a workgroup that never becomes resident looks like
@@ -2929,7 +2931,9 @@ static int rollout_steps(nm_ctx* c, RolloutBufs& r, int kind, int B, int Tcond, 
         // that share the first arriver's XCD run the rollout with plain-store / L2-served hand-offs; if that XCD cannot seat them all
         // (other work on its CUs) nobody starts and the cross-XCD launch behind it - which otherwise returns at its first instruction -
         // does the work.  The two launches share inputs, outputs and the (zeroed) granule buffers.
-        if (nm_ls().chain_xcd && B <= 8 && H == 512 && nm_ls().chain_cus >= 64 && drop == 0) {
+        // (B = 1 only by default: at B = 3 the one-XCD kernel itself is faster too - 767 against 818 us per 64 steps - but the call is not,
+        //  1.08 against 1.02 ms: profiles/r06_rollout_ab.txt; NM355_CHAIN_XCD=2 forces it for B <= 8)
+        if (nm_ls().chain_xcd && (B == 1 || (nm_ls().chain_xcd >= 2 && B <= 8)) && H == 512 && nm_ls().chain_cus >= 64 && drop == 0) {
             a.ctl = reinterpret_cast<int*>(a.abort) + 4;
             hipLaunchKernelGGL(vrnn_prior_chain_kernel<true>, dim3(nm_ls().chain_cus), dim3(NM_CHAIN_T), chain_lds, c->stream, a);
             if ((rc = nm_check_hip(hipGetLastError(), "vrnn_prior_chain (one XCD) launch"))) return rc;

@@ -514,23 +514,30 @@ def test_config5_rollout64(B):
     print("config-5 B=%d: %.1f us per VRNN step (eager, %d steps)" % (B, us, Tt))
 
 
+CHAIN_FORMS = {"default": {},                                                                    # one-XCD chain at B = 1, cross-XCD chain with one polling wave per workgroup otherwise
+               "one-xcd-forced": {"NM355_CHAIN_XCD": "2"},                                       # the one-XCD chain for every B <= 8
+               "one-xcd-refused": {"NM355_CHAIN_XCD": "2", "NM355_CHAIN_XCD_NOGO": "1"},            # its XCD "cannot seat the roles": nobody starts, the cross-XCD launch behind it does the work
+               "cross-xcd-one-poller": {"NM355_CHAIN_XCD": "0", "NM355_CHAIN_WGPOLL": "1"},
+               "cross-xcd-every-wave-polls": {"NM355_CHAIN_XCD": "0", "NM355_CHAIN_WGPOLL": "0"}}   # the round-5 form
+
+
+@pytest.mark.parametrize("form", list(CHAIN_FORMS))
 @pytest.mark.parametrize("B", [1, 2, 3, 4])
-def test_persistent_rollout_is_bit_identical_to_launch_per_phase_steps(B):
+def test_persistent_rollout_is_bit_identical_to_launch_per_phase_steps(B, form):
     """vrnn_prior_chain_kernel (round 4; BASELINE north_star "one kernel per timestep" - here the whole prior chain of a rollout is ONE
     persistent launch, weights register-resident, data-tagged granule hand-offs) against the three-launches-per-step path
     (NM355_VRNN_CHAIN=0, read when a context is created): HSVRNNBVH.generate and HSVRNNBVH.rollout, keypoints and the final state bit
-    for bit, both contexts alive in one process; the launch-per-phase path itself is held to the oracle by test_config5_rollout64."""
+    for bit, both contexts alive in one process; the launch-per-phase path itself is held to the oracle by test_config5_rollout64.
+    Round 6: in each of the chain's forms (CHAIN_FORMS) - workgroups of ONE XCD found through HW_REG_XCC_ID with plain-store / L2 hand-offs,
+    or workgroups anywhere with write-through hand-offs and one or eight polling waves each."""
     o = HotPathOptions(grid_size=32, Tcond=5)
     sd = synth.make_state_dict(o, seed=21, variant="default")
     nets = {}
-    for name, chain in (("launches", "0"), ("chain", "1")):
-        os.environ["NM355_VRNN_CHAIN"] = chain
-        try:
+    for name, env in (("launches", {"NM355_VRNN_CHAIN": "0"}), ("chain", dict(CHAIN_FORMS[form], NM355_VRNN_CHAIN="1"))):
+        with _switches(env):
             nets[name] = _net(o, sd)
-            with torch.no_grad():          # (creates the context while the switch is set)
+            with torch.no_grad():          # (creates the context while the switches are set)
                 nets[name].kypt_detector.get_affinity()
-        finally:
-            del os.environ["NM355_VRNN_CHAIN"]
     K, Z, Tc, Tt = o.nkeypoints, o.nlatent_kypt, 5, 37
     g = torch.Generator().manual_seed(B)
     kp = (torch.rand(B, Tc, K, 4, generator=g) * 1.6 - 0.8).cuda()

@@ -56,13 +56,13 @@ if [ -f neural_marionette_amd/libnm355_x4.so ]; then bash tools/ab_granule_loads
 {
   echo "config-5 rollout (tools/time_rollout.py: generate, Tcond = 5 posterior + 64 prior steps), alternating, one call:"
   for i in 1 2; do
-    echo "one-XCD chain (default)        : $(python3 tools/time_rollout.py /tmp/ro_x.pt 2>&1 | grep us/step | tr '\n' ';')"
+    echo "one-XCD chain (default at B = 1; forced at B = 3): $(NM355_CHAIN_XCD=2 python3 tools/time_rollout.py /tmp/ro_x.pt 2>&1 | grep us/step | tr '\n' ';')"
     echo "cross-XCD chain, one poller/WG : $(NM355_CHAIN_XCD=0 NM355_CHAIN_WGPOLL=1 python3 tools/time_rollout.py /tmp/ro_w.pt /tmp/ro_x.pt 2>&1 | grep -E 'us/step|identical' | tr '\n' ';')"
-    echo "cross-XCD chain, every wave polls: $(NM355_CHAIN_XCD=0 python3 tools/time_rollout.py /tmp/ro_c.pt /tmp/ro_x.pt 2>&1 | grep -E 'us/step|identical' | tr '\n' ';')"
+    echo "cross-XCD chain, every wave polls: $(NM355_CHAIN_XCD=0 NM355_CHAIN_WGPOLL=0 python3 tools/time_rollout.py /tmp/ro_c.pt /tmp/ro_x.pt 2>&1 | grep -E 'us/step|identical' | tr '\n' ';')"
     echo "three launches per prior step  : $(NM355_VRNN_CHAIN=0 python3 tools/time_rollout.py /tmp/ro_l.pt /tmp/ro_x.pt 2>&1 | grep -E 'us/step|identical' | tr '\n' ';')"
   done
   echo; echo "where a prior step's time goes (tools/diag_chain_stamps.py, s_memrealtime stamps, steps 8..63 of a rollout):"
-  for X in 1 0; do NM355_CHAIN_XCD=$X NM355_CHAIN_WGPOLL=1 python3 tools/diag_chain_stamps.py 2>&1 | grep -v amdgpu.ids; done
+  for X in 2 0; do NM355_CHAIN_XCD=$X NM355_CHAIN_WGPOLL=1 python3 tools/diag_chain_stamps.py 2>&1 | grep -v amdgpu.ids; done
 } > $E/${R}_rollout_ab.txt 2>&1
 python3 tools/time_encode_ab.py 2>&1 | grep -v amdgpu.ids > $E/${R}_encode_ab.txt
 {
