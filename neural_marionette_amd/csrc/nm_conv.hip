@@ -1712,8 +1712,16 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
 // IO: bit 0 = bfloat16 input (a producer piece is then an 8-byte load of the same four channels), bit 1 = bfloat16 output
-template <bool UP2, bool SINGLE = false, int IO = 0>
+// LATE (round 6, the default; NM355_F16P_LATE=0 selects the round-2 schedule): in-kernel stamps of the 32 -> 32 @64^3 layer
+// (tools/diag_f16p_steps.py) showed the MFMA waves waiting 760 + 1188 of a 10 400-tick step at the first two barriers - the producers
+// arrive last there: each weight group was loaded and WAITED for inside the phase that stores it (an L2 round trip per phase, the whole
+// third phase nothing else), and the tile of step s + 1 had to be complete at the SECOND barrier (pieces dealt 4 / 6 / 0).  As in
+// conv_f16p2 since round 3: the tile is complete at the step's LAST barrier (pieces 3 / 4 / 3; the MFMA waves request a step's first two
+// taps' A operands behind that barrier instead of during taps 25 / 26), and every weight group is requested one phase before it is
+// stored (two register sets, their roles alternate with the step's parity).
+template <bool UP2, bool SINGLE = false, int IO = 0, int LATE_ = 1>
 __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
+    constexpr bool LATE = LATE_ == 1, LATE_M = LATE_ != 0;      // (LATE_ == 2: diagnostic - old producer schedule, MFMA waves read the next tile late)
     constexpr bool IH = (IO & 1) != 0, OH = (IO & 2) != 0;
     constexpr unsigned EB = IH ? 2u : 4u;                           // bytes per input element
     constexpr int HV = 600, ZP = 100, HX = 10;
@@ -1788,9 +1796,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             pc_pos[k] = (v < HV) ? (hz | (hy << 8) | (hx << 16)) : -1;
         }
         using RawT = std::conditional_t<IH, nm_u32x2, f32x4>;
-        RawT raw[NP]; f32x4 sc, sh, wreg[5];
+        RawT raw[NP]; f32x4 sc, sh, scB = {0.f, 0.f, 0.f, 0.f}, shB = scB, wreg[5], wreg2[5];      // (scB / shB: LATE's second affine pair)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) wreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};       // (SINGLE uses three of them; all five are operands of the counted waits)
+        for (int i = 0; i < 5; ++i) { wreg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; wreg2[i] = wreg[i]; }       // (SINGLE uses three of them; all five are operands of the counted waits)
         const bool has_affine = p.in_scale != nullptr;
         const unsigned rel111 = (unsigned)(((p.IH + 1) * p.IW + 1) * p.Cin) * EB;   // halo voxel (1,1,1): always inside
         // bit k: piece k of a brick's halo tile lies inside the volume
@@ -1813,18 +1821,20 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             if constexpr (IH) raw[k] = load8_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * EB : rel111);
             else raw[k] = load16_untracked(base, ((mask >> k) & 1) ? (unsigned)pc_rel[k] * EB : rel111);
         };
-        auto load_affine = [&](const Work& w, int cb) {             // always two loads: the waits below count instructions
+        auto load_affine = [&](const Work& w, int cb, auto AFF) {             // always two loads: the waits below count instructions
             const float* ps = has_affine ? p.in_scale + (size_t)w.n * p.Cin + cb * 16 : p.in;
             const float* ph = has_affine ? p.in_shift + (size_t)w.n * p.Cin + cb * 16 : p.in;
-            sc = load16_untracked(ps, 16u * quad);
-            sh = load16_untracked(ph, 16u * quad);
+            if constexpr (decltype(AFF)::value) { scB = load16_untracked(ps, 16u * quad); shB = load16_untracked(ph, 16u * quad); }
+            else { sc = load16_untracked(ps, 16u * quad); sh = load16_untracked(ph, 16u * quad); }
         };
         // wait until all but the N youngest vector-memory operations are done; ties every load destination to the wait
 #define NM_PRODUCER_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" \
             : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]), \
-              "+v"(raw[8]), "+v"(raw[9]), "+v"(sc), "+v"(sh), "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]), "+v"(wreg[3]), "+v"(wreg[4]) :: "memory")
-        auto convert = [&](int buf, unsigned mask, auto K) {        // activate, split, write piece k into halo buffer buf
+              "+v"(raw[8]), "+v"(raw[9]), "+v"(sc), "+v"(sh), "+v"(wreg[0]), "+v"(wreg[1]), "+v"(wreg[2]), "+v"(wreg[3]), "+v"(wreg[4]), \
+              "+v"(wreg2[0]), "+v"(wreg2[1]), "+v"(wreg2[2]), "+v"(wreg2[3]), "+v"(wreg2[4]), "+v"(scB), "+v"(shB) :: "memory")
+        auto convert = [&](int buf, unsigned mask, auto K, auto AFF) {        // activate, split, write piece k into halo buffer buf (AFF: affine pair)
             constexpr int k = decltype(K)::value;
+            const f32x4& sc_ = decltype(AFF)::value ? scB : sc; const f32x4& sh_ = decltype(AFF)::value ? shB : sh;
             half4v hi4, lo4;
             const float keep = ((mask >> k) & 1) ? 1.f : 0.f;       // padding is zero AFTER the activation
 #pragma unroll
@@ -1832,7 +1842,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
                 float v0, v1;
                 if constexpr (IH) { const unsigned u = raw[k][e >> 1]; v0 = nm_bf_lo(u); v1 = nm_bf_hi(u); }
                 else { v0 = raw[k][e]; v1 = raw[k][e + 1]; }
-                if (has_affine) { v0 = __builtin_fmaf(v0, sc[e], sh[e]); v1 = __builtin_fmaf(v1, sc[e + 1], sh[e + 1]); }
+                if (has_affine) { v0 = __builtin_fmaf(v0, sc_[e], sh_[e]); v1 = __builtin_fmaf(v1, sc_[e + 1], sh_[e + 1]); }
                 // LeakyReLU (slope in (0, 1]) and the padding mask in two instructions per value: max(v, slope v) * keep
                 v0 = fmaxf(v0 * keep, (v0 * keep) * p.in_slope); v1 = fmaxf(v1 * keep, (v1 * keep) * p.in_slope);
                 half2v hv = __builtin_convertvector(f32x2{v0, v1}, half2v);
@@ -1864,15 +1874,15 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
         }
         // Through registers, not direct-to-LDS: an LDS-DMA instruction holds the issuing wave for ~200 cycles in this kernel
         // (15 per producer wave and step), a 16-byte load + ds_write_b128 pair a fraction of that.
-        auto load_b_group = [&](int cg, int cb, int g) {
+        auto load_b_group = [&](int cg, int cb, int g, auto SET) {
             const float* base = reinterpret_cast<const float*>(w8 + ((size_t)(9 * g) * C16 * 4 + (size_t)cb * 4) * plane + cg * 32);
 #pragma unroll
-            for (int i = 0; i < NWP; ++i) wreg[i] = load16_untracked(base, dma_src[i]);
+            for (int i = 0; i < NWP; ++i) { if constexpr (decltype(SET)::value) wreg2[i] = load16_untracked(base, dma_src[i]); else wreg[i] = load16_untracked(base, dma_src[i]); }
         };
-        auto store_b_group = [&](int g) {
+        auto store_b_group = [&](int g, auto SET) {
             char* lbase = reinterpret_cast<char*>(ldb + g * GB);
 #pragma unroll
-            for (int i = 0; i < NWP; ++i) *reinterpret_cast<f32x4*>(lbase + dma_dst[i]) = wreg[i];
+            for (int i = 0; i < NWP; ++i) *reinterpret_cast<f32x4*>(lbase + dma_dst[i]) = decltype(SET)::value ? wreg2[i] : wreg[i];
         };
 
         // The input runs two steps ahead of the MFMA waves: during step s the tile of step s+1 (loaded during step s-1) is
@@ -1884,18 +1894,80 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
         unsigned m_cvt = inside_mask(cur.w), m_ld = m_cvt;
         for (int c = pt; c < p.Cout; c += 256) lbias[c] = p.bias ? p.bias[c] : 0.f;
         // prologue: first tile + first two weight groups in the open, loads of the second tile in flight
-        load_b_group(cur.w.cg, 0, 0);
-        load_affine(cur.w, 0);
+        load_b_group(cur.w.cg, 0, 0, ic<0>{});
+        load_affine(cur.w, 0, ic<0>{});
         { const float* b = tile_base(cur.w, 0); static_for<NP>([&](auto K) { load_piece(b, m_cvt, K); }); }
         NM_PRODUCER_WAIT(0);
-        store_b_group(0);
-        load_b_group(cur.w.cg, 0, 1);
-        static_for<NP>([&](auto K) { convert(0, m_cvt, K); });
+        store_b_group(0, ic<0>{});
+        load_b_group(cur.w.cg, 0, 1, ic<0>{});
+        static_for<NP>([&](auto K) { convert(0, m_cvt, K, ic<0>{}); });
         NM_PRODUCER_WAIT(0);
-        store_b_group(1);
+        store_b_group(1, ic<0>{});
         m_cvt = inside_mask(s1.w);
-        load_affine(s1.w, s1.cb);
+        load_affine(s1.w, s1.cb, ic<0>{});
         { const float* b = tile_base(s1.w, s1.cb); static_for<NP>([&](auto K) { load_piece(b, m_cvt, K); }); }
+        if constexpr (LATE) {
+        // (weight group 2 of the first step: requested here, stored in its first phase)
+        load_b_group(cur.w.cg, cur.cb, 2, ic<0>{});
+        lds_barrier();
+        // Loads per step and thread, in issue order: phase 0 [W0' x NWP][pieces 0-2], phase 1 [W1' x NWP][pieces 3-6], phase 2 [W2' x NWP]
+        // [pieces 7-9][affine x 2]; Wg' = tap group g of the NEXT step (group 2: of the step after this phase, i.e. also the next).
+        // Set PAR holds the group requested in the previous phase.
+        auto step_body = [&](auto PARC) {
+            constexpr int PAR = decltype(PARC)::value;
+            if (s2.w.n != s1.w.n || s2.w.oz0 != s1.w.oz0 || s2.w.oy0 != s1.w.oy0 || s2.w.ox0 != s1.w.ox0) m_ld = inside_mask(s2.w);
+            else m_ld = m_cvt;
+            const float* b2 = tile_base(s2.w, s2.cb);
+            NM_PSTAMP(0);
+            // phase 0: request W0 of the next step; then wait for W2 of this step and everything older (this tile's pieces, its affine) - NOT
+            // for the three piece loads phase 2 has just issued (pieces 7-9 of the tile after this one: an HBM round trip)
+            load_b_group(s1.w.cg, s1.cb, 0, ic<PAR ^ 1>{});
+            if constexpr (SINGLE) { NM_PRODUCER_WAIT(6); } else { NM_PRODUCER_WAIT(8); }
+            NM_PSTAMP(1);
+            static_for<3>([&](auto K) { convert(hb ^ 1, m_cvt, K, ic<PAR>{}); load_piece(b2, m_ld, K); });
+            store_b_group(2, ic<PAR>{});                            // W2 of THIS step (buffer 2 was last read before the previous step's last barrier)
+            NM_PSTAMP(2);
+            lds_barrier();
+            NM_PSTAMP(3);
+            // phase 1: request W1 of the next step, store its W0 (younger than W0': 3 + NWP + 4 + 2 loads)
+            load_b_group(s1.w.cg, s1.cb, 1, ic<PAR>{});
+            static_for<4>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 3>{}, ic<PAR>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 3>{}); });
+            load_affine(s2.w, s2.cb, ic<PAR ^ 1>{});                 // the NEXT tile's affine into the other pair, a phase and a half before its first use
+            NM_PSTAMP(4);
+            if constexpr (SINGLE) { NM_PRODUCER_WAIT(12); } else { NM_PRODUCER_WAIT(14); }
+            store_b_group(0, ic<PAR ^ 1>{});
+            NM_PSTAMP(5);
+            lds_barrier();
+            NM_PSTAMP(6);
+            // phase 2: request W2 of the next step (stored in its phase 0), store its W1 (younger than W1': 4 + 2 + NWP + 3); the tile of
+            // step s + 1 is complete at this barrier
+            load_b_group(s1.w.cg, s1.cb, 2, ic<PAR ^ 1>{});
+            static_for<3>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 7>{}, ic<PAR>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 7>{}); });
+            if constexpr (SINGLE) { NM_PRODUCER_WAIT(12); } else { NM_PRODUCER_WAIT(14); }
+            store_b_group(1, ic<PAR>{});
+            NM_PSTAMP(7);
+            lds_barrier();
+            NM_PSTAMP(8);
+        };
+        // ONE straight-line body of two steps (the register sets swap roles with the step's parity): with the two parities as two
+        // branches of a loop the compiler reconciles their register assignments at the join - by moving registers whose untracked loads
+        // are still in flight (wrong weights whenever consecutive steps differ by more than their parity: found by the C16 = 4 tests)
+        auto next_step = [&]() {
+            cur = s1; s1 = s2; has1 = has2; has2 = has2 && advance(s2);
+            m_cvt = m_ld; hb ^= 1;
+#ifdef NM_DIAG
+            ++step_no;
+#endif
+        };
+        for (;;) {
+            step_body(ic<0>{});
+            if (!has1) break;
+            next_step();
+            step_body(ic<1>{});
+            if (!has1) break;
+            next_step();
+        }
+        } else {
         lds_barrier();
         for (;;) {
             // the tile being loaded (step s+2); its inside mask changes only with the brick
@@ -1905,29 +1977,29 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             NM_PSTAMP(0);
             // tap group 0: weights of this step's group 2; pieces 0-3.  Everything older than the 5 weight loads has landed
             // after the first wait (the tile of step s+1 and its affine were issued a step ago).
-            load_b_group(cur.w.cg, cur.cb, 2);
+            load_b_group(cur.w.cg, cur.cb, 2, ic<0>{});
             if constexpr (SINGLE) { NM_PRODUCER_WAIT(3); } else { NM_PRODUCER_WAIT(5); }      // (the NWP weight loads are the youngest)
             NM_PSTAMP(1);
-            static_for<4>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
+            static_for<4>([&](auto K) { convert(hb ^ 1, m_cvt, K, ic<0>{}); load_piece(b2, m_ld, K); });
             NM_PRODUCER_WAIT(4);                                    // the weight loads (older than the 4 new piece loads)
-            store_b_group(2);
+            store_b_group(2, ic<0>{});
             NM_PSTAMP(2);
             lds_barrier();
             NM_PSTAMP(3);
             // tap group 1: weights of the next step's group 0; pieces 4-9; the halo tile is complete at this barrier
-            load_b_group(s1.w.cg, s1.cb, 0);
-            static_for<6>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 4>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 4>{}); });
-            load_affine(s2.w, s2.cb);                               // (sc / sh are free: piece 9 was their last user)
+            load_b_group(s1.w.cg, s1.cb, 0, ic<0>{});
+            static_for<6>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 4>{}, ic<0>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 4>{}); });
+            load_affine(s2.w, s2.cb, ic<0>{});                               // (sc / sh are free: piece 9 was their last user)
             NM_PSTAMP(4);
             NM_PRODUCER_WAIT(8);                                    // the weight loads: 6 piece + 2 affine loads are younger
-            store_b_group(0);
+            store_b_group(0, ic<0>{});
             NM_PSTAMP(5);
             lds_barrier();
             NM_PSTAMP(6);
             // tap group 2: weights of the next step's group 1
-            load_b_group(s1.w.cg, s1.cb, 1);
+            load_b_group(s1.w.cg, s1.cb, 1, ic<0>{});
             NM_PRODUCER_WAIT(0);                                    // (everything: the input loads are a group or more old)
-            store_b_group(1);
+            store_b_group(1, ic<0>{});
             NM_PSTAMP(7);
             lds_barrier();
             NM_PSTAMP(8);
@@ -1937,6 +2009,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
 #ifdef NM_DIAG
             ++step_no;
 #endif
+        }
         }
         NM_PRODUCER_WAIT(0);                                        // loads still in flight for a step that does not exist
         lds_barrier();                                              // the two barriers of the MFMA waves' drain
@@ -2068,9 +2141,16 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;          // byte offsets of tap tt + 2 (taps 25, 26: of the
             constexpr int BO = (ug * GB + ut * 128) * 16;                           // next step's taps 0, 1)
             const unsigned vau = (u < 27) ? va : van;
+            constexpr bool aread = !LATE_M || u < 27;               // LATE: the next tile is complete only at the step's last barrier
 #define NM_WAIT_OPERANDS(x, y) asm volatile("" : "+v"(x), "+v"(y))
             // one wait per tap: this tap's six operands were issued during tap tt - 2; the six reads of tap tt - 1 are the only
             // younger LDS operations (anything else in the gaps only makes the wait stricter)
+            // (LATE: tap 25 requests only the two B operands of the next step's tap 0 - its A operands wait for the step's last barrier -
+            //  so at tap 26 the reads of tap 24 are covered by "all but the 2 youngest")
+            if constexpr (LATE_M && tt == 26)
+                asm volatile("s_waitcnt lgkmcnt(2)"
+                             : "+v"(ah0[i]), "+v"(al0[i]), "+v"(ah1[i]), "+v"(al1[i]), "+v"(bhv[i]), "+v"(blv[i]) :: "memory");
+            else
             asm volatile("s_waitcnt lgkmcnt(6)"
                          : "+v"(ah0[i]), "+v"(al0[i]), "+v"(ah1[i]), "+v"(al1[i]), "+v"(bhv[i]), "+v"(blv[i]) :: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -2083,7 +2163,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             NM_WAIT_OPERANDS(ah0[i], blv[i]);
             if constexpr (tt == 0 && with_epi) accl[0] = nm_mfma_lo<SINGLE>(blv[i], ah0[i], zero16);
             else accl[0] = nm_mfma_lo<SINGLE>(blv[i], ah0[i], accl[0]);
-            ah0[j] = lds_read16_untracked<AO>(vau);
+            if constexpr (aread) ah0[j] = lds_read16_untracked<AO>(vau);
             gap(ic<1>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(ah1[i], bhv[i]);
@@ -2095,17 +2175,17 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
             NM_WAIT_OPERANDS(ah1[i], blv[i]);
             if constexpr (tt == 0 && with_epi) accl[1] = nm_mfma_lo<SINGLE>(blv[i], ah1[i], zero16);
             else accl[1] = nm_mfma_lo<SINGLE>(blv[i], ah1[i], accl[1]);
-            ah1[j] = lds_read16_untracked<AO + YO>(vau);
+            if constexpr (aread) ah1[j] = lds_read16_untracked<AO + YO>(vau);
             gap(ic<3>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(al0[i], bhv[i]);
             accl[0] = nm_mfma_lo<SINGLE>(bhv[i], al0[i], accl[0]);
-            al0[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO>(vau);
+            if constexpr (aread) al0[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO>(vau);
             gap(ic<4>{});
             __builtin_amdgcn_sched_barrier(0);
             NM_WAIT_OPERANDS(al1[i], bhv[i]);
             accl[1] = nm_mfma_lo<SINGLE>(bhv[i], al1[i], accl[1]);
-            al1[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO + YO>(vau);
+            if constexpr (aread) al1[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO + YO>(vau);
             gap(ic<5>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (t == 8) {
@@ -2117,6 +2197,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
                 NM_PSTAMP(2 + 2 * (tt / 9));
             }
         });
+        if constexpr (LATE_M) {                                     // the next step's tile is complete since the barrier of tap 26
+            ah0[0] = lds_read16_untracked<0>(van); al0[0] = SINGLE ? half8{} : lds_read16_untracked<LO>(van);
+            ah1[0] = lds_read16_untracked<YO>(van); al1[0] = SINGLE ? half8{} : lds_read16_untracked<LO + YO>(van);
+            ah0[1] = lds_read16_untracked<16>(van); al0[1] = SINGLE ? half8{} : lds_read16_untracked<LO + 16>(van);
+            ah1[1] = lds_read16_untracked<YO + 16>(van); al1[1] = SINGLE ? half8{} : lds_read16_untracked<LO + YO + 16>(van);
+        }
         // the operands of the next step's taps 0, 1 were read one / two gaps ago; the two copies of the stream may keep them in
         // different registers, so they must have landed before the compiler moves them
         asm volatile("s_waitcnt lgkmcnt(0)"
@@ -3384,12 +3470,12 @@ int launch_pool_f16s(const ConvParams& p, dim3 grid, hipStream_t s) {
 
 int g_num_cus = 0;
 
-template <bool UP2, bool SINGLE, int IO = 0>
+template <bool UP2, bool SINGLE, int IO = 0, int LATE = 1>
 int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
     ConvParams p = p_in;
     static NmDeviceOnce attr_set;
     if (!attr_set.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2, SINGLE, IO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p_kernel<UP2, SINGLE, IO, LATE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p)");
         attr_set.mark();
@@ -3409,7 +3495,7 @@ int launch_f16p_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, h
     // persistent: one workgroup per CU (NM355_CONV_WGS caps the count: the co-residency A/B of DESIGN 5 - CUs left to the other queues)
     dim3 grid((unsigned)min(work_items, nm_ls().conv_wgs > 0 ? min(nm_ls().conv_wgs, g_num_cus) : g_num_cus));
     if (p.Cout == 32) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
-    hipLaunchKernelGGL((conv_f16p_kernel<UP2, SINGLE, IO>), grid, dim3(512), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16p_kernel<UP2, SINGLE, IO, LATE>), grid, dim3(512), lds_bytes, s, p);
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p launch");
 }
@@ -3420,6 +3506,9 @@ int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream
         if (io != 3 || !nm_ls().single) return io16_unsupported("conv_f16p", p);
         return launch_f16p_impl<UP2, true, 3>(p, lds_bytes, work_items, s);
     }
+    if (nm_ls().f16p_late == 2) return launch_f16p_impl<UP2, false, 0, 2>(p, lds_bytes, work_items, s);
+    if (!nm_ls().f16p_late)      // (A/B: the round-2 producer schedule)
+        return nm_ls().single ? launch_f16p_impl<UP2, true, 0, 0>(p, lds_bytes, work_items, s) : launch_f16p_impl<UP2, false, 0, 0>(p, lds_bytes, work_items, s);
     return nm_ls().single ? launch_f16p_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p_impl<UP2, false>(p, lds_bytes, work_items, s);
 }
 
