@@ -467,6 +467,26 @@ __device__ __forceinline__ float dpp_sum32(float x) {
     x = dpp_add<0xB1, 0xf>(x); x = dpp_add<0x4E, 0xf>(x); x = dpp_add<0x141, 0xf>(x); x = dpp_add<0x140, 0xf>(x);
     return dpp_add<0x142, 0xa>(x);
 }
+// dpp_sum32 of N values, stage by stage: a DPP add reads the register the previous VALU instruction wrote two wait states late, and a
+// chain per value (5 dependent adds) was issued value after value - in-kernel stamps of conv_f16p2's brick epilogue: 2 764 cycles for
+// 32 sums, 17 per add.  Same instructions, same order per value (bit-identical), N independent adds between dependent ones.
+template <int N> __device__ __forceinline__ void dpp_sum32_many(float (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = dpp_add<0xB1, 0xf>(x[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = dpp_add<0x4E, 0xf>(x[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = dpp_add<0x141, 0xf>(x[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = dpp_add<0x140, 0xf>(x[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = dpp_add<0x142, 0xa>(x[i]);
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // flags[n][brick] = 1 when the 4 x 8 x 8 brick holds an occupied voxel.  One workgroup per (frame, slab of four z-planes): the slab is
 // read once, coalesced (the first-layer kernel tests a brick's 8 x 12 x 12 halo with five scattered loads per thread - and 85 % of its
@@ -2241,8 +2261,28 @@ __global__ __launch_bounds__(512, 1) void conv_f16p_kernel(ConvParams p) {
 //     the barrier that publishes them; operands one tap (12 MFMAs) ahead, double buffered.
 //   LDS: halo [2][hi h0 | hi h1 | lo h0 | lo h1][600] x 16 B, weights [2][9 taps][4 planes][64] x 16 B, GroupNorm scratch, bias.
 // IO: bit 0 = bfloat16 input (a producer piece is then an 8-byte load of the same four channels), bit 1 = bfloat16 output
-template <bool UP2, bool SINGLE = false, int IO = 0>
+// WEMU (diagnostic build only, tools/diag_winograd_emu.py; WRONG RESULTS): the resource profile of a 1-D Winograd F(2,3) form of this
+// kernel along z - the one fast-convolution form whose accumulators (4 positions x 32 tile rows x 64 channels = 128 registers in the
+// single-accumulator form) and transformed tile (8 planes for 6) fit this machine mapping - without its arithmetic: bit 0 = a step is
+// 4 position groups x 9 (ky, kx) taps x 6 MFMAs (216 for 324), one A tile and the four B reads per tap, FOUR weight groups and four
+// barriers per step; bit 1 = the producers also convert 13 pieces for 10 (8 transformed planes for 6 raw ones; the extra loads and the
+// transform's adds are left out).  An upper bound of what such a kernel could reach, DESIGN 4 "Why there is no Winograd kernel".
+// DEFER (round 6; NM355_P2_DEFER=1, NOT the default - built, correct, slower): in-kernel stamps (tools/diag_f16p2_steps.py) put the
+// exposed epilogue at 7 800 of a 64-channel brick's 58 000 cycles (24 % at Cin = 32) - 128 values per lane to combine, store, square,
+// sum over 32 lanes (320 DPP adds) and park, all on the vector ALU with the matrix pipe idle.  With ONE accumulator per tile
+// (conv_up2c_x16's identity x w 2^11 = x_hi (2^11 w_hi) + x_hi w_lo' + x_lo' w_hi, w_hi scaled in place behind its unscaled uses) the
+// accumulators are 64 registers, the finished brick's outputs move to 64 others (one v_pk_fma per pair with the bias, exposed: ~700
+// cycles) and conv_f16p's gap-interleaved epilogue runs inside the NEXT brick's first step (second copy of the tap stream, zero C operand
+// for its first MFMAs, no extra barrier per brick).  Same results as the two-accumulator form to the op tests' 2e-5.  Measured
+// (profiles/r06_p2_defer_ab.txt): 64 -> 64 @32^3 1.31-1.33 -> 1.36-1.43 ms, 128 -> 128 @16^3 0.63 -> 0.68: the interleaved pieces are only 40 %
+// hidden (the first step of a brick grows by 4 650 cycles for 7 400 saved: the MFMA wave issues in order, its stores and DPP adds
+// share the SIMD's issue with a producer wave), the single-accumulator stream itself is 1-2 % slower per tap group, and at 256
+// registers the brick decode's hoisted division constants spill (a scratch reload per step).  What would be left after moving the
+// decode to the producers (an LDS ring of brick origins): <= 5 % of this kernel.  The exposed epilogue got the cheap part instead:
+// its arithmetic on value pairs (v_pk_*), 8 900 -> 8 160 stamped cycles.
+template <bool UP2, bool SINGLE = false, int IO = 0, int WEMU = 0, bool DEFER = false>
 __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
+    static_assert(!DEFER || (!SINGLE && WEMU == 0), "the deferred epilogue exists for the three-product form");
     constexpr bool IH = (IO & 1) != 0, OH = (IO & 2) != 0;
     constexpr unsigned EB = IH ? 2u : 4u;                           // bytes per input element
     constexpr int HV = 600, ZP = 100, HX = 10;
@@ -2293,6 +2333,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
         return true;
     };
 
+#ifdef NM_DIAG
+    int step_no = 0;                                                // (NM_PSTAMP: tools/diag_f16p2_steps.py)
+#endif
     if (wave >= 4) {
         // =========================== producer waves ===========================================================
         const int pt = tid - 256, pw = wave - 4;
@@ -2436,26 +2479,52 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             // therefore complete at the step's LAST barrier, and the MFMA waves fetch a step's first operands after that barrier.
             // tap group 0: weights of this step's group 1 (into the buffer group 2 of the last step was read from); pieces 0-2.
             // Everything older than the 9 weight loads has landed after the first wait.
+            NM_PSTAMP(0);
             load_b_group(cur.w.cg, cur.cb, 1, gpar ^ 1);
             if constexpr (SINGLE) { NM_PRODUCER2_WAIT(5); } else { NM_PRODUCER2_WAIT(9); }      // (NW weight loads are the youngest)
-            static_for<3>([&](auto K) { convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
+            NM_PSTAMP(1);
+            static_for<3>([&](auto K) { convert(hb ^ 1, m_cvt, K); if constexpr ((WEMU & 2) != 0 && decltype(K)::value == 0) convert(hb ^ 1, m_cvt, K); load_piece(b2, m_ld, K); });
             NM_PRODUCER2_WAIT(3);                                   // the weight loads (older than the 3 new piece loads)
             store_b_group(gpar ^ 1);
+            NM_PSTAMP(2);
             lds_barrier(); gpar ^= 1;
+            NM_PSTAMP(3);
             // tap group 1: weights of this step's group 2; pieces 3-7
             load_b_group(cur.w.cg, cur.cb, 2, gpar ^ 1);
+            if constexpr (WEMU != 0) {                              // (emulation: pieces 3-5 here, 6-7 behind a fourth weight group)
+                static_for<3>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 3>{}); if constexpr ((WEMU & 2) != 0 && decltype(K)::value == 0) convert(hb ^ 1, m_cvt, ic<3>{});
+                                            load_piece(b2, m_ld, ic<decltype(K)::value + 3>{}); });
+                NM_PRODUCER2_WAIT(3);
+                store_b_group(gpar ^ 1);
+                lds_barrier(); gpar ^= 1;
+                load_b_group(cur.w.cg, cur.cb, 1, gpar ^ 1);
+                static_for<2>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 6>{}); if constexpr ((WEMU & 2) != 0 && decltype(K)::value == 0) convert(hb ^ 1, m_cvt, ic<6>{});
+                                            load_piece(b2, m_ld, ic<decltype(K)::value + 6>{}); });
+                NM_PRODUCER2_WAIT(2);
+                store_b_group(gpar ^ 1);
+                lds_barrier(); gpar ^= 1;
+            } else {
             static_for<5>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 3>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 3>{}); });
+            NM_PSTAMP(4);
             NM_PRODUCER2_WAIT(5);                                   // the weight loads: 5 piece loads are younger
             store_b_group(gpar ^ 1);
+            NM_PSTAMP(5);
             lds_barrier(); gpar ^= 1;
+            NM_PSTAMP(6);
+            }
             // tap group 2: weights of the next step's group 0; pieces 8-9; the halo tile is complete at this barrier
             load_b_group(s1.w.cg, s1.cb, 0, gpar ^ 1);
             static_for<2>([&](auto K) { convert(hb ^ 1, m_cvt, ic<decltype(K)::value + 8>{}); load_piece(b2, m_ld, ic<decltype(K)::value + 8>{}); });
             load_affine(s2.w, s2.cb);                               // (sc / sh are free: piece 9 was their last user)
             NM_PRODUCER2_WAIT(0);
             store_b_group(gpar ^ 1);
+            NM_PSTAMP(7);
             lds_barrier(); gpar ^= 1;
-            if (cur.cb == C16 - 1) lds_barrier();                   // the MFMA waves' epilogue barrier of a finished brick
+            NM_PSTAMP(8);
+#ifdef NM_DIAG
+            ++step_no;
+#endif
+            if constexpr (!DEFER) { if (cur.cb == C16 - 1) lds_barrier(); }      // the MFMA waves' epilogue barrier of a finished brick
             if (!has1) break;
             cur = s1; s1 = s2; has1 = has2; has2 = has2 && advance(s2);
             m_cvt = m_ld; hb ^= 1;
@@ -2473,6 +2542,181 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
         arow0 = z * ZP + (2 * wave) * HX + x;
     }
     const int vx = ((((0x96 >> (l31 >> 2)) & 1) << 2) + (l31 & 3)), vz = l31 >> 3;
+    if constexpr (DEFER) {
+        // ---- one accumulator per tile, the finished brick's epilogue inside the next brick's first step ----------------------------
+        constexpr int LO = 2 * HV * 16, YO = HX * 16;
+        f32x16 acc[2][2], outv[2][2];                               // outv: the pending brick's outputs, then its partial sums in place
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[mt][nt][r] = 0.f; outv[mt][nt][r] = 0.f; }
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        size_t esb = 0;                                             // pending brick: element index of (its first voxel, cout group) - wave-uniform
+        const unsigned lane_off = (unsigned)(((vz * p.OH + 2 * wave) * p.OW + vx) * p.Cout + 4 * h);   // this lane's voxel and channel quad inside a brick
+        size_t epart = 0, ppart = 0;                      // pending brick: its outputs' place / its partial sums' place; ppart: of the sums red[] holds
+                                            // element index of (pending brick, this lane's voxel, mt = 0, nt = 0, k4 = 0)
+        const size_t erow = (size_t)p.OW * p.Cout;                  // mt = 0 -> 1
+        auto epi_store = [&](auto E) {                              // store e = (2 nt + mt) * 4 + k4 of the 16 per lane
+            constexpr int e = decltype(E)::value, nt = e >> 3, mt = (e >> 2) & 1, k4 = e & 3;
+            unsigned lo = lane_off;
+            asm volatile("" : "+v"(lo));                            // (the 16 addresses are loop invariants: hoisted, they are spilled and reloaded in the gaps)
+            nm_st4<OH>(p.out, esb + (mt ? erow : (size_t)0) + (size_t)(lo + (unsigned)(nt * 32 + 8 * k4)),
+                       f32x4{outv[mt][nt][4 * k4], outv[mt][nt][4 * k4 + 1], outv[mt][nt][4 * k4 + 2], outv[mt][nt][4 * k4 + 3]});
+        };
+        auto epi_sum_local = [&](auto R) {                          // pair R of tile column nt: sums / sums of squares over the two row tiles, in place
+            constexpr int nt = decltype(R)::value >> 3, r = 2 * (decltype(R)::value & 7);
+            const f32x2 a = f32x2{outv[0][nt][r], outv[0][nt][r + 1]}, b = f32x2{outv[1][nt][r], outv[1][nt][r + 1]};
+            const f32x2 s = a + b, q = a * a + b * b;
+            outv[0][nt][r] = s[0]; outv[0][nt][r + 1] = s[1]; outv[1][nt][r] = q[0]; outv[1][nt][r + 1] = q[1];
+        };
+        auto epi_sum_lanes = [&](auto I) {                          // DPP step (i >> 6) of value (i & 63) = 32 m + 16 nt + r
+            constexpr int i = decltype(I)::value, st = i >> 6, v = i & 63, m = v >> 5, nt = (v >> 4) & 1, r = v & 15;
+            constexpr int ctrl = st == 0 ? 0xB1 : st == 1 ? 0x4E : st == 2 ? 0x141 : st == 3 ? 0x140 : 0x142;
+            constexpr int rows = st == 4 ? 0xa : 0xf;
+            const float x = outv[m][nt][r];
+            outv[m][nt][r] = x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rows, 0xf, true));
+        };
+        auto epi_red = [&](auto R) {                                // lanes 16 / 48 park (sum, sum of squares) of channel c(nt, r, h)
+            constexpr int nt = decltype(R)::value >> 4, r = decltype(R)::value & 15;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                            // (addresses made here: as loop invariants they are hoisted, and then spilled)
+            if (p.part && (ln & 31) == 16) *reinterpret_cast<f32x2*>(red + (wave * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5)) * 2) = f32x2{outv[0][nt][r], outv[1][nt][r]};
+        };
+        auto epi_part = [&]() {                                     // behind a barrier: 64 threads sum the four wave partials
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            if (p.part && tq < 64) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a += red[(q * 64 + tq) * 2]; b += red[(q * 64 + tq) * 2 + 1]; }
+                float* dp = p.part + ppart + tq * 2;
+                dp[0] = a; dp[1] = b;
+            }
+        };
+        auto epi_take = [&](const Work& w) {                        // outputs of the brick just accumulated (exposed: 64 packed FMAs)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const float* lb = lbias + w.cg * 64 + 4 * (ln >> 5);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(lb + nt * 32 + 8 * k4);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            const f32x2 a2 = f32x2{acc[mt][nt][4 * k4 + e], acc[mt][nt][4 * k4 + e + 1]};
+                            const f32x2 v2 = __builtin_elementwise_fma(a2, f32x2{1.0f / NM_SPLIT_SCALE, 1.0f / NM_SPLIT_SCALE}, f32x2{b4[e], b4[e + 1]});
+                            outv[mt][nt][4 * k4 + e] = v2[0]; outv[mt][nt][4 * k4 + e + 1] = v2[1];
+                        }
+                }
+            epart = (((size_t)w.n * nbr + ((w.oz0 >> 2) * nby + (w.oy0 >> 3)) * nbx + (w.ox0 >> 3)) * p.Cout + w.cg * 64) * 2;
+            esb = ((((size_t)w.n * p.OD + w.oz0) * p.OH + w.oy0) * p.OW + w.ox0) * (size_t)p.Cout + w.cg * 64;
+        };
+
+        Step cur; cur.w = decode(id_first); cur.id = id_first; cur.cb = 0;
+        int hb = 0, gpar = 0;
+        lds_barrier();                                              // the producers' prologue
+        const unsigned vb0 = (unsigned)(size_t)(ldb + h * 64 + l31);
+        half8 ah0[2], al0[2], ah1[2], al1[2], bh0[2], bh1[2], bl0[2], bl1[2];
+        {
+            const unsigned va = (unsigned)(size_t)(ldh + h * HV + arow0);
+            ah0[0] = lds_read16_untracked<0>(va); al0[0] = lds_read16_untracked<LO>(va);
+            ah1[0] = lds_read16_untracked<YO>(va); al1[0] = lds_read16_untracked<LO + YO>(va);
+        }
+        bool pending = false, part_due = false;
+        for (;;) {
+            Step nxt = cur;
+            const bool has_next = advance(nxt);
+            if (part_due) { epi_part(); part_due = false; }
+            const bool run_epi = pending;
+            const unsigned va = (unsigned)(size_t)(ldh + hb * 4 * HV + h * HV + arow0);
+            const unsigned van = (unsigned)(size_t)(ldh + (hb ^ 1) * 4 * HV + h * HV + arow0);
+            const unsigned vbe = vb0 + (unsigned)(gpar * GB * 16), vbo = vb0 + (unsigned)((gpar ^ 1) * GB * 16);
+            NM_PSTAMP(0);
+            auto stream = [&](auto EPI) {
+                constexpr bool with_epi = decltype(EPI)::value;
+                static_for<27>([&](auto TT) {
+                    constexpr int tt = decltype(TT)::value, g = tt / 9, t = tt % 9, i = tt & 1, j = i ^ 1;
+                    const unsigned vb = (g & 1) ? vbo : vbe;
+                    constexpr int BT = t * 256 * 16;
+                    if constexpr (t == 0) {
+                        bh0[i] = lds_read16_untracked<BT>(vb); bh1[i] = lds_read16_untracked<BT + 32 * 16>(vb);
+                        bl0[i] = lds_read16_untracked<BT + 128 * 16>(vb); bl1[i] = lds_read16_untracked<BT + 160 * 16>(vb);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(ah0[i]), "+v"(al0[i]), "+v"(ah1[i]), "+v"(al1[i]), "+v"(bh0[i]), "+v"(bh1[i]), "+v"(bl0[i]), "+v"(bl1[i]) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    constexpr int u = tt + 1, ug = (u < 27) ? u / 9 : 0, ut = (u < 27) ? u % 9 : 0;
+                    constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;
+                    constexpr bool anext = u < 27, bnext = t < 8;
+                    constexpr int BN = (t + 1) * 256 * 16;
+                    constexpr bool z = with_epi && tt == 0;         // a new brick: C = 0 instead of cleared accumulators
+                    auto gap = [&](auto SUB) {
+                        constexpr int q = tt * 12 + decltype(SUB)::value;
+                        if constexpr (with_epi) {
+                            if constexpr (q >= 4 && q < 36 && (q & 1) == 0) epi_store(ic<((q - 4) >> 1) & 15>{});
+                            if constexpr (q >= 36 && q < 52) epi_sum_local(ic<(q - 36) & 15>{});
+                            if constexpr (q >= 52 && q < 212) { epi_sum_lanes(ic<(2 * (q - 52)) % 320>{}); epi_sum_lanes(ic<(2 * (q - 52) + 1) % 320>{}); }
+                            if constexpr (q >= 214 && q < 246) epi_red(ic<(q - 214) & 31>{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+#define NM_MFMA3(ACC, B, A, Z) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(B, A, (Z) ? zero16 : ACC, 0, 0, 0); __builtin_amdgcn_sched_barrier(0)
+                    // the cross products first: 2^11 w_hi of this tap is made in their gaps
+                    // the products with the unscaled w_hi first; it becomes 2^11 w_hi IN PLACE behind them (exact for |w| < 32; larger
+                    // weights overflow into the range guard like any fp16 overflow), in the gaps of the cross products
+                    NM_MFMA3(acc[0][0], bh0[i], al0[i], z); if constexpr (anext) ah0[j] = lds_read16_untracked<AO>(va); gap(ic<0>{});
+                    NM_MFMA3(acc[0][1], bh1[i], al0[i], z); if constexpr (anext) al0[j] = lds_read16_untracked<AO + LO>(va); gap(ic<1>{});
+                    NM_MFMA3(acc[1][0], bh0[i], al1[i], z); if constexpr (anext) ah1[j] = lds_read16_untracked<AO + YO>(va); gap(ic<2>{});
+                    NM_MFMA3(acc[1][1], bh1[i], al1[i], z); if constexpr (anext) al1[j] = lds_read16_untracked<AO + LO + YO>(va); gap(ic<3>{});
+                    NM_MFMA3(acc[0][0], bl0[i], ah0[i], false); if constexpr (bnext) bh0[j] = lds_read16_untracked<BN>(vb); gap(ic<4>{});
+                    NM_MFMA3(acc[0][1], bl1[i], ah0[i], false); if constexpr (bnext) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb); gap(ic<5>{});
+                    NM_MFMA3(acc[1][0], bl0[i], ah1[i], false); if constexpr (bnext) bl0[j] = lds_read16_untracked<BN + 128 * 16>(vb); bh0[i] = bh0[i] * (_Float16)NM_SPLIT_SCALE; gap(ic<6>{});
+                    NM_MFMA3(acc[1][1], bl1[i], ah1[i], false); if constexpr (bnext) bl1[j] = lds_read16_untracked<BN + 160 * 16>(vb); bh1[i] = bh1[i] * (_Float16)NM_SPLIT_SCALE; gap(ic<7>{});
+                    NM_MFMA3(acc[0][0], bh0[i], ah0[i], false); gap(ic<8>{});
+                    NM_MFMA3(acc[0][1], bh1[i], ah0[i], false); gap(ic<9>{});
+                    NM_MFMA3(acc[1][0], bh0[i], ah1[i], false); gap(ic<10>{});
+                    NM_MFMA3(acc[1][1], bh1[i], ah1[i], false); gap(ic<11>{});
+                    if constexpr (t == 8) {
+                        NM_PSTAMP(1 + 2 * g);
+                        asm volatile("s_barrier" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        NM_PSTAMP(2 + 2 * g);
+                    }
+                });
+            };
+            if (run_epi) stream(std::true_type{}); else stream(std::false_type{});
+            gpar ^= 1;
+            if (run_epi) { pending = false; part_due = true; ppart = epart; }
+            if (cur.cb == C16 - 1) { NM_PSTAMP(8); epi_take(cur.w); pending = true; NM_PSTAMP(13); }
+            // the next step's tile is complete since the barrier that ended tap group 2: its first tap's A operands (slot 0)
+            if (has_next) {
+                ah0[0] = lds_read16_untracked<0>(van); al0[0] = lds_read16_untracked<LO>(van);
+                ah1[0] = lds_read16_untracked<YO>(van); al1[0] = lds_read16_untracked<LO + YO>(van);
+            }
+            NM_PSTAMP(7);
+#ifdef NM_DIAG
+            ++step_no;
+#endif
+            if (!has_next) break;
+            cur = nxt; hb ^= 1;
+        }
+        // ---- drain: the last brick's epilogue in the open (the producers have left)
+        if (part_due) epi_part();
+        lds_barrier();
+        static_for<16>([&](auto E) { epi_store(E); });
+        static_for<16>([&](auto R) { epi_sum_local(R); });
+        static_for<320>([&](auto I) { epi_sum_lanes(I); });
+        static_for<32>([&](auto R) { epi_red(R); });
+        lds_barrier();
+        ppart = epart;
+        epi_part();
+        return;
+    }
     f32x16 acc[2][2], accl[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -2500,7 +2744,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
         const unsigned va = (unsigned)(size_t)(ldh + hb * 4 * HV + h * HV + arow0);          // this step's halo tile
         const unsigned van = (unsigned)(size_t)(ldh + (hb ^ 1) * 4 * HV + h * HV + arow0);   // the next step's
         const unsigned vbe = vb0 + (unsigned)(gpar * GB * 16), vbo = vb0 + (unsigned)((gpar ^ 1) * GB * 16);   // buffers of groups 0/2 and 1
-        static_for<27>([&](auto TT) {
+        NM_PSTAMP(0);
+        constexpr int NTAP = WEMU != 0 ? 36 : 27;
+        static_for<NTAP>([&](auto TT) {
             constexpr int tt = decltype(TT)::value, g = tt / 9, t = tt % 9, i = tt & 1, j = i ^ 1;
             const unsigned vb = (g & 1) ? vbo : vbe;
             constexpr int BT = t * 256 * 16;                        // byte offset of this tap in its weight buffer
@@ -2512,9 +2758,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(ah0[i]), "+v"(al0[i]), "+v"(ah1[i]), "+v"(al1[i]), "+v"(bh0[i]), "+v"(bh1[i]), "+v"(bl0[i]), "+v"(bl1[i]) :: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int u = tt + 1, ug = (u < 27) ? u / 9 : 0, ut = (u < 27) ? u % 9 : 0;
+            constexpr int u = tt + 1, ug = (u < NTAP) ? (u / 9) % 3 : 0, ut = (u < NTAP) ? u % 9 : 0;
             constexpr int AO = (ug * ZP + (ut / 3) * HX + (ut % 3)) * 16;           // A byte offset of tap tt + 1
-            constexpr bool anext = u < 27;                          // (tap 26 requests nothing: the next tile is complete only at the step's last barrier)
+            constexpr bool anext = u < NTAP;                        // (tap 26 requests nothing: the next tile is complete only at the step's last barrier)
+            constexpr bool a1 = WEMU == 0;                          // (emulation: one A tile per tap)
             const unsigned vau = va;
             constexpr bool bnext = t < 8;                           // the next tap's weights are in this group's buffer
             constexpr int BN = (t + 1) * 256 * 16;
@@ -2522,23 +2769,27 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
 #define NM_MFMA2L(ACC, B, A) ACC = nm_mfma_lo<SINGLE>(B, A, ACC); __builtin_amdgcn_sched_barrier(0)
             NM_MFMA2(acc[0][0], bh0[i], ah0[i]);  if constexpr (anext) ah0[j] = lds_read16_untracked<AO>(vau);
             NM_MFMA2(acc[0][1], bh1[i], ah0[i]);  if constexpr (anext) al0[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO>(vau);
-            NM_MFMA2L(accl[0][0], bl0[i], ah0[i]); if constexpr (anext) ah1[j] = lds_read16_untracked<AO + YO>(vau);
-            NM_MFMA2L(accl[0][1], bl1[i], ah0[i]); if constexpr (anext) al1[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO + YO>(vau);
-            NM_MFMA2L(accl[0][0], bh0[i], al0[i]); if constexpr (bnext) bh0[j] = lds_read16_untracked<BN>(vb);
-            NM_MFMA2L(accl[0][1], bh1[i], al0[i]); if constexpr (bnext) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb);
+            NM_MFMA2L(accl[0][0], bl0[i], ah0[i]); if constexpr (anext && a1) ah1[j] = lds_read16_untracked<AO + YO>(vau); else if constexpr (bnext && !a1) bh0[j] = lds_read16_untracked<BN>(vb);
+            NM_MFMA2L(accl[0][1], bl1[i], ah0[i]); if constexpr (anext && a1) al1[j] = SINGLE ? half8{} : lds_read16_untracked<AO + LO + YO>(vau); else if constexpr (bnext && !a1) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb);
+            NM_MFMA2L(accl[0][0], bh0[i], al0[i]); if constexpr (bnext && a1) bh0[j] = lds_read16_untracked<BN>(vb); else if constexpr (bnext && !a1) bl0[j] = SINGLE ? half8{} : lds_read16_untracked<BN + 128 * 16>(vb);
+            NM_MFMA2L(accl[0][1], bh1[i], al0[i]); if constexpr (bnext && a1) bh1[j] = lds_read16_untracked<BN + 32 * 16>(vb); else if constexpr (bnext && !a1) bl1[j] = SINGLE ? half8{} : lds_read16_untracked<BN + 160 * 16>(vb);
+            if constexpr (a1) {
             NM_MFMA2(acc[1][0], bh0[i], ah1[i]);  if constexpr (bnext) bl0[j] = SINGLE ? half8{} : lds_read16_untracked<BN + 128 * 16>(vb);
             NM_MFMA2(acc[1][1], bh1[i], ah1[i]);  if constexpr (bnext) bl1[j] = SINGLE ? half8{} : lds_read16_untracked<BN + 160 * 16>(vb);
             NM_MFMA2L(accl[1][0], bl0[i], ah1[i]);
             NM_MFMA2L(accl[1][1], bl1[i], ah1[i]);
             NM_MFMA2L(accl[1][0], bh0[i], al1[i]);
             NM_MFMA2L(accl[1][1], bh1[i], al1[i]);
+            }
             if constexpr (t == 8) {
                 // tap-group end: the producers publish the next group's weights (and, at the second barrier, the next tile)
+                NM_PSTAMP(1 + 2 * (g % 3));
                 asm volatile("s_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                NM_PSTAMP(2 + 2 * (g % 3));
             }
         });
-        gpar ^= 1;                                                  // three groups per step
+        if constexpr (WEMU == 0) gpar ^= 1;                         // three groups per step
         // the next step's tile is complete since the barrier that ended tap group 2: request its first tap's A operands now (slot 0;
         // the step's first wait covers them)
         if (has_next) {
@@ -2548,11 +2799,13 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
         if (cur.cb == C16 - 1) {
             // ---- epilogue of the finished brick (exposed): transposed accumulators -> 16-byte stores, DPP partial sums
             const Work& w = cur.w;
+            NM_PSTAMP(8);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
+                // (round 6: the epilogue's arithmetic on value PAIRS - v_pk_mul_f32 / v_pk_add_f32 - the same operations per value in
+                // the same order at half the vector instructions; the exposed epilogue is VALU-bound, in-kernel stamps: 7 800 of a
+                // 64-channel brick's 58 000 cycles)
                 float s1[16], s2[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const size_t dst = ((((size_t)w.n * p.OD + w.oz0 + vz) * p.OH + w.oy0 + 2 * wave + mt) * p.OW + w.ox0 + vx) * (size_t)p.Cout +
@@ -2562,23 +2815,36 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + w.cg * 64 + nt * 32 + 8 * k4 + 4 * h);
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = (acc[mt][nt][4 * k4 + e] + accl[mt][nt][4 * k4 + e] * (1.0f / NM_SPLIT_SCALE)) + b4[e];
-                            s1[4 * k4 + e] += v[e]; s2[4 * k4 + e] += v[e] * v[e];
-                            acc[mt][nt][4 * k4 + e] = 0.f; accl[mt][nt][4 * k4 + e] = 0.f;
+                        for (int e = 0; e < 4; e += 2) {
+                            const f32x2 a2 = f32x2{acc[mt][nt][4 * k4 + e], acc[mt][nt][4 * k4 + e + 1]};
+                            const f32x2 l2 = f32x2{accl[mt][nt][4 * k4 + e], accl[mt][nt][4 * k4 + e + 1]};
+                            const f32x2 v2 = (a2 + l2 * (1.0f / NM_SPLIT_SCALE)) + f32x2{b4[e], b4[e + 1]};
+                            const f32x2 q2 = v2 * v2;
+                            v[e] = v2[0]; v[e + 1] = v2[1];
+                            if (mt == 0) { s1[4 * k4 + e] = v2[0]; s1[4 * k4 + e + 1] = v2[1]; s2[4 * k4 + e] = q2[0]; s2[4 * k4 + e + 1] = q2[1]; }
+                            else {
+                                const f32x2 t1 = f32x2{s1[4 * k4 + e], s1[4 * k4 + e + 1]} + v2, t2 = f32x2{s2[4 * k4 + e], s2[4 * k4 + e + 1]} + q2;
+                                s1[4 * k4 + e] = t1[0]; s1[4 * k4 + e + 1] = t1[1]; s2[4 * k4 + e] = t2[0]; s2[4 * k4 + e + 1] = t2[1];
+                            }
+                            acc[mt][nt][4 * k4 + e] = 0.f; acc[mt][nt][4 * k4 + e + 1] = 0.f; accl[mt][nt][4 * k4 + e] = 0.f; accl[mt][nt][4 * k4 + e + 1] = 0.f;
                         }
                         nm_st4<OH>(p.out, dst + 8 * k4, v);
                     }
                 }
+                if (nt == 0) NM_PSTAMP(9); else NM_PSTAMP(11);
                 if (p.part) {
+                    dpp_sum32_many(s1); dpp_sum32_many(s2);
+                    if (l31 == 16) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float a = dpp_sum32(s1[r]), b = dpp_sum32(s2[r]);
-                        if (l31 == 16) *reinterpret_cast<f32x2*>(red + (wave * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2) = f32x2{a, b};
+                        for (int r = 0; r < 16; ++r)
+                            *reinterpret_cast<f32x2*>(red + (wave * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2) = f32x2{s1[r], s2[r]};
                     }
                 }
+                if (nt == 0) NM_PSTAMP(10);
             }
+            NM_PSTAMP(12);
             lds_barrier();                                          // (matched by the producers)
+            NM_PSTAMP(13);
             if (p.part && tid < 64) {
                 float a = 0.f, b = 0.f;
 #pragma unroll
@@ -2588,6 +2854,10 @@ __global__ __launch_bounds__(512, 1) void conv_f16p2_kernel(ConvParams p) {
                 dp[0] = a; dp[1] = b;
             }
         }
+        NM_PSTAMP(7);
+#ifdef NM_DIAG
+        ++step_no;
+#endif
         if (!has_next) break;
         cur = nxt; hb ^= 1;
     }
@@ -2910,9 +3180,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16q2_kernel(ConvParams p) {
             const Work& w = cur.w;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                float s1[16], s2[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+                float s1[16], s2[16];                               // (value pairs on v_pk_* as in conv_f16p2)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const size_t dst = ((((size_t)w.n * p.OD + w.oz0 + vz) * p.OH + w.oy0 + 2 * wave + mt) * p.OW + w.ox0 + vx) * (size_t)p.Cout +
@@ -2922,20 +3190,28 @@ __global__ __launch_bounds__(512, 1) void conv_f16q2_kernel(ConvParams p) {
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + w.cg * 64 + nt * 32 + 8 * k4 + 4 * h);
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = (acc[mt][nt][4 * k4 + e] + 0.f * (1.0f / NM_SPLIT_SCALE)) + b4[e];      // (conv_f16p2<SINGLE>'s expression: its correction accumulator is zero)
-                            s1[4 * k4 + e] += v[e]; s2[4 * k4 + e] += v[e] * v[e];
-                            acc[mt][nt][4 * k4 + e] = 0.f;
+                        for (int e = 0; e < 4; e += 2) {
+                            const f32x2 a2 = f32x2{acc[mt][nt][4 * k4 + e], acc[mt][nt][4 * k4 + e + 1]};
+                            const f32x2 v2 = (a2 + f32x2{0.f, 0.f} * (1.0f / NM_SPLIT_SCALE)) + f32x2{b4[e], b4[e + 1]};      // (conv_f16p2<SINGLE>'s expression: its correction accumulator is zero)
+                            const f32x2 q2 = v2 * v2;
+                            v[e] = v2[0]; v[e + 1] = v2[1];
+                            if (mt == 0) { s1[4 * k4 + e] = v2[0]; s1[4 * k4 + e + 1] = v2[1]; s2[4 * k4 + e] = q2[0]; s2[4 * k4 + e + 1] = q2[1]; }
+                            else {
+                                const f32x2 t1 = f32x2{s1[4 * k4 + e], s1[4 * k4 + e + 1]} + v2, t2 = f32x2{s2[4 * k4 + e], s2[4 * k4 + e + 1]} + q2;
+                                s1[4 * k4 + e] = t1[0]; s1[4 * k4 + e + 1] = t1[1]; s2[4 * k4 + e] = t2[0]; s2[4 * k4 + e + 1] = t2[1];
+                            }
+                            acc[mt][nt][4 * k4 + e] = 0.f; acc[mt][nt][4 * k4 + e + 1] = 0.f;
                         }
                         if constexpr (DBG != 3) nm_st4<OH>(p.out, dst + 8 * k4, v);
                         else if (v[0] == 12345.678f) nm_st4<OH>(p.out, dst + 8 * k4, v);
                     }
                 }
                 if (p.part) {
+                    dpp_sum32_many(s1); dpp_sum32_many(s2);
+                    if (l31 == 16) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float a = dpp_sum32(s1[r]), b = dpp_sum32(s2[r]);
-                        if (l31 == 16) *reinterpret_cast<f32x2*>(red + (wave * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2) = f32x2{a, b};
+                        for (int r = 0; r < 16; ++r)
+                            *reinterpret_cast<f32x2*>(red + (wave * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 2) = f32x2{s1[r], s2[r]};
                     }
                 }
             }
@@ -3512,12 +3788,19 @@ int launch_f16p(const ConvParams& p, size_t lds_bytes, int work_items, hipStream
     return nm_ls().single ? launch_f16p_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p_impl<UP2, false>(p, lds_bytes, work_items, s);
 }
 
-template <bool UP2, bool SINGLE, int IO = 0>
+template <bool UP2, bool SINGLE, int IO = 0, int WEMU = 0, bool DEFER = false>
 int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, hipStream_t s) {
     ConvParams p = p_in;
+#ifdef NM_Q2_DIAG
+    if constexpr (WEMU == 0 && !UP2 && !SINGLE && IO == 0) {       // diagnostic build: the Winograd resource-profile emulation (wrong results)
+        static const int wemu = getenv("NM355_P2_WEMU") ? atoi(getenv("NM355_P2_WEMU")) : 0;
+        if (wemu == 1) return launch_f16p2_impl<UP2, SINGLE, IO, 1>(p_in, lds_bytes, work_items, s);
+        if (wemu == 3) return launch_f16p2_impl<UP2, SINGLE, IO, 3>(p_in, lds_bytes, work_items, s);
+    }
+#endif
     static NmDeviceOnce attr_set;
     if (!attr_set.done()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p2_kernel<UP2, SINGLE, IO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16p2_kernel<UP2, SINGLE, IO, WEMU, DEFER>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return nm_check_hip(e, "hipFuncSetAttribute(conv_f16p2)");
         attr_set.mark();
@@ -3537,7 +3820,7 @@ int launch_f16p2_impl(const ConvParams& p_in, size_t lds_bytes, int work_items, 
     // persistent: one workgroup per CU (NM355_CONV_WGS caps the count: the co-residency A/B of DESIGN 5 - CUs left to the other queues)
     dim3 grid((unsigned)min(work_items, nm_ls().conv_wgs > 0 ? min(nm_ls().conv_wgs, g_num_cus) : g_num_cus));
     if (p.Cout == 64) choose_super_tile(p, (int)grid.x, p.OD / 4, p.OH / 8, p.OW / 8);   // (one cout group per brick)
-    hipLaunchKernelGGL((conv_f16p2_kernel<UP2, SINGLE, IO>), grid, dim3(512), lds_bytes, s, p);
+    hipLaunchKernelGGL((conv_f16p2_kernel<UP2, SINGLE, IO, WEMU, DEFER>), grid, dim3(512), lds_bytes, s, p);
     if (prof_rec) { (void)hipEventRecord(rec.b, s); nm_ls().prof.push_back(rec); }
     return nm_check_hip(hipGetLastError(), "conv_f16p2 launch");
 }
@@ -3623,7 +3906,9 @@ int launch_f16p2(const ConvParams& p, size_t lds_bytes, int work_items, hipStrea
         if (io != 3 || !nm_ls().single) return io16_unsupported("conv_f16p2", p);
         return launch_f16p2_impl<UP2, true, 3>(p, lds_bytes, work_items, s);
     }
-    return nm_ls().single ? launch_f16p2_impl<UP2, true>(p, lds_bytes, work_items, s) : launch_f16p2_impl<UP2, false>(p, lds_bytes, work_items, s);
+    if (nm_ls().single) return launch_f16p2_impl<UP2, true>(p, lds_bytes, work_items, s);
+    if (nm_ls().p2_defer) return launch_f16p2_impl<UP2, false, 0, 0, true>(p, lds_bytes, work_items, s);      // (A/B: the deferred epilogue, slower)
+    return launch_f16p2_impl<UP2, false>(p, lds_bytes, work_items, s);
 }
 
 #ifdef NM_DIAG

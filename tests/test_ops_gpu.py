@@ -138,6 +138,32 @@ def test_conv3d(ctx, case, mode):
         assert e < REL, f"fused GroupNorm rel err {e:.3e}"
 
 
+def test_conv3d_deferred_epilogue_variant_of_conv_f16p2():
+    """NM355_P2_DEFER=1: conv_f16p2 with ONE accumulator per tile and the finished brick's epilogue inside the next brick's first step
+    (built, measured slower, not the default - DESIGN 4 / profiles/r06_p2_defer_ab.txt): the 64-output-channel brick-aligned cases again
+    on a context created with the switch, same 2e-5 bounds for the raw output and the fused GroupNorm statistics."""
+    import os
+    from neural_marionette_amd import _lib
+    old = os.environ.get("NM355_P2_DEFER")
+    os.environ["NM355_P2_DEFER"] = "1"
+    try:
+        cfg = _lib.NmConfig(device=0, grid_size=64, nkeypoints=24, nlatent=128, nhidden=512, nneighbor=2,
+                            gaussian_sigma=1.5, sep_sigma=0.02, vol_fit_chamfer=1, use_graph_traj=1)
+        c = _lib.Context(cfg)
+        c.bind_stream()
+        try:
+            for case in [(32, 64, 3, 1, 1, 32, 3, True, 4), (64, 64, 3, 1, 1, 16, 1, True, 4), (32, 64, 3, 1, 1, 16, 2, False, 4),
+                         (16, 64, 3, 1, 1, 16, 3, True, 4), (128, 128, 3, 1, 1, 16, 2, True, 8)]:
+                test_conv3d(c, case, 1)
+        finally:
+            c.close()
+    finally:
+        if old is None:
+            os.environ.pop("NM355_P2_DEFER", None)
+        else:
+            os.environ["NM355_P2_DEFER"] = old
+
+
 @pytest.mark.parametrize("mode", [0, 1, 3], ids=["fp32mfma", "split16", "f16"])
 @pytest.mark.parametrize("Cin,Cout,size,prologue,N", [(128, 64, 8, False, 2), (64, 32, 12, True, 2), (16, 32, 5, True, 2),
                                                        (32, 32, 16, True, 5), (48, 32, 8, False, 40), (64, 64, 16, True, 3)])

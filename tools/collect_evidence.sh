@@ -53,6 +53,10 @@ python3 tools/pmc_mfma.py $(find $E/pmb -name "*.db" | head -1) $E/${R}_pmc_mfma
 bash tools/ab_mfma_shape.sh 7 > $E/${R}_mfma_shape_ab.txt 2>&1
 (hipcc -O3 -w --offload-arch=gfx950 tools/calib/hop_latency.hip -o /tmp/hop_latency && timeout 120 /tmp/hop_latency) > $E/${R}_hop_latency.txt 2>&1
 if [ -f neural_marionette_amd/libnm355_x4.so ]; then bash tools/ab_granule_loads.sh 2>&1 | grep -v amdgpu.ids > $E/${R}_granule_loads_ab.txt; fi
+# conv_f16p2's deferred epilogue (built, slower, opt-in) against the shipped exposed one; in-kernel stamps of both (libnm355_stamps.so: make stamps)
+{ bash tools/ab_p2_defer.sh; if [ -f neural_marionette_amd/libnm355_stamps.so ]; then for D in 0 1; do echo "in-kernel stamps, NM355_P2_DEFER=$D (tools/diag_f16p2_steps.py):"; NM355_P2_DEFER=$D python3 tools/diag_f16p2_steps.py 2>&1 | grep -v amdgpu.ids | head -5; done; fi; } > $E/${R}_p2_defer_ab.txt 2>&1
+# the measured upper bound of a Winograd F(2,3) form of conv_f16p2 (needs libnm355_diag.so: make -C neural_marionette_amd/csrc diag)
+if [ -f neural_marionette_amd/libnm355_diag.so ]; then python3 tools/diag_winograd_emu.py 2>&1 | grep -v amdgpu.ids > $E/${R}_winograd_emu.txt; fi
 {
   echo "config-5 rollout (tools/time_rollout.py: generate, Tcond = 5 posterior + 64 prior steps), alternating, one call:"
   for i in 1 2; do
