@@ -868,7 +868,7 @@ __global__ __launch_bounds__(NM_CHAIN_T) void vrnn_prior_chain_kernel(ChainArgs 
         // =========================== middle workgroup of batch element b ========================================================
         const MidArgs& m = a.mid;
         __shared__ __attribute__((aligned(16))) float s_z[128], s_hr[128], s_hj[128], s_root[36], s_rot[192];
-        __shared__ float s_Rl[32 * 9], s_Rg[32 * 9], s_pos[32 * 3];
+        __shared__ float s_Rl[32 * 9], s_pos[32 * 3];               // (the path walk keeps the global rotations in registers)
         __shared__ FkTables tb;
         const int half = lane >> 5, l32 = lane & 31, b = wg - NW;
         const int R0 = 3 + K, J6 = 6 * K, rows_c = R0 + J6;
