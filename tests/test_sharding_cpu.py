@@ -274,7 +274,9 @@ def _uneven_worker(rank, world, port, n_clips, q):
             bucket.reduce_chunk(0)
             return torch.full((11,), float(rank))
 
-        def _adam(self, params, grads, m, v):
+        def _adam(self, params, grads, m, v, ok=None):
+            if ok is not None and float(ok) == 0.0:
+                return
             b1, b2 = self.betas
             for p, g, mm, vv in zip(params, grads, m, v):
                 mm.mul_(b1).add_(g, alpha=1 - b1); vv.mul_(b2).addcmul_(g, g, value=1 - b2)
