@@ -12,8 +12,6 @@ mkdir -p gpurun_out || exit 1
 rm -rf "./$E"; mkdir -p "$E" || exit 1
 TREE=$(python3 tools/tree_id.py)
 echo "$TREE" > "$E/${R}_tree_id.txt"
-python bench.py --steps 20 --warmup 5 > $E/bench_default.log 2> $E/bench_default.err
-tail -1 $E/bench_default.log > $E/${R}_bench.json.log
 CMD="python3 bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $E/fwd -- $CMD > $E/fwd.log 2>&1
 cp $(find $E/fwd -name "*kernel_stats.csv" | head -1) $E/${R}_bench_kernel_stats.csv
@@ -85,6 +83,10 @@ python3 tools/time_encode_ab.py 2>&1 | grep -v amdgpu.ids > $E/${R}_encode_ab.tx
   python3 tools/host_ahead.py 20 2>&1 | grep "host per step"
 } > $E/${R}_ranks_on_one_gpu.txt 2>&1
 rm -rf $E/fwd $E/train $E/trainb $E/c4 $E/c5 $E/tf $E/tw $E/pm $E/pmb
+# the default bench line last: its roofline.traffic reads this run's PMC summary and calibration (profiles/ on the box is a scratch copy)
+mkdir -p profiles; cp $E/${R}_pmc_traffic.json $E/${R}_fetch_calib.json profiles/
+python bench.py --steps 20 --warmup 5 > $E/bench_default.log 2> $E/bench_default.err
+tail -1 $E/bench_default.log > $E/${R}_bench.json.log
 # stamp the tree id into every summary
 python3 tools/tree_id.py --stamp "$TREE" $E/${R}_*.json $E/${R}_*.csv $E/${R}_*.txt $E/${R}_bench.json.log
 head -12 $E/pmc_traffic_summary.txt; head -10 $E/pmc_mfma_summary.txt; head -12 $E/pmc_mfma_train_bf16_summary.txt; tail -c 600 $E/${R}_bench.json.log
