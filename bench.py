@@ -450,7 +450,7 @@ def other_configs(dev, timed):
             return n4(v4, acts, eps=e4)
     ms = timed(f4, 2, 5) * 1e3
     res["config4_96cubed"] = dict(value=16 / (ms * 1e-3), unit="voxel-frames/s (96^3 frames)", ms_per_step=ms, steps=5,
-                                  workload="full NeuralMarionette.forward, 96^3, T=8, B=2 (parity: tests/test_network_gpu.py::test_config4_96cubed_vs_oracle)",
+                                  workload="full NeuralMarionette.forward, 96^3, T=8, B=2 (parity: tests/test_network_gpu.py::test_config4_96cubed_vs_reference_fixture)",
                                   voxels_per_s=16 * 96 ** 3 / (ms * 1e-3))
     del n4, v4
     o5 = HotPathOptions(grid_size=32, Tcond=5)

@@ -101,6 +101,9 @@ SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
+NM_ERR_ARG, NM_ERR_HIP, NM_ERR_STATE, NM_ERR_UNSUPPORTED, NM_ERR_RANGE, NM_ERR_INTERNAL = -1, -2, -3, -4, -5, -6     # include/nm355.h
+
+
 class NmError(RuntimeError):
     pass
 

@@ -31,6 +31,36 @@ def test_library_exports_every_declared_symbol():
     assert lib.nm_abi_version() == 1
 
 
+def test_no_cpp_exception_crosses_the_abi():
+    """SURVEY 8(b) "no C++ exceptions across the ABI": nm_abi_selftest_throw raises a real std::bad_alloc (an allocation request of
+    SIZE_MAX / 2 bytes), a std::length_error (vector::reserve past max_size) and a non-std exception INSIDE an entry point; each must
+    come back as NM_ERR_INTERNAL with a message - under ctypes an escaping exception would abort the interpreter, so reaching the
+    asserts is the test.  Then the sources: every exported entry point that returns a status or a size is a function-try-block."""
+    lib = _lib.load()
+    assert _lib.NM_ERR_INTERNAL == -6
+    for kind, word in ((0, b"bad_alloc"), (1, b"reserve"), (2, b"unknown C++ exception")):
+        rc = lib.nm_abi_selftest_throw(kind)
+        assert rc == _lib.NM_ERR_INTERNAL, (kind, rc)
+        msg = lib.nm_last_error()
+        assert b"nm_abi_selftest_throw" in msg and word in msg, msg
+    assert lib.nm_abi_selftest_throw(3) == 0
+    # static half: the extern "C" definitions of every declared symbol
+    src = ""
+    csrc = os.path.join(ROOT, "neural_marionette_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            src += open(os.path.join(csrc, f)).read()
+    missing = []
+    for sym in _declared_symbols():
+        m = re.search(r"^(?:int|size_t|int32_t)\s+" + sym + r"\s*\([^{;]*?\)\s*(try\b)?\s*\{", src, flags=re.M | re.S)
+        if m is None:
+            continue                                   # void / const char* accessors (nm_last_error, nm_abi_version ...): nothing that throws
+        if m.group(1) is None and sym not in ("nm_abi_version",):      # (returns a constant)
+            missing.append(sym)
+    assert not missing, f"entry points without the exception barrier: {missing}"
+    assert len(re.findall(r"catch \(\.\.\.\) \{ return nm_abi_catch\(", src)) >= 40
+
+
 def test_host_linspace_matches_torch_bitwise():
     lib = _lib.load()
     for n in (2, 3, 8, 10, 16, 24, 40, 64, 88, 96):
