@@ -68,6 +68,7 @@ NmLaunchState::NmLaunchState()
       , up2c_all(env_int("NM355_UP2C_ALL", 0))              // 1: the decoder's FIRST fused-upsample layer (128 -> 64 @16^3 -> 32^3) on the composite-weight kernel too (A/B)
       , f16p_late(env_int("NM355_F16P_LATE", 1))            // 0: conv_f16p's round-2 producer schedule (tile complete at the second barrier, weights waited for in the phase that stores them; A/B)
       , p2_defer(env_int("NM355_P2_DEFER", 0))              // 1: conv_f16p2 with one accumulator per tile and the epilogue deferred into the next brick's first step (A/B: slower)
+      , fast_decode(env_int("NM355_FAST_DECODE", 1))        // 0: the persistent convs decode a brick's position with integer divisions instead of host-made reciprocal multiplications (A/B)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); chain_spin = env_int("NM355_CHAIN_SPIN", 1 << 20); chain_drop = env_int("NM355_CHAIN_DROP_WG", 0); chain_stat_delay = env_int("NM355_CHAIN_STAT_DELAY", 0);
   chain_wgpoll = env_int("NM355_CHAIN_WGPOLL", 1);      // 0: every wave of the cross-XCD rollout chain polls for itself (round 5; A/B)
   chain_xcd_nogo = env_int("NM355_CHAIN_XCD_NOGO", 0);  // test hook: the one-XCD chain never starts (its fallback must do the work)

@@ -183,7 +183,7 @@ struct NmLaunchState {
     unsigned* nf_flag = nullptr;           // sticky device word gn_finalize ORs a 1 into (null: no reporting)
     // A/B and diagnostic switches (NM355_SUPERTILE, _SMALL16, _KSPLIT, _OCC16, _POOL16, _F16P2, _F16P, _WGRAD_TR, _UP2C, _UP2C_DIAG,
     // _VRNN_MID, _VRNN_GEMM, _VRNN_GRAPH, _SPARSE_FIRST)
-    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, pool_q, occ_flags, gnb_apply4, defer_sums, wgrad_async, wgrad_wgs, wgrad_tr, wgrad_u, tail_rank1, wgrad_z, up2c, up2c_diag, vrnn_mid, vrnn_postmid, vrnn_nb, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res, adjust_split, hg_core, f16p_dma, clip_occ_mfma, vrnn_chain, wgrad_k2f16, convt_f16, k5_two, clip_late, gnb_u8, adj_zwalk, f16q2, vrnn_post_chain, f16r, up2_mat, conv_wgs, up2c_x16, up2c_all, f16p_late, p2_defer;
+    int supertile, small16, ksplit, occ16, pool16, f16p2, f16p, pool_q, occ_flags, gnb_apply4, defer_sums, wgrad_async, wgrad_wgs, wgrad_tr, wgrad_u, tail_rank1, wgrad_z, up2c, up2c_diag, vrnn_mid, vrnn_postmid, vrnn_nb, vrnn_gemm, vrnn_graph, sparse_first, gn_diag, lazy_res, adjust_split, hg_core, f16p_dma, clip_occ_mfma, vrnn_chain, wgrad_k2f16, convt_f16, k5_two, clip_late, gnb_u8, adj_zwalk, f16q2, vrnn_post_chain, f16r, up2_mat, conv_wgs, up2c_x16, up2c_all, f16p_late, p2_defer, fast_decode;
     NmLaunchState();
 };
 NmLaunchState& nm_ls();        // the state of the context whose ABI call runs on this thread

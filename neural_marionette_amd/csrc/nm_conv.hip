@@ -49,6 +49,8 @@ struct ConvParams {
     const void* w16;              // conv_mfma_kernel<1,NT>: split-fp16 weights (null: fp32 MFMA core)
     int ksplit;                   // conv_mfma_kernel<1,NT> + w16: the taps are dealt to 2 / 4 waves that share a row tile (tiny volumes)
     int st_z, st_y, st_x;         // f16s / f16p: XCD super-tile in bricks (0: bricks in linear order), see super_tile_item()
+    unsigned st_sx, st_sy, st_pf; // super-tiles per row / column / frame, and ceil(2^32 / d) of each (0: d = 1): the three divisions of a brick
+    unsigned st_m_sx, st_m_sy, st_m_pf;   // decode as multiplications (round 6); st_pf = 0: the host could not prove them exact, plain divisions
     const float* in_alt; const unsigned char* in_map;   // brick-sparse input (TensorRef::alt / brickmap), conv_pool_f16s only
     const float* in2; const float* in2_scale; const float* in2_shift; float in2_slope;   // un-materialised residual sum (TensorRef::p2 ...), conv_pool_f16s only
     int wdma;                     // conv_f16p2: the producers copy the weights global -> LDS by LDS-DMA instead of through registers (A/B switch)
@@ -962,6 +964,18 @@ __device__ __forceinline__ BrickPos super_tile_item(const ConvParams& p, int b, 
         return r;
     }
     const int l = b >> 3, S = (b & 7) * per + tau;
+    if (p.st_pf) {
+        // (round 6) a persistent workgroup decodes every brick it walks - nine integer divisions by launch constants, ~250 vector
+        // instructions and a dozen hoisted reciprocal registers per wave, in the MFMA waves' path between two steps (in-kernel stamps of
+        // conv_f16p: 720 of a 9 800-tick step).  The super-tile is always 4 x 4 bricks in (y, x); the three real divisions are by host
+        // constants: q = umulhi(x, ceil(2^32 / d)), exact while x d < 2^32 (checked by choose_super_tile).
+        auto fdiv = [](unsigned x, unsigned m) { return m ? __umulhi(x, m) : x; };
+        const unsigned n = fdiv((unsigned)S, p.st_m_pf), si = (unsigned)S - n * p.st_pf;
+        const unsigned q = fdiv(si, p.st_m_sx), sx = si - q * p.st_sx;
+        const unsigned sz = fdiv(q, p.st_m_sy), sy = q - sz * p.st_sy;
+        r.n = (int)n; r.bx = (int)(sx * 4u) + (l & 3); r.by = (int)(sy * 4u) + ((l >> 2) & 3); r.bz = (int)sz * p.st_z + (l >> 4);
+        return r;
+    }
     const int SX = nbx / p.st_x, SY = nby / p.st_y, stpf = SX * SY * (nbz / p.st_z);
     r.n = S / stpf; const int si = S % stpf;
     r.bx = (si % SX) * p.st_x + l % p.st_x;
@@ -3662,6 +3676,7 @@ int launch_t(const ConvParams& p, const Tiling& t, dim3 grid, hipStream_t s) {
 // a multiple of the super-tile, and the super-tiles split evenly over the eight XCDs
 void choose_super_tile(ConvParams& p, int nblocks, int nbz, int nby, int nbx) {
     p.st_z = p.st_y = p.st_x = 0;
+    p.st_sx = p.st_sy = p.st_pf = p.st_m_sx = p.st_m_sy = p.st_m_pf = 0;
     if (!nm_ls().supertile || nblocks % 8) return;
     const int gs = nblocks / 8;
     const int sz = gs == 64 ? 4 : gs == 32 ? 2 : 0;
@@ -3669,6 +3684,13 @@ void choose_super_tile(ConvParams& p, int nblocks, int nbz, int nby, int nbx) {
     const long long st = (long long)p.N * (nbz / sz) * (nby / 4) * (nbx / 4);
     if (st % 8 || st / 8 * nblocks != (long long)p.N * nbz * nby * nbx) return;
     p.st_z = sz; p.st_y = 4; p.st_x = 4;
+    // the decode's divisions as multiplications (super_tile_item): exact while (largest dividend) x (divisor) < 2^32
+    const unsigned SX = (unsigned)nbx / 4u, SY = (unsigned)nby / 4u, pf = SX * SY * (unsigned)(nbz / sz);
+    const unsigned long long smax = 8ull * (unsigned long long)(((long long)p.N * nbz * nby * nbx + nblocks - 1) / nblocks) + 8ull;
+    auto magic = [](unsigned d) { return d == 1u ? 0u : (unsigned)((0x100000000ull + d - 1ull) / d); };
+    if (nm_ls().fast_decode && smax * pf < 0x100000000ull) {
+        p.st_sx = SX; p.st_sy = SY; p.st_pf = pf; p.st_m_sx = magic(SX); p.st_m_sy = magic(SY); p.st_m_pf = magic(pf);
+    }
 }
 
 // conv mode 3 (nm_ls().single): the split-fp16 kernels keep only the hi x hi product (SINGLE instantiations)
@@ -4092,6 +4114,7 @@ int nm_launch_conv(const TensorRef& in, const float* w_packed, const float* bias
     p.cin_real = cin_real > 0 ? cin_real : in.C;
     p.up2 = g.up2 ? 1 : 0;
     p.st_z = p.st_y = p.st_x = 0;
+    p.st_sx = p.st_sy = p.st_pf = p.st_m_sx = p.st_m_sy = p.st_m_pf = 0;
     p.in_alt = in.alt; p.in_map = in.brickmap;
     p.in2 = in.p2; p.in2_scale = in.scale2; p.in2_shift = in.shift2; p.in2_slope = in.slope2;
     p.wdma = nm_ls().f16p_dma;

@@ -73,6 +73,7 @@ python3 tools/time_encode_ab.py 2>&1 | grep -v amdgpu.ids > $E/${R}_encode_ab.tx
   bash tools/ab_forward_env.sh "NM355_VRNN_POST_CHAIN=1" "NM355_VRNN_POST_CHAIN=2" 3
   bash tools/ab_forward_env.sh "NM355_UP2C_ALL=0" "NM355_UP2C_ALL=1" 2
   bash tools/ab_forward_env.sh "NM355_F16P_LATE=0" "NM355_F16P_LATE=1" 3
+  bash tools/ab_forward_env.sh "NM355_FAST_DECODE=0" "NM355_FAST_DECODE=1" 3
 } > $E/${R}_forward_ab.txt 2>&1
 {
   echo "R processes (one nm_ctx each) on ONE GPU, bench.py --ranks-on-one-gpu R --steps 12 --warmup 4: aggregate voxel-frames/s"
