@@ -140,8 +140,13 @@ int nm_forward_fused(nm_ctx* ctx, const float* vox, int32_t B, int32_t T, int32_
 int nm_decode_from_keypoints(nm_ctx* ctx, const float* keypoints, const float* first_feature,
                              const float* first_frame, int32_t B, int32_t Tg, float* gen);
 
-/* KyptDetector.get_affinity (ver 3) — model/kypt_detector.py:191-199 -> (N,K,K,1) */
+/* KyptDetector.get_affinity — model/kypt_detector.py:171-210 -> (N,K,K,1); version 3 unless nm_ctx_set_affinity_ver chose another */
 int nm_get_affinity(nm_ctx* ctx, float* affinity);
+/* options.affinity_ver (model/kypt_detector.py:29,57-68,173-189): 3 (default, every shipped configuration: affinity_params (N,K,K-1)) or
+ * 0 / 1 / 2 (affinity_params (N,K,K): row softmax / softplus Gram matrix, zero diagonal, row-normalised / softplus, zero diagonal, row
+ * softmax), forward and backward.  Call before nm_ctx_set_weights (a change invalidates loaded weights: the parameter's shape differs).
+ * Version 4 (Gumbel noise) is NM_ERR_UNSUPPORTED. */
+int nm_ctx_set_affinity_ver(nm_ctx* ctx, int32_t ver);
 
 /* Input path on the device: episodic_normalization (zero translation) + voxelize of
  * utils/dataset_utils.py:9-31, evaluated operation by operation in fp64 so that the voxel indices

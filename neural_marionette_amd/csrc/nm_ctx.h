@@ -66,7 +66,7 @@ struct DetectorW {
     float* zeros = nullptr;                // 512 zeros (bias of the data-gradient convolutions)
     ConvW d1, d4, d8, d11; NormW dn2, dn5, dn9, dn12;
     float* d14 = nullptr;                  // [32 weights, bias] of the final 1x1 conv (device)
-    float* affinity_params = nullptr;      // (N,K,K-1)
+    float* affinity_params = nullptr;      // (N,K,K-1); (N,K,K) for get_affinity versions 0 / 1 / 2
 };
 
 struct VrnnW {
@@ -112,6 +112,8 @@ struct nm_ctx {
     uint64_t nf_calls = 0;                 // forward-type calls so far
     unsigned nf_last = 0;                  // status bits of the slot that tripped (1: non-finite conv statistics, 2: rollout time-out)
     int range_check = 1;                   // NM355_RANGE_CHECK=0 switches the deferred guard off (A/B)
+    int affinity_ver = 3;                  // get_affinity version (kypt_detector.py:171-210): 3 = the shipped configurations; 0 / 1 / 2 by nm_ctx_set_affinity_ver
+    int64_t affinity_numel() const { return (int64_t)cfg.nneighbor * cfg.nkeypoints * (affinity_ver == 3 ? cfg.nkeypoints - 1 : cfg.nkeypoints); }
     Arena ws;                              // activations / scratch, reset per call
     Arena ws2;                             // scratch of work issued on stream2 (VRNN beside the decoder)
     std::vector<void*> owned;              // weight allocations

@@ -23,7 +23,7 @@ int nm_launch_clip_loss(const float* keypoints, const float* affinity, int B, in
 int nm_launch_loss_finalize(const float* tail_part, int tail_blocks, int B, int T, int K, int N, int G,
                             const float* heat_mean, const float* clip_part, const float* affinity, int chamfer,
                             int use_traj, float* frame_sums /* scratch [B*T][3] */, float* losses, hipStream_t s);
-int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_t s);
+int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_t s, int ver = 3);     // ver: get_affinity version (0-3)
 // episodic_normalization + voxelize (utils/dataset_utils.py:9-31) on the device, fp64, bit-exact indices
 int nm_launch_voxelize(const double* pts, int T, size_t N, int G, double scale, double* part_ws, float* vox, int32_t* idx_out,
                        hipStream_t s);

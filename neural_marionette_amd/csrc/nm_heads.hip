@@ -469,11 +469,35 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     }
 }
 
-// rows (n,k): softmax over K-1 logits, zero re-inserted on the diagonal
-__global__ void affinity_kernel(const float* __restrict__ params, int N, int K, float* __restrict__ out) {
+// get_affinity (kypt_detector.py:171-210), one thread per row (n, k).  ver 3 (the shipped configurations; params (N, K, K-1)): softmax
+// over K-1 logits, zero re-inserted on the diagonal.  ver 0 / 1 / 2 (round 6; params (N, K, K)): 0 = row softmax; 2 = softplus, zero
+// diagonal, row softmax; 1 = M = S S^T of S = softplus(params), zero diagonal, rows divided by (row sum + 1e-6).
+__device__ __forceinline__ float nm_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }     // torch.nn.Softplus (beta 1, threshold 20)
+__global__ void affinity_kernel(const float* __restrict__ params, int N, int K, int ver, float* __restrict__ out) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= N * K) return;
     const int k = row % K;
+    if (ver != 3) {
+        const float* p = params + (size_t)row * K;
+        float* o = out + (size_t)row * K;
+        if (ver == 1) {
+            const float* pn = params + (size_t)(row - k) * K;     // neighbour n's (K, K) block
+            float r = 0.f;
+            for (int j = 0; j < K; ++j) {
+                float m = 0.f;
+                if (j != k) for (int c = 0; c < K; ++c) m += nm_softplus(p[c]) * nm_softplus(pn[(size_t)j * K + c]);
+                o[j] = m; r += m;
+            }
+            for (int j = 0; j < K; ++j) o[j] = o[j] / (r + 1e-6f);
+            return;
+        }
+        float mx = -INFINITY;
+        for (int j = 0; j < K; ++j) { const float v = ver == 0 ? p[j] : (j == k ? 0.f : nm_softplus(p[j])); mx = fmaxf(mx, v); }
+        float s = 0.f;
+        for (int j = 0; j < K; ++j) { const float v = ver == 0 ? p[j] : (j == k ? 0.f : nm_softplus(p[j])); s += expf(v - mx); }
+        for (int j = 0; j < K; ++j) { const float v = ver == 0 ? p[j] : (j == k ? 0.f : nm_softplus(p[j])); o[j] = expf(v - mx) / s; }
+        return;
+    }
     const float* p = params + (size_t)row * (K - 1);
     float mx = -INFINITY;
     for (int j = 0; j < K - 1; ++j) mx = fmaxf(mx, p[j]);
@@ -644,8 +668,8 @@ int nm_launch_loss_finalize(const float* tail_part, int tail_blocks, int B, int 
     return nm_check_hip(hipGetLastError(), "loss_finalize launch");
 }
 
-int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(affinity_kernel, dim3((N * K + 63) / 64), dim3(64), 0, s, params, N, K, out);
+int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_t s, int ver) {
+    hipLaunchKernelGGL(affinity_kernel, dim3((N * K + 63) / 64), dim3(64), 0, s, params, N, K, ver, out);
     return nm_check_hip(hipGetLastError(), "affinity launch");
 }
 

@@ -23,4 +23,4 @@ int nm_launch_heat_bwd(const float* head, const float* clip_head, const float* p
 int nm_launch_clip_loss_bwd(const float* keypoints, const float* affinity, const float* dloss, int B, int T, int K, int N, float sep_sigma,
                             int use_traj, float* dkp, float* dinfl, hipStream_t s);
 int nm_launch_affinity_bwd(const float* params, const float* affinity, const float* dinfl, const float* dloss, int B, int N, int K,
-                           float* dparams, hipStream_t s);
+                           float* dparams, hipStream_t s, int ver = 3);

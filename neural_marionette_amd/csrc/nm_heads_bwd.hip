@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void clip_loss_bwd_kernel(const float* __restr
 // (softmax over K-1 logits with the zero diagonal re-inserted, kypt_detector.py:191-199)
 __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restrict__ params, const float* __restrict__ affinity,
                                                            const float* __restrict__ dinfl, const float* __restrict__ dloss, int B, int N,
-                                                           int K, float* __restrict__ dparams) {
+                                                           int K, int ver, float* __restrict__ dparams) {
     extern __shared__ float dA[];       // [N][K][K]
     const int KK = K * K;
     const float g_spc = dloss[7];
@@ -550,6 +550,51 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
         }
     }
     __syncthreads();
+    if (ver != 3) {
+        // get_affinity versions 0 / 1 / 2 (kypt_detector.py:173-189; params (N, K, K)); softplus' = sigmoid (1 beyond the threshold 20)
+        auto sp = [](float x) { return x > 20.f ? x : log1pf(expf(x)); };
+        auto dsp = [](float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); };
+        if (ver == 1) {
+            // W = M' / (r + eps), M' = (S S^T) with a zero diagonal, S = softplus(params): dM' in place of dA, then dS = (dM' + dM'^T) S
+            for (int row = threadIdx.x; row < N * K; row += 256) {
+                const int k = row % K;
+                const float* p = params + (size_t)row * K; const float* pn = params + (size_t)(row - k) * K;
+                float* d = dA + (size_t)row * K;
+                float r = 0.f, d1 = 0.f;
+                for (int j = 0; j < K; ++j) {
+                    if (j == k) continue;
+                    float m = 0.f;
+                    for (int c = 0; c < K; ++c) m += sp(p[c]) * sp(pn[(size_t)j * K + c]);
+                    r += m; d1 += d[j] * m;
+                }
+                const float inv = 1.f / (r + 1e-6f);
+                for (int j = 0; j < K; ++j) d[j] = (j == k) ? 0.f : d[j] * inv - d1 * inv * inv;
+            }
+            __syncthreads();
+            for (int row = threadIdx.x; row < N * K; row += 256) {
+                const int k = row % K, n = row / K;
+                const float* p = params + (size_t)row * K; const float* pn = params + (size_t)(row - k) * K;
+                const float* dn = dA + (size_t)n * KK;
+                for (int c = 0; c < K; ++c) {
+                    float ds = 0.f;
+                    for (int j = 0; j < K; ++j) ds += (dn[k * K + j] + dn[j * K + k]) * sp(pn[(size_t)j * K + c]);
+                    dparams[(size_t)row * K + c] = ds * dsp(p[c]);
+                }
+            }
+            return;
+        }
+        for (int row = threadIdx.x; row < N * K; row += 256) {      // 0: row softmax; 2: softplus, zero diagonal, row softmax
+            const int k = row % K;
+            const float* p = params + (size_t)row * K; const float* P = affinity + (size_t)row * K; const float* d = dA + (size_t)row * K;
+            float dot = 0.f;
+            for (int j = 0; j < K; ++j) dot += P[j] * d[j];
+            for (int j = 0; j < K; ++j) {
+                const float dv = P[j] * (d[j] - dot);
+                dparams[(size_t)row * K + j] = ver == 0 ? dv : (j == k ? 0.f : dv * dsp(p[j]));
+            }
+        }
+        return;
+    }
     for (int row = threadIdx.x; row < N * K; row += 256) {
         const int k = row % K;
         const float* p = params + (size_t)row * (K - 1);
@@ -646,8 +691,8 @@ int nm_launch_clip_loss_bwd(const float* keypoints, const float* affinity, const
 }
 
 int nm_launch_affinity_bwd(const float* params, const float* affinity, const float* dinfl, const float* dloss, int B, int N, int K,
-                           float* dparams, hipStream_t s) {
+                           float* dparams, hipStream_t s, int ver) {
     hipLaunchKernelGGL(affinity_bwd_kernel, dim3(1), dim3(256), (size_t)N * K * K * sizeof(float), s, params, affinity, dinfl, dloss, B, N, K,
-                       dparams);
+                       ver, dparams);
     return nm_check_hip(hipGetLastError(), "affinity_bwd launch");
 }

@@ -701,7 +701,7 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
     if (n.live()) {   // first_feature output: frame 0 of every clip, NCDHW
         TensorRef ff = mk(feat, B, g, g, g, FEAT);
         n.run(nm_launch_cl_to_ncdhw_strided(ff, T, first_feature, n.s));
-        if (affinity_on) n.run(nm_launch_affinity(d.affinity_params, N, K, aff, n.s));
+        if (affinity_on) n.run(nm_launch_affinity(d.affinity_params, N, K, aff, n.s, c->affinity_ver));
     }
     // (recon == nullptr: the keypoints-only pass of nm_detector_keypoints - no voxel decoder, no losses)
     if (recon) decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer != 0, recon, tail_part, tape);
@@ -1152,14 +1152,14 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
     {   // keypoint-only losses
         const size_t m = b.ws.mark();
         float* cws = b.alloc((size_t)F * nm_chamfer_bwd_blocks(G) * K * 3);
-        float* gaff = b.grad("kypt_detector.affinity_params", (int64_t)N * K * (K - 1));
+        float* gaff = b.grad("kypt_detector.affinity_params", c->affinity_numel());
         if (b.live()) {
             if (c->cfg.vol_fit_chamfer)
                 b.run(nm_launch_chamfer_bwd(t.vox, t.keypoints, t.tail_part, nm_tail_blocks(G), dloss, F, K, G, cws, dkp, b.s));
             b.run(nm_launch_clip_loss_bwd(t.keypoints, t.affinity_on ? t.aff : nullptr, dloss, B, T, K, N, c->cfg.sep_sigma, c->cfg.use_graph_traj,
                                           dkp, dinfl, b.s));
-            if (t.affinity_on) b.run(nm_launch_affinity_bwd(d.affinity_params, t.aff, dinfl, dloss, B, N, K, gaff, b.s));
-            else b.run(nm_check_hip(hipMemsetAsync(gaff, 0, (size_t)N * K * (K - 1) * sizeof(float), b.s), "backward: memset"));
+            if (t.affinity_on) b.run(nm_launch_affinity_bwd(d.affinity_params, t.aff, dinfl, dloss, B, N, K, gaff, b.s, c->affinity_ver));
+            else b.run(nm_check_hip(hipMemsetAsync(gaff, 0, (size_t)c->affinity_numel() * sizeof(float), b.s), "backward: memset"));
         }
         b.ws.release(m);
     }
@@ -1315,12 +1315,12 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
     int rc = NM_OK;
     c->owned_cursor = 0;                   // buffers are reused in call order (nm_ctx_weight_alloc): no free, no sync
     c->has_weights = false;
-    const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, N = c->cfg.nneighbor, S4 = K * 4;
+    const int K = c->cfg.nkeypoints, Z = c->cfg.nlatent, H = c->cfg.nhidden, S4 = K * 4;
     Loader L{c, sd};
     DetectorW& d = c->det;
     const std::string v = "kypt_detector.vox_to_kypt", k2v = "kypt_detector.kypt_to_vox";
     const std::string dec = k2v + ".decode_voxel_from_combined_representation";
-    d.affinity_params = L.copy("kypt_detector.affinity_params", (int64_t)N * K * (K - 1));
+    d.affinity_params = L.copy("kypt_detector.affinity_params", c->affinity_numel());
     d.zeros = nm_ctx_weight_alloc(c, 512);
     if (d.zeros) (void)hipMemsetAsync(d.zeros, 0, 512 * sizeof(float), c->stream);
     d.frame = L.featnet(v + ".extract_features", FEAT);
@@ -1571,7 +1571,14 @@ int nm_get_affinity(nm_ctx* c, float* affinity) try { NmScope nm_scope_(c);
     int rc = check_ready(c, "get_affinity");
     if (rc) return rc;
     if (!affinity) { nm_set_error("get_affinity: null output"); return NM_ERR_ARG; }
-    return nm_launch_affinity(c->det.affinity_params, c->cfg.nneighbor, c->cfg.nkeypoints, affinity, c->stream);
+    return nm_launch_affinity(c->det.affinity_params, c->cfg.nneighbor, c->cfg.nkeypoints, affinity, c->stream, c->affinity_ver);
 } catch (...) { return nm_abi_catch("nm_get_affinity"); }
+
+int nm_ctx_set_affinity_ver(nm_ctx* c, int32_t ver) try { NmScope nm_scope_(c);
+    if (!c) { nm_set_error("ctx_set_affinity_ver: null context"); return NM_ERR_ARG; }
+    if (ver < 0 || ver > 3) { nm_set_error("ctx_set_affinity_ver: version %d (0 .. 3; 4 = Gumbel noise is not implemented)", ver); return NM_ERR_UNSUPPORTED; }
+    if (ver != c->affinity_ver) { c->affinity_ver = ver; c->has_weights = false; }      // the parameter's shape changes: weights must be set again
+    return NM_OK;
+} catch (...) { return nm_abi_catch("nm_ctx_set_affinity_ver"); }
 
 }  // extern "C"

@@ -92,6 +92,8 @@ class Engine:
                                 vol_fit_chamfer=int(o.vol_fit_type == "chamfer"),
                                 use_graph_traj=int(o.graph_traj_weight > 0))
             self.ctx = _lib.Context(cfg)
+            if o.affinity_ver != 3:                        # (N, K, K) affinity parameters: before the first nm_ctx_set_weights
+                _lib.check(self.ctx.lib.nm_ctx_set_affinity_ver(self.ctx.handle, int(o.affinity_ver)), "set_affinity_ver")
             self._stamp = None
             self._named = None
         _lib.check(self.ctx.lib.nm_ctx_set_training(self.ctx.handle, int(self.training_packs)), "set_training")
@@ -253,7 +255,10 @@ class KyptDetector(nn.Module):
         self.kypt_to_vox = holders.KyptToVoxNet(grid_size=o.grid_size, nkeypoints=o.nkeypoints, input_dim=o.input_dim,
                                                 gaussian_cat_type=o.gaussian_cat_type)
         K, N = o.nkeypoints, o.nneighbor
-        self.affinity_params = nn.Parameter(torch.randn(N, K, K - 1) if o.graph_random_init else torch.ones(N, K, K - 1))
+        if o.affinity_ver < 3:                                 # kypt_detector.py:57-58,65-66
+            self.affinity_params = nn.Parameter(torch.randn(N, K, K) if o.graph_random_init else torch.zeros(N, K, K))
+        else:
+            self.affinity_params = nn.Parameter(torch.randn(N, K, K - 1) if o.graph_random_init else torch.ones(N, K, K - 1))
         object.__setattr__(self, "_engine", _engine if _engine is not None else Engine(o, self, prefix="kypt_detector."))
 
     def _eng(self) -> Engine:

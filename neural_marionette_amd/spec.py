@@ -76,7 +76,7 @@ class HotPathOptions:
         bad = []
         if self.input_dim != 3: bad.append("input_dim must be 3")
         if self.const_intensity != 3: bad.append("const_intensity must be 3")
-        if self.affinity_ver != 3: bad.append("affinity_ver must be 3")
+        if self.affinity_ver not in (0, 1, 2, 3): bad.append("affinity_ver must be 0, 1, 2 or 3 (4 draws Gumbel noise: not implemented)")
         if self.graph_loss_ver != 1: bad.append("graph_loss_ver must be 1")
         if self.gaussian_cat_type != "none": bad.append("gaussian_cat_type must be 'none'")
         if self.vol_fit_type not in ("chamfer", "none"): bad.append("vol_fit_type must be chamfer/none")
@@ -165,7 +165,7 @@ def param_spec(opts: HotPathOptions) -> List[Tuple[str, Shape]]:
     F = FEAT_DIM
     out: List[Tuple[str, Shape]] = []
     d = "kypt_detector"
-    out.append((d + ".affinity_params", (opts.nneighbor, K, K - 1)))
+    out.append((d + ".affinity_params", (opts.nneighbor, K, K if opts.affinity_ver < 3 else K - 1)))      # kypt_detector.py:57-68
     v = d + ".vox_to_kypt"
     out += list(_feature_net(v + ".extract_features", D, F))
     out += list(_conv(v + ".extract_heatmaps_from_features.0", K, F, 1))

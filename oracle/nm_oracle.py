@@ -228,6 +228,28 @@ def affinity_v3(params: Tensor) -> Tensor:
     return W[..., None]
 
 
+def affinity(params: Tensor, ver: int = 3) -> Tensor:
+    """KyptDetector.get_affinity (kypt_detector.py:171-210) -> (N,K,K,1).  ver 3: affinity_v3; 0 / 1 / 2 take (N,K,K) parameters:
+    0 row softmax (:173-174); 1 softplus, Gram matrix per neighbour, zero diagonal, rows divided by (row sum + 1e-6) (:177-182);
+    2 softplus, zero diagonal, row softmax (:185-188).  Version 4 (Gumbel noise) is not restated."""
+    if ver == 3:
+        return affinity_v3(params)
+    N, K, _ = params.shape
+    eye = torch.eye(K, dtype=params.dtype)[None]
+    if ver == 0:
+        W = torch.softmax(params, dim=2)
+    elif ver == 1:
+        S = F.softplus(params)
+        W = torch.stack([S[n] @ S[n].T for n in range(N)], dim=0)
+        W = W * (1 - eye)
+        W = W / (W.sum(dim=-1, keepdim=True) + 1e-6)
+    elif ver == 2:
+        W = torch.softmax(F.softplus(params) * (1 - eye), dim=2)
+    else:
+        raise NotImplementedError("affinity_ver %d" % ver)
+    return W[..., None]
+
+
 # --------------------------------------------------------------------------------------
 # detector (model/kypt_detector.py)
 # --------------------------------------------------------------------------------------
@@ -300,7 +322,7 @@ def detector_forward(sd: SD, opts, seq: Tensor, affinity_on: bool = True,
     else:
         vol = zeros
     if affinity_on:
-        aff = affinity_v3(sd["kypt_detector.affinity_params"])
+        aff = affinity(sd["kypt_detector.affinity_params"], getattr(opts, "affinity_ver", 3))
         kk = keypoints.detach() if opts.keypoints_detach else keypoints
         local, tim, spars, inten = loss_graph_consistency_v1(kk, aff)
         traj = loss_graph_traj_v1(kk, aff) if opts.graph_traj_weight > 0 else zeros

@@ -129,6 +129,43 @@ def test_full_forward_32(ref_modules, variant, clip):
     assert np.array_equal(net.dyna_module.parents.numpy(), mine["parents"])
 
 
+@pytest.mark.parametrize("ver", [0, 1, 2])
+def test_full_forward_32_other_affinity_versions(ref_modules, ver):
+    """options.affinity_ver 0 / 1 / 2 (kypt_detector.py:57-68,173-189; no shipped configuration selects them): (N,K,K) affinity
+    parameters, the reference's forward against the oracle's bit for bit - layout, affinity, every loss, the tree the VRNN is built on."""
+    NeuralMarionette, _ = ref_modules
+    import torch.distributions.normal as tdn
+    G, B, T = 32, 2, 5
+    opt = _opt(G)
+    opt.affinity_ver = ver
+    o = HotPathOptions.from_any(opt)
+    assert o.affinity_ver == ver
+    net = NeuralMarionette(opt).eval()
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(sh)) for k, sh in param_spec(o)]
+    sd = synth.make_state_dict(o, seed=23 + ver, variant="peaky")
+    assert tuple(sd["kypt_detector.affinity_params"].shape) == (2, 24, 24)
+    net.load_state_dict(sd)
+    net.anneal(1)
+    vox = synth.figure_clip(B, T, G, seed=2)
+    eps = synth.make_eps((T, 10, B, 128), seed=3)
+    it = iter(eps)
+    old = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: next(it).clone()
+    try:
+        with torch.no_grad():
+            ref = net(vox, {"detector": True, "learner": True})
+    finally:
+        tdn._standard_normal = old
+    with torch.no_grad():
+        mine = O.nm_forward(sd, o, vox, eps)
+    assert torch.equal(net.kypt_detector.get_affinity(), O.affinity(sd["kypt_detector.affinity_params"], ver))
+    for k in ("recon", "keypoints", "affinity", "kypt_recon", "R", "z_kypts", "h_kypts"):
+        assert torch.equal(ref[k], mine[k]), k
+    for k in DETECTOR_LOSS_KEYS + ("kl_kypt", "kypt_recon_loss"):
+        assert float(ref[k]) == float(mine[k]), k
+    assert np.array_equal(net.dyna_module.parents.numpy(), mine["parents"])
+
+
 def test_input_path_restatement_matches_reference():
     """synth.episodic_normalization / voxelize (the restated input path) against
     utils/dataset_utils.py of the reference: identical floats and identical occupancy grids."""
