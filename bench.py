@@ -256,8 +256,11 @@ def pmc_traffic(kernel):
         det["note"] = f"no profiles/{ROUND}_fetch_calib.json: FETCH_SIZE uncalibrated this round, traffic withheld (bounds above)"
         return None, det
     fac, why = next(((f, w) for pre, f, w in FETCH_FACTOR if base.startswith(pre)), (2.0, "contiguous 16 B per lane (pattern contig16)"))
-    det.update(fetch_factor=fac, fetch_pattern=why, calibration={k: v["factor"] for k, v in cal.items()},
-               calibration_file=f"{ROUND}_fetch_calib.json")
+    factors = {k: v["factor"] for k, v in cal.items() if isinstance(v, dict) and "factor" in v}     # (the file also carries its tree id)
+    if not factors:
+        det["note"] = f"profiles/{ROUND}_fetch_calib.json holds no calibration records: traffic withheld (bounds above)"
+        return None, det
+    det.update(fetch_factor=fac, fetch_pattern=why, calibration=factors, calibration_file=f"{ROUND}_fetch_calib.json")
     return fac * rec["fetch_bytes_raw"] + rec["write_bytes"], det
 
 
@@ -621,7 +624,10 @@ def main():
         if best:
             name, ms, fl, n = best
             ach = fl / (ms * 1e-3) / 1e12
-            traffic, traffic_detail = pmc_traffic(name)
+            try:
+                traffic, traffic_detail = pmc_traffic(name)
+            except Exception as e:                                  # an auxiliary file must never take the bench line down
+                traffic, traffic_detail = None, dict(file=None, note=f"profiles/{ROUND}_pmc_traffic.json could not be read: {e!r}")
             split = is_split(name)
             on_f16 = is_f16(name) and eng.conv_mode != 0
             peak = F16_MFMA_PEAK_TFLOPS if on_f16 else FP32_MFMA_PEAK_TFLOPS

@@ -139,3 +139,27 @@ def test_options_from_namespace():
     o = HotPathOptions.from_any(ns)
     assert o.Tcond == 5 and o.gaussian_sigma == 1.5
     assert HotPathOptions.from_any({"grid_size": 96}).grid_size == 96
+
+
+def test_bench_reads_the_committed_traffic_profiles():
+    """bench.py's roofline.traffic comes from profiles/<round>_pmc_traffic.json + <round>_fetch_calib.json as tools/collect_evidence.sh
+    leaves them - stamped with the tree id (an extra string-valued key in both).  The committed files must parse, give a number inside
+    their own bounds, and a file from another round must be refused, not crash."""
+    import importlib.util, json
+    spec = importlib.util.spec_from_file_location("nm_bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    path = os.path.join(ROOT, "profiles", f"{b.ROUND}_pmc_traffic.json")
+    if not os.path.exists(path):
+        t, det = b.pmc_traffic("conv_f16p2_kernel")
+        assert t is None and "note" in det
+        return
+    pm = json.load(open(path))
+    assert pm["round"] == b.ROUND and pm["kernels"]
+    for rec in pm["kernels"][:6]:
+        t, det = b.pmc_traffic(rec["kernel"])
+        assert t is not None, det
+        assert det["traffic_lower_bound"] <= t <= det["traffic_upper_bound"] + 1, det
+        assert all(isinstance(v, float) for v in det["calibration"].values()) and len(det["calibration"]) >= 3
+    t, det = b.pmc_traffic("no_such_kernel")
+    assert t is None and "no record" in det["note"]
