@@ -147,6 +147,10 @@ int nm_get_affinity(nm_ctx* ctx, float* affinity);
  * softmax), forward and backward.  Call before nm_ctx_set_weights (a change invalidates loaded weights: the parameter's shape differs).
  * Version 4 (Gumbel noise) is NM_ERR_UNSUPPORTED. */
 int nm_ctx_set_affinity_ver(nm_ctx* ctx, int32_t ver);
+/* options.gaussian_cat_type (model/kypt_detector.py:396-401): 0 'none' (default, every shipped configuration), 1 'max', 2 'sum' - the K
+ * Gaussian channels of the voxel decoder's combined representation all carry the maximum / the sum clipped to [0, 1] over the K maps;
+ * forward (nm_detector_forward*, nm_forward_fused, nm_decode_from_keypoints) and backward.  Takes effect at the next call. */
+int nm_ctx_set_gaussian_cat(nm_ctx* ctx, int32_t cat);
 
 /* Input path on the device: episodic_normalization (zero translation) + voxelize of
  * utils/dataset_utils.py:9-31, evaluated operation by operation in fp64 so that the voxel indices

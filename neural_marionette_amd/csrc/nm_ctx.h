@@ -112,6 +112,7 @@ struct nm_ctx {
     uint64_t nf_calls = 0;                 // forward-type calls so far
     unsigned nf_last = 0;                  // status bits of the slot that tripped (1: non-finite conv statistics, 2: rollout time-out)
     int range_check = 1;                   // NM355_RANGE_CHECK=0 switches the deferred guard off (A/B)
+    int gauss_cat = 0;                     // options.gaussian_cat_type (kypt_detector.py:396-401): 0 'none', 1 'max', 2 'sum' (nm_ctx_set_gaussian_cat)
     int affinity_ver = 3;                  // get_affinity version (kypt_detector.py:171-210): 3 = the shipped configurations; 0 / 1 / 2 by nm_ctx_set_affinity_ver
     int64_t affinity_numel() const { return (int64_t)cfg.nneighbor * cfg.nkeypoints * (affinity_ver == 3 ? cfg.nkeypoints - 1 : cfg.nkeypoints); }
     Arena ws;                              // activations / scratch, reset per call

@@ -7,7 +7,7 @@ int nm_launch_heatmap(const float* head, const float* clip_head, const float* pr
 int nm_launch_keypoints(const float* part, int F, int K, int g, float* keypoints, float* heat_mean, hipStream_t s);
 int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s);
 int nm_launch_combined(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int F,
-                       int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s);
+                       int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s, int cat = 0);
 // the 1x1 conv of the combined representation split by linearity (inference): per-clip part / per-frame part, see nm_heads.hip
 int nm_launch_combined_rest(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int nb, int T,
                             int K, int Fd, int g, int Cr, float* out, hipStream_t s);

@@ -156,28 +156,44 @@ __global__ __launch_bounds__(256) void gauss_table_kernel(const float* __restric
 // (f - f % T is frame 0 of the same clip; first_feature is channels-last with a frame stride)
 __global__ __launch_bounds__(256) void combined_kernel(const float* __restrict__ table, const float* __restrict__ keypoints,
                                                        const float* __restrict__ first_feature, int ff_stride, int F, int T,
-                                                       int K, int Fd, int g, int Cc, float* __restrict__ out) {
+                                                       int K, int Fd, int g, int Cc, int cat, float* __restrict__ out) {
     const int g2 = g * g, g3 = g2 * g, cq = Cc / 4;
     const size_t total = (size_t)F * g3 * cq;
+    // cat (options.gaussian_cat_type, kypt_detector.py:396-401): 1 'max' / 2 'sum' - each of the K Gaussian channels of a block carries
+    // the maximum / the sum clipped to [0, 1] of the block's K maps at that voxel
+    auto reduced = [&](int fr, int z, int y, int x) {
+        float m = cat == 1 ? -INFINITY : 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float* e = table + ((size_t)fr * K + k) * 3 * g;
+            const float gk = ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)fr * K + k) * 4 + 3];
+            m = cat == 1 ? fmaxf(m, gk) : m + gk;
+        }
+        return cat == 1 ? m : fminf(fmaxf(m, 0.f), 1.f);
+    };
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         int q = (int)(i % cq); size_t r = i / cq;
         int v = (int)(r % g3); int f = (int)(r / g3);
         int b = f / T, f0 = b * T;
         int x = v % g, y = (v / g) % g, z = v / g2;
         f32x4 o;
+        float red_t = 0.f, red_0 = 0.f;
+        if (cat) {
+            if (q * 4 < K) red_t = reduced(f, z, y, x);
+            if (q * 4 + 3 >= K + Fd && q * 4 < 2 * K + Fd) red_0 = reduced(f0, z, y, x);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int c = q * 4 + j;
             float val = 0.f;
             if (c < K) {
                 const float* e = table + ((size_t)f * K + c) * 3 * g;
-                val = ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f * K + c) * 4 + 3];
+                val = cat ? red_t : ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f * K + c) * 4 + 3];
             } else if (c < K + Fd) {
                 val = first_feature[(((size_t)b * ff_stride) * g3 + v) * Fd + (c - K)];
             } else if (c < 2 * K + Fd) {
                 int k = c - K - Fd;
                 const float* e = table + ((size_t)f0 * K + k) * 3 * g;
-                val = ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f0 * K + k) * 4 + 3];
+                val = cat ? red_0 : ((e[z] * e[g + y]) * e[2 * g + x]) * keypoints[((size_t)f0 * K + k) * 4 + 3];
             } else if (c < 2 * K + Fd + 3) {
                 int d = c - 2 * K - Fd;
                 val = lin_coord(d == 0 ? z : (d == 1 ? y : x), g);
@@ -633,11 +649,11 @@ int nm_launch_adjust_wg(const float* w, int Cout, int Cin_total, int K, float* w
 }
 
 int nm_launch_combined(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int F,
-                       int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s) {
+                       int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s, int cat) {
     size_t total = (size_t)F * g * g * g * (Cc / 4);
     int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(combined_kernel, dim3(blocks), dim3(256), 0, s, table, keypoints, first_feature, ff_stride, F, T, K, Fd,
-                       g, Cc, out);
+                       g, Cc, cat, out);
     return nm_check_hip(hipGetLastError(), "combined launch");
 }
 

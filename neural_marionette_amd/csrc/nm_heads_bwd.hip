@@ -228,7 +228,7 @@ __global__ void chamfer_bwd_finish_kernel(const float* __restrict__ part, int nb
 // out[((f*K+k)*2+role)*4 + j] = (dc0, dc1, dc2, dI) contributions
 __global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* __restrict__ dcomb, int Cd, const float* __restrict__ table,
                                                         const float* __restrict__ keypoints, int T, int K, int Fd, int g, float width,
-                                                        float* __restrict__ out) {
+                                                        int cat, float* __restrict__ out) {
     __shared__ float sh[256];
     const int fk = blockIdx.x, role = blockIdx.y, f = fk / K, k = fk % K;
     const int fr = role ? (f / T) * T : f;
@@ -240,8 +240,22 @@ __global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* __restrict_
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int v = threadIdx.x; v < g3; v += 256) {
         const int x = v % g, y = (v / g) % g, z = v / g2;
-        const float dG = dcomb[((size_t)f * g3 + v) * Cd + ch];
+        float dG = dcomb[((size_t)f * g3 + v) * Cd + ch];
         const float E = (e[z] * e[g + y]) * e[2 * g + x];
+        if (cat) {
+            // gaussian_cat_type 'max' / 'sum' (kypt_detector.py:396-401): the block's K channels all carry R(v) = max_k g_k(v) or
+            // clip(sum_k g_k(v), 0, 1); dR(v) = the sum of the K channels' gradients; max: it belongs to the first maximal map, sum: to
+            // every map where the sum lies inside [0, 1]
+            const float* dc = dcomb + ((size_t)f * g3 + v) * Cd + (role ? K + Fd : 0);
+            float dR = 0.f, red = cat == 1 ? -INFINITY : 0.f; int am = 0;
+            for (int j = 0; j < K; ++j) {
+                dR += dc[j];
+                const float* ej = table + ((size_t)fr * K + j) * 3 * g;
+                const float gj = ((ej[z] * ej[g + y]) * ej[2 * g + x]) * keypoints[((size_t)fr * K + j) * 4 + 3];
+                if (cat == 1) { if (gj > red) { red = gj; am = j; } } else red += gj;
+            }
+            dG = cat == 1 ? (am == k ? dR : 0.f) : ((red >= 0.f && red <= 1.f) ? dR : 0.f);
+        }
         const float GI = dG * E * I;
         a0 += GI * (2.0f * (lin_coord(z, g) - c0) / width);
         a1 += GI * (2.0f * (lin_coord(y, g) - c1) / width);
@@ -650,9 +664,9 @@ int nm_launch_chamfer_bwd(const float* target, const float* keypoints, const flo
 }
 
 int nm_launch_combined_bwd(const float* dcomb, int Cd, const float* table, const float* keypoints, int B, int T, int K, int Fd, int g,
-                           float width, float* ws, float* dfeat, float* dkp, hipStream_t s) {
+                           float width, float* ws, float* dfeat, float* dkp, hipStream_t s, int cat) {
     const int F = B * T, g3 = g * g * g;
-    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(F * K, 2), dim3(256), 0, s, dcomb, Cd, table, keypoints, T, K, Fd, g, width, ws);
+    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(F * K, 2), dim3(256), 0, s, dcomb, Cd, table, keypoints, T, K, Fd, g, width, cat, ws);
     hipLaunchKernelGGL(gauss_bwd_finish_kernel, dim3((F * K * 4 + 255) / 256), dim3(256), 0, s, ws, F, T, K, dkp);
     hipLaunchKernelGGL(first_feature_bwd_kernel, dim3(grid_for((size_t)B * g3 * (Fd / 4))), dim3(256), 0, s, dcomb, Cd, B, T, K, Fd, g3, dfeat);
     return nm_check_hip(hipGetLastError(), "combined_bwd launch");

@@ -572,7 +572,7 @@ void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int fea
         const int f0 = b0 * T, nf = nb * T;
         const size_t m1 = n.ws.mark();
         TensorRef x;
-        if (!tape && d.adjust_wg && d.adjust_rest.wp) {
+        if (!tape && d.adjust_wg && d.adjust_rest.wp && c->gauss_cat == 0) {     // (the split needs the K maps apart: 'max' / 'sum' take the materialised form)
             // inference: per-clip conv over [first_feature, gauss_0, coords] (+ bias), then the per-frame gaussian part on top of it
             const int Cr = d.adjust_rest.Cin_pad;
             float* rest = n.alloc((size_t)nb * g3 * Cr);
@@ -590,7 +590,7 @@ void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int fea
             if (n.live())
                 n.run(nm_launch_combined(table + (size_t)f0 * K * 3 * g, keypoints + (size_t)f0 * K * 4,
                                          feat_cl + (size_t)b0 * feat_frame_stride * g3 * FEAT, feat_frame_stride, nf, T, K, FEAT, g,
-                                         Cc, comb, n.s));
+                                         Cc, comb, n.s, c->gauss_cat));
             x = mk(comb, nf, g, g, g, Cc);
             x = conv_gn(n, x, d.adjust, nullptr, 1, 0, LRELU, nullptr, false, tape ? &tape->adjust : nullptr);
         }
@@ -1135,7 +1135,7 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         float* gws = b.alloc((size_t)F * K * 8);
         if (b.live()) {
             b.run(nm_check_hip(hipMemsetAsync(dfeat, 0, (size_t)F * g3 * FEAT * sizeof(float), b.s), "backward: memset"));
-            b.run(nm_launch_combined_bwd(dcomb, d.adjust.csel, t.table, t.keypoints, B, T, K, FEAT, g, (float)width_d, gws, dfeat, dkp, b.s));
+            b.run(nm_launch_combined_bwd(dcomb, d.adjust.csel, t.table, t.keypoints, B, T, K, FEAT, g, (float)width_d, gws, dfeat, dkp, b.s, c->gauss_cat));
             b.flush_sums();
             // every kypt_to_vox.* gradient is complete: the caller's collective for that bucket chunk may start behind this event
             if (c->ev_user_decoder) {
@@ -1573,6 +1573,13 @@ int nm_get_affinity(nm_ctx* c, float* affinity) try { NmScope nm_scope_(c);
     if (!affinity) { nm_set_error("get_affinity: null output"); return NM_ERR_ARG; }
     return nm_launch_affinity(c->det.affinity_params, c->cfg.nneighbor, c->cfg.nkeypoints, affinity, c->stream, c->affinity_ver);
 } catch (...) { return nm_abi_catch("nm_get_affinity"); }
+
+int nm_ctx_set_gaussian_cat(nm_ctx* c, int32_t cat) try { NmScope nm_scope_(c);
+    if (!c) { nm_set_error("ctx_set_gaussian_cat: null context"); return NM_ERR_ARG; }
+    if (cat < 0 || cat > 2) { nm_set_error("ctx_set_gaussian_cat: %d (0 'none', 1 'max', 2 'sum')", cat); return NM_ERR_UNSUPPORTED; }
+    c->gauss_cat = cat;
+    return NM_OK;
+} catch (...) { return nm_abi_catch("nm_ctx_set_gaussian_cat"); }
 
 int nm_ctx_set_affinity_ver(nm_ctx* c, int32_t ver) try { NmScope nm_scope_(c);
     if (!c) { nm_set_error("ctx_set_affinity_ver: null context"); return NM_ERR_ARG; }

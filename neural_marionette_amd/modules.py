@@ -92,6 +92,8 @@ class Engine:
                                 vol_fit_chamfer=int(o.vol_fit_type == "chamfer"),
                                 use_graph_traj=int(o.graph_traj_weight > 0))
             self.ctx = _lib.Context(cfg)
+            if o.gaussian_cat_type != "none":              # kypt_detector.py:396-401
+                _lib.check(self.ctx.lib.nm_ctx_set_gaussian_cat(self.ctx.handle, {"max": 1, "sum": 2}[o.gaussian_cat_type]), "set_gaussian_cat")
             if o.affinity_ver != 3:                        # (N, K, K) affinity parameters: before the first nm_ctx_set_weights
                 _lib.check(self.ctx.lib.nm_ctx_set_affinity_ver(self.ctx.handle, int(o.affinity_ver)), "set_affinity_ver")
             self._stamp = None

@@ -287,8 +287,16 @@ def vox_to_kypt(sd: SD, opts, seq: Tensor, taps: Optional[dict] = None):
 
 def kypt_to_vox(sd: SD, opts, gaussians: Tensor, first_feature: Tensor, first_frame: Tensor,
                 taps: Optional[dict] = None) -> Tensor:
-    """KyptToVoxNet.forward (gaussian_cat_type 'none'): kypt_detector.py:388-460."""
+    """KyptToVoxNet.forward: kypt_detector.py:388-460.  gaussian_cat_type 'max' / 'sum' (:396-401): every one of the K Gaussian channels
+    carries the maximum / the sum clipped to [0, 1] over the K maps."""
     T = gaussians.shape[1]
+    cat = getattr(opts, "gaussian_cat_type", "none")
+    if cat == "max":
+        gaussians = gaussians.max(dim=2, keepdim=True).values.expand_as(gaussians)
+    elif cat == "sum":
+        gaussians = gaussians.sum(dim=2, keepdim=True).clip(0, 1).expand_as(gaussians)
+    elif cat != "none":
+        raise NotImplementedError("gaussian_cat_type %r" % (cat,))
     aw = K2V + ".adjust_combined_representation.0"
     out = []
     for t in range(T):

@@ -166,6 +166,44 @@ def test_full_forward_32_other_affinity_versions(ref_modules, ver):
     assert np.array_equal(net.dyna_module.parents.numpy(), mine["parents"])
 
 
+@pytest.mark.parametrize("cat", ["max", "sum"])
+def test_full_forward_32_other_gaussian_cat_types(ref_modules, cat):
+    """options.gaussian_cat_type 'max' / 'sum' (kypt_detector.py:396-401; no shipped configuration selects them): the K Gaussian channels
+    of the decoder's combined representation all carry the maximum / the clipped sum over the K maps.  Reference forward against the
+    oracle's, bit for bit, incl. decode_from_dyna."""
+    NeuralMarionette, _ = ref_modules
+    import torch.distributions.normal as tdn
+    G, B, T = 32, 2, 5
+    opt = _opt(G)
+    opt.gaussian_cat_type = cat
+    o = HotPathOptions.from_any(opt)
+    assert o.gaussian_cat_type == cat
+    net = NeuralMarionette(opt).eval()
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(sh)) for k, sh in param_spec(o)]
+    sd = synth.make_state_dict(o, seed=31, variant="peaky")
+    net.load_state_dict(sd)
+    net.anneal(1)
+    vox = synth.figure_clip(B, T, G, seed=2)
+    eps = synth.make_eps((T, 10, B, 128), seed=3)
+    it = iter(eps)
+    old = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: next(it).clone()
+    try:
+        with torch.no_grad():
+            ref = net(vox, {"detector": True, "learner": True})
+            gen = net.kypt_detector.decode_from_dyna(ref["keypoints"][:, 1:4], ref["first_feature"], vox[:, 0])
+    finally:
+        tdn._standard_normal = old
+    with torch.no_grad():
+        mine = O.nm_forward(sd, o, vox, eps)
+        mine_gen = O.decode_from_keypoints(sd, o, ref["keypoints"][:, 1:4], ref["first_feature"], vox[:, 0])
+    for k in ("recon", "keypoints", "kypt_recon", "R", "z_kypts", "h_kypts"):
+        assert torch.equal(ref[k], mine[k]), k
+    assert torch.equal(gen["gen"], mine_gen)
+    for k in DETECTOR_LOSS_KEYS + ("kl_kypt", "kypt_recon_loss"):
+        assert float(ref[k]) == float(mine[k]), k
+
+
 def test_input_path_restatement_matches_reference():
     """synth.episodic_normalization / voxelize (the restated input path) against
     utils/dataset_utils.py of the reference: identical floats and identical occupancy grids."""
