@@ -50,7 +50,7 @@ typedef struct nm_config {
     int32_t nneighbor;       /* N (2) affinity neighbours */
     float gaussian_sigma;    /* 1.5 */
     float sep_sigma;         /* 0.02 */
-    int32_t vol_fit_chamfer; /* 1: vol_fit_type == 'chamfer', 0: 'none' */
+    int32_t vol_fit_chamfer; /* vol_fit_type: 1 'chamfer', 0 'none', 2 'gaussian' (kypt_detector_utils.py:154-169, as the reference computes it) */
     int32_t use_graph_traj;  /* graph_traj_weight > 0 */
 } nm_config;
 

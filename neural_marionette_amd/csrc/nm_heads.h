@@ -22,7 +22,11 @@ int nm_launch_clip_loss(const float* keypoints, const float* affinity, int B, in
                         float* out, hipStream_t s);
 int nm_launch_loss_finalize(const float* tail_part, int tail_blocks, int B, int T, int K, int N, int G,
                             const float* heat_mean, const float* clip_part, const float* affinity, int chamfer,
-                            int use_traj, float* frame_sums /* scratch [B*T][3] */, float* losses, hipStream_t s);
+                            int use_traj, float* frame_sums /* scratch [B*T][3] */, float* losses, hipStream_t s,
+                            const float* vol_override = nullptr /* [B*T][2]: vol_fit_type 'gaussian' */);
+// vol_fit_type 'gaussian' (kypt_detector_utils.py:154-169): per frame (numerator, denominator) into vol [B*T][2]
+size_t nm_volfit_gauss_ws_floats(int F, int G);
+int nm_launch_volfit_gauss(const float* vox, const float* keypoints, int B, int T, int K, int G, float sigma, float* ws, float* vol, hipStream_t s);
 int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_t s, int ver = 3);     // ver: get_affinity version (0-3)
 // episodic_normalization + voxelize (utils/dataset_utils.py:9-31) on the device, fp64, bit-exact indices
 int nm_launch_voxelize(const double* pts, int T, size_t N, int G, double scale, double* part_ws, float* vox, int32_t* idx_out,

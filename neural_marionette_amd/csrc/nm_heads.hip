@@ -420,6 +420,55 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
     }
 }
 
+
+// ---- vol_fit_type 'gaussian' (kypt_detector_utils.py:154-169), as the reference computes it (oracle.nm_oracle.loss_volume_gaussian has
+// the derivation): the Gaussian maps are TWO-dimensional - m_k[i][j] = ((1 e0_k[i]) e1_k[j]) c2_k with e_d = exp(-(lin - c_d)^2 / w),
+// w = 2 (4 sigma / G)^2, c = the keypoint's three coordinates - the mask max_k m_k multiplies the frame along its first spatial axis and
+// ACROSS the batch: reg[b'][t] = sum_b sum_ij (1 - mask[b][t][i][j]) col[b'][t][i][j] / S[b'][t], col = the frame summed over its first
+// axis, S its total.  Three small kernels; the projection is the only pass over the voxels.
+// grid (G, F), G threads: col[f][i][j] = sum_a vox[f][a][i][j]; rowsum[f][i] = sum_j col
+__global__ void volfit_proj_kernel(const float* __restrict__ vox, int G, float* __restrict__ col, float* __restrict__ rowsum) {
+    extern __shared__ float vsh[];
+    const int i = blockIdx.x, f = blockIdx.y, j = threadIdx.x;
+    const float* p = vox + ((size_t)f * G * G + i) * G + j;
+    float s = 0.f;
+    for (int a = 0; a < G; ++a) s += p[(size_t)a * G * G];
+    col[((size_t)f * G + i) * G + j] = s;
+    vsh[j] = s;
+    __syncthreads();
+    if (j == 0) { float r = 0.f; for (int q = 0; q < G; ++q) r += vsh[q]; rowsum[(size_t)f * G + i] = r; }
+}
+// grid (G, F), G threads: mneg[f][i][j] = 1 - max_k m_k[i][j]; arg (optional): the first maximal k
+__global__ void volfit_mask_kernel(const float* __restrict__ keypoints, int K, int G, float width, float* __restrict__ mneg,
+                                   unsigned char* __restrict__ arg) {
+    const int i = blockIdx.x, f = blockIdx.y, j = threadIdx.x;
+    const float li = lin_coord(i, G), lj = lin_coord(j, G);
+    float mx = -INFINITY; int am = 0;
+    for (int k = 0; k < K; ++k) {
+        const float* kp = keypoints + ((size_t)f * K + k) * 4;
+        const float d0 = li - kp[0], d1 = lj - kp[1];
+        const float m = (expf(-(d0 * d0) / width) * expf(-(d1 * d1) / width)) * kp[2];
+        if (m > mx) { mx = m; am = k; }
+    }
+    mneg[((size_t)f * G + i) * G + j] = 1.0f - mx;
+    if (arg) arg[((size_t)f * G + i) * G + j] = (unsigned char)am;
+}
+// grid F, 256 threads: vol[f] = (sum_b sum_ij mneg[b T + t][ij] col[f][ij], S[f])
+__global__ __launch_bounds__(256) void volfit_frame_kernel(const float* __restrict__ mneg, const float* __restrict__ col,
+                                                           const float* __restrict__ rowsum, int B, int T, int G, float* __restrict__ vol) {
+    __shared__ float sh[256];
+    const int f = blockIdx.x, t = f % T, G2 = G * G;
+    float num = 0.f, den = 0.f;
+    for (int p = threadIdx.x; p < G2; p += 256) {
+        float ms = 0.f;
+        for (int b = 0; b < B; ++b) ms += mneg[((size_t)(b * T + t)) * G2 + p];
+        num += ms * col[(size_t)f * G2 + p];
+    }
+    for (int i = threadIdx.x; i < G; i += 256) den += rowsum[(size_t)f * G + i];
+    num = block_sum256(num, sh); den = block_sum256(den, sh);
+    if (threadIdx.x == 0) { vol[2 * f] = num; vol[2 * f + 1] = den; }
+}
+
 // grid F: frame_sums[f] = (sum BCE, sum chamfer, occupied count) over the frame's tail partials
 __global__ __launch_bounds__(256) void tail_sums_kernel(const float* __restrict__ tail_part, int tail_blocks, float* __restrict__ frame_sums) {
     __shared__ float sh[12];
@@ -437,7 +486,8 @@ __global__ __launch_bounds__(256) void tail_sums_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ frame_sums, int B, int T,
                                                             int K, int N, int G, const float* __restrict__ heat_mean,
                                                             const float* __restrict__ clip_part, const float* __restrict__ affinity,
-                                                            int chamfer, int use_traj, float* __restrict__ losses) {
+                                                            int chamfer, int use_traj, const float* __restrict__ vol_override,
+                                                            float* __restrict__ losses) {
     __shared__ float sh[256];
     const int F = B * T;
     const float G3 = (float)G * (float)G * (float)G;
@@ -445,7 +495,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     for (int f = threadIdx.x; f < F; f += 256) {
         const float* fs = frame_sums + (size_t)f * 3;
         rec += fs[0] / G3;
-        vol += fs[1] / fs[2];
+        vol += vol_override ? vol_override[2 * f] / vol_override[2 * f + 1] : fs[1] / fs[2];      // (vol_fit_type 'gaussian': its own numerator / denominator)
         float a = 0.f;
         for (int k = 0; k < K; ++k) a += fabsf(heat_mean[(size_t)f * K + k]);
         sp += a / (float)K;
@@ -677,11 +727,24 @@ int nm_launch_clip_loss(const float* keypoints, const float* affinity, int B, in
 
 int nm_launch_loss_finalize(const float* tail_part, int tail_blocks, int B, int T, int K, int N, int G,
                             const float* heat_mean, const float* clip_part, const float* affinity, int chamfer,
-                            int use_traj, float* frame_sums, float* losses, hipStream_t s) {
+                            int use_traj, float* frame_sums, float* losses, hipStream_t s, const float* vol_override) {
     hipLaunchKernelGGL(tail_sums_kernel, dim3(B * T), dim3(256), 0, s, tail_part, tail_blocks, frame_sums);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, frame_sums, B, T, K, N, G, heat_mean,
-                       clip_part, affinity, chamfer, use_traj, losses);
+                       clip_part, affinity, chamfer, use_traj, vol_override, losses);
     return nm_check_hip(hipGetLastError(), "loss_finalize launch");
+}
+
+size_t nm_volfit_gauss_ws_floats(int F, int G) { return (size_t)F * G * G * 2 + (size_t)F * G + (size_t)F * G * G / 4 + 64; }
+// vol [F][2]: (numerator, denominator) of vol_fit_type 'gaussian' per frame; ws: nm_volfit_gauss_ws_floats(F, G) floats
+int nm_launch_volfit_gauss(const float* vox, const float* keypoints, int B, int T, int K, int G, float sigma, float* ws, float* vol, hipStream_t s) {
+    if (G > 1024 || K > 255) { nm_set_error("volfit_gauss: G %d / K %d unsupported", G, K); return NM_ERR_UNSUPPORTED; }
+    const int F = B * T;
+    float* col = ws; float* mneg = col + (size_t)F * G * G; float* rowsum = mneg + (size_t)F * G * G;
+    const float width = (float)(2.0 * std::pow((double)sigma * 4.0 / (double)G, 2.0));
+    hipLaunchKernelGGL(volfit_proj_kernel, dim3(G, F), dim3(G), G * sizeof(float), s, vox, G, col, rowsum);
+    hipLaunchKernelGGL(volfit_mask_kernel, dim3(G, F), dim3(G), 0, s, keypoints, K, G, width, mneg, (unsigned char*)nullptr);
+    hipLaunchKernelGGL(volfit_frame_kernel, dim3(F), dim3(256), 0, s, mneg, col, rowsum, B, T, G, vol);
+    return nm_check_hip(hipGetLastError(), "volfit_gauss launch");
 }
 
 int nm_launch_affinity(const float* params, int N, int K, float* out, hipStream_t s, int ver) {

@@ -22,5 +22,9 @@ int nm_launch_heat_bwd(const float* head, const float* clip_head, const float* p
 // dinfl [B][K][K] (written when affinity != nullptr)
 int nm_launch_clip_loss_bwd(const float* keypoints, const float* affinity, const float* dloss, int B, int T, int K, int N, float sep_sigma,
                             int use_traj, float* dkp, float* dinfl, hipStream_t s);
+// vol_fit_type 'gaussian' (kypt_detector_utils.py:154-169): dkp += d (dloss[1] * volume_fitting_loss) / d keypoints
+size_t nm_volfit_gauss_bwd_ws_floats(int B, int T, int G);
+int nm_launch_volfit_gauss_bwd(const float* vox, const float* keypoints, const float* dloss, int B, int T, int K, int G, float sigma,
+                               float* ws, float* dkp, hipStream_t s);
 int nm_launch_affinity_bwd(const float* params, const float* affinity, const float* dinfl, const float* dloss, int B, int N, int K,
                            float* dparams, hipStream_t s, int ver = 3);

@@ -223,6 +223,63 @@ __global__ void chamfer_bwd_finish_kernel(const float* __restrict__ part, int nb
     dkp[((size_t)f * K + t / 3) * 4 + t % 3] += (dloss[1] / (float)F) * (-2.0f * s) / cnt;
 }
 
+
+// ---- vol_fit_type 'gaussian' (kypt_detector_utils.py:154-169; forward: nm_heads.hip volfit_*): d loss[1] -> d keypoints ------------------
+// The loss is linear in mneg = 1 - max_k m_k with the weight wsum[t][ij] = sum_b' col[b'][t][ij] / S[b'][t] - the same for every batch
+// element b, the reference's cross-batch broadcast - so d m_k*[b][t][ij] = -(dloss[1] / (B T)) wsum[t][ij] at the maximal map k*.
+__global__ void volfit_proj_b_kernel(const float* __restrict__ vox, int G, float* __restrict__ col, float* __restrict__ rowsum) {
+    extern __shared__ float vsh[];
+    const int i = blockIdx.x, f = blockIdx.y, j = threadIdx.x;
+    const float* p = vox + ((size_t)f * G * G + i) * G + j;
+    float s = 0.f;
+    for (int a = 0; a < G; ++a) s += p[(size_t)a * G * G];
+    col[((size_t)f * G + i) * G + j] = s;
+    vsh[j] = s;
+    __syncthreads();
+    if (j == 0) { float r = 0.f; for (int q = 0; q < G; ++q) r += vsh[q]; rowsum[(size_t)f * G + i] = r; }
+}
+// grid (G, T), G threads: wsum[t][i][j]
+__global__ void volfit_wsum_kernel(const float* __restrict__ col, const float* __restrict__ rowsum, int B, int T, int G, float* __restrict__ wsum) {
+    const int i = blockIdx.x, t = blockIdx.y, j = threadIdx.x;
+    float w = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const int f = b * T + t;
+        float S = 0.f;
+        for (int q = 0; q < G; ++q) S += rowsum[(size_t)f * G + q];
+        w += col[((size_t)f * G + i) * G + j] / S;
+    }
+    wsum[((size_t)t * G + i) * G + j] = w;
+}
+// grid F * K, 256 threads: the pixels whose first maximal map is k
+__global__ __launch_bounds__(256) void volfit_bwd_kernel(const float* __restrict__ keypoints, const float* __restrict__ wsum,
+                                                         const float* __restrict__ dloss, int B, int T, int K, int G, float width,
+                                                         float* __restrict__ dkp) {
+    __shared__ float sh[256];
+    const int fk = blockIdx.x, f = fk / K, k = fk % K, t = f % T, G2 = G * G;
+    const float gl = -dloss[1] / (float)(B * T);
+    const float* kq = keypoints + (size_t)f * K * 4;
+    const float c0 = kq[k * 4], c1 = kq[k * 4 + 1], c2 = kq[k * 4 + 2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int p = threadIdx.x; p < G2; p += 256) {
+        const int i = p / G, j = p % G;
+        const float li = lin_coord(i, G), lj = lin_coord(j, G);
+        float mx = -INFINITY; int am = 0;
+        for (int q = 0; q < K; ++q) {
+            const float d0 = li - kq[q * 4], d1 = lj - kq[q * 4 + 1];
+            const float m = (expf(-(d0 * d0) / width) * expf(-(d1 * d1) / width)) * kq[q * 4 + 2];
+            if (m > mx) { mx = m; am = q; }
+        }
+        if (am != k) continue;
+        const float E = expf(-((li - c0) * (li - c0)) / width) * expf(-((lj - c1) * (lj - c1)) / width);
+        const float gw = gl * wsum[(size_t)t * G2 + p];
+        a0 += gw * (E * c2) * (2.0f * (li - c0) / width);
+        a1 += gw * (E * c2) * (2.0f * (lj - c1) / width);
+        a2 += gw * E;
+    }
+    a0 = block_sum256(a0, sh); a1 = block_sum256(a1, sh); a2 = block_sum256(a2, sh);
+    if (threadIdx.x == 0) { float* o = dkp + (size_t)fk * 4; o[0] += a0; o[1] += a1; o[2] += a2; }
+}
+
 // ---- combined representation (kypt_detector.py:406) and the gaussian maps (kypt_detector_utils.py:57-90) -------------------------
 // grid (F*K, 2): role 0 = channel k (gaussian of frame f), role 1 = channel K+Fd+k (gaussian of the clip's first frame)
 // out[((f*K+k)*2+role)*4 + j] = (dc0, dc1, dc2, dI) contributions
@@ -661,6 +718,19 @@ int nm_launch_chamfer_bwd(const float* target, const float* keypoints, const flo
     hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(nblk, F), dim3(256), 0, s, target, keypoints, K, G, ws);
     hipLaunchKernelGGL(chamfer_bwd_finish_kernel, dim3(F), dim3(128), 0, s, ws, nblk, tail_part, tail_blocks, dloss, F, K, dkp);
     return nm_check_hip(hipGetLastError(), "chamfer_bwd launch");
+}
+
+size_t nm_volfit_gauss_bwd_ws_floats(int B, int T, int G) { return (size_t)B * T * G * G + (size_t)B * T * G + (size_t)T * G * G + 64; }
+int nm_launch_volfit_gauss_bwd(const float* vox, const float* keypoints, const float* dloss, int B, int T, int K, int G, float sigma,
+                               float* ws, float* dkp, hipStream_t s) {
+    if (G > 1024) { nm_set_error("volfit_gauss_bwd: G %d unsupported", G); return NM_ERR_UNSUPPORTED; }
+    const int F = B * T;
+    float* col = ws; float* rowsum = col + (size_t)F * G * G; float* wsum = rowsum + (size_t)F * G;
+    const float width = (float)(2.0 * std::pow((double)sigma * 4.0 / (double)G, 2.0));
+    hipLaunchKernelGGL(volfit_proj_b_kernel, dim3(G, F), dim3(G), G * sizeof(float), s, vox, G, col, rowsum);
+    hipLaunchKernelGGL(volfit_wsum_kernel, dim3(G, T), dim3(G), 0, s, col, rowsum, B, T, G, wsum);
+    hipLaunchKernelGGL(volfit_bwd_kernel, dim3(F * K), dim3(256), 0, s, keypoints, wsum, dloss, B, T, K, G, width, dkp);
+    return nm_check_hip(hipGetLastError(), "volfit_gauss_bwd launch");
 }
 
 int nm_launch_combined_bwd(const float* dcomb, int Cd, const float* table, const float* keypoints, int B, int T, int K, int Fd, int g,

@@ -704,16 +704,19 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
         if (affinity_on) n.run(nm_launch_affinity(d.affinity_params, N, K, aff, n.s, c->affinity_ver));
     }
     // (recon == nullptr: the keypoints-only pass of nm_detector_keypoints - no voxel decoder, no losses)
-    if (recon) decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer != 0, recon, tail_part, tape);
+    if (recon) decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer == 1, recon, tail_part, tape);
     if (tape) {
         tape->B = B; tape->T = T; tape->affinity_on = affinity_on; tape->vox = vox_in; tape->feat = feat; tape->clip_head_out = clip_head;
         tape->heat_part = heat_part; tape->heat_mean = heat_mean; tape->tail_part = tail_part; tape->aff = aff;
         tape->keypoints = keypoints; tape->recon = recon;
     }
+    float* vol_fs = nullptr; float* vol_ws = nullptr;               // vol_fit_type 'gaussian' (cfg.vol_fit_chamfer == 2): its own per-frame sums
+    if (recon && losses && c->cfg.vol_fit_chamfer == 2) { vol_fs = n.alloc((size_t)F * 2); vol_ws = n.alloc(nm_volfit_gauss_ws_floats(F, G)); }
     if (n.live() && recon && losses) {
         n.run(nm_launch_clip_loss(keypoints, aff, B, T, K, N, c->cfg.sep_sigma, clip_part, n.s));
+        if (vol_fs) n.run(nm_launch_volfit_gauss(vox_in, keypoints, B, T, K, G, c->cfg.gaussian_sigma, vol_ws, vol_fs, n.s));
         n.run(nm_launch_loss_finalize(tail_part, tb, B, T, K, N, G, heat_mean, clip_part, aff, c->cfg.vol_fit_chamfer,
-                                      c->cfg.use_graph_traj, frame_sums, losses, n.s));
+                                      c->cfg.use_graph_traj, frame_sums, losses, n.s, vol_fs));
     }
     return n.rc;
 }
@@ -1152,10 +1155,13 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
     {   // keypoint-only losses
         const size_t m = b.ws.mark();
         float* cws = b.alloc((size_t)F * nm_chamfer_bwd_blocks(G) * K * 3);
+        float* gvws = c->cfg.vol_fit_chamfer == 2 ? b.alloc(nm_volfit_gauss_bwd_ws_floats(B, T, G)) : nullptr;
         float* gaff = b.grad("kypt_detector.affinity_params", c->affinity_numel());
         if (b.live()) {
-            if (c->cfg.vol_fit_chamfer)
+            if (c->cfg.vol_fit_chamfer == 1)
                 b.run(nm_launch_chamfer_bwd(t.vox, t.keypoints, t.tail_part, nm_tail_blocks(G), dloss, F, K, G, cws, dkp, b.s));
+            else if (c->cfg.vol_fit_chamfer == 2)
+                b.run(nm_launch_volfit_gauss_bwd(t.vox, t.keypoints, dloss, B, T, K, G, c->cfg.gaussian_sigma, gvws, dkp, b.s));
             b.run(nm_launch_clip_loss_bwd(t.keypoints, t.affinity_on ? t.aff : nullptr, dloss, B, T, K, N, c->cfg.sep_sigma, c->cfg.use_graph_traj,
                                           dkp, dinfl, b.s));
             if (t.affinity_on) b.run(nm_launch_affinity_bwd(d.affinity_params, t.aff, dinfl, dloss, B, N, K, gaff, b.s, c->affinity_ver));

@@ -89,7 +89,7 @@ class Engine:
             cfg = _lib.NmConfig(device=dev.index or 0, grid_size=o.grid_size, nkeypoints=o.nkeypoints,
                                 nlatent=o.nlatent_kypt, nhidden=o.nhidden_kypt, nneighbor=o.nneighbor,
                                 gaussian_sigma=o.gaussian_sigma, sep_sigma=o.sep_sigma,
-                                vol_fit_chamfer=int(o.vol_fit_type == "chamfer"),
+                                vol_fit_chamfer={"none": 0, "chamfer": 1, "gaussian": 2}[o.vol_fit_type],
                                 use_graph_traj=int(o.graph_traj_weight > 0))
             self.ctx = _lib.Context(cfg)
             if o.gaussian_cat_type != "none":              # kypt_detector.py:396-401

@@ -79,7 +79,7 @@ class HotPathOptions:
         if self.affinity_ver not in (0, 1, 2, 3): bad.append("affinity_ver must be 0, 1, 2 or 3 (4 draws Gumbel noise: not implemented)")
         if self.graph_loss_ver != 1: bad.append("graph_loss_ver must be 1")
         if self.gaussian_cat_type not in ("none", "max", "sum"): bad.append("gaussian_cat_type must be 'none', 'max' or 'sum'")
-        if self.vol_fit_type not in ("chamfer", "none"): bad.append("vol_fit_type must be chamfer/none")
+        if self.vol_fit_type not in ("chamfer", "none", "gaussian"): bad.append("vol_fit_type must be chamfer / none / gaussian")
         if self.keypoints_graph != "affinity_params": bad.append("keypoints_graph must be 'affinity_params'")
         if not self.fixed_sigma: bad.append("fixed_sigma must be 1")
         if self.transition_type != "dl": bad.append("transition_type must be 'dl'")

@@ -191,6 +191,30 @@ def loss_volume_chamfer(seq: Tensor, kp: Tensor) -> Tensor:
     return torch.stack(out, dim=1)
 
 
+def loss_volume_gaussian(seq: Tensor, kp: Tensor, sigma: float) -> Tensor:
+    """vol_fit_type 'gaussian', kypt_detector_utils.py:154-169, AS THE REFERENCE COMPUTES IT -> (B,T).  The call there hands a
+    (B,1,3) slice of coordinates to extract_gaussian_map_from_keypoints (:57-90), which takes the last entry for an intensity: the map
+    is TWO-dimensional, m_k[i,j] = ((1 exp(-(lin_i - c0)^2 / w)) exp(-(lin_j - c1)^2 / w)) c2 with w = 2 (4 sigma / G)^2, and the mask
+    max_k m_k has shape (B,1,G,G); multiplied with the (B,1,G,G,G) frame it broadcasts along the frame's FIRST spatial axis and ACROSS
+    the batch: reg[b',t] = sum_b sum_{a,i,j} (1 - mask[b,i,j]) seq[b',t,a,i,j] / sum seq[b',t].  (For B = 1: the occupied mass outside
+    the union of K blobs in the (i,j) projection.)  Restated with that broadcasting spelled out."""
+    B, T = seq.shape[:2]
+    G = seq.shape[3]
+    width = 2.0 * (sigma * 4.0 / G) ** 2.0
+    lin = torch.linspace(-1.0, 1.0, G, dtype=seq.dtype)
+    out = []
+    for t in range(T):
+        c = kp[:, t, :, :3]                                                  # (B,K,3)
+        e0 = (-(lin[None, None] - c[:, :, 0, None]).pow(2) / width).exp()    # (B,K,G) along i
+        e1 = (-(lin[None, None] - c[:, :, 1, None]).pow(2) / width).exp()    # (B,K,G) along j
+        m = ((torch.ones(B, c.shape[1], G, G, dtype=seq.dtype) * e0[:, :, :, None]) * e1[:, :, None, :]) * c[:, :, 2, None, None]
+        mask = m.max(dim=1, keepdim=True).values                             # (B,1,G,G)
+        frame = seq[:, t]                                                    # (B,1,G,G,G)
+        prod = (1 - mask)[None, :, :, :, :] * frame[:, :, :, :, :]           # (B', B, G(a), G(i), G(j)): the reference's broadcast, explicit
+        out.append(prod.sum(dim=(1, 2, 3, 4)) / frame.sum(dim=(1, 2, 3, 4)))
+    return torch.stack(out, dim=1)
+
+
 def loss_graph_consistency_v1(kp: Tensor, aff: Tensor):
     """kypt_detector_utils.py:172-225 with ver=1, all four switches on.
     Returns local (B,T), time (B,T), sparsity (1,1), intensity (1,1)=0."""
@@ -327,6 +351,8 @@ def detector_forward(sd: SD, opts, seq: Tensor, affinity_on: bool = True,
     zeros = torch.zeros(B, T)
     if opts.vol_fit_type == "chamfer":
         vol = loss_volume_chamfer(seq, keypoints)
+    elif opts.vol_fit_type == "gaussian":
+        vol = loss_volume_gaussian(seq, keypoints, opts.gaussian_sigma)
     else:
         vol = zeros
     if affinity_on:

@@ -4,6 +4,10 @@ options.gaussian_cat_type 'max' / 'sum' (kypt_detector.py:396-401): the K Gaussi
 all carry the maximum / the clipped sum over the K maps - the materialised combined tensor with the reduced maps, its adjoint through the
 arg-max / the clip; second half of this file.
 
+options.vol_fit_type 'gaussian' (kypt_detector_utils.py:154-169) as the reference computes it - two-dimensional Gaussian maps whose
+"intensity" is the keypoint's third coordinate, the mask broadcast along the frame's first axis and across the batch
+(oracle.nm_oracle.loss_volume_gaussian): last part of this file.
+
 options.affinity_ver 0 / 1 / 2 (kypt_detector.py:57-68,173-189): (N, K, K) affinity parameters; 0 = row softmax,
 1 = softplus Gram matrix with a zero diagonal, rows divided by (row sum + 1e-6), 2 = softplus, zero diagonal, row softmax.  No shipped
 configuration selects them (every dataset block and the pretrained options use 3); they exist so that a user flag away from the
@@ -28,8 +32,8 @@ def _err(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
 
 
-def _setup(ver, seed, G=32, B=2, T=4, cat="none"):
-    o = HotPathOptions(grid_size=G, affinity_ver=ver, gaussian_cat_type=cat)
+def _setup(ver, seed, G=32, B=2, T=4, cat="none", vol="chamfer"):
+    o = HotPathOptions(grid_size=G, affinity_ver=ver, gaussian_cat_type=cat, vol_fit_type=vol)
     sd = synth.make_state_dict(o, seed=seed, variant="peaky")
     assert tuple(sd["kypt_detector.affinity_params"].shape) == ((2, 24, 24) if ver < 3 else (2, 24, 23))
     vox = synth.figure_clip(B, T, G, seed=seed + 2)
@@ -202,4 +206,72 @@ def test_detector_gradients_gaussian_cat_types(cat):
         if e >= 2e-3 + 2.0 * slack:
             bad.append((k, e))
     print("gaussian_cat_type %s: worst relative gradient error %.2e at %s" % (cat, worst[1], worst[0]))
+    assert not bad, bad[:8]
+
+
+# ---- vol_fit_type 'gaussian' -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["train_fwd", "inference"])
+@pytest.mark.parametrize("B", [1, 3])
+def test_forward_parity_vol_fit_gaussian(B, path):
+    o, sd, vox, eps = _setup(3, 450 + B, B=B, vol="gaussian")
+    with torch.no_grad():
+        ref = O.nm_forward(sd, o, vox, eps)
+    net = _net(o, sd)
+
+    def run():
+        if path == "inference":
+            with torch.no_grad():
+                return net(vox.cuda(), ACTS, eps=eps.cuda())
+        return net(vox.cuda(), ACTS, eps=eps.cuda())
+    run()
+    out = run()
+    torch.cuda.synchronize()
+    assert _err(out["keypoints"], ref["keypoints"]) < 1e-4
+    r = float(ref["vol_fit_reg"])
+    print("vol_fit_type gaussian B=%d %s: vol_fit_reg %.6f (oracle %.6f)" % (B, path, float(out["vol_fit_reg"].detach()), r))
+    assert r > 0.05 * B                                     # (the cross-batch sum: grows with B)
+    for k in DETECTOR_LOSS_KEYS + ("kl_kypt", "kypt_recon_loss"):
+        rk = float(ref[k])
+        assert abs(float(out[k].detach()) - rk) <= 2e-5 * max(1.0, abs(rk)), (k, float(out[k].detach()), rk)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_detector_gradients_vol_fit_gaussian(B):
+    """The loss reaches the keypoints through the arg-max over the K two-dimensional maps (a selection, as for gaussian_cat_type 'max':
+    the oracle's own fp32 deviation from fp64 is measured and allowed twice)."""
+    o, sd, vox, _ = _setup(3, 460 + B, B=B, T=3, vol="gaussian")
+
+    def oracle_grads(dt):
+        sdd, voxd = {k: v.to(dt) for k, v in sd.items()}, vox.to(dt)
+        names = [k for k in sdd if k.startswith("kypt_detector.")]
+        leaf = {k: sdd[k].clone().requires_grad_(True) for k in names}
+        sd2 = dict(sdd); sd2.update(leaf)
+        ro = O.detector_forward(sd2, o, voxd, affinity_on=True)
+        loss = sum(w * ro[k] for k, w in AIST.items())
+        grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)
+        return loss.detach(), {k: (g if g is not None else torch.zeros_like(leaf[k])).double() for k, g in zip(names, grads)}
+    ref_loss, ref = oracle_grads(torch.float64)
+    _, g32 = oracle_grads(torch.float32)
+    gmax = max(r.abs().max().item() for r in ref.values())
+    slack = max((g32[k] - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-6 * gmax, 1e-30) for k in ref)
+    net = _net(o, sd, train=True)
+    acts = {"detector": True, "learner": False}
+    net.control_active(acts)
+    net.zero_grad()
+    out = net(vox.cuda(), acts)
+    loss = sum(w * out[k] for k, w in AIST.items())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 2e-5 * max(1.0, abs(float(ref_loss)))
+    got = {"kypt_detector." + n: p.grad for n, p in net.kypt_detector.named_parameters()}
+    worst, bad = ("", 0.0), []
+    for k, r in ref.items():
+        g = got[k]
+        assert g is not None and tuple(g.shape) == tuple(r.shape) and torch.isfinite(g).all(), k
+        e = (g.cpu().double() - r).abs().max().item() / max(r.abs().max().item(), 1e-6 * gmax, 1e-30)
+        if e > worst[1]:
+            worst = (k, e)
+        if e >= 2e-3 + 2.0 * slack:
+            bad.append((k, e))
+    print("vol_fit_type gaussian B=%d: worst relative gradient error %.2e at %s (the oracle's own fp32 deviation: %.2e)" % (B, worst[1], worst[0], slack))
     assert not bad, bad[:8]

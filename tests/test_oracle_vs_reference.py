@@ -204,6 +204,48 @@ def test_full_forward_32_other_gaussian_cat_types(ref_modules, cat):
         assert float(ref[k]) == float(mine[k]), k
 
 
+def test_full_forward_32_vol_fit_gaussian(ref_modules):
+    """options.vol_fit_type 'gaussian' (kypt_detector_utils.py:154-169; no shipped configuration selects it).  The reference's form
+    reads a keypoint's third coordinate as the Gaussian's intensity and broadcasts the (B,1,G,G) mask across the batch
+    (oracle.nm_oracle.loss_volume_gaussian spells it out): restated as it computes, bit for bit, for B = 1, 2, 3 on the loss alone and
+    through the full forward."""
+    NeuralMarionette, _ = ref_modules
+    sys.path.insert(0, REF)
+    try:
+        from utils.kypt_detector_utils import get_volume_fitting_loss
+    finally:
+        sys.path.remove(REF)
+    gen = torch.Generator().manual_seed(5)
+    for B in (1, 2, 3):
+        seq = (torch.rand(B, 3, 1, 16, 16, 16, generator=gen) < 0.1).float()
+        kp = torch.rand(B, 3, 7, 4, generator=gen) * 2 - 1
+        assert torch.equal(get_volume_fitting_loss(seq, kp, [1.5] * 7, "gaussian"), O.loss_volume_gaussian(seq, kp, 1.5))
+    import torch.distributions.normal as tdn
+    G, B, T = 32, 2, 5
+    opt = _opt(G)
+    opt.vol_fit_type = "gaussian"
+    o = HotPathOptions.from_any(opt)
+    sd = synth.make_state_dict(o, seed=37, variant="peaky")
+    net = NeuralMarionette(opt).eval()
+    net.load_state_dict(sd)
+    net.anneal(1)
+    vox = synth.figure_clip(B, T, G, seed=2)
+    eps = synth.make_eps((T, 10, B, 128), seed=3)
+    it = iter(eps)
+    old = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: next(it).clone()
+    try:
+        with torch.no_grad():
+            ref = net(vox, {"detector": True, "learner": True})
+    finally:
+        tdn._standard_normal = old
+    with torch.no_grad():
+        mine = O.nm_forward(sd, o, vox, eps)
+    for k in DETECTOR_LOSS_KEYS + ("kl_kypt", "kypt_recon_loss"):
+        assert float(ref[k]) == float(mine[k]), k
+    assert float(mine["vol_fit_reg"]) > 0
+
+
 def test_input_path_restatement_matches_reference():
     """synth.episodic_normalization / voxelize (the restated input path) against
     utils/dataset_utils.py of the reference: identical floats and identical occupancy grids."""
