@@ -151,6 +151,11 @@ int nm_ctx_set_affinity_ver(nm_ctx* ctx, int32_t ver);
  * Gaussian channels of the voxel decoder's combined representation all carry the maximum / the sum clipped to [0, 1] over the K maps;
  * forward (nm_detector_forward*, nm_forward_fused, nm_decode_from_keypoints) and backward.  Takes effect at the next call. */
 int nm_ctx_set_gaussian_cat(nm_ctx* ctx, int32_t cat);
+/* options.fixed_sigma == 0 (model/kypt_detector.py:258-260, 303-306): the state_dict carries `kypt_detector.vox_to_kypt.sigmas` (K), the
+ * detector's Gaussian maps take sigma_k = sigmoid(sigmas[k]) * 2 gaussian_sigma (nm_decode_from_keypoints keeps gaussian_sigma, as
+ * decode_from_dyna does), and the backward writes that parameter's gradient.  Call before nm_ctx_set_weights.  Not implemented together
+ * with vol_fit_type 'gaussian' (NM_ERR_UNSUPPORTED). */
+int nm_ctx_set_learnable_sigma(nm_ctx* ctx, int32_t on);
 
 /* Input path on the device: episodic_normalization (zero translation) + voxelize of
  * utils/dataset_utils.py:9-31, evaluated operation by operation in fp64 so that the voxel indices

@@ -55,6 +55,7 @@ SIGNATURES = {
     "nm_get_affinity": (C.c_int, [C.c_void_p, _P]),
     "nm_ctx_set_affinity_ver": (C.c_int, [C.c_void_p, _I]),
     "nm_ctx_set_gaussian_cat": (C.c_int, [C.c_void_p, _I]),
+    "nm_ctx_set_learnable_sigma": (C.c_int, [C.c_void_p, _I]),
     "nm_voxelize_clip": (C.c_int, [C.c_void_p, _P, _I, C.c_int64, C.c_double, _P, _P]),
     "nm_eval_voxel_chamfer": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P]),
     "nm_eval_semantic": (C.c_int, [C.c_void_p, _P, _P, _I, _I, _I, _P, _P]),

@@ -63,6 +63,7 @@ struct DetectorW {
     ConvW adjust_rest;                     // inference: columns K.. of `adjust` (first_feature, gauss_0, coords) as a conv of its own
     float* adjust_wg = nullptr;            //            columns 0..K-1 transposed to [K][Cout] (the per-frame gaussian part)
     float* prop = nullptr;                 // [w0, w1, b] of propagate_heatmaps (device)
+    float* sigma_param = nullptr;          // vox_to_kypt.sigmas [K] (fixed_sigma = 0 only)
     float* zeros = nullptr;                // 512 zeros (bias of the data-gradient convolutions)
     ConvW d1, d4, d8, d11; NormW dn2, dn5, dn9, dn12;
     float* d14 = nullptr;                  // [32 weights, bias] of the final 1x1 conv (device)
@@ -112,6 +113,7 @@ struct nm_ctx {
     uint64_t nf_calls = 0;                 // forward-type calls so far
     unsigned nf_last = 0;                  // status bits of the slot that tripped (1: non-finite conv statistics, 2: rollout time-out)
     int range_check = 1;                   // NM355_RANGE_CHECK=0 switches the deferred guard off (A/B)
+    int learn_sigma = 0;                   // options.fixed_sigma == 0 (kypt_detector.py:258-260): nm_ctx_set_learnable_sigma
     int gauss_cat = 0;                     // options.gaussian_cat_type (kypt_detector.py:396-401): 0 'none', 1 'max', 2 'sum' (nm_ctx_set_gaussian_cat)
     int affinity_ver = 3;                  // get_affinity version (kypt_detector.py:171-210): 3 = the shipped configurations; 0 / 1 / 2 by nm_ctx_set_affinity_ver
     int64_t affinity_numel() const { return (int64_t)cfg.nneighbor * cfg.nkeypoints * (affinity_ver == 3 ? cfg.nkeypoints - 1 : cfg.nkeypoints); }

@@ -5,7 +5,9 @@
 int nm_launch_heatmap(const float* head, const float* clip_head, const float* prop, int F, int T, int K, int Kc /* channels per voxel of head / clip_head (>= K, % 4 == 0) */, int g,
                       float* heatmaps, float* part, hipStream_t s);
 int nm_launch_keypoints(const float* part, int F, int K, int g, float* keypoints, float* heat_mean, hipStream_t s);
-int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s);
+int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s,
+                          const float* widthk = nullptr /* [K]: per-keypoint widths (fixed_sigma = 0) */, int K = 0);
+int nm_launch_gauss_width(const float* param, int K, float max_sigma, int g, float* widthk, hipStream_t s);
 int nm_launch_combined(const float* table, const float* keypoints, const float* first_feature, int ff_stride, int F,
                        int T, int K, int Fd, int g, int Cc, float* out, hipStream_t s, int cat = 0);
 // the 1x1 conv of the combined representation split by linearity (inference): per-clip part / per-frame part, see nm_heads.hip

@@ -141,15 +141,24 @@ __global__ __launch_bounds__(256) void keypoints_kernel(const float* __restrict_
     }
 }
 
-// E[f][k][d][j] = exp(-(lin_j - c_d)^2 / width)
+// E[f][k][d][j] = exp(-(lin_j - c_d)^2 / width); widthk (fixed_sigma = 0): one width per keypoint
 __global__ __launch_bounds__(256) void gauss_table_kernel(const float* __restrict__ keypoints, int FK, int g, float width,
-                                                          float* __restrict__ table) {
+                                                          const float* __restrict__ widthk, int K, float* __restrict__ table) {
     const int total = FK * 3 * g;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         int j = i % g, d = (i / g) % 3, fk = i / (3 * g);
         float diff = lin_coord(j, g) - keypoints[(size_t)fk * 4 + d];
-        table[i] = expf(-(diff * diff) / width);
+        table[i] = expf(-(diff * diff) / (widthk ? widthk[fk % K] : width));
     }
+}
+// fixed_sigma = 0 (kypt_detector.py:258-260, 303-306; kypt_detector_utils.py:68): width_k = 2 (sigmoid(p_k) max_sigma / g)^2, in the fp32
+// operation order of the reference's tensor arithmetic
+__global__ void gauss_width_kernel(const float* __restrict__ param, int K, float max_sigma, int g, float* __restrict__ widthk) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float s = 1.0f / (1.0f + expf(-param[k]));
+    const float q = (s * max_sigma) / (float)g;
+    widthk[k] = 2.0f * (q * q);
 }
 
 // combined[f][v][Cc]: [0,K) gauss_t | [K,K+Fd) feature of the clip's first frame | gauss_0 | 3 coords | zero pad
@@ -591,10 +600,14 @@ int nm_launch_keypoints(const float* part, int F, int K, int g, float* keypoints
     return nm_check_hip(hipGetLastError(), "keypoints launch");
 }
 
-int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s) {
+int nm_launch_gauss_table(const float* keypoints, int FK, int g, float width, float* table, hipStream_t s, const float* widthk, int K) {
     int total = FK * 3 * g;
-    hipLaunchKernelGGL(gauss_table_kernel, dim3((total + 255) / 256), dim3(256), 0, s, keypoints, FK, g, width, table);
+    hipLaunchKernelGGL(gauss_table_kernel, dim3((total + 255) / 256), dim3(256), 0, s, keypoints, FK, g, width, widthk, K > 0 ? K : 1, table);
     return nm_check_hip(hipGetLastError(), "gauss_table launch");
+}
+int nm_launch_gauss_width(const float* param, int K, float max_sigma, int g, float* widthk, hipStream_t s) {
+    hipLaunchKernelGGL(gauss_width_kernel, dim3((K + 63) / 64), dim3(64), 0, s, param, K, max_sigma, g, widthk);
+    return nm_check_hip(hipGetLastError(), "gauss_width launch");
 }
 
 // ---- the combined representation's 1x1 conv split by linearity (inference; kypt_detector.py:380-383,406) -----------------------------

@@ -14,7 +14,9 @@ int nm_launch_chamfer_bwd(const float* target, const float* keypoints, const flo
                           int K, int G, float* ws, float* dkp, hipStream_t s);
 // dcomb [F][g^3][Cd] (channels [0,K) gauss_t | [K,K+Fd) first feature | [K+Fd,2K+Fd) gauss_0); ws: F*K*8 floats
 int nm_launch_combined_bwd(const float* dcomb, int Cd, const float* table, const float* keypoints, int B, int T, int K, int Fd, int g,
-                           float width, float* ws, float* dfeat, float* dkp, hipStream_t s, int cat = 0);      // cat: gaussian_cat_type none / max / sum
+                           float width, float* ws /* F K 8 floats; F K 10 with widthk */, float* dfeat, float* dkp, hipStream_t s,
+                           int cat = 0 /* gaussian_cat_type none / max / sum */, const float* widthk = nullptr /* [K] per-keypoint widths (fixed_sigma = 0) */,
+                           const float* sigma_param = nullptr, float max_sigma = 0.f, float* dsigma_param = nullptr /* [K] out */);
 size_t nm_heat_bwd_ws_floats(int F, int K, int g);
 int nm_launch_heat_bwd(const float* head, const float* clip_head, const float* prop, const float* heat_part, const float* heat_mean,
                        const float* keypoints, const float* dkp, const float* dloss, int B, int T, int K, int Kc /* channels per voxel of the head tensors (>= K) */, int g, float* ws, float* dhead,

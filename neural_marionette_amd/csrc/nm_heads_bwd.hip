@@ -284,10 +284,13 @@ __global__ __launch_bounds__(256) void volfit_bwd_kernel(const float* __restrict
 // grid (F*K, 2): role 0 = channel k (gaussian of frame f), role 1 = channel K+Fd+k (gaussian of the clip's first frame)
 // out[((f*K+k)*2+role)*4 + j] = (dc0, dc1, dc2, dI) contributions
 __global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* __restrict__ dcomb, int Cd, const float* __restrict__ table,
-                                                        const float* __restrict__ keypoints, int T, int K, int Fd, int g, float width,
-                                                        int cat, float* __restrict__ out) {
+                                                        const float* __restrict__ keypoints, int T, int K, int Fd, int g, float width_in,
+                                                        int cat, const float* __restrict__ widthk, float* __restrict__ dwidth_part,
+                                                        float* __restrict__ out) {
     __shared__ float sh[256];
     const int fk = blockIdx.x, role = blockIdx.y, f = fk / K, k = fk % K;
+    const float width = widthk ? widthk[k] : width_in;                 // (fixed_sigma = 0: per-keypoint widths, and their gradient below)
+    float a4 = 0.f;
     const int fr = role ? (f / T) * T : f;
     const int ch = role ? K + Fd + k : k;
     const int g2 = g * g, g3 = g2 * g;
@@ -318,12 +321,28 @@ __global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* __restrict_
         a1 += GI * (2.0f * (lin_coord(y, g) - c1) / width);
         a2 += GI * (2.0f * (lin_coord(x, g) - c2) / width);
         a3 += dG * E;
+        if (dwidth_part) {                                              // d E / d width = E (sum_d diff_d^2) / width^2
+            const float q0 = lin_coord(z, g) - c0, q1 = lin_coord(y, g) - c1, q2 = lin_coord(x, g) - c2;
+            a4 += GI * (((q0 * q0 + q1 * q1) + q2 * q2) / (width * width));
+        }
     }
     a0 = block_sum256(a0, sh); a1 = block_sum256(a1, sh); a2 = block_sum256(a2, sh); a3 = block_sum256(a3, sh);
+    if (dwidth_part) { a4 = block_sum256(a4, sh); if (threadIdx.x == 0) dwidth_part[(size_t)fk * 2 + role] = a4; }
     if (threadIdx.x == 0) {
         float* o = out + (((size_t)fk) * 2 + role) * 4;
         o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
     }
+}
+// fixed_sigma = 0: d loss / d sigmas parameter [K] = (sum over frames and both roles of d loss / d width_k) * d width / d sigma * d sigma / d p,
+// width = 2 (sigma / g)^2, sigma = sigmoid(p) max_sigma
+__global__ void sigma_bwd_finish_kernel(const float* __restrict__ dwidth_part, const float* __restrict__ param, int F, int K, float max_sigma,
+                                        int g, float* __restrict__ dparam) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += dwidth_part[((size_t)f * K + k) * 2] + dwidth_part[((size_t)f * K + k) * 2 + 1];
+    const float sg = 1.0f / (1.0f + expf(-param[k])), sigma = sg * max_sigma;
+    dparam[k] = s * (4.0f * sigma / ((float)g * (float)g)) * (max_sigma * sg * (1.0f - sg));
 }
 __global__ void gauss_bwd_finish_kernel(const float* __restrict__ part, int F, int T, int K, float* __restrict__ dkp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -734,9 +753,12 @@ int nm_launch_volfit_gauss_bwd(const float* vox, const float* keypoints, const f
 }
 
 int nm_launch_combined_bwd(const float* dcomb, int Cd, const float* table, const float* keypoints, int B, int T, int K, int Fd, int g,
-                           float width, float* ws, float* dfeat, float* dkp, hipStream_t s, int cat) {
+                           float width, float* ws, float* dfeat, float* dkp, hipStream_t s, int cat, const float* widthk,
+                           const float* sigma_param, float max_sigma, float* dsigma_param) {
     const int F = B * T, g3 = g * g * g;
-    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(F * K, 2), dim3(256), 0, s, dcomb, Cd, table, keypoints, T, K, Fd, g, width, cat, ws);
+    float* dwp = widthk ? ws + (size_t)F * K * 8 : nullptr;             // [F][K][2] behind the [F][K][2][4] partials (the caller sizes ws for both)
+    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(F * K, 2), dim3(256), 0, s, dcomb, Cd, table, keypoints, T, K, Fd, g, width, cat, widthk, dwp, ws);
+    if (widthk) hipLaunchKernelGGL(sigma_bwd_finish_kernel, dim3((K + 63) / 64), dim3(64), 0, s, dwp, sigma_param, F, K, max_sigma, g, dsigma_param);
     hipLaunchKernelGGL(gauss_bwd_finish_kernel, dim3((F * K * 4 + 255) / 256), dim3(256), 0, s, ws, F, T, K, dkp);
     hipLaunchKernelGGL(first_feature_bwd_kernel, dim3(grid_for((size_t)B * g3 * (Fd / 4))), dim3(256), 0, s, dcomb, Cd, B, T, K, Fd, g3, dfeat);
     return nm_check_hip(hipGetLastError(), "combined_bwd launch");

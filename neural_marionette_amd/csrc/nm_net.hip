@@ -553,7 +553,7 @@ void feature_net(Net& n, const float* occ, int N, int G, const FeatNetW& w, int 
 //   target/tail_part/chamfer only for the training-style forward.
 void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int feat_frame_stride, const float* first_frames,
                    int ff_stride, int B, int T, const float* target, bool chamfer, float* recon, float* tail_part,
-                   TrainTape* tape = nullptr) {
+                   TrainTape* tape = nullptr, bool learn_sigma = false) {
     nm_ctx* c = n.c;
     const DetectorW& d = c->det;
     const int K = c->cfg.nkeypoints, G = c->cfg.grid_size, g = G / 4, F = B * T;
@@ -562,7 +562,13 @@ void decode_frames(Net& n, const float* keypoints, const float* feat_cl, int fea
     const double width_d = 2.0 * std::pow((double)c->cfg.gaussian_sigma / (double)g, 2.0);
     const size_t m0 = n.ws.mark();
     float* table = n.alloc((size_t)F * K * 3 * g);
-    if (n.live()) n.run(nm_launch_gauss_table(keypoints, F * K, g, (float)width_d, table, n.s));
+    // fixed_sigma = 0: the detector's maps take sigmoid(sigmas) * 2 gaussian_sigma per keypoint (kypt_detector.py:303-306); decode_from_dyna
+    // keeps the fixed list (:226), so only the detector's own call passes learn_sigma
+    float* widthk = learn_sigma ? n.alloc(64) : nullptr;
+    if (n.live()) {
+        if (widthk) n.run(nm_launch_gauss_width(d.sigma_param, K, 2.0f * c->cfg.gaussian_sigma, g, widthk, n.s));
+        n.run(nm_launch_gauss_table(keypoints, F * K, g, (float)width_d, table, n.s, widthk, K));
+    }
     const int tb = nm_tail_blocks(G);
     // whole clips per pass so that frame 0 of every clip in the pass is addressable
     const int clips_per_pass = tape ? B : ((int)(FRAME_CHUNK / (size_t)T) > 0 ? (int)(FRAME_CHUNK / (size_t)T) : 1);
@@ -704,7 +710,7 @@ int detector_graph(nm_ctx* c, const float* vox_in, int B, int T, int affinity_on
         if (affinity_on) n.run(nm_launch_affinity(d.affinity_params, N, K, aff, n.s, c->affinity_ver));
     }
     // (recon == nullptr: the keypoints-only pass of nm_detector_keypoints - no voxel decoder, no losses)
-    if (recon) decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer == 1, recon, tail_part, tape);
+    if (recon) decode_frames(n, keypoints, feat, T, vox_in, T, B, T, vox_in, c->cfg.vol_fit_chamfer == 1, recon, tail_part, tape, c->learn_sigma != 0);
     if (tape) {
         tape->B = B; tape->T = T; tape->affinity_on = affinity_on; tape->vox = vox_in; tape->feat = feat; tape->clip_head_out = clip_head;
         tape->heat_part = heat_part; tape->heat_mean = heat_mean; tape->tail_part = tail_part; tape->aff = aff;
@@ -1135,10 +1141,14 @@ int backward_graph(nm_ctx* c, const TrainTape& t, const float* dloss, const std:
         dx = conv_bwd(b, t.d4, dx, true, nullptr, &m4);
         dx = conv_bwd(b, t.d1, dx, true, m4);
         float* dcomb = conv_bwd(b, t.adjust, dx, true);                 // [F][g^3][csel = 2K + FEAT]
-        float* gws = b.alloc((size_t)F * K * 8);
+        float* gws = b.alloc((size_t)F * K * 10);
+        float* widthk = c->learn_sigma ? b.alloc(64) : nullptr;
+        float* gsig = c->learn_sigma ? b.grad("kypt_detector.vox_to_kypt.sigmas", K) : nullptr;
         if (b.live()) {
             b.run(nm_check_hip(hipMemsetAsync(dfeat, 0, (size_t)F * g3 * FEAT * sizeof(float), b.s), "backward: memset"));
-            b.run(nm_launch_combined_bwd(dcomb, d.adjust.csel, t.table, t.keypoints, B, T, K, FEAT, g, (float)width_d, gws, dfeat, dkp, b.s, c->gauss_cat));
+            if (widthk) b.run(nm_launch_gauss_width(d.sigma_param, K, 2.0f * c->cfg.gaussian_sigma, g, widthk, b.s));
+            b.run(nm_launch_combined_bwd(dcomb, d.adjust.csel, t.table, t.keypoints, B, T, K, FEAT, g, (float)width_d, gws, dfeat, dkp, b.s, c->gauss_cat,
+                                         widthk, d.sigma_param, 2.0f * c->cfg.gaussian_sigma, gsig));
             b.flush_sums();
             // every kypt_to_vox.* gradient is complete: the caller's collective for that bucket chunk may start behind this event
             if (c->ev_user_decoder) {
@@ -1327,6 +1337,7 @@ int nm_net_set_weights(nm_ctx* c, const std::map<std::string, std::pair<const fl
     const std::string v = "kypt_detector.vox_to_kypt", k2v = "kypt_detector.kypt_to_vox";
     const std::string dec = k2v + ".decode_voxel_from_combined_representation";
     d.affinity_params = L.copy("kypt_detector.affinity_params", c->affinity_numel());
+    d.sigma_param = c->learn_sigma ? L.copy("kypt_detector.vox_to_kypt.sigmas", K) : nullptr;
     d.zeros = nm_ctx_weight_alloc(c, 512);
     if (d.zeros) (void)hipMemsetAsync(d.zeros, 0, 512 * sizeof(float), c->stream);
     d.frame = L.featnet(v + ".extract_features", FEAT);
@@ -1579,6 +1590,13 @@ int nm_get_affinity(nm_ctx* c, float* affinity) try { NmScope nm_scope_(c);
     if (!affinity) { nm_set_error("get_affinity: null output"); return NM_ERR_ARG; }
     return nm_launch_affinity(c->det.affinity_params, c->cfg.nneighbor, c->cfg.nkeypoints, affinity, c->stream, c->affinity_ver);
 } catch (...) { return nm_abi_catch("nm_get_affinity"); }
+
+int nm_ctx_set_learnable_sigma(nm_ctx* c, int32_t on) try { NmScope nm_scope_(c);
+    if (!c) { nm_set_error("ctx_set_learnable_sigma: null context"); return NM_ERR_ARG; }
+    if (c->cfg.vol_fit_chamfer == 2 && on) { nm_set_error("ctx_set_learnable_sigma: not implemented together with vol_fit_type 'gaussian'"); return NM_ERR_UNSUPPORTED; }
+    if ((on != 0) != (c->learn_sigma != 0)) { c->learn_sigma = on ? 1 : 0; c->has_weights = false; }      // one more / one fewer tensor in the state_dict
+    return NM_OK;
+} catch (...) { return nm_abi_catch("nm_ctx_set_learnable_sigma"); }
 
 int nm_ctx_set_gaussian_cat(nm_ctx* c, int32_t cat) try { NmScope nm_scope_(c);
     if (!c) { nm_set_error("ctx_set_gaussian_cat: null context"); return NM_ERR_ARG; }

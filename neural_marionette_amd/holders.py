@@ -154,7 +154,11 @@ class VoxToKyptNet(nn.Module):
         super().__init__()
         self.grid_size, self.feat_dim, self.nkeypoints = grid_size, FEAT_DIM, nkeypoints
         self.fixed_sigma, self.const_intensity = fixed_sigma, const_intensity
-        self.sigmas = sigmas
+        if fixed_sigma:
+            self.sigmas = sigmas
+        else:                                               # kypt_detector.py:258-260
+            self.max_sigma = sigmas[0] * 2.0
+            self.sigmas = nn.Parameter(torch.randn(nkeypoints))
         self.extract_features = _feature_net(input_dim, FEAT_DIM, grid_size)
         self.extract_heatmaps_from_features = _head(FEAT_DIM, nkeypoints, "LeakyReLU(0.01)")
         self.extract_spatio_temporal_features = _feature_net(input_dim, 2 * FEAT_DIM, grid_size)

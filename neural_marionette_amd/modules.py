@@ -92,6 +92,8 @@ class Engine:
                                 vol_fit_chamfer={"none": 0, "chamfer": 1, "gaussian": 2}[o.vol_fit_type],
                                 use_graph_traj=int(o.graph_traj_weight > 0))
             self.ctx = _lib.Context(cfg)
+            if not o.fixed_sigma:                          # kypt_detector.py:258-260: one more state_dict entry, before the first nm_ctx_set_weights
+                _lib.check(self.ctx.lib.nm_ctx_set_learnable_sigma(self.ctx.handle, 1), "set_learnable_sigma")
             if o.gaussian_cat_type != "none":              # kypt_detector.py:396-401
                 _lib.check(self.ctx.lib.nm_ctx_set_gaussian_cat(self.ctx.handle, {"max": 1, "sum": 2}[o.gaussian_cat_type]), "set_gaussian_cat")
             if o.affinity_ver != 3:                        # (N, K, K) affinity parameters: before the first nm_ctx_set_weights

@@ -81,7 +81,7 @@ class HotPathOptions:
         if self.gaussian_cat_type not in ("none", "max", "sum"): bad.append("gaussian_cat_type must be 'none', 'max' or 'sum'")
         if self.vol_fit_type not in ("chamfer", "none", "gaussian"): bad.append("vol_fit_type must be chamfer / none / gaussian")
         if self.keypoints_graph != "affinity_params": bad.append("keypoints_graph must be 'affinity_params'")
-        if not self.fixed_sigma: bad.append("fixed_sigma must be 1")
+        if not self.fixed_sigma and self.vol_fit_type == "gaussian": bad.append("fixed_sigma = 0 with vol_fit_type 'gaussian' is not implemented")
         if self.transition_type != "dl": bad.append("transition_type must be 'dl'")
         if self.grid_size % 8 != 0 or self.grid_size < 32:
             bad.append("grid_size must be a multiple of 8 and >= 32")
@@ -167,6 +167,8 @@ def param_spec(opts: HotPathOptions) -> List[Tuple[str, Shape]]:
     d = "kypt_detector"
     out.append((d + ".affinity_params", (opts.nneighbor, K, K if opts.affinity_ver < 3 else K - 1)))      # kypt_detector.py:57-68
     v = d + ".vox_to_kypt"
+    if not opts.fixed_sigma:
+        out.append((v + ".sigmas", (K,)))                  # kypt_detector.py:258-260: created before the sub-modules
     out += list(_feature_net(v + ".extract_features", D, F))
     out += list(_conv(v + ".extract_heatmaps_from_features.0", K, F, 1))
     out += list(_feature_net(v + ".extract_spatio_temporal_features", D, 2 * F))

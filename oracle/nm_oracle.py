@@ -147,11 +147,14 @@ def heatmap_to_keypoints(hm: Tensor) -> Tensor:
     return torch.stack(cs + [inten], dim=-1)
 
 
-def gaussian_map(kp: Tensor, sigma: float, g: int) -> Tensor:
+def gaussian_map(kp: Tensor, sigma, g: int) -> Tensor:
     """kypt_detector_utils.py:57-90 for a python-float sigma: width = 2 (sigma/g)^2 in
     python double arithmetic, map = ((1 * e_x1) * e_x2) * e_x3 * intensity, each
-    e_d = exp(-(lin - c_d)^2 / width).  kp (B,K,4) -> (B,K,g,g,g)."""
+    e_d = exp(-(lin - c_d)^2 / width).  kp (B,K,4) -> (B,K,g,g,g).  A (K,) tensor of sigmas (fixed_sigma = 0: one 0-dim
+    tensor per keypoint in the reference's K calls) gives a per-keypoint width in tensor arithmetic."""
     width = 2.0 * (sigma / g) ** 2.0
+    if torch.is_tensor(width):
+        width = width[None, :, None]
     lin = torch.linspace(-1.0, 1.0, g)
     B, K = kp.shape[:2]
     m = torch.ones(B, K, g, g, g)
@@ -295,6 +298,8 @@ def vox_to_kypt(sd: SD, opts, seq: Tensor, taps: Optional[dict] = None):
     hw = V2K + ".extract_heatmaps_from_features.0"
     hms, kps, gss = [], [], []
     first = None
+    # fixed_sigma = 0 (kypt_detector.py:258-260, 303-306): sigmas = sigmoid(parameter) * max_sigma, max_sigma = 2 gaussian_sigma
+    sig = opts.gaussian_sigma if getattr(opts, "fixed_sigma", 1) else torch.sigmoid(sd[V2K + ".sigmas"]) * (opts.gaussian_sigma * 2.0)
     for t in range(T):
         feat = feature_net(add_coords(seq[:, t]), sd, V2K + ".extract_features", g,
                            taps if (t == 0) else None)
@@ -304,7 +309,7 @@ def vox_to_kypt(sd: SD, opts, seq: Tensor, taps: Optional[dict] = None):
         pair = torch.cat([hm.reshape(B * K, 1, g, g, g), prev.reshape(B * K, 1, g, g, g)], dim=1)
         hm = F.softplus(F.conv3d(pair, pw, pb)).view(B, K, g, g, g)     # (:339-343); prev not updated for ==3
         kp = heatmap_to_keypoints(hm)
-        gs = gaussian_map(kp, opts.gaussian_sigma, g)                   # K per-keypoint calls == one batched call
+        gs = gaussian_map(kp, sig, g)                                   # K per-keypoint calls == one batched call
         hms.append(hm); kps.append(kp); gss.append(gs)
     return torch.stack(hms, 1), torch.stack(kps, 1), torch.stack(gss, 1), first
 

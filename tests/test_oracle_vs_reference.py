@@ -246,6 +246,50 @@ def test_full_forward_32_vol_fit_gaussian(ref_modules):
     assert float(mine["vol_fit_reg"]) > 0
 
 
+def test_full_forward_32_learnable_sigmas(ref_modules):
+    """options.fixed_sigma = 0 (kypt_detector.py:258-260, 303-306; no shipped configuration selects it): a (K,) parameter
+    `vox_to_kypt.sigmas`, created before the sub-modules, sigmas = sigmoid(parameter) * 2 gaussian_sigma per keypoint in the detector's
+    Gaussian maps (decode_from_dyna keeps the fixed list, :226).  Layout, the seeded construction's RNG stream, forward bit for bit."""
+    NeuralMarionette, _ = ref_modules
+    import torch.distributions.normal as tdn
+    import neural_marionette_amd as nm
+    G, B, T = 32, 2, 5
+    opt = _opt(G)
+    opt.fixed_sigma = 0
+    o = HotPathOptions.from_any(opt)
+    assert o.fixed_sigma == 0
+    torch.manual_seed(11); net = NeuralMarionette(opt).eval(); tail_ref = torch.rand(3)
+    torch.manual_seed(11); mine_net = nm.NeuralMarionette(opt); tail_mine = torch.rand(3)
+    ref_layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert ref_layout == [(k, tuple(sh)) for k, sh in param_spec(o)]
+    assert ref_layout[1] == ("kypt_detector.vox_to_kypt.sigmas", (24,))
+    sa, sb = net.state_dict(), mine_net.state_dict()
+    assert list(sa) == list(sb) and all(torch.equal(sa[k], sb[k]) for k in sa) and torch.equal(tail_ref, tail_mine)
+    sd = synth.make_state_dict(o, seed=41, variant="peaky")
+    sd["kypt_detector.vox_to_kypt.sigmas"] = torch.randn(24, generator=torch.Generator().manual_seed(42))
+    net.load_state_dict(sd)
+    net.anneal(1)
+    vox = synth.figure_clip(B, T, G, seed=2)
+    eps = synth.make_eps((T, 10, B, 128), seed=3)
+    it = iter(eps)
+    old = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: next(it).clone()
+    try:
+        with torch.no_grad():
+            ref = net(vox, {"detector": True, "learner": True})
+            gen = net.kypt_detector.decode_from_dyna(ref["keypoints"][:, 1:3], ref["first_feature"], vox[:, 0])["gen"]
+    finally:
+        tdn._standard_normal = old
+    with torch.no_grad():
+        mine = O.nm_forward(sd, o, vox, eps)
+        mine_gen = O.decode_from_keypoints(sd, o, ref["keypoints"][:, 1:3], ref["first_feature"], vox[:, 0])
+    for k in ("recon", "keypoints", "kypt_recon", "R", "z_kypts", "h_kypts"):
+        assert torch.equal(ref[k], mine[k]), k
+    assert torch.equal(gen, mine_gen)
+    for k in DETECTOR_LOSS_KEYS + ("kl_kypt", "kypt_recon_loss"):
+        assert float(ref[k]) == float(mine[k]), k
+
+
 def test_input_path_restatement_matches_reference():
     """synth.episodic_normalization / voxelize (the restated input path) against
     utils/dataset_utils.py of the reference: identical floats and identical occupancy grids."""
