@@ -66,7 +66,7 @@ NmLaunchState::NmLaunchState()
       , conv_wgs(env_int("NM355_CONV_WGS", 0))              // > 0: the persistent producer / consumer convs launch at most this many workgroups (co-residency A/B: CUs left free for the other queues)
       , up2c_x16(env_int("NM355_UP2C_X16", 1))              // 0: conv_up2c stays on v_mfma_f32_32x32x16_f16 (A/B; 1: conv_up2c_x16_kernel, v_mfma_f32_16x16x32_f16, fp32-storage modes)
       , up2c_all(env_int("NM355_UP2C_ALL", 0))              // 1: the decoder's FIRST fused-upsample layer (128 -> 64 @16^3 -> 32^3) on the composite-weight kernel too (A/B)
-      , f16p_late(env_int("NM355_F16P_LATE", 1))            // 0: conv_f16p's round-2 producer schedule (tile complete at the second barrier, weights waited for in the phase that stores them; A/B)
+      , f16p_late(env_int("NM355_F16P_LATE", 0))            // 1: conv_f16p's LATE producer schedule (round 6: -0.05 ms per forward) - NOT the default: on some boxes one evaluation in ~1500 came back with non-finite decoder outputs under it (0 in 18 000 with the round-2 schedule, 12 in 18 000 with LATE, same box: profiles/r06_not_shipped_ab.txt)
       , p2_defer(env_int("NM355_P2_DEFER", 0))              // 1: conv_f16p2 with one accumulator per tile and the epilogue deferred into the next brick's first step (A/B: slower)
       , fast_decode(env_int("NM355_FAST_DECODE", 1))        // 0: the persistent convs decode a brick's position with integer divisions instead of host-made reciprocal multiplications (A/B)
 { store16_min = env_int("NM355_STORE16_MIN", 32768); chain_spin = env_int("NM355_CHAIN_SPIN", 1 << 20); chain_drop = env_int("NM355_CHAIN_DROP_WG", 0); chain_stat_delay = env_int("NM355_CHAIN_STAT_DELAY", 0);

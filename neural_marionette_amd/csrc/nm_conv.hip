@@ -1746,7 +1746,9 @@ __global__ __launch_bounds__(256, 2) void conv_pool_f16q_kernel(ConvParams p) {
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
 // IO: bit 0 = bfloat16 input (a producer piece is then an 8-byte load of the same four channels), bit 1 = bfloat16 output
-// LATE (round 6, the default; NM355_F16P_LATE=0 selects the round-2 schedule): in-kernel stamps of the 32 -> 32 @64^3 layer
+// LATE (round 6; NM355_F16P_LATE=1 - opt-in, NOT the default: the schedule below is 5 % faster on this kernel, and on some boxes one
+// evaluation in ~1500 of the detector's training forward came back non-finite under it, never under the round-2 schedule - a load still in
+// flight somewhere in the two-step body; not root-caused in the round, profiles/r06_not_shipped_ab.txt): in-kernel stamps of the 32 -> 32 @64^3 layer
 // (tools/diag_f16p_steps.py) showed the MFMA waves waiting 760 + 1188 of a 10 400-tick step at the first two barriers - the producers
 // arrive last there: each weight group was loaded and WAITED for inside the phase that stores it (an L2 round trip per phase, the whole
 // third phase nothing else), and the tile of step s + 1 had to be complete at the SECOND barrier (pieces dealt 4 / 6 / 0).  As in
